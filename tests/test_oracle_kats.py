@@ -1,0 +1,122 @@
+"""Pin the CPU oracle against the reference's own literal known-answer tests
+(tests/golden/ref_kats.json, transcribed from model/activation_test.go, model/cost_test.go,
+utils/util_test.go, nn/metrics/ranking_test.go) and against constants derivable from the
+reference (LCG stream, sigmoid table)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kats.json")))
+
+
+def test_prelu(oracle):
+    for k in KATS["prelu"]:
+        out = oracle.prelu32(np.array(k["x"], np.float32), k["slope"])
+        # ShouldResemble on []float32: exact
+        assert out.tolist() == np.array(k["expect"], np.float32).tolist(), k["src"]
+
+
+@pytest.mark.parametrize("k", KATS["euc_distance"], ids=lambda k: k["src"])
+def test_euc_distance(oracle, k):
+    x = np.array(k["x"], np.float32).reshape(k["x_shape"])
+    y = np.array(k["y"], np.float32).reshape(k["y_shape"])
+    out = oracle.euc_distance(x, y)
+    assert list(out.shape) == k["out_shape"]
+    assert out.ravel().tolist() == np.array(k["expect"], np.float32).tolist()
+
+
+@pytest.mark.parametrize("k", KATS["cosine_similarity"], ids=lambda k: k["src"])
+def test_cosine_similarity(oracle, k):
+    x = np.array(k["x"], np.float32).reshape(k["x_shape"])
+    y = np.array(k["y"], np.float32).reshape(k["y_shape"])
+    out = oracle.cosine_similarity(x, y)
+    assert list(out.shape) == k["out_shape"]
+    assert out.ravel().tolist() == np.array(k["expect"], np.float32).tolist()
+
+
+def test_shape_mismatch_errors(oracle):
+    for k in KATS["euc_distance_error"] + KATS["cosine_similarity_error"]:
+        x = np.zeros(k["x_shape"], np.float32)
+        y = np.zeros(k["y_shape"], np.float32)
+        with pytest.raises(ValueError):
+            oracle.euc_distance(x, y)
+        with pytest.raises(ValueError):
+            oracle.cosine_similarity(x, y)
+
+
+def test_costs(oracle):
+    for k in KATS["bce"]:
+        assert abs(oracle.bce32(k["y_pred"], k["y_true"]) - k["expect"]) <= k["tol"], k["src"]
+    for k in KATS["mse"]:
+        assert abs(oracle.mse32(k["y_pred"], k["y_true"]) - k["expect"]) <= k["tol"], k["src"]
+    for k in KATS["rms"]:
+        assert abs(oracle.rms32(k["y_pred"], k["y_true"]) - k["expect"]) <= k["tol"], k["src"]
+
+
+def test_bce_epsilon_is_noop(oracle):
+    # cost.go:12: float32(1.0+1e-8) == 1.0 exactly (quirk Q2) => p == 1 with y == 0 gives +inf
+    assert np.float32(1.0 + 1e-8) == np.float32(1.0)
+    assert math.isinf(oracle.bce32([1.0], [0.0]))
+
+
+def test_roc_auc(oracle):
+    for k in KATS["roc_auc"]:
+        assert oracle.roc_auc(k["pred"], k["y"]) == k["expect"], k["src"]
+        assert oracle.roc_auc32(k["pred"], k["y"]) == pytest.approx(k["expect"], abs=1e-7)
+    for k in KATS["roc_curve"]:
+        fpr, tpr, thr = oracle.roc_curve(k["scores"], k["y"], k["pos_label"])
+        assert fpr.tolist() == k["fpr"] and tpr.tolist() == k["tpr"] and thr.tolist() == k["thresholds"]
+
+
+def test_roc_auc_matches_sklearn_with_ties(oracle):
+    from sklearn.metrics import roc_auc_score
+    rng = np.random.default_rng(0)
+    for n in (5, 64, 1000):
+        s = np.round(rng.random(n), 1)  # many ties
+        y = (rng.random(n) < 0.4).astype(np.float64)
+        if y.min() == y.max():
+            y[0] = 1 - y[0]
+        assert oracle.roc_auc(s, y) == pytest.approx(roc_auc_score(y, s), abs=1e-12)
+
+
+def test_mt19937_matches_numpy():
+    # nn/base/source_test.go:18-25: randomkit seed 7 == numpy RandomState(7)
+    for k in KATS["mt19937_numpy"]:
+        got = np.random.RandomState(k["seed"]).random_sample(len(k["expect"]))
+        assert np.allclose(got, k["expect"], atol=5e-9)
+
+
+def test_lcg_stream(oracle):
+    # modelutil.go:21-29: next = next*25214903917 + 11 (mod 2^64), starts at 1
+    nxt, exp = 1, []
+    for _ in range(64):
+        nxt = (nxt * 25214903917 + 11) % (1 << 64)
+        exp.append(nxt % 5)
+    assert oracle.lcg_stream(64, 5) == exp
+    assert exp[:8] == [3, 3, 2, 4, 0, 2, 1, 3]
+
+
+def test_sigmoid_table(oracle):
+    t = oracle.sigmoid_table()
+    # sigmoid_table.go:28-45
+    for i in (0, 1, 499, 500, 999):
+        e = math.exp((i / 1000 * 2. - 1.) * 6.0)
+        assert t[i] == e / (e + 1.)
+    assert oracle.sigmoid_lookup(t, 3.0) == t[int((3.0 + 6.0) * (1000 / 6.0 / 2.0))]
+    assert oracle.sigmoid_lookup(t, 3.0) == pytest.approx(0.9525741268224333, abs=1e-15)
+    assert 0 <= oracle.sigmoid_lookup(t, 3.0) <= 1  # sigmoid_table_test.go:21-27
+
+
+def test_subsample_and_index_per_thread(oracle):
+    assert oracle.subsample_keep(1e-3, 1) == 1 - math.sqrt(1e-3)
+    assert oracle.subsample_keep(1e-3, 5) == 1 - math.sqrt(1e-3 / 5)
+    idx = oracle.index_per_thread(4, 10)
+    # modelutil.go:32-41
+    exp = [0]
+    for i in range(1, 4):
+        exp.append(exp[-1] + (10 + i) // 4)
+    exp.append(10)
+    assert idx.tolist() == exp
