@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- go-ctr hot path on MI355X: DIN training samples/sec (+ recommend QPS).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
+A "step" = one pass of the hot path (gather + attention + 3-layer MLP forward, BCE, backward, Adam)
+over one batch of synthetic MovieLens-20M-shaped input, BASELINE.json config 3:
+DIN cosine attention, T=50, D=16, U=52, C=53, batch 8192 per GPU, item vocab 26 744, ids + embedding
+table resident in HBM before the timed region (id mode).  N>1 shards rows data-parallel ("weak":
+per-GPU batch fixed) with one RCCL all-reduce of the flat gradient buffer per step.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     dominant kernel of the step, hipEvent-timed inside this process (an instrumented
+               re-run of the same K steps, eager, event pair around every launch on the engine's
+               stream); achieved = algorithmic flops (or bytes) per launch / average launch duration
+  gather_roofline  the embedding gather + attention kernel against the HBM roof (north_star asks for it)
+  cpu_baseline the CPU oracle (a port of the reference algorithm, oracle/) timed on this box's cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# BASELINE.json configs[2] / SURVEY.md section 8(d) cfg3
+CFG = dict(U=52, T=50, D=16, C=53, H1=200, H2=80, V=26744, B=8192, PRED_B=4096)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: f32-input MFMA peak
+
+
+def synth(rows: int, seed: int):
+    """MovieLens-20M-shaped synthetic keys: Zipf(1.05) item ids, 20 % padded behaviour slots,
+    U(0,1) dense side features, Bernoulli(0.5) labels."""
+    rng = np.random.default_rng(seed)
+    c = CFG
+    ub = (rng.zipf(1.05, size=(rows, c["T"])) - 1) % c["V"]
+    ub = ub.astype(np.int32)
+    ub[rng.random((rows, c["T"])) < 0.2] = -1
+    it = ((rng.zipf(1.05, size=rows) - 1) % c["V"]).astype(np.int32)
+    uf = rng.random((rows, c["U"]), dtype=np.float32)
+    cf = rng.random((rows, c["C"]), dtype=np.float32)
+    y = (rng.random(rows) < 0.5).astype(np.float32)
+    emb = (rng.standard_normal((c["V"], c["D"])) * 0.25).astype(np.float32)
+    return emb, ub, it, uf, cf, y
+
+
+def init_weights(m, seed):
+    from goctr_amd import model as gm  # noqa: F401
+    rng = np.random.default_rng(seed)
+    I = CFG["U"] + 2 * CFG["D"] + CFG["C"]
+    # random-init weights of the reference architecture (N(0,1) like din.go:187-191)
+    m.set_weights("mlp0", rng.standard_normal((I, CFG["H1"])).astype(np.float32))
+    m.set_weights("mlp1", rng.standard_normal((CFG["H1"], CFG["H2"])).astype(np.float32))
+    m.set_weights("mlp2", rng.standard_normal((CFG["H2"], 1)).astype(np.float32))
+
+
+def kernel_work():
+    """algorithmic work per launch of each kernel family for cfg3 (DESIGN.md 'Kernels')"""
+    c = CFG
+    B, I, H1, H2, T, D = c["B"], c["U"] + 2 * c["D"] + c["C"], c["H1"], c["H2"], c["T"], c["D"]
+    gather_bytes = B * ((T + 1) * D * 4 + (T + 1) * 4)   # 3 264 B rows + 204 B ids per sample
+    return {
+        "attn_fwd": ("hbm", gather_bytes), "attn_bwd": ("hbm", gather_bytes),
+        "gemm_fwd0": ("mfma", 2.0 * B * I * H1), "gemm_fwd1": ("mfma", 2.0 * B * H1 * H2),
+        "gemm_out": ("mfma", 2.0 * B * H2), "bwd_dz1": ("mfma", 2.0 * B * H2),
+        "bwd_dz0": ("mfma", 2.0 * B * H2 * H1), "bwd_dp": ("mfma", 2.0 * B * H1 * D),
+        "dW0": ("mfma", 2.0 * B * I * H1), "dW1": ("mfma", 2.0 * B * H1 * H2), "dW2": ("mfma", 2.0 * B * H2),
+    }
+
+
+def roofline_obj(kind, work, avg_ms):
+    if kind == "hbm":
+        ach = work / (avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+    ach = work / (avg_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None}
+
+
+def cpu_baseline(budget_s=15.0):
+    """the CPU oracle (port of the reference algorithm, float32, OpenMP over rows on all host cores)
+    timed on a bounded sample of the same workload: dense-X DIN training steps at B=8192."""
+    from oracle import pyoracle
+    c = CFG
+    cores = os.cpu_count() or 1
+    pyoracle.set_threads(cores)
+    rows = c["B"]
+    emb, ub, it, uf, cf, y = synth(rows, 7)
+    X = pyoracle.assemble_rows(emb, ub, it, uf, cf)
+    m = pyoracle.CtrModel(pyoracle.DIN, c["U"], c["T"], c["D"], c["C"]).init_gaussian(np.random.default_rng(1))
+    t0 = time.perf_counter()
+    m.train(X, y, batch=c["B"], epochs=1)          # one step (also warms the caches)
+    one = time.perf_counter() - t0
+    steps = int(max(2, min(200, budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    m.train(X, y, batch=c["B"], epochs=steps)      # rows == batch => epochs == steps
+    dt = time.perf_counter() - t0
+    return {"value": round(steps * rows / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} DIN training steps at batch {rows} (dense TrainSample rows, T=50, D=16), "
+                      f"oracle/orc_ctr.c with {cores} OpenMP threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=1 << 18, help="resident sample rows per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # control plane only (rendezvous / barrier / max); data plane is RCCL in the .so
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    from goctr_amd import capi, model as gm
+    capi.init(local_rank)
+    L = capi.load()
+    if world > 1:
+        import ctypes as C
+        import torch
+        idbuf = (C.c_uint8 * 128)()
+        if rank == 0:
+            capi.check(L.goctr_comm_unique_id(idbuf))
+        t = torch.tensor(list(idbuf), dtype=torch.uint8)
+        dist.broadcast(t, src=0)
+        idbuf = (C.c_uint8 * 128)(*t.tolist())
+        capi.check(L.goctr_comm_init(C.c_int(rank), C.c_int(world), idbuf))
+
+    def barrier():
+        capi.sync()
+        if dist is not None:
+            dist.barrier()
+
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    c = CFG
+    emb, ub, it, uf, cf, y = synth(args.rows, 42 + rank)
+    tab = gm.EmbeddingTable(emb)
+    ds = gm.Dataset.ids(ub, it, uf, cf, y)
+    m = gm.DinNet(c["U"], c["T"], c["D"], c["D"], c["C"])
+    init_weights(m, 1)                                   # same weights on every rank
+    cfg = capi.default_train_cfg(batch=c["B"], epochs=1)
+
+    # ---- training samples/sec: W warm-up steps, then exactly K timed steps
+    gm.train_steps(m, ds, cfg, args.warmup, emb=tab)
+    barrier()
+    t0 = time.perf_counter()
+    gm.train_steps(m, ds, cfg, args.steps, first_batch=args.warmup, emb=tab)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    samples_per_s = args.steps * c["B"] * world / dt
+
+    # ---- recommend QPS: rows scored per second through the predict path (PredBatch 4096)
+    pred_batches = max(args.steps, 1)
+    gm.predict_steps(m, ds, c["PRED_B"], min(args.warmup, 20), emb=tab)
+    barrier()
+    t0 = time.perf_counter()
+    gm.predict_steps(m, ds, c["PRED_B"], pred_batches, emb=tab)
+    barrier()
+    dtp = max_over_ranks(time.perf_counter() - t0)
+    qps = pred_batches * c["PRED_B"] * world / dtp
+
+    out = {
+        "metric": "training samples/sec (DIN, MovieLens-20M-shaped synthetic)", "value": round(samples_per_s, 1),
+        "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: DIN cosine attention, T=50, D=16, U=52, C=53, vocab 26744, "
+                               "batch 8192 per GPU, id mode (keys + table resident in HBM)",
+                   "global_batch": c["B"] * world, "parallelism": f"dp{world}", "resident_rows_per_gpu": args.rows},
+        "recommend_qps": round(qps, 1), "recommend_batch": c["PRED_B"],
+    }
+
+    # ---- roofline: instrumented re-run of the same K steps (eager, hipEvent pair per launch)
+    if not args.no_roofline:
+        # every rank repeats the K steps (the all-reduce needs all of them); rank 0 runs them eagerly
+        # with an event pair around every launch
+        if rank == 0:
+            capi.prof_enable(True)
+            capi.prof_reset()
+        gm.train_steps(m, ds, cfg, args.steps, first_batch=args.warmup, emb=tab)
+        capi.sync()
+        if rank == 0:
+            prof = capi.prof_get()
+            capi.prof_enable(False)
+            work = kernel_work()
+            table = {k: {"avg_us": round(ms / n * 1e3, 2), "launches": n} for k, (ms, n) in prof.items() if n}
+            dom = max((k for k in table if k in work), key=lambda k: prof[k][0])
+            kind, w = work[dom]
+            rl = roofline_obj(kind, w, prof[dom][0] / prof[dom][1])
+            rl["kernel"] = dom
+            out["roofline"] = rl
+            gk, gw = work["attn_fwd"]
+            grl = roofline_obj(gk, gw, prof["attn_fwd"][0] / prof["attn_fwd"][1])
+            grl["kernel"] = "attn_fwd (embedding gather + attention pooling)"
+            out["gather_roofline"] = grl
+            out["kernels"] = table
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        L.goctr_comm_destroy()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

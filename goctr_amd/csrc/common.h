@@ -1,0 +1,104 @@
+// common.h -- engine-wide plumbing for libgoctr_hip.so (gfx950 only): error strings, the bound
+// device + stream, device buffers, the optional RCCL communicator, per-kernel hipEvent timers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/goctr.h"
+
+namespace goctr {
+
+void set_error(const char* fmt, ...);
+
+#define GOCTR_HIP(call)                                                                       \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ::goctr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return -1;                                                                              \
+    }                                                                                         \
+  } while (0)
+
+#define GOCTR_CHECK(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      ::goctr::set_error(__VA_ARGS__);    \
+      return -1;                          \
+    }                                     \
+  } while (0)
+
+struct Engine {
+  bool inited = false;
+  int device = -1;
+  int compute_units = 0;
+  hipStream_t stream = nullptr;
+  // data-parallel communicator (comm.hip)
+  int rank = 0, world = 1;
+  void* nccl_comm = nullptr;
+  // profiling
+  bool prof = false;
+  double prof_ms[GOCTR_K_COUNT] = {0};
+  int64_t prof_n[GOCTR_K_COUNT] = {0};
+  struct Pending { int id; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+};
+Engine& engine();
+int require_engine();  // 0 if goctr_init succeeded, else sets the error and returns -1
+
+// timing scope used around every launch of a kernel family when profiling is on
+struct ProfScope {
+  int id; bool on; hipEvent_t a = nullptr, b = nullptr;
+  explicit ProfScope(int kernel_id);
+  ~ProfScope();
+};
+void prof_flush();
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+  }
+  int alloc(size_t count, bool zero = true) {
+    release();
+    if (count == 0) count = 1;
+    GOCTR_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    n = count;
+    if (zero) GOCTR_HIP(hipMemsetAsync(p, 0, count * sizeof(T), engine().stream));
+    return 0;
+  }
+  int ensure(size_t count, bool zero = true) { return count <= n && p ? 0 : alloc(count, zero); }
+  int upload(const T* host, size_t count, size_t dst_off = 0) {
+    GOCTR_HIP(hipMemcpyAsync(p + dst_off, host, count * sizeof(T), hipMemcpyHostToDevice, engine().stream));
+    GOCTR_HIP(hipStreamSynchronize(engine().stream));  // host buffer may be freed by the caller
+    return 0;
+  }
+  int download(T* host, size_t count, size_t src_off = 0) const {
+    GOCTR_HIP(hipMemcpyAsync(host, p + src_off, count * sizeof(T), hipMemcpyDeviceToHost, engine().stream));
+    GOCTR_HIP(hipStreamSynchronize(engine().stream));
+    return 0;
+  }
+};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// collective hook (comm.hip): in-place sum over ranks on the engine stream; no-op when world == 1
+int comm_allreduce_f32(float* dev, size_t n);
+int comm_allreduce_f64_dev(double* dev, size_t n);
+
+}  // namespace goctr

@@ -1,0 +1,798 @@
+// ctr.hip -- host side of the DIN / YouTube-DNN engine + its C-ABI (include/goctr.h).
+//
+// Replaces, behind the same operator surface, the gorgonia-executed training / predict loops of
+// model/model.go:27-352 for model/din and model/youtube (reference = auxten/go-ctr).  One step =
+//   attn_fwd -> 3 x gemm_nn(+epilogue) -> 3 x gemm_nn backward-data -> attn_bwd -> 3 x gemm_tn
+//   -> reduce -> [RCCL all-reduce] -> adam
+// all on one HIP stream; per-step varying values live in a device-side StepState so the sequence
+// can be captured once into a hipGraph and replayed.
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+
+#include "common.h"
+#include "ctr_kernels.h"
+#include "mfma_gemm.h"
+
+using namespace goctr;
+
+struct goctr_emb {
+  int64_t V = 0; int D = 0;
+  DevBuf<float> rows;
+};
+
+struct goctr_dataset {
+  bool id_mode = false;
+  int64_t rows = 0;
+  bool has_y = false;
+  // dense
+  DevBuf<float> X; int xcols = 0; int ranges[8] = {0};
+  // ids
+  DevBuf<int32_t> ub_ids, item_ids; DevBuf<float> ufeat, cfeat; int U = 0, C = 0, T = 0;
+  DevBuf<float> Y;
+};
+
+struct StepGraph {
+  hipGraphExec_t a = nullptr, b = nullptr;  // b only when a communicator splits the step
+  // cache key
+  const void* ds = nullptr; const void* emb = nullptr; int B = 0; int mode = 0; float p0 = 0, p1 = 0;
+  uint32_t seed = 0; double lr = 0, l2 = 0, b1 = 0, b2 = 0, eps = 0; int flags = 0; int world = 1;
+  void destroy() {
+    if (a) (void)hipGraphExecDestroy(a);
+    if (b) (void)hipGraphExecDestroy(b);
+    a = b = nullptr;
+  }
+};
+
+struct goctr_model {
+  goctr_ctr_cfg cfg{};
+  int I = 0, Ip = 0, H1p = 0, H2p = 0, Dp = 0, Tp = 0;
+  int off1 = 0, off2 = 0, offa = 0, nflat = 0;
+  DevBuf<float> W, G, Mo, Vo, W1T, W2T, W0sT;
+  // per-batch workspace
+  int wsB = 0, tnS = 0;
+  DevBuf<float> h0, P0, A0, P1, A1, yhat, lossrow, dz2, dz1, dz0, dp, gate, wgt, slabs0, slabs1, slabs2, attp;
+  DevBuf<float> mask0, mask1;
+  DevBuf<StepState> st, pst;
+  DevBuf<float> costs;
+  std::mutex mu;
+  StepGraph graph;
+  int attp_blocks = 0;
+};
+
+namespace {
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+int tn_rows_per_wg() { return round_up(env_int("GOCTR_TN_ROWS", 128), 16); }
+
+int ensure_workspace(goctr_model* m, int B) {
+  if (m->wsB >= B && m->tnS > 0) return 0;
+  const int S = (int)cdiv(B, tn_rows_per_wg());
+  m->tnS = S;
+  if (m->h0.alloc((size_t)B * m->Ip)) return -1;
+  if (m->P0.alloc((size_t)B * m->H1p)) return -1;
+  if (m->A0.alloc((size_t)B * m->H1p)) return -1;
+  if (m->P1.alloc((size_t)B * m->H2p)) return -1;
+  if (m->A1.alloc((size_t)B * m->H2p)) return -1;
+  if (m->yhat.alloc((size_t)B)) return -1;
+  if (m->lossrow.alloc((size_t)B)) return -1;
+  if (m->dz2.alloc((size_t)B * 16)) return -1;
+  if (m->dz1.alloc((size_t)B * m->H2p)) return -1;
+  if (m->dz0.alloc((size_t)B * m->H1p)) return -1;
+  if (m->dp.alloc((size_t)B * m->Dp)) return -1;
+  if (m->gate.alloc((size_t)B * m->cfg.T)) return -1;
+  if (m->wgt.alloc((size_t)B * m->cfg.T)) return -1;
+  if (m->slabs0.alloc((size_t)S * m->Ip * m->H1p)) return -1;
+  if (m->slabs1.alloc((size_t)S * m->H1p * m->H2p)) return -1;
+  if (m->slabs2.alloc((size_t)S * m->H2p * 16)) return -1;
+  m->attp_blocks = (int)std::min<int64_t>(cdiv(B, 4), 256);
+  if (m->attp.alloc((size_t)m->attp_blocks * m->Tp)) return -1;
+  m->wsB = B;
+  m->graph.destroy();
+  return 0;
+}
+
+RowSource make_source(const goctr_dataset* d, const goctr_emb* e) {
+  RowSource s{};
+  s.rows = d->rows;
+  s.Y = d->has_y ? d->Y.p : nullptr;
+  s.id_mode = d->id_mode ? 1 : 0;
+  if (d->id_mode) {
+    s.emb = e->rows.p; s.V = e->V;
+    s.ub_ids = d->ub_ids.p; s.item_ids = d->item_ids.p; s.ufeat = d->ufeat.p; s.cfeat = d->cfeat.p;
+  } else {
+    s.X = d->X.p; s.xcols = d->xcols;
+    s.r_u = d->ranges[0]; s.r_ub = d->ranges[2]; s.r_v = d->ranges[4]; s.r_c = d->ranges[6];
+  }
+  return s;
+}
+
+template <class Epi>
+int launch_nn(int kid, const float* A, int lda, const float* Bm, int ldb, int M, int Kp, int Np, Epi epi) {
+  const int NT = Np / 16;
+  const int WN = NT <= GEMM_NN_NTW ? 1 : (NT <= 2 * GEMM_NN_NTW ? 2 : 4);
+  const int WM = 4 / WN;
+  dim3 grid((unsigned)cdiv(M, 16 * WM), (unsigned)cdiv(NT, WN * GEMM_NN_NTW));
+  const int ncols_blk = std::min(NT, WN * GEMM_NN_NTW) * 16;
+  ProfScope ps(kid);
+  hipLaunchKernelGGL((gemm_nn_kernel<float, Epi>), grid, dim3(256), gemm_nn_lds_bytes<float>(ncols_blk),
+                     engine().stream, A, lda, Bm, ldb, M, Kp, Np, WN, epi);
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_tn(int kid, const float* A, int lda, int KT, const float* Dm, int ldd, int NT, int M, int rows_per_wg,
+              float* slabs, size_t slab_stride) {
+  const int S = (int)cdiv(M, rows_per_wg);
+  ProfScope ps(kid);
+  if (NT <= 5) {
+    constexpr int KTW = 4, NTW = 5;
+    const int WK = std::min(4, (int)cdiv(KT, KTW)), WN = 1;
+    dim3 grid(S, (unsigned)cdiv(KT, WK * KTW), (unsigned)cdiv(NT, WN * NTW));
+    hipLaunchKernelGGL((gemm_tn_kernel<float, KTW, NTW>), grid, dim3(64 * WK * WN),
+                       gemm_tn_lds_bytes<float>(WK * KTW, WN * NTW), engine().stream, A, lda, KT, Dm, ldd, NT, M,
+                       rows_per_wg, WK, WN, slabs, slab_stride);
+  } else {
+    constexpr int KTW = 3, NTW = 4;
+    const int WK = std::min(4, (int)cdiv(KT, KTW)), WN = std::min(4, (int)cdiv(NT, NTW));
+    dim3 grid(S, (unsigned)cdiv(KT, WK * KTW), (unsigned)cdiv(NT, WN * NTW));
+    hipLaunchKernelGGL((gemm_tn_kernel<float, KTW, NTW>), grid, dim3(64 * WK * WN),
+                       gemm_tn_lds_bytes<float>(WK * KTW, WN * NTW), engine().stream, A, lda, KT, Dm, ldd, NT, M,
+                       rows_per_wg, WK, WN, slabs, slab_stride);
+  }
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_attn_fwd(const AttnArgs& a) {
+  ProfScope ps(GOCTR_K_ATTN_FWD);
+  dim3 grid((unsigned)cdiv(a.B, 4)), blk(256);
+  hipStream_t st = engine().stream;
+  const bool vec4 = a.src.id_mode && a.D % 4 == 0;
+  const int groups = vec4 ? a.D / 4 : a.D;  // lanes needed per row
+#define GOCTR_ATTN_FWD(V, L) hipLaunchKernelGGL((attn_fwd_kernel<V, L>), grid, blk, 0, st, a)
+  if (vec4) {
+    if (groups <= 1) GOCTR_ATTN_FWD(4, 1);
+    else if (groups <= 2) GOCTR_ATTN_FWD(4, 2);
+    else if (groups <= 4) GOCTR_ATTN_FWD(4, 4);
+    else if (groups <= 8) GOCTR_ATTN_FWD(4, 8);
+    else if (groups <= 16) GOCTR_ATTN_FWD(4, 16);
+    else if (groups <= 32) GOCTR_ATTN_FWD(4, 32);
+    else GOCTR_ATTN_FWD(4, 64);
+  } else {
+    if (groups <= 8) GOCTR_ATTN_FWD(1, 8);
+    else if (groups <= 16) GOCTR_ATTN_FWD(1, 16);
+    else if (groups <= 32) GOCTR_ATTN_FWD(1, 32);
+    else GOCTR_ATTN_FWD(1, 64);
+  }
+#undef GOCTR_ATTN_FWD
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_attn_bwd(const AttnBwdArgs& a, int blocks) {
+  ProfScope ps(GOCTR_K_ATTN_BWD);
+  dim3 grid((unsigned)blocks), blk(256);
+  hipStream_t st = engine().stream;
+  const size_t lds = sizeof(float) * 4 * a.Tp;
+  const bool vec4 = a.src.id_mode && a.D % 4 == 0;
+  const int groups = vec4 ? a.D / 4 : a.D;
+#define GOCTR_ATTN_BWD(V, L) hipLaunchKernelGGL((attn_bwd_kernel<V, L>), grid, blk, lds, st, a)
+  if (vec4) {
+    if (groups <= 1) GOCTR_ATTN_BWD(4, 1);
+    else if (groups <= 2) GOCTR_ATTN_BWD(4, 2);
+    else if (groups <= 4) GOCTR_ATTN_BWD(4, 4);
+    else if (groups <= 8) GOCTR_ATTN_BWD(4, 8);
+    else if (groups <= 16) GOCTR_ATTN_BWD(4, 16);
+    else if (groups <= 32) GOCTR_ATTN_BWD(4, 32);
+    else GOCTR_ATTN_BWD(4, 64);
+  } else {
+    if (groups <= 8) GOCTR_ATTN_BWD(1, 8);
+    else if (groups <= 16) GOCTR_ATTN_BWD(1, 16);
+    else if (groups <= 32) GOCTR_ATTN_BWD(1, 32);
+    else GOCTR_ATTN_BWD(1, 64);
+  }
+#undef GOCTR_ATTN_BWD
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+struct StepOpts {
+  bool train = true;        // false: forward only (predict)
+  bool update = true;       // false: stop after the reduce (parity entry)
+  int drop_mode = 0; float p0 = 0, p1 = 0; uint32_t seed = 0;
+  const goctr_train_cfg* tc = nullptr;
+};
+
+// forward part: kernels 1-4
+int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st_override = nullptr) {
+  const goctr_ctr_cfg& c = m->cfg;
+  Engine& e = engine();
+  const StepState* st = st_override ? st_override : m->st.p;
+  AttnArgs aa{};
+  aa.src = src; aa.st = st; aa.B = B; aa.U = c.U; aa.T = c.T; aa.D = c.D; aa.C = c.C; aa.Ip = m->Ip;
+  aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = m->h0.p; aa.gate = m->gate.p; aa.wgt = m->wgt.p;
+  if (launch_attn_fwd(aa)) return -1;
+
+  const int bglobal = B * e.world;
+  const uint32_t row_off = (uint32_t)(e.rank * B);
+  const bool drop = o.train && o.drop_mode != 0;
+  DropCfg d0{drop && o.p0 > 0 ? o.drop_mode : 0, o.p0, m->mask0.p, c.H1, o.seed, 0u, row_off};
+  DropCfg d1{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
+  EpiSigDrop e0{m->P0.p, d0.mode ? m->A0.p : m->P0.p, m->H1p, c.H1, d0, st};
+  if (launch_nn(GOCTR_K_GEMM_FWD0, m->h0.p, m->Ip, m->W.p, m->H1p, B, m->Ip, m->H1p, e0)) return -1;
+  const float* A0 = d0.mode ? m->A0.p : m->P0.p;
+  EpiSigDrop e1{m->P1.p, d1.mode ? m->A1.p : m->P1.p, m->H2p, c.H2, d1, st};
+  if (launch_nn(GOCTR_K_GEMM_FWD1, A0, m->H1p, m->W.p + m->off1, m->H2p, B, m->H1p, m->H2p, e1)) return -1;
+  const float* A1 = d1.mode ? m->A1.p : m->P1.p;
+  EpiOut eo{m->yhat.p, o.train ? m->lossrow.p : nullptr, o.train ? m->dz2.p : nullptr, src.Y, src.rows, st, B,
+            1.0f / (float)bglobal};
+  if (launch_nn(GOCTR_K_GEMM_OUT, A1, m->H2p, m->W.p + m->off2, 16, B, m->H2p, 16, eo)) return -1;
+  return 0;
+}
+
+// backward part up to and including the slab reduce: kernels 5-12
+int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, bool advance) {
+  const goctr_ctr_cfg& c = m->cfg;
+  Engine& e = engine();
+  const StepState* st = m->st.p;
+  const uint32_t row_off = (uint32_t)(e.rank * B);
+  const bool drop = o.drop_mode != 0;
+  DropCfg d0{drop && o.p0 > 0 ? o.drop_mode : 0, o.p0, m->mask0.p, c.H1, o.seed, 0u, row_off};
+  DropCfg d1{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
+  const float* A0 = d0.mode ? m->A0.p : m->P0.p;
+  const float* A1 = d1.mode ? m->A1.p : m->P1.p;
+
+  EpiDSig b1{m->dz1.p, m->P1.p, m->H2p, c.H2, d1, st};
+  if (launch_nn(GOCTR_K_BWD_DZ1, m->dz2.p, 16, m->W2T.p, m->H2p, B, 16, m->H2p, b1)) return -1;
+  EpiDSig b0{m->dz0.p, m->P0.p, m->H1p, c.H1, d0, st};
+  if (launch_nn(GOCTR_K_BWD_DZ0, m->dz1.p, m->H2p, m->W1T.p, m->H1p, B, m->H2p, m->H1p, b0)) return -1;
+  if (c.kind == GOCTR_DIN) {
+    EpiStore sp{m->dp.p, m->Dp};
+    if (launch_nn(GOCTR_K_BWD_DP, m->dz0.p, m->H1p, m->W0sT.p, m->Dp, B, m->H1p, m->Dp, sp)) return -1;
+    AttnBwdArgs ab{};
+    ab.src = src; ab.st = st; ab.B = B; ab.T = c.T; ab.D = c.D; ab.Dp = m->Dp; ab.Tp = m->Tp;
+    ab.dp = m->dp.p; ab.gate = m->gate.p; ab.wgt = m->wgt.p; ab.partial = m->attp.p;
+    if (launch_attn_bwd(ab, m->attp_blocks)) return -1;
+  }
+  const int rpw = tn_rows_per_wg();
+  const int S = (int)cdiv(B, rpw);
+  if (launch_tn(GOCTR_K_DW0, m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, B, rpw, m->slabs0.p,
+                (size_t)m->Ip * m->H1p)) return -1;
+  if (launch_tn(GOCTR_K_DW1, A0, m->H1p, m->H1p / 16, m->dz1.p, m->H2p, m->H2p / 16, B, rpw, m->slabs1.p,
+                (size_t)m->H1p * m->H2p)) return -1;
+  if (launch_tn(GOCTR_K_DW2, A1, m->H2p, m->H2p / 16, m->dz2.p, 16, 1, B, rpw, m->slabs2.p, (size_t)m->H2p * 16)) return -1;
+
+  ReduceArgs ra{};
+  ra.seg[0] = {m->slabs0.p, S, (unsigned long long)m->Ip * m->H1p, 0, m->Ip * m->H1p};
+  ra.seg[1] = {m->slabs1.p, S, (unsigned long long)m->H1p * m->H2p, m->off1, m->H1p * m->H2p};
+  ra.seg[2] = {m->slabs2.p, S, (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
+  ra.nseg = 3;
+  if (c.kind == GOCTR_DIN) {
+    ra.seg[3] = {m->attp.p, m->attp_blocks, (unsigned long long)m->Tp, m->offa, m->Tp};
+    ra.nseg = 4;
+  }
+  ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st.p; ra.advance = advance ? 1 : 0;
+  {
+    ProfScope ps(GOCTR_K_REDUCE);
+    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)cdiv(m->nflat, 256) + 1), dim3(256), 0, e.stream, ra);
+    GOCTR_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int launch_adam(goctr_model* m, int B, const goctr_train_cfg& tc) {
+  Engine& e = engine();
+  AdamArgs a{};
+  a.W = m->W.p; a.G = m->G.p; a.Mo = m->Mo.p; a.Vo = m->Vo.p; a.nflat = m->nflat;
+  a.off1 = m->off1; a.off2 = m->off2; a.offa = m->offa;
+  a.Ip = m->Ip; a.H1p = m->H1p; a.H2p = m->H2p; a.Dp = m->Dp; a.U = m->cfg.U; a.D = m->cfg.D;
+  a.W1T = m->W1T.p; a.W2T = m->W2T.p; a.W0sT = m->W0sT.p;
+  a.lr = tc.lr; a.l2 = tc.l2; a.beta1 = tc.beta1; a.beta2 = tc.beta2; a.eps = tc.eps;
+  a.div_by_batch = tc.adam_div_by_batch; a.l2_first = tc.adam_l2_before_batch_div;
+  a.bglobal = B * e.world; a.st = m->st.p; a.costs = m->costs.p;
+  ProfScope ps(GOCTR_K_ADAM);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdiv(m->nflat, 256)), dim3(256), 0, e.stream, a);
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+int allreduce_grads(goctr_model* m) {
+  if (engine().world <= 1) return 0;
+  ProfScope ps(GOCTR_K_ALLREDUCE);
+  return comm_allreduce_f32(m->G.p, (size_t)m->nflat + 1);
+}
+
+// one full training step, eager
+int train_step_eager(goctr_model* m, const RowSource& src, int B, const StepOpts& o) {
+  if (launch_forward(m, src, B, o)) return -1;
+  if (launch_backward(m, src, B, o, true)) return -1;
+  if (allreduce_grads(m)) return -1;
+  return launch_adam(m, B, *o.tc);
+}
+
+bool graph_matches(const StepGraph& g, const goctr_dataset* d, const goctr_emb* e, int B, const StepOpts& o) {
+  return g.a && g.ds == d && g.emb == e && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
+         g.seed == o.seed && g.lr == o.tc->lr && g.l2 == o.tc->l2 && g.b1 == o.tc->beta1 && g.b2 == o.tc->beta2 &&
+         g.eps == o.tc->eps && g.flags == o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div &&
+         g.world == engine().world;
+}
+
+int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, const RowSource& src, int B,
+                const StepOpts& o) {
+  Engine& e = engine();
+  m->graph.destroy();
+  hipGraph_t g = nullptr;
+  GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+  int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true);
+  if (!rc && e.world <= 1) rc = launch_adam(m, B, *o.tc);
+  hipError_t ce = hipStreamEndCapture(e.stream, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
+  GOCTR_HIP(ce);
+  GOCTR_HIP(hipGraphInstantiate(&m->graph.a, g, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(g);
+  if (e.world > 1) {
+    hipGraph_t g2 = nullptr;
+    GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+    rc = launch_adam(m, B, *o.tc);
+    ce = hipStreamEndCapture(e.stream, &g2);
+    if (rc) { if (g2) (void)hipGraphDestroy(g2); return -1; }
+    GOCTR_HIP(ce);
+    GOCTR_HIP(hipGraphInstantiate(&m->graph.b, g2, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g2);
+  }
+  StepGraph& sg = m->graph;
+  sg.ds = d; sg.emb = emb; sg.B = B; sg.mode = o.drop_mode; sg.p0 = o.p0; sg.p1 = o.p1; sg.seed = o.seed;
+  sg.lr = o.tc->lr; sg.l2 = o.tc->l2; sg.b1 = o.tc->beta1; sg.b2 = o.tc->beta2; sg.eps = o.tc->eps;
+  sg.flags = o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div; sg.world = e.world;
+  return 0;
+}
+
+int set_state(goctr_model* m, unsigned gstep, unsigned slot, long long batch_idx, long long n_batches) {
+  StepState s{gstep, slot, batch_idx, n_batches};
+  GOCTR_HIP(hipMemcpyAsync(m->st.p, &s, sizeof s, hipMemcpyHostToDevice, engine().stream));
+  GOCTR_HIP(hipStreamSynchronize(engine().stream));
+  return 0;
+}
+
+int get_state(goctr_model* m, StepState* s) {
+  GOCTR_HIP(hipMemcpyAsync(s, m->st.p, sizeof *s, hipMemcpyDeviceToHost, engine().stream));
+  GOCTR_HIP(hipStreamSynchronize(engine().stream));
+  return 0;
+}
+
+StepOpts opts_from(const goctr_train_cfg* tc) {
+  StepOpts o;
+  o.tc = tc; o.drop_mode = tc->dropout_mode; o.p0 = tc->p0; o.p1 = tc->p1; o.seed = tc->seed;
+  return o;
+}
+
+int check_dataset(const goctr_model* m, const goctr_dataset* d, const goctr_emb* e) {
+  const goctr_ctr_cfg& c = m->cfg;
+  if (d->id_mode) {
+    GOCTR_CHECK(e != nullptr, "id-mode dataset needs an embedding table");
+    GOCTR_CHECK(e->D == c.D, "embedding dim %d != model D %d", e->D, c.D);
+    GOCTR_CHECK(d->U == c.U && d->C == c.C && d->T == c.T, "dataset dims (U=%d,T=%d,C=%d) != model (U=%d,T=%d,C=%d)",
+                d->U, d->T, d->C, c.U, c.T, c.C);
+  } else {
+    const int* r = d->ranges;
+    GOCTR_CHECK(r[1] - r[0] == c.U && r[3] - r[2] == c.T * c.D && r[5] - r[4] == c.D && r[7] - r[6] == c.C,
+                "SampleInfo ranges do not match the model dims");
+    GOCTR_CHECK(r[7] <= d->xcols && r[0] >= 0, "SampleInfo ranges exceed xcols");
+  }
+  return 0;
+}
+
+// queue n_steps training steps (graph replay unless profiling / disabled)
+int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* tc, int n_steps) {
+  Engine& e = engine();
+  const int B = tc->batch;
+  if (ensure_workspace(m, B)) return -1;
+  RowSource src = make_source(d, emb);
+  StepOpts o = opts_from(tc);
+  const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0;
+  if (use_graph) {
+    if (!graph_matches(m->graph, d, emb, B, o) && build_graph(m, d, emb, src, B, o)) return -1;
+    for (int s = 0; s < n_steps; ++s) {
+      GOCTR_HIP(hipGraphLaunch(m->graph.a, e.stream));
+      if (e.world > 1) {
+        if (allreduce_grads(m)) return -1;
+        GOCTR_HIP(hipGraphLaunch(m->graph.b, e.stream));
+      }
+    }
+  } else {
+    for (int s = 0; s < n_steps; ++s)
+      if (train_step_eager(m, src, B, o)) return -1;
+  }
+  return 0;
+}
+
+int upload_padded_weights(goctr_model* m, int tensor_id, const float* host, size_t n) {
+  const goctr_ctr_cfg& c = m->cfg;
+  std::vector<float> buf;
+  Engine& e = engine();
+  auto up = [&](float* dst, const std::vector<float>& v) -> int {
+    GOCTR_HIP(hipMemcpyAsync(dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, e.stream));
+    GOCTR_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  };
+  switch (tensor_id) {
+    case GOCTR_W0: {
+      GOCTR_CHECK(n == (size_t)m->I * c.H1, "W0 expects %d floats, got %zu", m->I * c.H1, n);
+      buf.assign((size_t)m->Ip * m->H1p, 0.f);
+      for (int r = 0; r < m->I; ++r) for (int k = 0; k < c.H1; ++k) buf[(size_t)r * m->H1p + k] = host[(size_t)r * c.H1 + k];
+      if (up(m->W.p, buf)) return -1;
+      std::vector<float> t((size_t)m->H1p * m->Dp, 0.f);
+      for (int d = 0; d < c.D; ++d) for (int k = 0; k < c.H1; ++k) t[(size_t)k * m->Dp + d] = host[(size_t)(c.U + d) * c.H1 + k];
+      return up(m->W0sT.p, t);
+    }
+    case GOCTR_W1: {
+      GOCTR_CHECK(n == (size_t)c.H1 * c.H2, "W1 expects %d floats, got %zu", c.H1 * c.H2, n);
+      buf.assign((size_t)m->H1p * m->H2p, 0.f);
+      std::vector<float> t((size_t)m->H2p * m->H1p, 0.f);
+      for (int r = 0; r < c.H1; ++r) for (int k = 0; k < c.H2; ++k) {
+        buf[(size_t)r * m->H2p + k] = host[(size_t)r * c.H2 + k];
+        t[(size_t)k * m->H1p + r] = host[(size_t)r * c.H2 + k];
+      }
+      if (up(m->W.p + m->off1, buf)) return -1;
+      return up(m->W1T.p, t);
+    }
+    case GOCTR_W2: {
+      GOCTR_CHECK(n == (size_t)c.H2, "W2 expects %d floats, got %zu", c.H2, n);
+      buf.assign((size_t)m->H2p * 16, 0.f);
+      std::vector<float> t((size_t)16 * m->H2p, 0.f);
+      for (int r = 0; r < c.H2; ++r) { buf[(size_t)r * 16] = host[r]; t[r] = host[r]; }
+      if (up(m->W.p + m->off2, buf)) return -1;
+      return up(m->W2T.p, t);
+    }
+    case GOCTR_ATT0: {
+      GOCTR_CHECK(n == (size_t)c.T, "att0 expects %d floats, got %zu", c.T, n);
+      buf.assign((size_t)m->Tp, 0.f);
+      for (int t = 0; t < c.T; ++t) buf[t] = host[t];
+      return up(m->W.p + m->offa, buf);
+    }
+  }
+  set_error("unknown tensor id %d", tensor_id);
+  return -1;
+}
+
+int download_padded(goctr_model* m, const float* flat_dev, int tensor_id, float* host, size_t n) {
+  const goctr_ctr_cfg& c = m->cfg;
+  Engine& e = engine();
+  std::vector<float> buf;
+  auto down = [&](const float* src, size_t cnt) -> int {
+    buf.resize(cnt);
+    GOCTR_HIP(hipMemcpyAsync(buf.data(), src, cnt * sizeof(float), hipMemcpyDeviceToHost, e.stream));
+    GOCTR_HIP(hipStreamSynchronize(e.stream));
+    return 0;
+  };
+  switch (tensor_id) {
+    case GOCTR_W0:
+      GOCTR_CHECK(n == (size_t)m->I * c.H1, "W0 expects %d floats, got %zu", m->I * c.H1, n);
+      if (down(flat_dev, (size_t)m->Ip * m->H1p)) return -1;
+      for (int r = 0; r < m->I; ++r) for (int k = 0; k < c.H1; ++k) host[(size_t)r * c.H1 + k] = buf[(size_t)r * m->H1p + k];
+      return 0;
+    case GOCTR_W1:
+      GOCTR_CHECK(n == (size_t)c.H1 * c.H2, "W1 expects %d floats, got %zu", c.H1 * c.H2, n);
+      if (down(flat_dev + m->off1, (size_t)m->H1p * m->H2p)) return -1;
+      for (int r = 0; r < c.H1; ++r) for (int k = 0; k < c.H2; ++k) host[(size_t)r * c.H2 + k] = buf[(size_t)r * m->H2p + k];
+      return 0;
+    case GOCTR_W2:
+      GOCTR_CHECK(n == (size_t)c.H2, "W2 expects %d floats, got %zu", c.H2, n);
+      if (down(flat_dev + m->off2, (size_t)m->H2p * 16)) return -1;
+      for (int r = 0; r < c.H2; ++r) host[r] = buf[(size_t)r * 16];
+      return 0;
+    case GOCTR_ATT0:
+      GOCTR_CHECK(n == (size_t)c.T, "att0 expects %d floats, got %zu", c.T, n);
+      if (down(flat_dev + m->offa, (size_t)m->Tp)) return -1;
+      for (int t = 0; t < c.T; ++t) host[t] = buf[t];
+      return 0;
+  }
+  set_error("unknown tensor id %d", tensor_id);
+  return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+void goctr_train_cfg_default(goctr_train_cfg* c) {
+  memset(c, 0, sizeof *c);
+  c->batch = 200; c->epochs = 200; c->early_stop = 20;  // dinimpl_test.go:36-43
+  c->lr = 0.01; c->l2 = 0.0001;                           // model.go:88
+  c->beta1 = 0.9; c->beta2 = 0.999; c->eps = 1e-8;
+  c->adam_div_by_batch = 1; c->adam_l2_before_batch_div = 1;
+  c->dropout_mode = 0; c->p0 = 0.005f; c->p1 = 0.005f; c->seed = 42;
+}
+
+int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(cfg && out, "goctr_model_create: null argument");
+  GOCTR_CHECK(cfg->kind == GOCTR_DIN || cfg->kind == GOCTR_YOUTUBE, "unknown model kind %d", cfg->kind);
+  GOCTR_CHECK(cfg->U >= 0 && cfg->T > 0 && cfg->D > 0 && cfg->C >= 0 && cfg->H1 > 0 && cfg->H2 > 0, "bad model dims");
+  GOCTR_CHECK(cfg->D <= 256, "embedding dim %d > 256 not supported", cfg->D);
+  std::unique_ptr<goctr_model> m(new goctr_model);
+  m->cfg = *cfg;
+  m->I = cfg->U + 2 * cfg->D + cfg->C;
+  m->Ip = round_up(m->I, 16); m->H1p = round_up(cfg->H1, 16); m->H2p = round_up(cfg->H2, 16);
+  m->Dp = round_up(cfg->D, 16); m->Tp = round_up(cfg->T, 16);
+  m->off1 = m->Ip * m->H1p; m->off2 = m->off1 + m->H1p * m->H2p; m->offa = m->off2 + m->H2p * 16;
+  m->nflat = m->offa + m->Tp;
+  if (m->W.alloc(m->nflat) || m->G.alloc((size_t)m->nflat + 1) || m->Mo.alloc(m->nflat) || m->Vo.alloc(m->nflat)) return -1;
+  if (m->W1T.alloc((size_t)m->H2p * m->H1p) || m->W2T.alloc((size_t)16 * m->H2p) || m->W0sT.alloc((size_t)m->H1p * m->Dp)) return -1;
+  if (m->st.alloc(1) || m->costs.alloc(COST_RING)) return -1;
+  std::vector<float> ones(cfg->T, 1.0f);  // din.go:181 att0 = 1
+  if (upload_padded_weights(m.get(), GOCTR_ATT0, ones.data(), ones.size())) return -1;
+  if (set_state(m.get(), 0, 0, 0, 1)) return -1;
+  *out = m.release();
+  return 0;
+}
+
+void goctr_model_destroy(goctr_model* m) {
+  if (!m) return;
+  m->graph.destroy();
+  delete m;
+}
+
+int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, size_t n) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && host, "goctr_model_set_weights: null argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  return upload_padded_weights(m, tensor_id, host, n);
+}
+
+int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && host, "goctr_model_get_weights: null argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  return download_padded(m, m->W.p, tensor_id, host, n);
+}
+
+int goctr_model_reset_optimizer(goctr_model* m) {
+  if (require_engine()) return -1;
+  std::lock_guard<std::mutex> lk(m->mu);
+  GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
+  GOCTR_HIP(hipMemsetAsync(m->Vo.p, 0, sizeof(float) * m->nflat, engine().stream));
+  return set_state(m, 0, 0, 0, 1);
+}
+
+// ------------------------------------------------------------------ embedding table / gather
+int goctr_emb_create(int64_t V, int D, const float* host_rows, goctr_emb** out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(V > 0 && D > 0 && out, "goctr_emb_create: bad arguments");
+  std::unique_ptr<goctr_emb> e(new goctr_emb);
+  e->V = V; e->D = D;
+  if (e->rows.alloc((size_t)V * D)) return -1;
+  if (host_rows && e->rows.upload(host_rows, (size_t)V * D)) return -1;
+  *out = e.release();
+  return 0;
+}
+int goctr_emb_set_rows(goctr_emb* e, int64_t first, int64_t n, const float* host_rows) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(e && host_rows && first >= 0 && first + n <= e->V, "goctr_emb_set_rows: range out of bounds");
+  return e->rows.upload(host_rows, (size_t)n * e->D, (size_t)first * e->D);
+}
+void goctr_emb_destroy(goctr_emb* e) { delete e; }
+
+int goctr_gather_rows(goctr_emb* e, const int32_t* ub_ids, const int32_t* item_ids, const float* user_feat, int U,
+                      const float* ctx_feat, int C, int T, int64_t rows, float* X_out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(e && X_out && rows >= 0, "goctr_gather_rows: bad arguments");
+  if (rows == 0) return 0;
+  const int xcols = U + T * e->D + e->D + C;
+  DevBuf<int32_t> dub, dit; DevBuf<float> duf, dcf, dX;
+  if (dub.alloc((size_t)rows * T, false) || dit.alloc(rows, false) || duf.alloc((size_t)rows * U, false) ||
+      dcf.alloc((size_t)rows * C, false) || dX.alloc((size_t)rows * xcols, false)) return -1;
+  if (dub.upload(ub_ids, (size_t)rows * T) || dit.upload(item_ids, rows)) return -1;
+  if (U && duf.upload(user_feat, (size_t)rows * U)) return -1;
+  if (C && dcf.upload(ctx_feat, (size_t)rows * C)) return -1;
+  GatherArgs a{e->rows.p, e->V, e->D, T, U, C, dub.p, dit.p, duf.p, dcf.p, rows, dX.p, xcols};
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, engine().stream, a);
+  GOCTR_HIP(hipGetLastError());
+  return dX.download(X_out, (size_t)rows * xcols);
+}
+
+// ------------------------------------------------------------------ datasets
+int goctr_dataset_create_dense(const float* X, const float* Y, int64_t rows, int xcols, const int ranges[8],
+                               goctr_dataset** out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(X && rows > 0 && xcols > 0 && ranges && out, "goctr_dataset_create_dense: bad arguments");
+  std::unique_ptr<goctr_dataset> d(new goctr_dataset);
+  d->id_mode = false; d->rows = rows; d->xcols = xcols;
+  memcpy(d->ranges, ranges, sizeof d->ranges);
+  if (d->X.alloc((size_t)rows * xcols, false) || d->X.upload(X, (size_t)rows * xcols)) return -1;
+  if (Y) { if (d->Y.alloc(rows, false) || d->Y.upload(Y, rows)) return -1; d->has_y = true; }
+  *out = d.release();
+  return 0;
+}
+
+int goctr_dataset_create_ids(const int32_t* ub_ids, const int32_t* item_ids, const float* user_feat, int U,
+                             const float* ctx_feat, int C, int T, const float* Y, int64_t rows, goctr_dataset** out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(ub_ids && item_ids && rows > 0 && T > 0 && out, "goctr_dataset_create_ids: bad arguments");
+  std::unique_ptr<goctr_dataset> d(new goctr_dataset);
+  d->id_mode = true; d->rows = rows; d->U = U; d->C = C; d->T = T;
+  if (d->ub_ids.alloc((size_t)rows * T, false) || d->ub_ids.upload(ub_ids, (size_t)rows * T)) return -1;
+  if (d->item_ids.alloc(rows, false) || d->item_ids.upload(item_ids, rows)) return -1;
+  if (d->ufeat.alloc((size_t)rows * U, false) || (U && d->ufeat.upload(user_feat, (size_t)rows * U))) return -1;
+  if (d->cfeat.alloc((size_t)rows * C, false) || (C && d->cfeat.upload(ctx_feat, (size_t)rows * C))) return -1;
+  if (Y) { if (d->Y.alloc(rows, false) || d->Y.upload(Y, rows)) return -1; d->has_y = true; }
+  *out = d.release();
+  return 0;
+}
+void goctr_dataset_destroy(goctr_dataset* d) { delete d; }
+
+// ------------------------------------------------------------------ training
+int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,
+                      int64_t first_batch, int n_steps, float* costs) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && d && cfg && cfg->batch > 0 && n_steps >= 0, "goctr_train_steps: bad arguments");
+  GOCTR_CHECK(d->has_y, "goctr_train_steps: dataset has no labels");
+  GOCTR_CHECK(cfg->dropout_mode == 0 || cfg->dropout_mode == 2, "multi-step training supports dropout_mode 0 or 2");
+  GOCTR_CHECK(n_steps <= COST_RING, "n_steps > %d per call", COST_RING);
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (check_dataset(m, d, emb)) return -1;
+  StepState s;
+  if (get_state(m, &s)) return -1;
+  const long long nb = cdiv(d->rows, cfg->batch);
+  if (set_state(m, s.gstep, 0, first_batch % nb, nb)) return -1;
+  if (run_steps(m, emb, d, cfg, n_steps)) return -1;
+  if (costs) {
+    GOCTR_HIP(hipStreamSynchronize(engine().stream));
+    if (m->costs.download(costs, n_steps)) return -1;
+  }
+  return 0;
+}
+
+int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,
+                        float* epoch_costs, int* epochs_run) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && d && cfg && cfg->batch > 0 && cfg->epochs >= 0, "goctr_train_dataset: bad arguments");
+  GOCTR_CHECK(d->has_y, "goctr_train_dataset: dataset has no labels");
+  GOCTR_CHECK(cfg->dropout_mode == 0 || cfg->dropout_mode == 2, "multi-step training supports dropout_mode 0 or 2");
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (check_dataset(m, d, emb)) return -1;
+  // a fresh solver per model.Train call (model.go:88)
+  GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
+  GOCTR_HIP(hipMemsetAsync(m->Vo.p, 0, sizeof(float) * m->nflat, engine().stream));
+  const long long nb = cdiv(d->rows, cfg->batch);
+  if (set_state(m, 0, 0, 0, nb)) return -1;
+  float best = 3.402823466e+38f;  // math.MaxFloat32 (model.go:103)
+  int no_improve = 0, e = 0;
+  for (e = 0; e < cfg->epochs; ++e) {
+    long long done = 0;
+    unsigned slot0 = 0;
+    while (done < nb) {  // keep each burst inside the cost ring
+      const int burst = (int)std::min<long long>(nb - done, COST_RING / 2);
+      if (run_steps(m, emb, d, cfg, burst)) return -1;
+      done += burst;
+    }
+    (void)slot0;
+    StepState s;
+    if (get_state(m, &s)) return -1;
+    float cost = 0.f;
+    if (m->costs.download(&cost, 1, (s.slot - 1u) % COST_RING)) return -1;  // cost of the LAST batch (model.go:198)
+    if (epoch_costs) epoch_costs[e] = cost;
+    if (cost < best) { best = cost; no_improve = 0; } else no_improve++;
+    if (cfg->early_stop != 0 && no_improve >= cfg->early_stop) { e++; break; }
+  }
+  if (epochs_run) *epochs_run = e;
+  return 0;
+}
+
+int goctr_train_dense(goctr_model* m, const float* X, const float* Y, int64_t rows, int xcols, const int ranges[8],
+                      const goctr_train_cfg* cfg, float* epoch_costs, int* epochs_run) {
+  goctr_dataset* d = nullptr;
+  GOCTR_CHECK(Y != nullptr, "goctr_train_dense: labels required");
+  if (goctr_dataset_create_dense(X, Y, rows, xcols, ranges, &d)) return -1;
+  int rc = goctr_train_dataset(m, nullptr, d, cfg, epoch_costs, epochs_run);
+  if (!rc) rc = goctr_sync();
+  m->graph.destroy();  // the graph holds pointers into the temporary dataset
+  goctr_dataset_destroy(d);
+  return rc;
+}
+
+int goctr_loss_grad_dense(goctr_model* m, const float* X, const float* Y, int valid, int B, int xcols,
+                          const int ranges[8], const goctr_train_cfg* cfg, uint32_t step, const float* m0,
+                          const float* m1, float* cost, float* gW0, float* gW1, float* gW2, float* gatt0, float* y_out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && X && Y && cfg && valid > 0 && valid <= B, "goctr_loss_grad_dense: bad arguments");
+  goctr_dataset* d = nullptr;
+  if (goctr_dataset_create_dense(X, Y, valid, xcols, ranges, &d)) return -1;
+  std::unique_ptr<goctr_dataset> guard(d);
+  std::lock_guard<std::mutex> lk(m->mu);
+  if (check_dataset(m, d, nullptr)) return -1;
+  if (ensure_workspace(m, B)) return -1;
+  StepOpts o = opts_from(cfg);
+  o.update = false;
+  if (o.drop_mode == 1) {
+    GOCTR_CHECK(m0 && m1, "dropout_mode 1 needs explicit masks");
+    if (m->mask0.alloc((size_t)B * m->cfg.H1, false) || m->mask0.upload(m0, (size_t)B * m->cfg.H1)) return -1;
+    if (m->mask1.alloc((size_t)B * m->cfg.H2, false) || m->mask1.upload(m1, (size_t)B * m->cfg.H2)) return -1;
+  }
+  StepState saved;
+  if (get_state(m, &saved)) return -1;
+  if (set_state(m, step, 0, 0, 1)) return -1;
+  RowSource src = make_source(d, nullptr);
+  int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, false);
+  if (rc) return -1;
+  GOCTR_HIP(hipStreamSynchronize(engine().stream));
+  if (gW0 && download_padded(m, m->G.p, GOCTR_W0, gW0, (size_t)m->I * m->cfg.H1)) return -1;
+  if (gW1 && download_padded(m, m->G.p, GOCTR_W1, gW1, (size_t)m->cfg.H1 * m->cfg.H2)) return -1;
+  if (gW2 && download_padded(m, m->G.p, GOCTR_W2, gW2, (size_t)m->cfg.H2)) return -1;
+  if (gatt0) {
+    if (m->cfg.kind == GOCTR_DIN) { if (download_padded(m, m->G.p, GOCTR_ATT0, gatt0, (size_t)m->cfg.T)) return -1; }
+    else memset(gatt0, 0, sizeof(float) * m->cfg.T);
+  }
+  if (cost) {
+    float s = 0.f;
+    if (m->G.download(&s, 1, m->nflat)) return -1;
+    *cost = -(s / (float)(B * engine().world));
+  }
+  if (y_out && m->yhat.download(y_out, B)) return -1;
+  return set_state(m, saved.gstep, saved.slot, saved.batch_idx, saved.n_batches);
+}
+
+// ------------------------------------------------------------------ predict
+static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, int64_t first_batch,
+                           int64_t n_batches, float* y_host) {
+  if (check_dataset(m, d, emb)) return -1;
+  if (ensure_workspace(m, batch)) return -1;
+  RowSource src = make_source(d, emb);
+  StepOpts o;
+  o.train = false;
+  const long long nb = cdiv(d->rows, batch);
+  // per-batch states are written up front so that no host stack memory is read asynchronously
+  const int64_t CH = 4096;
+  if (m->pst.ensure((size_t)std::min<int64_t>(n_batches, CH), false)) return -1;
+  std::vector<StepState> hs;
+  for (int64_t k0 = 0; k0 < n_batches; k0 += CH) {
+    const int64_t cnt = std::min<int64_t>(CH, n_batches - k0);
+    hs.resize(cnt);
+    for (int64_t k = 0; k < cnt; ++k) hs[k] = StepState{0u, 0u, (first_batch + k0 + k) % nb, nb};
+    if (m->pst.upload(hs.data(), (size_t)cnt)) return -1;
+    for (int64_t k = 0; k < cnt; ++k) {
+      if (launch_forward(m, src, batch, o, m->pst.p + k)) return -1;
+      if (y_host) {
+        const long long b = hs[k].batch_idx;
+        const long long start = b * batch, end = std::min<long long>(start + batch, d->rows);
+        if (m->yhat.download(y_host + start, (size_t)(end - start))) return -1;  // first end-start outputs (model.go:344-347)
+      }
+    }
+    if (k0 + CH < n_batches) GOCTR_HIP(hipStreamSynchronize(engine().stream));  // before the states are overwritten
+  }
+  return 0;
+}
+
+int goctr_predict_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, float* y_out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && d && y_out && batch > 0, "goctr_predict_dataset: bad arguments");
+  std::lock_guard<std::mutex> lk(m->mu);
+  return predict_batches(m, emb, d, batch, 0, cdiv(d->rows, batch), y_out);
+}
+
+int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, int64_t first_batch,
+                        int n_batches) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && d && batch > 0 && n_batches >= 0, "goctr_predict_steps: bad arguments");
+  std::lock_guard<std::mutex> lk(m->mu);
+  return predict_batches(m, emb, d, batch, first_batch, n_batches, nullptr);
+}
+
+int goctr_predict_dense(goctr_model* m, const float* X, int64_t rows, int xcols, const int ranges[8], int batch,
+                        float* y_out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && X && y_out && rows >= 0 && batch > 0, "goctr_predict_dense: bad arguments");
+  if (rows == 0) return 0;
+  goctr_dataset* d = nullptr;
+  if (goctr_dataset_create_dense(X, nullptr, rows, xcols, ranges, &d)) return -1;
+  int rc = goctr_predict_dataset(m, nullptr, d, batch, y_out);
+  goctr_dataset_destroy(d);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,495 @@
+// ctr_kernels.h -- device code of the DIN / YouTube-DNN step (float32, as in the reference):
+// embedding gather + attention pooling, GEMM epilogues, attention backward, slab reduce, Adam.
+//
+// Reference arithmetic (file:line relative to auxten/go-ctr):
+//   gather + row layout      recommend/rcmd.go:462-536, utils/util.go:22-28
+//   cosine / euclid gate     model/activation.go:23-83, model/din/din.go:230-298
+//   3 sigmoid layers+dropout model/din/din.go:301-315, model/youtube/dnn.go:162-177
+//   BCE                      model/cost.go:9-17
+//   Adam (gorgonia solver)   model/model.go:88,192  (semantics: SURVEY.md App. B)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace goctr {
+
+// Per-step values that change between replays of the captured step graph live in device memory so
+// that every kernel argument is a launch-time constant.
+struct StepState {
+  unsigned int gstep;     // global step counter: dropout hash input; Adam iter = gstep after ++
+  unsigned int slot;      // next cost slot
+  long long batch_idx;    // batch of the dataset the current step works on
+  long long n_batches;
+};
+
+constexpr int COST_RING = 1 << 16;
+
+// ---------------------------------------------------------------- scalar helpers
+// gorgonia's float32 sigmoid clamps at -88 / +15 [from memory, SURVEY App. B]
+__device__ __forceinline__ float sigm_hidden(float x) {
+  if (x < -88.f) return 0.f;
+  if (x > 15.f) return 1.f;
+  return 1.0f / (1.0f + expf(-x));
+}
+// The output unit feeds log(1-p) in the BCE, which is ill-conditioned near saturation: evaluate it
+// like the reference does (float64 exp, rounded once to float32).
+__device__ __forceinline__ float sigm_out(float x) {
+  if (x < -88.f) return 0.f;
+  if (x > 15.f) return 1.f;
+  return (float)(1.0 / (1.0 + exp((double)(-x))));
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+// counter-hash dropout keep mask; bit-identical to oracle/orc_ctr.c:orc_dropout_keep
+__device__ __forceinline__ float dropout_keep(uint32_t seed, uint32_t step, uint32_t layer, uint32_t row,
+                                              uint32_t col, float p) {
+  uint32_t h = mix32(seed ^ 0x9E3779B9u);
+  h = mix32(h ^ (step * 2u + layer));
+  h = mix32(h ^ row);
+  h = mix32(h ^ (col * 0x85EBCA6Bu + 0xC2B2AE35u));
+  float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u < (1.0f - p) ? 1.0f : 0.0f;
+}
+
+// where a batch's rows come from
+struct RowSource {
+  // dense-X mode (TrainSample layout, rcmd.go:56-63)
+  const float* X; int xcols; int r_u, r_ub, r_v, r_c;
+  // id mode (table + keys resident in HBM)
+  const float* emb; long long V;
+  const int32_t* ub_ids; const int32_t* item_ids; const float* ufeat; const float* cfeat;
+  const float* Y;          // may be null (predict)
+  long long rows;
+  int id_mode;
+};
+
+struct DropCfg {
+  int mode; float p; const float* mask; int mask_ld; uint32_t seed; uint32_t layer; uint32_t row_off;
+};
+
+// ---------------------------------------------------------------- attention forward
+struct AttnArgs {
+  RowSource src;
+  const StepState* st;
+  int B, U, T, D, C, Ip;
+  int kind, att;
+  const float* att0;
+  float* h0;    // [B, Ip]
+  float* gate;  // [B, T]
+  float* wgt;   // [B, T]
+};
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LPR>
+__device__ __forceinline__ float cross_row_sum(float v) {
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// One wavefront per sample.  A wavefront covers RPP = 64/LPR behaviour rows per pass, LPR lanes per
+// row, VEC consecutive embedding lanes per lane (VEC=4 => one 16-byte load per lane, a 64-byte row
+// of a D=16 table is fetched by 4 adjacent lanes: fully coalesced 64 B segments).
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int RPP = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= a.B) return;
+  const RowSource& s = a.src;
+  const long long gr = a.st->batch_idx * (long long)a.B + b;
+  const bool valid = gr < s.rows;
+  const int dl = lane % LPR, rl = lane / LPR;
+  const int d0 = dl * VEC;
+  const int D = a.D, T = a.T;
+
+  // candidate item embedding v
+  float vv[VEC];
+  const float* vrow = nullptr;
+  if (valid) {
+    if (s.id_mode) {
+      int it = s.item_ids[gr];
+      if (it >= 0 && it < s.V) vrow = s.emb + (long long)it * D;
+    } else {
+      vrow = s.X + gr * (long long)s.xcols + s.r_v;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) vv[e] = 0.f;
+  if (vrow && d0 < D) {
+    if (VEC == 4) {
+      float4 t4 = *reinterpret_cast<const float4*>(vrow + d0);
+      vv[0] = t4.x; vv[1] = t4.y; vv[2] = t4.z; vv[3] = t4.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) vv[e] = d0 + e < D ? vrow[d0 + e] : 0.f;
+    }
+  }
+  float syy = 0.f;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) syy += vv[e] * vv[e];
+  const float yn = sqrtf(group_sum<LPR>(syy));
+
+  float psum[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) psum[e] = 0.f;
+
+  for (int t0 = 0; t0 < T; t0 += RPP) {
+    const int t = t0 + rl;
+    float x[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) x[e] = 0.f;
+    const float* xrow = nullptr;
+    if (valid && t < T) {
+      if (s.id_mode) {
+        int id = s.ub_ids[gr * T + t];
+        if (id >= 0 && id < s.V) xrow = s.emb + (long long)id * D;
+      } else {
+        xrow = s.X + gr * (long long)s.xcols + s.r_ub + t * D;
+      }
+    }
+    if (xrow && d0 < D) {
+      if (VEC == 4) {
+        float4 t4 = *reinterpret_cast<const float4*>(xrow + d0);
+        x[0] = t4.x; x[1] = t4.y; x[2] = t4.z; x[3] = t4.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x[e] = d0 + e < D ? xrow[d0 + e] : 0.f;
+      }
+    }
+    float g = 1.0f, wv = 0.f;
+    if (a.kind == GOCTR_DIN) {
+      if (a.att == GOCTR_ATT_COSINE) {
+        float sxx = 0.f, sxy = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { sxx += x[e] * x[e]; sxy += x[e] * vv[e]; }
+        sxx = group_sum<LPR>(sxx);
+        sxy = group_sum<LPR>(sxy);
+        float cosv = sxy / (sqrtf(sxx) * yn + 1e-8f);
+        wv = (cosv + 1.0f) / 2.0f;
+      } else {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { float df = x[e] - vv[e]; ss += (d0 + e < D) ? df * df : 0.f; }
+        ss = group_sum<LPR>(ss);
+        wv = 1.0f - sqrtf(ss);
+      }
+      g = sigm_hidden(wv * (t < T ? a.att0[t] : 0.f));
+    }
+    if (t < T) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) psum[e] += g * x[e];
+      if (dl == 0) {
+        a.gate[(size_t)b * T + t] = g;
+        a.wgt[(size_t)b * T + t] = wv;
+      }
+    }
+  }
+  float* hrow = a.h0 + (size_t)b * a.Ip;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    float p = cross_row_sum<LPR>(psum[e]) / (float)T;
+    if (rl == 0 && d0 + e < D) {
+      hrow[a.U + d0 + e] = p;
+      hrow[a.U + D + d0 + e] = vv[e];
+    }
+  }
+  for (int j = lane; j < a.U; j += 64) {
+    float v = 0.f;
+    if (valid) v = s.id_mode ? s.ufeat[gr * a.U + j] : s.X[gr * (long long)s.xcols + s.r_u + j];
+    hrow[j] = v;
+  }
+  for (int j = lane; j < a.C; j += 64) {
+    float v = 0.f;
+    if (valid) v = s.id_mode ? s.cfeat[gr * a.C + j] : s.X[gr * (long long)s.xcols + s.r_c + j];
+    hrow[a.U + 2 * D + j] = v;
+  }
+}
+
+// ---------------------------------------------------------------- attention backward (att0 grad)
+struct AttnBwdArgs {
+  RowSource src;
+  const StepState* st;
+  int B, T, D, Dp, Tp;
+  const float* dp;    // [B, Dp]   d cost / d pooled
+  const float* gate;  // [B, T]
+  const float* wgt;   // [B, T]
+  float* partial;     // [gridDim.x, Tp]
+};
+
+// datt0[t] = sum_b dg[b,t] * g(1-g) * w ; dg[b,t] = (1/T) sum_d dp[b,d] * x[b,t,d]   
+template <int VEC, int LPR>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
+  constexpr int RPP = 64 / LPR;
+  extern __shared__ float att_acc[];  // [4][Tp]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const RowSource& s = a.src;
+  const int dl = lane % LPR, rl = lane / LPR, d0 = dl * VEC;
+  const int D = a.D, T = a.T;
+  for (int j = threadIdx.x; j < 4 * a.Tp; j += 256) att_acc[j] = 0.f;
+  __syncthreads();
+  float* my = att_acc + wave * a.Tp;
+  for (int b = blockIdx.x * 4 + wave; b < a.B; b += gridDim.x * 4) {
+    const long long gr = a.st->batch_idx * (long long)a.B + b;
+    const bool valid = gr < s.rows;
+    float dpt[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dpt[e] = d0 + e < D ? a.dp[(size_t)b * a.Dp + d0 + e] / (float)T : 0.f;
+    for (int t0 = 0; t0 < T; t0 += RPP) {
+      const int t = t0 + rl;
+      float x[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x[e] = 0.f;
+      const float* xrow = nullptr;
+      if (valid && t < T) {
+        if (s.id_mode) {
+          int id = s.ub_ids[gr * T + t];
+          if (id >= 0 && id < s.V) xrow = s.emb + (long long)id * D;
+        } else {
+          xrow = s.X + gr * (long long)s.xcols + s.r_ub + t * D;
+        }
+      }
+      if (xrow && d0 < D) {
+        if (VEC == 4) {
+          float4 t4 = *reinterpret_cast<const float4*>(xrow + d0);
+          x[0] = t4.x; x[1] = t4.y; x[2] = t4.z; x[3] = t4.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) x[e] = d0 + e < D ? xrow[d0 + e] : 0.f;
+        }
+      }
+      float dg = 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dg += dpt[e] * x[e];
+      dg = group_sum<LPR>(dg);
+      if (t < T && dl == 0) {
+        float g = a.gate[(size_t)b * T + t];
+        my[t] += dg * (g * (1.0f - g)) * a.wgt[(size_t)b * T + t];
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < a.Tp; t += 256) {
+    float v = 0.f;
+    if (t < T) v = ((att_acc[t] + att_acc[a.Tp + t]) + att_acc[2 * a.Tp + t]) + att_acc[3 * a.Tp + t];
+    a.partial[(size_t)blockIdx.x * a.Tp + t] = v;
+  }
+}
+
+// ---------------------------------------------------------------- GEMM epilogues
+// hidden layer: P = sigmoid(z) ; A = P * mask / keep   (din.go:307-308,311-312)
+struct EpiSigDrop {
+  float* P; float* Aout; int ld; int ncols; DropCfg dr; const StepState* st;
+  __device__ __forceinline__ void operator()(int row, int col, float z) const {
+    float a = 0.f, post = 0.f;
+    if (col < ncols) {
+      a = sigm_hidden(z);
+      post = a;
+      if (dr.mode) {
+        const float keep = 1.0f - dr.p;
+        float m = dr.mode == 1 ? dr.mask[(size_t)row * dr.mask_ld + col]
+                               : dropout_keep(dr.seed, st->gstep, dr.layer, dr.row_off + row, col, dr.p);
+        post = a * m / keep;
+      }
+    }
+    P[(size_t)row * ld + col] = a;
+    if (Aout != P) Aout[(size_t)row * ld + col] = post;
+  }
+};
+
+// output unit + BCE + d cost/d z2 (din.go:315, cost.go:9-17).  Works on the padded 16-column tile;
+// only column 0 is real.
+struct EpiOut {
+  float* yhat;      // [B]
+  float* lossrow;   // [B] or null (predict)
+  float* dz2;       // [B,16] or null
+  const float* Y; long long rows; const StepState* st; int B; float inv_bglobal;
+  __device__ __forceinline__ void operator()(int row, int col, float z) const {
+    if (col != 0) {
+      if (dz2) dz2[(size_t)row * 16 + col] = 0.f;
+      return;
+    }
+    const float p = sigm_out(z);
+    yhat[row] = p;
+    if (!lossrow) return;
+    const long long gr = st->batch_idx * (long long)B + row;
+    const float y = (Y && gr < rows) ? Y[gr] : 0.f;  // pad rows: y = 0 (model.go:180-184)
+    const float one_eps = (float)(1.0 + 1e-8);      // == 1.0f (quirk Q2)
+    const float positive = logf(p) * y;
+    const float negative = logf(one_eps - p) * (1.0f - y);
+    lossrow[row] = positive + negative;
+    const float dy = -((y / p) - ((1.0f - y) / (one_eps - p))) * inv_bglobal;
+    dz2[(size_t)row * 16] = dy * (p * (1.0f - p));
+  }
+};
+
+// backward data: dz = (delta . W^T) * (mask/keep) * P(1-P)
+struct EpiDSig {
+  float* out; const float* P; int ld; int ncols; DropCfg dr; const StepState* st;
+  __device__ __forceinline__ void operator()(int row, int col, float s) const {
+    float r = 0.f;
+    if (col < ncols) {
+      float k = 1.0f;
+      if (dr.mode) {
+        const float keep = 1.0f - dr.p;
+        float m = dr.mode == 1 ? dr.mask[(size_t)row * dr.mask_ld + col]
+                               : dropout_keep(dr.seed, st->gstep, dr.layer, dr.row_off + row, col, dr.p);
+        k = m / keep;
+      }
+      const float a = P[(size_t)row * ld + col];
+      r = (s * k) * (a * (1.0f - a));
+    }
+    out[(size_t)row * ld + col] = r;
+  }
+};
+
+struct EpiStore {
+  float* out; int ld;
+  __device__ __forceinline__ void operator()(int row, int col, float v) const { out[(size_t)row * ld + col] = v; }
+};
+
+// ---------------------------------------------------------------- slab reduce
+struct ReduceSeg { const float* slabs; int nslabs; unsigned long long stride; int begin; int len; };
+struct ReduceArgs {
+  ReduceSeg seg[4];
+  int nseg; int nflat;
+  const float* lossrow; int B;
+  float* G;           // [nflat + 1]; G[nflat] = sum of per-row BCE terms
+  StepState* st;
+  int advance;        // 1: this launch closes the step (++gstep, next batch)
+};
+
+__global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == gridDim.x - 1) {  // last block: deterministic loss sum
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.B; i += 256) s += a.lossrow[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      a.G[a.nflat] = red[0];
+      if (a.advance) {
+        a.st->gstep += 1;
+        a.st->slot += 1;
+        long long nb = a.st->batch_idx + 1;
+        a.st->batch_idx = nb >= a.st->n_batches ? 0 : nb;
+      }
+    }
+    return;
+  }
+  if (idx >= a.nflat) return;
+  float s = 0.f;
+  bool hit = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k < a.nseg && idx >= a.seg[k].begin && idx < a.seg[k].begin + a.seg[k].len) {
+      const float* p = a.seg[k].slabs + (idx - a.seg[k].begin);
+      for (int j = 0; j < a.seg[k].nslabs; ++j) s += p[(size_t)j * a.seg[k].stride];
+      hit = true;
+    }
+  }
+  a.G[idx] = hit ? s : 0.f;
+}
+
+// ---------------------------------------------------------------- Adam (gorgonia AdamSolver.Step)
+struct AdamArgs {
+  float* W; float* G; float* Mo; float* Vo; int nflat;
+  // layout of the flat parameter buffer
+  int off1, off2, offa;      // W0 at 0, W1 at off1, W2 at off2, att0 at offa
+  int Ip, H1p, H2p, Dp, U, D;
+  float* W1T; float* W2T; float* W0sT;  // transposed copies used by the backward-data GEMMs
+  double lr, l2, beta1, beta2, eps;
+  int div_by_batch, l2_first;
+  int bglobal;
+  const StepState* st;
+  float* costs;              // ring [COST_RING]
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float corr[2];
+  if (threadIdx.x == 0) {
+    const double it = (double)a.st->gstep;  // already incremented by the reduce kernel
+    corr[0] = 1.0f / (float)(1.0 - pow(a.beta1, it));
+    corr[1] = 1.0f / (float)(1.0 - pow(a.beta2, it));
+  }
+  __syncthreads();
+  if (idx == 0) {
+    const float s = a.G[a.nflat];
+    a.costs[(a.st->slot - 1u) % COST_RING] = -(s / (float)a.bglobal);  // cost.go:15 Neg(Mean(...))
+  }
+  if (idx >= a.nflat) return;
+  const float b1 = (float)a.beta1, b2 = (float)a.beta2;
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  const float l2 = (float)a.l2, eps = (float)a.eps, neg_eta = (float)(-a.lr);
+  const float one_per_batch = 1.0f / (float)a.bglobal;
+  float w = a.W[idx];
+  float g = a.G[idx];
+  if (a.l2_first) {
+    if (l2 != 0.f) g = g + w * l2;
+    if (a.div_by_batch && a.bglobal > 1) g = g * one_per_batch;
+  } else {
+    if (a.div_by_batch && a.bglobal > 1) g = g * one_per_batch;
+    if (l2 != 0.f) g = g + w * l2;
+  }
+  const float t1 = omb1 * g;
+  const float g2 = (g * g) * omb2;
+  const float m = b1 * a.Mo[idx] + t1;
+  const float v = b2 * a.Vo[idx] + g2;
+  a.Mo[idx] = m; a.Vo[idx] = v;
+  const float mhat = m * corr[0];
+  const float vhat = v * corr[1];
+  w = w + (neg_eta * mhat) / (sqrtf(vhat) + eps);
+  a.W[idx] = w;
+  a.G[idx] = 0.f;
+  // keep the transposed operand copies in sync
+  if (idx < a.off1) {
+    const int r = idx / a.H1p, c = idx - r * a.H1p;
+    if (r >= a.U && r < a.U + a.D) a.W0sT[(size_t)c * a.Dp + (r - a.U)] = w;
+  } else if (idx < a.off2) {
+    const int k = idx - a.off1;
+    const int r = k / a.H2p, c = k - r * a.H2p;
+    a.W1T[(size_t)c * a.H1p + r] = w;
+  } else if (idx < a.offa) {
+    const int k = idx - a.off2;
+    const int r = k / 16, c = k - r * 16;
+    a.W2T[(size_t)c * a.H2p + r] = w;
+  }
+}
+
+// ---------------------------------------------------------------- standalone gather (bit-exact)
+struct GatherArgs {
+  const float* emb; long long V; int D, T, U, C;
+  const int32_t* ub_ids; const int32_t* item_ids; const float* ufeat; const float* cfeat;
+  long long rows; float* X; int xcols;
+};
+// rcmd.go:497-533: one wavefront per row; pure copies => bit-exact
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long r = (long long)blockIdx.x * 4 + wave;
+  if (r >= a.rows) return;
+  float* row = a.X + r * a.xcols;
+  for (int j = lane; j < a.U; j += 64) row[j] = a.ufeat[r * a.U + j];
+  const int TD = a.T * a.D;
+  for (int j = lane; j < TD + a.D; j += 64) {
+    const int t = j / a.D, d = j - t * a.D;
+    const int id = t < a.T ? a.ub_ids[r * a.T + t] : a.item_ids[r];
+    row[a.U + j] = (id >= 0 && id < a.V) ? a.emb[(long long)id * a.D + d] : 0.f;
+  }
+  for (int j = lane; j < a.C; j += 64) row[a.U + TD + a.D + j] = a.cfeat[r * a.C + j];
+}
+
+}  // namespace goctr

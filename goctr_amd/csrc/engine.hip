@@ -1,0 +1,141 @@
+// engine.hip -- runtime plumbing of libgoctr_hip.so: device binding, error strings, hipEvent
+// per-kernel timers.  (No reference counterpart: go-ctr has no device runtime)
+#include "common.h"
+
+namespace goctr {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+Engine& engine() {
+  static Engine e;
+  return e;
+}
+
+int require_engine() {
+  if (!engine().inited) {
+    set_error("goctr: no HIP device bound -- call goctr_init() first (there is no CPU fallback)");
+    return -1;
+  }
+  return 0;
+}
+
+static const char* kNames[GOCTR_K_COUNT] = {
+    "attn_fwd", "gemm_fwd0", "gemm_fwd1", "gemm_out", "bwd_dz1", "bwd_dz0", "bwd_dp",
+    "attn_bwd", "dW0", "dW1", "dW2", "reduce", "allreduce", "adam"};
+
+ProfScope::ProfScope(int kernel_id) : id(kernel_id), on(engine().prof) {
+  if (!on) return;
+  Engine& e = engine();
+  auto get = [&]() {
+    hipEvent_t ev = nullptr;
+    if (!e.event_pool.empty()) { ev = e.event_pool.back(); e.event_pool.pop_back(); }
+    else (void)hipEventCreate(&ev);
+    return ev;
+  };
+  a = get(); b = get();
+  (void)hipEventRecord(a, e.stream);
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  Engine& e = engine();
+  (void)hipEventRecord(b, e.stream);
+  e.pending.push_back({id, a, b});
+  if (e.pending.size() > 4096) prof_flush();
+}
+void prof_flush() {
+  Engine& e = engine();
+  if (e.pending.empty()) return;
+  (void)hipStreamSynchronize(e.stream);
+  for (auto& p : e.pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { e.prof_ms[p.id] += ms; e.prof_n[p.id] += 1; }
+    e.event_pool.push_back(p.a); e.event_pool.push_back(p.b);
+  }
+  e.pending.clear();
+}
+
+}  // namespace goctr
+
+using namespace goctr;
+
+extern "C" {
+
+const char* goctr_last_error(void) { return g_err.c_str(); }
+const char* goctr_version(void) { return "goctr-hip 0.1 (gfx950)"; }
+
+int goctr_device_count(int* n) {
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { c = 0; (void)hipGetLastError(); }
+  *n = c;
+  return 0;
+}
+
+int goctr_init(int device_ordinal) {
+  Engine& e = engine();
+  int n = 0;
+  goctr_device_count(&n);
+  GOCTR_CHECK(n > 0, "goctr_init: no HIP device visible (this engine has no CPU fallback)");
+  GOCTR_CHECK(device_ordinal >= 0 && device_ordinal < n, "goctr_init: device %d out of range (have %d)", device_ordinal, n);
+  if (e.inited && e.device == device_ordinal) return 0;
+  GOCTR_HIP(hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  GOCTR_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+  GOCTR_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+              "goctr_init: device is %s; this library is built for gfx950 (MI355X) only", prop.gcnArchName);
+  e.compute_units = prop.multiProcessorCount;
+  if (!e.stream) GOCTR_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+  e.device = device_ordinal;
+  e.inited = true;
+  return 0;
+}
+
+int goctr_sync(void) {
+  if (require_engine()) return -1;
+  GOCTR_HIP(hipStreamSynchronize(engine().stream));
+  GOCTR_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+int goctr_device_info(char* name, size_t cap, int* cus, int64_t* hbm) {
+  if (require_engine()) return -1;
+  hipDeviceProp_t prop;
+  GOCTR_HIP(hipGetDeviceProperties(&prop, engine().device));
+  if (name && cap) snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
+  if (cus) *cus = prop.multiProcessorCount;
+  if (hbm) *hbm = (int64_t)prop.totalGlobalMem;
+  return 0;
+}
+
+int goctr_prof_enable(int on) {
+  if (require_engine()) return -1;
+  prof_flush();
+  engine().prof = on != 0;
+  return 0;
+}
+int goctr_prof_reset(void) {
+  if (require_engine()) return -1;
+  prof_flush();
+  for (int i = 0; i < GOCTR_K_COUNT; ++i) { engine().prof_ms[i] = 0; engine().prof_n[i] = 0; }
+  return 0;
+}
+int goctr_prof_get(int id, double* ms, int64_t* n) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(id >= 0 && id < GOCTR_K_COUNT, "goctr_prof_get: bad kernel id %d", id);
+  prof_flush();
+  if (ms) *ms = engine().prof_ms[id];
+  if (n) *n = engine().prof_n[id];
+  return 0;
+}
+const char* goctr_prof_name(int id) { return id >= 0 && id < GOCTR_K_COUNT ? kNames[id] : "?"; }
+
+}  // extern "C"

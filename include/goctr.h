@@ -1,0 +1,241 @@
+/*
+ * goctr.h -- C-ABI of libgoctr_hip.so, the MI355X (gfx950) engine behind go-ctr's hot path.
+ *
+ * This is the drop-in boundary: plain C, opaque handles, plain pointers and sizes, no torch / C++
+ * types.  Every entry point names the reference (auxten/go-ctr, Go) interface it replaces
+ * (file:line relative to the reference repo); INTEGRATION.md shows the cgo stub a go-ctr maintainer
+ * adds on the Go side.  Conventions:
+ *   - every function returns int status, 0 = ok; goctr_last_error() returns a thread-local string;
+ *   - no callback into the host language, no host pointer retained after a call returns;
+ *   - host buffers are row-major, float32 for DIN / YouTube (gorgonia tensor.Float32,
+ *     model/model.go:14), float64 for the sklearn-port MLP and item2vec (as in the reference);
+ *   - one handle is used by one thread at a time (an internal mutex serialises per handle);
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails loudly.
+ */
+#ifndef GOCTR_H
+#define GOCTR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct goctr_model goctr_model;     /* DIN / YouTube weights + Adam state on the device   */
+typedef struct goctr_emb goctr_emb;         /* item-embedding table [V,D] f32 resident in HBM      */
+typedef struct goctr_dataset goctr_dataset; /* training / scoring rows resident in HBM             */
+typedef struct goctr_mlp goctr_mlp;         /* sklearn-port MLP (float64)                          */
+typedef struct goctr_w2v goctr_w2v;         /* item2vec state (param, HS node vectors, paths)      */
+
+/* ---------------------------------------------------------------- runtime ---------------- */
+/* Binds the calling process to one GPU (one process per GPU) and creates the engine's streams. */
+int goctr_init(int device_ordinal);
+int goctr_device_count(int* n);
+/* blocks until all work queued by this library has finished (hipDeviceSynchronize) */
+int goctr_sync(void);
+const char* goctr_last_error(void);
+const char* goctr_version(void);
+/* name / CU count / HBM bytes of the bound device */
+int goctr_device_info(char* name, size_t name_cap, int* compute_units, int64_t* hbm_bytes);
+
+/* Data-parallel communicator (RCCL over xGMI).  rank 0 calls goctr_comm_unique_id, the 128 bytes are
+ * distributed by the host launcher (any side channel), every rank calls goctr_comm_init.
+ * No reference counterpart: go-ctr is single-process. */
+int goctr_comm_unique_id(uint8_t id[128]);
+int goctr_comm_init(int rank, int world, const uint8_t id[128]);
+int goctr_comm_world(int* rank, int* world);
+/* sum-all-reduce of a host double (used for timing / cost aggregation); world==1 => identity */
+int goctr_comm_allreduce_f64(double* v, int n);
+int goctr_comm_destroy(void);
+
+/* ---------------------------------------------------------------- DIN / YouTube ----------- */
+/* model kinds: model/din/din.go:21 (DinNet) and model/youtube/dnn.go:18 (YoutubeDnn) */
+enum { GOCTR_DIN = 0, GOCTR_YOUTUBE = 1 };
+/* attention activation: cosine = din.go:231-237 (shipping), euclid = din.go:230 (commented-out variant) */
+enum { GOCTR_ATT_COSINE = 0, GOCTR_ATT_EUCLID = 1 };
+/* learnable tensors, in Learnable() order (din.go:161-169): mlp0, mlp1, mlp2, att0 */
+enum { GOCTR_W0 = 0, GOCTR_W1 = 1, GOCTR_W2 = 2, GOCTR_ATT0 = 3 };
+
+typedef struct {
+  int kind;       /* GOCTR_DIN | GOCTR_YOUTUBE */
+  int att;        /* GOCTR_ATT_* (DIN only) */
+  int U, T, D, C; /* uProfileDim, uBehaviorSize, uBehaviorDim (= iFeatureDim), cFeatureDim
+                     -- the arguments of din.NewDinNet (din.go:171-175) */
+  int H1, H2;     /* hidden widths; 200 / 80 in the reference (din.go:17-18) */
+} goctr_ctr_cfg;
+
+/* replaces din.NewDinNet / youtube.NewYoutubeDnn (din.go:171, dnn.go:119).  Weights start at zero
+ * with att0 = 1; the host sets the N(0,1) init (din.go:187-191) or JSON weights through
+ * goctr_model_set_weights (NewDinNetFromJson, din.go:82).  Fails if kind==DIN and dims mismatch
+ * like din.go:176-178. */
+int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out);
+void goctr_model_destroy(goctr_model* m);
+/* flat row-major float32 arrays exactly as in the dinModel JSON (din.go:41-52): W0 [I,H1],
+ * W1 [H1,H2], W2 [H2,1], att0 [1,T];  replaces Marshal / NewDinNetFromJson (din.go:62,82) */
+int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, size_t n);
+int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n);
+/* resets the Adam moments and the step counter (a fresh gorgonia AdamSolver, model.go:88) */
+int goctr_model_reset_optimizer(goctr_model* m);
+
+typedef struct {
+  int batch;       /* batchSize  (model.go:28) */
+  int epochs;      /* epochs     (model.go:28) */
+  int early_stop;  /* earlyStop  (model.go:28; 0 = off) */
+  double lr, l2;   /* 0.01, 1e-4 (model.go:88) */
+  double beta1, beta2, eps;        /* gorgonia Adam defaults .9 .999 1e-8 */
+  int adam_div_by_batch;           /* WithBatchSize(B): 1 (model.go:88) */
+  int adam_l2_before_batch_div;    /* gorgonia order, 1 */
+  int dropout_mode;                /* 0 off, 1 explicit masks (single-step entry only), 2 counter-hash */
+  float p0, p1;                    /* 0.005/0.005 DIN (din.go:204-205), 0.003/0.003 YouTube (dnn.go:136-137) */
+  uint32_t seed;
+} goctr_train_cfg;
+void goctr_train_cfg_default(goctr_train_cfg* c); /* the reference's literals */
+
+/* --- dense-X (drop-in / parity) mode: the TrainSample layout of recommend/rcmd.go:56-63,132-137.
+ * ranges = {UserProfileRange, UserBehaviorRange, ItemFeatureRange, CtxFeatureRange} as 8 ints. */
+
+/* replaces model.Train (model/model.go:27-213) as called from dinImpl.Fit
+ * (example/movielens/dinimpl.go:62-67): uploads X,Y once, runs the whole epoch loop on the device
+ * (zero-padded last batch, Adam per batch, cost of the LAST batch per epoch, early stop).
+ * epoch_costs [epochs] and *epochs_run are outputs. */
+int goctr_train_dense(goctr_model* m, const float* X, const float* Y, int64_t rows, int xcols,
+                      const int ranges[8], const goctr_train_cfg* cfg, float* epoch_costs, int* epochs_run);
+/* replaces model.InitForwardOnlyVm + model.Predict (model.go:215-352) as called from
+ * dinImpl.Predict (dinimpl.go:32-42): batches of `batch`, zero padding, first end-start outputs
+ * kept; no dropout (the JSON round trip of dinimpl.go:73-89 drops d0/d1). */
+int goctr_predict_dense(goctr_model* m, const float* X, int64_t rows, int xcols, const int ranges[8],
+                        int batch, float* y_out);
+/* One instrumented step WITHOUT the parameter update, for parity tests: forward + BCE
+ * (model/cost.go:9-17) + backward over one batch of B rows of which the first `valid` come from
+ * X (the rest are zero rows, model.go:357-371).  m0/m1: explicit dropout masks for dropout_mode 1
+ * ([B,H1], [B,H2]) or NULL.  Any output pointer may be NULL. */
+int goctr_loss_grad_dense(goctr_model* m, const float* X, const float* Y, int valid, int B, int xcols,
+                          const int ranges[8], const goctr_train_cfg* cfg, uint32_t step,
+                          const float* m0, const float* m1,
+                          float* cost, float* gW0, float* gW1, float* gW2, float* gatt0, float* y_out);
+
+/* --- id (performance) mode: the embedding table and the sample keys live in HBM; replaces the
+ * host-side string-map gather of recommend.GetSampleVector (rcmd.go:462-536). */
+int goctr_emb_create(int64_t V, int D, const float* host_rows /* [V,D] or NULL = zeros */, goctr_emb** out);
+int goctr_emb_set_rows(goctr_emb* e, int64_t first, int64_t n, const float* host_rows);
+void goctr_emb_destroy(goctr_emb* e);
+/* standalone gather = the row-assembly half of GetSampleVector (rcmd.go:497-533): out row =
+ * [user | emb[ub_ids[0..T)] | emb[item] | ctx]; id < 0 or >= V => zero row.  Device-resident
+ * inputs come from a dataset handle; this host-buffer form is for bit-exact parity checks. */
+int goctr_gather_rows(goctr_emb* e, const int32_t* ub_ids, const int32_t* item_ids, const float* user_feat,
+                      int U, const float* ctx_feat, int C, int T, int64_t rows, float* X_out);
+
+/* device-resident sample sets (uploaded once; reused by train_steps / predict_dataset) */
+int goctr_dataset_create_dense(const float* X, const float* Y /* may be NULL */, int64_t rows, int xcols,
+                               const int ranges[8], goctr_dataset** out);
+int goctr_dataset_create_ids(const int32_t* ub_ids /*[rows,T]*/, const int32_t* item_ids /*[rows]*/,
+                             const float* user_feat /*[rows,U]*/, int U, const float* ctx_feat /*[rows,C]*/,
+                             int C, int T, const float* Y /* may be NULL */, int64_t rows, goctr_dataset** out);
+void goctr_dataset_destroy(goctr_dataset* d);
+
+/* model.Train's epoch loop over a resident dataset (emb == NULL for dense datasets). */
+int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,
+                        float* epoch_costs, int* epochs_run);
+/* exactly n_steps mini-batch steps (forward, backward, all-reduce when a communicator exists,
+ * Adam), cycling through the dataset from batch index first_batch; asynchronous -- returns after
+ * queueing, call goctr_sync().  costs_dev_to_host may be NULL; otherwise receives n_steps costs
+ * (forces a sync).  This is the unit bench.py times. */
+int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,
+                      int64_t first_batch, int n_steps, float* costs);
+/* model.Predict over a resident dataset; y_out host [rows] */
+int goctr_predict_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, float* y_out);
+/* scores n_batches batches (cycling) and leaves the scores on the device; async. bench QPS unit. */
+int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, int64_t first_batch,
+                        int n_batches);
+
+/* --- per-kernel timing (hipEvent, on the engine's stream) for bench.py's roofline object.
+ * While enabled the step runs eagerly (no hipGraph) with an event pair around every launch. */
+enum { GOCTR_K_ATTN_FWD = 0, GOCTR_K_GEMM_FWD0, GOCTR_K_GEMM_FWD1, GOCTR_K_GEMM_OUT, GOCTR_K_BWD_DZ1,
+       GOCTR_K_BWD_DZ0, GOCTR_K_BWD_DP, GOCTR_K_ATTN_BWD, GOCTR_K_DW0, GOCTR_K_DW1, GOCTR_K_DW2,
+       GOCTR_K_REDUCE, GOCTR_K_ALLREDUCE, GOCTR_K_ADAM, GOCTR_K_COUNT };
+int goctr_prof_enable(int on);
+int goctr_prof_reset(void);
+/* total milliseconds and launch count per kernel family since the last reset */
+int goctr_prof_get(int kernel_id, double* total_ms, int64_t* launches);
+const char* goctr_prof_name(int kernel_id);
+
+/* ---------------------------------------------------------------- sklearn-port MLP (f64) --- */
+/* replaces nn.NewMLPClassifier + Fit + Predict (nn/neural_network/multilayer_perceptron.go:81-125,
+ * basemlp64.go) behind mlp.SimpleMlpFitWrap / SimpleMlpPredWrap (model/mlp/mlp.go:15-65). */
+enum { GOCTR_ACT_IDENTITY = 0, GOCTR_ACT_LOGISTIC = 1, GOCTR_ACT_TANH = 2, GOCTR_ACT_RELU = 3 };
+enum { GOCTR_SOLVER_SGD = 0, GOCTR_SOLVER_ADAM = 1 };
+typedef struct {
+  int n_layers;          /* len(layerUnits): input, hidden..., output */
+  int units[8];
+  int activation;        /* hidden activation (basemlp64.go:79-117) */
+  int solver;            /* sgd | adam (basemlp64.go:733-752) */
+  double alpha;          /* L2 */
+  double lr_init, beta1, beta2, eps, momentum;
+  int nesterov;
+  int batch_normalize;   /* max-abs scaling (basemlp64.go:277-308) */
+  double weight_decay;   /* basemlp64.go:342-346 */
+  int batch, max_iter, n_iter_no_change;
+  double tol;
+} goctr_mlp_cfg;
+void goctr_mlp_cfg_default(goctr_mlp_cfg* c); /* NewBaseMultilayerPerceptron64 (basemlp64.go:228-254) */
+int goctr_mlp_create(const goctr_mlp_cfg* cfg, goctr_mlp** out);
+void goctr_mlp_destroy(goctr_mlp* p);
+size_t goctr_mlp_nparams(const goctr_mlp* p);
+/* packed parameters [ b_i | W_i ]... (basemlp64.go:432-463) */
+int goctr_mlp_set_params(goctr_mlp* p, const double* theta, size_t n);
+int goctr_mlp_get_params(goctr_mlp* p, double* theta, size_t n);
+/* backprop (basemlp64.go:340-406) on one batch, no update: loss + packed grads (parity entry) */
+int goctr_mlp_loss_grad(goctr_mlp* p, const double* X, const double* Y, int n, double* loss, double* grads);
+/* fitStochastic (basemlp64.go:729-857) from float32 rows like SimpleMlpFitWrap.Fit widens them
+ * (mlp.go:46-59).  perm: [max_iter][rows] row order per epoch (the host owns the shuffle RNG) or
+ * NULL = given order.  rows must be a multiple of batch.  loss_curve [max_iter]. */
+int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, const int32_t* perm,
+                  double* loss_curve, int* iters_run);
+/* exactly n_steps updates cycling over resident rows (async) -- bench unit */
+int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows);
+int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps);
+/* SimpleMlpPredWrap.Predict (mlp.go:15-39): f32 in, probabilities f32 out */
+int goctr_mlp_predict(goctr_mlp* p, const float* X, int64_t rows, float* y_out);
+
+/* ---------------------------------------------------------------- item2vec (f64) ----------- */
+/* replaces embedding.TrainEmbedding (feature/embedding/wordemb.go:9-32) -> word2vec.Train
+ * (model/word2vec/word2vec.go:90-243).  The host keeps the dictionary (string -> id, counts);
+ * the device owns param [V,dim], the Huffman inner-node vectors [V-1,dim] / NS ctx matrix and the
+ * root-to-leaf paths. */
+typedef struct {
+  int dim, window;       /* wordemb.go:9 arguments */
+  int optimizer;         /* 0 = hierarchical softmax (wordemb.go:13), 1 = negative sampling */
+  int model;             /* 0 = skip-gram (wordemb.go:12) */
+  int neg_samples;       /* options.go:51 */
+  double init_lr, min_lr;     /* options.go:42,49 */
+  int64_t update_lr_batch;    /* options.go:55 */
+  int max_depth;              /* options.go:46 */
+  int deterministic;     /* 1: single stream, bit-exact vs the oracle; 0: Hogwild over `streams` slices */
+  int streams;           /* Hogwild slices (the reference uses runtime.NumCPU(), options.go:41) */
+} goctr_w2v_cfg;
+void goctr_w2v_cfg_default(goctr_w2v_cfg* c);
+/* counts [V] = dictionary cfs (dictionary.go:70-81); builds the Huffman tree on the host with the
+ * reference's tie-breaking (huffman.go:23-57) and uploads the paths */
+int goctr_w2v_create(const goctr_w2v_cfg* cfg, int64_t V, const int64_t* counts, goctr_w2v** out);
+void goctr_w2v_destroy(goctr_w2v* w);
+/* word2vec.go:103-111 init is host-side RNG: inject it here */
+int goctr_w2v_set_param(goctr_w2v* w, const double* param /*[V,dim]*/);
+int goctr_w2v_set_aux(goctr_w2v* w, const double* aux /* HS: [V-1,dim]; NS: [V,dim] */);
+int goctr_w2v_get_param(goctr_w2v* w, double* param);
+int goctr_w2v_get_aux(goctr_w2v* w, double* aux);
+int goctr_w2v_get_paths(goctr_w2v* w, int64_t* path_off /*[V+1]*/, int32_t* nodes, uint8_t* codes, int64_t cap,
+                        int64_t* total);
+/* one iteration over doc (word2vec.go:151-175): keep_mask = injected sub-sampling trials
+ * (subsample.go:45-52) or NULL; corpus_len = unfiltered corpus length (Q17).  lr in/out. */
+int goctr_w2v_train(goctr_w2v* w, const int32_t* doc, int64_t n_words, int64_t corpus_len,
+                    const uint8_t* keep_mask, double* lr);
+/* same over a doc already resident in HBM (bench unit): upload once, then train passes */
+int goctr_w2v_upload_doc(goctr_w2v* w, const int32_t* doc, int64_t n_words, const uint8_t* keep_mask);
+int goctr_w2v_train_resident(goctr_w2v* w, int64_t corpus_len, double* lr);
+/* GenEmbeddingMap32 (word2vec.go:298-324): param rows narrowed to float32 */
+int goctr_w2v_export_f32(goctr_w2v* w, float* out /*[V,dim]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOCTR_H */
