@@ -67,7 +67,7 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-int tn_rows_per_wg() { return round_up(env_int("GOCTR_TN_ROWS", 128), 16); }
+int tn_rows_per_wg() { return round_up(env_int("GOCTR_TN_ROWS", 64), 32); }
 
 int ensure_workspace(goctr_model* m, int B) {
   if (m->wsB >= B && m->tnS > 0) return 0;
@@ -89,7 +89,7 @@ int ensure_workspace(goctr_model* m, int B) {
   if (m->slabs0.alloc((size_t)S * m->Ip * m->H1p)) return -1;
   if (m->slabs1.alloc((size_t)S * m->H1p * m->H2p)) return -1;
   if (m->slabs2.alloc((size_t)S * m->H2p * 16)) return -1;
-  m->attp_blocks = (int)std::min<int64_t>(cdiv(B, 4), 256);
+  m->attp_blocks = (int)cdiv(B, ATTN_BWD_WAVES);
   if (m->attp.alloc((size_t)m->attp_blocks * m->Tp)) return -1;
   m->wsB = B;
   m->graph.destroy();
@@ -111,40 +111,89 @@ RowSource make_source(const goctr_dataset* d, const goctr_emb* e) {
   return s;
 }
 
+// dynamic LDS above 64 KiB needs an explicit opt-in per kernel
+template <class K>
+int allow_big_lds(K kernel) {
+  GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(160 * 1024)));
+  return 0;
+}
+
 template <class Epi>
 int launch_nn(int kid, const float* A, int lda, const float* Bm, int ldb, int M, int Kp, int Np, Epi epi) {
   const int NT = Np / 16;
-  const int WN = NT <= GEMM_NN_NTW ? 1 : (NT <= 2 * GEMM_NN_NTW ? 2 : 4);
+  // wave grid: prefer >= 1 workgroup per CU (M/32 rows each) when the columns can be split
+  int WN = NT >= 2 ? 2 : 1;
+  while (WN < 4 && (int)cdiv(NT, WN) > GEMM_NN_NTW) WN *= 2;
+  int ntw = (int)cdiv(NT, WN);
+  if (ntw > GEMM_NN_NTW) ntw = GEMM_NN_NTW;   // more column blocks in grid.y
+  ntw = ntw <= 1 ? 1 : (ntw <= 3 ? 3 : (ntw <= 4 ? 4 : 7));  // instantiated tile counts
   const int WM = 4 / WN;
-  dim3 grid((unsigned)cdiv(M, 16 * WM), (unsigned)cdiv(NT, WN * GEMM_NN_NTW));
-  const int ncols_blk = std::min(NT, WN * GEMM_NN_NTW) * 16;
+  dim3 grid((unsigned)cdiv(M, 16 * WM), (unsigned)cdiv(NT, WN * ntw));
+  const int ncols_blk = std::min(NT, WN * ntw) * 16;
+  (void)ncols_blk;
+  const int ncols_alloc = WN * ntw * 16;
+  const int KPH = gemm_nn_phase_rows<float>(Kp, ncols_alloc);
+  const size_t lds = gemm_nn_lds_bytes<float>(KPH, ncols_alloc);
+  hipStream_t st = engine().stream;
   ProfScope ps(kid);
-  hipLaunchKernelGGL((gemm_nn_kernel<float, Epi>), grid, dim3(256), gemm_nn_lds_bytes<float>(ncols_blk),
-                     engine().stream, A, lda, Bm, ldb, M, Kp, Np, WN, epi);
+#define GOCTR_NN(N) hipLaunchKernelGGL((gemm_nn_kernel<float, Epi, N>), grid, dim3(256), lds, st, A, lda, Bm, ldb, M, Kp, Np, WN, KPH, epi)
+  switch (ntw) {
+    case 1: GOCTR_NN(1); break;
+    case 3: GOCTR_NN(3); break;
+    case 4: GOCTR_NN(4); break;
+    default: GOCTR_NN(7); break;
+  }
+#undef GOCTR_NN
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int KTW, int NTW, int CH>
+int launch_tn_cfg(const float* A, int lda, int KT, const float* Dm, int ldd, int NT, int M, int rows_per_wg,
+                  int WK, int WN, float* slabs, size_t slab_stride) {
+  const int S = (int)cdiv(M, rows_per_wg);
+  const int nthreads = 64 * WK * WN;
+  // staging registers must cover one chunk
+  GOCTR_CHECK((size_t)CH * (WK * KTW * 16 / 4) <= (size_t)GEMM_TN_MAXVA * nthreads &&
+              (size_t)CH * (WN * NTW * 16 / 4) <= (size_t)GEMM_TN_MAXVD * nthreads,
+              "gemm_tn: chunk does not fit the staging registers (WK=%d WN=%d)", WK, WN);
+  dim3 grid(S, (unsigned)cdiv(KT, WK * KTW), (unsigned)cdiv(NT, WN * NTW));
+  hipLaunchKernelGGL((gemm_tn_kernel<float, KTW, NTW, CH>), grid, dim3(nthreads),
+                     gemm_tn_lds_bytes<float>(WK * KTW, WN * NTW, CH), engine().stream, A, lda, KT, Dm, ldd, NT, M,
+                     rows_per_wg, WK, WN, slabs, slab_stride);
   GOCTR_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_tn(int kid, const float* A, int lda, int KT, const float* Dm, int ldd, int NT, int M, int rows_per_wg,
               float* slabs, size_t slab_stride) {
-  const int S = (int)cdiv(M, rows_per_wg);
   ProfScope ps(kid);
-  if (NT <= 5) {
-    constexpr int KTW = 4, NTW = 5;
-    const int WK = std::min(4, (int)cdiv(KT, KTW)), WN = 1;
-    dim3 grid(S, (unsigned)cdiv(KT, WK * KTW), (unsigned)cdiv(NT, WN * NTW));
-    hipLaunchKernelGGL((gemm_tn_kernel<float, KTW, NTW>), grid, dim3(64 * WK * WN),
-                       gemm_tn_lds_bytes<float>(WK * KTW, WN * NTW), engine().stream, A, lda, KT, Dm, ldd, NT, M,
-                       rows_per_wg, WK, WN, slabs, slab_stride);
-  } else {
-    constexpr int KTW = 3, NTW = 4;
-    const int WK = std::min(4, (int)cdiv(KT, KTW)), WN = std::min(4, (int)cdiv(NT, NTW));
-    dim3 grid(S, (unsigned)cdiv(KT, WK * KTW), (unsigned)cdiv(NT, WN * NTW));
-    hipLaunchKernelGGL((gemm_tn_kernel<float, KTW, NTW>), grid, dim3(64 * WK * WN),
-                       gemm_tn_lds_bytes<float>(WK * KTW, WN * NTW), engine().stream, A, lda, KT, Dm, ldd, NT, M,
-                       rows_per_wg, WK, WN, slabs, slab_stride);
+  if (NT <= 3) {
+    // narrow D (dz2: 1 tile): k-tiles across up to 4 waves
+    const int WK = std::min(4, (int)cdiv(KT, 4));
+    return launch_tn_cfg<4, 3, 16>(A, lda, KT, Dm, ldd, NT, M, rows_per_wg, WK, 1, slabs, slab_stride);
   }
-  GOCTR_HIP(hipGetLastError());
+  if (NT <= 6) {
+    // dW1-like (13 x 5 tiles): 4 x 2 waves of 4 x 3 tiles
+    const int WK = std::min(4, (int)cdiv(KT, 4)), WN = std::min(2, (int)cdiv(NT, 3));
+    return launch_tn_cfg<4, 3, 32>(A, lda, KT, Dm, ldd, NT, M, rows_per_wg, WK, WN, slabs, slab_stride);
+  }
+  // dW0-like (9 x 13 tiles): k-blocks of 3 tiles in grid.y, 4 waves of 3 x 4 tiles across N
+  const int WN = std::min(4, (int)cdiv(NT, 4));
+  return launch_tn_cfg<3, 4, 32>(A, lda, KT, Dm, ldd, NT, M, rows_per_wg, 1, WN, slabs, slab_stride);
+}
+
+// opt every GEMM instantiation into > 64 KiB of dynamic LDS up front (never inside a stream capture)
+int init_kernel_attrs() {
+  static bool done = false;
+  if (done) return 0;
+#define GOCTR_NN_ATTR(E) (allow_big_lds(gemm_nn_kernel<float, E, 1>) || allow_big_lds(gemm_nn_kernel<float, E, 3>) || \
+                          allow_big_lds(gemm_nn_kernel<float, E, 4>) || allow_big_lds(gemm_nn_kernel<float, E, 7>))
+  if (GOCTR_NN_ATTR(EpiSigDrop) || GOCTR_NN_ATTR(EpiOut) || GOCTR_NN_ATTR(EpiDSig) || GOCTR_NN_ATTR(EpiStore) ||
+      allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
+      allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>)) return -1;
+  done = true;
   return 0;
 }
 
@@ -176,9 +225,9 @@ int launch_attn_fwd(const AttnArgs& a) {
 
 int launch_attn_bwd(const AttnBwdArgs& a, int blocks) {
   ProfScope ps(GOCTR_K_ATTN_BWD);
-  dim3 grid((unsigned)blocks), blk(256);
+  dim3 grid((unsigned)blocks), blk(64 * ATTN_BWD_WAVES);
   hipStream_t st = engine().stream;
-  const size_t lds = sizeof(float) * 4 * a.Tp;
+  const size_t lds = sizeof(float) * ATTN_BWD_WAVES * a.Tp;
   const bool vec4 = a.src.id_mode && a.D % 4 == 0;
   const int groups = vec4 ? a.D / 4 : a.D;
 #define GOCTR_ATTN_BWD(V, L) hipLaunchKernelGGL((attn_bwd_kernel<V, L>), grid, blk, lds, st, a)
@@ -257,7 +306,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     AttnBwdArgs ab{};
     ab.src = src; ab.st = st; ab.B = B; ab.T = c.T; ab.D = c.D; ab.Dp = m->Dp; ab.Tp = m->Tp;
     ab.dp = m->dp.p; ab.gate = m->gate.p; ab.wgt = m->wgt.p; ab.partial = m->attp.p;
-    if (launch_attn_bwd(ab, m->attp_blocks)) return -1;
+    if (launch_attn_bwd(ab, (int)cdiv(B, ATTN_BWD_WAVES))) return -1;
   }
   const int rpw = tn_rows_per_wg();
   const int S = (int)cdiv(B, rpw);
@@ -273,13 +322,13 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   ra.seg[2] = {m->slabs2.p, S, (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
   ra.nseg = 3;
   if (c.kind == GOCTR_DIN) {
-    ra.seg[3] = {m->attp.p, m->attp_blocks, (unsigned long long)m->Tp, m->offa, m->Tp};
+    ra.seg[3] = {m->attp.p, (int)cdiv(B, ATTN_BWD_WAVES), (unsigned long long)m->Tp, m->offa, m->Tp};
     ra.nseg = 4;
   }
   ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st.p; ra.advance = advance ? 1 : 0;
   {
     ProfScope ps(GOCTR_K_REDUCE);
-    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)cdiv(m->nflat, 256) + 1), dim3(256), 0, e.stream, ra);
+    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)cdiv((int64_t)m->nflat * 2, 256) + 1), dim3(256), 0, e.stream, ra);
     GOCTR_HIP(hipGetLastError());
   }
   return 0;
@@ -515,6 +564,7 @@ int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
   GOCTR_CHECK(cfg->kind == GOCTR_DIN || cfg->kind == GOCTR_YOUTUBE, "unknown model kind %d", cfg->kind);
   GOCTR_CHECK(cfg->U >= 0 && cfg->T > 0 && cfg->D > 0 && cfg->C >= 0 && cfg->H1 > 0 && cfg->H2 > 0, "bad model dims");
   GOCTR_CHECK(cfg->D <= 256, "embedding dim %d > 256 not supported", cfg->D);
+  if (init_kernel_attrs()) return -1;
   std::unique_ptr<goctr_model> m(new goctr_model);
   m->cfg = *cfg;
   m->I = cfg->U + 2 * cfg->D + cfg->C;

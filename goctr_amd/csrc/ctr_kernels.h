@@ -26,10 +26,12 @@ constexpr int COST_RING = 1 << 16;
 
 // ---------------------------------------------------------------- scalar helpers
 // gorgonia's float32 sigmoid clamps at -88 / +15 [from memory, SURVEY App. B]
+// Hidden units and attention gates: v_exp_f32 / v_rcp_f32 based (|error| < 3e-7 absolute on
+// [-88, 15]), two transcendental issues instead of the ~25-instruction IEEE expf + divide.
 __device__ __forceinline__ float sigm_hidden(float x) {
   if (x < -88.f) return 0.f;
   if (x > 15.f) return 1.f;
-  return 1.0f / (1.0f + expf(-x));
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 // The output unit feeds log(1-p) in the BCE, which is ill-conditioned near saturation: evaluate it
 // like the reference does (float64 exp, rounded once to float32).
@@ -95,12 +97,32 @@ __device__ __forceinline__ float cross_row_sum(float v) {
   return v;
 }
 
+// load VEC consecutive embedding lanes of one row (all-zero when the row pointer is null)
+template <int VEC>
+__device__ __forceinline__ void load_row(const float* row, int d0, int D, float x[VEC]) {
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) x[e] = 0.f;
+  if (row && d0 < D) {
+    if (VEC == 4) {
+      float4 t4 = *reinterpret_cast<const float4*>(row + d0);
+      x[0] = t4.x; x[1] = t4.y; x[2] = t4.z; x[3] = t4.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x[e] = d0 + e < D ? row[d0 + e] : 0.f;
+    }
+  }
+}
+
 // One wavefront per sample.  A wavefront covers RPP = 64/LPR behaviour rows per pass, LPR lanes per
 // row, VEC consecutive embedding lanes per lane (VEC=4 => one 16-byte load per lane, a 64-byte row
-// of a D=16 table is fetched by 4 adjacent lanes: fully coalesced 64 B segments).
+// of a D=16 table is fetched by 4 adjacent lanes: fully coalesced 64 B segments).  The ids of up to
+// 64 behaviour slots are fetched with ONE coalesced load and handed to the row lanes by shuffle, then
+// the row loads of NPB passes are issued back to back before any arithmetic, so the dependent chain
+// is state -> ids -> rows (3 memory latencies) regardless of T.
 template <int VEC, int LPR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   constexpr int RPP = 64 / LPR;
+  constexpr int NPB = LPR < 4 ? LPR : 4;  // passes per block; NPB*RPP <= 64
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x * 4 + wave;
   if (b >= a.B) return;
@@ -112,7 +134,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int D = a.D, T = a.T;
 
   // candidate item embedding v
-  float vv[VEC];
   const float* vrow = nullptr;
   if (valid) {
     if (s.id_mode) {
@@ -122,17 +143,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       vrow = s.X + gr * (long long)s.xcols + s.r_v;
     }
   }
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) vv[e] = 0.f;
-  if (vrow && d0 < D) {
-    if (VEC == 4) {
-      float4 t4 = *reinterpret_cast<const float4*>(vrow + d0);
-      vv[0] = t4.x; vv[1] = t4.y; vv[2] = t4.z; vv[3] = t4.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) vv[e] = d0 + e < D ? vrow[d0 + e] : 0.f;
-    }
-  }
+  float vv[VEC];
+  load_row<VEC>(vrow, d0, D, vv);
   float syy = 0.f;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) syy += vv[e] * vv[e];
@@ -142,54 +154,51 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int e = 0; e < VEC; ++e) psum[e] = 0.f;
 
-  for (int t0 = 0; t0 < T; t0 += RPP) {
-    const int t = t0 + rl;
-    float x[VEC];
+  for (int tb = 0; tb < T; tb += NPB * RPP) {
+    int myid = -1;
+    if (s.id_mode && valid && lane < NPB * RPP && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
+    float x[NPB][VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) x[e] = 0.f;
-    const float* xrow = nullptr;
-    if (valid && t < T) {
+    for (int p = 0; p < NPB; ++p) {
+      const int t = tb + p * RPP + rl;
+      const float* xrow = nullptr;
       if (s.id_mode) {
-        int id = s.ub_ids[gr * T + t];
-        if (id >= 0 && id < s.V) xrow = s.emb + (long long)id * D;
-      } else {
+        const int id = __shfl(myid, p * RPP + rl, 64);
+        if (t < T && id >= 0 && id < s.V) xrow = s.emb + (long long)id * D;
+      } else if (valid && t < T) {
         xrow = s.X + gr * (long long)s.xcols + s.r_ub + t * D;
       }
+      load_row<VEC>(xrow, d0, D, x[p]);
     }
-    if (xrow && d0 < D) {
-      if (VEC == 4) {
-        float4 t4 = *reinterpret_cast<const float4*>(xrow + d0);
-        x[0] = t4.x; x[1] = t4.y; x[2] = t4.z; x[3] = t4.w;
-      } else {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) x[e] = d0 + e < D ? xrow[d0 + e] : 0.f;
+    for (int p = 0; p < NPB; ++p) {
+      const int t = tb + p * RPP + rl;
+      float g = 1.0f, wv = 0.f;
+      if (a.kind == GOCTR_DIN) {
+        if (a.att == GOCTR_ATT_COSINE) {
+          float sxx = 0.f, sxy = 0.f;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { sxx += x[p][e] * x[p][e]; sxy += x[p][e] * vv[e]; }
+          sxx = group_sum<LPR>(sxx);
+          sxy = group_sum<LPR>(sxy);
+          const float cosv = sxy / (sqrtf(sxx) * yn + 1e-8f);
+          wv = (cosv + 1.0f) / 2.0f;
+        } else {
+          float ss = 0.f;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { float df = x[p][e] - vv[e]; ss += (d0 + e < D) ? df * df : 0.f; }
+          ss = group_sum<LPR>(ss);
+          wv = 1.0f - sqrtf(ss);
+        }
+        g = sigm_hidden(wv * (t < T ? a.att0[t] : 0.f));
       }
-    }
-    float g = 1.0f, wv = 0.f;
-    if (a.kind == GOCTR_DIN) {
-      if (a.att == GOCTR_ATT_COSINE) {
-        float sxx = 0.f, sxy = 0.f;
+      if (t < T) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { sxx += x[e] * x[e]; sxy += x[e] * vv[e]; }
-        sxx = group_sum<LPR>(sxx);
-        sxy = group_sum<LPR>(sxy);
-        float cosv = sxy / (sqrtf(sxx) * yn + 1e-8f);
-        wv = (cosv + 1.0f) / 2.0f;
-      } else {
-        float ss = 0.f;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) { float df = x[e] - vv[e]; ss += (d0 + e < D) ? df * df : 0.f; }
-        ss = group_sum<LPR>(ss);
-        wv = 1.0f - sqrtf(ss);
-      }
-      g = sigm_hidden(wv * (t < T ? a.att0[t] : 0.f));
-    }
-    if (t < T) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) psum[e] += g * x[e];
-      if (dl == 0) {
-        a.gate[(size_t)b * T + t] = g;
-        a.wgt[(size_t)b * T + t] = wv;
+        for (int e = 0; e < VEC; ++e) psum[e] += g * x[p][e];
+        if (dl == 0) {
+          a.gate[(size_t)b * T + t] = g;
+          a.wgt[(size_t)b * T + t] = wv;
+        }
       }
     }
   }
@@ -225,61 +234,66 @@ struct AttnBwdArgs {
   float* partial;     // [gridDim.x, Tp]
 };
 
+constexpr int ATTN_BWD_WAVES = 16;  // samples per workgroup (one wavefront each)
+
 // datt0[t] = sum_b dg[b,t] * g(1-g) * w ; dg[b,t] = (1/T) sum_d dp[b,d] * x[b,t,d]   
+// 16 wavefronts = 16 samples per workgroup, all row gathers in flight at once; per-sample terms land
+// in the wavefront's own LDS row (no atomics), rows are summed in a fixed order => deterministic.
 template <int VEC, int LPR>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
+__global__ __launch_bounds__(64 * ATTN_BWD_WAVES) void attn_bwd_kernel(AttnBwdArgs a) {
   constexpr int RPP = 64 / LPR;
-  extern __shared__ float att_acc[];  // [4][Tp]
+  constexpr int NPB = LPR < 4 ? LPR : 4;
+  extern __shared__ float att_acc[];  // [ATTN_BWD_WAVES][Tp]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const RowSource& s = a.src;
   const int dl = lane % LPR, rl = lane / LPR, d0 = dl * VEC;
   const int D = a.D, T = a.T;
-  for (int j = threadIdx.x; j < 4 * a.Tp; j += 256) att_acc[j] = 0.f;
-  __syncthreads();
   float* my = att_acc + wave * a.Tp;
-  for (int b = blockIdx.x * 4 + wave; b < a.B; b += gridDim.x * 4) {
+  for (int j = lane; j < a.Tp; j += 64) my[j] = 0.f;
+  const int b = blockIdx.x * ATTN_BWD_WAVES + wave;
+  if (b < a.B) {
     const long long gr = a.st->batch_idx * (long long)a.B + b;
     const bool valid = gr < s.rows;
     float dpt[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) dpt[e] = d0 + e < D ? a.dp[(size_t)b * a.Dp + d0 + e] / (float)T : 0.f;
-    for (int t0 = 0; t0 < T; t0 += RPP) {
-      const int t = t0 + rl;
-      float x[VEC];
+    for (int tb = 0; tb < T; tb += NPB * RPP) {
+      int myid = -1;
+      if (s.id_mode && valid && lane < NPB * RPP && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
+      float x[NPB][VEC];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) x[e] = 0.f;
-      const float* xrow = nullptr;
-      if (valid && t < T) {
+      for (int p = 0; p < NPB; ++p) {
+        const int t = tb + p * RPP + rl;
+        const float* xrow = nullptr;
         if (s.id_mode) {
-          int id = s.ub_ids[gr * T + t];
-          if (id >= 0 && id < s.V) xrow = s.emb + (long long)id * D;
-        } else {
+          const int id = __shfl(myid, p * RPP + rl, 64);
+          if (t < T && id >= 0 && id < s.V) xrow = s.emb + (long long)id * D;
+        } else if (valid && t < T) {
           xrow = s.X + gr * (long long)s.xcols + s.r_ub + t * D;
         }
+        load_row<VEC>(xrow, d0, D, x[p]);
       }
-      if (xrow && d0 < D) {
-        if (VEC == 4) {
-          float4 t4 = *reinterpret_cast<const float4*>(xrow + d0);
-          x[0] = t4.x; x[1] = t4.y; x[2] = t4.z; x[3] = t4.w;
-        } else {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) x[e] = d0 + e < D ? xrow[d0 + e] : 0.f;
+      for (int p = 0; p < NPB; ++p) {
+        const int t = tb + p * RPP + rl;
+        float dg = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dg += dpt[e] * x[p][e];
+        dg = group_sum<LPR>(dg);
+        if (t < T && dl == 0) {
+          const float g = a.gate[(size_t)b * T + t];
+          my[t] = dg * (g * (1.0f - g)) * a.wgt[(size_t)b * T + t];
         }
-      }
-      float dg = 0.f;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) dg += dpt[e] * x[e];
-      dg = group_sum<LPR>(dg);
-      if (t < T && dl == 0) {
-        float g = a.gate[(size_t)b * T + t];
-        my[t] += dg * (g * (1.0f - g)) * a.wgt[(size_t)b * T + t];
       }
     }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < a.Tp; t += 256) {
+  for (int t = threadIdx.x; t < a.Tp; t += 64 * ATTN_BWD_WAVES) {
     float v = 0.f;
-    if (t < T) v = ((att_acc[t] + att_acc[a.Tp + t]) + att_acc[2 * a.Tp + t]) + att_acc[3 * a.Tp + t];
+    if (t < T) {
+#pragma unroll
+      for (int w = 0; w < ATTN_BWD_WAVES; ++w) v += att_acc[w * a.Tp + t];
+    }
     a.partial[(size_t)blockIdx.x * a.Tp + t] = v;
   }
 }
@@ -367,8 +381,10 @@ struct ReduceArgs {
   int advance;        // 1: this launch closes the step (++gstep, next batch)
 };
 
+// Every group of 4 consecutive gradient entries is summed by 8 adjacent lanes (lane p takes a
+// contiguous 1/8 of the slabs, 16-byte loads, all independent => deep memory-level parallelism),
+// partial sums are combined by xor-shuffles: a fixed association order => bitwise reproducible.
 __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   if (blockIdx.x == gridDim.x - 1) {  // last block: deterministic loss sum
     __shared__ float red[256];
     float s = 0.f;
@@ -390,18 +406,31 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
     }
     return;
   }
-  if (idx >= a.nflat) return;
-  float s = 0.f;
-  bool hit = false;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int e0 = (gid >> 3) * 4, p = gid & 7;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e0 < a.nflat) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (k < a.nseg && idx >= a.seg[k].begin && idx < a.seg[k].begin + a.seg[k].len) {
-      const float* p = a.seg[k].slabs + (idx - a.seg[k].begin);
-      for (int j = 0; j < a.seg[k].nslabs; ++j) s += p[(size_t)j * a.seg[k].stride];
-      hit = true;
+    for (int k = 0; k < 4; ++k) {
+      if (k < a.nseg && e0 >= a.seg[k].begin && e0 < a.seg[k].begin + a.seg[k].len) {
+        const int spp = (a.seg[k].nslabs + 7) >> 3;
+        int lo = p * spp, hi = lo + spp;
+        if (hi > a.seg[k].nslabs) hi = a.seg[k].nslabs;
+        const float* base = a.seg[k].slabs + (e0 - a.seg[k].begin);
+#pragma unroll 8
+        for (int j = lo; j < hi; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(base + (size_t)j * a.seg[k].stride);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
     }
   }
-  a.G[idx] = hit ? s : 0.f;
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  if (p == 0 && e0 < a.nflat) *reinterpret_cast<float4*>(a.G + e0) = acc;
 }
 
 // ---------------------------------------------------------------- Adam (gorgonia AdamSolver.Step)

@@ -5,13 +5,17 @@
 // Shapes on go-ctr's path are "tall and skinny": M = batch (4k-16k rows), K,N <= a few hundred
 // (model/din/din.go:17-18: 137->200->80->1; nn MLP 281->100->1).  Two kernels cover them:
 //
-//   gemm_nn : C[M,N] = epi(A[M,K] . B[K,N])   forward layers and backward-data (B = W^T copy)
-//             one workgroup = 4 wavefronts = (4/WN) row strips of 16 rows x WN column groups;
-//             B is streamed through LDS in 16-row K-chunks (double buffered), the A fragment is
-//             one 16-byte global load per lane per chunk (k-permuted so the 4 values feed 4 MFMAs).
-//   gemm_tn : dW[K,N] = sum_m A[m,K]^T . D[m,N] split over M (weight gradients); every workgroup
-//             owns a contiguous row range, stages 16-row chunks of A and D in LDS and writes one
-//             partial slab; slabs are summed in a fixed order by the reduce kernel (deterministic).
+//   gemm_nn : C[M,N] = epi(A[M,K] . B[K,N])   forward layers and backward-data (B = W^T copy).
+//             B is small (<= 120 KB): a workgroup (4 wavefronts) parks the WHOLE of B (or a K-phase
+//             of it) in LDS with one burst of 16-byte loads, fetches all of its A fragments with
+//             one burst of 16-byte global loads per lane (k-permuted so the 4 values of a load
+//             feed 4 consecutive MFMAs) and then runs an LDS->MFMA loop with no global traffic and
+//             no barrier.  One barrier per phase instead of one per 16-deep K chunk.
+//   gemm_tn : dW[K,N] = sum_m A[m,K]^T . D[m,N] split over M (weight gradients); a workgroup owns a
+//             contiguous row range and a block of the output, streams CH-row chunks of A and D
+//             through registers into double-buffered LDS (global loads of chunk c+1 are in flight
+//             while chunk c is multiplied) and writes one partial slab; slabs are summed in a fixed
+//             order by the reduce kernel (deterministic).
 //
 // Leading dimensions are multiples of 16 elements and all pad entries are zero, so there is no
 // bounds handling on K or N inside the loops.
@@ -53,28 +57,37 @@ template <> struct Mfma<double> {
   }
 };
 
-// LDS row stride (in elements) for the TN kernel's [16][cols] tiles: the two 16-lane groups of a
+// LDS row stride (in elements) for the TN kernel's [CH][cols] tiles: the two 16-lane groups of a
 // half wave read rows m and m+1, so the stride must be == 16 (mod 32) elements to land the second
 // row on the other half of the banks (ds_read_b32: 32 banks; ds_read_b64: 64 dword banks).
 __host__ __device__ inline int tn_lds_stride(int cols) { return cols + ((16 - cols % 32) + 32) % 32; }
 
-constexpr int GEMM_NN_NTW = 7;     // n-tiles (16 cols each) per wavefront
-constexpr int GEMM_NN_MAXV = 8;    // max 16-byte vectors a thread stages per K-chunk
+constexpr int GEMM_NN_NTW = 7;     // max n-tiles (16 cols each) per wavefront
+constexpr int GEMM_NN_PHCH = 16;   // max 16-deep K chunks per phase (A fragments live in registers)
+constexpr size_t GEMM_LDS_BUDGET = 152 * 1024;  // of the CU's 160 KiB
 
+// rows of B one phase can park in LDS for a block of ncols_blk columns
 template <typename T>
-inline size_t gemm_nn_lds_bytes(int ncols_blk) { return (size_t)2 * 16 * (ncols_blk + 4) * sizeof(T); }
+inline int gemm_nn_phase_rows(int Kp, int ncols_blk) {
+  int rows = (int)(GEMM_LDS_BUDGET / ((size_t)(ncols_blk + 4) * sizeof(T))) / 16 * 16;
+  if (rows > GEMM_NN_PHCH * 16) rows = GEMM_NN_PHCH * 16;
+  return rows < Kp ? rows : Kp;
+}
+template <typename T>
+inline size_t gemm_nn_lds_bytes(int kph, int ncols_alloc) { return (size_t)kph * (ncols_alloc + 4) * sizeof(T); }
 
-// C = epi(A . B).  grid = (ceil(M / (16*WM)), ceil(NT / (WN*NTW))), block = 256, WM = 4 / WN.
+// C = epi(A . B).  grid = (ceil(M / (16*WM)), n-blocks), block = 256, WM = 4 / WN; a column block is
+// WN*ntw tiles, wave (wm,wn) owns rows [16*wm,+16) x tiles [wn*ntw, +ntw).
 // epi(row, col, value) is called once per output element of rows < M.
-template <typename T, class Epi>
-__global__ __launch_bounds__(256, 4) void gemm_nn_kernel(const T* __restrict__ A, int lda,
-                                                      const T* __restrict__ Bm, int ldb, int M, int Kp,
-                                                      int Np, int WN, Epi epi) {
+template <typename T, class Epi, int NTW>
+__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const T* __restrict__ A, int lda,
+                                                         const T* __restrict__ Bm, int ldb, int M, int Kp,
+                                                         int Np, int WN, int KPH, Epi epi) {
+  constexpr int ntw = NTW;
   using MF = Mfma<T>;
   using acc_t = typename MF::acc_t;
   using vec_t = typename MF::vec_t;
   constexpr int VEC = MF::VEC;
-  constexpr int NTW = GEMM_NN_NTW;
   extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
   T* Bs = reinterpret_cast<T*>(goctr_smem);
 
@@ -83,13 +96,16 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_kernel(const T* __restrict__ A
   const int wm = wave / WN, wn = wave - wm * WN;
   const int i = lane & 15, q = lane >> 4;
   const int NTall = Np >> 4;
-  const int nblk0 = blockIdx.y * (WN * NTW);
+  const int nblk0 = blockIdx.y * (WN * ntw);
   int nt_blk = NTall - nblk0;
-  if (nt_blk > WN * NTW) nt_blk = WN * NTW;
+  if (nt_blk > WN * ntw) nt_blk = WN * ntw;
   const int ncols_blk = nt_blk * 16;
-  const int Ns = ncols_blk + 4;  // Ns % 8 == 4: rows k and k+4 sit on opposite bank halves
-  int ntiles = nt_blk - wn * NTW;
-  ntiles = ntiles < 0 ? 0 : (ntiles > NTW ? NTW : ntiles);
+  // LDS rows are WN*NTW tiles wide even when the block has fewer: edge waves then read (and discard)
+  // unfilled columns instead of needing per-tile address clamps.  Ns % 8 == 4: rows k and k+4 sit
+  // on opposite bank halves.
+  const int Ns = WN * ntw * 16 + 4;
+  int ntiles = nt_blk - wn * ntw;
+  ntiles = ntiles < 0 ? 0 : (ntiles > ntw ? ntw : ntiles);
   const int row0 = blockIdx.x * (16 * WM) + wm * 16;
   int arow = row0 + i;
   if (arow > M - 1) arow = M - 1;
@@ -99,46 +115,55 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_kernel(const T* __restrict__ A
 #pragma unroll
   for (int t = 0; t < NTW; ++t) acc[t] = acc_t{0, 0, 0, 0};
 
-  const int nchunks = Kp >> 4;
   const int vpr = ncols_blk / VEC;  // 16-byte vectors per staged row
-  const int total_v = 16 * vpr;
-  int goff[GEMM_NN_MAXV], loff[GEMM_NN_MAXV];
+  for (int k0 = 0; k0 < Kp; k0 += KPH) {
+    const int kph = Kp - k0 < KPH ? Kp - k0 : KPH;
+    const int nch = kph >> 4;
+    // all A fragments of this phase: one burst of 16-byte loads per lane
+    T av[GEMM_NN_PHCH][4];
 #pragma unroll
-  for (int s = 0; s < GEMM_NN_MAXV; ++s) {
-    int idx = tid + s * 256;
-    int r = idx / vpr, cv = idx - r * vpr;
-    goff[s] = r * ldb + nblk0 * 16 + cv * VEC;
-    loff[s] = r * Ns + cv * VEC;
-  }
-  auto stage = [&](int c, int buf) {
-    const T* src = Bm + (size_t)c * 16 * ldb;
-    T* dst = Bs + (size_t)buf * 16 * Ns;
+    for (int c = 0; c < GEMM_NN_PHCH; ++c)
+      if (c < nch) MF::load4(ap + k0 + c * 16, av[c]);
+    if (k0 > 0) __syncthreads();  // the previous phase's LDS reads are done
+    // park B[k0:k0+kph, block columns] in LDS
+    const int total_v = kph * vpr;
+    const T* bsrc = Bm + (size_t)k0 * ldb + nblk0 * 16;
+    for (int base = 0; base < total_v; base += 256 * 8) {
+      vec_t tmp[8];
+      int lo[8];
 #pragma unroll
-    for (int s = 0; s < GEMM_NN_MAXV; ++s)
-      if (tid + s * 256 < total_v)
-        *reinterpret_cast<vec_t*>(dst + loff[s]) = *reinterpret_cast<const vec_t*>(src + goff[s]);
-  };
-
-  stage(0, 0);
-  __syncthreads();
-  int buf = 0;
-  for (int c = 0; c < nchunks; ++c) {
-    T av[4];
-    MF::load4(ap + c * 16, av);
-    if (c + 1 < nchunks) stage(c + 1, buf ^ 1);
-    const T* bsb = Bs + (size_t)buf * 16 * Ns + wn * NTW * 16 + i;
+      for (int s = 0; s < 8; ++s) {
+        const int idx = base + tid + s * 256;
+        if (idx < total_v) {
+          const int r = idx / vpr, cv = idx - r * vpr;
+          tmp[s] = *reinterpret_cast<const vec_t*>(bsrc + (size_t)r * ldb + cv * VEC);
+          lo[s] = r * Ns + cv * VEC;
+        }
+      }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const T* brow = bsb + (4 * q + j) * Ns;
-#pragma unroll
-      for (int t = 0; t < NTW; ++t)
-        if (t < ntiles) acc[t] = MF::mma(av[j], brow[t * 16], acc[t]);
+      for (int s = 0; s < 8; ++s)
+        if (base + tid + s * 256 < total_v) *reinterpret_cast<vec_t*>(Bs + lo[s]) = tmp[s];
     }
     __syncthreads();
-    buf ^= 1;
+    // one row pointer walks down the staged rows; the tile offsets are ds_read immediates
+    const T* brow = Bs + (4 * q) * Ns + wn * ntw * 16 + i;
+#pragma unroll
+    for (int c = 0; c < GEMM_NN_PHCH; ++c) {
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = MF::mma(av[c][j], brow[t * 16], acc[t]);
+          brow += Ns;
+        }
+        brow += 12 * Ns;
+        // keep the scheduler from hoisting every later chunk's ds_reads above this chunk's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
 
-  const int nt0 = nblk0 + wn * NTW;
+  const int nt0 = nblk0 + wn * ntw;
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     if (t < ntiles) {
@@ -155,8 +180,11 @@ __global__ __launch_bounds__(256, 4) void gemm_nn_kernel(const T* __restrict__ A
 // block = 64*WK*WN threads; grid = (M-splits, k-blocks, n-blocks); a k-block is WK*KTW tiles of 16
 // columns of A, an n-block WN*NTW tiles of D; wave (wk,wn) owns KTW x NTW output tiles of it.
 // KT / NT = total number of 16-wide tiles of A's / D's columns; the slab is [KT*16][NT*16].
-template <typename T, int KTW, int NTW>
-__global__ __launch_bounds__(1024) void gemm_tn_kernel(const T* __restrict__ A, int lda, int KT,
+// CH = rows per pipelined chunk (multiple of 16).
+constexpr int GEMM_TN_MAXVA = 4, GEMM_TN_MAXVD = 8;
+
+template <typename T, int KTW, int NTW, int CH>
+__global__ __launch_bounds__(512) void gemm_tn_kernel(const T* __restrict__ A, int lda, int KT,
                                                        const T* __restrict__ Dm, int ldd, int NT, int M,
                                                        int rows_per_wg, int WK, int WN,
                                                        T* __restrict__ slabs, size_t slab_stride) {
@@ -169,9 +197,10 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(const T* __restrict__ A, 
   int kb_t = KT - kb0; if (kb_t > WK * KTW) kb_t = WK * KTW;
   int nb_t = NT - nb0; if (nb_t > WN * NTW) nb_t = WN * NTW;
   const int Kc = kb_t * 16, Nc = nb_t * 16;
-  const int Kas = tn_lds_stride(Kc), Nds = tn_lds_stride(Nc);
-  T* As = reinterpret_cast<T*>(goctr_smem);                 // [2][16][Kas]
-  T* Ds = As + 2 * 16 * tn_lds_stride(WK * KTW * 16);       // [2][16][Nds]
+  // strides cover the full WK*KTW / WN*NTW tile block so edge waves read in-bounds (unused) data
+  const int Kas = tn_lds_stride(WK * KTW * 16), Nds = tn_lds_stride(WN * NTW * 16);
+  T* As = reinterpret_cast<T*>(goctr_smem);                 // [2][CH][Kas]
+  T* Ds = As + 2 * CH * Kas;                                // [2][CH][Nds]
 
   const int tid = threadIdx.x, nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave / WN, wn = wave - wk * WN;
@@ -192,44 +221,75 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(const T* __restrict__ A, 
   const int kv = Kc / VEC, nv = Nc / VEC;
   const T* Ab = A + kb0 * 16;
   const T* Db = Dm + nb0 * 16;
-  auto stage = [&](int m0, int buf) {
-    T* as = As + (size_t)buf * 16 * Kas;
-    T* ds = Ds + (size_t)buf * 16 * Nds;
-    for (int idx = tid; idx < 16 * kv; idx += nthreads) {
-      int r = idx / kv, cv = idx - r * kv;
-      vec_t v = vec_t(0);
-      if (m0 + r < m_end) v = *reinterpret_cast<const vec_t*>(Ab + (size_t)(m0 + r) * lda + cv * VEC);
-      *reinterpret_cast<vec_t*>(as + r * Kas + cv * VEC) = v;
+  vec_t ra[GEMM_TN_MAXVA], rd[GEMM_TN_MAXVD];
+  // global -> registers (issued early, consumed late)
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int s = 0; s < GEMM_TN_MAXVA; ++s) {
+      const int idx = tid + s * nthreads;
+      ra[s] = vec_t(0);
+      if (idx < CH * kv) {
+        const int r = idx / kv, cv = idx - r * kv;
+        if (m0 + r < m_end) ra[s] = *reinterpret_cast<const vec_t*>(Ab + (size_t)(m0 + r) * lda + cv * VEC);
+      }
     }
-    for (int idx = tid; idx < 16 * nv; idx += nthreads) {
-      int r = idx / nv, cv = idx - r * nv;
-      vec_t v = vec_t(0);
-      if (m0 + r < m_end) v = *reinterpret_cast<const vec_t*>(Db + (size_t)(m0 + r) * ldd + cv * VEC);
-      *reinterpret_cast<vec_t*>(ds + r * Nds + cv * VEC) = v;
+#pragma unroll
+    for (int s = 0; s < GEMM_TN_MAXVD; ++s) {
+      const int idx = tid + s * nthreads;
+      rd[s] = vec_t(0);
+      if (idx < CH * nv) {
+        const int r = idx / nv, cv = idx - r * nv;
+        if (m0 + r < m_end) rd[s] = *reinterpret_cast<const vec_t*>(Db + (size_t)(m0 + r) * ldd + cv * VEC);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    T* as = As + (size_t)buf * CH * Kas;
+    T* ds = Ds + (size_t)buf * CH * Nds;
+#pragma unroll
+    for (int s = 0; s < GEMM_TN_MAXVA; ++s) {
+      const int idx = tid + s * nthreads;
+      if (idx < CH * kv) {
+        const int r = idx / kv, cv = idx - r * kv;
+        *reinterpret_cast<vec_t*>(as + r * Kas + cv * VEC) = ra[s];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < GEMM_TN_MAXVD; ++s) {
+      const int idx = tid + s * nthreads;
+      if (idx < CH * nv) {
+        const int r = idx / nv, cv = idx - r * nv;
+        *reinterpret_cast<vec_t*>(ds + r * Nds + cv * VEC) = rd[s];
+      }
     }
   };
 
   if (m_begin < m_end) {
-    stage(m_begin, 0);
+    gload(m_begin);
+    lstore(0);
     __syncthreads();
     int buf = 0;
-    for (int m0 = m_begin; m0 < m_end; m0 += 16) {
-      if (m0 + 16 < m_end) stage(m0 + 16, buf ^ 1);
-      const T* as = As + (size_t)buf * 16 * Kas + kt0 * 16 + i;
-      const T* ds = Ds + (size_t)buf * 16 * Nds + nt0 * 16 + i;
+    for (int m0 = m_begin; m0 < m_end; m0 += CH) {
+      const bool more = m0 + CH < m_end;
+      if (more) gload(m0 + CH);
+      const T* as = As + (size_t)buf * CH * Kas + q * Kas + kt0 * 16 + i;
+      const T* ds = Ds + (size_t)buf * CH * Nds + q * Nds + nt0 * 16 + i;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < CH / 4; ++s) {
         T a[KTW], d[NTW];
 #pragma unroll
-        for (int e = 0; e < KTW; ++e) a[e] = e < kcnt ? as[(4 * s + q) * Kas + e * 16] : T(0);
+        for (int e = 0; e < KTW; ++e) a[e] = as[e * 16];   // tiles past the block edge hold stale/zero
 #pragma unroll
-        for (int f = 0; f < NTW; ++f) d[f] = f < ncnt ? ds[(4 * s + q) * Nds + f * 16] : T(0);
+        for (int f = 0; f < NTW; ++f) d[f] = ds[f * 16];   // data: their products are never stored
 #pragma unroll
         for (int e = 0; e < KTW; ++e)
 #pragma unroll
-          for (int f = 0; f < NTW; ++f)
-            if (e < kcnt && f < ncnt) acc[e][f] = MF::mma(a[e], d[f], acc[e][f]);
+          for (int f = 0; f < NTW; ++f) acc[e][f] = MF::mma(a[e], d[f], acc[e][f]);
+        as += 4 * Kas;
+        ds += 4 * Nds;
+        __builtin_amdgcn_sched_barrier(0);
       }
+      if (more) lstore(buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
@@ -248,10 +308,10 @@ __global__ __launch_bounds__(1024) void gemm_tn_kernel(const T* __restrict__ A, 
       }
 }
 
-// LDS bytes for a (WK*KTW) x (WN*NTW)-tile block
+// LDS bytes for a (WK*KTW) x (WN*NTW)-tile block with CH-row chunks
 template <typename T>
-inline size_t gemm_tn_lds_bytes(int kb_tiles, int nb_tiles) {
-  return (size_t)2 * 16 * (tn_lds_stride(kb_tiles * 16) + tn_lds_stride(nb_tiles * 16)) * sizeof(T);
+inline size_t gemm_tn_lds_bytes(int kb_tiles, int nb_tiles, int ch) {
+  return (size_t)2 * ch * (tn_lds_stride(kb_tiles * 16) + tn_lds_stride(nb_tiles * 16)) * sizeof(T);
 }
 
 }  // namespace goctr
