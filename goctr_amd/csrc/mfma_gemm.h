@@ -63,14 +63,15 @@ template <> struct Mfma<double> {
 __host__ __device__ inline int tn_lds_stride(int cols) { return cols + ((16 - cols % 32) + 32) % 32; }
 
 constexpr int GEMM_NN_NTW = 7;     // max n-tiles (16 cols each) per wavefront
-constexpr int GEMM_NN_PHCH = 16;   // max 16-deep K chunks per phase (A fragments live in registers)
+// max 16-deep K chunks per phase (the A fragments of a phase live in registers: 4 values per chunk)
+template <typename T> struct NnPhase { static constexpr int CH = sizeof(T) == 4 ? 16 : 8; };
 constexpr size_t GEMM_LDS_BUDGET = 152 * 1024;  // of the CU's 160 KiB
 
 // rows of B one phase can park in LDS for a block of ncols_blk columns
 template <typename T>
 inline int gemm_nn_phase_rows(int Kp, int ncols_blk) {
   int rows = (int)(GEMM_LDS_BUDGET / ((size_t)(ncols_blk + 4) * sizeof(T))) / 16 * 16;
-  if (rows > GEMM_NN_PHCH * 16) rows = GEMM_NN_PHCH * 16;
+  if (rows > NnPhase<T>::CH * 16) rows = NnPhase<T>::CH * 16;
   return rows < Kp ? rows : Kp;
 }
 template <typename T>
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const T* __restrict__ A
   using acc_t = typename MF::acc_t;
   using vec_t = typename MF::vec_t;
   constexpr int VEC = MF::VEC;
+  constexpr int GEMM_NN_PHCH = NnPhase<T>::CH;
   extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
   T* Bs = reinterpret_cast<T*>(goctr_smem);
 
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(const T* __restrict__ A
 // columns of A, an n-block WN*NTW tiles of D; wave (wk,wn) owns KTW x NTW output tiles of it.
 // KT / NT = total number of 16-wide tiles of A's / D's columns; the slab is [KT*16][NT*16].
 // CH = rows per pipelined chunk (multiple of 16).
-constexpr int GEMM_TN_MAXVA = 4, GEMM_TN_MAXVD = 8;
+constexpr int GEMM_TN_MAXVA = 8, GEMM_TN_MAXVD = 8;
 
 template <typename T, int KTW, int NTW, int CH>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(const T* __restrict__ A, int lda, int KT,

@@ -1,17 +1,621 @@
-// mlp.hip -- sklearn-port MLP engine (float64).  TEMPORARY stubs: every entry point fails loudly.
+// mlp.hip -- sklearn-port MLP engine (float64, like the reference) + its C-ABI.
+//
+// Replaces nn.MLPClassifier.Fit / Predict (nn/neural_network/basemlp64.go, reference = auxten/go-ctr)
+// behind model/mlp's SimpleMlpFitWrap / SimpleMlpPredWrap (model/mlp/mlp.go:15-65).
+//   forward      basemlp64.go:259-274   gemm_nn<double> on v_mfma_f64_16x16x4_f64, bias folded in
+//   backprop     basemlp64.go:340-406   delta = h - y; gemm_tn<double> weight grads; gemm_nn<double>
+//                                       backward data with the activation derivative as epilogue
+//   optimizers   basemlp64.go:1024-1091 SGD (Nesterov) and Adam with the per-PARAMETER beta powers (Q7)
+//   max-abs "batch normalisation"  basemlp64.go:277-308
+//
+// Layout: layer i's activations are [n, up_i] with up_i = round_up(units_i + 1, 16); column units_i is a
+// constant 1 ("ones column") and row units_i of the augmented weight block W_i [up_i, up_{i+1}] holds the
+// intercepts, so  A_i . W_i  already contains  + b_i  (addIntercepts64 :205) and the bias gradients
+// (matRowMean64 :213) fall out of the weight-gradient GEMM as row units_i.
+#include <cmath>
+#include <memory>
+
 #include "common.h"
+#include "mfma_gemm.h"
+
 using namespace goctr;
-#define NOTYET(name) do { set_error(name ": not implemented in this build"); return -1; } while (0)
-extern "C" {
-void goctr_mlp_cfg_default(goctr_mlp_cfg* c) { memset(c, 0, sizeof *c); }
-int goctr_mlp_create(const goctr_mlp_cfg*, goctr_mlp**) { NOTYET("goctr_mlp_create"); }
-void goctr_mlp_destroy(goctr_mlp*) {}
-size_t goctr_mlp_nparams(const goctr_mlp*) { return 0; }
-int goctr_mlp_set_params(goctr_mlp*, const double*, size_t) { NOTYET("goctr_mlp_set_params"); }
-int goctr_mlp_get_params(goctr_mlp*, double*, size_t) { NOTYET("goctr_mlp_get_params"); }
-int goctr_mlp_loss_grad(goctr_mlp*, const double*, const double*, int, double*, double*) { NOTYET("goctr_mlp_loss_grad"); }
-int goctr_mlp_fit(goctr_mlp*, const float*, const float*, int64_t, const int32_t*, double*, int*) { NOTYET("goctr_mlp_fit"); }
-int goctr_mlp_upload(goctr_mlp*, const float*, const float*, int64_t) { NOTYET("goctr_mlp_upload"); }
-int goctr_mlp_train_steps(goctr_mlp*, int64_t, int) { NOTYET("goctr_mlp_train_steps"); }
-int goctr_mlp_predict(goctr_mlp*, const float*, int64_t, float*) { NOTYET("goctr_mlp_predict"); }
+
+namespace {
+
+constexpr int MLP_LOSS_RING = 1 << 14;
+
+struct MlpState {
+  long long t;          // optimizer step counter (AdamOptimizer64.t)
+  long long batch_idx;  // next batch (for train_steps)
+  long long n_batches;
+  unsigned int slot;
+};
+
+__device__ __forceinline__ double act_fwd(int kind, double z) {
+  switch (kind) {
+    case GOCTR_ACT_LOGISTIC: return 1 / (1 + exp(-z));
+    case GOCTR_ACT_TANH: return tanh(-z);  // quirk Q9 (basemlp64.go:91)
+    case GOCTR_ACT_RELU: return z < 0 ? 0 : z;
+    default: return z;
+  }
 }
+
+// forward epilogue: activation, ones column, zero pad
+struct EpiMlpAct {
+  double* out; int ld; int ncols; int kind;
+  __device__ __forceinline__ void operator()(int row, int col, double z) const {
+    double v = 0;
+    if (col < ncols) v = act_fwd(kind, z);
+    else if (col == ncols) v = 1.0;
+    out[(size_t)row * ld + col] = v;
+  }
+};
+
+// backward-data epilogue: delta_prev = (delta . W^T) * act'(a) [/ M]   (basemlp64.go:120-148,302-308)
+struct EpiMlpDAct {
+  double* out; const double* a; int ld; int ncols; int kind; const double* bn;  // bn: max-abs per column or null
+  __device__ __forceinline__ void operator()(int row, int col, double s) const {
+    double r = 0;
+    if (col < ncols) {
+      const double av = a[(size_t)row * ld + col];
+      switch (kind) {
+        case GOCTR_ACT_LOGISTIC: r = s * (av * (1 - av)); break;
+        case GOCTR_ACT_TANH: r = s * (1 - av * av); break;
+        case GOCTR_ACT_RELU: r = av == 0 ? 0 : s; break;  // quirk Q12
+        default: r = s;
+      }
+      if (bn) r /= bn[col];  // quirk Q10: unconditional divide
+    }
+    out[(size_t)row * ld + col] = r;
+  }
+};
+
+// widen f32 rows to f64 like mlp.go:46-59, append the ones column
+__global__ __launch_bounds__(256) void mlp_gather_kernel(const float* X, const float* Y, const int* perm,
+                                                         const MlpState* st, long long start_fixed, int use_state,
+                                                         int batch, int F, int up0, int no, int upL, double* A0,
+                                                         double* Yb) {
+  const int r = blockIdx.x;
+  const long long start = use_state ? st->batch_idx * (long long)batch : start_fixed;
+  const long long src = perm ? perm[start + r] : start + r;
+  for (int j = threadIdx.x; j < up0; j += 256)
+    A0[(size_t)r * up0 + j] = j < F ? (double)X[src * F + j] : (j == F ? 1.0 : 0.0);
+  if (Y)
+    for (int j = threadIdx.x; j < upL; j += 256) Yb[(size_t)r * upL + j] = j < no ? (double)Y[src * no + j] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void mlp_copy_f64_kernel(const double* X, const double* Y, int n, int F, int up0, int no,
+                                                           int upL, double* A0, double* Yb) {
+  const int r = blockIdx.x;
+  for (int j = threadIdx.x; j < up0; j += 256) A0[(size_t)r * up0 + j] = j < F ? X[(size_t)r * F + j] : (j == F ? 1.0 : 0.0);
+  if (Y)
+    for (int j = threadIdx.x; j < upL; j += 256) Yb[(size_t)r * upL + j] = j < no ? Y[(size_t)r * no + j] : 0.0;
+}
+
+// delta_last = h - y and the binary log-loss terms (basemlp64.go:180-195,373-381); one block per row group
+__global__ __launch_bounds__(256) void mlp_delta_last_kernel(const double* H, const double* Yb, int n, int no, int upL,
+                                                             double* delta, double* lossterm) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * upL) return;
+  const int c = idx % upL;
+  double d = 0, l = 0;
+  if (c < no) {
+    const double h = H[idx], y = Yb[idx];
+    d = h - y;
+    const double hmin = 4.9406564584124654e-324, hmax = 0.99999999999999989;  // Nextafter(0,1), Nextafter(1,0)
+    double hc = h < hmin ? hmin : (h > hmax ? hmax : h);
+    l = -y * log(hc) - (1 - y) * log1p(-hc);
+  }
+  delta[idx] = d;
+  lossterm[idx] = l;
+}
+
+// max-abs column scaling of a hidden activation block (basemlp64.go:277-299); one block per column
+__global__ __launch_bounds__(256) void mlp_bn_kernel(double* A, int n, int ld, int ncols, double* bn) {
+  const int o = blockIdx.x;
+  __shared__ double red[256];
+  double m = 0;
+  for (int r = threadIdx.x; r < n; r += 256) { double a = fabs(A[(size_t)r * ld + o]); if (m < a) m = a; }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s && red[threadIdx.x] < red[threadIdx.x + s]) red[threadIdx.x] = red[threadIdx.x + s]; __syncthreads(); }
+  const double M = red[0];
+  if (threadIdx.x == 0) bn[o] = M;
+  if (M > 0) for (int r = threadIdx.x; r < n; r += 256) A[(size_t)r * ld + o] /= M;
+}
+
+struct MlpLayerDesc {
+  int fi, fo, upi, upo;       // fan-in/out and padded sizes
+  long long woff;             // offset of the augmented block in the flat padded parameter buffer
+  long long poff;             // offset of [b | W] of this layer in the packed (reference) order
+  const double* slabs; int nslabs;
+  double* WT;                 // [upo][upi] transposed copy without the bias row
+};
+struct MlpReduceArgs {
+  MlpLayerDesc L[7]; int nl;
+  long long nflat;            // padded parameter count
+  long long nparams;          // packed parameter count (reference n)
+  double* W; double* G; double* Mo; double* Vo; double* Vel;
+  double alpha; int n;        // rows in the batch
+  // optimizer
+  int solver; int do_update;
+  double lr_init, beta1, beta2, eps, momentum; int nesterov;
+  double weight_decay;
+  MlpState* st;
+  double* sumsq_part;         // [gridDim.x] partial sums of W^2 (coefs only)
+};
+
+// grad = slab sum / n + alpha/n * W (coefs), mean(delta) (intercepts)  [computeLossGrad :322-330]; then the
+// optimizer step in packed-parameter order semantics.
+__global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  __shared__ double red[256];
+  double sq = 0;
+  if (idx < a.nflat) {
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 7; ++k) if (k < a.nl && idx >= a.L[k].woff) l = k;
+    const MlpLayerDesc& d = a.L[l];
+    const long long e = idx - d.woff;
+    const int r = (int)(e / d.upo), c = (int)(e - (long long)r * d.upo);
+    const bool is_w = r < d.fi && c < d.fo, is_b = r == d.fi && c < d.fo;
+    if (is_w || is_b) {
+      double s = 0;
+      for (int j = 0; j < d.nslabs; ++j) s += d.slabs[(size_t)j * d.upi * d.upo + e];
+      const double w = a.W[idx];
+      double g = s * (1 / (double)a.n);                       // gemm alpha = 1/n (and mean for the bias row)
+      if (is_w) { g += (a.alpha / (double)a.n) * w; sq = w * w; }
+      a.G[idx] = g;
+      if (a.do_update) {
+        const long long pidx = d.poff + (is_b ? c : (long long)d.fo + (long long)r * d.fo + c);
+        double wn = w;
+        if (a.solver == GOCTR_SOLVER_ADAM) {
+          const double m = a.beta1 * a.Mo[idx] + (1 - a.beta1) * g;
+          const double v = a.beta2 * a.Vo[idx] + (1 - a.beta2) * g * g;
+          a.Mo[idx] = m; a.Vo[idx] = v;
+          // quirk Q7: beta powers advance once per parameter: exponent (t-1)*n + i + 1
+          const double ex = (double)((a.st->t) * a.nparams + pidx + 1);
+          const double b1t = pow(a.beta1, ex), b2t = pow(a.beta2, ex);
+          const double lr = a.lr_init * sqrt(1 - b2t) / (1. - b1t);
+          wn = w + (-lr * m / (sqrt(v) + a.eps));
+        } else {
+          const double upd = a.momentum * a.Vel[idx] - a.lr_init * g;
+          a.Vel[idx] = upd;
+          wn = a.nesterov ? w + (a.momentum * upd - a.lr_init * g) : w + upd;
+        }
+        a.W[idx] = wn;
+        if (is_w) d.WT[(size_t)c * d.upi + r] = wn;
+      }
+    } else {
+      a.G[idx] = 0;
+    }
+  }
+  red[threadIdx.x] = sq;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) a.sumsq_part[blockIdx.x] = red[0];
+}
+
+// loss = sum(terms)/n + 0.5*alpha*sum(W^2)/n  (basemlp64.go:359-361); closes the step
+__global__ __launch_bounds__(256) void mlp_loss_kernel(const double* lossterm, int nterms, const double* sumsq_part,
+                                                       int nparts, double alpha, int n, MlpState* st, double* ring,
+                                                       int advance) {
+  __shared__ double red[256];
+  double s = 0;
+  for (int i = threadIdx.x; i < nterms; i += 256) s += lossterm[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  const double lsum = red[0];
+  __syncthreads();
+  s = 0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += sumsq_part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    ring[st->slot % MLP_LOSS_RING] = lsum / (double)n + (0.5 * alpha) * red[0] / (double)n;
+    if (advance) {
+      st->slot += 1;
+      st->t += 1;
+      long long nb = st->batch_idx + 1;
+      st->batch_idx = nb >= st->n_batches ? 0 : nb;
+    }
+  }
+}
+
+__global__ void mlp_scale_kernel(double* W, long long n, double f) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) W[i] *= f;
+}
+__global__ void mlp_narrow_kernel(const double* H, int n, int ld, int no, float* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n * no) out[i] = (float)H[(size_t)(i / no) * ld + i % no];
+}
+
+template <class K>
+int allow_big_lds(K kernel) {
+  GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(160 * 1024)));
+  return 0;
+}
+
+template <class Epi>
+int launch_nn64(const double* A, int lda, const double* Bm, int ldb, int M, int Kp, int Np, Epi epi) {
+  const int NT = Np / 16;
+  int WN = NT >= 2 ? 2 : 1;
+  int ntw = (int)cdiv(NT, WN);
+  ntw = ntw <= 1 ? 1 : (ntw <= 2 ? 2 : 4);  // instantiated tile counts (f64: 8 VGPRs per accumulator tile)
+  const int WM = 4 / WN;
+  dim3 grid((unsigned)cdiv(M, 16 * WM), (unsigned)cdiv(NT, WN * ntw));
+  const int ncols_alloc = WN * ntw * 16;
+  const int KPH = gemm_nn_phase_rows<double>(Kp, ncols_alloc);
+  const size_t lds = gemm_nn_lds_bytes<double>(KPH, ncols_alloc);
+  hipStream_t st = engine().stream;
+#define GOCTR_NN64(N) hipLaunchKernelGGL((gemm_nn_kernel<double, Epi, N>), grid, dim3(256), lds, st, A, lda, Bm, ldb, M, Kp, Np, WN, KPH, epi)
+  switch (ntw) {
+    case 1: GOCTR_NN64(1); break;
+    case 2: GOCTR_NN64(2); break;
+    default: GOCTR_NN64(4); break;
+  }
+#undef GOCTR_NN64
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int NT, int M, int rows_per_wg,
+                double* slabs) {
+  const int S = (int)cdiv(M, rows_per_wg);
+  constexpr int KTW = 3, NTW = 4, CH = 16;
+  const int WK = 1, WN = std::min(2, (int)cdiv(NT, NTW));
+  dim3 grid(S, (unsigned)cdiv(KT, WK * KTW), (unsigned)cdiv(NT, WN * NTW));
+  hipLaunchKernelGGL((gemm_tn_kernel<double, KTW, NTW, CH>), grid, dim3(64 * WK * WN),
+                     gemm_tn_lds_bytes<double>(WK * KTW, WN * NTW, CH), engine().stream, A, lda, KT, Dm, ldd, NT, M,
+                     rows_per_wg, WK, WN, slabs, (size_t)KT * 16 * NT * 16);
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+int init_attrs64() {
+  static bool done = false;
+  if (done) return 0;
+  if (allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 1>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 2>) ||
+      allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 4>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 1>) ||
+      allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 2>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 4>) ||
+      allow_big_lds(gemm_tn_kernel<double, 3, 4, 16>)) return -1;
+  done = true;
+  return 0;
+}
+
+}  // namespace
+
+struct goctr_mlp {
+  goctr_mlp_cfg cfg{};
+  int nl = 0;                 // number of weight layers = n_layers - 1
+  int units[8] = {0}, up[8] = {0};
+  long long woff[8] = {0}, poff[8] = {0};
+  long long nflat = 0, nparams = 0;
+  DevBuf<double> W, G, Mo, Vo, Vel, WT[7], bn[7];
+  // batch workspace
+  int wsN = 0, S = 0;
+  DevBuf<double> A[8], D[8], Yb, lossterm, slabs[7], sumsq_part, ring;
+  DevBuf<MlpState> st;
+  // resident rows
+  DevBuf<float> Xr, Yr; int64_t rows = 0; DevBuf<int> perm;
+  std::mutex mu;
+};
+
+namespace {
+
+int tn_rows64() { return 64; }
+
+int ensure_ws(goctr_mlp* p, int n) {
+  if (p->wsN >= n) return 0;
+  p->S = (int)cdiv(n, tn_rows64());
+  for (int i = 0; i <= p->nl; ++i) {
+    if (p->A[i].alloc((size_t)n * p->up[i])) return -1;
+    if (i > 0 && p->D[i].alloc((size_t)n * p->up[i])) return -1;
+  }
+  if (p->Yb.alloc((size_t)n * p->up[p->nl]) || p->lossterm.alloc((size_t)n * p->up[p->nl])) return -1;
+  for (int l = 0; l < p->nl; ++l)
+    if (p->slabs[l].alloc((size_t)p->S * p->up[l] * p->up[l + 1])) return -1;
+  p->wsN = n;
+  return 0;
+}
+
+// forward over A[0] (already filled) for n rows; bn applied afterwards like the reference
+int forward(goctr_mlp* p, int n, bool train) {
+  for (int l = 0; l < p->nl; ++l) {
+    const bool last = l == p->nl - 1;
+    EpiMlpAct e{p->A[l + 1].p, p->up[l + 1], p->units[l + 1], last ? GOCTR_ACT_LOGISTIC : p->cfg.activation};
+    if (launch_nn64(p->A[l].p, p->up[l], p->W.p + p->woff[l], p->up[l + 1], n, p->up[l], p->up[l + 1], e)) return -1;
+  }
+  if (train && p->cfg.batch_normalize) {
+    for (int l = 0; l < p->nl - 1; ++l) {
+      hipLaunchKernelGGL(mlp_bn_kernel, dim3(p->units[l + 1]), dim3(256), 0, engine().stream, p->A[l + 1].p, n,
+                         p->up[l + 1], p->units[l + 1], p->bn[l].p);
+      GOCTR_HIP(hipGetLastError());
+    }
+  }
+  return 0;
+}
+
+// backprop + optional update for the n rows in A[0]/Yb
+int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
+  Engine& e = engine();
+  const int L = p->nl;
+  if (p->cfg.weight_decay > 0) {  // basemlp64.go:342-346 (applied before the forward pass by the caller order)
+  }
+  const int upL = p->up[L], no = p->units[L];
+  hipLaunchKernelGGL(mlp_delta_last_kernel, dim3((unsigned)cdiv((int64_t)n * upL, 256)), dim3(256), 0, e.stream,
+                     p->A[L].p, p->Yb.p, n, no, upL, p->D[L].p, p->lossterm.p);
+  GOCTR_HIP(hipGetLastError());
+  for (int l = L - 1; l >= 0; --l) {
+    if (launch_tn64(p->A[l].p, p->up[l], p->up[l] / 16, p->D[l + 1].p, p->up[l + 1], p->up[l + 1] / 16, n, tn_rows64(),
+                    p->slabs[l].p)) return -1;
+    if (l >= 1) {
+      EpiMlpDAct d{p->D[l].p, p->A[l].p, p->up[l], p->units[l], p->cfg.activation,
+                   p->cfg.batch_normalize ? p->bn[l - 1].p : nullptr};
+      if (launch_nn64(p->D[l + 1].p, p->up[l + 1], p->WT[l].p, p->up[l], n, p->up[l + 1], p->up[l], d)) return -1;
+    }
+  }
+  MlpReduceArgs a{};
+  a.nl = L;
+  for (int l = 0; l < L; ++l)
+    a.L[l] = {p->units[l], p->units[l + 1], p->up[l], p->up[l + 1], p->woff[l], p->poff[l], p->slabs[l].p,
+              (int)cdiv(n, tn_rows64()), p->WT[l].p};
+  a.nflat = p->nflat; a.nparams = p->nparams;
+  a.W = p->W.p; a.G = p->G.p; a.Mo = p->Mo.p; a.Vo = p->Vo.p; a.Vel = p->Vel.p;
+  a.alpha = p->cfg.alpha; a.n = n; a.solver = p->cfg.solver; a.do_update = do_update ? 1 : 0;
+  a.lr_init = p->cfg.lr_init; a.beta1 = p->cfg.beta1; a.beta2 = p->cfg.beta2; a.eps = p->cfg.eps;
+  a.momentum = p->cfg.momentum; a.nesterov = p->cfg.nesterov; a.weight_decay = p->cfg.weight_decay;
+  a.st = p->st.p; a.sumsq_part = p->sumsq_part.p;
+  const int nblk = (int)cdiv(p->nflat, 256);
+  hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk), dim3(256), 0, e.stream, a);
+  GOCTR_HIP(hipGetLastError());
+  hipLaunchKernelGGL(mlp_loss_kernel, dim3(1), dim3(256), 0, e.stream, p->lossterm.p, n * upL, p->sumsq_part.p, nblk,
+                     p->cfg.alpha, n, p->st.p, p->ring.p, advance ? 1 : 0);
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+int weight_decay(goctr_mlp* p) {
+  if (!(p->cfg.weight_decay > 0)) return 0;
+  hipLaunchKernelGGL(mlp_scale_kernel, dim3((unsigned)cdiv(p->nflat, 256)), dim3(256), 0, engine().stream, p->W.p,
+                     p->nflat, 1 - p->cfg.weight_decay);
+  GOCTR_HIP(hipGetLastError());
+  for (int l = 0; l < p->nl; ++l) {
+    hipLaunchKernelGGL(mlp_scale_kernel, dim3((unsigned)cdiv((int64_t)p->up[l] * p->up[l + 1], 256)), dim3(256), 0,
+                       engine().stream, p->WT[l].p, (long long)p->up[l] * p->up[l + 1], 1 - p->cfg.weight_decay);
+    GOCTR_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int set_mstate(goctr_mlp* p, long long t, long long b, long long nb, unsigned slot) {
+  MlpState s{t, b, nb, slot};
+  GOCTR_HIP(hipMemcpyAsync(p->st.p, &s, sizeof s, hipMemcpyHostToDevice, engine().stream));
+  GOCTR_HIP(hipStreamSynchronize(engine().stream));
+  return 0;
+}
+int get_mstate(goctr_mlp* p, MlpState* s) {
+  GOCTR_HIP(hipMemcpyAsync(s, p->st.p, sizeof *s, hipMemcpyDeviceToHost, engine().stream));
+  GOCTR_HIP(hipStreamSynchronize(engine().stream));
+  return 0;
+}
+
+// one optimisation step over resident rows [state.batch_idx*batch, +batch) (or a fixed start)
+int train_step_resident(goctr_mlp* p, bool use_state, long long start) {
+  const int B = p->cfg.batch, L = p->nl;
+  if (weight_decay(p)) return -1;
+  hipLaunchKernelGGL(mlp_gather_kernel, dim3(B), dim3(256), 0, engine().stream, p->Xr.p, p->Yr.p,
+                     p->perm.n > 1 ? p->perm.p : nullptr, p->st.p, start, use_state ? 1 : 0, B, p->units[0], p->up[0],
+                     p->units[L], p->up[L], p->A[0].p, p->Yb.p);
+  GOCTR_HIP(hipGetLastError());
+  if (forward(p, B, true)) return -1;
+  return backward(p, B, true, true);
+}
+
+}  // namespace
+
+extern "C" {
+
+void goctr_mlp_cfg_default(goctr_mlp_cfg* c) {
+  memset(c, 0, sizeof *c);  // NewBaseMultilayerPerceptron64 (basemlp64.go:228-254)
+  c->n_layers = 3; c->units[0] = 0; c->units[1] = 100; c->units[2] = 1;
+  c->activation = GOCTR_ACT_RELU; c->solver = GOCTR_SOLVER_ADAM; c->alpha = 0.0001;
+  c->lr_init = 0.001; c->beta1 = 0.9; c->beta2 = 0.999; c->eps = 1e-8; c->momentum = 0.9; c->nesterov = 1;
+  c->batch_normalize = 0; c->weight_decay = 0; c->batch = 200; c->max_iter = 200; c->n_iter_no_change = 10; c->tol = 1e-4;
+}
+
+int goctr_mlp_create(const goctr_mlp_cfg* cfg, goctr_mlp** out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(cfg && out && cfg->n_layers >= 2 && cfg->n_layers <= 8, "goctr_mlp_create: n_layers must be 2..8");
+  // validateHyperparameters panics on these (basemlp64.go:625-673)
+  GOCTR_CHECK(cfg->activation >= 0 && cfg->activation <= 3, "unknown activation %d", cfg->activation);
+  GOCTR_CHECK(cfg->solver == GOCTR_SOLVER_SGD || cfg->solver == GOCTR_SOLVER_ADAM, "solver must be sgd or adam");
+  GOCTR_CHECK(cfg->alpha >= 0 && cfg->lr_init > 0 && cfg->batch > 0, "bad hyper-parameters");
+  for (int i = 0; i < cfg->n_layers; ++i) GOCTR_CHECK(cfg->units[i] > 0, "layer %d has %d units", i, cfg->units[i]);
+  if (init_attrs64()) return -1;
+  std::unique_ptr<goctr_mlp> p(new goctr_mlp);
+  p->cfg = *cfg;
+  p->nl = cfg->n_layers - 1;
+  long long wo = 0, po = 0;
+  for (int i = 0; i < cfg->n_layers; ++i) { p->units[i] = cfg->units[i]; p->up[i] = round_up(cfg->units[i] + 1, 16); }
+  for (int l = 0; l < p->nl; ++l) {
+    p->woff[l] = wo; p->poff[l] = po;
+    wo += (long long)p->up[l] * p->up[l + 1];
+    po += (long long)(1 + p->units[l]) * p->units[l + 1];
+  }
+  p->nflat = wo; p->nparams = po;
+  if (p->W.alloc(wo) || p->G.alloc(wo) || p->Mo.alloc(wo) || p->Vo.alloc(wo) || p->Vel.alloc(wo)) return -1;
+  for (int l = 0; l < p->nl; ++l) {
+    if (p->WT[l].alloc((size_t)p->up[l] * p->up[l + 1])) return -1;
+    if (p->bn[l].alloc(p->up[l + 1])) return -1;
+  }
+  if (p->sumsq_part.alloc((size_t)cdiv(wo, 256)) || p->ring.alloc(MLP_LOSS_RING) || p->st.alloc(1)) return -1;
+  if (set_mstate(p.get(), 0, 0, 1, 0)) return -1;
+  *out = p.release();
+  return 0;
+}
+
+void goctr_mlp_destroy(goctr_mlp* p) { delete p; }
+size_t goctr_mlp_nparams(const goctr_mlp* p) { return p ? (size_t)p->nparams : 0; }
+
+int goctr_mlp_set_params(goctr_mlp* p, const double* theta, size_t n) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(p && theta && n == (size_t)p->nparams, "goctr_mlp_set_params: expected %lld values", p ? p->nparams : 0);
+  std::lock_guard<std::mutex> lk(p->mu);
+  std::vector<double> w((size_t)p->nflat, 0.0);
+  for (int l = 0; l < p->nl; ++l) {
+    const int fi = p->units[l], fo = p->units[l + 1], upo = p->up[l + 1];
+    const double* b = theta + p->poff[l];
+    const double* W = b + fo;
+    std::vector<double> wt((size_t)p->up[l] * upo, 0.0);
+    for (int c = 0; c < fo; ++c) w[(size_t)p->woff[l] + (size_t)fi * upo + c] = b[c];
+    for (int r = 0; r < fi; ++r)
+      for (int c = 0; c < fo; ++c) {
+        w[(size_t)p->woff[l] + (size_t)r * upo + c] = W[(size_t)r * fo + c];
+        wt[(size_t)c * p->up[l] + r] = W[(size_t)r * fo + c];
+      }
+    if (p->WT[l].upload(wt.data(), wt.size())) return -1;
+  }
+  if (p->W.upload(w.data(), w.size())) return -1;
+  // a fresh optimizer (fitStochastic builds one per Fit: basemlp64.go:731-752)
+  GOCTR_HIP(hipMemsetAsync(p->Mo.p, 0, sizeof(double) * p->nflat, engine().stream));
+  GOCTR_HIP(hipMemsetAsync(p->Vo.p, 0, sizeof(double) * p->nflat, engine().stream));
+  GOCTR_HIP(hipMemsetAsync(p->Vel.p, 0, sizeof(double) * p->nflat, engine().stream));
+  return set_mstate(p, 0, 0, 1, 0);
+}
+
+static int unpack(goctr_mlp* p, const DevBuf<double>& src, double* theta) {
+  std::vector<double> w((size_t)p->nflat);
+  if (src.download(w.data(), w.size())) return -1;
+  for (int l = 0; l < p->nl; ++l) {
+    const int fi = p->units[l], fo = p->units[l + 1], upo = p->up[l + 1];
+    double* b = theta + p->poff[l];
+    double* W = b + fo;
+    for (int c = 0; c < fo; ++c) b[c] = w[(size_t)p->woff[l] + (size_t)fi * upo + c];
+    for (int r = 0; r < fi; ++r)
+      for (int c = 0; c < fo; ++c) W[(size_t)r * fo + c] = w[(size_t)p->woff[l] + (size_t)r * upo + c];
+  }
+  return 0;
+}
+
+int goctr_mlp_get_params(goctr_mlp* p, double* theta, size_t n) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(p && theta && n == (size_t)p->nparams, "goctr_mlp_get_params: expected %lld values", p ? p->nparams : 0);
+  std::lock_guard<std::mutex> lk(p->mu);
+  return unpack(p, p->W, theta);
+}
+
+int goctr_mlp_loss_grad(goctr_mlp* p, const double* X, const double* Y, int n, double* loss, double* grads) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(p && X && Y && n > 0, "goctr_mlp_loss_grad: bad arguments");
+  std::lock_guard<std::mutex> lk(p->mu);
+  if (ensure_ws(p, n)) return -1;
+  const int L = p->nl, F = p->units[0], no = p->units[L];
+  DevBuf<double> dX, dY;
+  if (dX.alloc((size_t)n * F, false) || dX.upload(X, (size_t)n * F) || dY.alloc((size_t)n * no, false) ||
+      dY.upload(Y, (size_t)n * no)) return -1;
+  if (weight_decay(p)) return -1;
+  hipLaunchKernelGGL(mlp_copy_f64_kernel, dim3(n), dim3(256), 0, engine().stream, dX.p, dY.p, n, F, p->up[0], no,
+                     p->up[L], p->A[0].p, p->Yb.p);
+  GOCTR_HIP(hipGetLastError());
+  MlpState s;
+  if (get_mstate(p, &s)) return -1;
+  if (forward(p, n, true) || backward(p, n, false, false)) return -1;
+  GOCTR_HIP(hipStreamSynchronize(engine().stream));
+  if (loss && p->ring.download(loss, 1, s.slot % MLP_LOSS_RING)) return -1;
+  if (grads && unpack(p, p->G, grads)) return -1;
+  return 0;
+}
+
+int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(p && X && Y && rows > 0, "goctr_mlp_upload: bad arguments");
+  std::lock_guard<std::mutex> lk(p->mu);
+  const int F = p->units[0], no = p->units[p->nl];
+  if (p->Xr.alloc((size_t)rows * F, false) || p->Xr.upload(X, (size_t)rows * F)) return -1;
+  if (p->Yr.alloc((size_t)rows * no, false) || p->Yr.upload(Y, (size_t)rows * no)) return -1;
+  p->rows = rows;
+  p->perm.release();
+  return ensure_ws(p, p->cfg.batch);
+}
+
+int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(p && p->rows > 0 && n_steps >= 0, "goctr_mlp_train_steps: upload rows first");
+  std::lock_guard<std::mutex> lk(p->mu);
+  const long long nb = p->rows / p->cfg.batch;
+  GOCTR_CHECK(nb > 0, "fewer rows than one batch");
+  MlpState s;
+  if (get_mstate(p, &s)) return -1;
+  if (set_mstate(p, s.t, first_batch % nb, nb, 0)) return -1;
+  for (int i = 0; i < n_steps; ++i)
+    if (train_step_resident(p, true, 0)) return -1;
+  return 0;
+}
+
+int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, const int32_t* perm, double* loss_curve,
+                  int* iters_run) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(p && X && Y && rows > 0, "goctr_mlp_fit: bad arguments");
+  GOCTR_CHECK(rows % p->cfg.batch == 0, "goctr_mlp_fit: rows (%lld) must be a multiple of batch (%d) -- the reference "
+              "leaves stale rows in a short last batch (basemlp64.go:800-802)", (long long)rows, p->cfg.batch);
+  if (goctr_mlp_upload(p, X, Y, rows)) return -1;
+  std::lock_guard<std::mutex> lk(p->mu);
+  const long long nb = rows / p->cfg.batch;
+  GOCTR_CHECK(nb <= MLP_LOSS_RING, "too many batches per epoch for the loss ring");
+  if (perm && p->perm.alloc((size_t)rows, false)) return -1;
+  MlpState s;
+  if (get_mstate(p, &s)) return -1;
+  double best = INFINITY;
+  int no_improve = 0, it = 0;
+  std::vector<double> bl((size_t)nb);
+  for (it = 0; it < p->cfg.max_iter; ++it) {
+    if (perm && p->perm.upload(reinterpret_cast<const int*>(perm) + (int64_t)it * rows, (size_t)rows)) return -1;
+    if (set_mstate(p, s.t + (long long)it * nb, 0, nb, 0)) return -1;
+    for (long long b = 0; b < nb; ++b)
+      if (train_step_resident(p, true, 0)) return -1;
+    GOCTR_HIP(hipStreamSynchronize(engine().stream));
+    if (p->ring.download(bl.data(), (size_t)nb)) return -1;
+    double acc = 0;
+    for (long long b = 0; b < nb; ++b) acc += bl[b] * (double)p->cfg.batch;  // basemlp64.go:806
+    const double loss = acc / (double)rows;
+    if (loss_curve) loss_curve[it] = loss;
+    if (loss > best - p->cfg.tol) no_improve++; else no_improve = 0;  // updateNoImprovementCount :859-895
+    if (loss < best) best = loss;
+    if (no_improve > p->cfg.n_iter_no_change) { it++; break; }        // constant lr schedule: stop (:826-835)
+  }
+  if (iters_run) *iters_run = it;
+  p->perm.release();
+  return 0;
+}
+
+int goctr_mlp_predict(goctr_mlp* p, const float* X, int64_t rows, float* y_out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(p && X && y_out && rows >= 0, "goctr_mlp_predict: bad arguments");
+  if (rows == 0) return 0;
+  std::lock_guard<std::mutex> lk(p->mu);
+  const int L = p->nl, F = p->units[0], no = p->units[L];
+  const int CHUNK = 16384;
+  if (ensure_ws(p, (int)std::min<int64_t>(rows, CHUNK))) return -1;
+  DevBuf<float> dX, dy;
+  if (dX.alloc((size_t)std::min<int64_t>(rows, CHUNK) * F, false) || dy.alloc((size_t)std::min<int64_t>(rows, CHUNK) * no, false)) return -1;
+  for (int64_t s0 = 0; s0 < rows; s0 += CHUNK) {
+    const int n = (int)std::min<int64_t>(CHUNK, rows - s0);
+    if (dX.upload(X + s0 * F, (size_t)n * F)) return -1;
+    hipLaunchKernelGGL(mlp_gather_kernel, dim3(n), dim3(256), 0, engine().stream, dX.p, (const float*)nullptr,
+                       (const int*)nullptr, p->st.p, 0LL, 0, n, F, p->up[0], no, p->up[L], p->A[0].p, (double*)nullptr);
+    GOCTR_HIP(hipGetLastError());
+    if (forward(p, n, false)) return -1;
+    hipLaunchKernelGGL(mlp_narrow_kernel, dim3((unsigned)cdiv((int64_t)n * no, 256)), dim3(256), 0, engine().stream,
+                       p->A[L].p, n, p->up[L], no, dy.p);
+    GOCTR_HIP(hipGetLastError());
+    if (dy.download(y_out + s0 * no, (size_t)n * no)) return -1;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+"""GPU parity tests for the sklearn-port MLP path (float64 on v_mfma_f64_16x16x4_f64) against the CPU
+oracle (oracle/orc_sklmlp.c).  Tolerance: 1e-9 relative -- both sides are float64 and differ only in
+summation order (and pow() vs the reference's running beta products in the Adam quirk Q7)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def close(a, b, rtol=RTOL, atol=1e-13):
+    return np.allclose(a, b, rtol=rtol, atol=atol)
+
+
+def make(rng, n, F):
+    X = rng.random((n, F)).astype(np.float32)
+    Y = ((X[:, 0] + X[:, 1]) > 1).astype(np.float32).reshape(-1, 1)
+    return X, Y
+
+
+@pytest.mark.parametrize("act", ["relu", "logistic", "tanh", "identity"])
+@pytest.mark.parametrize("units", [[6, 4, 1], [281, 100, 1], [40, 33, 17, 1]])
+def test_loss_grad(oracle, act, units):
+    from goctr_amd import mlp as gmlp
+    rng = np.random.default_rng(0)
+    clf = gmlp.MLPClassifier(units[1:-1], act, "adam", 1e-2)
+    theta = clf.init_params(units, rng) * 0.5
+    clf.create(units, 64, theta)
+    X, Y = make(rng, 64, units[0])
+    loss, g = clf.loss_grad(X, Y)
+    cfg = oracle.mlp_cfg(units, act, alpha=1e-2)
+    rloss, rg = oracle.mlp_loss_grad(cfg, theta.copy(), X.astype(np.float64), Y.astype(np.float64))
+    assert loss == pytest.approx(rloss, rel=RTOL)
+    assert close(g, rg)
+
+
+def test_predict(oracle):
+    from goctr_amd import mlp as gmlp
+    rng = np.random.default_rng(1)
+    units = [281, 100, 1]
+    clf = gmlp.MLPClassifier([100], "relu", "adam", 1e-5)
+    theta = clf.init_params(units, rng)
+    clf.create(units, 200, theta)
+    X, _ = make(rng, 1237, 281)
+    y = clf.Predict(X)
+    ref = oracle.mlp_predict(oracle.mlp_cfg(units, "relu", 1e-5), theta, X.astype(np.float64))
+    assert y.dtype == np.float32 and y.shape == (1237, 1)
+    assert np.array_equal(y, ref.astype(np.float32)) or np.max(np.abs(y - ref)) < 1e-7
+
+
+@pytest.mark.parametrize("solver", ["adam", "sgd"])
+def test_fit_matches_oracle(oracle, solver):
+    """fitStochastic with a given batch order: loss curve + final parameters (incl. the Adam quirk Q7)"""
+    from goctr_amd import mlp as gmlp
+    rng = np.random.default_rng(2)
+    units = [20, 12, 1]
+    n, batch, iters = 600, 200, 6
+    X, Y = make(rng, n, 20)
+    clf = gmlp.MLPClassifier([12], "relu", solver, 1e-4)
+    clf.BatchSize, clf.MaxIter, clf.Tol = batch, iters, -1.0          # never stop early
+    theta0 = clf.init_params(units, rng)
+    perm = np.stack([rng.permutation(n) for _ in range(iters)]).astype(np.int32)
+    clf.Fit(X, Y, theta0=theta0.copy(), perm=perm)
+    cfg = oracle.mlp_cfg(units, "relu", alpha=1e-4)
+    theta = theta0.copy()
+    opt = oracle.MlpOptimizer(solver, theta.size)
+    ref = oracle.mlp_fit(cfg, theta, opt, X.astype(np.float64), Y.astype(np.float64), batch, iters, tol=-1.0, perm=perm)
+    assert close(clf.LossCurve, ref, rtol=1e-8)
+    assert close(clf.get_params(), theta, rtol=1e-7, atol=1e-10)
+
+
+def test_fit_stops_on_tolerance(oracle):
+    from goctr_amd import mlp as gmlp
+    rng = np.random.default_rng(3)
+    units = [8, 6, 1]
+    X, Y = make(rng, 400, 8)
+    clf = gmlp.MLPClassifier([6], "relu", "adam", 1e-5)
+    clf.BatchSize, clf.MaxIter, clf.Tol, clf.Shuffle = 200, 60, 1e-2, False
+    theta0 = clf.init_params(units, rng)
+    clf.Fit(X, Y, theta0=theta0.copy())
+    theta = theta0.copy()
+    ref = oracle.mlp_fit(oracle.mlp_cfg(units, "relu", 1e-5), theta, oracle.MlpOptimizer("adam", theta.size),
+                         X.astype(np.float64), Y.astype(np.float64), 200, 60, tol=1e-2)
+    assert clf.NIter == len(ref) < 60
+
+
+def test_batchnorm_and_weight_decay(oracle):
+    from goctr_amd import mlp as gmlp
+    rng = np.random.default_rng(4)
+    units = [10, 7, 1]
+    clf = gmlp.MLPClassifier([7], "relu", "adam", 1e-3)
+    clf.BatchNormalize, clf.WeightDecay = True, 1e-3
+    theta = clf.init_params(units, rng)
+    clf.create(units, 50, theta)
+    X, Y = make(rng, 50, 10)
+    loss, g = clf.loss_grad(X, Y)
+    cfg = oracle.mlp_cfg(units, "relu", alpha=1e-3, batch_normalize=True, weight_decay=1e-3)
+    th = theta.copy()
+    rloss, rg = oracle.mlp_loss_grad(cfg, th, X.astype(np.float64), Y.astype(np.float64))
+    assert loss == pytest.approx(rloss, rel=RTOL) and close(g, rg)
+    assert close(clf.get_params(), th)                      # theta *= (1 - wd) happened on both sides
+
+
+def test_wrappers_and_hyperparameter_errors():
+    from goctr_amd import mlp as gmlp
+    from goctr_amd.recommend import SampleInfo, TrainSample
+    rng = np.random.default_rng(5)
+    X, Y = make(rng, 800, 12)
+    clf = gmlp.NewMLPClassifier([16], "relu", "adam", 1e-5)       # main.go:39-46 style
+    clf.MaxIter, clf.RandomState, clf.LearningRateInit = 200, np.random.default_rng(7), 0.01
+    pred = gmlp.SimpleMlpFitWrap(clf).Fit(TrainSample(X.ravel(), Y.ravel(), 800, 12, SampleInfo()))
+    p = pred.Predict(X)
+    from sklearn.metrics import roc_auc_score
+    assert roc_auc_score(Y.ravel(), p.ravel()) > 0.85
+    assert clf.LossCurve[-1] < clf.LossCurve[0]
+    bad = gmlp.MLPClassifier([4], "swish", "adam", 1e-5)
+    with pytest.raises(ValueError):
+        bad.Fit(X, Y)
+    with pytest.raises(ValueError):
+        gmlp.MLPClassifier([4], "relu", "lbfgs", 1e-5).Fit(X, Y)
+
+
+def test_full_size_cfg2_properties():
+    """BASELINE config 2 shape ([281,100,1], batch 4096): determinism and learning on a separable rule"""
+    from goctr_amd import mlp as gmlp
+    rng = np.random.default_rng(6)
+    X, Y = make(rng, 1 << 15, 281)
+    res = []
+    for _ in range(2):
+        clf = gmlp.MLPClassifier([100], "relu", "adam", 1e-5)
+        units = [281, 100, 1]
+        clf.create(units, 4096, clf.init_params(units, np.random.default_rng(8)))
+        clf.upload(X, Y)
+        clf.train_steps(64)
+        res.append(clf.get_params())
+    assert np.array_equal(res[0], res[1])
+    l0, _ = clf.loss_grad(X[:4096], Y[:4096])
+    clf.train_steps(200)
+    l1, _ = clf.loss_grad(X[:4096], Y[:4096])
+    assert np.isfinite(l1) and l1 < l0
