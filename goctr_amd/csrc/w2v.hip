@@ -1,18 +1,449 @@
-// w2v.hip -- item2vec engine (float64).  TEMPORARY stubs: every entry point fails loudly.
+// w2v.hip -- item2vec engine (float64, like the reference) + its C-ABI.
+//
+// Replaces embedding.TrainEmbedding (feature/embedding/wordemb.go:9-32, reference = auxten/go-ctr) ->
+// word2vec.Train / train / trainPerThread / observe (model/word2vec/word2vec.go:90-243),
+// skipGram.trainOne (model/word2vec/model.go:48-78), hierarchicalSoftmax.optim and
+// negativeSampling.optim (model/word2vec/optimizer.go:52-129), the Huffman tree
+// (corpus/dictionary/huffman.go:23-57, node/node.go:26-43), the sigmoid table (sigmoid_table.go) and the
+// LCG (modelutil/modelutil.go:21-29).
+//
+// Two execution modes:
+//   deterministic  ONE wavefront walks the doc in order; lane d owns embedding lane d; the dot product
+//                  is summed in the reference's j = 0..dim-1 order (v_readlane broadcast) so every float64
+//                  is bit-identical to a single-goroutine run of the reference algorithm.
+//   hogwild        `streams` lane-groups (dim rounded up to a power of two lanes each) walk contiguous
+//                  slices of the doc concurrently and update the shared vectors without synchronisation,
+//                  exactly the reference's goroutine scheme (word2vec.go:151-175) with ~10^4 "goroutines".
+//                  The learning-rate observer is replaced by a per-stream estimate of the global word
+//                  count (no per-word channel send / atomic).
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <numeric>
+
 #include "common.h"
+
 using namespace goctr;
-#define NOTYET(name) do { set_error(name ": not implemented in this build"); return -1; } while (0)
-extern "C" {
-void goctr_w2v_cfg_default(goctr_w2v_cfg* c) { memset(c, 0, sizeof *c); }
-int goctr_w2v_create(const goctr_w2v_cfg*, int64_t, const int64_t*, goctr_w2v**) { NOTYET("goctr_w2v_create"); }
-void goctr_w2v_destroy(goctr_w2v*) {}
-int goctr_w2v_set_param(goctr_w2v*, const double*) { NOTYET("goctr_w2v_set_param"); }
-int goctr_w2v_set_aux(goctr_w2v*, const double*) { NOTYET("goctr_w2v_set_aux"); }
-int goctr_w2v_get_param(goctr_w2v*, double*) { NOTYET("goctr_w2v_get_param"); }
-int goctr_w2v_get_aux(goctr_w2v*, double*) { NOTYET("goctr_w2v_get_aux"); }
-int goctr_w2v_get_paths(goctr_w2v*, int64_t*, int32_t*, uint8_t*, int64_t, int64_t*) { NOTYET("goctr_w2v_get_paths"); }
-int goctr_w2v_train(goctr_w2v*, const int32_t*, int64_t, int64_t, const uint8_t*, double*) { NOTYET("goctr_w2v_train"); }
-int goctr_w2v_upload_doc(goctr_w2v*, const int32_t*, int64_t, const uint8_t*) { NOTYET("goctr_w2v_upload_doc"); }
-int goctr_w2v_train_resident(goctr_w2v*, int64_t, double*) { NOTYET("goctr_w2v_train_resident"); }
-int goctr_w2v_export_f32(goctr_w2v*, float*) { NOTYET("goctr_w2v_export_f32"); }
+
+namespace {
+
+struct W2vDev {
+  int dim, window, optimizer, neg;
+  double init_lr, min_lr;
+  long long update_lr_batch;
+  long long V;
+  double* param; double* aux;
+  const long long* path_off; const int* path_nodes; const unsigned char* path_codes;
+  const double* sigtab;
+  const int* doc; const unsigned char* keep;  // keep may be null
+  long long n_words, corpus_len;
+  double* lr;              // in/out (deterministic) / in (hogwild)
+  unsigned long long* lcg; // shared LCG state (deterministic)
+  long long* trained;      // observer counter
+};
+
+__device__ __forceinline__ int lcg_next(unsigned long long& next, int value) {
+  next = next * 25214903917ULL + 11ULL;  // modelutil.go:26-29
+  return (int)(next % (unsigned long long)value);
 }
+
+__device__ __forceinline__ double sig_lookup(const double* tab, double x) {
+  return tab[(int)((x + 6.0) * (1000.0 / 6.0 / 2.0))];  // sigmoid_table.go:43-45
+}
+
+// wave-uniform sequential sum of the first `dim` lanes' values, j = 0..dim-1 (bit-exact vs the Go loop)
+__device__ __forceinline__ double seq_sum(double v, int dim) {
+  double s = 0;
+  for (int j = 0; j < dim; ++j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+    s += __hiloint2double(hi, lo);
+  }
+  return s;
+}
+
+// ---- deterministic single-stream pass: one block of 64 threads
+__global__ __launch_bounds__(64) void w2v_deterministic_kernel(W2vDev a) {
+  __shared__ double tab[1000];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 1000; i += 64) tab[i] = a.sigtab[i];
+  __syncthreads();
+  const int dim = a.dim, win = a.window;
+  const bool act = lane < dim;
+  unsigned long long next = *a.lcg;
+  double lr = *a.lr;
+  long long cnt = *a.trained;
+  for (long long pos = 0; pos < a.n_words; ++pos) {
+    const int id = a.doc[pos];
+    if (!a.keep || a.keep[pos]) {
+      const int del = lcg_next(next, win);  // model.go:59
+      for (int w = del; w < win * 2 + 1 - del; ++w) {
+        if (w == win) continue;
+        const long long c = pos - win + w;
+        if (c < 0 || c >= a.n_words) continue;
+        const int ctxid = a.doc[c];
+        double* ctxp = a.param + (long long)ctxid * dim + lane;
+        double ctx = act ? *ctxp : 0.0, tmp = 0.0;
+        if (a.optimizer == 0) {  // hierarchical softmax, optimizer.go:107-129
+          for (long long i = a.path_off[id]; i < a.path_off[id + 1]; ++i) {
+            double* pvp = a.aux + (long long)a.path_nodes[i] * dim + lane;
+            double pv = act ? *pvp : 0.0;
+            const double inner = seq_sum(ctx * pv, dim);
+            if (inner <= -6.0 || inner >= 6.0) break;  // quirk Q13: `return`
+            const double g = (1.0 - (double)a.path_codes[i] - sig_lookup(tab, inner)) * lr;
+            tmp += g * pv;
+            pv += g * ctx;
+            if (act) *pvp = pv;
+          }
+        } else {  // negative sampling, optimizer.go:52-91
+          for (int n = -1; n < a.neg; ++n) {
+            int label, picked;
+            if (n == -1) { label = 1; picked = id; }
+            else {
+              label = 0;
+              picked = lcg_next(next, (int)a.V);
+              if (id == picked) continue;
+            }
+            double* rp = a.aux + (long long)picked * dim + lane;
+            double rnd = act ? *rp : 0.0;
+            const double inner = seq_sum(rnd * ctx, dim);
+            double g;
+            if (inner <= -6.0) g = ((double)(label - 0)) * lr;
+            else if (inner >= 6.0) g = ((double)(label - 1)) * lr;
+            else g = ((double)label - sig_lookup(tab, inner)) * lr;
+            tmp += g * rnd;
+            rnd += g * ctx;
+            if (act) *rp = rnd;
+          }
+        }
+        ctx += tmp;  // model.go:74-76
+        if (act) *ctxp = ctx;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+    }
+    ++cnt;  // observe(): word2vec.go:223-233
+    if (cnt % a.update_lr_batch == 0) {
+      if (lr < a.min_lr) lr = a.min_lr;
+      else lr = a.init_lr * (1.0 - (double)cnt / (double)a.corpus_len);
+    }
+  }
+  if (lane == 0) { *a.lcg = next; *a.lr = lr; *a.trained = cnt; }
+}
+
+template <int GS>
+__device__ __forceinline__ double group_sum64(double v) {
+#pragma unroll
+  for (int o = 1; o < GS; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- hogwild: one lane-group (GS lanes) per stream = per contiguous doc slice (IndexPerThread,
+// modelutil.go:32-41).  Window clipping is against the slice (quirk Q18).
+template <int GS>
+__global__ __launch_bounds__(256) void w2v_hogwild_kernel(W2vDev a, int streams, const long long* slice_idx) {
+  __shared__ double tab[1000];
+  for (int i = threadIdx.x; i < 1000; i += 256) tab[i] = a.sigtab[i];
+  __syncthreads();
+  constexpr int GPB = 256 / GS;  // groups per block
+  const int g = blockIdx.x * GPB + threadIdx.x / GS;
+  const int l = threadIdx.x % GS;
+  const int dim = a.dim, win = a.window;
+  const bool act = l < dim && g < streams;
+  const int gs = g < streams ? g : streams - 1;
+  const long long lo = slice_idx[gs], hi = g < streams ? slice_idx[gs + 1] : lo;  // idle groups run 0 words
+  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * (unsigned long long)(g + 1);  // per-stream LCG
+  const double lr0 = *a.lr;
+  double lr = lr0;
+  long long cnt = 0;
+  const int* doc = a.doc + lo;
+  const long long len = hi - lo;
+  for (long long pos = 0; pos < len; ++pos) {
+    const int id = doc[pos];
+    if (!a.keep || a.keep[lo + pos]) {
+      const int del = lcg_next(next, win);
+      for (int w = del; w < win * 2 + 1 - del; ++w) {
+        if (w == win) continue;
+        const long long c = pos - win + w;
+        if (c < 0 || c >= len) continue;
+        double* ctxp = a.param + (long long)doc[c] * dim + l;
+        double ctx = act ? *ctxp : 0.0, tmp = 0.0;
+        if (a.optimizer == 0) {
+          const long long p0 = a.path_off[id], p1 = a.path_off[id + 1];
+          double* pvp = p0 < p1 ? a.aux + (long long)a.path_nodes[p0] * dim + l : nullptr;
+          double pv = (act && pvp) ? *pvp : 0.0;
+          for (long long i = p0; i < p1; ++i) {
+            // prefetch the next node vector while this one is processed (the path is known up front)
+            double* nvp = i + 1 < p1 ? a.aux + (long long)a.path_nodes[i + 1] * dim + l : nullptr;
+            const double nv = (act && nvp) ? *nvp : 0.0;
+            const double inner = group_sum64<GS>(ctx * pv);
+            if (inner <= -6.0 || inner >= 6.0) break;
+            const double gg = (1.0 - (double)a.path_codes[i] - sig_lookup(tab, inner)) * lr;
+            tmp += gg * pv;
+            pv += gg * ctx;
+            if (act) *pvp = pv;
+            pvp = nvp; pv = nv;
+          }
+        } else {
+          for (int n = -1; n < a.neg; ++n) {
+            int label, picked;
+            if (n == -1) { label = 1; picked = id; }
+            else {
+              label = 0;
+              picked = lcg_next(next, (int)a.V);
+              if (id == picked) continue;
+            }
+            double* rp = a.aux + (long long)picked * dim + l;
+            double rnd = act ? *rp : 0.0;
+            const double inner = group_sum64<GS>(rnd * ctx);
+            double gg;
+            if (inner <= -6.0) gg = ((double)(label - 0)) * lr;
+            else if (inner >= 6.0) gg = ((double)(label - 1)) * lr;
+            else gg = ((double)label - sig_lookup(tab, inner)) * lr;
+            tmp += gg * rnd;
+            rnd += gg * ctx;
+            if (act) *rp = rnd;
+          }
+        }
+        ctx += tmp;
+        if (act) *ctxp = ctx;
+      }
+    }
+    ++cnt;
+    // observer estimate: all streams advance at the same rate => global count ~= cnt * streams
+    const long long est = cnt * (long long)streams, prev = (cnt - 1) * (long long)streams;
+    if (est / a.update_lr_batch != prev / a.update_lr_batch) {
+      const long long at = est / a.update_lr_batch * a.update_lr_batch;
+      if (lr < a.min_lr) lr = a.min_lr;
+      else lr = a.init_lr * (1.0 - (double)at / (double)a.corpus_len);
+    }
+  }
+  if (g == 0 && l == 0) *a.trained = a.n_words;
+  if (g == streams - 1 && l == 0) *a.lr = lr;  // the lr the last words saw
+}
+
+__global__ void w2v_narrow_kernel(const double* p, long long n, float* out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (float)p[i];  // word2vec.go:315-318
+}
+
+// Huffman tree with the reference's tie-breaking (huffman.go:23-57): leaves stable-sorted by count; the
+// merged node goes in front of every node of equal value.  Two queues: sorted leaves, and merged nodes
+// (values non-decreasing) kept as runs of equal value that are consumed newest-first.
+void build_huffman(const int64_t* counts, int64_t V, int max_depth, std::vector<long long>& off,
+                   std::vector<int>& nodes, std::vector<unsigned char>& codes) {
+  off.assign((size_t)V + 1, 0);
+  nodes.clear(); codes.clear();
+  if (V <= 0) return;
+  const int64_t total = 2 * V - 1;
+  std::vector<int64_t> val((size_t)total);
+  std::vector<int> parent((size_t)total, -1);
+  std::vector<unsigned char> code((size_t)total, 0);
+  std::vector<int> order((size_t)V);
+  std::iota(order.begin(), order.end(), 0);
+  for (int64_t i = 0; i < V; ++i) val[i] = counts[i];
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return counts[x] < counts[y]; });
+  struct Run { int64_t v; std::vector<int> stack; };
+  std::vector<Run> runs;
+  size_t rfront = 0;
+  int64_t lq = 0;
+  for (int64_t k = 0; k + 1 < V; ++k) {
+    int pick[2];
+    for (int s = 0; s < 2; ++s) {
+      const bool have_leaf = lq < V, have_m = rfront < runs.size();
+      const bool take_m = have_leaf && have_m ? runs[rfront].v <= val[order[lq]] : have_m;
+      if (take_m) {
+        pick[s] = runs[rfront].stack.back();
+        runs[rfront].stack.pop_back();
+        if (runs[rfront].stack.empty()) ++rfront;
+      } else {
+        pick[s] = order[lq++];
+      }
+    }
+    const int id = (int)(V + k);
+    val[id] = val[pick[0]] + val[pick[1]];
+    code[pick[0]] = 0; code[pick[1]] = 1;
+    parent[pick[0]] = id; parent[pick[1]] = id;
+    if (rfront < runs.size() && runs.back().v == val[id]) runs.back().stack.push_back(id);
+    else runs.push_back(Run{val[id], {id}});
+  }
+  std::vector<int> tmp;
+  for (int64_t i = 0; i < V; ++i) {
+    off[i] = (long long)nodes.size();
+    tmp.clear();
+    for (int p = (int)i; p >= 0; p = parent[p]) tmp.push_back(p);  // leaf .. root
+    const int64_t len = (int64_t)tmp.size();
+    const int64_t depth = std::min<int64_t>(max_depth, len);  // GetPath keeps cache[:depth] (node.go:39-42)
+    for (int64_t j = 0; j + 1 < depth; ++j) {
+      nodes.push_back(tmp[len - 1 - j] - (int)V);
+      codes.push_back(code[tmp[len - 2 - j]]);
+    }
+  }
+  off[V] = (long long)nodes.size();
+}
+
+}  // namespace
+
+struct goctr_w2v {
+  goctr_w2v_cfg cfg{};
+  int64_t V = 0;
+  int64_t aux_rows = 0;
+  DevBuf<double> param, aux, sigtab, lr;
+  DevBuf<long long> path_off, trained, slice_idx;
+  DevBuf<int> path_nodes, doc;
+  DevBuf<unsigned char> path_codes, keep;
+  DevBuf<unsigned long long> lcg;
+  std::vector<long long> h_off; std::vector<int> h_nodes; std::vector<unsigned char> h_codes;
+  int64_t n_words = 0; bool has_keep = false;
+  std::mutex mu;
+};
+
+namespace {
+
+int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
+  Engine& e = engine();
+  GOCTR_CHECK(w->n_words > 0, "goctr_w2v: no doc uploaded");
+  if (w->lr.upload(lr_io, 1)) return -1;
+  long long zero = 0;
+  if (w->trained.upload(&zero, 1)) return -1;  // a fresh observer per iteration (word2vec.go:159-160)
+  W2vDev a{};
+  a.dim = w->cfg.dim; a.window = w->cfg.window; a.optimizer = w->cfg.optimizer; a.neg = w->cfg.neg_samples;
+  a.init_lr = w->cfg.init_lr; a.min_lr = w->cfg.min_lr; a.update_lr_batch = w->cfg.update_lr_batch; a.V = w->V;
+  a.param = w->param.p; a.aux = w->aux.p; a.path_off = w->path_off.p; a.path_nodes = w->path_nodes.p;
+  a.path_codes = w->path_codes.p; a.sigtab = w->sigtab.p; a.doc = w->doc.p; a.keep = w->has_keep ? w->keep.p : nullptr;
+  a.n_words = w->n_words; a.corpus_len = corpus_len; a.lr = w->lr.p; a.lcg = w->lcg.p; a.trained = w->trained.p;
+  if (w->cfg.deterministic) {
+    hipLaunchKernelGGL(w2v_deterministic_kernel, dim3(1), dim3(64), 0, e.stream, a);
+    GOCTR_HIP(hipGetLastError());
+  } else {
+    int streams = w->cfg.streams > 0 ? w->cfg.streams : 8192;
+    if ((int64_t)streams > w->n_words) streams = (int)w->n_words;
+    // IndexPerThread (modelutil.go:32-41)
+    std::vector<long long> idx((size_t)streams + 1);
+    idx[0] = 0; idx[streams] = w->n_words;
+    for (int i = 1; i < streams; ++i) idx[i] = idx[i - 1] + (long long)std::trunc((double)((w->n_words + i) / streams));
+    if (w->slice_idx.alloc(idx.size(), false) || w->slice_idx.upload(idx.data(), idx.size())) return -1;
+    const int dim = w->cfg.dim;
+#define GOCTR_HOG(GS) hipLaunchKernelGGL((w2v_hogwild_kernel<GS>), dim3((unsigned)cdiv(streams, 256 / GS)), dim3(256), 0, e.stream, a, streams, w->slice_idx.p)
+    if (dim <= 8) GOCTR_HOG(8);
+    else if (dim <= 16) GOCTR_HOG(16);
+    else if (dim <= 32) GOCTR_HOG(32);
+    else GOCTR_HOG(64);
+#undef GOCTR_HOG
+    GOCTR_HIP(hipGetLastError());
+  }
+  GOCTR_HIP(hipStreamSynchronize(e.stream));
+  return w->lr.download(lr_io, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+void goctr_w2v_cfg_default(goctr_w2v_cfg* c) {
+  memset(c, 0, sizeof *c);  // options.go:38-58 + wordemb.go:10-18
+  c->dim = 16; c->window = 5; c->optimizer = 0; c->model = 0; c->neg_samples = 5;
+  c->init_lr = 0.025; c->min_lr = 0.025 * 1.0e-4; c->update_lr_batch = 100000; c->max_depth = 100;
+  c->deterministic = 0; c->streams = 8192;
+}
+
+int goctr_w2v_create(const goctr_w2v_cfg* cfg, int64_t V, const int64_t* counts, goctr_w2v** out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(cfg && counts && out && V > 0, "goctr_w2v_create: bad arguments");
+  GOCTR_CHECK(cfg->dim > 0 && cfg->dim <= 64, "goctr_w2v: dim %d not in 1..64", cfg->dim);
+  GOCTR_CHECK(cfg->window > 0 && cfg->max_depth > 0 && cfg->update_lr_batch > 0, "goctr_w2v: bad options");
+  GOCTR_CHECK(cfg->model == 0, "goctr_w2v: only skip-gram has a device path (TrainEmbedding hard-codes it, wordemb.go:12)");
+  GOCTR_CHECK(cfg->optimizer == 0 || cfg->optimizer == 1, "goctr_w2v: optimizer must be hs (0) or ns (1)");
+  std::unique_ptr<goctr_w2v> w(new goctr_w2v);
+  w->cfg = *cfg; w->V = V;
+  build_huffman(counts, V, cfg->max_depth, w->h_off, w->h_nodes, w->h_codes);
+  w->aux_rows = cfg->optimizer == 0 ? std::max<int64_t>(V - 1, 1) : V;
+  if (w->param.alloc((size_t)V * cfg->dim) || w->aux.alloc((size_t)w->aux_rows * cfg->dim)) return -1;
+  if (w->path_off.alloc(w->h_off.size(), false) || w->path_off.upload(w->h_off.data(), w->h_off.size())) return -1;
+  if (w->path_nodes.alloc(std::max<size_t>(w->h_nodes.size(), 1)) ||
+      (!w->h_nodes.empty() && w->path_nodes.upload(w->h_nodes.data(), w->h_nodes.size()))) return -1;
+  if (w->path_codes.alloc(std::max<size_t>(w->h_codes.size(), 1)) ||
+      (!w->h_codes.empty() && w->path_codes.upload(w->h_codes.data(), w->h_codes.size()))) return -1;
+  std::vector<double> tab(1000);
+  for (int i = 0; i < 1000; ++i) {  // sigmoid_table.go:28-38
+    const double ev = std::exp(((double)i / 1000.0 * 2. - 1.) * 6.0);
+    tab[i] = ev / (ev + 1.);
+  }
+  if (w->sigtab.alloc(1000, false) || w->sigtab.upload(tab.data(), 1000)) return -1;
+  unsigned long long one = 1;  // modelutil.go:21-23: next starts at 1
+  if (w->lcg.alloc(1, false) || w->lcg.upload(&one, 1)) return -1;
+  if (w->lr.alloc(1) || w->trained.alloc(1)) return -1;
+  *out = w.release();
+  return 0;
+}
+
+void goctr_w2v_destroy(goctr_w2v* w) { delete w; }
+
+int goctr_w2v_set_param(goctr_w2v* w, const double* param) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(w && param, "goctr_w2v_set_param: null argument");
+  return w->param.upload(param, (size_t)w->V * w->cfg.dim);
+}
+int goctr_w2v_set_aux(goctr_w2v* w, const double* aux) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(w && aux, "goctr_w2v_set_aux: null argument");
+  return w->aux.upload(aux, (size_t)w->aux_rows * w->cfg.dim);
+}
+int goctr_w2v_get_param(goctr_w2v* w, double* param) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(w && param, "goctr_w2v_get_param: null argument");
+  return w->param.download(param, (size_t)w->V * w->cfg.dim);
+}
+int goctr_w2v_get_aux(goctr_w2v* w, double* aux) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(w && aux, "goctr_w2v_get_aux: null argument");
+  return w->aux.download(aux, (size_t)w->aux_rows * w->cfg.dim);
+}
+
+int goctr_w2v_get_paths(goctr_w2v* w, int64_t* path_off, int32_t* nodes, uint8_t* codes, int64_t cap, int64_t* total) {
+  GOCTR_CHECK(w, "goctr_w2v_get_paths: null handle");
+  if (total) *total = (int64_t)w->h_nodes.size();
+  if (path_off) for (size_t i = 0; i < w->h_off.size(); ++i) path_off[i] = w->h_off[i];
+  const int64_t n = std::min<int64_t>(cap, (int64_t)w->h_nodes.size());
+  if (nodes) memcpy(nodes, w->h_nodes.data(), sizeof(int32_t) * (size_t)n);
+  if (codes) memcpy(codes, w->h_codes.data(), (size_t)n);
+  return 0;
+}
+
+int goctr_w2v_upload_doc(goctr_w2v* w, const int32_t* doc, int64_t n_words, const uint8_t* keep_mask) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(w && doc && n_words > 0, "goctr_w2v_upload_doc: bad arguments");
+  std::lock_guard<std::mutex> lk(w->mu);
+  for (int64_t i = 0; i < n_words; ++i)
+    GOCTR_CHECK(doc[i] >= 0 && doc[i] < w->V, "doc[%lld] = %d outside the dictionary (V = %lld)", (long long)i, doc[i], (long long)w->V);
+  if (w->doc.alloc((size_t)n_words, false) || w->doc.upload(doc, (size_t)n_words)) return -1;
+  w->has_keep = keep_mask != nullptr;
+  if (keep_mask && (w->keep.alloc((size_t)n_words, false) || w->keep.upload(keep_mask, (size_t)n_words))) return -1;
+  w->n_words = n_words;
+  return 0;
+}
+
+int goctr_w2v_train_resident(goctr_w2v* w, int64_t corpus_len, double* lr) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(w && lr && corpus_len > 0, "goctr_w2v_train_resident: bad arguments");
+  std::lock_guard<std::mutex> lk(w->mu);
+  return run_pass(w, corpus_len, lr);
+}
+
+int goctr_w2v_train(goctr_w2v* w, const int32_t* doc, int64_t n_words, int64_t corpus_len, const uint8_t* keep_mask,
+                    double* lr) {
+  if (goctr_w2v_upload_doc(w, doc, n_words, keep_mask)) return -1;
+  return goctr_w2v_train_resident(w, corpus_len, lr);
+}
+
+int goctr_w2v_export_f32(goctr_w2v* w, float* out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(w && out, "goctr_w2v_export_f32: null argument");
+  const long long n = (long long)w->V * w->cfg.dim;
+  DevBuf<float> d;
+  if (d.alloc((size_t)n, false)) return -1;
+  hipLaunchKernelGGL(w2v_narrow_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, engine().stream, w->param.p, n, d.p);
+  GOCTR_HIP(hipGetLastError());
+  return d.download(out, (size_t)n);
+}
+
+}  // extern "C"

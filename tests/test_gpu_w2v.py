@@ -1,0 +1,111 @@
+"""GPU parity tests for item2vec (SkipGram + hierarchical softmax / negative sampling, float64).
+Deterministic single-stream mode must be BIT-EXACT against the oracle (given init matrix, doc, keep mask
+and the LCG stream); Hogwild mode is racy by design in the reference too and is checked statistically."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def corpus(rng, V, n, zipf=1.3):
+    p = 1.0 / np.arange(1, V + 1) ** zipf
+    p /= p.sum()
+    return rng.choice(V, size=n, p=p).astype(np.int32)
+
+
+@pytest.mark.parametrize("V", [1, 2, 3, 50, 999])
+def test_huffman_paths_match_oracle(oracle, V):
+    from goctr_amd import embedding as ge
+    rng = np.random.default_rng(V)
+    counts = rng.integers(1, 5, size=V)            # many ties
+    m = ge.Word2Vec(dim=4).create(counts)
+    off, nodes, codes = m.get_paths()
+    roff, rnodes, rcodes = oracle.huffman_paths(counts, slow=True)       # the literal huffman.go restatement
+    assert np.array_equal(off, roff) and np.array_equal(nodes, rnodes) and np.array_equal(codes, rcodes)
+
+
+@pytest.mark.parametrize("opt", ["hs", "ns"])
+@pytest.mark.parametrize("dim", [4, 16, 10])
+def test_deterministic_bit_exact(oracle, opt, dim):
+    from goctr_amd import embedding as ge
+    rng = np.random.default_rng(1)
+    V, n = 40, 3000
+    doc = corpus(rng, V, n)
+    counts = np.bincount(doc, minlength=V) + 1
+    keep = (rng.random(n) < 0.9).astype(np.uint8)
+    p0 = (rng.random((V, dim)) - 0.5) / dim
+    aux0 = (rng.random((V, dim)) - 0.5) / dim if opt == "ns" else None
+    m = ge.Word2Vec(dim=dim, optimizer=opt, deterministic=True)
+    m.create(counts, p0, aux0)
+    lr = m.train_pass(doc, n + 17, keep, lr=0.025)
+    # oracle
+    cfg = oracle.w2v_cfg(dim=dim, optimizer=opt, update_lr_batch=100000)
+    paths = oracle.huffman_paths(counts)
+    rp = p0.copy()
+    raux = aux0.copy() if aux0 is not None else np.zeros((V - 1, dim))
+    rlr, cnt = oracle.w2v_train_slice(cfg, doc, 0, n, keep, rp, raux, paths, oracle.sigmoid_table(), oracle.Lcg(1),
+                                      0.025, 0, n + 17)
+    assert np.array_equal(m.get_param(), rp)         # bit-exact float64
+    assert np.array_equal(m.get_aux(), raux)
+    assert lr == rlr
+    assert np.array_equal(m.export_f32(), rp.astype(np.float32))          # GenEmbeddingMap32 narrowing
+
+
+def test_deterministic_lr_schedule_and_second_iteration(oracle):
+    from goctr_amd import embedding as ge
+    rng = np.random.default_rng(2)
+    V, n, dim = 30, 2500, 8
+    doc = corpus(rng, V, n)
+    counts = np.bincount(doc, minlength=V) + 1
+    p0 = (rng.random((V, dim)) - 0.5) / dim
+    # small update batch so the observer (word2vec.go:223-233) fires many times
+    m = ge.Word2Vec(dim=dim, deterministic=True, update_lr_batch=100)
+    m.create(counts, p0)
+    lr1 = m.train_pass(doc, n, None, lr=0.025)
+    lr2 = m.train_pass(doc, n, None, lr=lr1)            # second iteration: LCG state and vectors carry over
+    ocfg = oracle.w2v_cfg(dim=dim, update_lr_batch=100)
+    paths = oracle.huffman_paths(counts)
+    rp, rn, lcg = p0.copy(), np.zeros((V - 1, dim)), oracle.Lcg(1)
+    r1, _ = oracle.w2v_train_slice(ocfg, doc, 0, n, None, rp, rn, paths, oracle.sigmoid_table(), lcg, 0.025, 0, n)
+    r2, _ = oracle.w2v_train_slice(ocfg, doc, 0, n, None, rp, rn, paths, oracle.sigmoid_table(), lcg, r1, 0, n)
+    assert (lr1, lr2) == (r1, r2)
+    assert np.array_equal(m.get_param(), rp) and np.array_equal(m.get_aux(), rn)
+
+
+def test_hogwild_learns_cooccurrence():
+    """two disjoint 'session' vocabularies: after Hogwild training, within-group cosine >> across-group"""
+    from goctr_amd import embedding as ge
+    rng = np.random.default_rng(3)
+    V, dim = 200, 16
+    sessions = []
+    for _ in range(4000):
+        g = rng.integers(0, 2)
+        sessions.append(rng.integers(g * 100, g * 100 + 100, size=50))
+    doc = np.concatenate(sessions).astype(np.int32)
+    counts = np.bincount(doc, minlength=V)
+    m = ge.Word2Vec(dim=dim, deterministic=False, streams=512, rng=np.random.default_rng(4))
+    m.create(counts)
+    for _ in range(3):
+        m.train_pass(doc, doc.size, None, lr=0.025)
+    P = m.get_param()
+    assert np.all(np.isfinite(P))
+    Pn = P / np.linalg.norm(P, axis=1, keepdims=True)
+    S = Pn @ Pn.T
+    within = (S[:100, :100].sum() - 100) / (100 * 99)
+    across = S[:100, 100:].mean()
+    assert within > across + 0.2
+
+
+def test_train_embedding_surface():
+    from goctr_amd import embedding as ge
+    rng = np.random.default_rng(5)
+    words = [str(int(x)) for x in corpus(rng, 300, 40000)]
+    mod = ge.TrainEmbedding(iter(words), 5, 16, 1, rng=np.random.default_rng(6), streams=256)
+    emb = mod.GenEmbeddingMap32()
+    assert len(emb) == mod.dic.Len()
+    v = emb[words[0]]
+    assert v.dtype == np.float32 and v.shape == (16,) and v[0] != 0      # wordemb_test.go: len(vec)==Dim, vec[0]!=0
+    # words below MinCount keep their random init but are still exported (quirk Q16)
+    rare = [w for w, i in mod.dic.word2id.items() if mod.dic.cfs[i] < 5]
+    if rare:
+        assert rare[0] in emb
