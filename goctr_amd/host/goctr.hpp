@@ -1,0 +1,221 @@
+// goctr.hpp -- C++ host mirror of go-ctr's operator surface above the C-ABI (include/goctr.h).
+//
+// The reference is compiled Go and the Go toolchain is absent from the build image, so this header restates
+// the Go-side contracts of the hot path (recommend/rcmd.go:56-97,132-137; model/model.go:16-33,215-242;
+// model/din/din.go:21-52,62-211; model/youtube/dnn.go; model/mlp/mlp.go:15-65;
+// feature/embedding/wordemb.go:9-32) with the same names, argument order and error behaviour.  It moves
+// buffers only: every number comes out of libgoctr_hip.so.  Errors surface as std::runtime_error carrying
+// goctr_last_error() (the Go adapters log.Fatalf / return error at the same places).
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/goctr.h"
+
+namespace goctr {
+
+inline void check(int rc) {
+  if (rc != 0) throw std::runtime_error(goctr_last_error());
+}
+
+namespace recommend {
+// recommend/rcmd.go:19-28
+constexpr int ItemEmbDim = 16, ItemEmbWindow = 5, UserBehaviorLen = 10;
+
+struct SampleInfo {  // rcmd.go:132-137
+  std::array<int, 2> UserProfileRange{}, UserBehaviorRange{}, ItemFeatureRange{}, CtxFeatureRange{};
+  std::array<int, 8> ranges() const {
+    return {UserProfileRange[0], UserProfileRange[1], UserBehaviorRange[0], UserBehaviorRange[1],
+            ItemFeatureRange[0], ItemFeatureRange[1], CtxFeatureRange[0], CtxFeatureRange[1]};
+  }
+  static SampleInfo FromDims(int U, int T, int D, int C) {  // rcmd.go:401-422
+    SampleInfo s;
+    s.UserProfileRange = {0, U};
+    s.UserBehaviorRange = {U, U + T * D};
+    s.ItemFeatureRange = {U + T * D, U + T * D + D};
+    s.CtxFeatureRange = {U + T * D + D, U + T * D + D + C};
+    return s;
+  }
+};
+
+struct TrainSample {  // rcmd.go:56-63
+  std::vector<float> X, Y;
+  int Rows = 0, XCols = 0;
+  SampleInfo Info;
+};
+
+struct PredictAbstract {  // rcmd.go:87-89
+  virtual ~PredictAbstract() = default;
+  virtual std::vector<float> Predict(const float* X, int64_t rows, int xcols) = 0;
+};
+struct Fitter {  // rcmd.go:95-97
+  virtual ~Fitter() = default;
+  virtual std::shared_ptr<PredictAbstract> Fit(const TrainSample& s) = 0;
+};
+}  // namespace recommend
+
+namespace model {
+constexpr int mlp0_1 = 200, mlp1_2 = 80;  // din.go:17-18
+
+class CtrNet {  // the device twin of model.Model (model.go:16-25)
+ public:
+  CtrNet(int kind, int U, int T, int D, int iD, int C, int att = GOCTR_ATT_COSINE) : U(U), T(T), D(D), C(C) {
+    if (kind == GOCTR_DIN && D != iD)  // din.go:176-178
+      throw std::invalid_argument("uBehaviorDim != iFeatureDim");
+    check(goctr_init(0));
+    goctr_ctr_cfg cfg{kind, att, U, T, D, C, mlp0_1, mlp1_2};
+    check(goctr_model_create(&cfg, &h_));
+  }
+  ~CtrNet() { goctr_model_destroy(h_); }
+  CtrNet(const CtrNet&) = delete;
+  CtrNet& operator=(const CtrNet&) = delete;
+  goctr_model* Vm() const { return h_; }
+  void SetWeights(int tensor, const std::vector<float>& w) { check(goctr_model_set_weights(h_, tensor, w.data(), w.size())); }
+  std::vector<float> GetWeights(int tensor) const {
+    const int I = U + 2 * D + C;
+    const size_t n = tensor == GOCTR_W0 ? (size_t)I * mlp0_1 : tensor == GOCTR_W1 ? (size_t)mlp0_1 * mlp1_2
+                   : tensor == GOCTR_W2 ? (size_t)mlp1_2 : (size_t)T;
+    std::vector<float> w(n);
+    check(goctr_model_get_weights(h_, tensor, w.data(), n));
+    return w;
+  }
+  // G.Gaussian(0,1) init (din.go:187-191)
+  void InitGaussian(uint64_t seed) {
+    std::mt19937_64 g(seed);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (int t : {GOCTR_W0, GOCTR_W1, GOCTR_W2}) {
+      auto w = GetWeights(t);
+      for (auto& v : w) v = nd(g);
+      SetWeights(t, w);
+    }
+  }
+  int U, T, D, C;
+
+ private:
+  goctr_model* h_ = nullptr;
+};
+
+// model.Train (model.go:27-33); returns the per-epoch costs the Go version logs (model.go:205)
+inline std::vector<float> Train(int /*uProfileDim*/, int /*uBehaviorSize*/, int /*uBehaviorDim*/, int /*iFeatureDim*/,
+                                int /*cFeatureDim*/, int numExamples, int batchSize, int epochs, int earlyStop,
+                                const recommend::SampleInfo& si, const float* inputs, int xcols, const float* targets,
+                                CtrNet& m) {
+  goctr_train_cfg cfg;
+  goctr_train_cfg_default(&cfg);
+  cfg.batch = batchSize; cfg.epochs = epochs; cfg.early_stop = earlyStop;
+  auto r = si.ranges();
+  std::vector<float> costs((size_t)std::max(epochs, 1));
+  int ran = 0;
+  check(goctr_train_dense(m.Vm(), inputs, targets, numExamples, xcols, r.data(), &cfg, costs.data(), &ran));
+  costs.resize((size_t)ran);
+  return costs;
+}
+
+// model.Predict (model.go:242)
+inline std::vector<float> Predict(CtrNet& m, int numExamples, int batchSize, const recommend::SampleInfo& si,
+                                  const float* inputs, int xcols) {
+  std::vector<float> y((size_t)numExamples);
+  auto r = si.ranges();
+  check(goctr_predict_dense(m.Vm(), inputs, numExamples, xcols, r.data(), batchSize, y.data()));
+  return y;
+}
+}  // namespace model
+
+namespace din {
+struct DinNet : model::CtrNet {
+  DinNet(int U, int T, int D, int iD, int C) : CtrNet(GOCTR_DIN, U, T, D, iD, C) {}
+};
+}  // namespace din
+namespace youtube {
+struct YoutubeDnn : model::CtrNet {
+  YoutubeDnn(int U, int T, int D, int iD, int C) : CtrNet(GOCTR_YOUTUBE, U, T, D, iD, C) {}
+};
+}  // namespace youtube
+
+namespace mlp {
+// nn.MLPClassifier behind model/mlp's wrappers (multilayer_perceptron.go:81-125, mlp.go:15-65)
+class MLPClassifier {
+ public:
+  std::vector<int> HiddenLayerSizes{100};
+  int Activation = GOCTR_ACT_RELU, Solver = GOCTR_SOLVER_ADAM;
+  double Alpha = 1e-4, LearningRateInit = 1e-3;
+  int BatchSize = 200, MaxIter = 200;
+  uint64_t RandomState = 1;
+  std::vector<double> LossCurve;
+  ~MLPClassifier() { goctr_mlp_destroy(h_); }
+  void Fit(const float* X, const float* Y, int64_t rows, int xcols) {
+    check(goctr_init(0));
+    goctr_mlp_cfg cfg;
+    goctr_mlp_cfg_default(&cfg);
+    std::vector<int> units{xcols};
+    units.insert(units.end(), HiddenLayerSizes.begin(), HiddenLayerSizes.end());
+    units.push_back(1);
+    cfg.n_layers = (int)units.size();
+    for (size_t i = 0; i < units.size(); ++i) cfg.units[i] = units[i];
+    cfg.activation = Activation; cfg.solver = Solver; cfg.alpha = Alpha; cfg.lr_init = LearningRateInit;
+    cfg.batch = BatchSize; cfg.max_iter = MaxIter;
+    goctr_mlp_destroy(h_);
+    check(goctr_mlp_create(&cfg, &h_));
+    // initialize (basemlp64.go:466-475): U[0,1) * sqrt(f / (fanIn + fanOut)), one-sided (quirk Q8)
+    std::mt19937_64 g(RandomState);
+    std::uniform_real_distribution<double> ud(0.0, 1.0);
+    std::vector<double> theta;
+    for (size_t i = 0; i + 1 < units.size(); ++i) {
+      const double bound = std::sqrt((Activation == GOCTR_ACT_LOGISTIC ? 2.0 : 6.0) / (units[i] + units[i + 1]));
+      for (int k = 0; k < (1 + units[i]) * units[i + 1]; ++k) theta.push_back(ud(g) * bound);
+    }
+    check(goctr_mlp_set_params(h_, theta.data(), theta.size()));
+    const int64_t use = rows / BatchSize * BatchSize;
+    LossCurve.assign((size_t)MaxIter, 0.0);
+    int iters = 0;
+    check(goctr_mlp_fit(h_, X, Y, use, nullptr, LossCurve.data(), &iters));
+    LossCurve.resize((size_t)iters);
+  }
+  std::vector<float> Predict(const float* X, int64_t rows) {
+    std::vector<float> y((size_t)rows);
+    check(goctr_mlp_predict(h_, X, rows, y.data()));
+    return y;
+  }
+
+ private:
+  goctr_mlp* h_ = nullptr;
+};
+}  // namespace mlp
+
+namespace embedding {
+// TrainEmbedding's device half (wordemb.go:9-32): the caller owns the dictionary and passes counts + id doc
+struct Model {
+  int64_t V = 0; int dim = 0;
+  std::vector<float> vectors;  // GenEmbeddingMap32 rows (word2vec.go:298-324)
+};
+inline Model TrainEmbedding(const std::vector<int64_t>& counts, const std::vector<int32_t>& doc, int64_t corpus_len,
+                            int window, int dim, int iter, uint64_t seed = 1) {
+  check(goctr_init(0));
+  goctr_w2v_cfg cfg;
+  goctr_w2v_cfg_default(&cfg);
+  cfg.dim = dim; cfg.window = window;
+  goctr_w2v* h = nullptr;
+  check(goctr_w2v_create(&cfg, (int64_t)counts.size(), counts.data(), &h));
+  std::mt19937_64 g(seed);
+  std::uniform_real_distribution<double> ud(0.0, 1.0);
+  std::vector<double> param(counts.size() * (size_t)dim);
+  for (auto& v : param) v = (ud(g) - 0.5) / dim;  // word2vec.go:103-111
+  check(goctr_w2v_set_param(h, param.data()));
+  double lr = cfg.init_lr;
+  for (int it = 0; it < iter; ++it) check(goctr_w2v_train(h, doc.data(), (int64_t)doc.size(), corpus_len, nullptr, &lr));
+  Model m;
+  m.V = (int64_t)counts.size(); m.dim = dim;
+  m.vectors.resize(counts.size() * (size_t)dim);
+  check(goctr_w2v_export_f32(h, m.vectors.data()));
+  goctr_w2v_destroy(h);
+  return m;
+}
+}  // namespace embedding
+
+}  // namespace goctr

@@ -118,3 +118,29 @@ def test_host_mirror_sample_info():
     si = SampleInfo.from_dims(52, UserBehaviorLen, ItemEmbDim, 53)         # MovieLens widths
     assert si.as_ranges().tolist() == [0, 52, 52, 212, 212, 228, 228, 281]
     assert si.CtxFeatureRange[1] == 281
+
+
+def _build_cpp_example(tmpdir):
+    exe = os.path.join(tmpdir, "example_main")
+    subprocess.run(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "goctr_amd", "host", "example_main.cpp"), "-o", exe,
+                    "-L" + os.path.join(ROOT, "goctr_amd"), "-lgoctr_hip",
+                    "-Wl,-rpath," + os.path.join(ROOT, "goctr_amd")], check=True)
+    return exe
+
+
+def test_cpp_host_mirror_links_and_fails_loudly_without_gpu(tmp_path):
+    """goctr_amd/host/goctr.hpp (the C++ twin of the Go surface) compiles against include/goctr.h and links
+    the C-ABI; on a GPU-less box the example exits non-zero with the no-device error, it does not compute"""
+    exe = _build_cpp_example(str(tmp_path))
+    if not _no_gpu():
+        pytest.skip("GPU present (covered by the gpu test)")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_runs_on_gpu(tmp_path):
+    exe = _build_cpp_example(str(tmp_path))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "epochs 5" in r.stdout and "n 118" in r.stdout
