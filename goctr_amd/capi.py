@@ -143,7 +143,7 @@ def default_train_cfg(**kw) -> TrainCfg:
     return c
 
 
-PROF_COUNT = 14
+PROF_COUNT = 15
 
 
 def prof_enable(on: bool):

@@ -38,7 +38,10 @@ struct Engine {
   bool inited = false;
   int device = -1;
   int compute_units = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // the engine's main stream
+  hipStream_t side = nullptr;     // forked inside captured step graphs for independent kernels
+  hipStream_t active = nullptr;   // stream the launch helpers currently target (main unless forked)
+  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join = nullptr;
   // data-parallel communicator (comm.hip)
   int rank = 0, world = 1;
   void* nccl_comm = nullptr;
@@ -61,6 +64,19 @@ struct ProfScope {
 };
 void prof_flush();
 
+// RAII switch of the stream the launch helpers target
+struct StreamScope {
+  hipStream_t prev;
+  explicit StreamScope(hipStream_t s) : prev(engine().active) { engine().active = s; }
+  ~StreamScope() { engine().active = prev; }
+};
+
+// Device memory comes from ONE large hipMalloc'd arena (first-fit free list) so that every buffer of
+// the engine sits in the same 2 MiB-fragment mapping (few TLB entries) instead of dozens of small
+// separately-mapped allocations.  Requests that do not fit fall back to a plain hipMalloc.
+void* arena_alloc(size_t bytes);
+void arena_free(void* p);
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -70,13 +86,14 @@ struct DevBuf {
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) arena_free(p);
     p = nullptr; n = 0;
   }
   int alloc(size_t count, bool zero = true) {
     release();
     if (count == 0) count = 1;
-    GOCTR_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    p = static_cast<T*>(arena_alloc(count * sizeof(T)));
+    if (!p) return -1;
     n = count;
     if (zero) GOCTR_HIP(hipMemsetAsync(p, 0, count * sizeof(T), engine().stream));
     return 0;

@@ -11,6 +11,7 @@
 #include <memory>
 
 #include "common.h"
+#include "ctr_chain.h"
 #include "ctr_kernels.h"
 #include "mfma_gemm.h"
 
@@ -135,7 +136,7 @@ int launch_nn(int kid, const float* A, int lda, const float* Bm, int ldb, int M,
   const int ncols_alloc = WN * ntw * 16;
   const int KPH = gemm_nn_phase_rows<float>(Kp, ncols_alloc);
   const size_t lds = gemm_nn_lds_bytes<float>(KPH, ncols_alloc);
-  hipStream_t st = engine().stream;
+  hipStream_t st = engine().active;
   ProfScope ps(kid);
 #define GOCTR_NN(N) hipLaunchKernelGGL((gemm_nn_kernel<float, Epi, N>), grid, dim3(256), lds, st, A, lda, Bm, ldb, M, Kp, Np, WN, KPH, epi)
   switch (ntw) {
@@ -160,7 +161,7 @@ int launch_tn_cfg(const float* A, int lda, int KT, const float* Dm, int ldd, int
               "gemm_tn: chunk does not fit the staging registers (WK=%d WN=%d)", WK, WN);
   dim3 grid(S, (unsigned)cdiv(KT, WK * KTW), (unsigned)cdiv(NT, WN * NTW));
   hipLaunchKernelGGL((gemm_tn_kernel<float, KTW, NTW, CH>), grid, dim3(nthreads),
-                     gemm_tn_lds_bytes<float>(WK * KTW, WN * NTW, CH), engine().stream, A, lda, KT, Dm, ldd, NT, M,
+                     gemm_tn_lds_bytes<float>(WK * KTW, WN * NTW, CH), engine().active, A, lda, KT, Dm, ldd, NT, M,
                      rows_per_wg, WK, WN, slabs, slab_stride);
   GOCTR_HIP(hipGetLastError());
   return 0;
@@ -191,7 +192,8 @@ int init_kernel_attrs() {
 #define GOCTR_NN_ATTR(E) (allow_big_lds(gemm_nn_kernel<float, E, 1>) || allow_big_lds(gemm_nn_kernel<float, E, 3>) || \
                           allow_big_lds(gemm_nn_kernel<float, E, 4>) || allow_big_lds(gemm_nn_kernel<float, E, 7>))
   if (GOCTR_NN_ATTR(EpiSigDrop) || GOCTR_NN_ATTR(EpiOut) || GOCTR_NN_ATTR(EpiDSig) || GOCTR_NN_ATTR(EpiStore) ||
-      allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
+      allow_big_lds(ctr_chain_kernel<7, 5, 0>) || allow_big_lds(ctr_chain_kernel<7, 5, 1>) ||
+      allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>)) return -1;
   done = true;
   return 0;
@@ -200,7 +202,7 @@ int init_kernel_attrs() {
 int launch_attn_fwd(const AttnArgs& a) {
   ProfScope ps(GOCTR_K_ATTN_FWD);
   dim3 grid((unsigned)cdiv(a.B, 4)), blk(256);
-  hipStream_t st = engine().stream;
+  hipStream_t st = engine().active;
   const bool vec4 = a.src.id_mode && a.D % 4 == 0;
   const int groups = vec4 ? a.D / 4 : a.D;  // lanes needed per row
 #define GOCTR_ATTN_FWD(V, L) hipLaunchKernelGGL((attn_fwd_kernel<V, L>), grid, blk, 0, st, a)
@@ -226,7 +228,7 @@ int launch_attn_fwd(const AttnArgs& a) {
 int launch_attn_bwd(const AttnBwdArgs& a, int blocks) {
   ProfScope ps(GOCTR_K_ATTN_BWD);
   dim3 grid((unsigned)blocks), blk(64 * ATTN_BWD_WAVES);
-  hipStream_t st = engine().stream;
+  hipStream_t st = engine().active;
   const size_t lds = sizeof(float) * ATTN_BWD_WAVES * a.Tp;
   const bool vec4 = a.src.id_mode && a.D % 4 == 0;
   const int groups = vec4 ? a.D / 4 : a.D;
@@ -257,6 +259,52 @@ struct StepOpts {
   const goctr_train_cfg* tc = nullptr;
 };
 
+// the fused chain kernel covers the reference's fixed hidden widths (200 -> 13 tiles, 80 -> 5 tiles)
+bool chain_ok(const goctr_model* m) {
+  const int nt0 = m->H1p / 16;
+  const int blocks_bwd = (m->H2p / 4) * (m->H1p / 4) + (m->cfg.kind == GOCTR_DIN ? (m->H1p / 4) * (m->Dp / 4) : 0);
+  return (nt0 == 13 || nt0 == 14) && m->H2p == 80 && m->Dp <= 16 * CHAIN_NDP && blocks_bwd <= CHAIN_PF * 256 &&
+         env_int("GOCTR_NO_CHAIN", 0) == 0;
+}
+
+int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st) {
+  const goctr_ctr_cfg& c = m->cfg;
+  Engine& e = engine();
+  const uint32_t row_off = (uint32_t)(e.rank * B);
+  const bool drop = o.train && o.drop_mode != 0;
+  ChainArgs a{};
+  a.h0 = m->h0.p; a.Ip = m->Ip;
+  a.W0 = m->W.p; a.W1 = m->W.p + m->off1; a.W2 = m->W.p + m->off2; a.W1T = m->W1T.p; a.W0sT = m->W0sT.p;
+  a.H1 = c.H1; a.H2 = c.H2; a.H1p = m->H1p; a.H2p = m->H2p; a.Dp = m->Dp; a.B = B;
+  a.train = o.train ? 1 : 0; a.kind = c.kind;
+  a.d0 = DropCfg{drop && o.p0 > 0 ? o.drop_mode : 0, o.p0, m->mask0.p, c.H1, o.seed, 0u, row_off};
+  a.d1 = DropCfg{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
+  a.st = st; a.Y = src.Y; a.rows = src.rows; a.inv_bglobal = 1.0f / (float)(B * e.world);
+  a.wb_floats = chain_wb_floats(m->Ip, m->H1p, m->H2p, m->Dp);
+  a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;
+  a.yhat = m->yhat.p; a.lossrow = m->lossrow.p;
+  static DevBuf<unsigned long long> dbgbuf;
+  const bool dbg = env_int("GOCTR_CHAIN_DBG", 0) != 0;
+  if (dbg && !dbgbuf.p && dbgbuf.alloc(16)) return -1;
+  a.dbg = dbg ? dbgbuf.p : nullptr;
+  ProfScope ps(GOCTR_K_CHAIN);
+  const dim3 grid((unsigned)cdiv(B, 32));
+  const size_t lds = chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p, m->Dp);
+  const int dmode = (a.d0.mode || a.d1.mode) ? o.drop_mode : 0;
+  if (dmode == 0) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 0>), grid, dim3(256), lds, e.active, a);
+  else if (dmode == 1) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 1>), grid, dim3(256), lds, e.active, a);
+  else hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 2>), grid, dim3(256), lds, e.active, a);
+  GOCTR_HIP(hipGetLastError());
+  if (dbg) {
+    unsigned long long h[16];
+    if (dbgbuf.download(h, 16)) return -1;
+    fprintf(stderr, "chain phases (s_memtime ticks, 100 MHz):");
+    for (int k = 1; k < 13; ++k) fprintf(stderr, " %d:%lld", k, (long long)(h[k] - h[k - 1]));
+    fprintf(stderr, "  total %lld\n", (long long)(h[12] - h[0]));
+  }
+  return 0;
+}
+
 // forward part: kernels 1-4
 int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st_override = nullptr) {
   const goctr_ctr_cfg& c = m->cfg;
@@ -266,6 +314,7 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
   aa.src = src; aa.st = st; aa.B = B; aa.U = c.U; aa.T = c.T; aa.D = c.D; aa.C = c.C; aa.Ip = m->Ip;
   aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = m->h0.p; aa.gate = m->gate.p; aa.wgt = m->wgt.p;
   if (launch_attn_fwd(aa)) return -1;
+  if (chain_ok(m)) return launch_chain(m, src, B, o, st);  // layers + (when training) backward-data, fused
 
   const int bglobal = B * e.world;
   const uint32_t row_off = (uint32_t)(e.rank * B);
@@ -285,7 +334,7 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
 }
 
 // backward part up to and including the slab reduce: kernels 5-12
-int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, bool advance) {
+int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, bool advance, bool fork = false) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
   const StepState* st = m->st.p;
@@ -296,25 +345,56 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   const float* A0 = d0.mode ? m->A0.p : m->P0.p;
   const float* A1 = d1.mode ? m->A1.p : m->P1.p;
 
-  EpiDSig b1{m->dz1.p, m->P1.p, m->H2p, c.H2, d1, st};
-  if (launch_nn(GOCTR_K_BWD_DZ1, m->dz2.p, 16, m->W2T.p, m->H2p, B, 16, m->H2p, b1)) return -1;
-  EpiDSig b0{m->dz0.p, m->P0.p, m->H1p, c.H1, d0, st};
-  if (launch_nn(GOCTR_K_BWD_DZ0, m->dz1.p, m->H2p, m->W1T.p, m->H1p, B, m->H2p, m->H1p, b0)) return -1;
+  // fork: the weight-gradient GEMMs only depend on dz2 / dz1 / dz0 and run on the side stream while the
+  // main stream continues down the backward-data chain (captured into the step graph as parallel branches)
+  const int rpw = tn_rows_per_wg();
+  const int S = (int)cdiv(B, rpw);
+  const bool fused = chain_ok(m);  // dz1 / dz0 / dp were already produced by the chain kernel
+  if (fused) {
+    A0 = m->A0.p; A1 = m->A1.p;    // the chain kernel always writes the post-dropout activations here
+  } else {
+    EpiDSig b1{m->dz1.p, m->P1.p, m->H2p, c.H2, d1, st};
+    if (launch_nn(GOCTR_K_BWD_DZ1, m->dz2.p, 16, m->W2T.p, m->H2p, B, 16, m->H2p, b1)) return -1;
+  }
+  if (fork) {
+    GOCTR_HIP(hipEventRecord(e.ev_fork[0], e.stream));
+    GOCTR_HIP(hipStreamWaitEvent(e.side, e.ev_fork[0], 0));
+    StreamScope sc(e.side);
+    if (launch_tn(GOCTR_K_DW2, A1, m->H2p, m->H2p / 16, m->dz2.p, 16, 1, B, rpw, m->slabs2.p, (size_t)m->H2p * 16)) return -1;
+    if (launch_tn(GOCTR_K_DW1, A0, m->H1p, m->H1p / 16, m->dz1.p, m->H2p, m->H2p / 16, B, rpw, m->slabs1.p,
+                  (size_t)m->H1p * m->H2p)) return -1;
+  }
+  if (!fused) {
+    EpiDSig b0{m->dz0.p, m->P0.p, m->H1p, c.H1, d0, st};
+    if (launch_nn(GOCTR_K_BWD_DZ0, m->dz1.p, m->H2p, m->W1T.p, m->H1p, B, m->H2p, m->H1p, b0)) return -1;
+  }
+  if (fork) {
+    GOCTR_HIP(hipEventRecord(e.ev_fork[1], e.stream));
+    GOCTR_HIP(hipStreamWaitEvent(e.side, e.ev_fork[1], 0));
+    StreamScope sc(e.side);
+    if (launch_tn(GOCTR_K_DW0, m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, B, rpw, m->slabs0.p,
+                  (size_t)m->Ip * m->H1p)) return -1;
+  }
   if (c.kind == GOCTR_DIN) {
-    EpiStore sp{m->dp.p, m->Dp};
-    if (launch_nn(GOCTR_K_BWD_DP, m->dz0.p, m->H1p, m->W0sT.p, m->Dp, B, m->H1p, m->Dp, sp)) return -1;
+    if (!fused) {
+      EpiStore sp{m->dp.p, m->Dp};
+      if (launch_nn(GOCTR_K_BWD_DP, m->dz0.p, m->H1p, m->W0sT.p, m->Dp, B, m->H1p, m->Dp, sp)) return -1;
+    }
     AttnBwdArgs ab{};
     ab.src = src; ab.st = st; ab.B = B; ab.T = c.T; ab.D = c.D; ab.Dp = m->Dp; ab.Tp = m->Tp;
     ab.dp = m->dp.p; ab.gate = m->gate.p; ab.wgt = m->wgt.p; ab.partial = m->attp.p;
     if (launch_attn_bwd(ab, (int)cdiv(B, ATTN_BWD_WAVES))) return -1;
   }
-  const int rpw = tn_rows_per_wg();
-  const int S = (int)cdiv(B, rpw);
-  if (launch_tn(GOCTR_K_DW0, m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, B, rpw, m->slabs0.p,
-                (size_t)m->Ip * m->H1p)) return -1;
-  if (launch_tn(GOCTR_K_DW1, A0, m->H1p, m->H1p / 16, m->dz1.p, m->H2p, m->H2p / 16, B, rpw, m->slabs1.p,
-                (size_t)m->H1p * m->H2p)) return -1;
-  if (launch_tn(GOCTR_K_DW2, A1, m->H2p, m->H2p / 16, m->dz2.p, 16, 1, B, rpw, m->slabs2.p, (size_t)m->H2p * 16)) return -1;
+  if (fork) {
+    GOCTR_HIP(hipEventRecord(e.ev_join, e.side));
+    GOCTR_HIP(hipStreamWaitEvent(e.stream, e.ev_join, 0));
+  } else {
+    if (launch_tn(GOCTR_K_DW0, m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, B, rpw, m->slabs0.p,
+                  (size_t)m->Ip * m->H1p)) return -1;
+    if (launch_tn(GOCTR_K_DW1, A0, m->H1p, m->H1p / 16, m->dz1.p, m->H2p, m->H2p / 16, B, rpw, m->slabs1.p,
+                  (size_t)m->H1p * m->H2p)) return -1;
+    if (launch_tn(GOCTR_K_DW2, A1, m->H2p, m->H2p / 16, m->dz2.p, 16, 1, B, rpw, m->slabs2.p, (size_t)m->H2p * 16)) return -1;
+  }
 
   ReduceArgs ra{};
   ra.seg[0] = {m->slabs0.p, S, (unsigned long long)m->Ip * m->H1p, 0, m->Ip * m->H1p};
@@ -377,7 +457,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   m->graph.destroy();
   hipGraph_t g = nullptr;
   GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-  int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true);
+  int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, env_int("GOCTR_FORK", 0) != 0);
   if (!rc && e.world <= 1) rc = launch_adam(m, B, *o.tc);
   hipError_t ce = hipStreamEndCapture(e.stream, &g);
   if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }

@@ -2,6 +2,9 @@
 // per-kernel timers.  (No reference counterpart: go-ctr has no device runtime)
 #include "common.h"
 
+#include <cstdlib>
+#include <map>
+
 namespace goctr {
 
 static thread_local std::string g_err;
@@ -30,7 +33,7 @@ int require_engine() {
 
 static const char* kNames[GOCTR_K_COUNT] = {
     "attn_fwd", "gemm_fwd0", "gemm_fwd1", "gemm_out", "bwd_dz1", "bwd_dz0", "bwd_dp",
-    "attn_bwd", "dW0", "dW1", "dW2", "reduce", "allreduce", "adam"};
+    "attn_bwd", "dW0", "dW1", "dW2", "reduce", "allreduce", "adam", "chain"};
 
 ProfScope::ProfScope(int kernel_id) : id(kernel_id), on(engine().prof) {
   if (!on) return;
@@ -42,12 +45,12 @@ ProfScope::ProfScope(int kernel_id) : id(kernel_id), on(engine().prof) {
     return ev;
   };
   a = get(); b = get();
-  (void)hipEventRecord(a, e.stream);
+  (void)hipEventRecord(a, e.active);
 }
 ProfScope::~ProfScope() {
   if (!on) return;
   Engine& e = engine();
-  (void)hipEventRecord(b, e.stream);
+  (void)hipEventRecord(b, e.active);
   e.pending.push_back({id, a, b});
   if (e.pending.size() > 4096) prof_flush();
 }
@@ -61,6 +64,75 @@ void prof_flush() {
     e.event_pool.push_back(p.a); e.event_pool.push_back(p.b);
   }
   e.pending.clear();
+}
+
+// ---------------------------------------------------------------- device arena
+namespace {
+struct Arena {
+  char* base = nullptr;
+  size_t size = 0;
+  std::map<size_t, size_t> free_blocks;   // offset -> length
+  std::map<size_t, size_t> used;          // offset -> length
+  std::mutex mu;
+};
+Arena g_arena;
+}  // namespace
+
+void* arena_alloc(size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_arena.mu);
+  Arena& a = g_arena;
+  const size_t need = (bytes + 255) / 256 * 256;
+  if (!a.base) {
+    const char* ev = getenv("GOCTR_ARENA_MB");
+    size_t mb = ev && *ev ? (size_t)atoll(ev) : 2048;
+    if (mb > 0 && hipMalloc((void**)&a.base, mb << 20) == hipSuccess) {
+      a.size = mb << 20;
+      a.free_blocks[0] = a.size;
+    } else {
+      (void)hipGetLastError();
+      a.base = nullptr; a.size = 0;
+    }
+  }
+  if (a.base) {
+    for (auto it = a.free_blocks.begin(); it != a.free_blocks.end(); ++it) {
+      if (it->second >= need) {
+        const size_t off = it->first, len = it->second;
+        a.free_blocks.erase(it);
+        if (len > need) a.free_blocks[off + need] = len - need;
+        a.used[off] = need;
+        return a.base + off;
+      }
+    }
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, need) != hipSuccess) {
+    set_error("device allocation of %zu bytes failed", need);
+    return nullptr;
+  }
+  return p;
+}
+
+void arena_free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_arena.mu);
+  Arena& a = g_arena;
+  char* c = static_cast<char*>(p);
+  if (a.base && c >= a.base && c < a.base + a.size) {
+    size_t off = (size_t)(c - a.base);
+    auto u = a.used.find(off);
+    if (u == a.used.end()) return;
+    size_t len = u->second;
+    a.used.erase(u);
+    auto nxt = a.free_blocks.lower_bound(off);
+    if (nxt != a.free_blocks.end() && off + len == nxt->first) { len += nxt->second; nxt = a.free_blocks.erase(nxt); }
+    if (nxt != a.free_blocks.begin()) {
+      auto prv = std::prev(nxt);
+      if (prv->first + prv->second == off) { off = prv->first; len += prv->second; a.free_blocks.erase(prv); }
+    }
+    a.free_blocks[off] = len;
+    return;
+  }
+  (void)hipFree(p);
 }
 
 }  // namespace goctr
@@ -93,7 +165,13 @@ int goctr_init(int device_ordinal) {
   GOCTR_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
               "goctr_init: device is %s; this library is built for gfx950 (MI355X) only", prop.gcnArchName);
   e.compute_units = prop.multiProcessorCount;
-  if (!e.stream) GOCTR_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+  if (!e.stream) {
+    GOCTR_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+    GOCTR_HIP(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
+    for (auto& ev : e.ev_fork) GOCTR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GOCTR_HIP(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
+  }
+  e.active = e.stream;
   e.device = device_ordinal;
   e.inited = true;
   return 0;
