@@ -53,8 +53,9 @@ struct goctr_model {
   // per-batch workspace
   int wsB = 0, tnS = 0;
   DevBuf<float> h0, P0, A0, P1, A1, yhat, lossrow, dz2, dz1, dz0, dp, gate, wgt, slabs0, slabs1, slabs2, attp;
-  DevBuf<float> mask0, mask1;
+  DevBuf<float> mask0, mask1, slabs3, ones16;
   DevBuf<StepState> st, pst;
+  DevBuf<unsigned int> arrive;   // arrival counter of the fused reduce+adam kernel
   DevBuf<float> costs;
   std::mutex mu;
   StepGraph graph;
@@ -68,7 +69,7 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-int tn_rows_per_wg() { return round_up(env_int("GOCTR_TN_ROWS", 64), 32); }
+int tn_rows_per_wg() { return round_up(env_int("GOCTR_TN_ROWS", 128), 32); }
 
 int ensure_workspace(goctr_model* m, int B) {
   if (m->wsB >= B && m->tnS > 0) return 0;
@@ -91,7 +92,13 @@ int ensure_workspace(goctr_model* m, int B) {
   if (m->slabs1.alloc((size_t)S * m->H1p * m->H2p)) return -1;
   if (m->slabs2.alloc((size_t)S * m->H2p * 16)) return -1;
   m->attp_blocks = (int)cdiv(B, ATTN_BWD_WAVES);
-  if (m->attp.alloc((size_t)m->attp_blocks * m->Tp)) return -1;
+  if (m->attp.alloc((size_t)B * m->Tp)) return -1;               // dgs [B, Tp]
+  if (m->slabs3.alloc((size_t)S * 16 * m->Tp)) return -1;        // att0 gradient slabs (row 0 of 16)
+  {
+    std::vector<float> ones((size_t)B * 16, 0.f);
+    for (int r = 0; r < B; ++r) ones[(size_t)r * 16] = 1.0f;
+    if (m->ones16.alloc(ones.size(), false) || m->ones16.upload(ones.data(), ones.size())) return -1;
+  }
   m->wsB = B;
   m->graph.destroy();
   return 0;
@@ -194,7 +201,7 @@ int init_kernel_attrs() {
   if (GOCTR_NN_ATTR(EpiSigDrop) || GOCTR_NN_ATTR(EpiOut) || GOCTR_NN_ATTR(EpiDSig) || GOCTR_NN_ATTR(EpiStore) ||
       allow_big_lds(ctr_chain_kernel<7, 5, 0>) || allow_big_lds(ctr_chain_kernel<7, 5, 1>) ||
       allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
-      allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>)) return -1;
+      allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, 16>)) return -1;
   done = true;
   return 0;
 }
@@ -229,7 +236,7 @@ int launch_attn_bwd(const AttnBwdArgs& a, int blocks) {
   ProfScope ps(GOCTR_K_ATTN_BWD);
   dim3 grid((unsigned)blocks), blk(64 * ATTN_BWD_WAVES);
   hipStream_t st = engine().active;
-  const size_t lds = sizeof(float) * ATTN_BWD_WAVES * a.Tp;
+  const size_t lds = 0;
   const bool vec4 = a.src.id_mode && a.D % 4 == 0;
   const int groups = vec4 ? a.D / 4 : a.D;
 #define GOCTR_ATTN_BWD(V, L) hipLaunchKernelGGL((attn_bwd_kernel<V, L>), grid, blk, lds, st, a)
@@ -334,7 +341,11 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
 }
 
 // backward part up to and including the slab reduce: kernels 5-12
-int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, bool advance, bool fork = false) {
+AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc);
+
+// backward part up to and including the slab reduce (optionally fused with Adam on a single GPU)
+int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, bool advance,
+                    bool fuse_update = false) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
   const StepState* st = m->st.p;
@@ -344,36 +355,17 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   DropCfg d1{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
   const float* A0 = d0.mode ? m->A0.p : m->P0.p;
   const float* A1 = d1.mode ? m->A1.p : m->P1.p;
-
-  // fork: the weight-gradient GEMMs only depend on dz2 / dz1 / dz0 and run on the side stream while the
-  // main stream continues down the backward-data chain (captured into the step graph as parallel branches)
   const int rpw = tn_rows_per_wg();
   const int S = (int)cdiv(B, rpw);
+
   const bool fused = chain_ok(m);  // dz1 / dz0 / dp were already produced by the chain kernel
   if (fused) {
     A0 = m->A0.p; A1 = m->A1.p;    // the chain kernel always writes the post-dropout activations here
   } else {
     EpiDSig b1{m->dz1.p, m->P1.p, m->H2p, c.H2, d1, st};
     if (launch_nn(GOCTR_K_BWD_DZ1, m->dz2.p, 16, m->W2T.p, m->H2p, B, 16, m->H2p, b1)) return -1;
-  }
-  if (fork) {
-    GOCTR_HIP(hipEventRecord(e.ev_fork[0], e.stream));
-    GOCTR_HIP(hipStreamWaitEvent(e.side, e.ev_fork[0], 0));
-    StreamScope sc(e.side);
-    if (launch_tn(GOCTR_K_DW2, A1, m->H2p, m->H2p / 16, m->dz2.p, 16, 1, B, rpw, m->slabs2.p, (size_t)m->H2p * 16)) return -1;
-    if (launch_tn(GOCTR_K_DW1, A0, m->H1p, m->H1p / 16, m->dz1.p, m->H2p, m->H2p / 16, B, rpw, m->slabs1.p,
-                  (size_t)m->H1p * m->H2p)) return -1;
-  }
-  if (!fused) {
     EpiDSig b0{m->dz0.p, m->P0.p, m->H1p, c.H1, d0, st};
     if (launch_nn(GOCTR_K_BWD_DZ0, m->dz1.p, m->H2p, m->W1T.p, m->H1p, B, m->H2p, m->H1p, b0)) return -1;
-  }
-  if (fork) {
-    GOCTR_HIP(hipEventRecord(e.ev_fork[1], e.stream));
-    GOCTR_HIP(hipStreamWaitEvent(e.side, e.ev_fork[1], 0));
-    StreamScope sc(e.side);
-    if (launch_tn(GOCTR_K_DW0, m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, B, rpw, m->slabs0.p,
-                  (size_t)m->Ip * m->H1p)) return -1;
   }
   if (c.kind == GOCTR_DIN) {
     if (!fused) {
@@ -385,15 +377,40 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     ab.dp = m->dp.p; ab.gate = m->gate.p; ab.wgt = m->wgt.p; ab.partial = m->attp.p;
     if (launch_attn_bwd(ab, (int)cdiv(B, ATTN_BWD_WAVES))) return -1;
   }
-  if (fork) {
-    GOCTR_HIP(hipEventRecord(e.ev_join, e.side));
-    GOCTR_HIP(hipStreamWaitEvent(e.stream, e.ev_join, 0));
+
+  // weight gradients: all GEMMs in one launch; dW1 and dW2 are posed transposed, datt0 is a ones-column
+  // product over the per-sample terms (see mfma_gemm.h: gemm_tn_multi_kernel)
+  const bool multi = m->H1p <= 256 && m->H2p <= 256 && m->Tp <= 256 && env_int("GOCTR_NO_TNMULTI", 0) == 0;
+  if (multi) {
+    TnMulti tm{};
+    tm.M = B; tm.rows_per_wg = rpw; tm.S = S; tm.np = 3;
+    const int kb0 = (int)cdiv(m->Ip / 16, 3), kb1 = (int)cdiv(m->H2p / 16, 3), kb2 = 1;
+    tm.p[0] = {m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, m->slabs0.p,
+               (unsigned long long)m->Ip * m->H1p, 0, m->H1p, 0};
+    tm.p[1] = {m->dz1.p, m->H2p, m->H2p / 16, A0, m->H1p, m->H1p / 16, m->slabs1.p,
+               (unsigned long long)m->H1p * m->H2p, 1, m->H2p, kb0 * S};
+    tm.p[2] = {m->dz2.p, 16, 1, A1, m->H2p, m->H2p / 16, m->slabs2.p, (unsigned long long)m->H2p * 16, 1, 16,
+               (kb0 + kb1) * S};
+    int nblk = (kb0 + kb1 + kb2) * S;
+    if (c.kind == GOCTR_DIN) {  // datt0 = ones^T . dgs  (column sums over the batch)
+      tm.p[3] = {m->ones16.p, 16, 1, m->attp.p, m->Tp, m->Tp / 16, m->slabs3.p, (unsigned long long)16 * m->Tp, 0, m->Tp,
+                 nblk};
+      tm.np = 4;
+      nblk += S;
+    }
+    const size_t lds_tm = gemm_tn_multi_lds_bytes<3, 4, 16>();
+    ProfScope ps(GOCTR_K_DW0);
+    hipLaunchKernelGGL((gemm_tn_multi_kernel<3, 4, 16>), dim3((unsigned)nblk), dim3(256), lds_tm, e.stream, tm);
+    GOCTR_HIP(hipGetLastError());
   } else {
     if (launch_tn(GOCTR_K_DW0, m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, B, rpw, m->slabs0.p,
                   (size_t)m->Ip * m->H1p)) return -1;
     if (launch_tn(GOCTR_K_DW1, A0, m->H1p, m->H1p / 16, m->dz1.p, m->H2p, m->H2p / 16, B, rpw, m->slabs1.p,
                   (size_t)m->H1p * m->H2p)) return -1;
     if (launch_tn(GOCTR_K_DW2, A1, m->H2p, m->H2p / 16, m->dz2.p, 16, 1, B, rpw, m->slabs2.p, (size_t)m->H2p * 16)) return -1;
+    if (c.kind == GOCTR_DIN &&
+        launch_tn(GOCTR_K_DW2, m->ones16.p, 16, 1, m->attp.p, m->Tp, m->Tp / 16, B, rpw, m->slabs3.p, (size_t)16 * m->Tp))
+      return -1;
   }
 
   ReduceArgs ra{};
@@ -402,10 +419,18 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   ra.seg[2] = {m->slabs2.p, S, (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
   ra.nseg = 3;
   if (c.kind == GOCTR_DIN) {
-    ra.seg[3] = {m->attp.p, (int)cdiv(B, ATTN_BWD_WAVES), (unsigned long long)m->Tp, m->offa, m->Tp};
+    ra.seg[3] = {m->slabs3.p, S, (unsigned long long)16 * m->Tp, m->offa, m->Tp};
     ra.nseg = 4;
   }
   ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st.p; ra.advance = advance ? 1 : 0;
+  if (fuse_update) {
+    ReduceAdamArgs p{};
+    p.r = ra; p.ad = make_adam_args(m, B, *o.tc); p.arrive = m->arrive.p;
+    ProfScope ps(GOCTR_K_REDUCE);
+    hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)cdiv((int64_t)m->nflat * 2, 256)), dim3(256), 0, e.stream, p);
+    GOCTR_HIP(hipGetLastError());
+    return 0;
+  }
   {
     ProfScope ps(GOCTR_K_REDUCE);
     hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)cdiv((int64_t)m->nflat * 2, 256) + 1), dim3(256), 0, e.stream, ra);
@@ -414,7 +439,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   return 0;
 }
 
-int launch_adam(goctr_model* m, int B, const goctr_train_cfg& tc) {
+AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc) {
   Engine& e = engine();
   AdamArgs a{};
   a.W = m->W.p; a.G = m->G.p; a.Mo = m->Mo.p; a.Vo = m->Vo.p; a.nflat = m->nflat;
@@ -424,8 +449,13 @@ int launch_adam(goctr_model* m, int B, const goctr_train_cfg& tc) {
   a.lr = tc.lr; a.l2 = tc.l2; a.beta1 = tc.beta1; a.beta2 = tc.beta2; a.eps = tc.eps;
   a.div_by_batch = tc.adam_div_by_batch; a.l2_first = tc.adam_l2_before_batch_div;
   a.bglobal = B * e.world; a.st = m->st.p; a.costs = m->costs.p;
+  return a;
+}
+
+int launch_adam(goctr_model* m, int B, const goctr_train_cfg& tc) {
+  AdamArgs a = make_adam_args(m, B, tc);
   ProfScope ps(GOCTR_K_ADAM);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdiv(m->nflat, 256)), dim3(256), 0, e.stream, a);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdiv(m->nflat, 256)), dim3(256), 0, engine().stream, a);
   GOCTR_HIP(hipGetLastError());
   return 0;
 }
@@ -439,7 +469,9 @@ int allreduce_grads(goctr_model* m) {
 // one full training step, eager
 int train_step_eager(goctr_model* m, const RowSource& src, int B, const StepOpts& o) {
   if (launch_forward(m, src, B, o)) return -1;
-  if (launch_backward(m, src, B, o, true)) return -1;
+  const bool fuse = engine().world <= 1 && env_int("GOCTR_FUSED_UPDATE", 0) != 0;
+  if (launch_backward(m, src, B, o, true, fuse)) return -1;
+  if (fuse) return 0;
   if (allreduce_grads(m)) return -1;
   return launch_adam(m, B, *o.tc);
 }
@@ -457,8 +489,9 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   m->graph.destroy();
   hipGraph_t g = nullptr;
   GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-  int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, env_int("GOCTR_FORK", 0) != 0);
-  if (!rc && e.world <= 1) rc = launch_adam(m, B, *o.tc);
+  const bool fuse = e.world <= 1 && env_int("GOCTR_FUSED_UPDATE", 0) != 0;
+  int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse);
+  if (!rc && e.world <= 1 && !fuse) rc = launch_adam(m, B, *o.tc);
   hipError_t ce = hipStreamEndCapture(e.stream, &g);
   if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
   GOCTR_HIP(ce);
@@ -654,7 +687,7 @@ int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
   m->nflat = m->offa + m->Tp;
   if (m->W.alloc(m->nflat) || m->G.alloc((size_t)m->nflat + 1) || m->Mo.alloc(m->nflat) || m->Vo.alloc(m->nflat)) return -1;
   if (m->W1T.alloc((size_t)m->H2p * m->H1p) || m->W2T.alloc((size_t)16 * m->H2p) || m->W0sT.alloc((size_t)m->H1p * m->Dp)) return -1;
-  if (m->st.alloc(1) || m->costs.alloc(COST_RING)) return -1;
+  if (m->st.alloc(1) || m->costs.alloc(COST_RING) || m->arrive.alloc(1)) return -1;
   std::vector<float> ones(cfg->T, 1.0f);  // din.go:181 att0 = 1
   if (upload_padded_weights(m.get(), GOCTR_ATT0, ones.data(), ones.size())) return -1;
   if (set_state(m.get(), 0, 0, 0, 1)) return -1;

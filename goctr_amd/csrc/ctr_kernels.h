@@ -231,70 +231,60 @@ struct AttnBwdArgs {
   const float* dp;    // [B, Dp]   d cost / d pooled
   const float* gate;  // [B, T]
   const float* wgt;   // [B, T]
-  float* partial;     // [gridDim.x, Tp]
+  float* partial;     // dgs [B, Tp]: per-sample terms of the att0 gradient
 };
 
 constexpr int ATTN_BWD_WAVES = 16;  // samples per workgroup (one wavefront each)
 
-// datt0[t] = sum_b dg[b,t] * g(1-g) * w ; dg[b,t] = (1/T) sum_d dp[b,d] * x[b,t,d]   
-// 16 wavefronts = 16 samples per workgroup, all row gathers in flight at once; per-sample terms land
-// in the wavefront's own LDS row (no atomics), rows are summed in a fixed order => deterministic.
+// per-sample terms of  datt0[t] = sum_b dg[b,t] * g(1-g) * w ,  dg[b,t] = (1/T) sum_d dp[b,d] * x[b,t,d]
+// (SURVEY A.1).  One wavefront per sample, all row gathers in flight at once; the terms go to
+// dgs [B, Tp] and the sum over the batch is done by the weight-gradient GEMM launch as a ones-column
+// product (same deterministic slab reduction as every other gradient).
 template <int VEC, int LPR>
 __global__ __launch_bounds__(64 * ATTN_BWD_WAVES) void attn_bwd_kernel(AttnBwdArgs a) {
   constexpr int RPP = 64 / LPR;
   constexpr int NPB = LPR < 4 ? LPR : 4;
-  extern __shared__ float att_acc[];  // [ATTN_BWD_WAVES][Tp]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const RowSource& s = a.src;
   const int dl = lane % LPR, rl = lane / LPR, d0 = dl * VEC;
   const int D = a.D, T = a.T;
-  float* my = att_acc + wave * a.Tp;
-  for (int j = lane; j < a.Tp; j += 64) my[j] = 0.f;
   const int b = blockIdx.x * ATTN_BWD_WAVES + wave;
-  if (b < a.B) {
-    const long long gr = a.st->batch_idx * (long long)a.B + b;
-    const bool valid = gr < s.rows;
-    float dpt[VEC];
+  if (b >= a.B) return;
+  const long long gr = a.st->batch_idx * (long long)a.B + b;
+  const bool valid = gr < s.rows;
+  float dpt[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) dpt[e] = d0 + e < D ? a.dp[(size_t)b * a.Dp + d0 + e] / (float)T : 0.f;
-    for (int tb = 0; tb < T; tb += NPB * RPP) {
-      int myid = -1;
-      if (s.id_mode && valid && lane < NPB * RPP && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
-      float x[NPB][VEC];
+  for (int e = 0; e < VEC; ++e) dpt[e] = d0 + e < D ? a.dp[(size_t)b * a.Dp + d0 + e] / (float)T : 0.f;
+  float* out = a.partial + (size_t)b * a.Tp;
+  for (int t = T + lane; t < a.Tp; t += 64) out[t] = 0.f;
+  for (int tb = 0; tb < T; tb += NPB * RPP) {
+    int myid = -1;
+    if (s.id_mode && valid && lane < NPB * RPP && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
+    float x[NPB][VEC];
 #pragma unroll
-      for (int p = 0; p < NPB; ++p) {
-        const int t = tb + p * RPP + rl;
-        const float* xrow = nullptr;
-        if (s.id_mode) {
-          const int id = __shfl(myid, p * RPP + rl, 64);
-          if (t < T && id >= 0 && id < s.V) xrow = s.emb + (long long)id * D;
-        } else if (valid && t < T) {
-          xrow = s.X + gr * (long long)s.xcols + s.r_ub + t * D;
-        }
-        load_row<VEC>(xrow, d0, D, x[p]);
+    for (int p = 0; p < NPB; ++p) {
+      const int t = tb + p * RPP + rl;
+      const float* xrow = nullptr;
+      if (s.id_mode) {
+        const int id = __shfl(myid, p * RPP + rl, 64);
+        if (t < T && id >= 0 && id < s.V) xrow = s.emb + (long long)id * D;
+      } else if (valid && t < T) {
+        xrow = s.X + gr * (long long)s.xcols + s.r_ub + t * D;
       }
+      load_row<VEC>(xrow, d0, D, x[p]);
+    }
 #pragma unroll
-      for (int p = 0; p < NPB; ++p) {
-        const int t = tb + p * RPP + rl;
-        float dg = 0.f;
+    for (int p = 0; p < NPB; ++p) {
+      const int t = tb + p * RPP + rl;
+      float dg = 0.f;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) dg += dpt[e] * x[p][e];
-        dg = group_sum<LPR>(dg);
-        if (t < T && dl == 0) {
-          const float g = a.gate[(size_t)b * T + t];
-          my[t] = dg * (g * (1.0f - g)) * a.wgt[(size_t)b * T + t];
-        }
+      for (int e = 0; e < VEC; ++e) dg += dpt[e] * x[p][e];
+      dg = group_sum<LPR>(dg);
+      if (t < T && dl == 0) {
+        const float g = a.gate[(size_t)b * T + t];
+        out[t] = dg * (g * (1.0f - g)) * a.wgt[(size_t)b * T + t];
       }
     }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < a.Tp; t += 64 * ATTN_BWD_WAVES) {
-    float v = 0.f;
-    if (t < T) {
-#pragma unroll
-      for (int w = 0; w < ATTN_BWD_WAVES; ++w) v += att_acc[w * a.Tp + t];
-    }
-    a.partial[(size_t)blockIdx.x * a.Tp + t] = v;
   }
 }
 
@@ -387,8 +377,20 @@ struct ReduceArgs {
 __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
   if (blockIdx.x == gridDim.x - 1) {  // last block: deterministic loss sum
     __shared__ float red[256];
+    // all loads of a thread are issued before the (fixed-order) adds: one memory latency, not B/256
     float s = 0.f;
-    for (int i = threadIdx.x; i < a.B; i += 256) s += a.lossrow[i];
+    for (int i0 = threadIdx.x * 4; i0 < a.B; i0 += 256 * 4 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 1024;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i + 3 < a.B) v[u] = *reinterpret_cast<const float4*>(a.lossrow + i);
+        else if (i < a.B) { v[u].x = a.lossrow[i]; if (i + 1 < a.B) v[u].y = a.lossrow[i + 1]; if (i + 2 < a.B) v[u].z = a.lossrow[i + 2]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -447,6 +449,44 @@ struct AdamArgs {
   float* costs;              // ring [COST_RING]
 };
 
+// one parameter's gorgonia-order Adam update (+ transposed operand copies)
+__device__ __forceinline__ void adam_apply(const AdamArgs& a, int idx, float g, float corr1, float corr2) {
+  const float b1 = (float)a.beta1, b2 = (float)a.beta2;
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  const float l2 = (float)a.l2, eps = (float)a.eps, neg_eta = (float)(-a.lr);
+  const float one_per_batch = 1.0f / (float)a.bglobal;
+  float w = a.W[idx];
+  if (a.l2_first) {
+    if (l2 != 0.f) g = g + w * l2;
+    if (a.div_by_batch && a.bglobal > 1) g = g * one_per_batch;
+  } else {
+    if (a.div_by_batch && a.bglobal > 1) g = g * one_per_batch;
+    if (l2 != 0.f) g = g + w * l2;
+  }
+  const float t1 = omb1 * g;
+  const float g2 = (g * g) * omb2;
+  const float m = b1 * a.Mo[idx] + t1;
+  const float v = b2 * a.Vo[idx] + g2;
+  a.Mo[idx] = m; a.Vo[idx] = v;
+  const float mhat = m * corr1;
+  const float vhat = v * corr2;
+  w = w + (neg_eta * mhat) / (sqrtf(vhat) + eps);
+  a.W[idx] = w;
+  // keep the transposed operand copies in sync
+  if (idx < a.off1) {
+    const int r = idx / a.H1p, c = idx - r * a.H1p;
+    if (r >= a.U && r < a.U + a.D) a.W0sT[(size_t)c * a.Dp + (r - a.U)] = w;
+  } else if (idx < a.off2) {
+    const int k = idx - a.off1;
+    const int r = k / a.H2p, c = k - r * a.H2p;
+    a.W1T[(size_t)c * a.H1p + r] = w;
+  } else if (idx < a.offa) {
+    const int k = idx - a.off2;
+    const int r = k / 16, c = k - r * 16;
+    a.W2T[(size_t)c * a.H2p + r] = w;
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   __shared__ float corr[2];
@@ -461,41 +501,78 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     a.costs[(a.st->slot - 1u) % COST_RING] = -(s / (float)a.bglobal);  // cost.go:15 Neg(Mean(...))
   }
   if (idx >= a.nflat) return;
-  const float b1 = (float)a.beta1, b2 = (float)a.beta2;
-  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
-  const float l2 = (float)a.l2, eps = (float)a.eps, neg_eta = (float)(-a.lr);
-  const float one_per_batch = 1.0f / (float)a.bglobal;
-  float w = a.W[idx];
-  float g = a.G[idx];
-  if (a.l2_first) {
-    if (l2 != 0.f) g = g + w * l2;
-    if (a.div_by_batch && a.bglobal > 1) g = g * one_per_batch;
-  } else {
-    if (a.div_by_batch && a.bglobal > 1) g = g * one_per_batch;
-    if (l2 != 0.f) g = g + w * l2;
-  }
-  const float t1 = omb1 * g;
-  const float g2 = (g * g) * omb2;
-  const float m = b1 * a.Mo[idx] + t1;
-  const float v = b2 * a.Vo[idx] + g2;
-  a.Mo[idx] = m; a.Vo[idx] = v;
-  const float mhat = m * corr[0];
-  const float vhat = v * corr[1];
-  w = w + (neg_eta * mhat) / (sqrtf(vhat) + eps);
-  a.W[idx] = w;
+  const float g = a.G[idx];
   a.G[idx] = 0.f;
-  // keep the transposed operand copies in sync
-  if (idx < a.off1) {
-    const int r = idx / a.H1p, c = idx - r * a.H1p;
-    if (r >= a.U && r < a.U + a.D) a.W0sT[(size_t)c * a.Dp + (r - a.U)] = w;
-  } else if (idx < a.off2) {
-    const int k = idx - a.off1;
-    const int r = k / a.H2p, c = k - r * a.H2p;
-    a.W1T[(size_t)c * a.H1p + r] = w;
-  } else if (idx < a.offa) {
-    const int k = idx - a.off2;
-    const int r = k / 16, c = k - r * 16;
-    a.W2T[(size_t)c * a.H2p + r] = w;
+  adam_apply(a, idx, g, corr[0], corr[1]);
+}
+
+// Single-GPU fast path: slab reduce + Adam + BCE sum + step advance in ONE launch.  The step state is
+// advanced by the LAST workgroup to finish (arrival counter), i.e. after every workgroup has read it.
+struct ReduceAdamArgs { ReduceArgs r; AdamArgs ad; unsigned int* arrive; };
+
+__global__ __launch_bounds__(256) void reduce_adam_kernel(ReduceAdamArgs p) {
+  const ReduceArgs& a = p.r;
+  __shared__ float corr[2];
+  __shared__ float red[256];
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    const double it = (double)a.st->gstep + 1.0;  // this step's iteration number
+    corr[0] = 1.0f / (float)(1.0 - pow(p.ad.beta1, it));
+    corr[1] = 1.0f / (float)(1.0 - pow(p.ad.beta2, it));
+  }
+  __syncthreads();
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int e0 = (gid >> 3) * 4, pl = gid & 7;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e0 < a.nflat) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < a.nseg && e0 >= a.seg[k].begin && e0 < a.seg[k].begin + a.seg[k].len) {
+        const int spp = (a.seg[k].nslabs + 7) >> 3;
+        int lo = pl * spp, hi = lo + spp;
+        if (hi > a.seg[k].nslabs) hi = a.seg[k].nslabs;
+        const float* base = a.seg[k].slabs + (e0 - a.seg[k].begin);
+#pragma unroll 8
+        for (int j = lo; j < hi; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(base + (size_t)j * a.seg[k].stride);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  // after the butterfly all 8 lanes hold the sums: lanes 0..3 of the group update one element each
+  if (pl < 4 && e0 + pl < a.nflat) {
+    const float g = pl == 0 ? acc.x : (pl == 1 ? acc.y : (pl == 2 ? acc.z : acc.w));
+    adam_apply(p.ad, e0 + pl, g, corr[0], corr[1]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    is_last = atomicAdd(p.arrive, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < a.B; i += 256) s += a.lossrow[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *p.arrive = 0;
+    a.G[a.nflat] = red[0];
+    p.ad.costs[a.st->slot % COST_RING] = -(red[0] / (float)p.ad.bglobal);
+    a.st->gstep += 1;
+    a.st->slot += 1;
+    long long nb = a.st->batch_idx + 1;
+    a.st->batch_idx = nb >= a.st->n_batches ? 0 : nb;
   }
 }
 

@@ -316,4 +316,147 @@ inline size_t gemm_tn_lds_bytes(int kb_tiles, int nb_tiles, int ch) {
   return (size_t)2 * ch * (tn_lds_stride(kb_tiles * 16) + tn_lds_stride(nb_tiles * 16)) * sizeof(T);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Several weight-gradient GEMMs in ONE launch (they are independent, individually too small to fill the
+// chip, and each pays the same load -> LDS -> MFMA -> slab-store latency chain: run them side by side).
+// Every workgroup = 4 wavefronts = 1 x 4 waves of KTW x NTW tiles: a k-block of KTW tiles of A's columns
+// against up to 4*NTW tiles of D's columns, over `rows_per_wg` batch rows.  A problem may be posed
+// transposed (A and D swapped) so that its tile grid suits this shape; `transpose_out` then stores
+// out[k][n] at slab[n*ld_out + k] (one 16-byte store per lane: the f32 C layout has 4 consecutive k).
+struct TnProblem {
+  const float* A; int lda; int KT;
+  const float* D; int ldd; int NT;
+  float* slabs; unsigned long long slab_stride;
+  int transpose_out; int ld_out;
+  int first;   // first blockIdx.x of this problem; it owns kblocks*S blocks
+};
+struct TnMulti { TnProblem p[4]; int np; int M; int rows_per_wg; int S; };
+
+template <int KTW, int NTW, int CH>
+__global__ __launch_bounds__(256, 2) void gemm_tn_multi_kernel(TnMulti a) {
+  using MF = Mfma<float>;
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  typedef float vec_t __attribute__((ext_vector_type(4)));
+  constexpr int WN = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) if (k < a.np && (int)blockIdx.x >= a.p[k].first) pi = k;
+  const TnProblem& P = a.p[pi];
+  const int local = blockIdx.x - P.first;
+  const int kb = local / a.S, split = local - kb * a.S;
+  const int kb0 = kb * KTW;
+  int kb_t = P.KT - kb0; if (kb_t > KTW) kb_t = KTW;
+  const int nb_t = P.NT;                       // <= WN*NTW (host-checked)
+  const int Kc = kb_t * 16, Nc = nb_t * 16;
+  const int Kas = tn_lds_stride(KTW * 16), Nds = tn_lds_stride(WN * NTW * 16);
+  float* As = reinterpret_cast<float*>(goctr_smem);   // [2][CH][Kas]
+  float* Ds = As + 2 * CH * Kas;                      // [2][CH][Nds]
+
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int nt0 = wn * NTW;
+  int ncnt = nb_t - nt0; ncnt = ncnt < 0 ? 0 : (ncnt > NTW ? NTW : ncnt);
+  const int m_begin = split * a.rows_per_wg;
+  int m_end = m_begin + a.rows_per_wg;
+  if (m_end > a.M) m_end = a.M;
+
+  acc_t acc[KTW][NTW];
+#pragma unroll
+  for (int e = 0; e < KTW; ++e)
+#pragma unroll
+    for (int f = 0; f < NTW; ++f) acc[e][f] = acc_t{0, 0, 0, 0};
+
+  const int kv = Kc >> 2, nv = Nc >> 2;
+  const float* Ab = P.A + kb0 * 16;
+  const float* Db = P.D;
+  constexpr int MAXA = (CH * KTW * 4 + 255) / 256, MAXD = (CH * WN * NTW * 4 + 255) / 256;
+  vec_t ra[MAXA], rd[MAXD];
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int s = 0; s < MAXA; ++s) {
+      const int idx = tid + s * 256;
+      ra[s] = vec_t(0);
+      if (idx < CH * kv) {
+        const int r = idx / kv, cv = idx - r * kv;
+        if (m0 + r < m_end) ra[s] = *reinterpret_cast<const vec_t*>(Ab + (size_t)(m0 + r) * P.lda + cv * 4);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < MAXD; ++s) {
+      const int idx = tid + s * 256;
+      rd[s] = vec_t(0);
+      if (idx < CH * nv) {
+        const int r = idx / nv, cv = idx - r * nv;
+        if (m0 + r < m_end) rd[s] = *reinterpret_cast<const vec_t*>(Db + (size_t)(m0 + r) * P.ldd + cv * 4);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* as = As + (size_t)buf * CH * Kas;
+    float* ds = Ds + (size_t)buf * CH * Nds;
+#pragma unroll
+    for (int s = 0; s < MAXA; ++s) {
+      const int idx = tid + s * 256;
+      if (idx < CH * kv) { const int r = idx / kv, cv = idx - r * kv; *reinterpret_cast<vec_t*>(as + r * Kas + cv * 4) = ra[s]; }
+    }
+#pragma unroll
+    for (int s = 0; s < MAXD; ++s) {
+      const int idx = tid + s * 256;
+      if (idx < CH * nv) { const int r = idx / nv, cv = idx - r * nv; *reinterpret_cast<vec_t*>(ds + r * Nds + cv * 4) = rd[s]; }
+    }
+  };
+
+  if (m_begin < m_end) {
+    gload(m_begin);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += CH) {
+      const bool more = m0 + CH < m_end;
+      if (more) gload(m0 + CH);
+      const float* as = As + (size_t)buf * CH * Kas + q * Kas + i;
+      const float* ds = Ds + (size_t)buf * CH * Nds + q * Nds + nt0 * 16 + i;
+#pragma unroll
+      for (int s = 0; s < CH / 4; ++s) {
+        float av[KTW], dv[NTW];
+#pragma unroll
+        for (int e = 0; e < KTW; ++e) av[e] = as[e * 16];
+#pragma unroll
+        for (int f = 0; f < NTW; ++f) dv[f] = ds[f * 16];
+#pragma unroll
+        for (int e = 0; e < KTW; ++e)
+#pragma unroll
+          for (int f = 0; f < NTW; ++f) acc[e][f] = MF::mma(av[e], dv[f], acc[e][f]);
+        as += 4 * Kas;
+        ds += 4 * Nds;
+      }
+      if (more) lstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  float* out = P.slabs + (size_t)split * P.slab_stride;
+#pragma unroll
+  for (int e = 0; e < KTW; ++e) {
+#pragma unroll
+    for (int f = 0; f < NTW; ++f) {
+      if (e < kb_t && f < ncnt) {
+        const int k = (kb0 + e) * 16 + 4 * q, n = (nt0 + f) * 16 + i;
+        if (P.transpose_out) {
+          *reinterpret_cast<acc_t*>(out + (size_t)n * P.ld_out + k) = acc[e][f];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[(size_t)(k + r) * P.ld_out + n] = acc[e][f][r];
+        }
+      }
+    }
+  }
+}
+template <int KTW, int NTW, int CH>
+inline size_t gemm_tn_multi_lds_bytes() {
+  return sizeof(float) * 2 * CH * (tn_lds_stride(KTW * 16) + tn_lds_stride(4 * NTW * 16));
+}
+
 }  // namespace goctr
