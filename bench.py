@@ -72,7 +72,11 @@ def kernel_work():
         "gemm_fwd0": ("mfma", 2.0 * B * I * H1), "gemm_fwd1": ("mfma", 2.0 * B * H1 * H2),
         "gemm_out": ("mfma", 2.0 * B * H2), "bwd_dz1": ("mfma", 2.0 * B * H2),
         "bwd_dz0": ("mfma", 2.0 * B * H2 * H1), "bwd_dp": ("mfma", 2.0 * B * H1 * D),
-        "dW0": ("mfma", 2.0 * B * I * H1), "dW1": ("mfma", 2.0 * B * H1 * H2), "dW2": ("mfma", 2.0 * B * H2),
+        # since the fused kernels: "dW0" = ONE launch computing dW0 + dW1 + dW2 + datt0,
+        # "chain" = layers 0..2 forward + BCE + dz1 + dz0 + dp per 32-row tile
+        "dW0": ("mfma", 2.0 * B * (I * H1 + H1 * H2 + H2 + T)),
+        "dW1": ("mfma", 2.0 * B * H1 * H2), "dW2": ("mfma", 2.0 * B * H2),
+        "chain": ("mfma", 2.0 * B * (I * H1 + H1 * H2 + H2 + H2 + H2 * H1 + H1 * D)),
     }
 
 
@@ -86,12 +90,32 @@ def roofline_obj(kind, work, avg_ms):
             "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None}
 
 
+def usable_cores() -> int:
+    """host cores this process may actually use: min(affinity mask, cgroup CPU quota).  The GPU boxes run the
+    job in a container with a CPU quota far below the 256 logical CPUs nproc reports; oversubscribing it
+    collapses OpenMP throughput (measured: 686 k samples/s at 32 threads vs 16 k at 256)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())             # cgroup v1
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // p)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(budget_s=15.0):
     """the CPU oracle (port of the reference algorithm, float32, OpenMP over rows on all host cores)
     timed on a bounded sample of the same workload: dense-X DIN training steps at B=8192."""
     from oracle import pyoracle
     c = CFG
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     pyoracle.set_threads(cores)
     rows = c["B"]
     emb, ub, it, uf, cf, y = synth(rows, 7)
@@ -106,7 +130,8 @@ def cpu_baseline(budget_s=15.0):
     dt = time.perf_counter() - t0
     return {"value": round(steps * rows / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{steps} DIN training steps at batch {rows} (dense TrainSample rows, T=50, D=16), "
-                      f"oracle/orc_ctr.c with {cores} OpenMP threads, {dt:.1f} s"}
+                      f"oracle/orc_ctr.c with {cores} OpenMP threads (= the container's CPU quota; "
+                      f"{os.cpu_count()} logical CPUs visible), {dt:.1f} s"}
 
 
 def main():

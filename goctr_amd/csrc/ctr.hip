@@ -271,6 +271,7 @@ bool chain_ok(const goctr_model* m) {
   const int nt0 = m->H1p / 16;
   const int blocks_bwd = (m->H2p / 4) * (m->H1p / 4) + (m->cfg.kind == GOCTR_DIN ? (m->H1p / 4) * (m->Dp / 4) : 0);
   return (nt0 == 13 || nt0 == 14) && m->H2p == 80 && m->Dp <= 16 * CHAIN_NDP && blocks_bwd <= CHAIN_PF * 256 &&
+         m->Ip <= 16 * CHAIN_HV &&
          env_int("GOCTR_NO_CHAIN", 0) == 0;
 }
 

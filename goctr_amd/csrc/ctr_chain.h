@@ -35,6 +35,7 @@ namespace goctr {
 
 constexpr int CHAIN_KPH0 = 80;   // rows of W0 per LDS phase (5 chunks of 16)
 constexpr int CHAIN_NDP = 4;     // max 16-wide tiles of the pooled-embedding gradient (D <= 64)
+constexpr int CHAIN_HV = 10;     // h0 fragments (16 columns each) a lane keeps in registers: Ip <= 160
 constexpr int CHAIN_PF = 5;      // 4x4 blocks a thread stages per operand (5*256 >= 1248 blocks)
 
 struct ChainArgs {
@@ -74,11 +75,12 @@ struct ChainPf { chain_f4 v[CHAIN_PF][4]; };
 __device__ __forceinline__ void chain_pf_load(ChainPf& pf, const float* __restrict__ src, int src_ld, int K, int N,
                                               int tid, int blk0 = 0) {
   const int nb = N >> 2, total = (K >> 2) * nb;
+  const float rnb = 1.0f / (float)nb;
 #pragma unroll
   for (int s = 0; s < CHAIN_PF; ++s) {
     const int b = tid + s * 256 - blk0;
     if (b >= 0 && b < total) {
-      const int kq = b / nb, n4 = b - kq * nb;
+      const int kq = (int)(((float)b + 0.5f) * rnb), n4 = b - kq * nb;   // exact for b < 2^20
       const float* p = src + (size_t)(4 * kq) * src_ld + 4 * n4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) pf.v[s][r] = *reinterpret_cast<const chain_f4*>(p + (size_t)r * src_ld);
@@ -87,11 +89,12 @@ __device__ __forceinline__ void chain_pf_load(ChainPf& pf, const float* __restri
 }
 __device__ __forceinline__ void chain_pf_store(const ChainPf& pf, float* dst, int K, int N, int tid, int blk0 = 0) {
   const int nb = N >> 2, total = (K >> 2) * nb;
+  const float rnb = 1.0f / (float)nb;
 #pragma unroll
   for (int s = 0; s < CHAIN_PF; ++s) {
     const int b = tid + s * 256 - blk0;
     if (b >= 0 && b < total) {
-      const int kq = b / nb, n4 = b - kq * nb;
+      const int kq = (int)(((float)b + 0.5f) * rnb), n4 = b - kq * nb;
       float* d = dst + ((size_t)kq * N + 4 * n4) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -150,6 +153,11 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
 #pragma unroll
   for (int t = 0; t < NT0H; ++t) acc0[t] = f4{0, 0, 0, 0};
   const float* hp = a.h0 + (size_t)rowc * Ip + 4 * q;
+  // every h0 fragment of this lane: one burst of 16-byte loads up front (host guarantees Ip <= 16*CHAIN_HV)
+  f4 hall[CHAIN_HV];
+#pragma unroll
+  for (int c = 0; c < CHAIN_HV; ++c)
+    if (c * 16 < Ip) hall[c] = *reinterpret_cast<const f4*>(hp + c * 16);
   ChainPf pf;
   {
     const int kph = Ip < CHAIN_KPH0 ? Ip : CHAIN_KPH0;
@@ -158,10 +166,6 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
   for (int k0 = 0; k0 < Ip; k0 += CHAIN_KPH0) {
     const int kph = Ip - k0 < CHAIN_KPH0 ? Ip - k0 : CHAIN_KPH0;
     const int nch = kph >> 4;
-    f4 hv[CHAIN_KPH0 / 16];
-#pragma unroll
-    for (int c = 0; c < CHAIN_KPH0 / 16; ++c)
-      if (c < nch) hv[c] = *reinterpret_cast<const f4*>(hp + k0 + c * 16);
     if (k0 > 0) __syncthreads();          // previous phase's LDS reads are done
     chain_pf_store(pf, Wb, kph, H1p, tid);
     __syncthreads();
@@ -171,6 +175,9 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
     if (k1 < Ip) chain_pf_load(pf, a.W0 + (size_t)k1 * H1p, H1p, Ip - k1 < CHAIN_KPH0 ? Ip - k1 : CHAIN_KPH0, H1p, tid);
     else chain_pf_load(pf, a.W1, H2p, H1p, H2p, tid);
     const float* wp = Wb + ((size_t)q * H1p + t0 * 16 + i) * 4;
+    f4 hcur[CHAIN_KPH0 / 16];
+#pragma unroll
+    for (int c = 0; c < CHAIN_KPH0 / 16; ++c) hcur[c] = k0 == 0 ? hall[c] : hall[c + CHAIN_KPH0 / 16 < CHAIN_HV ? c + CHAIN_KPH0 / 16 : CHAIN_HV - 1];
 #pragma unroll
     for (int c = 0; c < CHAIN_KPH0 / 16; ++c) {
       if (c < nch) {
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
         for (int r = 0; r < 4; ++r)
 #pragma unroll
           for (int t = 0; t < NT0H; ++t)
-            if (t < NT0H - 1 || full) acc0[t] = MF::mma(w4[t][r], hv[c][r], acc0[t]);
+            if (t < NT0H - 1 || full) acc0[t] = MF::mma(w4[t][r], hcur[c][r], acc0[t]);
         wp += (size_t)4 * H1p * 4;
       }
     }

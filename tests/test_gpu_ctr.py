@@ -46,7 +46,7 @@ def pair(oracle, kind, U, T, D, Cc, rng, att=0, scale=None):
     return om, dm, SampleInfo.from_dims(U, T, D, Cc)
 
 
-DIMS = [(5, 3, 7, 5), (52, 10, 16, 53), (52, 50, 16, 53)]
+DIMS = [(5, 3, 7, 5), (52, 10, 16, 53), (52, 50, 16, 53), (52, 50, 64, 53)]   # last: BASELINE cfg4 (D=64, I=233)
 
 
 def test_device_is_mi355x():
@@ -102,7 +102,8 @@ def test_predict_logits(oracle, kind, att, dims):
 
 
 @pytest.mark.parametrize("kind,att", [(0, 0), (0, 1), (1, 0)])
-@pytest.mark.parametrize("dims,B,valid", [((5, 3, 7, 5), 8, 8), ((52, 10, 16, 53), 200, 137), ((52, 50, 16, 53), 512, 512)])
+@pytest.mark.parametrize("dims,B,valid", [((5, 3, 7, 5), 8, 8), ((52, 10, 16, 53), 200, 137), ((52, 50, 16, 53), 512, 512),
+                                          ((52, 50, 64, 53), 256, 250)])
 def test_loss_and_grads(oracle, kind, att, dims, B, valid):
     from goctr_amd import model as gm
     U, T, D, Cc = dims
@@ -270,3 +271,23 @@ def test_full_size_properties_cfg3():
     assert np.all((y1 > 0) & (y1 < 1))
     from sklearn.metrics import roc_auc_score
     assert roc_auc_score(Y, y1) > 0.6
+
+
+def test_modular_path_equals_fused_chain(oracle):
+    """GOCTR_NO_CHAIN=1 (generic per-layer GEMM launches, used for hidden widths other than 200/80) must agree
+    with the fused chain kernel"""
+    from goctr_amd import capi, model as gm
+    U, T, D, Cc = 52, 10, 16, 53
+    rng = np.random.default_rng(14)
+    X, Y = make_data(rng, 600, U, T, D, Cc)
+    res = []
+    for no_chain in ("0", "1"):
+        os.environ["GOCTR_NO_CHAIN"] = no_chain
+        om, dm, si = pair(oracle, 0, U, T, D, Cc, np.random.default_rng(15), scale=0.15)
+        ds = gm.Dataset.dense(X, Y, si)
+        cfg = capi.default_train_cfg(batch=200, epochs=1, dropout_mode=2, p0=0.1, p1=0.1, seed=5)
+        costs = gm.train_steps(dm, ds, cfg, 6, want_costs=True)
+        res.append((costs, dm.get_weights("mlp0"), dm.get_weights("att0")))
+    os.environ.pop("GOCTR_NO_CHAIN")
+    assert np.max(np.abs(res[0][0] - res[1][0])) <= 2e-5
+    assert np.max(np.abs(res[0][1] - res[1][1])) <= 1e-4 and np.max(np.abs(res[0][2] - res[1][2])) <= 1e-4
