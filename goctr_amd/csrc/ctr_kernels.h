@@ -84,16 +84,31 @@ struct AttnArgs {
   float* wgt;   // [B, T]
 };
 
+// DPP lane exchanges (VALU, no LDS crossbar): quad_perm / row_half_mirror / row_mirror / row_ror
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the LPR consecutive lanes of a group (LPR = 1,2,4,8,16,32,64); every lane gets the sum
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+  if (LPR >= 2) v += dpp_f32<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
+  if (LPR >= 4) v += dpp_f32<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
+  if (LPR >= 8) v += dpp_f32<0x141>(v);   // row_half_mirror: the other quad of the 8-lane half
+  if (LPR >= 16) v += dpp_f32<0x140>(v);  // row_mirror: the other half of the 16-lane row
+  if (LPR >= 32) v += __shfl_xor(v, 16, 64);
+  if (LPR >= 64) v += __shfl_xor(v, 32, 64);
   return v;
 }
+// sum over the lanes that hold the same position (lane % LPR) in every group of the wavefront
 template <int LPR>
 __device__ __forceinline__ float cross_row_sum(float v) {
-#pragma unroll
-  for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  if (LPR <= 1) v += dpp_f32<0xB1>(v);
+  if (LPR <= 2) v += dpp_f32<0x4E>(v);
+  if (LPR <= 4) v += dpp_f32<0x124>(v);   // row_ror:4  (position mod 4 preserved)
+  if (LPR <= 8) v += dpp_f32<0x128>(v);   // row_ror:8
+  if (LPR <= 16) v += __shfl_xor(v, 16, 64);
+  if (LPR <= 32) v += __shfl_xor(v, 32, 64);
   return v;
 }
 
@@ -133,6 +148,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int d0 = dl * VEC;
   const int D = a.D, T = a.T;
 
+  // user / context side features: issue the loads first so they overlap the gather chain
+  float uside[2], cside[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int ju = lane + 64 * k;
+    uside[k] = (valid && ju < a.U) ? (s.id_mode ? s.ufeat[gr * a.U + ju] : s.X[gr * (long long)s.xcols + s.r_u + ju]) : 0.f;
+    cside[k] = (valid && ju < a.C) ? (s.id_mode ? s.cfeat[gr * a.C + ju] : s.X[gr * (long long)s.xcols + s.r_c + ju]) : 0.f;
+  }
   // candidate item embedding v
   const float* vrow = nullptr;
   if (valid) {
@@ -211,16 +234,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       hrow[a.U + D + d0 + e] = vv[e];
     }
   }
-  for (int j = lane; j < a.U; j += 64) {
-    float v = 0.f;
-    if (valid) v = s.id_mode ? s.ufeat[gr * a.U + j] : s.X[gr * (long long)s.xcols + s.r_u + j];
-    hrow[j] = v;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int j = lane + 64 * k;
+    if (j < a.U) hrow[j] = uside[k];
+    if (j < a.C) hrow[a.U + 2 * D + j] = cside[k];
   }
-  for (int j = lane; j < a.C; j += 64) {
-    float v = 0.f;
-    if (valid) v = s.id_mode ? s.cfeat[gr * a.C + j] : s.X[gr * (long long)s.xcols + s.r_c + j];
-    hrow[a.U + 2 * D + j] = v;
-  }
+  for (int j = lane + 128; j < a.U; j += 64)   // (side blocks wider than 128 columns)
+    hrow[j] = valid ? (s.id_mode ? s.ufeat[gr * a.U + j] : s.X[gr * (long long)s.xcols + s.r_u + j]) : 0.f;
+  for (int j = lane + 128; j < a.C; j += 64)
+    hrow[a.U + 2 * D + j] = valid ? (s.id_mode ? s.cfeat[gr * a.C + j] : s.X[gr * (long long)s.xcols + s.r_c + j]) : 0.f;
 }
 
 // ---------------------------------------------------------------- attention backward (att0 grad)
