@@ -80,6 +80,13 @@ def kernel_work():
     }
 
 
+def chain_algorithmic_bytes():
+    """HBM bytes the fused chain launch must move: h0 in; a0, a1, dz0, dz1, dp, loss terms out."""
+    c = CFG
+    B, Ip, H1p, H2p = c["B"], 160, 208, 80
+    return 4 * B * (Ip + 2 * H1p + 2 * H2p + 16 + 3)
+
+
 def roofline_obj(kind, work, avg_ms):
     if kind == "hbm":
         ach = work / (avg_ms * 1e-3) / 1e9
@@ -88,6 +95,21 @@ def roofline_obj(kind, work, avg_ms):
     ach = work / (avg_ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc_traffic.json, written by scripts/prof_summarize.py from separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes over this same command); None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        t = json.load(open(files[-1]))["per_launch"].get(kernel)
+        return (round(t["hbm_bytes"]) if t else None), os.path.basename(files[-1])
+    except Exception:
+        return None, None
 
 
 def usable_cores() -> int:
@@ -241,10 +263,13 @@ def main():
             kind, w = work[dom]
             rl = roofline_obj(kind, w, prof[dom][0] / prof[dom][1])
             rl["kernel"] = dom
+            rl["traffic"], rl["traffic_source"] = pmc_traffic(dom)
+            rl["algorithmic_bytes"] = chain_algorithmic_bytes() if dom == "chain" else None
             out["roofline"] = rl
             gk, gw = work["attn_fwd"]
             grl = roofline_obj(gk, gw, prof["attn_fwd"][0] / prof["attn_fwd"][1])
             grl["kernel"] = "attn_fwd (embedding gather + attention pooling)"
+            grl["traffic"], grl["traffic_source"] = pmc_traffic("attn_fwd")
             out["gather_roofline"] = grl
             out["kernels"] = table
     if dist is not None:

@@ -50,6 +50,8 @@ struct goctr_model {
   int I = 0, Ip = 0, H1p = 0, H2p = 0, Dp = 0, Tp = 0;
   int off1 = 0, off2 = 0, offa = 0, nflat = 0;
   DevBuf<float> W, G, Mo, Vo, W1T, W2T, W0sT;
+  DevBuf<float> Wimg;   // LDS images of W0 | W1 | W1^T | W0[U:U+D,:]^T (ctr_chain.h), kept in sync by Adam
+  float* img(int which) { return Wimg.p + (which == 0 ? 0 : which == 1 ? off1 : which == 2 ? off1 + H1p * H2p : off1 + 2 * H1p * H2p); }
   // per-batch workspace
   int wsB = 0, tnS = 0;
   DevBuf<float> h0, P0, A0, P1, A1, yhat, lossrow, dz2, dz1, dz0, dp, gate, wgt, slabs0, slabs1, slabs2, attp;
@@ -269,9 +271,8 @@ struct StepOpts {
 // the fused chain kernel covers the reference's fixed hidden widths (200 -> 13 tiles, 80 -> 5 tiles)
 bool chain_ok(const goctr_model* m) {
   const int nt0 = m->H1p / 16;
-  const int blocks_bwd = (m->H2p / 4) * (m->H1p / 4) + (m->cfg.kind == GOCTR_DIN ? (m->H1p / 4) * (m->Dp / 4) : 0);
-  return (nt0 == 13 || nt0 == 14) && m->H2p == 80 && m->Dp <= 16 * CHAIN_NDP && blocks_bwd <= CHAIN_PF * 256 &&
-         m->Ip <= 16 * CHAIN_HV &&
+  return (nt0 == 13 || nt0 == 14) && m->H2p == 80 && m->Dp <= 16 * CHAIN_NDP && m->Ip <= 16 * CHAIN_HV &&
+         chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p) <= 160u * 1024u &&
          env_int("GOCTR_NO_CHAIN", 0) == 0;
 }
 
@@ -282,33 +283,35 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
   const bool drop = o.train && o.drop_mode != 0;
   ChainArgs a{};
   a.h0 = m->h0.p; a.Ip = m->Ip;
-  a.W0 = m->W.p; a.W1 = m->W.p + m->off1; a.W2 = m->W.p + m->off2; a.W1T = m->W1T.p; a.W0sT = m->W0sT.p;
+  a.W0i = m->img(0); a.W1i = m->img(1); a.W1Ti = m->img(2); a.W0sTi = m->img(3); a.w2 = m->W2T.p;
   a.H1 = c.H1; a.H2 = c.H2; a.H1p = m->H1p; a.H2p = m->H2p; a.Dp = m->Dp; a.B = B;
   a.train = o.train ? 1 : 0; a.kind = c.kind;
   a.d0 = DropCfg{drop && o.p0 > 0 ? o.drop_mode : 0, o.p0, m->mask0.p, c.H1, o.seed, 0u, row_off};
   a.d1 = DropCfg{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
   a.st = st; a.Y = src.Y; a.rows = src.rows; a.inv_bglobal = 1.0f / (float)(B * e.world);
-  a.wb_floats = chain_wb_floats(m->Ip, m->H1p, m->H2p, m->Dp);
+  a.buf_floats = chain_buf_floats(m->Ip, m->H1p, m->H2p);
   a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;
   a.yhat = m->yhat.p; a.lossrow = m->lossrow.p;
   static DevBuf<unsigned long long> dbgbuf;
   const bool dbg = env_int("GOCTR_CHAIN_DBG", 0) != 0;
-  if (dbg && !dbgbuf.p && dbgbuf.alloc(16)) return -1;
+  if (dbg && !dbgbuf.p && dbgbuf.alloc(CHAIN_NSTAMP)) return -1;
   a.dbg = dbg ? dbgbuf.p : nullptr;
   ProfScope ps(GOCTR_K_CHAIN);
   const dim3 grid((unsigned)cdiv(B, 32));
-  const size_t lds = chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p, m->Dp);
+  const size_t lds = chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p);
   const int dmode = (a.d0.mode || a.d1.mode) ? o.drop_mode : 0;
-  if (dmode == 0) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 0>), grid, dim3(256), lds, e.active, a);
-  else if (dmode == 1) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 1>), grid, dim3(256), lds, e.active, a);
-  else hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 2>), grid, dim3(256), lds, e.active, a);
+  if (dmode == 0) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 0>), grid, dim3(512), lds, e.active, a);
+  else if (dmode == 1) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 1>), grid, dim3(512), lds, e.active, a);
+  else hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 2>), grid, dim3(512), lds, e.active, a);
   GOCTR_HIP(hipGetLastError());
   if (dbg) {
-    unsigned long long h[16];
-    if (dbgbuf.download(h, 16)) return -1;
-    fprintf(stderr, "chain phases (s_memtime ticks, 100 MHz):");
-    for (int k = 1; k < 13; ++k) fprintf(stderr, " %d:%lld", k, (long long)(h[k] - h[k - 1]));
-    fprintf(stderr, "  total %lld\n", (long long)(h[12] - h[0]));
+    unsigned long long h[CHAIN_NSTAMP];
+    if (dbgbuf.download(h, CHAIN_NSTAMP)) return -1;
+    fprintf(stderr, "chain phases (s_memtime ticks):");
+    for (int k = 1; k < 10; ++k) fprintf(stderr, " %d:%lld", k, (long long)(h[k] - h[k - 1]));
+    fprintf(stderr, " | ph0 mma %lld bar %lld | ph1 mma %lld bar %lld | F1 mma+xw %lld bar %lld", (long long)(h[10] - h[1]), (long long)(h[2] - h[10]),
+            (long long)(h[11] - h[2]), (long long)(h[3] - h[11]), (long long)(h[12] - h[4]), (long long)(h[13] - h[12]));
+    fprintf(stderr, "  total %lld\n", (long long)(h[9] - h[0]));
   }
   return 0;
 }
@@ -447,6 +450,7 @@ AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc) {
   a.off1 = m->off1; a.off2 = m->off2; a.offa = m->offa;
   a.Ip = m->Ip; a.H1p = m->H1p; a.H2p = m->H2p; a.Dp = m->Dp; a.U = m->cfg.U; a.D = m->cfg.D;
   a.W1T = m->W1T.p; a.W2T = m->W2T.p; a.W0sT = m->W0sT.p;
+  a.W0i = m->img(0); a.W1i = m->img(1); a.W1Ti = m->img(2); a.W0sTi = m->img(3);
   a.lr = tc.lr; a.l2 = tc.l2; a.beta1 = tc.beta1; a.beta2 = tc.beta2; a.eps = tc.eps;
   a.div_by_batch = tc.adam_div_by_batch; a.l2_first = tc.adam_l2_before_batch_div;
   a.bglobal = B * e.world; a.st = m->st.p; a.costs = m->costs.p;
@@ -589,8 +593,13 @@ int upload_padded_weights(goctr_model* m, int tensor_id, const float* host, size
       buf.assign((size_t)m->Ip * m->H1p, 0.f);
       for (int r = 0; r < m->I; ++r) for (int k = 0; k < c.H1; ++k) buf[(size_t)r * m->H1p + k] = host[(size_t)r * c.H1 + k];
       if (up(m->W.p, buf)) return -1;
-      std::vector<float> t((size_t)m->H1p * m->Dp, 0.f);
-      for (int d = 0; d < c.D; ++d) for (int k = 0; k < c.H1; ++k) t[(size_t)k * m->Dp + d] = host[(size_t)(c.U + d) * c.H1 + k];
+      std::vector<float> t((size_t)m->H1p * m->Dp, 0.f), ti((size_t)m->H1p * m->Dp, 0.f), wi((size_t)m->Ip * m->H1p, 0.f);
+      for (int d = 0; d < c.D; ++d) for (int k = 0; k < c.H1; ++k) {
+        t[(size_t)k * m->Dp + d] = host[(size_t)(c.U + d) * c.H1 + k];
+        ti[img_index(k, d, m->Dp)] = host[(size_t)(c.U + d) * c.H1 + k];
+      }
+      for (int r = 0; r < m->I; ++r) for (int k = 0; k < c.H1; ++k) wi[img_index(r, k, m->H1p)] = host[(size_t)r * c.H1 + k];
+      if (up(m->img(0), wi) || up(m->img(3), ti)) return -1;
       return up(m->W0sT.p, t);
     }
     case GOCTR_W1: {
@@ -601,7 +610,12 @@ int upload_padded_weights(goctr_model* m, int tensor_id, const float* host, size
         buf[(size_t)r * m->H2p + k] = host[(size_t)r * c.H2 + k];
         t[(size_t)k * m->H1p + r] = host[(size_t)r * c.H2 + k];
       }
-      if (up(m->W.p + m->off1, buf)) return -1;
+      std::vector<float> wi((size_t)m->H1p * m->H2p, 0.f), ti((size_t)m->H2p * m->H1p, 0.f);
+      for (int r = 0; r < c.H1; ++r) for (int k = 0; k < c.H2; ++k) {
+        wi[img_index(r, k, m->H2p)] = host[(size_t)r * c.H2 + k];
+        ti[img_index(k, r, m->H1p)] = host[(size_t)r * c.H2 + k];
+      }
+      if (up(m->W.p + m->off1, buf) || up(m->img(1), wi) || up(m->img(2), ti)) return -1;
       return up(m->W1T.p, t);
     }
     case GOCTR_W2: {
@@ -688,6 +702,7 @@ int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
   m->nflat = m->offa + m->Tp;
   if (m->W.alloc(m->nflat) || m->G.alloc((size_t)m->nflat + 1) || m->Mo.alloc(m->nflat) || m->Vo.alloc(m->nflat)) return -1;
   if (m->W1T.alloc((size_t)m->H2p * m->H1p) || m->W2T.alloc((size_t)16 * m->H2p) || m->W0sT.alloc((size_t)m->H1p * m->Dp)) return -1;
+  if (m->Wimg.alloc((size_t)m->off1 + 2 * (size_t)m->H1p * m->H2p + (size_t)m->H1p * m->Dp)) return -1;
   if (m->st.alloc(1) || m->costs.alloc(COST_RING) || m->arrive.alloc(1)) return -1;
   std::vector<float> ones(cfg->T, 1.0f);  // din.go:181 att0 = 1
   if (upload_padded_weights(m.get(), GOCTR_ATT0, ones.data(), ones.size())) return -1;

@@ -12,16 +12,22 @@
 // the NEXT layer's MFMAs want.  A wavefront carries its 16 batch rows through all layers without touching
 // LDS or shuffling; LDS only stages the weight operands shared by the workgroup's 4 wavefronts.
 //
-// LDS weight image: [k/4][n][k%4] -- the 4 k-values one lane feeds to 4 consecutive MFMAs are one 16-byte
+// Weight operands live in HBM as ready-made LDS images [k/4][n][k%4] (kept in sync by the Adam kernel, one
+// extra store per parameter): the 4 k-values one lane feeds to 4 consecutive MFMAs are one 16-byte
 // ds_read_b128 (measured: one ds_read_b32 per MFMA costs 47 cycles/MFMA against 32 for register operands,
-// scripts/ubench/mfma_rate.hip).  The image is produced while staging: a thread loads a 4x4 block (4 coalesced
-// 16-byte global loads), transposes it in registers and writes 4 ds_write_b128.  Rows of n are 16 B apart, so
-// the 16 lanes of a q-group read one contiguous 256 B bank row: conflict-free.
+// scripts/ubench/mfma_rate.hip), and staging an operand is a straight copy done with the LDS-DMA path
+// (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging registers, no ds_write pass).  Rows of n
+// are 16 B apart, so the 16 lanes of a q-group read one contiguous 256 B bank row: conflict-free.
 //
-// Latency hiding with one wavefront per SIMD: the global loads of the NEXT weight operand are issued into
-// registers before the current MFMA phase and written to LDS after it (the staging area is single-buffered).
+// Two LDS weight buffers; four extra LOADER wavefronts (4..7, one per SIMD) issue the DMA of operand j+1
+// right after the barrier that retires operand j-1, so the compute wavefronts' instruction streams carry
+// nothing but ds_read_b128 + MFMA (+ epilogue VALU); inside a phase the ds_read_b128 of the next 16-k chunk
+// are issued before the current chunk's MFMAs.  Measured on gfx950 (scripts/ubench/mfma_dma_overlap.hip):
+// v_mfma_f32_* does NOT overlap with another wavefront's VALU, LDS or vector-memory work on the same SIMD
+// (bf16 MFMA does) -- fp32 matrix time and DMA landing time add up, so the byte count of the staged
+// operands (280 KB per workgroup) is part of the kernel's critical path, not hidden behind it.
 //
-// Workgroup = 4 wavefronts = 2 row tiles (32 batch rows) x 2 halves: the two wavefronts of a row tile split
+// Workgroup = 4 compute wavefronts = 2 row tiles (32 batch rows) x 2 halves: the two wavefronts of a row tile split
 // the H1 = 208 columns 7 + 6 tiles, so each holds half of A0 -- i.e. half of the K range of the next GEMM --
 // and the partial Z1 (and later partial dp) are summed through a 20 KB LDS exchange.  8192 rows => 256
 // workgroups => one per CU, 1024 wavefronts => one per SIMD.
@@ -34,74 +40,72 @@
 namespace goctr {
 
 constexpr int CHAIN_KPH0 = 80;   // rows of W0 per LDS phase (5 chunks of 16)
-constexpr int CHAIN_NDP = 4;     // max 16-wide tiles of the pooled-embedding gradient (D <= 64)
+constexpr int CHAIN_NDP = 2;     // max 16-wide tiles of the pooled-embedding gradient (D <= 32)
 constexpr int CHAIN_HV = 10;     // h0 fragments (16 columns each) a lane keeps in registers: Ip <= 160
-constexpr int CHAIN_PF = 5;      // 4x4 blocks a thread stages per operand (5*256 >= 1248 blocks)
+constexpr int CHAIN_NSTAMP = 16;
 
 struct ChainArgs {
   const float* h0; int Ip;                       // [B, Ip]
-  const float* W0; const float* W1; const float* W2;   // padded [Ip,H1p], [H1p,H2p], [H2p,16]
-  const float* W1T; const float* W0sT;                 // [H2p,H1p], [H1p,Dp]
+  // weight operands as LDS images [K/4][N][4]: W0 [Ip x H1p], W1 [H1p x H2p], W1^T [H2p x H1p],
+  // W0[U:U+D,:]^T [H1p x Dp]; w2 = the output unit's weight column, contiguous [H2p]
+  const float* W0i; const float* W1i; const float* W1Ti; const float* W0sTi; const float* w2;
   int H1, H2, H1p, H2p, Dp; int B;
   int train; int kind;
   DropCfg d0, d1; const StepState* st;
   const float* Y; long long rows; float inv_bglobal;
-  int wb_floats;                                 // size of the weight staging area (floats)
+  int buf_floats;                                // size of each of the two LDS weight buffers (floats)
   // outputs (training only, except yhat)
   float* A0; float* A1; float* dz0; float* dz1; float* dz2; float* dp; float* yhat; float* lossrow;
-  unsigned long long* dbg;                       // optional [16] phase timestamps of block 0 / wave 0 (s_memtime)
+  unsigned long long* dbg;                       // optional [CHAIN_NSTAMP] phase timestamps of block 0 / wave 0 (s_memtime)
 };
 
-inline int chain_wb_floats(int Ip, int H1p, int H2p, int Dp) {
+// floats of one LDS weight buffer: the largest staged operand (+ one tile of slack when the second half of
+// an odd tile count reads -- and discards -- one tile past the block)
+inline int chain_buf_floats(int Ip, int H1p, int H2p) {
   const int kph = Ip < CHAIN_KPH0 ? Ip : CHAIN_KPH0;
-  int a = kph * H1p;
-  int b = H1p * H2p;
-  int c = H2p * H1p + H1p * Dp;
-  int m = a > b ? a : b;
-  return (m > c ? m : c) + 256;  // slack: edge waves read (and discard) one tile past the block
+  const int a = kph * H1p, b = H1p * H2p;
+  return (a > b ? a : b) + (((H1p >> 4) & 1) ? 256 : 0);
 }
 template <int NT1>
-inline size_t chain_lds_bytes(int Ip, int H1p, int H2p, int Dp) {
-  return sizeof(float) * ((size_t)chain_wb_floats(Ip, H1p, H2p, Dp) + 4 * 64 * (NT1 * 4 > CHAIN_NDP * 4 ? NT1 * 4 : CHAIN_NDP * 4));
+inline size_t chain_lds_bytes(int Ip, int H1p, int H2p) {
+  return sizeof(float) * ((size_t)2 * chain_buf_floats(Ip, H1p, H2p) + 4 * 64 * (NT1 * 4 > CHAIN_NDP * 4 ? NT1 * 4 : CHAIN_NDP * 4));
 }
 
 typedef float chain_f4 __attribute__((ext_vector_type(4)));
 
-// One staged operand = a [K x N] row-major f32 block in global memory (K % 4 == 0, N % 4 == 0).  A thread
-// owns up to CHAIN_PF 4x4 blocks: load = 4 coalesced 16-byte loads per block (issued early), store = the
-// transposed block as 4 ds_write_b128 into the [K/4][N][4] LDS image.
-struct ChainPf { chain_f4 v[CHAIN_PF][4]; };
-
-__device__ __forceinline__ void chain_pf_load(ChainPf& pf, const float* __restrict__ src, int src_ld, int K, int N,
-                                              int tid, int blk0 = 0) {
-  const int nb = N >> 2, total = (K >> 2) * nb;
-  const float rnb = 1.0f / (float)nb;
-#pragma unroll
-  for (int s = 0; s < CHAIN_PF; ++s) {
-    const int b = tid + s * 256 - blk0;
-    if (b >= 0 && b < total) {
-      const int kq = (int)(((float)b + 0.5f) * rnb), n4 = b - kq * nb;   // exact for b < 2^20
-      const float* p = src + (size_t)(4 * kq) * src_ld + 4 * n4;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pf.v[s][r] = *reinterpret_cast<const chain_f4*>(p + (size_t)r * src_ld);
+// Asynchronous copy of nfl floats (multiple of 4) of a weight image into LDS with the LDS-DMA path: every
+// wave instruction moves 1 KiB (lane l -> dst + 16 l bytes); completion is covered by the vmcnt(0) of the
+// next __syncthreads().  The copy is issued one instruction at a time (step) so that the issue cost hides
+// in the shadow of the MFMAs of the phase it is interleaved with; drain() issues whatever is left.  The
+// workgroups start at rotated positions so that the CUs of an XCD do not all hit the same L2 lines at once.
+struct ChainStager {
+  const float* src; float* dst; int nfl; int steps; int j; int rot; int wave;
+  __device__ __forceinline__ void begin(const float* s, float* d, int n, int w) {
+    src = s; dst = d; nfl = n; wave = w; j = 0;
+    const int nchunks = (n + 255) >> 8;
+    steps = (nchunks + 3) >> 2;
+    rot = steps ? (int)(blockIdx.x % (unsigned)steps) : 0;
+  }
+  // every staged operand is a whole number of 16-k chunks = a multiple of 1 KiB (N % 16 == 0), so a step is
+  // all-or-nothing for the wavefront: scalar bookkeeping + one DMA instruction, no vector ALU work that would
+  // have to squeeze in between the MFMAs of the compute wavefront sharing the SIMD
+  __device__ __forceinline__ void step(int lane) {
+    if (j < steps) {
+      int jj = j + rot;
+      jj = jj >= steps ? jj - steps : jj;
+      const int c = wave + 4 * jj;
+      if (c * 256 < nfl) {
+        const char* sbase = reinterpret_cast<const char*>(src + c * 256);
+        const unsigned voff = (unsigned)lane * 16u;
+        __builtin_amdgcn_global_load_lds(sbase + voff, (__attribute__((address_space(3))) void*)(dst + c * 256), 16, 0, 0);
+      }
+      ++j;
     }
   }
-}
-__device__ __forceinline__ void chain_pf_store(const ChainPf& pf, float* dst, int K, int N, int tid, int blk0 = 0) {
-  const int nb = N >> 2, total = (K >> 2) * nb;
-  const float rnb = 1.0f / (float)nb;
-#pragma unroll
-  for (int s = 0; s < CHAIN_PF; ++s) {
-    const int b = tid + s * 256 - blk0;
-    if (b >= 0 && b < total) {
-      const int kq = (int)(((float)b + 0.5f) * rnb), n4 = b - kq * nb;
-      float* d = dst + ((size_t)kq * N + 4 * n4) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<chain_f4*>(d + 4 * j) = chain_f4{pf.v[s][0][j], pf.v[s][1][j], pf.v[s][2][j], pf.v[s][3][j]};
-    }
+  __device__ __forceinline__ void drain(int lane) {
+    while (j < steps) step(lane);
   }
-}
+};
 
 // dropout scale factor mask/keep for (row, col); DROP: 0 none, 1 explicit mask, 2 counter hash
 template <int DROP>
@@ -121,15 +125,47 @@ __device__ __forceinline__ float chain_sigm(float x) {
   return x < -88.f ? 0.0f : s;
 }
 
+// One MFMA phase: acc[t] += sum over `nch` 16-k chunks of  Wimg(chunk)[tile t] x bfrag[chunk], the A operands
+// read from LDS one chunk ahead of the MFMAs that use them.  wp = this lane's address of (chunk 0, tile 0),
+// cstride = floats between chunks, tiles are 64 floats apart.  Always all NT tiles: the wave that owns one
+// tile less multiplies a throw-away tile (it would otherwise wait for its partner at the next barrier anyway;
+// a conditional MFMA costs accumulator shuffles in every group).
+template <int NT, int NCH, typename BF>
+__device__ __forceinline__ void chain_mma_phase(chain_f4 (&acc)[NT], const float* wp, int cstride, int nch, BF&& bfrag) {
+  typedef chain_f4 f4;
+  using MF = Mfma<float>;
+  f4 wa[NT], wb[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wa[t] = *reinterpret_cast<const f4*>(wp + t * 64);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c < nch) {
+      f4 (&cur)[NT] = (c & 1) ? wb : wa;
+      f4 (&nxt)[NT] = (c & 1) ? wa : wb;
+      if (c + 1 < NCH && c + 1 < nch) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) nxt[t] = *reinterpret_cast<const f4*>(wp + (size_t)(c + 1) * cstride + t * 64);
+      }
+      const f4 b = bfrag(c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = MF::mma(cur[t][r], b[r], acc[t]);
+    }
+  }
+}
+
 template <int NT0H, int NT1, int DROP>
-__global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
+__global__ __launch_bounds__(512, 1) void ctr_chain_kernel(ChainArgs a) {
   typedef chain_f4 f4;
   using MF = Mfma<float>;
   extern __shared__ __attribute__((aligned(16))) float chain_smem[];
-  float* Wb = chain_smem;
-  float* xch = chain_smem + a.wb_floats;
+  float* const bufP = chain_smem;
+  float* const bufQ = chain_smem + a.buf_floats;
+  float* const xch = chain_smem + 2 * a.buf_floats;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rt = wave >> 1, hf = wave & 1;
   const int i = lane & 15, q = lane >> 4;
   const int row = blockIdx.x * 32 + rt * 16 + i;
@@ -141,59 +177,91 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
   int ntl = NT0 - t0;
   ntl = ntl > NT0H ? NT0H : (ntl < 0 ? 0 : ntl);
   const bool full = ntl == NT0H;   // the second half of a 13-tile layer owns one tile less
-  int stamp_i = 0;
-  auto stamp = [&]() {
-    if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[stamp_i] = __builtin_amdgcn_s_memtime();
-    ++stamp_i;
+  // phase timestamps stay in scalar registers and are written once at the end: a store in flight would be
+  // waited for by the vmcnt(0) of the next barrier and distort the very phases being timed
+  unsigned long long ts[CHAIN_NSTAMP];
+#pragma unroll
+  for (int k = 0; k < CHAIN_NSTAMP; ++k) ts[k] = 0;
+  auto stamp = [&](int k) { if (a.dbg) ts[k] = __builtin_amdgcn_s_memtime(); };
+  auto flush_stamps = [&]() {
+    if (a.dbg && blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+      for (int k = 0; k < CHAIN_NSTAMP; ++k) a.dbg[k] = ts[k];
+    }
   };
-  stamp();  // 0
+  stamp(0);
+
+  const int kph0 = Ip < CHAIN_KPH0 ? Ip : CHAIN_KPH0;
+  // ------------------------------------------------------------------ loader wavefronts (4..7)
+  // Operand j goes to LDS buffer j & 1; it is issued right after the barrier that retires operand j-1's
+  // phase... i.e. one full MFMA phase ahead of its use, and the vmcnt(0) of the loaders' next barrier makes
+  // it visible.  The barrier sequence below mirrors the compute wavefronts' one for one.
+  if (wave >= 4) {
+    ChainStager stg;
+    const int lw = wave - 4;
+    stg.begin(a.W0i, bufP, kph0 * H1p, lw);
+    stg.drain(lane);
+    __syncthreads();                                   // B1: operand 0 landed
+    int lpar = 0;
+    for (int k0 = 0; k0 < Ip; k0 += CHAIN_KPH0) {
+      float* oth = lpar ? bufP : bufQ;
+      const int k1 = k0 + CHAIN_KPH0;
+      if (k1 < Ip) stg.begin(a.W0i + (size_t)k1 * H1p, oth, (Ip - k1 < CHAIN_KPH0 ? Ip - k1 : CHAIN_KPH0) * H1p, lw);
+      else stg.begin(a.W1i, oth, H1p * H2p, lw);
+      stg.drain(lane);
+      lpar ^= 1;
+      __syncthreads();                                 // end of an F0 phase: next operand landed
+    }
+    // W1 sits in buffer lpar; W1^T goes to the other one while F1 multiplies
+    stg.begin(a.W1Ti, lpar ? bufP : bufQ, a.train ? H2p * H1p : 0, lw);
+    stg.drain(lane);
+    __syncthreads();                                   // F1 exchange barrier
+    if (a.train && a.kind == GOCTR_DIN) __syncthreads();  // dp exchange barrier
+    return;
+  }
+
+  // ------------------------------------------------------------------ compute wavefronts (0..3)
+  // every h0 fragment of this lane: one burst of 16-byte loads up front (host guarantees Ip <= 16*CHAIN_HV)
+  const float* hp = a.h0 + (size_t)rowc * Ip + 4 * q;
+  f4 hall[CHAIN_HV];
+#pragma unroll
+  for (int c = 0; c < CHAIN_HV; ++c)
+    if (c * 16 < Ip) hall[c] = *reinterpret_cast<const f4*>(hp + c * 16);
+  // small operands of the later phases, fetched while the first DMA flies
+  f4 w2v[NT1];
+#pragma unroll
+  for (int u = 0; u < NT1; ++u) w2v[u] = *reinterpret_cast<const f4*>(a.w2 + u * 16 + 4 * q);
+  float y = 0.f;
+  if (a.train) {
+    const long long gr = a.st->batch_idx * (long long)a.B + row;
+    y = (a.Y && vrow && gr < a.rows) ? a.Y[gr] : 0.f;
+  }
 
   // ------------------------------------------------------------------ F0: Z0^T = W0^T . h0^T
   f4 acc0[NT0H];
 #pragma unroll
   for (int t = 0; t < NT0H; ++t) acc0[t] = f4{0, 0, 0, 0};
-  const float* hp = a.h0 + (size_t)rowc * Ip + 4 * q;
-  // every h0 fragment of this lane: one burst of 16-byte loads up front (host guarantees Ip <= 16*CHAIN_HV)
-  f4 hall[CHAIN_HV];
+  int par = 0;   // LDS buffer holding the operand about to be consumed
+  __syncthreads();
+  stamp(1);  // first W0 phase landed
 #pragma unroll
-  for (int c = 0; c < CHAIN_HV; ++c)
-    if (c * 16 < Ip) hall[c] = *reinterpret_cast<const f4*>(hp + c * 16);
-  ChainPf pf;
-  {
-    const int kph = Ip < CHAIN_KPH0 ? Ip : CHAIN_KPH0;
-    chain_pf_load(pf, a.W0, H1p, kph, H1p, tid);
-  }
-  for (int k0 = 0; k0 < Ip; k0 += CHAIN_KPH0) {
-    const int kph = Ip - k0 < CHAIN_KPH0 ? Ip - k0 : CHAIN_KPH0;
-    const int nch = kph >> 4;
-    if (k0 > 0) __syncthreads();          // previous phase's LDS reads are done
-    chain_pf_store(pf, Wb, kph, H1p, tid);
-    __syncthreads();
-    stamp();  // 1 (3): W0 phase in LDS
-    // prefetch the next operand while this phase multiplies
-    const int k1 = k0 + CHAIN_KPH0;
-    if (k1 < Ip) chain_pf_load(pf, a.W0 + (size_t)k1 * H1p, H1p, Ip - k1 < CHAIN_KPH0 ? Ip - k1 : CHAIN_KPH0, H1p, tid);
-    else chain_pf_load(pf, a.W1, H2p, H1p, H2p, tid);
-    const float* wp = Wb + ((size_t)q * H1p + t0 * 16 + i) * 4;
-    f4 hcur[CHAIN_KPH0 / 16];
-#pragma unroll
-    for (int c = 0; c < CHAIN_KPH0 / 16; ++c) hcur[c] = k0 == 0 ? hall[c] : hall[c + CHAIN_KPH0 / 16 < CHAIN_HV ? c + CHAIN_KPH0 / 16 : CHAIN_HV - 1];
-#pragma unroll
-    for (int c = 0; c < CHAIN_KPH0 / 16; ++c) {
-      if (c < nch) {
-        f4 w4[NT0H];
-#pragma unroll
-        for (int t = 0; t < NT0H; ++t) w4[t] = *reinterpret_cast<const f4*>(wp + t * 64);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int t = 0; t < NT0H; ++t)
-            if (t < NT0H - 1 || full) acc0[t] = MF::mma(w4[t][r], hcur[c][r], acc0[t]);
-        wp += (size_t)4 * H1p * 4;
-      }
+  for (int ph = 0; ph < CHAIN_HV * 16 / CHAIN_KPH0; ++ph) {
+    const int k0 = ph * CHAIN_KPH0;
+    if (k0 < Ip) {
+      const int kph = Ip - k0 < CHAIN_KPH0 ? Ip - k0 : CHAIN_KPH0;
+      float* cur = par ? bufQ : bufP;
+      const float* wp = cur + ((size_t)q * H1p + t0 * 16 + i) * 4;
+      chain_mma_phase<NT0H, CHAIN_KPH0 / 16>(acc0, wp, 16 * H1p, kph >> 4,
+                                             [&](int c) { return hall[ph * (CHAIN_KPH0 / 16) + c < CHAIN_HV ? ph * (CHAIN_KPH0 / 16) + c : CHAIN_HV - 1]; });
+      par ^= 1;
+      stamp(10 + ph);  // MFMAs issued, before the barrier
+      __syncthreads();
+      stamp(2 + ph);  // phase done, next operand landed
     }
-    stamp();  // 2 (4): phase MFMAs issued
   }
+  // here: W1 sits in buffer `par`, the other buffer is free
+  float* const bufW1 = par ? bufQ : bufP;
+  float* const bufB = par ? bufP : bufQ;
   // sigmoid + dropout in registers; acc0 becomes A0 (post-dropout), p0 keeps the pre-dropout sigmoid
   f4 p0[NT0H];
 #pragma unroll
@@ -209,37 +277,17 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
     if (a.train && vrow && (t < NT0H - 1 || full))
       *reinterpret_cast<f4*>(a.A0 + (size_t)row * H1p + (t0 + t) * 16 + 4 * q) = acc0[t];
   }
-  stamp();  // 5: F0 epilogue
+  stamp(4);  // F0 epilogue
 
   // ------------------------------------------------------------------ F1: Z1^T = W1^T . A0^T (K split over the pair)
-  __syncthreads();
-  chain_pf_store(pf, Wb, H1p, H2p, tid);
-  __syncthreads();
-  stamp();  // 6: W1 in LDS
-  if (a.train) {  // prefetch W1^T and (DIN) W0[U:U+D,:]^T for the backward phases
-    chain_pf_load(pf, a.W1T, H1p, H2p, H1p, tid);
-    if (a.kind == GOCTR_DIN) chain_pf_load(pf, a.W0sT, Dp, H1p, Dp, tid, (H2p >> 2) * (H1p >> 2));
-  }
   f4 acc1[NT1];
 #pragma unroll
   for (int u = 0; u < NT1; ++u) acc1[u] = f4{0, 0, 0, 0};
   {
-    const float* wp = Wb + ((size_t)(t0 * 4 + q) * H2p + i) * 4;
-#pragma unroll
-    for (int t = 0; t < NT0H; ++t) {
-      if (t < NT0H - 1 || full) {
-        f4 w4[NT1];
-#pragma unroll
-        for (int u = 0; u < NT1; ++u) w4[u] = *reinterpret_cast<const f4*>(wp + u * 64);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int u = 0; u < NT1; ++u) acc1[u] = MF::mma(w4[u][r], acc0[t][r], acc1[u]);
-        wp += (size_t)4 * H2p * 4;
-      }
-    }
+    const float* wp = bufW1 + ((size_t)(t0 * 4 + q) * H2p + i) * 4;
+    chain_mma_phase<NT1, NT0H>(acc1, wp, 16 * H2p, ntl, [&](int t) { return acc0[t]; });
   }
-  stamp();  // 7: F1 MFMAs
+  stamp(5);  // F1 MFMAs
   constexpr int XS = NT1 * 4 > CHAIN_NDP * 4 ? NT1 * 4 : CHAIN_NDP * 4;
   {
     float* xw = xch + ((rt * 2 + hf) * XS) * 64 + lane;
@@ -247,15 +295,27 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
     for (int u = 0; u < NT1; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) xw[(u * 4 + r) * 64] = acc1[u][r];
-    __syncthreads();
+    stamp(12);
+    __syncthreads();   // exchange visible; W1^T landed; W1 retired
+    stamp(13);
     const float* xr = xch + ((rt * 2 + (hf ^ 1)) * XS) * 64 + lane;
 #pragma unroll
     for (int u = 0; u < NT1; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc1[u][r] += xr[(u * 4 + r) * 64];  // a+b == b+a: both halves agree bitwise
   }
+  // A operands of the dp product (this wave's K half of W0[U:U+D,:]^T) straight into registers
+  f4 wdp[CHAIN_NDP][NT0H];
+  const int ndp = Dp >> 4;
+  if (a.train && a.kind == GOCTR_DIN) {
+#pragma unroll
+    for (int v = 0; v < CHAIN_NDP; ++v)
+#pragma unroll
+      for (int t = 0; t < NT0H; ++t)
+        if (v < ndp && (t < NT0H - 1 || full))
+          wdp[v][t] = *reinterpret_cast<const f4*>(a.W0sTi + ((size_t)((t0 + t) * 4 + q) * Dp + v * 16 + i) * 4);
+  }
   f4 p1[NT1];
-  f4 w2v[NT1];
   float part = 0.f;
 #pragma unroll
   for (int u = 0; u < NT1; ++u) {
@@ -267,7 +327,6 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
       p1[u][r] = s;
       const float post = DROP ? s * chain_dropk<DROP>(a.d1, a.st, row, n) : s;
       acc1[u][r] = post;
-      w2v[u][r] = a.W2[(size_t)n * 16];
       part += post * w2v[u][r];
     }
     if (a.train && vrow && hf == 0) *reinterpret_cast<f4*>(a.A1 + (size_t)row * H2p + u * 16 + 4 * q) = acc1[u];
@@ -278,9 +337,7 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
   const float yh = sigm_out(z2);
   const bool writer = hf == 0 && q == 0 && vrow;
   if (writer) a.yhat[row] = yh;
-  if (!a.train) return;
-  const long long gr = a.st->batch_idx * (long long)a.B + row;
-  const float y = (a.Y && vrow && gr < a.rows) ? a.Y[gr] : 0.f;
+  if (!a.train) { flush_stamps(); return; }
   const float one_eps = (float)(1.0 + 1e-8);
   const float dy = -((y / yh) - ((1.0f - y) / (one_eps - yh))) * a.inv_bglobal;
   const float d2 = dy * (yh * (1.0f - yh));
@@ -299,34 +356,17 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
     }
     if (vrow && hf == 0) *reinterpret_cast<f4*>(a.dz1 + (size_t)row * H2p + u * 16 + 4 * q) = acc1[u];
   }
-  stamp();  // 8: exchange + layer-1 epilogue + output unit + dz1
+  stamp(6);  // exchange + layer-1 epilogue + output unit + dz1
 
   // ------------------------------------------------------------------ B0: dz0^T = W1 . dz1^T  (this wave's column half)
-  __syncthreads();
-  float* Wp = Wb + (size_t)H2p * H1p;
-  chain_pf_store(pf, Wb, H2p, H1p, tid);
-  if (a.kind == GOCTR_DIN) chain_pf_store(pf, Wp, H1p, Dp, tid, (H2p >> 2) * (H1p >> 2));
-  __syncthreads();
-  stamp();  // 9: W1T in LDS
   f4 dza[NT0H];
 #pragma unroll
   for (int t = 0; t < NT0H; ++t) dza[t] = f4{0, 0, 0, 0};
   {
-    const float* wp = Wb + ((size_t)q * H1p + t0 * 16 + i) * 4;
-#pragma unroll
-    for (int u = 0; u < NT1; ++u) {
-      f4 w4[NT0H];
-#pragma unroll
-      for (int t = 0; t < NT0H; ++t) w4[t] = *reinterpret_cast<const f4*>(wp + t * 64);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int t = 0; t < NT0H; ++t)
-          if (t < NT0H - 1 || full) dza[t] = MF::mma(w4[t][r], acc1[u][r], dza[t]);
-      wp += (size_t)4 * H1p * 4;
-    }
+    const float* wp = bufB + ((size_t)q * H1p + t0 * 16 + i) * 4;
+    chain_mma_phase<NT0H, NT1>(dza, wp, 16 * H1p, NT1, [&](int u) { return acc1[u]; });
   }
-  stamp();  // 10: B0 MFMAs
+  stamp(7);  // B0 MFMAs
 #pragma unroll
   for (int t = 0; t < NT0H; ++t) {
 #pragma unroll
@@ -338,39 +378,35 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
     }
     if (vrow && (t < NT0H - 1 || full)) *reinterpret_cast<f4*>(a.dz0 + (size_t)row * H1p + (t0 + t) * 16 + 4 * q) = dza[t];
   }
-  stamp();  // 11: dz0 epilogue
-  if (a.kind != GOCTR_DIN) return;
+  stamp(8);  // dz0 epilogue
+  if (a.kind != GOCTR_DIN) { flush_stamps(); return; }
 
   // ------------------------------------------------------------------ BP: dp^T = W0[U:U+D,:] . dz0^T (K split over the pair)
-  const int ndp = Dp >> 4;
   f4 dpa[CHAIN_NDP];
 #pragma unroll
   for (int v = 0; v < CHAIN_NDP; ++v) dpa[v] = f4{0, 0, 0, 0};
-  {
-    const float* wp = Wp + ((size_t)(t0 * 4 + q) * Dp + i) * 4;
 #pragma unroll
-    for (int t = 0; t < NT0H; ++t) {
-      if (t < NT0H - 1 || full) {
+  for (int t = 0; t < NT0H; ++t) {
+    if (t < NT0H - 1 || full) {
 #pragma unroll
-        for (int v = 0; v < CHAIN_NDP; ++v) {
-          if (v < ndp) {
-            const f4 w4 = *reinterpret_cast<const f4*>(wp + v * 64);
+      for (int v = 0; v < CHAIN_NDP; ++v) {
+        if (v < ndp) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dpa[v] = MF::mma(w4[r], dza[t][r], dpa[v]);
-          }
+          for (int r = 0; r < 4; ++r) dpa[v] = MF::mma(wdp[v][t][r], dza[t][r], dpa[v]);
         }
-        wp += (size_t)4 * Dp * 4;
       }
     }
   }
   {
-    float* xw = xch + ((rt * 2 + hf) * XS) * 64 + lane;
+    // second exchange area = the W1 buffer (retired by the barrier of the first exchange), so that a fast
+    // wave cannot overwrite a slot its partner has not read yet
+    float* xw = bufW1 + ((rt * 2 + hf) * XS) * 64 + lane;
 #pragma unroll
     for (int v = 0; v < CHAIN_NDP; ++v)
 #pragma unroll
       for (int r = 0; r < 4; ++r) xw[(v * 4 + r) * 64] = dpa[v][r];
     __syncthreads();
-    const float* xr = xch + ((rt * 2 + (hf ^ 1)) * XS) * 64 + lane;
+    const float* xr = bufW1 + ((rt * 2 + (hf ^ 1)) * XS) * 64 + lane;
 #pragma unroll
     for (int v = 0; v < CHAIN_NDP; ++v) {
 #pragma unroll
@@ -378,7 +414,8 @@ __global__ __launch_bounds__(256, 1) void ctr_chain_kernel(ChainArgs a) {
       if (vrow && hf == 0 && v < ndp) *reinterpret_cast<f4*>(a.dp + (size_t)row * Dp + v * 16 + 4 * q) = dpa[v];
     }
   }
-  stamp();  // 12: dp done
+  stamp(9);  // dp done
+  flush_stamps();
 }
 
 }  // namespace goctr

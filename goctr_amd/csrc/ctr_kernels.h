@@ -465,12 +465,16 @@ struct AdamArgs {
   int off1, off2, offa;      // W0 at 0, W1 at off1, W2 at off2, att0 at offa
   int Ip, H1p, H2p, Dp, U, D;
   float* W1T; float* W2T; float* W0sT;  // transposed copies used by the backward-data GEMMs
+  float* W0i; float* W1i; float* W1Ti; float* W0sTi;  // LDS images [K/4][N][4] read by the chain kernel
   double lr, l2, beta1, beta2, eps;
   int div_by_batch, l2_first;
   int bglobal;
   const StepState* st;
   float* costs;              // ring [COST_RING]
 };
+
+// index of element (k, n) of a [K x N] operand inside its LDS image [K/4][N][4] (ctr_chain.h)
+__host__ __device__ inline size_t img_index(int k, int n, int N) { return ((size_t)(k >> 2) * N + n) * 4 + (k & 3); }
 
 // one parameter's gorgonia-order Adam update (+ transposed operand copies)
 __device__ __forceinline__ void adam_apply(const AdamArgs& a, int idx, float g, float corr1, float corr2) {
@@ -498,11 +502,17 @@ __device__ __forceinline__ void adam_apply(const AdamArgs& a, int idx, float g, 
   // keep the transposed operand copies in sync
   if (idx < a.off1) {
     const int r = idx / a.H1p, c = idx - r * a.H1p;
-    if (r >= a.U && r < a.U + a.D) a.W0sT[(size_t)c * a.Dp + (r - a.U)] = w;
+    a.W0i[img_index(r, c, a.H1p)] = w;
+    if (r >= a.U && r < a.U + a.D) {
+      a.W0sT[(size_t)c * a.Dp + (r - a.U)] = w;
+      a.W0sTi[img_index(c, r - a.U, a.Dp)] = w;
+    }
   } else if (idx < a.off2) {
     const int k = idx - a.off1;
     const int r = k / a.H2p, c = k - r * a.H2p;
     a.W1T[(size_t)c * a.H1p + r] = w;
+    a.W1i[img_index(r, c, a.H2p)] = w;
+    a.W1Ti[img_index(c, r, a.H1p)] = w;
   } else if (idx < a.offa) {
     const int k = idx - a.off2;
     const int r = k / 16, c = k - r * 16;
