@@ -71,11 +71,39 @@ int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-int tn_rows_per_wg() { return round_up(env_int("GOCTR_TN_ROWS", 128), 32); }
+// Slab heights of the weight-gradient launch.  fp32 MFMA work of co-resident workgroups serialises on a SIMD,
+// so the launch is sized to ONE equally expensive workgroup per CU: the 3-tile problems (dW0: ceil(Ip/48)
+// blocks, dW1: ceil(H2p/48) blocks per slab) take `rows` batch rows per workgroup, the one-tile problems
+// (dW2, datt0: a third of the MFMAs per row) take 3x as many.
+#ifndef GOCTR_TN_CH
+#define GOCTR_TN_CH 32
+#endif
+struct TnSchedule { int rows, S, rows_light, S_light; };
+TnSchedule tn_schedule(const goctr_model* m, int B) {
+  TnSchedule t{};
+  const int forced = env_int("GOCTR_TN_ROWS", 0);
+  const int heavy = (int)cdiv(m->Ip / 16, 3) + (int)cdiv(m->H2p / 16, 3);
+  const int light = m->cfg.kind == GOCTR_DIN ? 2 : 1;
+  int cus = engine().compute_units > 0 ? engine().compute_units : 256;
+  const int lf = env_int("GOCTR_TN_LIGHT", 25);   // light slab height = lf/10 x the heavy one
+  // workgroups(rows) = heavy*ceil(B/rows) + light*ceil(B/(lf rows)) <= cus ; smallest such rows (multiple of 4)
+  int rows = forced > 0 ? round_up(forced, 4) : 32;
+  if (forced <= 0) {
+    for (;; rows += 4) {
+      const long wgs = (long)heavy * cdiv(B, rows) + (long)light * cdiv(B, round_up(rows * lf / 10, 4));
+      if (wgs <= cus || rows >= B) break;
+    }
+    if (rows < 32) rows = 32;
+  }
+  t.rows = rows; t.S = (int)cdiv(B, rows);
+  t.rows_light = round_up(rows * lf / 10, 4); t.S_light = (int)cdiv(B, t.rows_light);
+  return t;
+}
+int tn_max_slabs(int B) { return (int)cdiv(B, 32); }
 
 int ensure_workspace(goctr_model* m, int B) {
   if (m->wsB >= B && m->tnS > 0) return 0;
-  const int S = (int)cdiv(B, tn_rows_per_wg());
+  const int S = tn_max_slabs(B);   // upper bound over every schedule tn_schedule() can pick
   m->tnS = S;
   if (m->h0.alloc((size_t)B * m->Ip)) return -1;
   if (m->P0.alloc((size_t)B * m->H1p)) return -1;
@@ -203,7 +231,7 @@ int init_kernel_attrs() {
   if (GOCTR_NN_ATTR(EpiSigDrop) || GOCTR_NN_ATTR(EpiOut) || GOCTR_NN_ATTR(EpiDSig) || GOCTR_NN_ATTR(EpiStore) ||
       allow_big_lds(ctr_chain_kernel<7, 5, 0>) || allow_big_lds(ctr_chain_kernel<7, 5, 1>) ||
       allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
-      allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, 16>)) return -1;
+      allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>)) return -1;
   done = true;
   return 0;
 }
@@ -359,8 +387,8 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   DropCfg d1{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
   const float* A0 = d0.mode ? m->A0.p : m->P0.p;
   const float* A1 = d1.mode ? m->A1.p : m->P1.p;
-  const int rpw = tn_rows_per_wg();
-  const int S = (int)cdiv(B, rpw);
+  const TnSchedule ts = tn_schedule(m, B);
+  const int rpw = ts.rows, S = ts.S, rpl = ts.rows_light, SL = ts.S_light;
 
   const bool fused = chain_ok(m);  // dz1 / dz0 / dp were already produced by the chain kernel
   if (fused) {
@@ -384,28 +412,45 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
 
   // weight gradients: all GEMMs in one launch; dW1 and dW2 are posed transposed, datt0 is a ones-column
   // product over the per-sample terms (see mfma_gemm.h: gemm_tn_multi_kernel)
-  const bool multi = m->H1p <= 256 && m->H2p <= 256 && m->Tp <= 256 && env_int("GOCTR_NO_TNMULTI", 0) == 0;
+  int nt_max = m->H1p / 16;
+  if (m->H2p / 16 > nt_max) nt_max = m->H2p / 16;
+  if (c.kind == GOCTR_DIN && m->Tp / 16 > nt_max) nt_max = m->Tp / 16;
+  const bool multi = nt_max <= 16 && gemm_tn_multi_fits<3, GOCTR_TN_CH>(nt_max) && env_int("GOCTR_NO_TNMULTI", 0) == 0;
   if (multi) {
     TnMulti tm{};
-    tm.M = B; tm.rows_per_wg = rpw; tm.S = S; tm.np = 3;
+    tm.M = B; tm.np = 3;
     const int kb0 = (int)cdiv(m->Ip / 16, 3), kb1 = (int)cdiv(m->H2p / 16, 3), kb2 = 1;
     tm.p[0] = {m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, m->slabs0.p,
-               (unsigned long long)m->Ip * m->H1p, 0, m->H1p, 0};
+               (unsigned long long)m->Ip * m->H1p, 0, m->H1p, 0, rpw, S};
     tm.p[1] = {m->dz1.p, m->H2p, m->H2p / 16, A0, m->H1p, m->H1p / 16, m->slabs1.p,
-               (unsigned long long)m->H1p * m->H2p, 1, m->H2p, kb0 * S};
+               (unsigned long long)m->H1p * m->H2p, 1, m->H2p, kb0 * S, rpw, S};
     tm.p[2] = {m->dz2.p, 16, 1, A1, m->H2p, m->H2p / 16, m->slabs2.p, (unsigned long long)m->H2p * 16, 1, 16,
-               (kb0 + kb1) * S};
-    int nblk = (kb0 + kb1 + kb2) * S;
+               (kb0 + kb1) * S, rpl, SL};
+    int nblk = (kb0 + kb1) * S + kb2 * SL;
     if (c.kind == GOCTR_DIN) {  // datt0 = ones^T . dgs  (column sums over the batch)
       tm.p[3] = {m->ones16.p, 16, 1, m->attp.p, m->Tp, m->Tp / 16, m->slabs3.p, (unsigned long long)16 * m->Tp, 0, m->Tp,
-                 nblk};
+                 nblk, rpl, SL};
       tm.np = 4;
-      nblk += S;
+      nblk += SL;
     }
-    const size_t lds_tm = gemm_tn_multi_lds_bytes<3, 4, 16>();
-    ProfScope ps(GOCTR_K_DW0);
-    hipLaunchKernelGGL((gemm_tn_multi_kernel<3, 4, 16>), dim3((unsigned)nblk), dim3(256), lds_tm, e.stream, tm);
-    GOCTR_HIP(hipGetLastError());
+    const size_t lds_tm = gemm_tn_multi_lds_bytes<3, 4, GOCTR_TN_CH>(nt_max);
+    static DevBuf<unsigned long long> tndbg;
+    const bool dbg = env_int("GOCTR_TN_DBG", 0) != 0;
+    if (dbg && !tndbg.p && tndbg.alloc(16)) return -1;
+    tm.dbg = dbg ? tndbg.p : nullptr;
+    {
+      ProfScope ps(GOCTR_K_DW0);
+      hipLaunchKernelGGL((gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>), dim3((unsigned)nblk), dim3(256), lds_tm, e.stream, tm);
+      GOCTR_HIP(hipGetLastError());
+    }
+    if (dbg) {
+      unsigned long long h[16];
+      if (tndbg.download(h, 16)) return -1;
+      for (int w = 0; w < 2; ++w)
+        fprintf(stderr, "dW wg %s: rows %d S %d nblk %d | prologue %lld, first chunk mma %lld, loop %lld, epilogue %lld, total %lld\n",
+                w ? "last" : "0", rpw, S, nblk, (long long)(h[8 * w + 1] - h[8 * w]), (long long)(h[8 * w + 2] - h[8 * w + 1]),
+                (long long)(h[8 * w + 3] - h[8 * w + 1]), (long long)(h[8 * w + 4] - h[8 * w + 3]), (long long)(h[8 * w + 4] - h[8 * w]));
+    }
   } else {
     if (launch_tn(GOCTR_K_DW0, m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, B, rpw, m->slabs0.p,
                   (size_t)m->Ip * m->H1p)) return -1;
@@ -420,10 +465,10 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   ReduceArgs ra{};
   ra.seg[0] = {m->slabs0.p, S, (unsigned long long)m->Ip * m->H1p, 0, m->Ip * m->H1p};
   ra.seg[1] = {m->slabs1.p, S, (unsigned long long)m->H1p * m->H2p, m->off1, m->H1p * m->H2p};
-  ra.seg[2] = {m->slabs2.p, S, (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
+  ra.seg[2] = {m->slabs2.p, multi ? SL : S, (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
   ra.nseg = 3;
   if (c.kind == GOCTR_DIN) {
-    ra.seg[3] = {m->slabs3.p, S, (unsigned long long)16 * m->Tp, m->offa, m->Tp};
+    ra.seg[3] = {m->slabs3.p, multi ? SL : S, (unsigned long long)16 * m->Tp, m->offa, m->Tp};
     ra.nseg = 4;
   }
   ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st.p; ra.advance = advance ? 1 : 0;

@@ -329,36 +329,41 @@ struct TnProblem {
   float* slabs; unsigned long long slab_stride;
   int transpose_out; int ld_out;
   int first;   // first blockIdx.x of this problem; it owns kblocks*S blocks
+  int rows;    // batch rows per workgroup (slab height) of this problem
+  int S;       // slabs = ceil(M / rows)
 };
-struct TnMulti { TnProblem p[4]; int np; int M; int rows_per_wg; int S; };
+struct TnMulti { TnProblem p[4]; int np; int M; unsigned long long* dbg; };
 
+// The multi-problem weight-gradient kernel.  Per workgroup: one problem, one block of KTW (3, or 1 for the
+// one-tile problems) 16-column tiles of A, ALL 16-column tiles of D split NTW = 4 per wavefront, one slab of
+// rows_per_wg batch rows.  The reduction index of  slab[k][n] = sum_m A[m][k] * D[m][n]  is the ROW of both
+// operands, so the staging transposes: a thread loads a 4-row x 4-column block (4 coalesced 16-byte loads),
+// and writes it as 4 ds_write_b128 into column-major LDS strips T[col][m] (row stride CH + 4 floats = 16 B
+// mod 128 B: the 16 lanes of a q-group read distinct bank groups).  One ds_read_b128 then holds the 4 rows a
+// lane feeds to 4 consecutive MFMAs: 7 LDS instructions per 48 MFMAs instead of 7 per 12 (on gfx950 every
+// LDS return stalls the fp32 MFMA stream of its SIMD, scripts/ubench/mfma_dma_overlap.hip).
 template <int KTW, int NTW, int CH>
-__global__ __launch_bounds__(256, 2) void gemm_tn_multi_kernel(TnMulti a) {
+__device__ __forceinline__ void tn_multi_body(const TnMulti& a, const TnProblem& P, int kb, int split, unsigned char* smem) {
   using MF = Mfma<float>;
   typedef float acc_t __attribute__((ext_vector_type(4)));
   typedef float vec_t __attribute__((ext_vector_type(4)));
-  constexpr int WN = 4;
-  extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
-  int pi = 0;
-#pragma unroll
-  for (int k = 1; k < 4; ++k) if (k < a.np && (int)blockIdx.x >= a.p[k].first) pi = k;
-  const TnProblem& P = a.p[pi];
-  const int local = blockIdx.x - P.first;
-  const int kb = local / a.S, split = local - kb * a.S;
+  constexpr int CHS = CH + 4;            // LDS floats per strip column
+  constexpr int MAXB = ((CH / 4) * (KTW * 4 + 16 * 4) + 255) / 256;   // 4x4 staging blocks per thread and chunk (NT <= 16)
   const int kb0 = kb * KTW;
   int kb_t = P.KT - kb0; if (kb_t > KTW) kb_t = KTW;
-  const int nb_t = P.NT;                       // <= WN*NTW (host-checked)
+  const int nb_t = P.NT;                 // <= 4*NTW (host-checked)
   const int Kc = kb_t * 16, Nc = nb_t * 16;
-  const int Kas = tn_lds_stride(KTW * 16), Nds = tn_lds_stride(WN * NTW * 16);
-  float* As = reinterpret_cast<float*>(goctr_smem);   // [2][CH][Kas]
-  float* Ds = As + 2 * CH * Kas;                      // [2][CH][Nds]
+  const int kv = Kc >> 2, nv = Nc >> 2;
+  float* As = reinterpret_cast<float*>(smem);       // [2][KTW*16][CHS]
+  float* Ds = As + 2 * KTW * 16 * CHS;              // [2][Nc][CHS]
+  const int a_buf = KTW * 16 * CHS, d_buf = Nc * CHS;
 
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int nt0 = wn * NTW;
   int ncnt = nb_t - nt0; ncnt = ncnt < 0 ? 0 : (ncnt > NTW ? NTW : ncnt);
-  const int m_begin = split * a.rows_per_wg;
-  int m_end = m_begin + a.rows_per_wg;
+  const int m_begin = split * P.rows;
+  int m_end = m_begin + P.rows;
   if (m_end > a.M) m_end = a.M;
 
   acc_t acc[KTW][NTW];
@@ -367,76 +372,104 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_multi_kernel(TnMulti a) {
 #pragma unroll
     for (int f = 0; f < NTW; ++f) acc[e][f] = acc_t{0, 0, 0, 0};
 
-  const int kv = Kc >> 2, nv = Nc >> 2;
-  const float* Ab = P.A + kb0 * 16;
-  const float* Db = P.D;
-  constexpr int MAXA = (CH * KTW * 4 + 255) / 256, MAXD = (CH * WN * NTW * 4 + 255) / 256;
-  vec_t ra[MAXA], rd[MAXD];
+  // staging slots of this thread: block b = tid + 256 s  ->  (strip, row group rg, column group cg)
+  const int nA = (CH / 4) * kv, nAll = nA + (CH / 4) * nv;
+  const float* gsrc[MAXB]; int ld[MAXB]; int rg[MAXB]; int lofs[MAXB];   // lofs < 0: slot unused
+  {
+    const float rkv = 1.0f / (float)kv, rnv = 1.0f / (float)nv;
+#pragma unroll
+    for (int s = 0; s < MAXB; ++s) {
+      const int b = tid + s * 256;
+      gsrc[s] = P.A; ld[s] = P.lda; rg[s] = 0; lofs[s] = -1;
+      if (b < nA) {
+        const int r = (int)(((float)b + 0.5f) * rkv), cg = b - r * kv;       // exact for b < 2^20
+        rg[s] = r; ld[s] = P.lda;
+        gsrc[s] = P.A + kb0 * 16 + cg * 4;
+        lofs[s] = (cg * 4) * CHS + 4 * r;
+      } else if (b < nAll) {
+        const int bb = b - nA;
+        const int r = (int)(((float)bb + 0.5f) * rnv), cg = bb - r * nv;
+        rg[s] = r; ld[s] = P.ldd;
+        gsrc[s] = P.D + cg * 4;
+        lofs[s] = 2 * a_buf + (cg * 4) * CHS + 4 * r;                         // relative to As
+      }
+    }
+  }
+  // Loads are unconditional (rows past the slab's end re-read its last row and are zeroed when the block is
+  // written to LDS): no predicate, no register merge, hence no s_waitcnt between the loads of a chunk.
+  vec_t st[MAXB][4];
   auto gload = [&](int m0) {
 #pragma unroll
-    for (int s = 0; s < MAXA; ++s) {
-      const int idx = tid + s * 256;
-      ra[s] = vec_t(0);
-      if (idx < CH * kv) {
-        const int r = idx / kv, cv = idx - r * kv;
-        if (m0 + r < m_end) ra[s] = *reinterpret_cast<const vec_t*>(Ab + (size_t)(m0 + r) * P.lda + cv * 4);
-      }
-    }
+    for (int s = 0; s < MAXB; ++s) {
 #pragma unroll
-    for (int s = 0; s < MAXD; ++s) {
-      const int idx = tid + s * 256;
-      rd[s] = vec_t(0);
-      if (idx < CH * nv) {
-        const int r = idx / nv, cv = idx - r * nv;
-        if (m0 + r < m_end) rd[s] = *reinterpret_cast<const vec_t*>(Db + (size_t)(m0 + r) * P.ldd + cv * 4);
+      for (int r = 0; r < 4; ++r) {
+        int rr = m0 + 4 * rg[s] + r;
+        rr = rr < m_end ? rr : m_end - 1;
+        st[s][r] = *reinterpret_cast<const vec_t*>(gsrc[s] + (size_t)rr * ld[s]);
       }
     }
   };
-  auto lstore = [&](int buf) {
-    float* as = As + (size_t)buf * CH * Kas;
-    float* ds = Ds + (size_t)buf * CH * Nds;
+  auto lstore = [&](int buf, int m0) {
 #pragma unroll
-    for (int s = 0; s < MAXA; ++s) {
-      const int idx = tid + s * 256;
-      if (idx < CH * kv) { const int r = idx / kv, cv = idx - r * kv; *reinterpret_cast<vec_t*>(as + r * Kas + cv * 4) = ra[s]; }
-    }
+    for (int s = 0; s < MAXB; ++s) {
+      if (lofs[s] >= 0) {
+        float* d = As + lofs[s] + (lofs[s] >= 2 * a_buf ? buf * d_buf : buf * a_buf);
+        if (m0 + CH <= m_end) {                      // whole chunk inside the slab (wave-uniform)
 #pragma unroll
-    for (int s = 0; s < MAXD; ++s) {
-      const int idx = tid + s * 256;
-      if (idx < CH * nv) { const int r = idx / nv, cv = idx - r * nv; *reinterpret_cast<vec_t*>(ds + r * Nds + cv * 4) = rd[s]; }
+          for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<vec_t*>(d + c * CHS) = vec_t{st[s][0][c], st[s][1][c], st[s][2][c], st[s][3][c]};
+        } else {
+          const int left = m_end - (m0 + 4 * rg[s]);   // rows of this block that exist
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<vec_t*>(d + c * CHS) = vec_t{left > 0 ? st[s][0][c] : 0.f, left > 1 ? st[s][1][c] : 0.f,
+                                                           left > 2 ? st[s][2][c] : 0.f, left > 3 ? st[s][3][c] : 0.f};
+        }
+      }
     }
   };
+  // per-lane LDS offsets of the operand columns (tiles past the problem's edge re-read the last column)
+  int aofs[KTW], dofs[NTW];
+#pragma unroll
+  for (int e = 0; e < KTW; ++e) { int c = e * 16 + i; c = c < Kc ? c : Kc - 1; aofs[e] = c * CHS + 4 * q; }
+#pragma unroll
+  for (int f = 0; f < NTW; ++f) { int c = (nt0 + f) * 16 + i; c = c < Nc ? c : Nc - 1; dofs[f] = c * CHS + 4 * q; }
 
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, tsm = 0;
+  if (a.dbg) ts0 = __builtin_amdgcn_s_memtime();
   if (m_begin < m_end) {
     gload(m_begin);
-    lstore(0);
+    lstore(0, m_begin);
     __syncthreads();
+    if (a.dbg) ts1 = __builtin_amdgcn_s_memtime();
     int buf = 0;
     for (int m0 = m_begin; m0 < m_end; m0 += CH) {
       const bool more = m0 + CH < m_end;
       if (more) gload(m0 + CH);
-      const float* as = As + (size_t)buf * CH * Kas + q * Kas + i;
-      const float* ds = Ds + (size_t)buf * CH * Nds + q * Nds + nt0 * 16 + i;
+      const float* as = As + buf * a_buf;
+      const float* ds = Ds + buf * d_buf;
 #pragma unroll
-      for (int s = 0; s < CH / 4; ++s) {
-        float av[KTW], dv[NTW];
+      for (int g = 0; g < CH / 16; ++g) {
+        vec_t av[KTW], dv[NTW];
 #pragma unroll
-        for (int e = 0; e < KTW; ++e) av[e] = as[e * 16];
+        for (int e = 0; e < KTW; ++e) av[e] = *reinterpret_cast<const vec_t*>(as + aofs[e] + g * 16);
 #pragma unroll
-        for (int f = 0; f < NTW; ++f) dv[f] = ds[f * 16];
+        for (int f = 0; f < NTW; ++f) dv[f] = *reinterpret_cast<const vec_t*>(ds + dofs[f] + g * 16);
 #pragma unroll
-        for (int e = 0; e < KTW; ++e)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int f = 0; f < NTW; ++f) acc[e][f] = MF::mma(av[e], dv[f], acc[e][f]);
-        as += 4 * Kas;
-        ds += 4 * Nds;
+          for (int e = 0; e < KTW; ++e)
+#pragma unroll
+            for (int f = 0; f < NTW; ++f) acc[e][f] = MF::mma(av[e][r], dv[f][r], acc[e][f]);
       }
-      if (more) lstore(buf ^ 1);
+      if (a.dbg && m0 == m_begin) tsm = __builtin_amdgcn_s_memtime();
+      if (more) lstore(buf ^ 1, m0 + CH);
       __syncthreads();
       buf ^= 1;
     }
   }
 
+  if (a.dbg) ts2 = __builtin_amdgcn_s_memtime();
   float* out = P.slabs + (size_t)split * P.slab_stride;
 #pragma unroll
   for (int e = 0; e < KTW; ++e) {
@@ -453,10 +486,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_multi_kernel(TnMulti a) {
       }
     }
   }
+  if (a.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) {
+    ts3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* d = a.dbg + (blockIdx.x == 0 ? 0 : 8);
+    d[0] = ts0; d[1] = ts1; d[2] = tsm; d[3] = ts2; d[4] = ts3;
+  }
 }
+
 template <int KTW, int NTW, int CH>
-inline size_t gemm_tn_multi_lds_bytes() {
-  return sizeof(float) * 2 * CH * (tn_lds_stride(KTW * 16) + tn_lds_stride(4 * NTW * 16));
+__global__ __launch_bounds__(256, 2) void gemm_tn_multi_kernel(TnMulti a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) if (k < a.np && (int)blockIdx.x >= a.p[k].first) pi = k;
+  const TnProblem& P = a.p[pi];
+  const int local = blockIdx.x - P.first;
+  const int kb = local / P.S, split = local - kb * P.S;
+  if (P.KT == 1) tn_multi_body<1, NTW, CH>(a, P, kb, split, goctr_smem);   // one-tile problems: a third of the MFMAs
+  else tn_multi_body<KTW, NTW, CH>(a, P, kb, split, goctr_smem);
 }
+// LDS bytes for problems whose widest D operand has nt_max 16-column tiles
+template <int KTW, int NTW, int CH>
+inline size_t gemm_tn_multi_lds_bytes(int nt_max) {
+  return sizeof(float) * 2 * (CH + 4) * (size_t)(KTW * 16 + nt_max * 16);
+}
+template <int KTW, int CH>
+inline bool gemm_tn_multi_fits(int nt_max) { return nt_max <= 16; }
 
 }  // namespace goctr
