@@ -34,14 +34,18 @@ struct goctr_dataset {
 };
 
 struct StepGraph {
-  hipGraphExec_t a = nullptr, b = nullptr;  // b only when a communicator splits the step
+  // One captured step per ping-pong parity of the step state (a step reads slot p and writes slot p^1).
+  // b[] only when a communicator splits the step (all-reduce between reduce and Adam).
+  hipGraphExec_t a[2] = {nullptr, nullptr}, b[2] = {nullptr, nullptr};
   // cache key
   const void* ds = nullptr; const void* emb = nullptr; int B = 0; int mode = 0; float p0 = 0, p1 = 0;
   uint32_t seed = 0; double lr = 0, l2 = 0, b1 = 0, b2 = 0, eps = 0; int flags = 0; int world = 1;
   void destroy() {
-    if (a) (void)hipGraphExecDestroy(a);
-    if (b) (void)hipGraphExecDestroy(b);
-    a = b = nullptr;
+    for (int k = 0; k < 2; ++k) {
+      if (a[k]) (void)hipGraphExecDestroy(a[k]);
+      if (b[k]) (void)hipGraphExecDestroy(b[k]);
+      a[k] = b[k] = nullptr;
+    }
   }
 };
 
@@ -56,8 +60,10 @@ struct goctr_model {
   int wsB = 0, tnS = 0;
   DevBuf<float> h0, P0, A0, P1, A1, yhat, lossrow, dz2, dz1, dz0, dp, gate, wgt, slabs0, slabs1, slabs2, attp;
   DevBuf<float> mask0, mask1, slabs3, ones16;
-  DevBuf<StepState> st, pst;
-  DevBuf<unsigned int> arrive;   // arrival counter of the fused reduce+adam kernel
+  DevBuf<StepState> st, pst;   // st: two ping-pong slots, stp = the one the next step reads
+  int stp = 0;
+  StepState* st_cur() { return st.p + stp; }
+  StepState* st_next() { return st.p + (stp ^ 1); }
   DevBuf<float> costs;
   std::mutex mu;
   StepGraph graph;
@@ -348,7 +354,7 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
 int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st_override = nullptr) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
-  const StepState* st = st_override ? st_override : m->st.p;
+  const StepState* st = st_override ? st_override : m->st_cur();
   AttnArgs aa{};
   aa.src = src; aa.st = st; aa.B = B; aa.U = c.U; aa.T = c.T; aa.D = c.D; aa.C = c.C; aa.Ip = m->Ip;
   aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = m->h0.p; aa.gate = m->gate.p; aa.wgt = m->wgt.p;
@@ -380,7 +386,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
                     bool fuse_update = false) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
-  const StepState* st = m->st.p;
+  const StepState* st = m->st_cur();
   const uint32_t row_off = (uint32_t)(e.rank * B);
   const bool drop = o.drop_mode != 0;
   DropCfg d0{drop && o.p0 > 0 ? o.drop_mode : 0, o.p0, m->mask0.p, c.H1, o.seed, 0u, row_off};
@@ -471,13 +477,14 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     ra.seg[3] = {m->slabs3.p, multi ? SL : S, (unsigned long long)16 * m->Tp, m->offa, m->Tp};
     ra.nseg = 4;
   }
-  ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st.p; ra.advance = advance ? 1 : 0;
+  ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st_cur(); ra.st_out = m->st_next(); ra.advance = advance ? 1 : 0;
   if (fuse_update) {
     ReduceAdamArgs p{};
-    p.r = ra; p.ad = make_adam_args(m, B, *o.tc); p.arrive = m->arrive.p;
+    p.r = ra; p.ad = make_adam_args(m, B, *o.tc);
     ProfScope ps(GOCTR_K_REDUCE);
-    hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)cdiv((int64_t)m->nflat * 2, 256)), dim3(256), 0, e.stream, p);
+    hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)cdiv((int64_t)m->nflat * 2, 256) + 1), dim3(256), 0, e.stream, p);
     GOCTR_HIP(hipGetLastError());
+    m->stp ^= 1;   // the step is closed: later launches read the slot just written
     return 0;
   }
   {
@@ -485,6 +492,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)cdiv((int64_t)m->nflat * 2, 256) + 1), dim3(256), 0, e.stream, ra);
     GOCTR_HIP(hipGetLastError());
   }
+  if (advance) m->stp ^= 1;
   return 0;
 }
 
@@ -498,7 +506,7 @@ AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc) {
   a.W0i = m->img(0); a.W1i = m->img(1); a.W1Ti = m->img(2); a.W0sTi = m->img(3);
   a.lr = tc.lr; a.l2 = tc.l2; a.beta1 = tc.beta1; a.beta2 = tc.beta2; a.eps = tc.eps;
   a.div_by_batch = tc.adam_div_by_batch; a.l2_first = tc.adam_l2_before_batch_div;
-  a.bglobal = B * e.world; a.st = m->st.p; a.costs = m->costs.p;
+  a.bglobal = B * e.world; a.st = m->st_cur(); a.costs = m->costs.p;
   return a;
 }
 
@@ -519,7 +527,7 @@ int allreduce_grads(goctr_model* m) {
 // one full training step, eager
 int train_step_eager(goctr_model* m, const RowSource& src, int B, const StepOpts& o) {
   if (launch_forward(m, src, B, o)) return -1;
-  const bool fuse = engine().world <= 1 && env_int("GOCTR_FUSED_UPDATE", 0) != 0;
+  const bool fuse = engine().world <= 1 && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
   if (launch_backward(m, src, B, o, true, fuse)) return -1;
   if (fuse) return 0;
   if (allreduce_grads(m)) return -1;
@@ -527,7 +535,7 @@ int train_step_eager(goctr_model* m, const RowSource& src, int B, const StepOpts
 }
 
 bool graph_matches(const StepGraph& g, const goctr_dataset* d, const goctr_emb* e, int B, const StepOpts& o) {
-  return g.a && g.ds == d && g.emb == e && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
+  return g.a[0] && g.a[1] && g.ds == d && g.emb == e && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
          g.seed == o.seed && g.lr == o.tc->lr && g.l2 == o.tc->l2 && g.b1 == o.tc->beta1 && g.b2 == o.tc->beta2 &&
          g.eps == o.tc->eps && g.flags == o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div &&
          g.world == engine().world;
@@ -537,26 +545,31 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
                 const StepOpts& o) {
   Engine& e = engine();
   m->graph.destroy();
-  hipGraph_t g = nullptr;
-  GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-  const bool fuse = e.world <= 1 && env_int("GOCTR_FUSED_UPDATE", 0) != 0;
-  int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse);
-  if (!rc && e.world <= 1 && !fuse) rc = launch_adam(m, B, *o.tc);
-  hipError_t ce = hipStreamEndCapture(e.stream, &g);
-  if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
-  GOCTR_HIP(ce);
-  GOCTR_HIP(hipGraphInstantiate(&m->graph.a, g, nullptr, nullptr, 0));
-  (void)hipGraphDestroy(g);
-  if (e.world > 1) {
-    hipGraph_t g2 = nullptr;
+  const bool fuse = e.world <= 1 && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
+  const int stp_now = m->stp;
+  for (int par = 0; par < 2; ++par) {
+    m->stp = par;                      // the captured launches bake this parity's state pointers in
+    hipGraph_t g = nullptr;
     GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-    rc = launch_adam(m, B, *o.tc);
-    ce = hipStreamEndCapture(e.stream, &g2);
-    if (rc) { if (g2) (void)hipGraphDestroy(g2); return -1; }
+    int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse);
+    if (!rc && e.world <= 1 && !fuse) rc = launch_adam(m, B, *o.tc);
+    hipError_t ce = hipStreamEndCapture(e.stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); m->stp = stp_now; return -1; }
     GOCTR_HIP(ce);
-    GOCTR_HIP(hipGraphInstantiate(&m->graph.b, g2, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(g2);
+    GOCTR_HIP(hipGraphInstantiate(&m->graph.a[par], g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    if (e.world > 1) {
+      hipGraph_t g2 = nullptr;
+      GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+      rc = launch_adam(m, B, *o.tc);     // m->stp was flipped by launch_backward: Adam reads the new slot
+      ce = hipStreamEndCapture(e.stream, &g2);
+      if (rc) { if (g2) (void)hipGraphDestroy(g2); m->stp = stp_now; return -1; }
+      GOCTR_HIP(ce);
+      GOCTR_HIP(hipGraphInstantiate(&m->graph.b[par], g2, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g2);
+    }
   }
+  m->stp = stp_now;
   StepGraph& sg = m->graph;
   sg.ds = d; sg.emb = emb; sg.B = B; sg.mode = o.drop_mode; sg.p0 = o.p0; sg.p1 = o.p1; sg.seed = o.seed;
   sg.lr = o.tc->lr; sg.l2 = o.tc->l2; sg.b1 = o.tc->beta1; sg.b2 = o.tc->beta2; sg.eps = o.tc->eps;
@@ -566,13 +579,13 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
 
 int set_state(goctr_model* m, unsigned gstep, unsigned slot, long long batch_idx, long long n_batches) {
   StepState s{gstep, slot, batch_idx, n_batches};
-  GOCTR_HIP(hipMemcpyAsync(m->st.p, &s, sizeof s, hipMemcpyHostToDevice, engine().stream));
+  GOCTR_HIP(hipMemcpyAsync(m->st_cur(), &s, sizeof s, hipMemcpyHostToDevice, engine().stream));
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
   return 0;
 }
 
 int get_state(goctr_model* m, StepState* s) {
-  GOCTR_HIP(hipMemcpyAsync(s, m->st.p, sizeof *s, hipMemcpyDeviceToHost, engine().stream));
+  GOCTR_HIP(hipMemcpyAsync(s, m->st_cur(), sizeof *s, hipMemcpyDeviceToHost, engine().stream));
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
   return 0;
 }
@@ -610,10 +623,12 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
   if (use_graph) {
     if (!graph_matches(m->graph, d, emb, B, o) && build_graph(m, d, emb, src, B, o)) return -1;
     for (int s = 0; s < n_steps; ++s) {
-      GOCTR_HIP(hipGraphLaunch(m->graph.a, e.stream));
+      const int par = m->stp;
+      GOCTR_HIP(hipGraphLaunch(m->graph.a[par], e.stream));
+      m->stp ^= 1;
       if (e.world > 1) {
         if (allreduce_grads(m)) return -1;
-        GOCTR_HIP(hipGraphLaunch(m->graph.b, e.stream));
+        GOCTR_HIP(hipGraphLaunch(m->graph.b[par], e.stream));
       }
     }
   } else {
@@ -748,7 +763,7 @@ int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
   if (m->W.alloc(m->nflat) || m->G.alloc((size_t)m->nflat + 1) || m->Mo.alloc(m->nflat) || m->Vo.alloc(m->nflat)) return -1;
   if (m->W1T.alloc((size_t)m->H2p * m->H1p) || m->W2T.alloc((size_t)16 * m->H2p) || m->W0sT.alloc((size_t)m->H1p * m->Dp)) return -1;
   if (m->Wimg.alloc((size_t)m->off1 + 2 * (size_t)m->H1p * m->H2p + (size_t)m->H1p * m->Dp)) return -1;
-  if (m->st.alloc(1) || m->costs.alloc(COST_RING) || m->arrive.alloc(1)) return -1;
+  if (m->st.alloc(2) || m->costs.alloc(COST_RING)) return -1;
   std::vector<float> ones(cfg->T, 1.0f);  // din.go:181 att0 = 1
   if (upload_padded_weights(m.get(), GOCTR_ATT0, ones.data(), ones.size())) return -1;
   if (set_state(m.get(), 0, 0, 0, 1)) return -1;

@@ -390,9 +390,44 @@ struct ReduceArgs {
   int nseg; int nflat;
   const float* lossrow; int B;
   float* G;           // [nflat + 1]; G[nflat] = sum of per-row BCE terms
-  StepState* st;
+  const StepState* st;   // the step's state (read by every kernel of the step)
+  StepState* st_out;     // advance == 1: where the NEXT step's state is written (the other ping-pong slot, so
+                         // no kernel of this step can observe the update: no inter-workgroup ordering needed)
   int advance;        // 1: this launch closes the step (++gstep, next batch)
 };
+
+__device__ __forceinline__ void advance_state(const StepState* in, StepState* out) {
+  StepState s = *in;
+  s.gstep += 1;
+  s.slot += 1;
+  const long long nb = s.batch_idx + 1;
+  s.batch_idx = nb >= s.n_batches ? 0 : nb;
+  *out = s;
+}
+
+// deterministic sum of the per-row BCE terms by ONE workgroup: all loads of a thread are issued before the
+// (fixed-order) adds -- one memory latency, not B/256 -- then a fixed-shape tree in LDS; result in red[0]
+__device__ __forceinline__ void loss_sum_block(const float* lossrow, int B, float* red) {
+  float s = 0.f;
+  for (int i0 = threadIdx.x * 4; i0 < B; i0 += 256 * 4 * 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 1024;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i + 3 < B) v[u] = *reinterpret_cast<const float4*>(lossrow + i);
+      else if (i < B) { v[u].x = lossrow[i]; if (i + 1 < B) v[u].y = lossrow[i + 1]; if (i + 2 < B) v[u].z = lossrow[i + 2]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+}
 
 // Every group of 4 consecutive gradient entries is summed by 8 adjacent lanes (lane p takes a
 // contiguous 1/8 of the slabs, 16-byte loads, all independent => deep memory-level parallelism),
@@ -400,34 +435,10 @@ struct ReduceArgs {
 __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
   if (blockIdx.x == gridDim.x - 1) {  // last block: deterministic loss sum
     __shared__ float red[256];
-    // all loads of a thread are issued before the (fixed-order) adds: one memory latency, not B/256
-    float s = 0.f;
-    for (int i0 = threadIdx.x * 4; i0 < a.B; i0 += 256 * 4 * 8) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 1024;
-        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i + 3 < a.B) v[u] = *reinterpret_cast<const float4*>(a.lossrow + i);
-        else if (i < a.B) { v[u].x = a.lossrow[i]; if (i + 1 < a.B) v[u].y = a.lossrow[i + 1]; if (i + 2 < a.B) v[u].z = a.lossrow[i + 2]; }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
-    }
+    loss_sum_block(a.lossrow, a.B, red);
     if (threadIdx.x == 0) {
       a.G[a.nflat] = red[0];
-      if (a.advance) {
-        a.st->gstep += 1;
-        a.st->slot += 1;
-        long long nb = a.st->batch_idx + 1;
-        a.st->batch_idx = nb >= a.st->n_batches ? 0 : nb;
-      }
+      if (a.advance) advance_state(a.st, a.st_out);
     }
     return;
   }
@@ -539,73 +550,56 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   adam_apply(a, idx, g, corr[0], corr[1]);
 }
 
-// Single-GPU fast path: slab reduce + Adam + BCE sum + step advance in ONE launch.  The step state is
-// advanced by the LAST workgroup to finish (arrival counter), i.e. after every workgroup has read it.
-struct ReduceAdamArgs { ReduceArgs r; AdamArgs ad; unsigned int* arrive; };
+// Single-GPU fast path: slab reduce + Adam + BCE sum + step advance in ONE launch.
+struct ReduceAdamArgs { ReduceArgs r; AdamArgs ad; };
 
 __global__ __launch_bounds__(256) void reduce_adam_kernel(ReduceAdamArgs p) {
   const ReduceArgs& a = p.r;
   __shared__ float corr[2];
   __shared__ float red[256];
-  __shared__ int is_last;
-  if (threadIdx.x == 0) {
-    const double it = (double)a.st->gstep + 1.0;  // this step's iteration number
-    corr[0] = 1.0f / (float)(1.0 - pow(p.ad.beta1, it));
-    corr[1] = 1.0f / (float)(1.0 - pow(p.ad.beta2, it));
-  }
-  __syncthreads();
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int e0 = (gid >> 3) * 4, pl = gid & 7;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (e0 < a.nflat) {
+  if (blockIdx.x == gridDim.x - 1) {   // the loss block runs beside the gradient blocks
+    loss_sum_block(a.lossrow, a.B, red);
+    if (threadIdx.x == 0) {
+      a.G[a.nflat] = red[0];
+      p.ad.costs[a.st->slot % COST_RING] = -(red[0] / (float)p.ad.bglobal);   // cost.go:15 Neg(Mean(...))
+      advance_state(a.st, a.st_out);
+    }
+  } else {
+    if (threadIdx.x == 0) {
+      const double it = (double)a.st->gstep + 1.0;  // this step's iteration number
+      corr[0] = 1.0f / (float)(1.0 - pow(p.ad.beta1, it));
+      corr[1] = 1.0f / (float)(1.0 - pow(p.ad.beta2, it));
+    }
+    __syncthreads();
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int e0 = (gid >> 3) * 4, pl = gid & 7;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e0 < a.nflat) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < a.nseg && e0 >= a.seg[k].begin && e0 < a.seg[k].begin + a.seg[k].len) {
-        const int spp = (a.seg[k].nslabs + 7) >> 3;
-        int lo = pl * spp, hi = lo + spp;
-        if (hi > a.seg[k].nslabs) hi = a.seg[k].nslabs;
-        const float* base = a.seg[k].slabs + (e0 - a.seg[k].begin);
+      for (int k = 0; k < 4; ++k) {
+        if (k < a.nseg && e0 >= a.seg[k].begin && e0 < a.seg[k].begin + a.seg[k].len) {
+          const int spp = (a.seg[k].nslabs + 7) >> 3;
+          int lo = pl * spp, hi = lo + spp;
+          if (hi > a.seg[k].nslabs) hi = a.seg[k].nslabs;
+          const float* base = a.seg[k].slabs + (e0 - a.seg[k].begin);
 #pragma unroll 8
-        for (int j = lo; j < hi; ++j) {
-          const float4 v = *reinterpret_cast<const float4*>(base + (size_t)j * a.seg[k].stride);
-          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          for (int j = lo; j < hi; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)j * a.seg[k].stride);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          }
         }
       }
     }
-  }
 #pragma unroll
-  for (int o = 1; o < 8; o <<= 1) {
-    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
-    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
-  }
-  // after the butterfly all 8 lanes hold the sums: lanes 0..3 of the group update one element each
-  if (pl < 4 && e0 + pl < a.nflat) {
-    const float g = pl == 0 ? acc.x : (pl == 1 ? acc.y : (pl == 2 ? acc.z : acc.w));
-    adam_apply(p.ad, e0 + pl, g, corr[0], corr[1]);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    is_last = atomicAdd(p.arrive, 1u) == gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!is_last) return;
-  float s = 0.f;
-  for (int i = threadIdx.x; i < a.B; i += 256) s += a.lossrow[i];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    *p.arrive = 0;
-    a.G[a.nflat] = red[0];
-    p.ad.costs[a.st->slot % COST_RING] = -(red[0] / (float)p.ad.bglobal);
-    a.st->gstep += 1;
-    a.st->slot += 1;
-    long long nb = a.st->batch_idx + 1;
-    a.st->batch_idx = nb >= a.st->n_batches ? 0 : nb;
+    for (int o = 1; o < 8; o <<= 1) {
+      acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+      acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    // after the butterfly all 8 lanes hold the sums: lanes 0..3 of the group update one element each
+    if (pl < 4 && e0 + pl < a.nflat) {
+      const float g = pl == 0 ? acc.x : (pl == 1 ? acc.y : (pl == 2 ? acc.z : acc.w));
+      adam_apply(p.ad, e0 + pl, g, corr[0], corr[1]);
+    }
   }
 }
 
