@@ -31,7 +31,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # BASELINE.json configs[2] / SURVEY.md section 8(d) cfg3
-CFG = dict(U=52, T=50, D=16, C=53, H1=200, H2=80, V=26744, B=8192, PRED_B=4096)
+CFG = dict(U=52, T=50, D=16, C=53, H1=200, H2=80, V=26744, B=8192, PRED_B=4096, KIND="din")
+FP64_MFMA_PEAK_TF = 78.6     # MI355X_MICROARCH.md: f64 MFMA peak
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: f32-input MFMA peak
 
@@ -48,7 +49,8 @@ def synth(rows: int, seed: int):
     uf = rng.random((rows, c["U"]), dtype=np.float32)
     cf = rng.random((rows, c["C"]), dtype=np.float32)
     y = (rng.random(rows) < 0.5).astype(np.float32)
-    emb = (rng.standard_normal((c["V"], c["D"])) * 0.25).astype(np.float32)
+    emb = rng.random((c["V"], c["D"]), dtype=np.float32) - 0.5 if c["V"] > 1_000_000 else \
+        (rng.standard_normal((c["V"], c["D"])) * 0.25).astype(np.float32)
     return emb, ub, it, uf, cf, y
 
 
@@ -142,7 +144,8 @@ def cpu_baseline(budget_s=15.0):
     rows = c["B"]
     emb, ub, it, uf, cf, y = synth(rows, 7)
     X = pyoracle.assemble_rows(emb, ub, it, uf, cf)
-    m = pyoracle.CtrModel(pyoracle.DIN, c["U"], c["T"], c["D"], c["C"]).init_gaussian(np.random.default_rng(1))
+    kind = pyoracle.YOUTUBE if c["KIND"] == "youtube" else pyoracle.DIN
+    m = pyoracle.CtrModel(kind, c["U"], c["T"], c["D"], c["C"]).init_gaussian(np.random.default_rng(1))
     t0 = time.perf_counter()
     m.train(X, y, batch=c["B"], epochs=1)          # one step (also warms the caches)
     one = time.perf_counter() - t0
@@ -151,9 +154,110 @@ def cpu_baseline(budget_s=15.0):
     m.train(X, y, batch=c["B"], epochs=steps)      # rows == batch => epochs == steps
     dt = time.perf_counter() - t0
     return {"value": round(steps * rows / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} DIN training steps at batch {rows} (dense TrainSample rows, T=50, D=16), "
+            "sample": f"{steps} {c['KIND']} training steps at batch {rows} (dense TrainSample rows, T=50, D={c['D']}), "
                       f"oracle/orc_ctr.c with {cores} OpenMP threads (= the container's CPU quota; "
                       f"{os.cpu_count()} logical CPUs visible), {dt:.1f} s"}
+
+
+def _emit(out):
+    print(json.dumps(out))
+
+
+def bench_mlp(args):
+    """BASELINE configs[1] / SURVEY 8(d) cfg2: sklearn-port MLP [281,100,1] relu/adam (float64), B = 4096, rows resident
+    in HBM; a step = forward, log-loss, backward, per-parameter Adam over one batch (nn/neural_network/basemlp64.go)."""
+    from goctr_amd import capi, mlp as gmlp
+    capi.init(0)
+    F, H, B, rows = 281, 100, 4096, 1 << 20
+    rng = np.random.default_rng(42)
+    X = rng.random((rows, F), dtype=np.float32)
+    y = (rng.random(rows) < 0.5).astype(np.float32)
+    clf = gmlp.MLPClassifier([H], "relu", "adam", 1e-5)
+    clf.BatchSize = B
+    units = [F, H, 1]
+    clf.create(units, B, clf.init_params(units, rng))
+    clf.upload(X, y)
+    clf.train_steps(args.warmup)
+    capi.sync()
+    t0 = time.perf_counter()
+    clf.train_steps(args.steps, first_batch=args.warmup)
+    capi.sync()
+    dt = time.perf_counter() - t0
+    flops = 3 * 2.0 * B * (F * H + H)                      # fwd + dX-free bwd (dW + dA): SURVEY 8(d) 113 000 / sample
+    out = {"metric": "training samples/sec (sklearn-port MLP [281,100,1], float64)", "value": round(args.steps * B / dt, 1),
+           "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[1]: MLP [281,100,1] relu/adam alpha=1e-5, batch 4096, 2^20 rows resident in HBM",
+                      "global_batch": B, "parallelism": "dp1"},
+           "roofline": {"bound": "mfma", "achieved": round(flops / (dt / args.steps) / 1e12, 3), "peak": FP64_MFMA_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": round(flops / (dt / args.steps) / 1e12 / FP64_MFMA_PEAK_TF, 4),
+                        "traffic": None, "kernel": "whole step (all launches; launch-latency bound at this size)"}}
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        cfg = pyoracle.mlp_cfg(units, "relu", alpha=1e-5)
+        theta = clf.init_params(units, np.random.default_rng(1))
+        opt = pyoracle.MlpOptimizer("adam", theta.size)
+        n = 16 * B
+        t0 = time.perf_counter()
+        pyoracle.mlp_fit(cfg, theta, opt, X[:n].astype(np.float64), y[:n, None].astype(np.float64), B, 2, tol=-1.0,
+                         perm=np.stack([np.arange(n), np.arange(n)]).astype(np.int32))
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(2 * n / dtc, 1), "unit": "samples/s", "cores": 1, "kind": "port",
+                               "sample": f"2 epochs over {n} rows at batch {B}, oracle/orc_sklmlp.c (scalar float64 port of "
+                                         f"basemlp64.go, 1 thread), {dtc:.1f} s"}
+    _emit(out)
+
+
+def bench_item2vec(args):
+    """BASELINE configs[4] per-GPU slice / SURVEY 8(d) cfg5: SkipGram + hierarchical softmax, window 5, D = 16 float64,
+    V = 10 681, Zipf(1.0) corpus resident in HBM; a step = one pass over a 10^6-word slice (Hogwild kernel, 8192 streams)."""
+    from goctr_amd import capi, embedding as ge
+    capi.init(0)
+    V, dim, n = 10681, 16, 1_000_000
+    rng = np.random.default_rng(42)
+    p = 1.0 / np.arange(1, V + 1)
+    p /= p.sum()
+    doc = rng.choice(V, size=n, p=p).astype(np.int32)
+    counts = np.bincount(doc, minlength=V) + 1
+    m = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=False)
+    m.create(counts)
+    m.upload_doc(doc)
+    steps, warm = max(1, args.steps // 20), max(1, args.warmup // 20)
+    for _ in range(warm):
+        m.train_resident(n * (steps + warm), lr=0.025)
+    capi.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.train_resident(n * (steps + warm), lr=0.025)
+    capi.sync()
+    dt = time.perf_counter() - t0
+    wps = steps * n / dt
+    bytes_per_word = 19968.0                                  # SURVEY 8(d): 6 contexts x (12 nodes x 2 x 128 B + 2 x 128 B)
+    out = {"metric": "item2vec training words/sec (SkipGram + HS, float64)", "value": round(wps, 1), "unit": "words/s",
+           "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[4] per-GPU slice: SkipGram+HS, window 5, D=16, V=10681, Zipf(1.0), "
+                                  "10^6 resident words per step, Hogwild (8192 streams)", "parallelism": "dp1"},
+           "roofline": {"bound": "hbm", "achieved": round(wps * bytes_per_word / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(wps * bytes_per_word / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "w2v hogwild kernel (algorithmic row read-modify-write bytes; the 2.7 MB of parameters "
+                                  "are L2/MALL resident)"}}
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        cores = usable_cores()
+        pyoracle.set_threads(cores)
+        cfg = pyoracle.w2v_cfg(dim=dim, optimizer="hs")
+        paths = pyoracle.huffman_paths(counts)
+        param = (np.random.default_rng(1).random((V, dim)) - 0.5) / dim
+        aux = np.zeros((V - 1, dim))
+        t0 = time.perf_counter()
+        pyoracle.w2v_train_hogwild(cfg, doc, cores, None, param, aux, paths, pyoracle.sigmoid_table(), 0.025, n)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(n / dtc, 1), "unit": "words/s", "cores": cores, "kind": "port",
+                               "sample": f"one Hogwild pass over the same 10^6-word corpus, oracle/orc_w2v.c with {cores} "
+                                         f"threads, {dtc:.1f} s"}
+    _emit(out)
 
 
 def main():
@@ -164,7 +268,17 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 18, help="resident sample rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--workload", default="din", choices=["din", "youtube", "mlp", "item2vec"],
+                    help="din = BASELINE configs[2] (the headline metric, default); youtube = configs[3] per-GPU slice "
+                         "(10M x 64 table: the HBM-bound gather); mlp = configs[1]; item2vec = configs[4] per-GPU slice")
     args = ap.parse_args()
+    if args.workload == "mlp":
+        return bench_mlp(args)
+    if args.workload == "item2vec":
+        return bench_item2vec(args)
+    if args.workload == "youtube":
+        # BASELINE configs[3] / SURVEY 8(d) cfg4: YouTube-DNN, V = 10^7, D = 64, B = 16384 per GPU
+        CFG.update(D=64, V=10_000_000, B=16384, KIND="youtube")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,7 +325,7 @@ def main():
     emb, ub, it, uf, cf, y = synth(args.rows, 42 + rank)
     tab = gm.EmbeddingTable(emb)
     ds = gm.Dataset.ids(ub, it, uf, cf, y)
-    m = gm.DinNet(c["U"], c["T"], c["D"], c["D"], c["C"])
+    m = (gm.YoutubeDnn if c["KIND"] == "youtube" else gm.DinNet)(c["U"], c["T"], c["D"], c["D"], c["C"])
     init_weights(m, 1)                                   # same weights on every rank
     cfg = capi.default_train_cfg(batch=c["B"], epochs=1)
 
@@ -235,12 +349,16 @@ def main():
     qps = pred_batches * c["PRED_B"] * world / dtp
 
     out = {
-        "metric": "training samples/sec (DIN, MovieLens-20M-shaped synthetic)", "value": round(samples_per_s, 1),
+        "metric": "training samples/sec (%s, MovieLens-20M-shaped synthetic)" % ("YouTube-DNN" if c["KIND"] == "youtube" else "DIN"),
+        "value": round(samples_per_s, 1),
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: DIN cosine attention, T=50, D=16, U=52, C=53, vocab 26744, "
-                               "batch 8192 per GPU, id mode (keys + table resident in HBM)",
+        "config": {"workload": ("BASELINE configs[3] per-GPU slice: YouTube-DNN (mean pooling), T=50, D=64, U=52, C=53, vocab 10^7 "
+                                "(2.56 GB table replicated per GPU, frozen = reference semantics), batch 16384 per GPU, id mode"
+                                if c["KIND"] == "youtube" else
+                                "BASELINE configs[2]: DIN cosine attention, T=50, D=16, U=52, C=53, vocab 26744, "
+                                "batch 8192 per GPU, id mode (keys + table resident in HBM)"),
                    "global_batch": c["B"] * world, "parallelism": f"dp{world}", "resident_rows_per_gpu": args.rows},
         "recommend_qps": round(qps, 1), "recommend_batch": c["PRED_B"],
     }
@@ -263,13 +381,15 @@ def main():
             kind, w = work[dom]
             rl = roofline_obj(kind, w, prof[dom][0] / prof[dom][1])
             rl["kernel"] = dom
-            rl["traffic"], rl["traffic_source"] = pmc_traffic(dom)
-            rl["algorithmic_bytes"] = chain_algorithmic_bytes() if dom == "chain" else None
+            if c["KIND"] == "din":     # the committed PMC passes were taken on this workload
+                rl["traffic"], rl["traffic_source"] = pmc_traffic(dom)
+                rl["algorithmic_bytes"] = chain_algorithmic_bytes() if dom == "chain" else None
             out["roofline"] = rl
             gk, gw = work["attn_fwd"]
             grl = roofline_obj(gk, gw, prof["attn_fwd"][0] / prof["attn_fwd"][1])
             grl["kernel"] = "attn_fwd (embedding gather + attention pooling)"
-            grl["traffic"], grl["traffic_source"] = pmc_traffic("attn_fwd")
+            if c["KIND"] == "din":
+                grl["traffic"], grl["traffic_source"] = pmc_traffic("attn_fwd")
             out["gather_roofline"] = grl
             out["kernels"] = table
     if dist is not None:

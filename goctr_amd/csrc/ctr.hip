@@ -305,7 +305,8 @@ struct StepOpts {
 // the fused chain kernel covers the reference's fixed hidden widths (200 -> 13 tiles, 80 -> 5 tiles)
 bool chain_ok(const goctr_model* m) {
   const int nt0 = m->H1p / 16;
-  return (nt0 == 13 || nt0 == 14) && m->H2p == 80 && m->Dp <= 16 * CHAIN_NDP && m->Ip <= 16 * CHAIN_HV &&
+  return (nt0 == 13 || nt0 == 14) && m->H2p == 80 && (m->cfg.kind != GOCTR_DIN || m->Dp <= 16 * CHAIN_NDP) &&
+         m->Ip <= 16 * CHAIN_HV &&
          chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p) <= 160u * 1024u &&
          env_int("GOCTR_NO_CHAIN", 0) == 0;
 }

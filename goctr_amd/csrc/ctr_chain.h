@@ -41,7 +41,7 @@ namespace goctr {
 
 constexpr int CHAIN_KPH0 = 80;   // rows of W0 per LDS phase (5 chunks of 16)
 constexpr int CHAIN_NDP = 2;     // max 16-wide tiles of the pooled-embedding gradient (D <= 32)
-constexpr int CHAIN_HV = 10;     // h0 fragments (16 columns each) a lane keeps in registers: Ip <= 160
+constexpr int CHAIN_HV = 15;     // h0 fragments (16 columns each) a lane keeps in registers: Ip <= 240
 constexpr int CHAIN_NSTAMP = 16;
 
 struct ChainArgs {
