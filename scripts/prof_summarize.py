@@ -16,7 +16,7 @@ import os
 import shutil
 import sys
 
-SHORT = {"attn_fwd_kernel": "attn_fwd", "ctr_chain_kernel": "chain", "attn_bwd_kernel": "attn_bwd",
+SHORT = {"reduce_adam_kernel": "reduce", "attn_fwd_kernel": "attn_fwd", "ctr_chain_kernel": "chain", "attn_bwd_kernel": "attn_bwd",
          "gemm_tn_multi_kernel": "dW0", "reduce_kernel": "reduce", "adam_kernel": "adam",
          "gemm_nn_kernel": "gemm_nn", "gemm_tn_kernel": "gemm_tn"}
 
