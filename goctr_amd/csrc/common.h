@@ -45,6 +45,9 @@ struct Engine {
   // data-parallel communicator (comm.hip)
   int rank = 0, world = 1;
   void* nccl_comm = nullptr;
+  // true when the step must take the split path (reduce -> all-reduce -> Adam): world > 1, or a one-rank
+  // communicator forced with GOCTR_FORCE_COMM=1 (exercises the RCCL path on a single-GPU box)
+  bool comm_active() const { return nccl_comm != nullptr; }
   // profiling
   bool prof = false;
   double prof_ms[GOCTR_K_COUNT] = {0};

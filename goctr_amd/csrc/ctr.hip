@@ -39,7 +39,7 @@ struct StepGraph {
   hipGraphExec_t a[2] = {nullptr, nullptr}, b[2] = {nullptr, nullptr};
   // cache key
   const void* ds = nullptr; const void* emb = nullptr; int B = 0; int mode = 0; float p0 = 0, p1 = 0;
-  uint32_t seed = 0; double lr = 0, l2 = 0, b1 = 0, b2 = 0, eps = 0; int flags = 0; int world = 1;
+  uint32_t seed = 0; double lr = 0, l2 = 0, b1 = 0, b2 = 0, eps = 0; int flags = 0; int world = 1; bool comm = false;
   void destroy() {
     for (int k = 0; k < 2; ++k) {
       if (a[k]) (void)hipGraphExecDestroy(a[k]);
@@ -520,7 +520,7 @@ int launch_adam(goctr_model* m, int B, const goctr_train_cfg& tc) {
 }
 
 int allreduce_grads(goctr_model* m) {
-  if (engine().world <= 1) return 0;
+  if (!engine().comm_active()) return 0;
   ProfScope ps(GOCTR_K_ALLREDUCE);
   return comm_allreduce_f32(m->G.p, (size_t)m->nflat + 1);
 }
@@ -528,7 +528,7 @@ int allreduce_grads(goctr_model* m) {
 // one full training step, eager
 int train_step_eager(goctr_model* m, const RowSource& src, int B, const StepOpts& o) {
   if (launch_forward(m, src, B, o)) return -1;
-  const bool fuse = engine().world <= 1 && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
+  const bool fuse = !engine().comm_active() && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
   if (launch_backward(m, src, B, o, true, fuse)) return -1;
   if (fuse) return 0;
   if (allreduce_grads(m)) return -1;
@@ -539,27 +539,27 @@ bool graph_matches(const StepGraph& g, const goctr_dataset* d, const goctr_emb* 
   return g.a[0] && g.a[1] && g.ds == d && g.emb == e && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
          g.seed == o.seed && g.lr == o.tc->lr && g.l2 == o.tc->l2 && g.b1 == o.tc->beta1 && g.b2 == o.tc->beta2 &&
          g.eps == o.tc->eps && g.flags == o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div &&
-         g.world == engine().world;
+         g.world == engine().world && g.comm == engine().comm_active();
 }
 
 int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, const RowSource& src, int B,
                 const StepOpts& o) {
   Engine& e = engine();
   m->graph.destroy();
-  const bool fuse = e.world <= 1 && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
+  const bool fuse = !e.comm_active() && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
   const int stp_now = m->stp;
   for (int par = 0; par < 2; ++par) {
     m->stp = par;                      // the captured launches bake this parity's state pointers in
     hipGraph_t g = nullptr;
     GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
     int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse);
-    if (!rc && e.world <= 1 && !fuse) rc = launch_adam(m, B, *o.tc);
+    if (!rc && !e.comm_active() && !fuse) rc = launch_adam(m, B, *o.tc);
     hipError_t ce = hipStreamEndCapture(e.stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); m->stp = stp_now; return -1; }
     GOCTR_HIP(ce);
     GOCTR_HIP(hipGraphInstantiate(&m->graph.a[par], g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
-    if (e.world > 1) {
+    if (e.comm_active()) {
       hipGraph_t g2 = nullptr;
       GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
       rc = launch_adam(m, B, *o.tc);     // m->stp was flipped by launch_backward: Adam reads the new slot
@@ -574,7 +574,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   StepGraph& sg = m->graph;
   sg.ds = d; sg.emb = emb; sg.B = B; sg.mode = o.drop_mode; sg.p0 = o.p0; sg.p1 = o.p1; sg.seed = o.seed;
   sg.lr = o.tc->lr; sg.l2 = o.tc->l2; sg.b1 = o.tc->beta1; sg.b2 = o.tc->beta2; sg.eps = o.tc->eps;
-  sg.flags = o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div; sg.world = e.world;
+  sg.flags = o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div; sg.world = e.world; sg.comm = e.comm_active();
   return 0;
 }
 
@@ -627,7 +627,7 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
       const int par = m->stp;
       GOCTR_HIP(hipGraphLaunch(m->graph.a[par], e.stream));
       m->stp ^= 1;
-      if (e.world > 1) {
+      if (e.comm_active()) {
         if (allreduce_grads(m)) return -1;
         GOCTR_HIP(hipGraphLaunch(m->graph.b[par], e.stream));
       }

@@ -161,7 +161,18 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     const bool is_w = r < d.fi && c < d.fo, is_b = r == d.fi && c < d.fo;
     if (is_w || is_b) {
       double s = 0;
-      for (int j = 0; j < d.nslabs; ++j) s += d.slabs[(size_t)j * d.upi * d.upo + e];
+      {   // same left-to-right order as a plain loop, but 8 loads in flight at a time
+        const size_t sstr = (size_t)d.upi * d.upo;
+        int j = 0;
+        for (; j + 8 <= d.nslabs; j += 8) {
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = d.slabs[(size_t)(j + u) * sstr + e];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; j < d.nslabs; ++j) s += d.slabs[(size_t)j * sstr + e];
+      }
       const double w = a.W[idx];
       double g = s * (1 / (double)a.n);                       // gemm alpha = 1/n (and mean for the bias row)
       if (is_w) { g += (a.alpha / (double)a.n) * w; sq = w * w; }
@@ -202,7 +213,14 @@ __global__ __launch_bounds__(256) void mlp_loss_kernel(const double* lossterm, i
                                                        int advance) {
   __shared__ double red[256];
   double s = 0;
-  for (int i = threadIdx.x; i < nterms; i += 256) s += lossterm[i];
+  // 16 independent loads in flight per thread (one memory latency per 4096 terms, not per 256), fixed order
+  for (int i0 = threadIdx.x; i0 < nterms; i0 += 256 * 16) {
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int i = i0 + u * 256; v[u] = i < nterms ? lossterm[i] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }

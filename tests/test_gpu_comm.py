@@ -1,0 +1,62 @@
+"""The multi-GPU step path (reduce -> RCCL all-reduce -> Adam, two captured graphs per state parity) exercised on ONE
+GPU: GOCTR_FORCE_COMM=1 makes goctr_comm_init build a real one-rank RCCL communicator, so every call the 8-GPU run
+makes (dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllReduce on the engine stream between the two graphs) runs
+here; with one rank the all-reduce is the identity, so the result must equal the fused single-GPU path bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %(root)r)
+from goctr_amd import capi, model as gm
+capi.init(0)
+L = capi.load()
+if %(comm)d:
+    idbuf = (C.c_uint8 * 128)()
+    capi.check(L.goctr_comm_unique_id(idbuf))
+    capi.check(L.goctr_comm_init(C.c_int(0), C.c_int(1), idbuf))
+rng = np.random.default_rng(5)
+rows, U, T, D, Cc, V = 4096, 52, 50, 16, 53, 500
+emb = (rng.standard_normal((V, D)) * 0.25).astype(np.float32)
+ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
+it = rng.integers(0, V, size=rows).astype(np.int32)
+uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+y = (rng.random(rows) < 0.5).astype(np.float32)
+tab = gm.EmbeddingTable(emb); ds = gm.Dataset.ids(ub, it, uf, cf, y)
+m = gm.DinNet(U, T, D, D, Cc).init_gaussian(np.random.default_rng(1))
+cfg = capi.default_train_cfg(batch=1024, epochs=1)
+gm.train_steps(m, ds, cfg, 7, emb=tab)          # odd count: both graph parities are replayed
+capi.sync()
+out = np.concatenate([m.get_weights(n).ravel() for n in ("mlp0", "mlp1", "mlp2", "att0")])
+np.save(%(out)r, out)
+if %(comm)d:
+    capi.check(L.goctr_comm_destroy())
+'''
+
+
+def run(tmp_path, comm, graph):
+    out = str(tmp_path / f"w_{comm}_{graph}.npy")
+    env = dict(os.environ)
+    env["GOCTR_FORCE_COMM"] = "1" if comm else "0"
+    if not graph:
+        env["GOCTR_NO_GRAPH"] = "1"
+    r = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT, comm=int(comm), out=out)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_one_rank_communicator_equals_fused_path(tmp_path, graph):
+    ref = run(tmp_path, comm=False, graph=graph)
+    got = run(tmp_path, comm=True, graph=graph)
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+    assert np.array_equal(ref, got)
