@@ -260,6 +260,48 @@ def bench_item2vec(args):
     _emit(out)
 
 
+def bench_knn(args):
+    """Searcher.Search (search.go:92-134), brute-force cosine top-10 over V = 10^6 item vectors of
+    D = 16 float64 (128 MB resident), 64 queries per call; a step = one call (scores + selection + D2H of the results)."""
+    from goctr_amd import capi, search as gs
+    capi.init(0)
+    V, D, Q, k = 1_000_000, 16, 64, 10
+    rng = np.random.default_rng(42)
+    items = rng.standard_normal((V, D))
+    s = gs.Searcher([""] * V, items)
+    queries = rng.standard_normal((Q, D))
+    steps, warm = max(1, args.steps // 10), max(1, args.warmup // 10)
+    for _ in range(warm):
+        s.search_vectors(queries, k)
+    capi.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        idx, sim, cnt = s.search_vectors(queries, k)
+    capi.sync()
+    dt = time.perf_counter() - t0
+    qps = steps * Q / dt
+    scan = qps * V * D * 8 / 1e9
+    out = {"metric": "k-NN search queries/sec (cosine top-10 over 10^6 x 16 float64 items)", "value": round(qps, 1),
+           "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "SURVEY 8(f)2: Searcher.Search, V=10^6, D=16 f64, k=10, 64 queries per call", "parallelism": "dp1"},
+           "roofline": {"bound": "hbm", "achieved": round(scan, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(scan / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "knn_tile_kernel (algorithmic: every query scans V*D*8 bytes; the 128 MB table is MALL-resident "
+                                  "across the 64 queries of a call)"}}
+    if not args.no_cpu_baseline:
+        from oracle import pyoracle
+        norms = np.sqrt((items * items).sum(1))
+        t0 = time.perf_counter()
+        nq = 4
+        for q in range(nq):
+            pyoracle.knn_search(items, queries[q], k, norms=norms)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(nq / dtc, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": f"{nq} queries through oracle/orc_search.c (the reference's sequential loop, 1 thread), {dtc:.1f} s"}
+    _emit(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,7 +310,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 18, help="resident sample rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--workload", default="din", choices=["din", "youtube", "mlp", "item2vec"],
+    ap.add_argument("--workload", default="din", choices=["din", "youtube", "mlp", "item2vec", "knn"],
                     help="din = BASELINE configs[2] (the headline metric, default); youtube = configs[3] per-GPU slice "
                          "(10M x 64 table: the HBM-bound gather); mlp = configs[1]; item2vec = configs[4] per-GPU slice")
     args = ap.parse_args()
@@ -276,6 +318,8 @@ def main():
         return bench_mlp(args)
     if args.workload == "item2vec":
         return bench_item2vec(args)
+    if args.workload == "knn":
+        return bench_knn(args)
     if args.workload == "youtube":
         # BASELINE configs[3] / SURVEY 8(d) cfg4: YouTube-DNN, V = 10^7, D = 64, B = 16384 per GPU
         CFG.update(D=64, V=10_000_000, B=16384, KIND="youtube")

@@ -218,4 +218,44 @@ inline Model TrainEmbedding(const std::vector<int64_t>& counts, const std::vecto
 }
 }  // namespace embedding
 
+namespace search {
+// feature/embedding/search/search.go: Neighbor :27-31, Searcher :52-63, SearchInternal :65-83, SearchVector :85-90
+struct Neighbor { std::string Word; unsigned Rank = 0; double Similarity = 0; };
+using Neighbors = std::vector<Neighbor>;
+class Searcher {
+ public:
+  Searcher(std::vector<std::string> words, const std::vector<double>& vectors, int dim) : words_(std::move(words)), dim_(dim) {
+    if (words_.empty() || vectors.size() != words_.size() * (size_t)dim) throw std::runtime_error("embeddings do not validate");
+    vec_ = vectors;
+    check(goctr_init(0));
+    check(goctr_searcher_create(vec_.data(), (int64_t)words_.size(), dim, &h_));
+  }
+  ~Searcher() { if (h_) goctr_searcher_destroy(h_); }
+  Searcher(const Searcher&) = delete;
+  Searcher& operator=(const Searcher&) = delete;
+  Neighbors SearchVector(const std::vector<double>& query, int k) { return search(query.data(), k, -1); }
+  Neighbors SearchInternal(const std::string& word, int k) {
+    for (size_t i = 0; i < words_.size(); ++i)
+      if (words_[i] == word) return search(vec_.data() + i * (size_t)dim_, k, (int64_t)i);
+    throw std::runtime_error(word + " is not found in searcher");   // search.go:73-75
+  }
+
+ private:
+  Neighbors search(const double* q, int k, int64_t ignore) {
+    std::vector<int64_t> idx(k);
+    std::vector<double> sim(k);
+    int count = 0;
+    check(goctr_searcher_search(h_, q, 1, k, ignore >= 0 ? &ignore : nullptr, idx.data(), sim.data(), &count));
+    Neighbors out(count);
+    for (int r = 0; r < count; ++r)
+      if (idx[r] >= 0) out[r] = Neighbor{words_[(size_t)idx[r]], (unsigned)r + 1, sim[r]};
+    return out;
+  }
+  std::vector<std::string> words_;
+  std::vector<double> vec_;
+  int dim_;
+  goctr_searcher* h_ = nullptr;
+};
+}  // namespace search
+
 }  // namespace goctr

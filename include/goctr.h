@@ -235,6 +235,22 @@ int goctr_w2v_train_resident(goctr_w2v* w, int64_t corpus_len, double* lr);
 /* GenEmbeddingMap32 (word2vec.go:298-324): param rows narrowed to float32 */
 int goctr_w2v_export_f32(goctr_w2v* w, float* out /*[V,dim]*/);
 
+/* ---------------------------------------------------------------- embedding k-NN search
+ * Replaces search.Searcher (feature/embedding/search/search.go:52-134): brute-force cosine top-k over all items,
+ * float64.  Results are bit-identical to the reference loop: the k best by (similarity descending, item index
+ * ascending) among similarity > 0, the ignored item skipped (SearchInternal passes the query word, :79). */
+typedef struct goctr_searcher goctr_searcher;
+/* search.New (:57-63): items [V, D] float64 row-major (emb.Embedding.Vector); the norms (emb.Embedding.Norm =
+ * embutil.Norm, embutil.go:21-27) are computed on the device */
+int goctr_searcher_create(const double* items, int64_t V, int D, goctr_searcher** out);
+void goctr_searcher_destroy(goctr_searcher* s);
+/* Searcher.Search (:92-134) for Q queries per call: queries [Q, D]; ignore [Q] = item index to skip or -1 (may be
+ * NULL).  out_idx [Q, k] (-1 = the Go zero-value neighbour), out_sim [Q, k]; Rank = position + 1.  out_count [Q] =
+ * length of the slice the reference returns, including its guard-loop quirk (:126-131: k - 1 whenever fewer than k
+ * items qualify, the surplus entries empty).  k <= 256. */
+int goctr_searcher_search(goctr_searcher* s, const double* queries, int Q, int k, const int64_t* ignore,
+                          int64_t* out_idx, double* out_sim, int* out_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -252,6 +252,12 @@ void orc_w2v_train_hogwild(const orc_w2v_cfg* cfg, const int32_t* doc, int64_t n
                            const int64_t* path_off, const int32_t* path_nodes, const uint8_t* path_codes,
                            const double* sigtab, double* lr, int64_t corpus_len);
 
+/* ---- embedding k-NN search (orc_search.c): search.go:92-134, searchutil.go:17-26, embutil.go:21-27 ---- */
+double orc_norm64(const double* v, int d);
+double orc_cosine64(const double* v1, const double* v2, int d, double n1, double n2);
+int orc_knn_search(const double* items, const double* norms, int64_t V, int D, const double* query, double qnorm,
+                   int k, int64_t ignore, int64_t* out_idx, double* out_sim, int* out_rank);
+
 #ifdef __cplusplus
 }
 #endif

@@ -491,3 +491,37 @@ def w2v_train_hogwild(cfg, doc, threads, keep_mask, param, aux, paths, sigtab, l
                                 _p(nodes, C.c_int32), _p(codes, C.c_uint8), _p(sigtab, C.c_double),
                                 C.byref(lr_c), C.c_int64(corpus_len))
     return lr_c.value
+
+
+# ---------------------------------------------------------------- k-NN search --
+def norm64(v):
+    v = np.ascontiguousarray(v, np.float64)
+    lib().orc_norm64.restype = C.c_double
+    return lib().orc_norm64(_p(v, C.c_double), C.c_int(v.size))
+
+
+def cosine64(v1, v2, n1=None, n2=None):
+    v1 = np.ascontiguousarray(v1, np.float64)
+    v2 = np.ascontiguousarray(v2, np.float64)
+    lib().orc_cosine64.restype = C.c_double
+    return lib().orc_cosine64(_p(v1, C.c_double), _p(v2, C.c_double), C.c_int(v1.size),
+                              C.c_double(norm64(v1) if n1 is None else n1), C.c_double(norm64(v2) if n2 is None else n2))
+
+
+def knn_search(items, query, k, ignore=-1, norms=None, qnorm=None):
+    """Searcher.Search (search.go:92-134): returns (idx[count], sim[count], rank[count]); idx -1 = empty neighbour."""
+    items = np.ascontiguousarray(items, np.float64)
+    query = np.ascontiguousarray(query, np.float64)
+    V, D = items.shape
+    if norms is None:
+        norms = np.array([norm64(items[i]) for i in range(V)], np.float64)
+    norms = np.ascontiguousarray(norms, np.float64)
+    qn = norm64(query) if qnorm is None else qnorm
+    idx = np.zeros(max(k, 1), np.int64)
+    sim = np.zeros(max(k, 1), np.float64)
+    rank = np.zeros(max(k, 1), np.int32)
+    lib().orc_knn_search.restype = C.c_int
+    n = lib().orc_knn_search(_p(items, C.c_double), _p(norms, C.c_double), C.c_int64(V), C.c_int(D), _p(query, C.c_double),
+                             C.c_double(qn), C.c_int(k), C.c_int64(ignore), _p(idx, C.c_int64), _p(sim, C.c_double),
+                             _p(rank, C.c_int32))
+    return idx[:n], sim[:n], rank[:n]

@@ -1,0 +1,93 @@
+"""GPU parity for the embedding k-NN searcher: indices, similarities (float64) and the returned
+slice length must equal the oracle's sequential restatement of search.go:92-134 BIT FOR BIT, through the C ABI."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kats.json")))
+
+
+def test_reference_kats():
+    from goctr_amd import search as gs
+    case = KATS["search_internal"]
+    s = gs.New(*[(w, v) for w, v in case["items"]])
+    got = s.SearchInternal(case["word"], case["k"])
+    assert [vars(n) for n in got] == case["expect"]
+    case = KATS["search_vector"]
+    got = gs.New(*[(w, v) for w, v in case["items"]]).SearchVector(case["query"], case["k"])
+    assert [vars(n) for n in got] == case["expect"]
+    with pytest.raises(KeyError):
+        s.SearchInternal("zebra", 1)
+
+
+@pytest.mark.parametrize("V,D,k", [(1, 4, 3), (37, 5, 1), (300, 16, 10), (5000, 16, 25), (4097, 64, 256), (20000, 10, 7)])
+def test_matches_oracle_bit_exact(oracle, V, D, k):
+    from goctr_amd import search as gs
+    rng = np.random.default_rng(V + D + k)
+    items = rng.standard_normal((V, D))
+    items[rng.random(V) < 0.05] = 0.0                       # zero-norm items score 0 and never qualify
+    dup = rng.integers(0, V, size=max(V // 10, 1))          # exact duplicates: ties resolved by arrival order
+    items[dup] = items[rng.integers(0, V, size=dup.size)]
+    s = gs.Searcher([f"w{i}" for i in range(V)], items)
+    Q = 9
+    queries = rng.standard_normal((Q, D))
+    queries[0] = items[min(3, V - 1)]                       # a query that is one of the items
+    queries[1] = 0.0                                        # zero query: nothing qualifies
+    ignore = np.full(Q, -1, np.int64)
+    ignore[0] = min(3, V - 1)
+    ignore[2] = 0
+    idx, sim, cnt = s.search_vectors(queries, k, ignore)
+    for q in range(Q):
+        ri, rs, _ = oracle.knn_search(items, queries[q], k, ignore=int(ignore[q]))
+        assert cnt[q] == ri.size
+        assert np.array_equal(idx[q, :cnt[q]], ri)
+        assert np.array_equal(sim[q, :cnt[q]], rs)          # bit-exact float64
+
+
+@pytest.mark.parametrize("V,k", [(5000, 3), (5000, 25), (9000, 256)])
+def test_heavy_ties_replay(oracle, V, k):
+    """items drawn from a pool of a few distinct vectors: thousands of exactly equal similarities, tie groups cut by
+    the k-th place and by the per-tile lists -- the order inside a tie group depends on the arrival history
+    (search.go:108-115 uses a strict > for displaced elements too) and must still match bit for bit"""
+    from goctr_amd import search as gs
+    rng = np.random.default_rng(V + k)
+    pool = rng.standard_normal((6, 8))
+    items = pool[rng.integers(0, 6, size=V)]
+    items[rng.random(V) < 0.02] = rng.standard_normal(8)            # a few singletons in between
+    s = gs.Searcher([str(i) for i in range(V)], items)
+    queries = rng.standard_normal((5, 8))
+    queries[0] = pool[0]
+    idx, sim, cnt = s.search_vectors(queries, k)
+    for q in range(5):
+        ri, rs, _ = oracle.knn_search(items, queries[q], k)
+        assert cnt[q] == ri.size
+        assert np.array_equal(idx[q, :cnt[q]], ri) and np.array_equal(sim[q, :cnt[q]], rs)
+
+
+def test_tail_quirk_and_mirror_objects(oracle):
+    from goctr_amd import search as gs
+    s = gs.Searcher(["a", "b", "c", "d"], [[1, 0], [2, 0], [0, 1], [-1, 0]])
+    nb = s.SearchVector([1.0, 0.0], 4)                      # only 2 items qualify: 3 entries come back, the last empty
+    assert [(n.Word, n.Rank, n.Similarity) for n in nb] == [("a", 1, 1.0), ("b", 2, 1.0), ("", 0, 0.0)]
+    assert [n.Word for n in s.SearchInternal("a", 1)] == ["b"]
+
+
+def test_large_scan_properties():
+    """full-size property check (V = 10^6): every returned similarity is >= every non-returned one"""
+    from goctr_amd import search as gs
+    rng = np.random.default_rng(3)
+    V, D, k = 1_000_000, 16, 20
+    items = rng.standard_normal((V, D))
+    s = gs.Searcher([str(i) for i in range(V)], items)
+    q = rng.standard_normal((2, D))
+    idx, sim, cnt = s.search_vectors(q, k)
+    for j in range(2):
+        scores = items @ q[j] / np.linalg.norm(q[j]) / np.linalg.norm(items, axis=1)
+        top = np.sort(scores)[::-1][:k]
+        assert cnt[j] == k and np.all(np.diff(sim[j]) <= 0)
+        assert np.allclose(sim[j], top, rtol=1e-12, atol=0)
+        assert np.allclose(scores[idx[j]], sim[j], rtol=1e-12)

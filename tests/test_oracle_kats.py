@@ -120,3 +120,45 @@ def test_subsample_and_index_per_thread(oracle):
         exp.append(exp[-1] + (10 + i) // 4)
     exp.append(10)
     assert idx.tolist() == exp
+
+
+# ---------------------------------------------------------------- embedding k-NN search
+def test_search_cosine_kat(oracle):
+    for c in KATS["search_cosine"]["cases"]:
+        assert oracle.cosine64(c["v1"], c["v2"]) == c["expect"]
+
+
+def _search_case(oracle, case, query, ignore):
+    words = [w for w, _ in case["items"]]
+    items = np.array([v for _, v in case["items"]], np.float64)
+    idx, sim, rank = oracle.knn_search(items, query, case["k"], ignore=ignore)
+    got = [{"Word": words[i] if i >= 0 else "", "Rank": int(r), "Similarity": float(s)} for i, s, r in zip(idx, sim, rank)]
+    assert got == case["expect"]
+
+
+def test_search_internal_kat(oracle):
+    case = KATS["search_internal"]
+    words = [w for w, _ in case["items"]]
+    q = words.index(case["word"])
+    _search_case(oracle, case, case["items"][q][1], q)
+
+
+def test_search_vector_kat(oracle):
+    case = KATS["search_vector"]
+    _search_case(oracle, case, case["query"], -1)
+
+
+def test_search_tail_quirk_and_ties(oracle):
+    # fewer positive-score items than k: the guard loop leaves k-1 entries, the surplus ones empty (search.go:126-131)
+    items = np.array([[1, 0], [2, 0], [0, 1], [-1, 0]], np.float64)
+    idx, sim, rank = oracle.knn_search(items, [1.0, 0.0], 4)
+    assert idx.tolist() == [0, 1, -1] and sim.tolist() == [1.0, 1.0, 0.0] and rank.tolist() == [1, 2, 0]
+    # ties keep arrival order (strict > in the bubble-up), non-positive scores never enter
+    idx, sim, _ = oracle.knn_search(items, [1.0, 0.0], 2)
+    assert idx.tolist() == [0, 1]
+    idx, _, _ = oracle.knn_search(items, [1.0, 0.0], 1, ignore=0)
+    assert idx.tolist() == [1]
+    # a displaced element jumps over its equals (the bubble-up compares with a strict > for it too): inserting a
+    # better item above two equal ones rotates them
+    idx, _, _ = oracle.knn_search(np.array([[1, 0], [1, 0], [1, 0.1]], np.float64), [1.0, 0.05], 3)
+    assert idx.tolist() == [2, 1, 0]
