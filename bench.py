@@ -46,6 +46,12 @@ def synth(rows: int, seed: int):
     ub = ub.astype(np.int32)
     ub[rng.random((rows, c["T"])) < 0.2] = -1
     it = ((rng.zipf(1.05, size=rows) - 1) % c["V"]).astype(np.int32)
+    mode = os.environ.get("GOCTR_BENCH_IDS", "")          # experiments only: uniform | none
+    if mode == "uniform":
+        ub = rng.integers(0, c["V"], size=(rows, c["T"])).astype(np.int32)
+        it = rng.integers(0, c["V"], size=rows).astype(np.int32)
+    elif mode == "none":
+        ub[:] = -1
     uf = rng.random((rows, c["U"]), dtype=np.float32)
     cf = rng.random((rows, c["C"]), dtype=np.float32)
     y = (rng.random(rows) < 0.5).astype(np.float32)
@@ -429,12 +435,13 @@ def main():
                 rl["traffic"], rl["traffic_source"] = pmc_traffic(dom)
                 rl["algorithmic_bytes"] = chain_algorithmic_bytes() if dom == "chain" else None
             out["roofline"] = rl
-            gk, gw = work["attn_fwd"]
-            grl = roofline_obj(gk, gw, prof["attn_fwd"][0] / prof["attn_fwd"][1])
-            grl["kernel"] = "attn_fwd (embedding gather + attention pooling)"
-            if c["KIND"] == "din":
-                grl["traffic"], grl["traffic_source"] = pmc_traffic("attn_fwd")
-            out["gather_roofline"] = grl
+            if "attn_fwd" in table:       # (the DIN cfg3 step fuses the gather into the chain kernel: no separate launch)
+                gk, gw = work["attn_fwd"]
+                grl = roofline_obj(gk, gw, prof["attn_fwd"][0] / prof["attn_fwd"][1])
+                grl["kernel"] = "attn_fwd (embedding gather + attention pooling)"
+                if c["KIND"] == "din":
+                    grl["traffic"], grl["traffic_source"] = pmc_traffic("attn_fwd")
+                out["gather_roofline"] = grl
             out["kernels"] = table
     if dist is not None:
         dist.barrier()

@@ -248,7 +248,23 @@ int launch_attn_fwd(const AttnArgs& a) {
   hipStream_t st = engine().active;
   const bool vec4 = a.src.id_mode && a.D % 4 == 0;
   const int groups = vec4 ? a.D / 4 : a.D;  // lanes needed per row
-#define GOCTR_ATTN_FWD(V, L) hipLaunchKernelGGL((attn_fwd_kernel<V, L>), grid, blk, 0, st, a)
+  // compile-time mode for the shapes that matter (id mode, every lane owns 4 in-range columns)
+  const int fast = !(vec4 && groups * 4 == a.D && (groups & (groups - 1)) == 0) ? 0
+                   : a.kind != GOCTR_DIN ? 1 : (a.att == GOCTR_ATT_COSINE ? 2 : 3);
+#define GOCTR_ATTN_FWD(V, L) hipLaunchKernelGGL((attn_fwd_kernel<V, L, 0>), grid, blk, 0, st, a)
+#define GOCTR_ATTN_FWD_FAST(L)                                                                     \
+  do {                                                                                             \
+    if (fast == 1) hipLaunchKernelGGL((attn_fwd_kernel<4, L, 1>), grid, blk, 0, st, a);            \
+    else if (fast == 2) hipLaunchKernelGGL((attn_fwd_kernel<4, L, 2>), grid, blk, 0, st, a);       \
+    else hipLaunchKernelGGL((attn_fwd_kernel<4, L, 3>), grid, blk, 0, st, a);                      \
+  } while (0)
+  if (fast && groups <= 16) {
+    if (groups == 1) GOCTR_ATTN_FWD_FAST(1);
+    else if (groups == 2) GOCTR_ATTN_FWD_FAST(2);
+    else if (groups == 4) GOCTR_ATTN_FWD_FAST(4);
+    else if (groups == 8) GOCTR_ATTN_FWD_FAST(8);
+    else GOCTR_ATTN_FWD_FAST(16);
+  } else
   if (vec4) {
     if (groups <= 1) GOCTR_ATTN_FWD(4, 1);
     else if (groups <= 2) GOCTR_ATTN_FWD(4, 2);
@@ -263,6 +279,7 @@ int launch_attn_fwd(const AttnArgs& a) {
     else if (groups <= 32) GOCTR_ATTN_FWD(1, 32);
     else GOCTR_ATTN_FWD(1, 64);
   }
+#undef GOCTR_ATTN_FWD_FAST
 #undef GOCTR_ATTN_FWD
   GOCTR_HIP(hipGetLastError());
   return 0;
@@ -275,7 +292,16 @@ int launch_attn_bwd(const AttnBwdArgs& a, int blocks) {
   const size_t lds = 0;
   const bool vec4 = a.src.id_mode && a.D % 4 == 0;
   const int groups = vec4 ? a.D / 4 : a.D;
-#define GOCTR_ATTN_BWD(V, L) hipLaunchKernelGGL((attn_bwd_kernel<V, L>), grid, blk, lds, st, a)
+  const bool fast = vec4 && groups * 4 == a.D && (groups & (groups - 1)) == 0 && groups <= 16;
+#define GOCTR_ATTN_BWD(V, L) hipLaunchKernelGGL((attn_bwd_kernel<V, L, 0>), grid, blk, lds, st, a)
+#define GOCTR_ATTN_BWD_FAST(L) hipLaunchKernelGGL((attn_bwd_kernel<4, L, 1>), grid, blk, lds, st, a)
+  if (fast) {
+    if (groups == 1) GOCTR_ATTN_BWD_FAST(1);
+    else if (groups == 2) GOCTR_ATTN_BWD_FAST(2);
+    else if (groups == 4) GOCTR_ATTN_BWD_FAST(4);
+    else if (groups == 8) GOCTR_ATTN_BWD_FAST(8);
+    else GOCTR_ATTN_BWD_FAST(16);
+  } else
   if (vec4) {
     if (groups <= 1) GOCTR_ATTN_BWD(4, 1);
     else if (groups <= 2) GOCTR_ATTN_BWD(4, 2);
@@ -290,6 +316,7 @@ int launch_attn_bwd(const AttnBwdArgs& a, int blocks) {
     else if (groups <= 32) GOCTR_ATTN_BWD(1, 32);
     else GOCTR_ATTN_BWD(1, 64);
   }
+#undef GOCTR_ATTN_BWD_FAST
 #undef GOCTR_ATTN_BWD
   GOCTR_HIP(hipGetLastError());
   return 0;
@@ -806,7 +833,7 @@ int goctr_emb_create(int64_t V, int D, const float* host_rows, goctr_emb** out) 
   GOCTR_CHECK(V > 0 && D > 0 && out, "goctr_emb_create: bad arguments");
   std::unique_ptr<goctr_emb> e(new goctr_emb);
   e->V = V; e->D = D;
-  if (e->rows.alloc((size_t)V * D)) return -1;
+  if (e->rows.alloc((size_t)(V + 1) * D)) return -1;   // row V stays all-zero: where missing ids point (attention kernels)
   if (host_rows && e->rows.upload(host_rows, (size_t)V * D)) return -1;
   *out = e.release();
   return 0;

@@ -128,17 +128,37 @@ __device__ __forceinline__ void load_row(const float* row, int d0, int D, float 
   }
 }
 
+// same for a row pointer that is never null (id mode points missing ids at the all-zero row V of the device
+// table, so the load needs no predicate and no zero-initialised destination); `full` = every lane's d0 < D
+template <int VEC>
+__device__ __forceinline__ void load_row_nn(const float* row, int d0, int D, bool full, float x[VEC]) {
+  if (VEC == 4 && full) {
+    float4 t4 = *reinterpret_cast<const float4*>(row + d0);
+    x[0] = t4.x; x[1] = t4.y; x[2] = t4.z; x[3] = t4.w;
+  } else {
+    load_row<VEC>(row, d0, D, x);
+  }
+}
+
 // One wavefront per sample.  A wavefront covers RPP = 64/LPR behaviour rows per pass, LPR lanes per
 // row, VEC consecutive embedding lanes per lane (VEC=4 => one 16-byte load per lane, a 64-byte row
 // of a D=16 table is fetched by 4 adjacent lanes: fully coalesced 64 B segments).  The ids of up to
 // 64 behaviour slots are fetched with ONE coalesced load and handed to the row lanes by shuffle, then
 // the row loads of NPB passes are issued back to back before any arithmetic, so the dependent chain
 // is state -> ids -> rows (3 memory latencies) regardless of T.
-template <int VEC, int LPR>
+// FAST: 0 = every mode decided at run time; 1 / 2 / 3 = id mode with D == LPR * VEC and the model kind fixed at
+// compile time (YouTube mean pooling / DIN cosine / DIN euclid): the kernel is VALU-bound (rocprofv3: ~500 VALU
+// instructions per sample against 10 loads and 6 stores), and run-time mode branches inside its unrolled loops cost
+// more instructions than the arithmetic they select.
+template <int VEC, int LPR, int FAST>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  const bool idm = FAST ? true : (bool)a.src.id_mode;
+  const bool din = FAST ? FAST >= 2 : a.kind == GOCTR_DIN;
+  const bool cosine = FAST ? FAST == 2 : a.att == GOCTR_ATT_COSINE;
   constexpr int RPP = 64 / LPR;
   constexpr int NPB = LPR < 4 ? LPR : 4;  // passes per block; NPB*RPP <= 64
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the sample's base addresses live in SGPRs
   const int b = blockIdx.x * 4 + wave;
   if (b >= a.B) return;
   const RowSource& s = a.src;
@@ -153,21 +173,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int ju = lane + 64 * k;
-    uside[k] = (valid && ju < a.U) ? (s.id_mode ? s.ufeat[gr * a.U + ju] : s.X[gr * (long long)s.xcols + s.r_u + ju]) : 0.f;
-    cside[k] = (valid && ju < a.C) ? (s.id_mode ? s.cfeat[gr * a.C + ju] : s.X[gr * (long long)s.xcols + s.r_c + ju]) : 0.f;
+    uside[k] = (valid && ju < a.U) ? (idm ? s.ufeat[gr * a.U + ju] : s.X[gr * (long long)s.xcols + s.r_u + ju]) : 0.f;
+    cside[k] = (valid && ju < a.C) ? (idm ? s.cfeat[gr * a.C + ju] : s.X[gr * (long long)s.xcols + s.r_c + ju]) : 0.f;
   }
   // candidate item embedding v
-  const float* vrow = nullptr;
-  if (valid) {
-    if (s.id_mode) {
-      int it = s.item_ids[gr];
-      if (it >= 0 && it < s.V) vrow = s.emb + (long long)it * D;
-    } else {
-      vrow = s.X + gr * (long long)s.xcols + s.r_v;
-    }
-  }
+  const bool full = FAST ? true : D == LPR * VEC;   // every lane owns VEC in-range embedding columns (wave-uniform)
   float vv[VEC];
-  load_row<VEC>(vrow, d0, D, vv);
+  if (idm) {
+    const int it = valid ? s.item_ids[gr] : -1;
+    load_row_nn<VEC>(s.emb + (long long)((it >= 0 && it < s.V) ? it : s.V) * D, d0, D, full, vv);
+  } else {
+    load_row<VEC>(valid ? s.X + gr * (long long)s.xcols + s.r_v : nullptr, d0, D, vv);
+  }
   float syy = 0.f;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) syy += vv[e] * vv[e];
@@ -179,59 +196,85 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
   for (int tb = 0; tb < T; tb += NPB * RPP) {
     int myid = -1;
-    if (s.id_mode && valid && lane < NPB * RPP && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
+    if (idm && valid && lane < NPB * RPP && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
     float x[NPB][VEC];
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
       const int t = tb + p * RPP + rl;
-      const float* xrow = nullptr;
-      if (s.id_mode) {
+      if (idm) {
         const int id = __shfl(myid, p * RPP + rl, 64);
-        if (t < T && id >= 0 && id < s.V) xrow = s.emb + (long long)id * D;
-      } else if (valid && t < T) {
-        xrow = s.X + gr * (long long)s.xcols + s.r_ub + t * D;
+        load_row_nn<VEC>(s.emb + (long long)((t < T && id >= 0 && id < s.V) ? id : s.V) * D, d0, D, full, x[p]);
+      } else {
+        load_row<VEC>((valid && t < T) ? s.X + gr * (long long)s.xcols + s.r_ub + t * D : nullptr, d0, D, x[p]);
       }
-      load_row<VEC>(xrow, d0, D, x[p]);
+    }
+    // Row sums of every pass first; then slot tb + L's similarity / gate is computed ONCE, in lane L (the lanes of a
+    // row group would otherwise all repeat the same sqrt / divide / exp once per pass), which also leaves gate and
+    // weight in the layout of one coalesced store; the gate travels back to the row groups by shuffle.
+    const int src = (lane % RPP) * LPR, pw = lane / RPP;
+    float g_l = 1.0f, w_l = 0.f;
+    if (din) {
+      float s0 = 0.f, s1 = 0.f;      // cosine: (sxx, sxy) of slot tb + lane; euclid: (ss, -)
+#pragma unroll
+      for (int p = 0; p < NPB; ++p) {
+        float u0 = 0.f, u1 = 0.f;
+        if (cosine) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { u0 += x[p][e] * x[p][e]; u1 += x[p][e] * vv[e]; }
+          u0 = group_sum<LPR>(u0);
+          u1 = group_sum<LPR>(u1);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { float df = x[p][e] - vv[e]; u0 += (d0 + e < D) ? df * df : 0.f; }
+          u0 = group_sum<LPR>(u0);
+        }
+        const float v0 = __shfl(u0, src, 64), v1 = __shfl(u1, src, 64);
+        if (pw == p) { s0 = v0; s1 = v1; }
+      }
+      if (cosine) {
+        const float cosv = s1 / (sqrtf(s0) * yn + 1e-8f);
+        w_l = (cosv + 1.0f) / 2.0f;
+      } else {
+        w_l = 1.0f - sqrtf(s0);
+      }
+      const int tl = tb + lane;
+      g_l = sigm_hidden(w_l * ((lane < NPB * RPP && tl < T) ? a.att0[tl] : 0.f));
+    }
+    if (lane < NPB * RPP && tb + lane < T) {
+      a.gate[(size_t)b * T + tb + lane] = g_l;
+      a.wgt[(size_t)b * T + tb + lane] = w_l;
     }
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
       const int t = tb + p * RPP + rl;
-      float g = 1.0f, wv = 0.f;
-      if (a.kind == GOCTR_DIN) {
-        if (a.att == GOCTR_ATT_COSINE) {
-          float sxx = 0.f, sxy = 0.f;
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) { sxx += x[p][e] * x[p][e]; sxy += x[p][e] * vv[e]; }
-          sxx = group_sum<LPR>(sxx);
-          sxy = group_sum<LPR>(sxy);
-          const float cosv = sxy / (sqrtf(sxx) * yn + 1e-8f);
-          wv = (cosv + 1.0f) / 2.0f;
-        } else {
-          float ss = 0.f;
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) { float df = x[p][e] - vv[e]; ss += (d0 + e < D) ? df * df : 0.f; }
-          ss = group_sum<LPR>(ss);
-          wv = 1.0f - sqrtf(ss);
-        }
-        g = sigm_hidden(wv * (t < T ? a.att0[t] : 0.f));
-      }
+      const float g = din ? __shfl(g_l, p * RPP + rl, 64) : 1.0f;
       if (t < T) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) psum[e] += g * x[p][e];
-        if (dl == 0) {
-          a.gate[(size_t)b * T + t] = g;
-          a.wgt[(size_t)b * T + t] = wv;
-        }
       }
     }
   }
+  // mean over T as a multiply by 1/T (one division per sample instead of one per column; <= 1 ulp from x / T)
+  const float invT = 1.0f / (float)T;
   float* hrow = a.h0 + (size_t)b * a.Ip;
+  if (VEC == 4 && (a.U & 3) == 0 && (a.Ip & 3) == 0 && (D & 3) == 0) {
+    // pooled sum and candidate embedding as two 16-byte stores from the first row group
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    v4 pv;
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    float p = cross_row_sum<LPR>(psum[e]) / (float)T;
-    if (rl == 0 && d0 + e < D) {
-      hrow[a.U + d0 + e] = p;
-      hrow[a.U + D + d0 + e] = vv[e];
+    for (int e = 0; e < 4; ++e) pv[e] = cross_row_sum<LPR>(psum[e]) * invT;
+    if (rl == 0 && d0 < D) {
+      *reinterpret_cast<v4*>(hrow + a.U + d0) = pv;
+      *reinterpret_cast<v4*>(hrow + a.U + D + d0) = v4{vv[0], vv[1], vv[2], vv[3]};
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float p = cross_row_sum<LPR>(psum[e]) * invT;
+      if (rl == 0 && d0 + e < D) {
+        hrow[a.U + d0 + e] = p;
+        hrow[a.U + D + d0 + e] = vv[e];
+      }
     }
   }
 #pragma unroll
@@ -241,9 +284,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     if (j < a.C) hrow[a.U + 2 * D + j] = cside[k];
   }
   for (int j = lane + 128; j < a.U; j += 64)   // (side blocks wider than 128 columns)
-    hrow[j] = valid ? (s.id_mode ? s.ufeat[gr * a.U + j] : s.X[gr * (long long)s.xcols + s.r_u + j]) : 0.f;
+    hrow[j] = valid ? (idm ? s.ufeat[gr * a.U + j] : s.X[gr * (long long)s.xcols + s.r_u + j]) : 0.f;
   for (int j = lane + 128; j < a.C; j += 64)
-    hrow[a.U + 2 * D + j] = valid ? (s.id_mode ? s.cfeat[gr * a.C + j] : s.X[gr * (long long)s.xcols + s.r_c + j]) : 0.f;
+    hrow[a.U + 2 * D + j] = valid ? (idm ? s.cfeat[gr * a.C + j] : s.X[gr * (long long)s.xcols + s.r_c + j]) : 0.f;
 }
 
 // ---------------------------------------------------------------- attention backward (att0 grad)
@@ -263,11 +306,13 @@ constexpr int ATTN_BWD_WAVES = 16;  // samples per workgroup (one wavefront each
 // (SURVEY A.1).  One wavefront per sample, all row gathers in flight at once; the terms go to
 // dgs [B, Tp] and the sum over the batch is done by the weight-gradient GEMM launch as a ones-column
 // product (same deterministic slab reduction as every other gradient).
-template <int VEC, int LPR>
+template <int VEC, int LPR, int FAST>
 __global__ __launch_bounds__(64 * ATTN_BWD_WAVES) void attn_bwd_kernel(AttnBwdArgs a) {
+  const bool idm = FAST ? true : (bool)a.src.id_mode;
   constexpr int RPP = 64 / LPR;
   constexpr int NPB = LPR < 4 ? LPR : 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const RowSource& s = a.src;
   const int dl = lane % LPR, rl = lane / LPR, d0 = dl * VEC;
   const int D = a.D, T = a.T;
@@ -282,32 +327,37 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES) void attn_bwd_kernel(AttnBwdAr
   for (int t = T + lane; t < a.Tp; t += 64) out[t] = 0.f;
   for (int tb = 0; tb < T; tb += NPB * RPP) {
     int myid = -1;
-    if (s.id_mode && valid && lane < NPB * RPP && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
+    if (idm && valid && lane < NPB * RPP && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
+    // gate / weight of slot tb + L arrive in lane L with one coalesced load each
+    float gl = 0.f, wl = 0.f;
+    if (lane < NPB * RPP && tb + lane < T) {
+      gl = a.gate[(size_t)b * T + tb + lane];
+      wl = a.wgt[(size_t)b * T + tb + lane];
+    }
     float x[NPB][VEC];
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
       const int t = tb + p * RPP + rl;
-      const float* xrow = nullptr;
-      if (s.id_mode) {
+      if (idm) {
         const int id = __shfl(myid, p * RPP + rl, 64);
-        if (t < T && id >= 0 && id < s.V) xrow = s.emb + (long long)id * D;
-      } else if (valid && t < T) {
-        xrow = s.X + gr * (long long)s.xcols + s.r_ub + t * D;
+        load_row_nn<VEC>(s.emb + (long long)((t < T && id >= 0 && id < s.V) ? id : s.V) * D, d0, D, FAST ? true : D == LPR * VEC, x[p]);
+      } else {
+        load_row<VEC>((valid && t < T) ? s.X + gr * (long long)s.xcols + s.r_ub + t * D : nullptr, d0, D, x[p]);
       }
-      load_row<VEC>(xrow, d0, D, x[p]);
     }
+    const float gw = (gl * (1.0f - gl));     // g (1 - g) of slot tb + lane
+    const int src = (lane % RPP) * LPR, pw = lane / RPP;
+    float term = 0.f;
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
-      const int t = tb + p * RPP + rl;
       float dg = 0.f;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) dg += dpt[e] * x[p][e];
       dg = group_sum<LPR>(dg);
-      if (t < T && dl == 0) {
-        const float g = a.gate[(size_t)b * T + t];
-        out[t] = dg * (g * (1.0f - g)) * a.wgt[(size_t)b * T + t];
-      }
+      const float dgs = __shfl(dg, src, 64);   // the row group of slot (p, lane % RPP)
+      if (pw == p) term = dgs;
     }
+    if (lane < NPB * RPP && tb + lane < T) out[tb + lane] = term * gw * wl;   // one coalesced store
   }
 }
 
