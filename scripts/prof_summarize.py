@@ -71,6 +71,32 @@ def main():
         t["hbm_bytes"] = t.get("fetch_bytes", 0.0) + t.get("write_bytes", 0.0)
         for g, us in grids.get(s, []):
             pass
+    # SQ pass: MFMA busy / issue counters per training launch (MfmaUtil = MFMA_BUSY / (GUI_ACTIVE * SIMDs))
+    sqf = glob.glob(f"{src}/sq/*/*_counter_collection.csv")
+    sq = {}
+    if sqf:
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(sqf[0])):
+            sname = short(r["Kernel_Name"])
+            if sname:
+                acc[(sname, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for (sname, g), v in acc.items():
+            if g != max(gg for (ss, gg) in acc if ss == sname):
+                continue
+            m = {c: sum(x) / len(x) for c, x in v.items()}
+            ent = {c.lower(): round(val) for c, val in m.items()}
+            # SQ_BUSY_CYCLES is reported per shader engine and summed over the 32 SEs (8 XCDs x 4): /32 = the launch's
+            # duration in shader cycles (cross-checks against the kernel-trace duration at ~2.0 GHz);
+            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs
+            if m.get("SQ_BUSY_CYCLES"):
+                ent["kernel_cycles"] = round(m["SQ_BUSY_CYCLES"] / 32)
+                ent["mfma_busy_pct"] = round(100.0 * (m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024) / (m["SQ_BUSY_CYCLES"] / 32), 1)
+            ent["mfma_flops_f32"] = round(m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512)
+            sq[sname] = ent
+        json.dump({"source": "rocprofv3 --pmc SQ_* (own pass, GOCTR_NO_GRAPH=1); mfma_busy_pct = (SQ_VALU_MFMA_BUSY_CYCLES / "
+                             "1024 SIMDs) / (SQ_BUSY_CYCLES / 32 SEs)", "per_launch": sq},
+                  open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
+        print(json.dumps({k: (v.get("mfma_busy_pct"), v.get("mfma_flops_f32"), v.get("kernel_cycles")) for k, v in sq.items()}))
     out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, GOCTR_NO_GRAPH=1), "
                      "bench.py cfg3 training launches; FETCH_SIZE x2 (gfx950 correction), KiB -> bytes",
            "per_launch": traffic}
