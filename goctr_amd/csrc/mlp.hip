@@ -13,6 +13,7 @@
 // intercepts, so  A_i . W_i  already contains  + b_i  (addIntercepts64 :205) and the bias gradients
 // (matRowMean64 :213) fall out of the weight-gradient GEMM as row units_i.
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 #include "common.h"
@@ -124,6 +125,11 @@ __global__ __launch_bounds__(256) void mlp_bn_kernel(double* A, int n, int ld, i
   if (M > 0) for (int r = threadIdx.x; r < n; r += 256) A[(size_t)r * ld + o] /= M;
 }
 
+// element (k, n) of the first weight block inside its LDS image [n/32][k/4][32][k%4] (mlp_fwd_kernel)
+__host__ __device__ inline size_t mlp_img_index(int k, int n, int up0) {
+  return (((size_t)(n >> 5) * (up0 >> 2) + (k >> 2)) * 32 + (n & 31)) * 4 + (k & 3);
+}
+
 struct MlpLayerDesc {
   int fi, fo, upi, upo;       // fan-in/out and padded sizes
   long long woff;             // offset of the augmented block in the flat padded parameter buffer
@@ -143,6 +149,7 @@ struct MlpReduceArgs {
   double weight_decay;
   MlpState* st;
   double* sumsq_part;         // [gridDim.x] partial sums of W^2 (coefs only)
+  double* W0img; int up1_img; // LDS image of layer 0 for the fused forward (or null)
 };
 
 // grad = slab sum / n + alpha/n * W (coefs), mean(delta) (intercepts)  [computeLossGrad :322-330]; then the
@@ -196,6 +203,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
         }
         a.W[idx] = wn;
         if (is_w) d.WT[(size_t)c * d.upi + r] = wn;
+        if (l == 0 && a.W0img) a.W0img[mlp_img_index(r, c, d.upi)] = wn;
       }
     } else {
       a.G[idx] = 0;
@@ -210,14 +218,19 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
 // loss = sum(terms)/n + 0.5*alpha*sum(W^2)/n  (basemlp64.go:359-361); closes the step
 __global__ __launch_bounds__(256) void mlp_loss_kernel(const double* lossterm, int nterms, const double* sumsq_part,
                                                        int nparts, double alpha, int n, MlpState* st, double* ring,
-                                                       int advance) {
+                                                       int advance, int upL, int no) {
   __shared__ double red[256];
   double s = 0;
   // 16 independent loads in flight per thread (one memory latency per 4096 terms, not per 256), fixed order
-  for (int i0 = threadIdx.x; i0 < nterms; i0 += 256 * 16) {
+  // only the `no` real columns of each padded row carry a term (the pad columns hold zeros)
+  const int real = (nterms / upL) * no;
+  for (int i0 = threadIdx.x; i0 < real; i0 += 256 * 16) {
     double v[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { const int i = i0 + u * 256; v[u] = i < nterms ? lossterm[i] : 0.0; }
+    for (int u = 0; u < 16; ++u) {
+      const int i = i0 + u * 256;
+      v[u] = i < real ? lossterm[(size_t)(i / no) * upL + (i % no)] : 0.0;
+    }
 #pragma unroll
     for (int u = 0; u < 16; ++u) s += v[u];
   }
@@ -249,6 +262,104 @@ __global__ void mlp_scale_kernel(double* W, long long n, double f) {
 __global__ void mlp_narrow_kernel(const double* H, int n, int ld, int no, float* out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n * no) out[i] = (float)H[(size_t)(i / no) * ld + i % no];
+}
+
+
+// ---------------------------------------------------------------- fused forward of a one-hidden-layer net
+// (the shape go-ctr trains: [F, H, 1], mlp.go:40-47).  Grid = (64-row blocks, 32-column groups of the hidden layer):
+// a workgroup keeps its 32-column slice of W1 (all K rows, stored in HBM as the LDS image
+// [group][k/4][32][k%4], one straight LDS-DMA copy) in LDS, each of its 4 wavefronts carries 16 batch rows:
+//   Z^T[h][row] = sum_k W1[k][h] * A0[row][k]   (v_mfma_f64_16x16x4_f64: A operand = W1 tile from LDS, B operand =
+//   4 consecutive k of the row, two 16-byte loads per 16-k chunk, all issued before the first MFMA),
+// then activation -> A1 (+ ones column), and the partial output pre-activation  sum_h A1[row][h] W2[h]  of the
+// group.  mlp_out_kernel adds the group partials in a fixed order: logistic, delta = h - y, log-loss term.
+// Replaces two gemm_nn launches + mlp_delta_last for this shape (basemlp64.go:259-274, :373-381).
+
+template <int MAXCH>   // 16-k chunks of the input layer kept in registers (up0 <= 16 * MAXCH)
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(const double* __restrict__ A0, int up0, const double* __restrict__ W1img,
+                                                      const double* __restrict__ W2, int upL, int n, int units1, int up1,
+                                                      int act, double* __restrict__ A1, double* __restrict__ zpart) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) double mlp_smem[];   // [up0/4][32][4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int g = blockIdx.y;
+  // stage this group's weight slice: up0 * 32 doubles, 1 KiB per wave instruction
+  {
+    const double* src = W1img + (size_t)g * up0 * 32;
+    const int nchunks = (up0 * 32) >> 7;              // 128 doubles per KiB
+    for (int c = wave; c < nchunks; c += 4)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(src + c * 128) + lane * 16,
+                                       (__attribute__((address_space(3))) void*)(mlp_smem + c * 128), 16, 0, 0);
+  }
+  const int row = blockIdx.x * 64 + wave * 16 + i;
+  const bool vrow = row < n;
+  const double* ap = A0 + (size_t)(vrow ? row : n - 1) * up0 + 4 * q;
+  const int nch = up0 >> 4;
+  d2 xa[MAXCH], xb[MAXCH];
+#pragma unroll
+  for (int c = 0; c < MAXCH; ++c)
+    if (c < nch) { xa[c] = *reinterpret_cast<const d2*>(ap + c * 16); xb[c] = *reinterpret_cast<const d2*>(ap + c * 16 + 2); }
+  d4 acc[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+  __syncthreads();
+  const double* wp = mlp_smem + ((size_t)q * 32 + i) * 4;
+#pragma unroll
+  for (int c = 0; c < MAXCH; ++c) {
+    if (c < nch) {
+      const double* w = wp + (size_t)c * 4 * 32 * 4;   // chunk c = k rows 16c..16c+15 = 4 (k/4) rows of the image
+      const d2 w0a = *reinterpret_cast<const d2*>(w), w0b = *reinterpret_cast<const d2*>(w + 2);
+      const d2 w1a = *reinterpret_cast<const d2*>(w + 64), w1b = *reinterpret_cast<const d2*>(w + 66);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0a.x, xa[c].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1a.x, xa[c].x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0a.y, xa[c].y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1a.y, xa[c].y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0b.x, xb[c].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1b.x, xb[c].x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0b.y, xb[c].y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1b.y, xb[c].y, acc[1], 0, 0, 0);
+    }
+  }
+  // accumulator of lane (row = i, q): Z[row][32 g + 16 t + q + 4 r]
+  double part = 0;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 32 * g + 16 * t + q + 4 * r;
+      double v = 0;
+      if (h < units1) v = act_fwd(act, acc[t][r]);
+      else if (h == units1) v = 1.0;
+      if (h < up1) {
+        if (vrow) A1[(size_t)row * up1 + h] = v;
+        part += v * W2[(size_t)h * upL];
+      }
+    }
+  }
+  part += __shfl_xor(part, 16, 64);
+  part += __shfl_xor(part, 32, 64);
+  if (q == 0 && vrow) zpart[(size_t)g * n + row] = part;
+}
+
+// output unit of the fused path: fixed-order sum of the group partials, logistic, delta, log-loss term
+__global__ __launch_bounds__(256) void mlp_out_kernel(const double* zpart, int ngroups, int n, const double* Yb, int upL,
+                                                      double* A2, double* delta, double* lossterm) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // one thread per (row, padded output column): coalesced stores
+  if (idx >= n * upL) return;
+  const int r = idx / upL, c = idx - r * upL;
+  double a2 = c == 1 ? 1.0 : 0.0, d = 0, l = 0;
+  if (c == 0) {
+    double z = 0;
+    for (int g = 0; g < ngroups; ++g) z += zpart[(size_t)g * n + r];
+    const double h = 1 / (1 + exp(-z));
+    const double y = Yb ? Yb[idx] : 0.0;
+    const double hmin = 4.9406564584124654e-324, hmax = 0.99999999999999989;  // Nextafter(0,1), Nextafter(1,0)
+    const double hc = h < hmin ? hmin : (h > hmax ? hmax : h);
+    a2 = h; d = h - y;
+    l = -y * log(hc) - (1 - y) * log1p(-hc);
+  }
+  A2[idx] = a2; delta[idx] = d; lossterm[idx] = l;
 }
 
 template <class K>
@@ -300,7 +411,7 @@ int init_attrs64() {
   if (allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 1>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 2>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 4>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 1>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 2>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 4>) ||
-      allow_big_lds(gemm_tn_kernel<double, 3, 4, 16>)) return -1;
+      allow_big_lds(gemm_tn_kernel<double, 3, 4, 16>) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
   done = true;
   return 0;
 }
@@ -314,6 +425,9 @@ struct goctr_mlp {
   long long woff[8] = {0}, poff[8] = {0};
   long long nflat = 0, nparams = 0;
   DevBuf<double> W, G, Mo, Vo, Vel, WT[7], bn[7];
+  bool fused_fwd_done = false;
+  DevBuf<double> W0img, zpart;   // fused [F,H,1] forward: LDS image of the first weight block, per-group output partials
+  bool fused_ok() const { return nl == 2 && units[2] == 1 && !cfg.batch_normalize && up[1] <= 128 && up[0] <= 16 * 24; }
   // batch workspace
   int wsN = 0, S = 0;
   DevBuf<double> A[8], D[8], Yb, lossterm, slabs[7], sumsq_part, ring;
@@ -326,6 +440,7 @@ struct goctr_mlp {
 namespace {
 
 int tn_rows64() { return 64; }
+int env_int_mlp(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 
 int ensure_ws(goctr_mlp* p, int n) {
   if (p->wsN >= n) return 0;
@@ -343,6 +458,21 @@ int ensure_ws(goctr_mlp* p, int n) {
 
 // forward over A[0] (already filled) for n rows; bn applied afterwards like the reference
 int forward(goctr_mlp* p, int n, bool train) {
+  if (p->fused_ok() && p->W0img.p && env_int_mlp("GOCTR_MLP_NO_FUSED", 0) == 0) {
+    const int up0 = p->up[0], up1 = p->up[1], upL = p->up[2];
+    const int ng = (int)cdiv(up1, 32);
+    if (p->zpart.ensure((size_t)ng * n, false)) return -1;
+    const size_t lds = sizeof(double) * (size_t)up0 * 32;
+    hipLaunchKernelGGL((mlp_fwd_kernel<24>), dim3((unsigned)cdiv(n, 64), ng), dim3(256), lds, engine().stream, p->A[0].p, up0,
+                       p->W0img.p, p->W.p + p->woff[1], upL, n, p->units[1], up1, p->cfg.activation, p->A[1].p, p->zpart.p);
+    GOCTR_HIP(hipGetLastError());
+    p->fused_fwd_done = train;   // backward() then skips mlp_delta_last: the out kernel already wrote delta + loss terms
+    hipLaunchKernelGGL(mlp_out_kernel, dim3((unsigned)cdiv((int64_t)n * upL, 256)), dim3(256), 0, engine().stream, p->zpart.p, ng, n,
+                       train ? p->Yb.p : nullptr, upL, p->A[2].p, p->D[2].p, p->lossterm.p);
+    GOCTR_HIP(hipGetLastError());
+    return 0;
+  }
+  p->fused_fwd_done = false;
   for (int l = 0; l < p->nl; ++l) {
     const bool last = l == p->nl - 1;
     EpiMlpAct e{p->A[l + 1].p, p->up[l + 1], p->units[l + 1], last ? GOCTR_ACT_LOGISTIC : p->cfg.activation};
@@ -365,6 +495,7 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   if (p->cfg.weight_decay > 0) {  // basemlp64.go:342-346 (applied before the forward pass by the caller order)
   }
   const int upL = p->up[L], no = p->units[L];
+  if (!p->fused_fwd_done)
   hipLaunchKernelGGL(mlp_delta_last_kernel, dim3((unsigned)cdiv((int64_t)n * upL, 256)), dim3(256), 0, e.stream,
                      p->A[L].p, p->Yb.p, n, no, upL, p->D[L].p, p->lossterm.p);
   GOCTR_HIP(hipGetLastError());
@@ -388,11 +519,12 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   a.lr_init = p->cfg.lr_init; a.beta1 = p->cfg.beta1; a.beta2 = p->cfg.beta2; a.eps = p->cfg.eps;
   a.momentum = p->cfg.momentum; a.nesterov = p->cfg.nesterov; a.weight_decay = p->cfg.weight_decay;
   a.st = p->st.p; a.sumsq_part = p->sumsq_part.p;
+  a.W0img = p->fused_ok() ? p->W0img.p : nullptr; a.up1_img = p->up[1];
   const int nblk = (int)cdiv(p->nflat, 256);
   hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk), dim3(256), 0, e.stream, a);
   GOCTR_HIP(hipGetLastError());
   hipLaunchKernelGGL(mlp_loss_kernel, dim3(1), dim3(256), 0, e.stream, p->lossterm.p, n * upL, p->sumsq_part.p, nblk,
-                     p->cfg.alpha, n, p->st.p, p->ring.p, advance ? 1 : 0);
+                     p->cfg.alpha, n, p->st.p, p->ring.p, advance ? 1 : 0, upL, no);
   GOCTR_HIP(hipGetLastError());
   return 0;
 }
@@ -405,6 +537,11 @@ int weight_decay(goctr_mlp* p) {
   for (int l = 0; l < p->nl; ++l) {
     hipLaunchKernelGGL(mlp_scale_kernel, dim3((unsigned)cdiv((int64_t)p->up[l] * p->up[l + 1], 256)), dim3(256), 0,
                        engine().stream, p->WT[l].p, (long long)p->up[l] * p->up[l + 1], 1 - p->cfg.weight_decay);
+    GOCTR_HIP(hipGetLastError());
+  }
+  if (p->fused_ok()) {
+    hipLaunchKernelGGL(mlp_scale_kernel, dim3((unsigned)cdiv((int64_t)p->W0img.n, 256)), dim3(256), 0, engine().stream,
+                       p->W0img.p, (long long)p->W0img.n, 1 - p->cfg.weight_decay);
     GOCTR_HIP(hipGetLastError());
   }
   return 0;
@@ -499,6 +636,13 @@ int goctr_mlp_set_params(goctr_mlp* p, const double* theta, size_t n) {
     if (p->WT[l].upload(wt.data(), wt.size())) return -1;
   }
   if (p->W.upload(w.data(), w.size())) return -1;
+  if (p->fused_ok()) {
+    const int up0 = p->up[0], up1 = p->up[1];
+    std::vector<double> img((size_t)cdiv(up1, 32) * 32 * up0, 0.0);
+    for (int r = 0; r <= p->units[0]; ++r)            // coefficient rows + the intercept row
+      for (int c = 0; c < p->units[1]; ++c) img[mlp_img_index(r, c, up0)] = w[(size_t)p->woff[0] + (size_t)r * up1 + c];
+    if (p->W0img.alloc(img.size(), false) || p->W0img.upload(img.data(), img.size())) return -1;
+  }
   // a fresh optimizer (fitStochastic builds one per Fit: basemlp64.go:731-752)
   GOCTR_HIP(hipMemsetAsync(p->Mo.p, 0, sizeof(double) * p->nflat, engine().stream));
   GOCTR_HIP(hipMemsetAsync(p->Vo.p, 0, sizeof(double) * p->nflat, engine().stream));

@@ -19,6 +19,9 @@ __global__ __launch_bounds__(512, 1) void k(const float* __restrict__ src, int n
   for (int t = 0; t < 4; ++t) for (int j = 0; j < 16; ++j) big[t][j] = 0;
   s4 hb = {(short)tid, 1, 2, 3};
   f4 ld = {0, 0, 0, 0};
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 dacc[7];
+  for (int t = 0; t < 7; ++t) dacc[t] = d4{0, 0, 0, 0};
   __syncthreads();
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int rep = 0; rep < reps; ++rep) {
@@ -28,6 +31,12 @@ __global__ __launch_bounds__(512, 1) void k(const float* __restrict__ src, int n
         for (int it = 0; it < nm / 8; ++it)
 #pragma unroll
           for (int t = 0; t < 4; ++t) big[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, big[t], 0, 0, 0);
+      } else if (MF && (MODE == 8 || MODE == 9)) {   // f64 16x16x4 (64 cycles each): half as many
+        for (int it = 0; it < nm / 56; ++it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 7; ++t) dacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)b, (double)b, dacc[t], 0, 0, 0);
       } else if (MF && MODE == 5) {   // bf16 16x16x16: 8 passes like the f32 16x16x4
         for (int it = 0; it < nm / 28; ++it)
 #pragma unroll
@@ -43,7 +52,14 @@ __global__ __launch_bounds__(512, 1) void k(const float* __restrict__ src, int n
     } else if (DMA) {
       if (MODE == 1) __builtin_amdgcn_s_setprio(3);
       const int nchunks = nfl / 256;
-      if (MODE == 6) {   // pure VALU work in the partner wavefronts: nm*8 dependent-free FMAs
+      if (MODE == 9) {   // pure VALU beside the f64 MFMAs
+        float x0 = b, x1 = b + 1, x2 = b + 2, x3 = b + 3;
+        for (int it = 0; it < nm * 2; ++it) {
+          x0 = __builtin_fmaf(x0, 1.0001f, 0.5f); x1 = __builtin_fmaf(x1, 1.0001f, 0.5f);
+          x2 = __builtin_fmaf(x2, 1.0001f, 0.5f); x3 = __builtin_fmaf(x3, 1.0001f, 0.5f);
+        }
+        ld[0] += x0 + x1 + x2 + x3;
+      } else if (MODE == 6) {   // pure VALU work in the partner wavefronts: nm*8 dependent-free FMAs
         float x0 = b, x1 = b + 1, x2 = b + 2, x3 = b + 3;
         for (int it = 0; it < nm * 2; ++it) {
           x0 = __builtin_fmaf(x0, 1.0001f, 0.5f); x1 = __builtin_fmaf(x1, 1.0001f, 0.5f);
@@ -66,6 +82,7 @@ __global__ __launch_bounds__(512, 1) void k(const float* __restrict__ src, int n
   for (int t = 0; t < 7; ++t) s += acc[t][0] + acc[t][3];
   for (int t = 0; t < 4; ++t) s += big[t][0] + big[t][7];
   s += ld[0] + ld[1] + ld[2] + ld[3];
+  for (int t = 0; t < 7; ++t) s += (float)(dacc[t][0] + dacc[t][3]);
   out[blockIdx.x * 512 + tid] = s;
   if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
@@ -108,5 +125,8 @@ int main() {
   RUNM(true, true, 65, 140, 256, 6);
   RUNM(false, true, 65, 140, 256, 7);
   RUNM(true, true, 65, 140, 256, 7);
+  RUNM(true, false, 65, 140, 256, 8);
+  RUNM(true, true, 65, 140, 256, 8);
+  RUNM(true, true, 65, 140, 256, 9);
   return 0;
 }
