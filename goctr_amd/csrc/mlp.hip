@@ -362,6 +362,60 @@ __global__ __launch_bounds__(256) void mlp_out_kernel(const double* zpart, int n
   A2[idx] = a2; delta[idx] = d; lossterm[idx] = l;
 }
 
+
+// backward through a single-output head (fused [F,H,1] path): no GEMM is needed --
+//   D1[r][h] = delta[r] * W2[h] * act'(A1[r][h])          (basemlp64.go:120-148,302-308 with one output unit)
+//   dW2[h]   = sum_r A1[r][h] * delta[r]  (the ones column of A1 makes row `units1` the intercept gradient)
+// one workgroup per slab of `rows` batch rows writes D1 and the slab's partial dW2 (column 0 of [up1][upL]).
+__global__ __launch_bounds__(1024) void mlp_bwd_hidden_kernel(const double* __restrict__ A1, const double* __restrict__ delta,
+                                                              const double* __restrict__ W2, int n, int rows, int units1,
+                                                              int up1, int upL, int act, double* __restrict__ D1,
+                                                              double* __restrict__ slab) {
+  __shared__ double red[1024];
+  const int h = threadIdx.x & 127, part = threadIdx.x >> 7;   // 8 row lanes x 128 columns
+  const int r0 = blockIdx.x * rows;
+  int r1 = r0 + rows; if (r1 > n) r1 = n;
+  double acc = 0;
+  if (h < up1) {
+    const double w2 = W2[(size_t)h * upL];
+    for (int rb = r0 + part; rb < r1; rb += 32) {          // 4 rows in flight per thread
+      double av[4], dl[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = rb + 8 * u;
+        av[u] = r < r1 ? A1[(size_t)r * up1 + h] : 0.0;
+        dl[u] = r < r1 ? delta[(size_t)r * upL] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = rb + 8 * u;
+        if (r < r1) {
+          double d = 0;
+          if (h < units1) {
+            const double s = dl[u] * w2;
+            switch (act) {
+              case GOCTR_ACT_LOGISTIC: d = s * (av[u] * (1 - av[u])); break;
+              case GOCTR_ACT_TANH: d = s * (1 - av[u] * av[u]); break;
+              case GOCTR_ACT_RELU: d = av[u] == 0 ? 0 : s; break;  // quirk Q12
+              default: d = s;
+            }
+          }
+          D1[(size_t)r * up1 + h] = d;
+          acc += av[u] * dl[u];
+        }
+      }
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (part == 0 && h < up1) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[h + 128 * k];
+    slab[(size_t)blockIdx.x * up1 * upL + (size_t)h * upL] = s;
+  }
+}
+
 template <class K>
 int allow_big_lds(K kernel) {
   GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -439,12 +493,24 @@ struct goctr_mlp {
 
 namespace {
 
-int tn_rows64() { return 64; }
+// slab height of the weight-gradient GEMMs: the widest layer's k-blocks x slabs should not exceed the CUs (f64 MFMA
+// work of co-resident workgroups serialises per SIMD like the f32 one does)
+int tn_rows64(const goctr_mlp* p, int n);
+int tn_rows64(const goctr_mlp* p, int n) {
+  int kb = 1;
+  for (int l = 0; l < p->nl; ++l) { const int k = (int)cdiv(p->up[l] / 16, 3); if (k > kb) kb = k; }
+  int cus = engine().compute_units > 0 ? engine().compute_units : 256;
+  const int S = cus / kb > 0 ? cus / kb : 1;
+  int rows = (int)cdiv(n, S);
+  rows = rows < 32 ? 32 : round_up(rows, 2);
+  return rows;
+}
+bool up1_le128(const goctr_mlp* p) { return p->up[1] <= 128; }
 int env_int_mlp(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 
 int ensure_ws(goctr_mlp* p, int n) {
   if (p->wsN >= n) return 0;
-  p->S = (int)cdiv(n, tn_rows64());
+  p->S = (int)cdiv(n, tn_rows64(p, n));
   for (int i = 0; i <= p->nl; ++i) {
     if (p->A[i].alloc((size_t)n * p->up[i])) return -1;
     if (i > 0 && p->D[i].alloc((size_t)n * p->up[i])) return -1;
@@ -499,8 +565,16 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   hipLaunchKernelGGL(mlp_delta_last_kernel, dim3((unsigned)cdiv((int64_t)n * upL, 256)), dim3(256), 0, e.stream,
                      p->A[L].p, p->Yb.p, n, no, upL, p->D[L].p, p->lossterm.p);
   GOCTR_HIP(hipGetLastError());
-  for (int l = L - 1; l >= 0; --l) {
-    if (launch_tn64(p->A[l].p, p->up[l], p->up[l] / 16, p->D[l + 1].p, p->up[l + 1], p->up[l + 1] / 16, n, tn_rows64(),
+  const bool fused_bwd = p->fused_fwd_done && up1_le128(p);
+  if (fused_bwd) {
+    const int rows = tn_rows64(p, n);
+    hipLaunchKernelGGL(mlp_bwd_hidden_kernel, dim3((unsigned)cdiv(n, rows)), dim3(1024), 0, e.stream, p->A[1].p, p->D[2].p,
+                       p->W.p + p->woff[1], n, rows, p->units[1], p->up[1], p->up[2], p->cfg.activation, p->D[1].p,
+                       p->slabs[1].p);
+    GOCTR_HIP(hipGetLastError());
+  }
+  for (int l = fused_bwd ? 0 : L - 1; l >= 0; --l) {
+    if (launch_tn64(p->A[l].p, p->up[l], p->up[l] / 16, p->D[l + 1].p, p->up[l + 1], p->up[l + 1] / 16, n, tn_rows64(p, n),
                     p->slabs[l].p)) return -1;
     if (l >= 1) {
       EpiMlpDAct d{p->D[l].p, p->A[l].p, p->up[l], p->units[l], p->cfg.activation,
@@ -512,7 +586,7 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   a.nl = L;
   for (int l = 0; l < L; ++l)
     a.L[l] = {p->units[l], p->units[l + 1], p->up[l], p->up[l + 1], p->woff[l], p->poff[l], p->slabs[l].p,
-              (int)cdiv(n, tn_rows64()), p->WT[l].p};
+              (int)cdiv(n, tn_rows64(p, n)), p->WT[l].p};
   a.nflat = p->nflat; a.nparams = p->nparams;
   a.W = p->W.p; a.G = p->G.p; a.Mo = p->Mo.p; a.Vo = p->Vo.p; a.Vel = p->Vel.p;
   a.alpha = p->cfg.alpha; a.n = n; a.solver = p->cfg.solver; a.do_update = do_update ? 1 : 0;
