@@ -449,8 +449,10 @@ int launch_nn64(const double* A, int lda, const double* Bm, int ldb, int M, int 
 int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int NT, int M, int rows_per_wg,
                 double* slabs) {
   const int S = (int)cdiv(M, rows_per_wg);
-  constexpr int KTW = 3, NTW = 4, CH = 16;
-  const int WK = 1, WN = std::min(2, (int)cdiv(NT, NTW));
+  // 4 wavefronts per workgroup = 2 k-groups x 2 n-groups of 3 x 2 tiles: every SIMD of a CU gets a wavefront
+  // (the former 1 x 2 arrangement of 3 x 4 tiles left half the SIMDs idle at this problem size)
+  constexpr int KTW = 3, NTW = 2, CH = 16;
+  const int WK = KT >= 2 * KTW ? 2 : 1, WN = std::min(2, (int)cdiv(NT, NTW));
   dim3 grid(S, (unsigned)cdiv(KT, WK * KTW), (unsigned)cdiv(NT, WN * NTW));
   hipLaunchKernelGGL((gemm_tn_kernel<double, KTW, NTW, CH>), grid, dim3(64 * WK * WN),
                      gemm_tn_lds_bytes<double>(WK * KTW, WN * NTW, CH), engine().stream, A, lda, KT, Dm, ldd, NT, M,
@@ -465,7 +467,7 @@ int init_attrs64() {
   if (allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 1>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 2>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 4>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 1>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 2>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 4>) ||
-      allow_big_lds(gemm_tn_kernel<double, 3, 4, 16>) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
+      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
   done = true;
   return 0;
 }
@@ -497,8 +499,12 @@ namespace {
 // work of co-resident workgroups serialises per SIMD like the f32 one does)
 int tn_rows64(const goctr_mlp* p, int n);
 int tn_rows64(const goctr_mlp* p, int n) {
-  int kb = 1;
-  for (int l = 0; l < p->nl; ++l) { const int k = (int)cdiv(p->up[l] / 16, 3); if (k > kb) kb = k; }
+  int kb = 1;   // workgroups per slab of the widest layer (see launch_tn64)
+  for (int l = 0; l < p->nl; ++l) {
+    const int KT = p->up[l] / 16, NT = p->up[l + 1] / 16;
+    const int k = (int)cdiv(KT, KT >= 6 ? 6 : 3) * (int)cdiv(NT, NT >= 3 ? 4 : 2);
+    if (k > kb) kb = k;
+  }
   int cus = engine().compute_units > 0 ? engine().compute_units : 256;
   const int S = cus / kb > 0 ? cus / kb : 1;
   int rows = (int)cdiv(n, S);
