@@ -490,6 +490,9 @@ struct goctr_mlp {
   DevBuf<MlpState> st;
   // resident rows
   DevBuf<float> Xr, Yr; int64_t rows = 0; DevBuf<int> perm;
+  hipGraphExec_t step_graph = nullptr; int64_t step_graph_rows = 0; bool step_graph_perm = false;   // resident training step
+  const void* step_graph_x = nullptr; const void* step_graph_y = nullptr; const void* step_graph_p = nullptr; const void* step_graph_w = nullptr;
+  ~goctr_mlp() { if (step_graph) (void)hipGraphExecDestroy(step_graph); }
   std::mutex mu;
 };
 
@@ -794,6 +797,29 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
   MlpState s;
   if (get_mstate(p, &s)) return -1;
   if (set_mstate(p, s.t, first_batch % nb, nb, 0)) return -1;
+  // every per-step scalar lives in the device MlpState, so one captured step replays for all of them
+  Engine& e = engine();
+  const bool use_graph = !e.prof && env_int_mlp("GOCTR_NO_GRAPH", 0) == 0 && n_steps > 1;
+  if (use_graph) {
+    if (ensure_ws(p, p->cfg.batch)) return -1;                 // no allocation inside the capture
+    if (p->fused_ok() && p->zpart.ensure((size_t)cdiv(p->up[1], 32) * p->cfg.batch, false)) return -1;
+    if (!p->step_graph || p->step_graph_rows != p->rows || p->step_graph_perm != (p->perm.n > 1) ||
+        p->step_graph_x != p->Xr.p || p->step_graph_y != p->Yr.p || p->step_graph_p != p->perm.p || p->step_graph_w != p->W0img.p) {
+      if (p->step_graph) { (void)hipGraphExecDestroy(p->step_graph); p->step_graph = nullptr; }
+      hipGraph_t g = nullptr;
+      GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+      const int rc = train_step_resident(p, true, 0);
+      const hipError_t ce = hipStreamEndCapture(e.stream, &g);
+      if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
+      GOCTR_HIP(ce);
+      GOCTR_HIP(hipGraphInstantiate(&p->step_graph, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      p->step_graph_rows = p->rows; p->step_graph_perm = p->perm.n > 1;
+      p->step_graph_x = p->Xr.p; p->step_graph_y = p->Yr.p; p->step_graph_p = p->perm.p; p->step_graph_w = p->W0img.p;
+    }
+    for (int i = 0; i < n_steps; ++i) GOCTR_HIP(hipGraphLaunch(p->step_graph, e.stream));
+    return 0;
+  }
   for (int i = 0; i < n_steps; ++i)
     if (train_step_resident(p, true, 0)) return -1;
   return 0;
