@@ -893,6 +893,139 @@ int goctr_dataset_create_ids(const int32_t* ub_ids, const int32_t* item_ids, con
 }
 void goctr_dataset_destroy(goctr_dataset* d) { delete d; }
 
+}  // extern "C"
+
+// ------------------------------------------------------------------ device-side sample assembly
+// ubcache.UserBehaviorCache (feature/ubcache/cache.go) as a CSR in HBM + the per-sample gather of GetSampleVector
+// (recommend/rcmd.go:460-536) as one kernel: keys (user, item, timestamp) -> behaviour ids, user / item feature rows.
+struct goctr_ubcache {
+  int64_t n_users = 0, nnz = 0;
+  DevBuf<long long> off, ts;
+  DevBuf<int32_t> items;
+};
+
+namespace {
+// TimeSeq.Filter (cache.go:71-94) for one key: the sequence is newest-first, so "the first i with Ts[i] <= maxTs"
+// is a lower bound found by bisection; then up to T items from there.
+__global__ __launch_bounds__(256) void assemble_keys_kernel(const long long* __restrict__ off, const int32_t* __restrict__ seq_items,
+                                                            const long long* __restrict__ seq_ts, long long n_users,
+                                                            const float* __restrict__ user_table, int U,
+                                                            const float* __restrict__ item_table, long long n_items, int C,
+                                                            const int32_t* __restrict__ users, const int32_t* __restrict__ items,
+                                                            const long long* __restrict__ ts, long long rows, int T,
+                                                            int32_t* __restrict__ ub_ids, float* __restrict__ ufeat,
+                                                            float* __restrict__ cfeat) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wavefront per sample
+  if (r >= rows) return;
+  const int u = users[r];
+  const bool uok = u >= 0 && u < n_users;
+  long long first = 0, cnt = 0;
+  const long long b = uok ? off[u] : 0, len = uok ? off[u + 1] - b : 0;
+  if (len > 0) {
+    long long mts = ts ? ts[r] : 0;
+    if (mts == 0) mts = seq_ts[b];                       // cache.go:72-74
+    long long lo = 0, hi = len;                          // first i with seq_ts[b + i] <= mts (descending order)
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (seq_ts[b + mid] <= mts) hi = mid; else lo = mid + 1;
+    }
+    first = lo;
+    cnt = len - first < T ? len - first : T;
+  }
+  if (ub_ids)
+    for (int j = lane; j < T; j += 64) ub_ids[r * T + j] = j < cnt ? seq_items[b + first + j] : -1;
+  if (ufeat)
+    for (int j = lane; j < U; j += 64) ufeat[r * U + j] = uok ? user_table[(long long)u * U + j] : 0.f;
+  if (cfeat) {
+    const int it = items[r];
+    const bool iok = it >= 0 && it < n_items;
+    for (int j = lane; j < C; j += 64) cfeat[r * C + j] = iok ? item_table[(long long)it * C + j] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int goctr_ubcache_create(int64_t n_users, const int64_t* off, const int32_t* items, const int64_t* ts, goctr_ubcache** out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(n_users > 0 && off && out && off[0] == 0, "goctr_ubcache_create: bad arguments");
+  const int64_t nnz = off[n_users];
+  GOCTR_CHECK(nnz >= 0 && (nnz == 0 || (items && ts)), "goctr_ubcache_create: sequences missing");
+  for (int64_t u = 0; u < n_users; ++u) {
+    GOCTR_CHECK(off[u + 1] >= off[u], "goctr_ubcache_create: offsets must be non-decreasing");
+    for (int64_t k = off[u] + 1; k < off[u + 1]; ++k)
+      GOCTR_CHECK(ts[k] <= ts[k - 1], "goctr_ubcache_create: user %lld's sequence is not in timestamp-descending order "
+                  "(cache.go:8 TimeSeq)", (long long)u);
+  }
+  std::unique_ptr<goctr_ubcache> c(new goctr_ubcache);
+  c->n_users = n_users; c->nnz = nnz;
+  std::vector<long long> o(off, off + n_users + 1), t(ts, ts + nnz);
+  if (c->off.alloc(o.size(), false) || c->off.upload(o.data(), o.size())) return -1;
+  if (c->items.alloc((size_t)nnz, false) || (nnz && c->items.upload(items, (size_t)nnz))) return -1;
+  if (c->ts.alloc((size_t)nnz, false) || (nnz && c->ts.upload(t.data(), (size_t)nnz))) return -1;
+  *out = c.release();
+  return 0;
+}
+void goctr_ubcache_destroy(goctr_ubcache* c) { delete c; }
+
+int goctr_ubcache_get(goctr_ubcache* c, const int32_t* users, const int64_t* max_ts, int64_t rows, int T, int32_t* out_ids) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(c && users && out_ids && rows > 0 && T > 0, "goctr_ubcache_get: bad arguments");
+  DevBuf<int32_t> du, dout; DevBuf<long long> dts;
+  std::vector<long long> t(rows, 0);
+  if (max_ts) for (int64_t i = 0; i < rows; ++i) t[i] = max_ts[i];
+  if (du.alloc(rows, false) || du.upload(users, rows) || dts.alloc(rows, false) || dts.upload(t.data(), rows) ||
+      dout.alloc((size_t)rows * T, false)) return -1;
+  hipLaunchKernelGGL(assemble_keys_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, engine().stream, c->off.p, c->items.p,
+                     c->ts.p, (long long)c->n_users, (const float*)nullptr, 0, (const float*)nullptr, 0LL, 0, du.p,
+                     (const int32_t*)nullptr, dts.p, (long long)rows, T, dout.p, (float*)nullptr, (float*)nullptr);
+  GOCTR_HIP(hipGetLastError());
+  return dout.download(out_ids, (size_t)rows * T);
+}
+
+int goctr_dataset_create_keys(goctr_ubcache* c, const float* user_table, int64_t n_users, int U, const float* item_table,
+                              int64_t n_items, int C, const int32_t* users, const int32_t* items, const int64_t* ts,
+                              const float* Y, int64_t rows, int T, goctr_dataset** out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(c && users && items && rows > 0 && T > 0 && out, "goctr_dataset_create_keys: bad arguments");
+  GOCTR_CHECK(n_users == c->n_users, "goctr_dataset_create_keys: user table has %lld rows, the behaviour cache %lld users",
+              (long long)n_users, (long long)c->n_users);
+  GOCTR_CHECK((U == 0 || user_table) && (C == 0 || item_table), "goctr_dataset_create_keys: feature table missing");
+  std::unique_ptr<goctr_dataset> d(new goctr_dataset);
+  d->id_mode = true; d->rows = rows; d->U = U; d->C = C; d->T = T;
+  DevBuf<float> dut, dit; DevBuf<int32_t> du; DevBuf<long long> dts;
+  std::vector<long long> t(rows, 0);
+  if (ts) for (int64_t i = 0; i < rows; ++i) t[i] = ts[i];
+  if (dut.alloc((size_t)n_users * U, false) || (U && dut.upload(user_table, (size_t)n_users * U))) return -1;
+  if (dit.alloc((size_t)n_items * C, false) || (C && dit.upload(item_table, (size_t)n_items * C))) return -1;
+  if (du.alloc(rows, false) || du.upload(users, rows) || dts.alloc(rows, false) || dts.upload(t.data(), rows)) return -1;
+  if (d->ub_ids.alloc((size_t)rows * T, false) || d->item_ids.alloc(rows, false) || d->item_ids.upload(items, rows)) return -1;
+  if (d->ufeat.alloc((size_t)rows * U, false) || d->cfeat.alloc((size_t)rows * C, false)) return -1;
+  hipLaunchKernelGGL(assemble_keys_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, engine().stream, c->off.p, c->items.p,
+                     c->ts.p, (long long)c->n_users, dut.p, U, dit.p, (long long)n_items, C, du.p, d->item_ids.p, dts.p,
+                     (long long)rows, T, d->ub_ids.p, d->ufeat.p, d->cfeat.p);
+  GOCTR_HIP(hipGetLastError());
+  GOCTR_HIP(hipStreamSynchronize(engine().stream));   // the temporaries above are released on return
+  if (Y) { if (d->Y.alloc(rows, false) || d->Y.upload(Y, rows)) return -1; d->has_y = true; }
+  *out = d.release();
+  return 0;
+}
+
+// read back the assembled keys of an id-mode dataset (tests, debugging)
+int goctr_dataset_get_ids(goctr_dataset* d, int32_t* ub_ids, float* user_feat, float* ctx_feat) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(d && d->id_mode, "goctr_dataset_get_ids: not an id-mode dataset");
+  if (ub_ids && d->ub_ids.download(ub_ids, (size_t)d->rows * d->T)) return -1;
+  if (user_feat && d->U && d->ufeat.download(user_feat, (size_t)d->rows * d->U)) return -1;
+  if (ctx_feat && d->C && d->cfeat.download(ctx_feat, (size_t)d->rows * d->C)) return -1;
+  return 0;
+}
+
+}  // extern "C"
+
+extern "C" {
+
 // ------------------------------------------------------------------ training
 int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,
                       int64_t first_batch, int n_steps, float* costs) {

@@ -278,6 +278,37 @@ class Dataset:
                                                         capi.ptr(Yp, C.c_float), C.c_int64(rows), C.byref(h)))
         return Dataset(h, rows)
 
+    @staticmethod
+    def keys(ubc, user_table, item_table, users, items, ts, Y, T):
+        """device-side sample assembly (replaces GetSample / GetSampleVector's per-sample host gather, rcmd.go:339-536):
+        ubc = ubcache.UserBehaviorCache; users / items = DENSE row indices into user_table / item_table (and into
+        ubc.user_index() order); ts = the samples' timestamps"""
+        users = np.ascontiguousarray(users, np.int32)
+        items = np.ascontiguousarray(items, np.int32)
+        ts = np.ascontiguousarray(ts, np.int64)
+        ut = capi.f32(user_table)
+        it = capi.f32(item_table)
+        y = None if Y is None else capi.f32(Y)
+        h = C.c_void_p()
+        capi.check(capi.load().goctr_dataset_create_keys(ubc.device(), capi.ptr(ut, C.c_float), C.c_int64(ut.shape[0]),
+                                                         C.c_int(ut.shape[1]), capi.ptr(it, C.c_float), C.c_int64(it.shape[0]),
+                                                         C.c_int(it.shape[1]), capi.ptr(users, C.c_int32),
+                                                         capi.ptr(items, C.c_int32), capi.ptr(ts, C.c_int64),
+                                                         capi.ptr(y, C.c_float), C.c_int64(users.size), C.c_int(T), C.byref(h)))
+        d = Dataset(h, users.size)
+        d._dims = (T, ut.shape[1], it.shape[1])
+        return d
+
+    def get_ids(self):
+        """(ub_ids [rows,T], user_feat [rows,U], ctx_feat [rows,C]) of a dataset built by keys()"""
+        T, U, Cc = self._dims
+        ub = np.empty((self.rows, T), np.int32)
+        uf = np.empty((self.rows, U), np.float32)
+        cf = np.empty((self.rows, Cc), np.float32)
+        capi.check(capi.load().goctr_dataset_get_ids(self._h, capi.ptr(ub, C.c_int32), capi.ptr(uf, C.c_float),
+                                                     capi.ptr(cf, C.c_float)))
+        return ub, uf, cf
+
     def close(self):
         if self._h:
             capi.load().goctr_dataset_destroy(self._h)

@@ -133,6 +133,26 @@ int goctr_dataset_create_ids(const int32_t* ub_ids /*[rows,T]*/, const int32_t* 
                              int C, int T, const float* Y /* may be NULL */, int64_t rows, goctr_dataset** out);
 void goctr_dataset_destroy(goctr_dataset* d);
 
+/* ---- device-side sample assembly: replaces the per-sample host gather of GetSample /
+ * GetSampleVector (recommend/rcmd.go:339-536) and the ubcache lookup it calls (feature/ubcache/cache.go:58-94).
+ * The behaviour cache is a CSR resident in HBM: user u's sequence = items/ts[off[u] .. off[u+1]) in timestamp-
+ * DESCENDING order (cache.go:8).  A key (user, maxTs) selects Filter(maxTs, T): the first T entries with ts <= maxTs
+ * (maxTs == 0: from the newest, cache.go:72-74); unused slots are -1 (zero embedding rows, rcmd.go:497-505). */
+typedef struct goctr_ubcache goctr_ubcache;
+int goctr_ubcache_create(int64_t n_users, const int64_t* off /*[n_users+1]*/, const int32_t* items, const int64_t* ts,
+                         goctr_ubcache** out);
+void goctr_ubcache_destroy(goctr_ubcache* c);
+/* UserBehaviorCache.Get for `rows` keys at once; out_ids [rows, T] */
+int goctr_ubcache_get(goctr_ubcache* c, const int32_t* users, const int64_t* max_ts /* may be NULL = 0 */, int64_t rows,
+                      int T, int32_t* out_ids);
+/* id-mode dataset assembled on the device from sample keys (rcmd.Sample{UserId, ItemId, Timestamp}, rcmd.go:65-71):
+ * behaviour ids from the cache, user_table[user] and item_table[item] rows as the dense side features */
+int goctr_dataset_create_keys(goctr_ubcache* c, const float* user_table /*[n_users,U]*/, int64_t n_users, int U,
+                              const float* item_table /*[n_items,C]*/, int64_t n_items, int C, const int32_t* users,
+                              const int32_t* items, const int64_t* ts, const float* Y /* may be NULL */, int64_t rows, int T,
+                              goctr_dataset** out);
+int goctr_dataset_get_ids(goctr_dataset* d, int32_t* ub_ids, float* user_feat, float* ctx_feat);
+
 /* model.Train's epoch loop over a resident dataset (emb == NULL for dense datasets). */
 int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,
                         float* epoch_costs, int* epochs_run);

@@ -258,6 +258,14 @@ double orc_cosine64(const double* v1, const double* v2, int d, double n1, double
 int orc_knn_search(const double* items, const double* norms, int64_t V, int D, const double* query, double qnorm,
                    int k, int64_t ignore, int64_t* out_idx, double* out_sim, int* out_rank);
 
+/* ---- user-behaviour cache lookup + per-sample key assembly (orc_ubcache.c): cache.go:71-94, rcmd.go:460-536 ---- */
+int64_t orc_ubcache_filter(const int64_t* ts, const int32_t* items, int64_t len, int64_t max_ts, int64_t max_len,
+                           int32_t* out);
+void orc_assemble_keys(const int64_t* off, const int32_t* seq_items, const int64_t* seq_ts, int64_t n_users,
+                       const float* user_table, int U, const float* item_table, int64_t n_items, int C,
+                       const int32_t* users, const int32_t* items, const int64_t* ts, int64_t rows, int T,
+                       int32_t* ub_ids, float* ufeat, float* cfeat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -525,3 +525,35 @@ def knn_search(items, query, k, ignore=-1, norms=None, qnorm=None):
                              C.c_double(qn), C.c_int(k), C.c_int64(ignore), _p(idx, C.c_int64), _p(sim, C.c_double),
                              _p(rank, C.c_int32))
     return idx[:n], sim[:n], rank[:n]
+
+
+# ---------------------------------------------------------------- user-behaviour cache / key assembly --
+def ubcache_filter(ts, items, max_ts, max_len):
+    """TimeSeq.Filter (cache.go:71-94) on a newest-first sequence -> the selected item ids"""
+    ts = np.ascontiguousarray(ts, np.int64)
+    items = np.ascontiguousarray(items, np.int32)
+    out = np.zeros(max(ts.size, 1), np.int32)
+    lib().orc_ubcache_filter.restype = C.c_int64
+    n = lib().orc_ubcache_filter(_p(ts, C.c_int64), _p(items, C.c_int32), C.c_int64(ts.size), C.c_int64(max_ts),
+                                 C.c_int64(max_len), _p(out, C.c_int32))
+    return out[:n]
+
+
+def assemble_keys(off, seq_items, seq_ts, user_table, item_table, users, items, ts, T):
+    off = np.ascontiguousarray(off, np.int64)
+    seq_items = np.ascontiguousarray(seq_items, np.int32)
+    seq_ts = np.ascontiguousarray(seq_ts, np.int64)
+    ut = np.ascontiguousarray(user_table, np.float32)
+    it = np.ascontiguousarray(item_table, np.float32)
+    users = np.ascontiguousarray(users, np.int32)
+    items = np.ascontiguousarray(items, np.int32)
+    ts = np.ascontiguousarray(ts, np.int64)
+    rows = users.size
+    ub = np.empty((rows, T), np.int32)
+    uf = np.empty((rows, ut.shape[1]), np.float32)
+    cf = np.empty((rows, it.shape[1]), np.float32)
+    lib().orc_assemble_keys(_p(off, C.c_int64), _p(seq_items, C.c_int32), _p(seq_ts, C.c_int64), C.c_int64(off.size - 1),
+                            _p(ut, C.c_float), C.c_int(ut.shape[1]), _p(it, C.c_float), C.c_int64(it.shape[0]),
+                            C.c_int(it.shape[1]), _p(users, C.c_int32), _p(items, C.c_int32), _p(ts, C.c_int64),
+                            C.c_int64(rows), C.c_int(T), _p(ub, C.c_int32), _p(uf, C.c_float), _p(cf, C.c_float))
+    return ub, uf, cf

@@ -162,3 +162,13 @@ def test_search_tail_quirk_and_ties(oracle):
     # better item above two equal ones rotates them
     idx, _, _ = oracle.knn_search(np.array([[1, 0], [1, 0], [1, 0.1]], np.float64), [1.0, 0.05], 3)
     assert idx.tolist() == [2, 1, 0]
+
+
+# ---------------------------------------------------------------- user-behaviour cache
+def test_ubcache_filter_kats(oracle):
+    k = KATS["ubcache_filter"]
+    for c in k["cases"]:
+        assert oracle.ubcache_filter(k["ts"], k["items"], c["max_ts"], c["max_len"]).tolist() == c["expect"]
+    # nothing at or before max_ts -> empty; duplicates of the boundary timestamp are all kept
+    assert oracle.ubcache_filter([9, 8, 7], [1, 2, 3], 5, 2).size == 0
+    assert oracle.ubcache_filter([9, 7, 7, 7, 3], [1, 2, 3, 4, 5], 7, 2).tolist() == [2, 3]
