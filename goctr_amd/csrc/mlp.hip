@@ -125,9 +125,11 @@ __global__ __launch_bounds__(256) void mlp_bn_kernel(double* A, int n, int ld, i
   if (M > 0) for (int r = threadIdx.x; r < n; r += 256) A[(size_t)r * ld + o] /= M;
 }
 
-// element (k, n) of the first weight block inside its LDS image [n/32][k/4][32][k%4] (mlp_fwd_kernel)
+// element (k, n) of the first weight block inside its LDS image [n/32][k/4][(k%4)/2][32][k%2] (mlp_fwd_kernel):
+// the two doubles a lane feeds to 2 consecutive MFMAs are one 16-byte read and the 16 lanes of a q-group read 256
+// contiguous bytes (a [..][32][4] layout made every ds_read_b128 a 2-way bank conflict)
 __host__ __device__ inline size_t mlp_img_index(int k, int n, int up0) {
-  return (((size_t)(n >> 5) * (up0 >> 2) + (k >> 2)) * 32 + (n & 31)) * 4 + (k & 3);
+  return ((((size_t)(n >> 5) * (up0 >> 2) + (k >> 2)) * 2 + ((k & 3) >> 1)) * 32 + (n & 31)) * 2 + (k & 1);
 }
 
 struct MlpLayerDesc {
@@ -268,17 +270,19 @@ __global__ void mlp_narrow_kernel(const double* H, int n, int ld, int no, float*
 // ---------------------------------------------------------------- fused forward of a one-hidden-layer net
 // (the shape go-ctr trains: [F, H, 1], mlp.go:40-47).  Grid = (64-row blocks, 32-column groups of the hidden layer):
 // a workgroup keeps its 32-column slice of W1 (all K rows, stored in HBM as the LDS image
-// [group][k/4][32][k%4], one straight LDS-DMA copy) in LDS, each of its 4 wavefronts carries 16 batch rows:
+// [group][k/4][(k%4)/2][32][k%2], one straight LDS-DMA copy) in LDS, each of its 4 wavefronts carries 16 batch rows:
 //   Z^T[h][row] = sum_k W1[k][h] * A0[row][k]   (v_mfma_f64_16x16x4_f64: A operand = W1 tile from LDS, B operand =
 //   4 consecutive k of the row, two 16-byte loads per 16-k chunk, all issued before the first MFMA),
 // then activation -> A1 (+ ones column), and the partial output pre-activation  sum_h A1[row][h] W2[h]  of the
 // group.  mlp_out_kernel adds the group partials in a fixed order: logistic, delta = h - y, log-loss term.
 // Replaces two gemm_nn launches + mlp_delta_last for this shape (basemlp64.go:259-274, :373-381).
 
-template <int MAXCH>   // 16-k chunks of the input layer kept in registers (up0 <= 16 * MAXCH)
+template <int MAXCH>   // (unused bound: the k loop is a run-time loop)
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(const double* __restrict__ A0, int up0, const double* __restrict__ W1img,
                                                       const double* __restrict__ W2, int upL, int n, int units1, int up1,
-                                                      int act, double* __restrict__ A1, double* __restrict__ zpart) {
+                                                      int act, double* __restrict__ A1, double* __restrict__ zpart, unsigned long long* dbg) {
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (dbg) t0 = __builtin_amdgcn_s_memtime();
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef double d4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) double mlp_smem[];   // [up0/4][32][4]
@@ -298,29 +302,61 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const double* __restrict__
   const bool vrow = row < n;
   const double* ap = A0 + (size_t)(vrow ? row : n - 1) * up0 + 4 * q;
   const int nch = up0 >> 4;
-  d2 xa[MAXCH], xb[MAXCH];
+  // the row's k-fragments stream through an R-slot register ring, R chunks (R x 32 bytes per lane) ahead of the MFMAs
+  // that use them; slot j is refilled in place right after its use (all 18 chunks at once cost 144 VGPRs, which the
+  // compiler parked in AGPRs and shuffled back between chunks)
+  constexpr int R = 6;
+  d2 xr[R][2];
 #pragma unroll
-  for (int c = 0; c < MAXCH; ++c)
-    if (c < nch) { xa[c] = *reinterpret_cast<const d2*>(ap + c * 16); xb[c] = *reinterpret_cast<const d2*>(ap + c * 16 + 2); }
-  d4 acc[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+  for (int c = 0; c < R; ++c) {
+    const int cc = c < nch ? c : nch - 1;
+    xr[c][0] = *reinterpret_cast<const d2*>(ap + cc * 16); xr[c][1] = *reinterpret_cast<const d2*>(ap + cc * 16 + 2);
+  }
+  double w2v[2][4];   // output-unit weights of this lane's 8 hidden columns, fetched under the first wait
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 32 * g + 16 * t + q + 4 * r;
+      w2v[t][r] = h < up1 ? W2[(size_t)h * upL] : 0.0;
+    }
+  // four independent accumulation chains (two per tile: k%4 in {0,1} and {2,3}): with two, every MFMA waits for the
+  // result of the one issued 2 slots earlier (measured 95 cycles per MFMA instead of 65)
+  d4 acc[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}}, acd[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
   __syncthreads();
-  const double* wp = mlp_smem + ((size_t)q * 32 + i) * 4;
+  if (dbg) t1 = __builtin_amdgcn_s_memtime();
+  const double* wp = mlp_smem + ((size_t)q * 64 + i) * 2;   // (k/4 = 4c + q, plane 0, column i)
+  // A real loop over groups of R chunks with a branch-free body (prefetch addresses are clamped; chunks past the end
+  // multiply zeros): guards around the MFMA groups of a fully unrolled loop made the compiler copy the accumulators
+  // AGPR -> VGPR -> AGPR and drain the MFMA pipeline (s_nop 15) once per chunk -- 108 cycles per MFMA instead of 65.
+  d2 wn0a = *reinterpret_cast<const d2*>(wp), wn0b = *reinterpret_cast<const d2*>(wp + 64);
+  d2 wn1a = *reinterpret_cast<const d2*>(wp + 32), wn1b = *reinterpret_cast<const d2*>(wp + 96);
+  for (int c0 = 0; c0 < nch; c0 += R) {
 #pragma unroll
-  for (int c = 0; c < MAXCH; ++c) {
-    if (c < nch) {
-      const double* w = wp + (size_t)c * 4 * 32 * 4;   // chunk c = k rows 16c..16c+15 = 4 (k/4) rows of the image
-      const d2 w0a = *reinterpret_cast<const d2*>(w), w0b = *reinterpret_cast<const d2*>(w + 2);
-      const d2 w1a = *reinterpret_cast<const d2*>(w + 64), w1b = *reinterpret_cast<const d2*>(w + 66);
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0a.x, xa[c].x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1a.x, xa[c].x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0a.y, xa[c].y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1a.y, xa[c].y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0b.x, xb[c].x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1b.x, xb[c].x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0b.y, xb[c].y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1b.y, xb[c].y, acc[1], 0, 0, 0);
+    for (int j = 0; j < R; ++j) {
+      const int c = c0 + j;
+      const bool on = c < nch;
+      const d2 zero = {0.0, 0.0};
+      const d2 xa = on ? xr[j][0] : zero, xb = on ? xr[j][1] : zero;
+      const d2 w0a = wn0a, w0b = wn0b, w1a = wn1a, w1b = wn1b;
+      const int cx = c + R < nch ? c + R : nch - 1;
+      xr[j][0] = *reinterpret_cast<const d2*>(ap + cx * 16); xr[j][1] = *reinterpret_cast<const d2*>(ap + cx * 16 + 2);
+      const int cw = c + 1 < nch ? c + 1 : nch - 1;
+      const double* w = wp + (size_t)cw * 4 * 32 * 4;      // chunk = k rows 16c..16c+15 = 4 (k/4) rows of the image
+      wn0a = *reinterpret_cast<const d2*>(w); wn0b = *reinterpret_cast<const d2*>(w + 64);        // tile 0: k%4 = 0,1 | 2,3
+      wn1a = *reinterpret_cast<const d2*>(w + 32); wn1b = *reinterpret_cast<const d2*>(w + 96);   // tile 1 (columns 16..31)
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0a.x, xa.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1a.x, xa.x, acc[1], 0, 0, 0);
+      acd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0b.x, xb.x, acd[0], 0, 0, 0);
+      acd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1b.x, xb.x, acd[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0a.y, xa.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1a.y, xa.y, acc[1], 0, 0, 0);
+      acd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0b.y, xb.y, acd[0], 0, 0, 0);
+      acd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1b.y, xb.y, acd[1], 0, 0, 0);
     }
   }
+  acc[0] += acd[0]; acc[1] += acd[1];
+  if (dbg) t2 = __builtin_amdgcn_s_memtime();
   // accumulator of lane (row = i, q): Z[row][32 g + 16 t + q + 4 r]
   double part = 0;
 #pragma unroll
@@ -333,13 +369,16 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(const double* __restrict__
       else if (h == units1) v = 1.0;
       if (h < up1) {
         if (vrow) A1[(size_t)row * up1 + h] = v;
-        part += v * W2[(size_t)h * upL];
+        part += v * w2v[t][r];
       }
     }
   }
   part += __shfl_xor(part, 16, 64);
   part += __shfl_xor(part, 32, 64);
   if (q == 0 && vrow) zpart[(size_t)g * n + row] = part;
+  if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    dbg[0] = t1 - t0; dbg[1] = t2 - t1; dbg[2] = __builtin_amdgcn_s_memtime() - t2;
+  }
 }
 
 // output unit of the fused path: fixed-order sum of the group partials, logistic, delta, log-loss term
@@ -538,9 +577,18 @@ int forward(goctr_mlp* p, int n, bool train) {
     const int ng = (int)cdiv(up1, 32);
     if (p->zpart.ensure((size_t)ng * n, false)) return -1;
     const size_t lds = sizeof(double) * (size_t)up0 * 32;
+    static DevBuf<unsigned long long> dbgb;
+    const bool dbg = env_int_mlp("GOCTR_MLP_DBG", 0) != 0;
+    if (dbg && !dbgb.p && dbgb.alloc(4)) return -1;
+    unsigned long long* dbgp = dbg ? dbgb.p : nullptr;
     hipLaunchKernelGGL((mlp_fwd_kernel<24>), dim3((unsigned)cdiv(n, 64), ng), dim3(256), lds, engine().stream, p->A[0].p, up0,
-                       p->W0img.p, p->W.p + p->woff[1], upL, n, p->units[1], up1, p->cfg.activation, p->A[1].p, p->zpart.p);
+                       p->W0img.p, p->W.p + p->woff[1], upL, n, p->units[1], up1, p->cfg.activation, p->A[1].p, p->zpart.p, dbgp);
     GOCTR_HIP(hipGetLastError());
+    if (dbg) {
+      unsigned long long h[4];
+      if (dbgb.download(h, 4)) return -1;
+      fprintf(stderr, "mlp_fwd: load+dma %llu, mfma %llu, epilogue %llu cycles\n", h[0], h[1], h[2]);
+    }
     p->fused_fwd_done = train;   // backward() then skips mlp_delta_last: the out kernel already wrote delta + loss terms
     hipLaunchKernelGGL(mlp_out_kernel, dim3((unsigned)cdiv((int64_t)n * upL, 256)), dim3(256), 0, engine().stream, p->zpart.p, ng, n,
                        train ? p->Yb.p : nullptr, upL, p->A[2].p, p->D[2].p, p->lossterm.p);
