@@ -75,8 +75,11 @@ struct EpiMlpDAct {
 __global__ __launch_bounds__(256) void mlp_gather_kernel(const float* X, const float* Y, const int* perm,
                                                          const MlpState* st, long long start_fixed, int use_state,
                                                          int batch, int F, int up0, int no, int upL, double* A0,
-                                                         double* Yb) {
+                                                         double* Yb, MlpState* st_step) {
   const int r = blockIdx.x;
+  // first kernel of a step: freeze the step's state; the last kernel advances the master copy in place while every
+  // other kernel of the step reads the frozen one (no inter-workgroup ordering needed)
+  if (st_step && r == 0 && threadIdx.x == 0) *st_step = *st;
   const long long start = use_state ? st->batch_idx * (long long)batch : start_fixed;
   const long long src = perm ? perm[start + r] : start + r;
   for (int j = threadIdx.x; j < up0; j += 256)
@@ -86,8 +89,10 @@ __global__ __launch_bounds__(256) void mlp_gather_kernel(const float* X, const f
 }
 
 __global__ __launch_bounds__(256) void mlp_copy_f64_kernel(const double* X, const double* Y, int n, int F, int up0, int no,
-                                                           int upL, double* A0, double* Yb) {
+                                                           int upL, double* A0, double* Yb, const MlpState* st,
+                                                           MlpState* st_step) {
   const int r = blockIdx.x;
+  if (st_step && r == 0 && threadIdx.x == 0) *st_step = *st;
   for (int j = threadIdx.x; j < up0; j += 256) A0[(size_t)r * up0 + j] = j < F ? X[(size_t)r * F + j] : (j == F ? 1.0 : 0.0);
   if (Y)
     for (int j = threadIdx.x; j < upL; j += 256) Yb[(size_t)r * upL + j] = j < no ? Y[(size_t)r * no + j] : 0.0;
@@ -149,8 +154,12 @@ struct MlpReduceArgs {
   int solver; int do_update;
   double lr_init, beta1, beta2, eps, momentum; int nesterov;
   double weight_decay;
-  MlpState* st;
-  double* sumsq_part;         // [gridDim.x] partial sums of W^2 (coefs only)
+  const MlpState* st;         // the step's frozen state (mlp_gather_kernel / mlp_copy_f64_kernel)
+  MlpState* st_master;        // advanced by the loss block when `advance`
+  double* sumsq_part;         // [2][nblk] per-block sums of W^2 (coefs only), parity = step counter & 1
+  int mode;                   // 0: reduce (+ update) and, in block nblk, the loss; 2: only recompute sumsq_part
+  int nblk;                   // blocks that own parameters; block nblk is the loss block
+  const double* lossterm; int upL, no; double* ring; int advance;
   double* W0img; int up1_img; // LDS image of layer 0 for the fused forward (or null)
 };
 
@@ -159,7 +168,57 @@ struct MlpReduceArgs {
 __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   __shared__ double red[256];
+  const int par = (int)(a.st->t & 1);
+  if ((int)blockIdx.x == a.nblk) {
+    // loss = sum(terms)/n + 0.5*alpha*sum(W^2)/n (basemlp64.go:359-361) over the weights the forward pass used: their
+    // squares were summed per block by the launch that wrote them (parity `par`); closes the step
+    double s = 0;
+    const int real = a.n * a.no;      // only the `no` real columns of each padded row carry a term
+    for (int i0 = threadIdx.x; i0 < real; i0 += 256 * 16) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = i0 + u * 256;
+        v[u] = i < real ? a.lossterm[(size_t)(i / a.no) * a.upL + (i % a.no)] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const double lsum = red[0];
+    __syncthreads();
+    s = 0;
+    for (int i = threadIdx.x; i < a.nblk; i += 256) s += a.sumsq_part[(size_t)par * a.nblk + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) {
+      a.ring[a.st->slot % MLP_LOSS_RING] = lsum / (double)a.n + (0.5 * a.alpha) * red[0] / (double)a.n;
+      if (a.advance) {
+        MlpState ns = *a.st;
+        ns.slot += 1;
+        ns.t += 1;
+        const long long nb = ns.batch_idx + 1;
+        ns.batch_idx = nb >= ns.n_batches ? 0 : nb;
+        *a.st_master = ns;
+      }
+    }
+    return;
+  }
   double sq = 0;
+  if (a.mode == 2) {          // (re)build the partial sums of squares of the current weights
+    if (idx < a.nflat) {
+      int l = 0;
+#pragma unroll
+      for (int k = 1; k < 7; ++k) if (k < a.nl && idx >= a.L[k].woff) l = k;
+      const MlpLayerDesc& d = a.L[l];
+      const long long e = idx - d.woff;
+      const int r = (int)(e / d.upo), c = (int)(e - (long long)r * d.upo);
+      if (r < d.fi && c < d.fo) { const double w = a.W[idx]; sq = w * w; }
+    }
+  } else
   if (idx < a.nflat) {
     int l = 0;
 #pragma unroll
@@ -184,7 +243,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
       }
       const double w = a.W[idx];
       double g = s * (1 / (double)a.n);                       // gemm alpha = 1/n (and mean for the bias row)
-      if (is_w) { g += (a.alpha / (double)a.n) * w; sq = w * w; }
+      if (is_w) g += (a.alpha / (double)a.n) * w;
       a.G[idx] = g;
       if (a.do_update) {
         const long long pidx = d.poff + (is_b ? c : (long long)d.fo + (long long)r * d.fo + c);
@@ -204,7 +263,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
           wn = a.nesterov ? w + (a.momentum * upd - a.lr_init * g) : w + upd;
         }
         a.W[idx] = wn;
-        if (is_w) d.WT[(size_t)c * d.upi + r] = wn;
+        if (is_w) { d.WT[(size_t)c * d.upi + r] = wn; sq = wn * wn; }   // squares of the NEW weights: next step's penalty
         if (l == 0 && a.W0img) a.W0img[mlp_img_index(r, c, d.upi)] = wn;
       }
     } else {
@@ -214,46 +273,11 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
   red[threadIdx.x] = sq;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-  if (threadIdx.x == 0) a.sumsq_part[blockIdx.x] = red[0];
-}
-
-// loss = sum(terms)/n + 0.5*alpha*sum(W^2)/n  (basemlp64.go:359-361); closes the step
-__global__ __launch_bounds__(256) void mlp_loss_kernel(const double* lossterm, int nterms, const double* sumsq_part,
-                                                       int nparts, double alpha, int n, MlpState* st, double* ring,
-                                                       int advance, int upL, int no) {
-  __shared__ double red[256];
-  double s = 0;
-  // 16 independent loads in flight per thread (one memory latency per 4096 terms, not per 256), fixed order
-  // only the `no` real columns of each padded row carry a term (the pad columns hold zeros)
-  const int real = (nterms / upL) * no;
-  for (int i0 = threadIdx.x; i0 < real; i0 += 256 * 16) {
-    double v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = i0 + u * 256;
-      v[u] = i < real ? lossterm[(size_t)(i / no) * upL + (i % no)] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s += v[u];
-  }
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  const double lsum = red[0];
-  __syncthreads();
-  s = 0;
-  for (int i = threadIdx.x; i < nparts; i += 256) s += sumsq_part[i];
-  red[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  // mode 2 refreshes this step's parity; an update writes the parity the NEXT step will read; a pure gradient
+  // evaluation leaves the weights -- and therefore both buffers -- alone
   if (threadIdx.x == 0) {
-    ring[st->slot % MLP_LOSS_RING] = lsum / (double)n + (0.5 * alpha) * red[0] / (double)n;
-    if (advance) {
-      st->slot += 1;
-      st->t += 1;
-      long long nb = st->batch_idx + 1;
-      st->batch_idx = nb >= st->n_batches ? 0 : nb;
-    }
+    if (a.mode == 2) a.sumsq_part[(size_t)par * a.nblk + blockIdx.x] = red[0];
+    else if (a.do_update) a.sumsq_part[(size_t)(par ^ 1) * a.nblk + blockIdx.x] = red[0];
   }
 }
 
@@ -409,11 +433,31 @@ __global__ __launch_bounds__(256) void mlp_out_kernel(const double* zpart, int n
 __global__ __launch_bounds__(1024) void mlp_bwd_hidden_kernel(const double* __restrict__ A1, const double* __restrict__ delta,
                                                               const double* __restrict__ W2, int n, int rows, int units1,
                                                               int up1, int upL, int act, double* __restrict__ D1,
-                                                              double* __restrict__ slab) {
+                                                              double* __restrict__ slab, const double* __restrict__ zpart,
+                                                              int ngroups, const double* __restrict__ Yb,
+                                                              double* __restrict__ A2, double* __restrict__ delta_out,
+                                                              double* __restrict__ lossterm) {
   __shared__ double red[1024];
   const int h = threadIdx.x & 127, part = threadIdx.x >> 7;   // 8 row lanes x 128 columns
   const int r0 = blockIdx.x * rows;
   int r1 = r0 + rows; if (r1 > n) r1 = n;
+  if (zpart) {
+    // output unit of the slab's rows first (what mlp_out_kernel does for the predict path): fixed-order sum of the
+    // group partials, logistic, delta = h - y, log-loss term; the rest of the workgroup reads delta back after the
+    // barrier (same CU)
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += 1024) {
+      double z = 0;
+      for (int g = 0; g < ngroups; ++g) z += zpart[(size_t)g * n + r];
+      const double hh = 1 / (1 + exp(-z));
+      const double y = Yb[(size_t)r * upL];
+      const double hmin = 4.9406564584124654e-324, hmax = 0.99999999999999989;  // Nextafter(0,1), Nextafter(1,0)
+      const double hc = hh < hmin ? hmin : (hh > hmax ? hmax : hh);
+      A2[(size_t)r * upL] = hh;
+      delta_out[(size_t)r * upL] = hh - y;
+      lossterm[(size_t)r * upL] = -y * log(hc) - (1 - y) * log1p(-hc);
+    }
+    __syncthreads();
+  }
   double acc = 0;
   if (h < up1) {
     const double w2 = W2[(size_t)h * upL];
@@ -526,7 +570,7 @@ struct goctr_mlp {
   // batch workspace
   int wsN = 0, S = 0;
   DevBuf<double> A[8], D[8], Yb, lossterm, slabs[7], sumsq_part, ring;
-  DevBuf<MlpState> st;
+  DevBuf<MlpState> st, st_step;   // master copy / the running step's frozen copy
   // resident rows
   DevBuf<float> Xr, Yr; int64_t rows = 0; DevBuf<int> perm;
   hipGraphExec_t step_graph = nullptr; int64_t step_graph_rows = 0; bool step_graph_perm = false;   // resident training step
@@ -589,7 +633,8 @@ int forward(goctr_mlp* p, int n, bool train) {
       if (dbgb.download(h, 4)) return -1;
       fprintf(stderr, "mlp_fwd: load+dma %llu, mfma %llu, epilogue %llu cycles\n", h[0], h[1], h[2]);
     }
-    p->fused_fwd_done = train;   // backward() then skips mlp_delta_last: the out kernel already wrote delta + loss terms
+    p->fused_fwd_done = train;   // backward() then skips mlp_delta_last: mlp_bwd_hidden_kernel computes the output unit itself
+    if (!train)
     hipLaunchKernelGGL(mlp_out_kernel, dim3((unsigned)cdiv((int64_t)n * upL, 256)), dim3(256), 0, engine().stream, p->zpart.p, ng, n,
                        train ? p->Yb.p : nullptr, upL, p->A[2].p, p->D[2].p, p->lossterm.p);
     GOCTR_HIP(hipGetLastError());
@@ -627,7 +672,7 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
     const int rows = tn_rows64(p, n);
     hipLaunchKernelGGL(mlp_bwd_hidden_kernel, dim3((unsigned)cdiv(n, rows)), dim3(1024), 0, e.stream, p->A[1].p, p->D[2].p,
                        p->W.p + p->woff[1], n, rows, p->units[1], p->up[1], p->up[2], p->cfg.activation, p->D[1].p,
-                       p->slabs[1].p);
+                       p->slabs[1].p, p->zpart.p, (int)cdiv(p->up[1], 32), p->Yb.p, p->A[2].p, p->D[2].p, p->lossterm.p);
     GOCTR_HIP(hipGetLastError());
   }
   for (int l = fused_bwd ? 0 : L - 1; l >= 0; --l) {
@@ -649,13 +694,25 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   a.alpha = p->cfg.alpha; a.n = n; a.solver = p->cfg.solver; a.do_update = do_update ? 1 : 0;
   a.lr_init = p->cfg.lr_init; a.beta1 = p->cfg.beta1; a.beta2 = p->cfg.beta2; a.eps = p->cfg.eps;
   a.momentum = p->cfg.momentum; a.nesterov = p->cfg.nesterov; a.weight_decay = p->cfg.weight_decay;
-  a.st = p->st.p; a.sumsq_part = p->sumsq_part.p;
+  a.st = p->st_step.p; a.st_master = p->st.p; a.sumsq_part = p->sumsq_part.p;
   a.W0img = p->fused_ok() ? p->W0img.p : nullptr; a.up1_img = p->up[1];
   const int nblk = (int)cdiv(p->nflat, 256);
-  hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk), dim3(256), 0, e.stream, a);
+  a.mode = 0; a.nblk = nblk; a.lossterm = p->lossterm.p; a.upL = upL; a.no = no; a.ring = p->ring.p; a.advance = advance ? 1 : 0;
+  hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk + 1), dim3(256), 0, e.stream, a);   // block nblk: loss + state
   GOCTR_HIP(hipGetLastError());
-  hipLaunchKernelGGL(mlp_loss_kernel, dim3(1), dim3(256), 0, e.stream, p->lossterm.p, n * upL, p->sumsq_part.p, nblk,
-                     p->cfg.alpha, n, p->st.p, p->ring.p, advance ? 1 : 0, upL, no);
+  return 0;
+}
+
+// (re)build the per-block sums of squares of the current weights for the parity of the current step counter; `st`
+// = the state copy whose t decides the parity
+int refresh_sumsq(goctr_mlp* p, const MlpState* st) {
+  MlpReduceArgs a{};
+  a.nl = p->nl;
+  for (int l = 0; l < p->nl; ++l)
+    a.L[l] = {p->units[l], p->units[l + 1], p->up[l], p->up[l + 1], p->woff[l], p->poff[l], nullptr, 0, nullptr};
+  a.nflat = p->nflat; a.nparams = p->nparams; a.W = p->W.p; a.st = st; a.sumsq_part = p->sumsq_part.p;
+  a.mode = 2; a.nblk = (int)cdiv(p->nflat, 256);
+  hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(a.nblk), dim3(256), 0, engine().stream, a);
   GOCTR_HIP(hipGetLastError());
   return 0;
 }
@@ -675,14 +732,15 @@ int weight_decay(goctr_mlp* p) {
                        p->W0img.p, (long long)p->W0img.n, 1 - p->cfg.weight_decay);
     GOCTR_HIP(hipGetLastError());
   }
-  return 0;
+  return refresh_sumsq(p, p->st.p);
 }
 
 int set_mstate(goctr_mlp* p, long long t, long long b, long long nb, unsigned slot) {
   MlpState s{t, b, nb, slot};
   GOCTR_HIP(hipMemcpyAsync(p->st.p, &s, sizeof s, hipMemcpyHostToDevice, engine().stream));
+  GOCTR_HIP(hipMemcpyAsync(p->st_step.p, &s, sizeof s, hipMemcpyHostToDevice, engine().stream));
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
-  return 0;
+  return p->W.p ? refresh_sumsq(p, p->st.p) : 0;   // the penalty sums live under the parity of t
 }
 int get_mstate(goctr_mlp* p, MlpState* s) {
   GOCTR_HIP(hipMemcpyAsync(s, p->st.p, sizeof *s, hipMemcpyDeviceToHost, engine().stream));
@@ -696,7 +754,7 @@ int train_step_resident(goctr_mlp* p, bool use_state, long long start) {
   if (weight_decay(p)) return -1;
   hipLaunchKernelGGL(mlp_gather_kernel, dim3(B), dim3(256), 0, engine().stream, p->Xr.p, p->Yr.p,
                      p->perm.n > 1 ? p->perm.p : nullptr, p->st.p, start, use_state ? 1 : 0, B, p->units[0], p->up[0],
-                     p->units[L], p->up[L], p->A[0].p, p->Yb.p);
+                     p->units[L], p->up[L], p->A[0].p, p->Yb.p, p->st_step.p);
   GOCTR_HIP(hipGetLastError());
   if (forward(p, B, true)) return -1;
   return backward(p, B, true, true);
@@ -739,7 +797,7 @@ int goctr_mlp_create(const goctr_mlp_cfg* cfg, goctr_mlp** out) {
     if (p->WT[l].alloc((size_t)p->up[l] * p->up[l + 1])) return -1;
     if (p->bn[l].alloc(p->up[l + 1])) return -1;
   }
-  if (p->sumsq_part.alloc((size_t)cdiv(wo, 256)) || p->ring.alloc(MLP_LOSS_RING) || p->st.alloc(1)) return -1;
+  if (p->sumsq_part.alloc(2 * (size_t)cdiv(wo, 256)) || p->ring.alloc(MLP_LOSS_RING) || p->st.alloc(1) || p->st_step.alloc(1)) return -1;
   if (set_mstate(p.get(), 0, 0, 1, 0)) return -1;
   *out = p.release();
   return 0;
@@ -813,7 +871,7 @@ int goctr_mlp_loss_grad(goctr_mlp* p, const double* X, const double* Y, int n, d
       dY.upload(Y, (size_t)n * no)) return -1;
   if (weight_decay(p)) return -1;
   hipLaunchKernelGGL(mlp_copy_f64_kernel, dim3(n), dim3(256), 0, engine().stream, dX.p, dY.p, n, F, p->up[0], no,
-                     p->up[L], p->A[0].p, p->Yb.p);
+                     p->up[L], p->A[0].p, p->Yb.p, p->st.p, p->st_step.p);
   GOCTR_HIP(hipGetLastError());
   MlpState s;
   if (get_mstate(p, &s)) return -1;
@@ -923,7 +981,8 @@ int goctr_mlp_predict(goctr_mlp* p, const float* X, int64_t rows, float* y_out) 
     const int n = (int)std::min<int64_t>(CHUNK, rows - s0);
     if (dX.upload(X + s0 * F, (size_t)n * F)) return -1;
     hipLaunchKernelGGL(mlp_gather_kernel, dim3(n), dim3(256), 0, engine().stream, dX.p, (const float*)nullptr,
-                       (const int*)nullptr, p->st.p, 0LL, 0, n, F, p->up[0], no, p->up[L], p->A[0].p, (double*)nullptr);
+                       (const int*)nullptr, p->st.p, 0LL, 0, n, F, p->up[0], no, p->up[L], p->A[0].p, (double*)nullptr,
+                       (MlpState*)nullptr);
     GOCTR_HIP(hipGetLastError());
     if (forward(p, n, false)) return -1;
     hipLaunchKernelGGL(mlp_narrow_kernel, dim3((unsigned)cdiv((int64_t)n * no, 256)), dim3(256), 0, engine().stream,
