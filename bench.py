@@ -318,6 +318,9 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 18, help="resident sample rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--host-rows", action="store_true",
+                    help="also time the drop-in boundary as the reference drives it: dense TrainSample rows handed over in HOST "
+                         "memory (goctr_predict_dense: PCIe copy + predict + copy back); reported as recommend_qps_host_rows")
     ap.add_argument("--workload", default="din", choices=["din", "youtube", "mlp", "item2vec", "knn"],
                     help="din = BASELINE configs[2] (the headline metric, default); youtube = configs[3] per-GPU slice "
                          "(10M x 64 table: the HBM-bound gather); mlp = configs[1]; item2vec = configs[4] per-GPU slice")
@@ -414,6 +417,22 @@ def main():
                    "global_batch": c["B"] * world, "parallelism": f"dp{world}", "resident_rows_per_gpu": args.rows},
         "recommend_qps": round(qps, 1), "recommend_batch": c["PRED_B"],
     }
+
+    if args.host_rows and rank == 0:
+        # model.Predict's own calling convention (model.go:242): X [rows, XCols] float32 in host memory, y back to the host
+        from oracle import pyoracle           # (only to assemble dense rows from the synthetic keys; not timed)
+        from goctr_amd import recommend as gr
+        n = 1 << 16
+        X = pyoracle.assemble_rows(emb, ub[:n], it[:n], uf[:n], cf[:n])
+        si = gr.SampleInfo.from_dims(c["U"], c["T"], c["D"], c["C"])
+        gm.Predict(m, n, c["PRED_B"], si, X)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            gm.Predict(m, n, c["PRED_B"], si, X)
+        dth = (time.perf_counter() - t0) / 3
+        out["recommend_qps_host_rows"] = round(n / dth, 1)
+        out["host_rows_note"] = (f"{n} dense rows x {X.shape[1]} f32 = {X.nbytes / 1e6:.0f} MB over PCIe per call, predict, "
+                                 f"y back: {dth * 1e3:.1f} ms per call")
 
     # ---- roofline: instrumented re-run of the same K steps (eager, hipEvent pair per launch)
     if not args.no_roofline:
