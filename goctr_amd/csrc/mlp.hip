@@ -24,6 +24,7 @@ using namespace goctr;
 namespace {
 
 constexpr int MLP_LOSS_RING = 1 << 14;
+int env_int_mlp(const char* name, int dflt);
 
 struct MlpState {
   long long t;          // optimizer step counter (AdamOptimizer64.t)
@@ -499,6 +500,148 @@ __global__ __launch_bounds__(1024) void mlp_bwd_hidden_kernel(const double* __re
   }
 }
 
+
+// ---------------------------------------------------------------- weight-gradient GEMM, float64 (csrc/mfma_gemm.h
+// gemm_tn_multi_kernel's design with v_mfma_f64_16x16x4_f64):  slab[k][n] = sum over the slab's rows m of
+// A[m][k] * D[m][n].  Workgroup = one block of 3 16-column tiles of A, all tiles of D (2 per wavefront), one slab of
+// batch rows, in chunks of CH rows: a thread loads 4-row x 4-column blocks with 16-byte loads (unconditional:
+// clamped row, zeroed when written), transposes them in registers and writes the columns as 16-byte stores into
+// column-major LDS strips T[col][m] (stride CH + 2 doubles = 16 B mod 128 B); two ds_read_b128 then hold the 4
+// consecutive rows a lane feeds to 4 MFMAs.
+constexpr int TN64_CH = 32, TN64_CHS = TN64_CH + 2, TN64_KTW = 3, TN64_NTW = 2;
+
+__global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restrict__ A, int lda, int KT,
+                                                          const double* __restrict__ Dm, int ldd, int NT, int M, int rows,
+                                                          double* __restrict__ slabs, size_t slab_stride) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  constexpr int CH = TN64_CH, CHS = TN64_CHS, KTW = TN64_KTW, NTW = TN64_NTW;
+  constexpr int MAXB = ((CH / 4) * (KTW * 4 + 8 * 4) + 255) / 256;     // 4x4 blocks per thread and chunk (NT <= 8)
+  extern __shared__ __attribute__((aligned(16))) double tn64_smem[];
+  const int split = blockIdx.x, kb = blockIdx.y;
+  const int kb0 = kb * KTW;
+  int kb_t = KT - kb0; if (kb_t > KTW) kb_t = KTW;
+  const int Kc = kb_t * 16, Nc = NT * 16;
+  const int kv = Kc >> 2, nv = Nc >> 2;
+  double* As = tn64_smem;                         // [2][KTW*16][CHS]
+  double* Ds = As + 2 * KTW * 16 * CHS;           // [2][Nc][CHS]
+  const int a_buf = KTW * 16 * CHS, d_buf = Nc * CHS;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int nt0 = wn * NTW;
+  int ncnt = NT - nt0; ncnt = ncnt < 0 ? 0 : (ncnt > NTW ? NTW : ncnt);
+  const int m_begin = split * rows;
+  int m_end = m_begin + rows; if (m_end > M) m_end = M;
+
+  d4 acc[KTW][NTW];
+#pragma unroll
+  for (int e = 0; e < KTW; ++e)
+#pragma unroll
+    for (int f = 0; f < NTW; ++f) acc[e][f] = d4{0, 0, 0, 0};
+
+  const int nA = (CH / 4) * kv, nAll = nA + (CH / 4) * nv;
+  const double* gsrc[MAXB]; int ld[MAXB]; int rg[MAXB]; int lofs[MAXB];
+  {
+    const float rkv = 1.0f / (float)kv, rnv = 1.0f / (float)nv;
+#pragma unroll
+    for (int s = 0; s < MAXB; ++s) {
+      const int b = tid + s * 256;
+      gsrc[s] = A; ld[s] = lda; rg[s] = 0; lofs[s] = -1;
+      if (b < nA) {
+        const int r = (int)(((float)b + 0.5f) * rkv), cg = b - r * kv;
+        rg[s] = r; ld[s] = lda; gsrc[s] = A + kb0 * 16 + cg * 4; lofs[s] = (cg * 4) * CHS + 4 * r;
+      } else if (b < nAll) {
+        const int bb = b - nA;
+        const int r = (int)(((float)bb + 0.5f) * rnv), cg = bb - r * nv;
+        rg[s] = r; ld[s] = ldd; gsrc[s] = Dm + cg * 4; lofs[s] = 2 * a_buf + (cg * 4) * CHS + 4 * r;
+      }
+    }
+  }
+  d2 st[MAXB][4][2];   // [slot][row][column pair]
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int s = 0; s < MAXB; ++s)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int rr = m0 + 4 * rg[s] + r;
+        rr = rr < m_end ? rr : m_end - 1;
+        const double* p = gsrc[s] + (size_t)rr * ld[s];
+        st[s][r][0] = *reinterpret_cast<const d2*>(p);
+        st[s][r][1] = *reinterpret_cast<const d2*>(p + 2);
+      }
+  };
+  auto lstore = [&](int buf, int m0) {
+#pragma unroll
+    for (int s = 0; s < MAXB; ++s) {
+      if (lofs[s] >= 0) {
+        double* d = As + lofs[s] + (lofs[s] >= 2 * a_buf ? buf * d_buf : buf * a_buf);
+        const int left = m_end - (m0 + 4 * rg[s]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double v0 = left > 0 ? st[s][0][c >> 1][c & 1] : 0.0, v1 = left > 1 ? st[s][1][c >> 1][c & 1] : 0.0;
+          const double v2 = left > 2 ? st[s][2][c >> 1][c & 1] : 0.0, v3 = left > 3 ? st[s][3][c >> 1][c & 1] : 0.0;
+          *reinterpret_cast<d2*>(d + c * CHS) = d2{v0, v1};
+          *reinterpret_cast<d2*>(d + c * CHS + 2) = d2{v2, v3};
+        }
+      }
+    }
+  };
+  int aofs[KTW], dofs[NTW];
+#pragma unroll
+  for (int e = 0; e < KTW; ++e) { int c = e * 16 + i; c = c < Kc ? c : Kc - 1; aofs[e] = c * CHS + 4 * q; }
+#pragma unroll
+  for (int f = 0; f < NTW; ++f) { int c = (nt0 + f) * 16 + i; c = c < Nc ? c : Nc - 1; dofs[f] = c * CHS + 4 * q; }
+
+  if (m_begin < m_end) {
+    gload(m_begin);
+    lstore(0, m_begin);
+    __syncthreads();
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += CH) {
+      const bool more = m0 + CH < m_end;
+      if (more) gload(m0 + CH);
+      const double* as = As + buf * a_buf;
+      const double* ds = Ds + buf * d_buf;
+#pragma unroll
+      for (int g = 0; g < CH / 16; ++g) {
+        d2 av[KTW][2], dv[NTW][2];
+#pragma unroll
+        for (int e = 0; e < KTW; ++e) {
+          av[e][0] = *reinterpret_cast<const d2*>(as + aofs[e] + g * 16);
+          av[e][1] = *reinterpret_cast<const d2*>(as + aofs[e] + g * 16 + 2);
+        }
+#pragma unroll
+        for (int f = 0; f < NTW; ++f) {
+          dv[f][0] = *reinterpret_cast<const d2*>(ds + dofs[f] + g * 16);
+          dv[f][1] = *reinterpret_cast<const d2*>(ds + dofs[f] + g * 16 + 2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int e = 0; e < KTW; ++e)
+#pragma unroll
+            for (int f = 0; f < NTW; ++f)
+              acc[e][f] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[e][r >> 1][r & 1], dv[f][r >> 1][r & 1], acc[e][f], 0, 0, 0);
+      }
+      if (more) lstore(buf ^ 1, m0 + CH);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  // f64 accumulator layout: column n = lane & 15, row k = (lane >> 4) + 4 r
+  double* out = slabs + (size_t)split * slab_stride;
+  const int ld_out = NT * 16;
+#pragma unroll
+  for (int e = 0; e < KTW; ++e)
+#pragma unroll
+    for (int f = 0; f < NTW; ++f)
+      if (e < kb_t && f < ncnt) {
+        const int n = (nt0 + f) * 16 + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)((kb0 + e) * 16 + q + 4 * r) * ld_out + n] = acc[e][f][r];
+      }
+}
+
 template <class K>
 int allow_big_lds(K kernel) {
   GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -531,6 +674,14 @@ int launch_nn64(const double* A, int lda, const double* Bm, int ldb, int M, int 
 
 int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int NT, int M, int rows_per_wg,
                 double* slabs) {
+  if (NT <= 8 && env_int_mlp("GOCTR_MLP_OLD_TN", 0) == 0) {
+    const int Sn = (int)cdiv(M, rows_per_wg);
+    const size_t lds = sizeof(double) * 2 * TN64_CHS * (size_t)(TN64_KTW * 16 + NT * 16);
+    hipLaunchKernelGGL(mlp_tn64_kernel, dim3(Sn, (unsigned)cdiv(KT, TN64_KTW)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
+                       ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16);
+    GOCTR_HIP(hipGetLastError());
+    return 0;
+  }
   const int S = (int)cdiv(M, rows_per_wg);
   // 4 wavefronts per workgroup = 2 k-groups x 2 n-groups of 3 x 2 tiles: every SIMD of a CU gets a wavefront
   // (the former 1 x 2 arrangement of 3 x 4 tiles left half the SIMDs idle at this problem size)
@@ -550,7 +701,7 @@ int init_attrs64() {
   if (allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 1>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 2>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 4>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 1>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 2>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 4>) ||
-      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
+      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_tn64_kernel) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
   done = true;
   return 0;
 }
@@ -588,7 +739,7 @@ int tn_rows64(const goctr_mlp* p, int n) {
   int kb = 1;   // workgroups per slab of the widest layer (see launch_tn64)
   for (int l = 0; l < p->nl; ++l) {
     const int KT = p->up[l] / 16, NT = p->up[l + 1] / 16;
-    const int k = (int)cdiv(KT, KT >= 6 ? 6 : 3) * (int)cdiv(NT, NT >= 3 ? 4 : 2);
+    const int k = NT <= 8 ? (int)cdiv(KT, 3) : (int)cdiv(KT, KT >= 6 ? 6 : 3) * (int)cdiv(NT, NT >= 3 ? 4 : 2);
     if (k > kb) kb = k;
   }
   int cus = engine().compute_units > 0 ? engine().compute_units : 256;
