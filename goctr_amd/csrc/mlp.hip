@@ -431,34 +431,42 @@ __global__ __launch_bounds__(256) void mlp_out_kernel(const double* zpart, int n
 //   D1[r][h] = delta[r] * W2[h] * act'(A1[r][h])          (basemlp64.go:120-148,302-308 with one output unit)
 //   dW2[h]   = sum_r A1[r][h] * delta[r]  (the ones column of A1 makes row `units1` the intercept gradient)
 // one workgroup per slab of `rows` batch rows writes D1 and the slab's partial dW2 (column 0 of [up1][upL]).
-__global__ __launch_bounds__(1024) void mlp_bwd_hidden_kernel(const double* __restrict__ A1, const double* __restrict__ delta,
-                                                              const double* __restrict__ W2, int n, int rows, int units1,
-                                                              int up1, int upL, int act, double* __restrict__ D1,
-                                                              double* __restrict__ slab, const double* __restrict__ zpart,
-                                                              int ngroups, const double* __restrict__ Yb,
-                                                              double* __restrict__ A2, double* __restrict__ delta_out,
-                                                              double* __restrict__ lossterm) {
-  __shared__ double red[1024];
-  const int h = threadIdx.x & 127, part = threadIdx.x >> 7;   // 8 row lanes x 128 columns
+__global__ __launch_bounds__(256) void mlp_bwd_hidden_kernel(const double* __restrict__ A1, const double* __restrict__ delta,
+                                                             const double* __restrict__ W2, int n, int rows, int units1,
+                                                             int up1, int upL, int act, double* __restrict__ D1,
+                                                             double* __restrict__ slab, const double* __restrict__ zpart,
+                                                             int ngroups, const double* __restrict__ Yb,
+                                                             double* __restrict__ A2, double* __restrict__ delta_out,
+                                                             double* __restrict__ lossterm) {
+  // grid = (slabs, 32-column groups): 8 row lanes x 32 columns per workgroup
+  extern __shared__ __attribute__((aligned(16))) double bh_smem[];   // [rows] delta of the slab's rows, then [256] partial sums
+  double* dsh = bh_smem;
+  double* red = bh_smem + rows;
+  const int hl = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int h = blockIdx.y * 32 + hl;
   const int r0 = blockIdx.x * rows;
   int r1 = r0 + rows; if (r1 > n) r1 = n;
   if (zpart) {
     // output unit of the slab's rows first (what mlp_out_kernel does for the predict path): fixed-order sum of the
-    // group partials, logistic, delta = h - y, log-loss term; the rest of the workgroup reads delta back after the
-    // barrier (same CU)
-    for (int r = r0 + (int)threadIdx.x; r < r1; r += 1024) {
+    // group partials, logistic, delta = h - y, log-loss term; every column group needs the deltas, group 0 stores them
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) {
       double z = 0;
       for (int g = 0; g < ngroups; ++g) z += zpart[(size_t)g * n + r];
       const double hh = 1 / (1 + exp(-z));
       const double y = Yb[(size_t)r * upL];
-      const double hmin = 4.9406564584124654e-324, hmax = 0.99999999999999989;  // Nextafter(0,1), Nextafter(1,0)
-      const double hc = hh < hmin ? hmin : (hh > hmax ? hmax : hh);
-      A2[(size_t)r * upL] = hh;
-      delta_out[(size_t)r * upL] = hh - y;
-      lossterm[(size_t)r * upL] = -y * log(hc) - (1 - y) * log1p(-hc);
+      dsh[r - r0] = hh - y;
+      if (blockIdx.y == 0) {
+        const double hmin = 4.9406564584124654e-324, hmax = 0.99999999999999989;  // Nextafter(0,1), Nextafter(1,0)
+        const double hc = hh < hmin ? hmin : (hh > hmax ? hmax : hh);
+        A2[(size_t)r * upL] = hh;
+        delta_out[(size_t)r * upL] = hh - y;
+        lossterm[(size_t)r * upL] = -y * log(hc) - (1 - y) * log1p(-hc);
+      }
     }
-    __syncthreads();
+  } else {
+    for (int r = r0 + (int)threadIdx.x; r < r1; r += 256) dsh[r - r0] = delta[(size_t)r * upL];
   }
+  __syncthreads();
   double acc = 0;
   if (h < up1) {
     const double w2 = W2[(size_t)h * upL];
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(1024) void mlp_bwd_hidden_kernel(const double* __re
       for (int u = 0; u < 4; ++u) {
         const int r = rb + 8 * u;
         av[u] = r < r1 ? A1[(size_t)r * up1 + h] : 0.0;
-        dl[u] = r < r1 ? delta[(size_t)r * upL] : 0.0;
+        dl[u] = r < r1 ? dsh[r - r0] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -495,11 +503,10 @@ __global__ __launch_bounds__(1024) void mlp_bwd_hidden_kernel(const double* __re
   if (part == 0 && h < up1) {
     double s = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[h + 128 * k];
+    for (int k = 0; k < 8; ++k) s += red[hl + 32 * k];
     slab[(size_t)blockIdx.x * up1 * upL + (size_t)h * upL] = s;
   }
 }
-
 
 // ---------------------------------------------------------------- weight-gradient GEMM, float64 (csrc/mfma_gemm.h
 // gemm_tn_multi_kernel's design with v_mfma_f64_16x16x4_f64):  slab[k][n] = sum over the slab's rows m of
@@ -821,7 +828,8 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   const bool fused_bwd = p->fused_fwd_done && up1_le128(p);
   if (fused_bwd) {
     const int rows = tn_rows64(p, n);
-    hipLaunchKernelGGL(mlp_bwd_hidden_kernel, dim3((unsigned)cdiv(n, rows)), dim3(1024), 0, e.stream, p->A[1].p, p->D[2].p,
+    hipLaunchKernelGGL(mlp_bwd_hidden_kernel, dim3((unsigned)cdiv(n, rows), (unsigned)cdiv(p->up[1], 32)), dim3(256),
+                       sizeof(double) * ((size_t)rows + 256), e.stream, p->A[1].p, p->D[2].p,
                        p->W.p + p->woff[1], n, rows, p->units[1], p->up[1], p->up[2], p->cfg.activation, p->D[1].p,
                        p->slabs[1].p, p->zpart.p, (int)cdiv(p->up[1], 32), p->Yb.p, p->A[2].p, p->D[2].p, p->lossterm.p);
     GOCTR_HIP(hipGetLastError());
