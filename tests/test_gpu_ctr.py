@@ -291,3 +291,41 @@ def test_modular_path_equals_fused_chain(oracle):
     os.environ.pop("GOCTR_NO_CHAIN")
     assert np.max(np.abs(res[0][0] - res[1][0])) <= 2e-5
     assert np.max(np.abs(res[0][1] - res[1][1])) <= 1e-4 and np.max(np.abs(res[0][2] - res[1][2])) <= 1e-4
+
+
+@pytest.mark.parametrize("kind,att", [(0, 0), (0, 1), (1, 0)])
+@pytest.mark.parametrize("U,T,D,Cc", [
+    (3, 5, 4, 2),        # one lane per row (LPR 1), tiny everything
+    (9, 17, 8, 11),      # LPR 2
+    (52, 50, 16, 53),    # the cfg3 shape (LPR 4)
+    (20, 70, 32, 10),    # LPR 8, T > 64: two id blocks per sample
+    (52, 50, 64, 53),    # the cfg4 shape (LPR 16)
+    (7, 12, 12, 5),      # D % 4 == 0 but not a power-of-two lane count: run-time mode kernel
+    (6, 9, 10, 4),       # D % 4 != 0: scalar-lane kernel
+    (140, 20, 16, 150),  # side-feature blocks wider than 128 columns
+])
+def test_id_mode_shape_sweep(oracle, kind, att, U, T, D, Cc):
+    """every attention-kernel instantiation (vector width, lanes per row, compile-time mode) against the oracle"""
+    from goctr_amd import capi, model as gm
+    V, rows, B = 300, 192, 64
+    rng = np.random.default_rng(U + T + D + Cc + 10 * kind + att)
+    om, dm, si = pair(oracle, kind, U, T, D, Cc, rng, att=att, scale=0.15)
+    emb = (rng.standard_normal((V, D)) * 0.5).astype(np.float32)
+    ub = rng.integers(0, V, size=(rows, T)).astype(np.int32)
+    ub[rng.random((rows, T)) < 0.25] = -1
+    ub[0, :] = -1                                                         # a sample with no behaviour at all
+    it = rng.integers(0, V, size=rows).astype(np.int32)
+    it[1] = -1                                                            # a missing candidate embedding
+    uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+    Y = (rng.random(rows) < 0.5).astype(np.float32)
+    X = oracle.assemble_rows(emb, ub, it, uf, cf)
+    tab = gm.EmbeddingTable(emb)
+    ds = gm.Dataset.ids(ub, it, uf, cf, Y)
+    y = gm.predict_dataset(dm, ds, B, emb=tab)
+    assert np.max(np.abs(y - om.predict(X, B))) <= LOGIT_TOL
+    cfg = capi.default_train_cfg(batch=B, epochs=2, early_stop=0)
+    costs = gm.train_dataset(dm, ds, cfg, emb=tab)
+    ref = om.train(X, Y, batch=B, epochs=2)
+    assert np.max(np.abs(costs - ref)) <= 5e-5
+    for name, w in (("mlp0", om.W0), ("mlp1", om.W1), ("mlp2", om.W2)):
+        assert np.max(np.abs(dm.get_weights(name) - w)) <= 2e-4 * max(1.0, np.max(np.abs(w)))
