@@ -287,7 +287,7 @@ struct goctr_w2v {
   goctr_w2v_cfg cfg{};
   int64_t V = 0;
   int64_t aux_rows = 0;
-  DevBuf<double> param, aux, sigtab, lr;
+  DevBuf<double> param, aux, sigtab, lr, snap_param, snap_aux;   // snap_*: the pass's starting point (multi-GPU exchange)
   DevBuf<long long> path_off, trained, slice_idx;
   DevBuf<int> path_nodes, doc;
   DevBuf<unsigned char> path_codes, keep;
@@ -299,12 +299,46 @@ struct goctr_w2v {
 
 namespace {
 
+// data-parallel exchange (item2vec row): every rank trains its own corpus shard on a full replica; after
+// the pass the ranks' parameter DELTAS are summed (what Hogwild's shared matrices do with the threads' updates) and
+// applied to the common starting point, so all replicas agree again:  p = p0 + sum_r (p_r - p0)
+__global__ void w2v_delta_kernel(double* cur, const double* snap, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) cur[i] -= snap[i];
+}
+__global__ void w2v_apply_kernel(double* cur, const double* snap, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) cur[i] += snap[i];
+}
+
+int exchange_deltas(goctr_w2v* w) {
+  Engine& e = engine();
+  struct Part { DevBuf<double>* cur; DevBuf<double>* snap; long long n; };
+  Part parts[2] = {{&w->param, &w->snap_param, (long long)w->V * w->cfg.dim}, {&w->aux, &w->snap_aux, (long long)w->aux_rows * w->cfg.dim}};
+  for (const Part& p : parts) {
+    if (p.n <= 0) continue;
+    hipLaunchKernelGGL(w2v_delta_kernel, dim3((unsigned)cdiv(p.n, 256)), dim3(256), 0, e.stream, p.cur->p, p.snap->p, p.n);
+    GOCTR_HIP(hipGetLastError());
+    if (comm_allreduce_f64_dev(p.cur->p, (size_t)p.n)) return -1;
+    hipLaunchKernelGGL(w2v_apply_kernel, dim3((unsigned)cdiv(p.n, 256)), dim3(256), 0, e.stream, p.cur->p, p.snap->p, p.n);
+    GOCTR_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
 int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
   Engine& e = engine();
   GOCTR_CHECK(w->n_words > 0, "goctr_w2v: no doc uploaded");
   if (w->lr.upload(lr_io, 1)) return -1;
   long long zero = 0;
   if (w->trained.upload(&zero, 1)) return -1;  // a fresh observer per iteration (word2vec.go:159-160)
+  const bool dp = e.comm_active();             // one exchange of parameter deltas per pass
+  if (dp) {
+    const size_t np = (size_t)w->V * w->cfg.dim, na = (size_t)w->aux_rows * w->cfg.dim;
+    if (w->snap_param.ensure(np, false) || (na && w->snap_aux.ensure(na, false))) return -1;
+    GOCTR_HIP(hipMemcpyAsync(w->snap_param.p, w->param.p, np * sizeof(double), hipMemcpyDeviceToDevice, e.stream));
+    if (na) GOCTR_HIP(hipMemcpyAsync(w->snap_aux.p, w->aux.p, na * sizeof(double), hipMemcpyDeviceToDevice, e.stream));
+  }
   W2vDev a{};
   a.dim = w->cfg.dim; a.window = w->cfg.window; a.optimizer = w->cfg.optimizer; a.neg = w->cfg.neg_samples;
   a.init_lr = w->cfg.init_lr; a.min_lr = w->cfg.min_lr; a.update_lr_batch = w->cfg.update_lr_batch; a.V = w->V;
@@ -331,6 +365,7 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
 #undef GOCTR_HOG
     GOCTR_HIP(hipGetLastError());
   }
+  if (dp && exchange_deltas(w)) return -1;
   GOCTR_HIP(hipStreamSynchronize(e.stream));
   return w->lr.download(lr_io, 1);
 }

@@ -90,3 +90,49 @@ def test_rank_row_offsets_make_the_dropout_mask_global(oracle):
         shard = np.array([[L.orc_dropout_keep(9, 2, 0, rank * 4 + r, c, C.c_float(0.3)) for c in range(16)]
                           for r in range(4)])
         assert np.array_equal(shard, full[rank * 4:(rank + 1) * 4])
+
+
+# ---------------------------------------------------------------- item2vec: exchange of parameter deltas
+def _w2v_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pyoracle
+    rng = np.random.default_rng(7)
+    V, n, dim = 40, 3000, 8
+    doc = rng.integers(0, V, size=n).astype(np.int32)
+    counts = np.bincount(doc, minlength=V) + 1
+    p0 = (rng.random((V, dim)) - 0.5) / dim
+    cfg = pyoracle.w2v_cfg(dim=dim, optimizer="hs")
+    paths = pyoracle.huffman_paths(counts)
+    # every rank: full replica, its own contiguous corpus shard (IndexPerThread-style split, modelutil.go:32-41)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    param, aux = p0.copy(), np.zeros((V - 1, dim))
+    pyoracle.w2v_train_slice(cfg, doc, lo, hi, None, param, aux, paths, pyoracle.sigmoid_table(), pyoracle.Lcg(1 + rank), 0.025, 0, n)
+    # the exchange libgoctr_hip.so does after a pass (csrc/w2v.hip exchange_deltas): p = p0 + sum_r (p_r - p0)
+    dparam, daux = torch.from_numpy(param - p0), torch.from_numpy(aux.copy())
+    dist.all_reduce(dparam); dist.all_reduce(daux)
+    merged_p, merged_a = p0 + dparam.numpy(), daux.numpy()
+    if rank == 0:
+        # reference for the math: both shards trained from the same start, deltas added up in one process
+        exp_p, exp_a = p0.copy(), np.zeros((V - 1, dim))
+        for r in range(world):
+            pr, ar = p0.copy(), np.zeros((V - 1, dim))
+            l2, h2 = r * n // world, (r + 1) * n // world
+            pyoracle.w2v_train_slice(cfg, doc, l2, h2, None, pr, ar, paths, pyoracle.sigmoid_table(), pyoracle.Lcg(1 + r), 0.025, 0, n)
+            exp_p += pr - p0
+            exp_a += ar
+        np.save(out, np.array([np.max(np.abs(merged_p - exp_p)), np.max(np.abs(merged_a - exp_a)),
+                               np.max(np.abs(merged_p - p0))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_item2vec_delta_exchange_world2(tmp_path):
+    out = str(tmp_path / "w2v_dp.npy")
+    mp.spawn(_w2v_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ep, ea, moved = np.load(out)
+    assert ep <= 1e-15 and ea <= 1e-15      # all-reduce(sum) of the deltas == adding the shards' deltas in one process
+    assert moved > 1e-4                     # and the replicas really moved

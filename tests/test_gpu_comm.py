@@ -60,3 +60,44 @@ def test_one_rank_communicator_equals_fused_path(tmp_path, graph):
     got = run(tmp_path, comm=True, graph=graph)
     assert np.isfinite(ref).all() and np.abs(ref).max() > 0
     assert np.array_equal(ref, got)
+
+
+W2V_SCRIPT = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %(root)r)
+from goctr_amd import capi, embedding as ge
+capi.init(0)
+L = capi.load()
+if %(comm)d:
+    idbuf = (C.c_uint8 * 128)()
+    capi.check(L.goctr_comm_unique_id(idbuf))
+    capi.check(L.goctr_comm_init(C.c_int(0), C.c_int(1), idbuf))
+rng = np.random.default_rng(3)
+V, n, dim = 60, 4000, 16
+p = 1.0 / np.arange(1, V + 1); p /= p.sum()
+doc = rng.choice(V, size=n, p=p).astype(np.int32)
+counts = np.bincount(doc, minlength=V) + 1
+p0 = (rng.random((V, dim)) - 0.5) / dim
+m = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=True)
+m.create(counts, p0)
+lr = m.train_pass(doc, n, None, lr=0.025)
+lr = m.train_pass(doc, n, None, lr=lr)
+np.save(%(out)r, np.concatenate([m.get_param().ravel(), m.get_aux().ravel(), [lr]]))
+'''
+
+
+def test_item2vec_delta_exchange_one_rank(tmp_path):
+    """item2vec's data-parallel step (snapshot, pass, all-reduce of the parameter deltas, p = p0 + sum) with a one-rank
+    RCCL communicator: p0 + (p - p0) must give back the single-GPU result (deterministic mode) up to the rounding of
+    that one subtraction / addition"""
+    res = []
+    for comm in (0, 1):
+        out = str(tmp_path / f"w2v_{comm}.npy")
+        env = dict(os.environ)
+        env["GOCTR_FORCE_COMM"] = str(comm)
+        r = subprocess.run([sys.executable, "-c", W2V_SCRIPT % dict(root=ROOT, comm=comm, out=out)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    assert np.isfinite(res[0]).all()
+    assert np.max(np.abs(res[0] - res[1])) <= 1e-12          # (the rounding of p0 + (p - p0), carried through the second pass)
