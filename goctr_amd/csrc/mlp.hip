@@ -158,7 +158,11 @@ struct MlpReduceArgs {
   const MlpState* st;         // the step's frozen state (mlp_gather_kernel / mlp_copy_f64_kernel)
   MlpState* st_master;        // advanced by the loss block when `advance`
   double* sumsq_part;         // [2][nblk] per-block sums of W^2 (coefs only), parity = step counter & 1
-  int mode;                   // 0: reduce (+ update) and, in block nblk, the loss; 2: only recompute sumsq_part
+  int mode;                   // 0: reduce (+ update) and, in block nblk, the loss; 2: only recompute sumsq_part;
+                              // 3 / 1: data-parallel first half (slab sums -> G, local loss-term sum -> G[nflat]) and second
+                              // half (G holds the all-reduced gradient: update, loss, state advance)
+  int n_local;                // rows of this rank's batch (= n when world == 1)
+  int world;                  // ranks sharing the step (n is the GLOBAL batch then); G[nflat] carries the loss-term sum
   int nblk;                   // blocks that own parameters; block nblk is the loss block
   const double* lossterm; int upL, no; double* ring; int advance;
   double* W0img; int up1_img; // LDS image of layer 0 for the fused forward (or null)
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     // loss = sum(terms)/n + 0.5*alpha*sum(W^2)/n (basemlp64.go:359-361) over the weights the forward pass used: their
     // squares were summed per block by the launch that wrote them (parity `par`); closes the step
     double s = 0;
-    const int real = a.n * a.no;      // only the `no` real columns of each padded row carry a term
+    const int real = a.mode == 1 ? 0 : a.n_local * a.no;      // only the `no` real columns of each padded row carry a term
     for (int i0 = threadIdx.x; i0 < real; i0 += 256 * 16) {
       double v[16];
 #pragma unroll
@@ -188,8 +192,13 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-    const double lsum = red[0];
+    double lsum = red[0];
     __syncthreads();
+    if (a.mode == 3) {                         // data-parallel first half: the local term sum travels with the gradient
+      if (threadIdx.x == 0) a.G[a.nflat] = lsum;
+      return;
+    }
+    if (a.mode == 1) lsum = a.G[a.nflat];
     s = 0;
     for (int i = threadIdx.x; i < a.nblk; i += 256) s += a.sumsq_part[(size_t)par * a.nblk + i];
     red[threadIdx.x] = s;
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     const bool is_w = r < d.fi && c < d.fo, is_b = r == d.fi && c < d.fo;
     if (is_w || is_b) {
       double s = 0;
-      {   // same left-to-right order as a plain loop, but 8 loads in flight at a time
+      if (a.mode != 1) {   // same left-to-right order as a plain loop, but 8 loads in flight at a time
         const size_t sstr = (size_t)d.upi * d.upo;
         int j = 0;
         for (; j + 8 <= d.nslabs; j += 8) {
@@ -243,9 +252,14 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
         for (; j < d.nslabs; ++j) s += d.slabs[(size_t)j * sstr + e];
       }
       const double w = a.W[idx];
-      double g = s * (1 / (double)a.n);                       // gemm alpha = 1/n (and mean for the bias row)
-      if (is_w) g += (a.alpha / (double)a.n) * w;
-      a.G[idx] = g;
+      double g;
+      if (a.mode == 1) {
+        g = a.G[idx];                                         // summed over the ranks by the all-reduce
+      } else {
+        g = s * (1 / (double)a.n);                            // gemm alpha = 1/n (and mean for the bias row)
+        if (is_w) g += (a.alpha / (double)a.n) * w / (double)a.world;   // every rank adds its share of the penalty term
+        a.G[idx] = g;
+      }
       if (a.do_update) {
         const long long pidx = d.poff + (is_b ? c : (long long)d.fo + (long long)r * d.fo + c);
         double wn = w;
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
         if (is_w) { d.WT[(size_t)c * d.upi + r] = wn; sq = wn * wn; }   // squares of the NEW weights: next step's penalty
         if (l == 0 && a.W0img) a.W0img[mlp_img_index(r, c, d.upi)] = wn;
       }
-    } else {
+    } else if (a.mode != 1) {
       a.G[idx] = 0;
     }
   }
@@ -856,7 +870,22 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   a.st = p->st_step.p; a.st_master = p->st.p; a.sumsq_part = p->sumsq_part.p;
   a.W0img = p->fused_ok() ? p->W0img.p : nullptr; a.up1_img = p->up[1];
   const int nblk = (int)cdiv(p->nflat, 256);
-  a.mode = 0; a.nblk = nblk; a.lossterm = p->lossterm.p; a.upL = upL; a.no = no; a.ring = p->ring.p; a.advance = advance ? 1 : 0;
+  a.nblk = nblk; a.lossterm = p->lossterm.p; a.upL = upL; a.no = no; a.ring = p->ring.p; a.advance = advance ? 1 : 0;
+  a.n_local = n; a.world = 1;
+  if (e.comm_active() && do_update) {
+    // data-parallel step: rows sharded over the ranks (each rank's resident rows are its shard), local slab sums with the
+    // GLOBAL batch size in the 1/n factors, ONE f64 all-reduce of [G | loss-term sum], then the identical update everywhere
+    a.world = e.world; a.n = n * e.world;
+    a.mode = 3; a.do_update = 0;
+    hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk + 1), dim3(256), 0, e.stream, a);
+    GOCTR_HIP(hipGetLastError());
+    if (comm_allreduce_f64_dev(p->G.p, (size_t)p->nflat + 1)) return -1;
+    a.mode = 1; a.do_update = 1;
+    hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk + 1), dim3(256), 0, e.stream, a);
+    GOCTR_HIP(hipGetLastError());
+    return 0;
+  }
+  a.mode = 0;
   hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk + 1), dim3(256), 0, e.stream, a);   // block nblk: loss + state
   GOCTR_HIP(hipGetLastError());
   return 0;
@@ -951,7 +980,7 @@ int goctr_mlp_create(const goctr_mlp_cfg* cfg, goctr_mlp** out) {
     po += (long long)(1 + p->units[l]) * p->units[l + 1];
   }
   p->nflat = wo; p->nparams = po;
-  if (p->W.alloc(wo) || p->G.alloc(wo) || p->Mo.alloc(wo) || p->Vo.alloc(wo) || p->Vel.alloc(wo)) return -1;
+  if (p->W.alloc(wo) || p->G.alloc(wo + 1) || p->Mo.alloc(wo) || p->Vo.alloc(wo) || p->Vel.alloc(wo)) return -1;
   for (int l = 0; l < p->nl; ++l) {
     if (p->WT[l].alloc((size_t)p->up[l] * p->up[l + 1])) return -1;
     if (p->bn[l].alloc(p->up[l + 1])) return -1;
@@ -1064,7 +1093,7 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
   if (set_mstate(p, s.t, first_batch % nb, nb, 0)) return -1;
   // every per-step scalar lives in the device MlpState, so one captured step replays for all of them
   Engine& e = engine();
-  const bool use_graph = !e.prof && env_int_mlp("GOCTR_NO_GRAPH", 0) == 0 && n_steps > 1;
+  const bool use_graph = !e.prof && !e.comm_active() && env_int_mlp("GOCTR_NO_GRAPH", 0) == 0 && n_steps > 1;
   if (use_graph) {
     if (ensure_ws(p, p->cfg.batch)) return -1;                 // no allocation inside the capture
     if (p->fused_ok() && p->zpart.ensure((size_t)cdiv(p->up[1], 32) * p->cfg.batch, false)) return -1;

@@ -136,3 +136,41 @@ def test_item2vec_delta_exchange_world2(tmp_path):
     ep, ea, moved = np.load(out)
     assert ep <= 1e-15 and ea <= 1e-15      # all-reduce(sum) of the deltas == adding the shards' deltas in one process
     assert moved > 1e-4                     # and the replicas really moved
+
+
+# ---------------------------------------------------------------- sklearn-port MLP: sharded rows == full batch
+def _mlp_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pyoracle
+    rng = np.random.default_rng(5)
+    F, H, n = 9, 6, 48
+    X = rng.random((n, F)); Y = (rng.random((n, 1)) < 0.5).astype(np.float64)
+    cfg = pyoracle.mlp_cfg([F, H, 1], "relu", alpha=1e-3)
+    theta = rng.standard_normal(pyoracle.mlp_nparams(cfg)) * 0.3
+    nloc = n // world
+    Xs, Ys = X[rank * nloc:(rank + 1) * nloc], Y[rank * nloc:(rank + 1) * nloc]
+    alpha = 1e-3
+    cfg0 = pyoracle.mlp_cfg([F, H, 1], "relu", alpha=0.0)
+    _, d_loc = pyoracle.mlp_loss_grad(cfg0, theta.copy(), Xs, Ys)        # data term only: s_r / nloc
+    coef = np.zeros(theta.size, bool)                                    # packed order per layer: [intercepts | coefs]
+    coef[H:H + F * H] = True
+    coef[H + F * H + 1:] = True
+    # what csrc/mlp.hip exchanges: the rank's slab sums with the GLOBAL 1/N plus its 1/world share of the penalty gradient
+    t = torch.from_numpy(d_loc * (nloc / n) + np.where(coef, (alpha / n) * theta / world, 0.0))
+    dist.all_reduce(t)
+    if rank == 0:
+        loss_full, g_full = pyoracle.mlp_loss_grad(cfg, theta.copy(), X, Y)
+        np.save(out, np.array([np.max(np.abs(t.numpy() - g_full)), np.max(np.abs(g_full))]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mlp_sharded_gradient_world2(tmp_path):
+    out = str(tmp_path / "mlp_dp.npy")
+    mp.spawn(_mlp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    err, scale = np.load(out)
+    assert scale > 1e-3 and err <= 1e-14 * max(1.0, scale)

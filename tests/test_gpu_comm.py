@@ -101,3 +101,43 @@ def test_item2vec_delta_exchange_one_rank(tmp_path):
         res.append(np.load(out))
     assert np.isfinite(res[0]).all()
     assert np.max(np.abs(res[0] - res[1])) <= 1e-12          # (the rounding of p0 + (p - p0), carried through the second pass)
+
+
+MLP_SCRIPT = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %(root)r)
+from goctr_amd import capi, mlp as gmlp
+capi.init(0)
+L = capi.load()
+if %(comm)d:
+    idbuf = (C.c_uint8 * 128)()
+    capi.check(L.goctr_comm_unique_id(idbuf))
+    capi.check(L.goctr_comm_init(C.c_int(0), C.c_int(1), idbuf))
+rng = np.random.default_rng(4)
+F, H, B, rows = 37, 20, 128, 1024
+X = rng.random((rows, F), dtype=np.float32)
+y = (X[:, 0] + X[:, 1] > 1.0).astype(np.float32)
+clf = gmlp.MLPClassifier([H], "relu", "adam", 1e-4)
+clf.BatchSize = B
+units = [F, H, 1]
+clf.create(units, B, clf.init_params(units, np.random.default_rng(1)))
+clf.upload(X, y)
+clf.train_steps(11)
+capi.sync()
+np.save(%(out)r, clf.get_params())
+'''
+
+
+def test_mlp_data_parallel_step_one_rank(tmp_path):
+    """the sklearn-port MLP's split step (slab sums -> f64 all-reduce of [G | loss-term sum] -> update) with a one-rank RCCL
+    communicator must reproduce the fused single-GPU step bit for bit"""
+    res = []
+    for comm in (0, 1):
+        out = str(tmp_path / f"mlp_{comm}.npy")
+        env = dict(os.environ)
+        env["GOCTR_FORCE_COMM"] = str(comm)
+        r = subprocess.run([sys.executable, "-c", MLP_SCRIPT % dict(root=ROOT, comm=comm, out=out)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    assert np.isfinite(res[0]).all() and np.array_equal(res[0], res[1])
