@@ -236,7 +236,7 @@ int init_kernel_attrs() {
                           allow_big_lds(gemm_nn_kernel<float, E, 4>) || allow_big_lds(gemm_nn_kernel<float, E, 7>))
   if (GOCTR_NN_ATTR(EpiSigDrop) || GOCTR_NN_ATTR(EpiOut) || GOCTR_NN_ATTR(EpiDSig) || GOCTR_NN_ATTR(EpiStore) ||
       allow_big_lds(ctr_chain_kernel<7, 5, 0>) || allow_big_lds(ctr_chain_kernel<7, 5, 1>) ||
-      allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
+      allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(ctr_fwd16_kernel<4, 5>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>)) return -1;
   done = true;
   return 0;
@@ -362,6 +362,10 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
   const dim3 grid((unsigned)cdiv(B, 32));
   const size_t lds = chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p);
   const int dmode = (a.d0.mode || a.d1.mode) ? o.drop_mode : 0;
+  // forward only and too few rows to give every CU a 32-row workgroup: 16-row workgroups, H1 split over 4 wavefronts
+  if (!o.train && cdiv(B, 32) < e.compute_units && env_int("GOCTR_NO_FWD16", 0) == 0)
+    hipLaunchKernelGGL((ctr_fwd16_kernel<4, 5>), dim3((unsigned)cdiv(B, 16)), dim3(512), lds, e.active, a);
+  else
   if (dmode == 0) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 0>), grid, dim3(512), lds, e.active, a);
   else if (dmode == 1) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 1>), grid, dim3(512), lds, e.active, a);
   else hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 2>), grid, dim3(512), lds, e.active, a);

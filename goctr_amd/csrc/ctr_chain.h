@@ -418,4 +418,123 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_kernel(ChainArgs a) {
   flush_stamps();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward-only variant for small batches (the recommend / predict path, PredBatchSize = 4096): 16 batch rows per
+// workgroup instead of 32, so 4096 rows still put one workgroup on every CU, and the 13 H1 tiles are split over FOUR
+// compute wavefronts (4 + 3 + 3 + 3): each wavefront issues 144 + 80 MFMAs instead of 252 + 140.  The four partial
+// Z1 are exchanged through LDS and added in wavefront order by every wavefront.  Same operands, staging and loader
+// wavefronts as ctr_chain_kernel; no dropout at inference (the reference's predict graph has p = 0, quirk Q1).
+template <int NT0Q, int NT1>
+__global__ __launch_bounds__(512, 1) void ctr_fwd16_kernel(ChainArgs a) {
+  typedef chain_f4 f4;
+  extern __shared__ __attribute__((aligned(16))) float chain_smem[];
+  float* const bufP = chain_smem;
+  float* const bufQ = chain_smem + a.buf_floats;
+  float* const xch = chain_smem + 2 * a.buf_floats;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  const int H1p = a.H1p, H2p = a.H2p, Ip = a.Ip;
+  const int kph0 = Ip < CHAIN_KPH0 ? Ip : CHAIN_KPH0;
+  if (wave >= 4) {                         // loader wavefronts: the barrier sequence mirrors the compute wavefronts'
+    ChainStager stg;
+    const int lw = wave - 4;
+    stg.begin(a.W0i, bufP, kph0 * H1p, lw);
+    stg.drain(lane);
+    __syncthreads();
+    int lpar = 0;
+    for (int k0 = 0; k0 < Ip; k0 += CHAIN_KPH0) {
+      float* oth = lpar ? bufP : bufQ;
+      const int k1 = k0 + CHAIN_KPH0;
+      if (k1 < Ip) stg.begin(a.W0i + (size_t)k1 * H1p, oth, (Ip - k1 < CHAIN_KPH0 ? Ip - k1 : CHAIN_KPH0) * H1p, lw);
+      else stg.begin(a.W1i, oth, H1p * H2p, lw);
+      stg.drain(lane);
+      lpar ^= 1;
+      __syncthreads();
+    }
+    __syncthreads();                       // Z1 exchange barrier
+    return;
+  }
+  const int row = blockIdx.x * 16 + i;
+  const bool vrow = row < a.B;
+  const int rowc = vrow ? row : a.B - 1;
+  const int NT0 = H1p >> 4;
+  // tiles of this wavefront: 4,3,3,3 of 13 (or 4,4,3,3 of 14): wave w starts at min(w * NT0Q, ...) balanced from the front
+  const int base = NT0 / 4, extra = NT0 - 4 * base;                   // `extra` wavefronts own base + 1 tiles
+  const int t0 = wave * base + (wave < extra ? wave : extra);
+  const int ntl = base + (wave < extra ? 1 : 0);
+  const float* hp = a.h0 + (size_t)rowc * Ip + 4 * q;
+  f4 hall[CHAIN_HV];
+#pragma unroll
+  for (int c = 0; c < CHAIN_HV; ++c)
+    if (c * 16 < Ip) hall[c] = *reinterpret_cast<const f4*>(hp + c * 16);
+  f4 w2v[NT1];
+#pragma unroll
+  for (int u = 0; u < NT1; ++u) w2v[u] = *reinterpret_cast<const f4*>(a.w2 + u * 16 + 4 * q);
+  f4 acc0[NT0Q];
+#pragma unroll
+  for (int t = 0; t < NT0Q; ++t) acc0[t] = f4{0, 0, 0, 0};
+  int par = 0;
+  __syncthreads();
+#pragma unroll
+  for (int ph = 0; ph < CHAIN_HV * 16 / CHAIN_KPH0; ++ph) {
+    const int k0 = ph * CHAIN_KPH0;
+    if (k0 < Ip) {
+      const int kph = Ip - k0 < CHAIN_KPH0 ? Ip - k0 : CHAIN_KPH0;
+      float* cur = par ? bufQ : bufP;
+      const float* wp = cur + ((size_t)q * H1p + t0 * 16 + i) * 4;    // (a wavefront with one tile less multiplies a throw-away one)
+      chain_mma_phase<NT0Q, CHAIN_KPH0 / 16>(acc0, wp, 16 * H1p, kph >> 4,
+                                             [&](int c) { return hall[ph * (CHAIN_KPH0 / 16) + c < CHAIN_HV ? ph * (CHAIN_KPH0 / 16) + c : CHAIN_HV - 1]; });
+      par ^= 1;
+      __syncthreads();
+    }
+  }
+  float* const bufW1 = par ? bufQ : bufP;
+#pragma unroll
+  for (int t = 0; t < NT0Q; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = (t0 + t) * 16 + 4 * q + r;
+      const float sg = chain_sigm(acc0[t][r]);
+      acc0[t][r] = (n < a.H1 && t < ntl) ? sg : 0.0f;
+    }
+  f4 acc1[NT1];
+#pragma unroll
+  for (int u = 0; u < NT1; ++u) acc1[u] = f4{0, 0, 0, 0};
+  {
+    const float* wp = bufW1 + ((size_t)(t0 * 4 + q) * H2p + i) * 4;
+    chain_mma_phase<NT1, NT0Q>(acc1, wp, 16 * H2p, ntl, [&](int t) { return acc0[t]; });
+  }
+  constexpr int XS = NT1 * 4;
+  {
+    float* xw = xch + (wave * XS) * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < NT1; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xw[(u * 4 + r) * 64] = acc1[u][r];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NT1; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float z = 0.f;                     // fixed wavefront order: every wavefront computes the same bits
+#pragma unroll
+        for (int w = 0; w < 4; ++w) z += xch[(w * XS + u * 4 + r) * 64 + lane];
+        acc1[u][r] = z;
+      }
+  }
+  float part = 0.f;
+#pragma unroll
+  for (int u = 0; u < NT1; ++u)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = u * 16 + 4 * q + r;
+      const float sg = chain_sigm(acc1[u][r]);
+      part += (n < a.H2 ? sg : 0.0f) * w2v[u][r];
+    }
+  float z2 = part + __shfl_xor(part, 16, 64);
+  z2 += __shfl_xor(z2, 32, 64);
+  if (wave == 0 && q == 0 && vrow) a.yhat[row] = sigm_out(z2);
+}
+
 }  // namespace goctr
