@@ -823,6 +823,73 @@ int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n
   return download_padded(m, m->W.p, tensor_id, host, n);
 }
 
+// Adam moments of one tensor in the tensor's own (unpadded, row-major) shape: what a checkpoint needs next to the
+// weights to resume `model.Train` where it stopped.  which = 0: first moment, 1: second moment.
+int upload_padded_flat(goctr_model* m, float* flat_dev, int tensor_id, const float* host, size_t n) {
+  const goctr_ctr_cfg& c = m->cfg;
+  std::vector<float> buf;
+  size_t off = 0;
+  switch (tensor_id) {
+    case GOCTR_W0:
+      GOCTR_CHECK(n == (size_t)m->I * c.H1, "W0 expects %d floats, got %zu", m->I * c.H1, n);
+      buf.assign((size_t)m->Ip * m->H1p, 0.f);
+      for (int r = 0; r < m->I; ++r) for (int k = 0; k < c.H1; ++k) buf[(size_t)r * m->H1p + k] = host[(size_t)r * c.H1 + k];
+      break;
+    case GOCTR_W1:
+      GOCTR_CHECK(n == (size_t)c.H1 * c.H2, "W1 expects %d floats, got %zu", c.H1 * c.H2, n);
+      buf.assign((size_t)m->H1p * m->H2p, 0.f); off = m->off1;
+      for (int r = 0; r < c.H1; ++r) for (int k = 0; k < c.H2; ++k) buf[(size_t)r * m->H2p + k] = host[(size_t)r * c.H2 + k];
+      break;
+    case GOCTR_W2:
+      GOCTR_CHECK(n == (size_t)c.H2, "W2 expects %d floats, got %zu", c.H2, n);
+      buf.assign((size_t)m->H2p * 16, 0.f); off = m->off2;
+      for (int r = 0; r < c.H2; ++r) buf[(size_t)r * 16] = host[r];
+      break;
+    case GOCTR_ATT0:
+      GOCTR_CHECK(n == (size_t)c.T, "att0 expects %d floats, got %zu", c.T, n);
+      buf.assign((size_t)m->Tp, 0.f); off = m->offa;
+      for (int t = 0; t < c.T; ++t) buf[t] = host[t];
+      break;
+    default:
+      GOCTR_CHECK(false, "unknown tensor id %d", tensor_id);
+  }
+  GOCTR_HIP(hipMemcpyAsync(flat_dev + off, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, engine().stream));
+  GOCTR_HIP(hipStreamSynchronize(engine().stream));
+  return 0;
+}
+
+int goctr_model_get_moments(goctr_model* m, int tensor_id, int which, float* host, size_t n) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && host && (which == 0 || which == 1), "goctr_model_get_moments: bad argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  return download_padded(m, which ? m->Vo.p : m->Mo.p, tensor_id, host, n);
+}
+
+int goctr_model_set_moments(goctr_model* m, int tensor_id, int which, const float* host, size_t n) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && host && (which == 0 || which == 1), "goctr_model_set_moments: bad argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  return upload_padded_flat(m, which ? m->Vo.p : m->Mo.p, tensor_id, host, n);
+}
+
+// Global step counter: Adam's iteration number and the dropout stream position.
+int goctr_model_get_step(goctr_model* m, uint32_t* step) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && step, "goctr_model_get_step: null argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  StepState s;
+  if (get_state(m, &s)) return -1;
+  *step = s.gstep;
+  return 0;
+}
+
+int goctr_model_set_step(goctr_model* m, uint32_t step) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m, "goctr_model_set_step: null argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  return set_state(m, step, 0, 0, 1);
+}
+
 int goctr_model_reset_optimizer(goctr_model* m) {
   if (require_engine()) return -1;
   std::lock_guard<std::mutex> lk(m->mu);

@@ -28,7 +28,7 @@ using namespace goctr;
 namespace {
 
 struct W2vDev {
-  int dim, window, optimizer, neg;
+  int dim, window, optimizer, neg, model;
   double init_lr, min_lr;
   long long update_lr_batch;
   long long V;
@@ -62,6 +62,72 @@ __device__ __forceinline__ double seq_sum(double v, int dim) {
   return s;
 }
 
+// One optimizer call (optimizer.go:52-91 / :107-129) for the lane that owns component l of the vectors:
+// ctx = that component of the input vector, tmp accumulates the component of the input's update.
+// `sum` is the inner-product reduction (sequential for the deterministic mode, butterfly for Hogwild).
+template <class Sum>
+__device__ __forceinline__ void w2v_optim(const W2vDev& a, const double* tab, int id, double lr, double ctx, double& tmp,
+                                          unsigned long long& next, bool act, int l, Sum sum) {
+  const int dim = a.dim;
+  if (a.optimizer == 0) {
+    for (long long i = a.path_off[id]; i < a.path_off[id + 1]; ++i) {
+      double* pvp = a.aux + (long long)a.path_nodes[i] * dim + l;
+      double pv = act ? *pvp : 0.0;
+      const double inner = sum(ctx * pv);
+      if (inner <= -6.0 || inner >= 6.0) break;  // quirk Q13: `return`
+      const double g = (1.0 - (double)a.path_codes[i] - sig_lookup(tab, inner)) * lr;
+      tmp += g * pv;
+      pv += g * ctx;
+      if (act) *pvp = pv;
+    }
+  } else {
+    for (int n = -1; n < a.neg; ++n) {
+      int label, picked;
+      if (n == -1) { label = 1; picked = id; }
+      else {
+        label = 0;
+        picked = lcg_next(next, (int)a.V);
+        if (id == picked) continue;
+      }
+      double* rp = a.aux + (long long)picked * dim + l;
+      double rnd = act ? *rp : 0.0;
+      const double inner = sum(rnd * ctx);
+      double g;
+      if (inner <= -6.0) g = ((double)(label - 0)) * lr;
+      else if (inner >= 6.0) g = ((double)(label - 1)) * lr;
+      else g = ((double)label - sig_lookup(tab, inner)) * lr;
+      tmp += g * rnd;
+      rnd += g * ctx;
+      if (act) *rp = rnd;
+    }
+  }
+}
+
+// cbow.trainOne (model.go:96-148): aggregate the window's vectors, one optimizer call on the aggregate, add its
+// update to every window vector.  The window shrink is drawn twice (once in the aggregate pass, once in the update
+// pass — `dowith` calls NextRandom each time), so the two passes may cover different windows.
+template <class Sum>
+__device__ __forceinline__ void w2v_cbow_one(const W2vDev& a, const double* tab, const int* doc, long long len, long long pos,
+                                             double lr, unsigned long long& next, bool act, int l, Sum sum) {
+  const int dim = a.dim, win = a.window;
+  double agg = 0.0, tmp = 0.0;
+  int del = lcg_next(next, win);
+  for (int w = del; w < win * 2 + 1 - del; ++w) {
+    if (w == win) continue;
+    const long long c = pos - win + w;
+    if (c < 0 || c >= len) continue;
+    if (act) agg += a.param[(long long)doc[c] * dim + l];
+  }
+  w2v_optim(a, tab, doc[pos], lr, agg, tmp, next, act, l, sum);
+  del = lcg_next(next, win);
+  for (int w = del; w < win * 2 + 1 - del; ++w) {
+    if (w == win) continue;
+    const long long c = pos - win + w;
+    if (c < 0 || c >= len) continue;
+    if (act) a.param[(long long)doc[c] * dim + l] += tmp;   // a word twice in the window gets the update twice
+  }
+}
+
 // ---- deterministic single-stream pass: one block of 64 threads
 __global__ __launch_bounds__(64) void w2v_deterministic_kernel(W2vDev a) {
   __shared__ double tab[1000];
@@ -75,7 +141,12 @@ __global__ __launch_bounds__(64) void w2v_deterministic_kernel(W2vDev a) {
   long long cnt = *a.trained;
   for (long long pos = 0; pos < a.n_words; ++pos) {
     const int id = a.doc[pos];
-    if (!a.keep || a.keep[pos]) {
+    if (a.model == 1) {
+      if (!a.keep || a.keep[pos]) {
+        w2v_cbow_one(a, tab, a.doc, a.n_words, pos, lr, next, act, lane, [&](double v) { return seq_sum(v, dim); });
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      }
+    } else if (!a.keep || a.keep[pos]) {
       const int del = lcg_next(next, win);  // model.go:59
       for (int w = del; w < win * 2 + 1 - del; ++w) {
         if (w == win) continue;
@@ -159,7 +230,10 @@ __global__ __launch_bounds__(256) void w2v_hogwild_kernel(W2vDev a, int streams,
   const long long len = hi - lo;
   for (long long pos = 0; pos < len; ++pos) {
     const int id = doc[pos];
-    if (!a.keep || a.keep[lo + pos]) {
+    if (a.model == 1) {
+      if (!a.keep || a.keep[lo + pos])
+        w2v_cbow_one(a, tab, doc, len, pos, lr, next, act, l, [&](double v) { return group_sum64<GS>(v); });
+    } else if (!a.keep || a.keep[lo + pos]) {
       const int del = lcg_next(next, win);
       for (int w = del; w < win * 2 + 1 - del; ++w) {
         if (w == win) continue;
@@ -340,7 +414,7 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     if (na) GOCTR_HIP(hipMemcpyAsync(w->snap_aux.p, w->aux.p, na * sizeof(double), hipMemcpyDeviceToDevice, e.stream));
   }
   W2vDev a{};
-  a.dim = w->cfg.dim; a.window = w->cfg.window; a.optimizer = w->cfg.optimizer; a.neg = w->cfg.neg_samples;
+  a.dim = w->cfg.dim; a.window = w->cfg.window; a.optimizer = w->cfg.optimizer; a.neg = w->cfg.neg_samples; a.model = w->cfg.model;
   a.init_lr = w->cfg.init_lr; a.min_lr = w->cfg.min_lr; a.update_lr_batch = w->cfg.update_lr_batch; a.V = w->V;
   a.param = w->param.p; a.aux = w->aux.p; a.path_off = w->path_off.p; a.path_nodes = w->path_nodes.p;
   a.path_codes = w->path_codes.p; a.sigtab = w->sigtab.p; a.doc = w->doc.p; a.keep = w->has_keep ? w->keep.p : nullptr;
@@ -386,7 +460,7 @@ int goctr_w2v_create(const goctr_w2v_cfg* cfg, int64_t V, const int64_t* counts,
   GOCTR_CHECK(cfg && counts && out && V > 0, "goctr_w2v_create: bad arguments");
   GOCTR_CHECK(cfg->dim > 0 && cfg->dim <= 64, "goctr_w2v: dim %d not in 1..64", cfg->dim);
   GOCTR_CHECK(cfg->window > 0 && cfg->max_depth > 0 && cfg->update_lr_batch > 0, "goctr_w2v: bad options");
-  GOCTR_CHECK(cfg->model == 0, "goctr_w2v: only skip-gram has a device path (TrainEmbedding hard-codes it, wordemb.go:12)");
+  GOCTR_CHECK(cfg->model == 0 || cfg->model == 1, "goctr_w2v: model must be skip-gram (0) or cbow (1)");
   GOCTR_CHECK(cfg->optimizer == 0 || cfg->optimizer == 1, "goctr_w2v: optimizer must be hs (0) or ns (1)");
   std::unique_ptr<goctr_w2v> w(new goctr_w2v);
   w->cfg = *cfg; w->V = V;

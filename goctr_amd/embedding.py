@@ -40,13 +40,15 @@ class Word2Vec:
     """embedding/model.Model (model/model.go:24-31) backed by the device engine."""
 
     def __init__(self, window=5, dim=16, iter=1, optimizer="hs", min_count=5, max_count=-1, init_lr=0.025,
-                 subsample_threshold=1e-3, deterministic=False, streams=8192, update_lr_batch=100000, rng=None):
+                 subsample_threshold=1e-3, deterministic=False, streams=8192, update_lr_batch=100000, rng=None,
+                 model="skipgram"):
         # options.go:38-58 defaults; wordemb.go:10-18 fixes SkipGram + HS + DocInMemory
         self.window, self.dim, self.iter, self.optimizer = window, dim, iter, optimizer
         self.min_count, self.max_count, self.init_lr = min_count, max_count, init_lr
         self.threshold = subsample_threshold
         self.deterministic, self.streams = deterministic, streams
         self.update_lr_batch = update_lr_batch
+        self.model = model                                                  # options.go ModelType: skipgram | cbow
         self.rng = rng or np.random.default_rng()
         self.dic = Dictionary()
         self.idoc = []
@@ -72,6 +74,7 @@ class Word2Vec:
         c = capi.W2vCfg()
         capi.load().goctr_w2v_cfg_default(C.byref(c))
         c.dim, c.window, c.optimizer = self.dim, self.window, 0 if self.optimizer == "hs" else 1
+        c.model = 0 if self.model == "skipgram" else 1
         c.init_lr, c.min_lr = self.init_lr, self.init_lr * 1.0e-4           # options.go:42,49
         c.update_lr_batch = self.update_lr_batch
         c.deterministic, c.streams = int(self.deterministic), self.streams

@@ -74,6 +74,29 @@ class _CtrNet:
                                                        C.c_size_t(a.size)))
         return a.reshape(shp)
 
+    # --- optimizer state (checkpoint / resume) -----------------------------------
+    def get_moments(self, name, which):
+        shp = self._shape(name)
+        a = np.empty(int(np.prod(shp)), np.float32)
+        capi.check(capi.load().goctr_model_get_moments(self._h, C.c_int(_TENSORS[name]), C.c_int(which),
+                                                       capi.ptr(a, C.c_float), C.c_size_t(a.size)))
+        return a.reshape(shp)
+
+    def set_moments(self, name, which, arr):
+        a = capi.f32(arr).ravel()
+        capi.check(capi.load().goctr_model_set_moments(self._h, C.c_int(_TENSORS[name]), C.c_int(which),
+                                                       capi.ptr(a, C.c_float), C.c_size_t(a.size)))
+
+    @property
+    def step(self):
+        v = C.c_uint32()
+        capi.check(capi.load().goctr_model_get_step(self._h, C.byref(v)))
+        return int(v.value)
+
+    @step.setter
+    def step(self, v):
+        capi.check(capi.load().goctr_model_set_step(self._h, C.c_uint32(int(v))))
+
     def init_gaussian(self, rng):
         """G.Gaussian(0, 1) weights, att0 = 1 (din.go:181-191; dnn.go:125-127)."""
         for n in ("mlp0", "mlp1", "mlp2"):
@@ -82,12 +105,19 @@ class _CtrNet:
             self.set_weights("att0", np.ones(self._shape("att0"), np.float32))
         return self
 
-    def Marshal(self) -> bytes:
-        """din.go:62-80 / dnn.go:49-61: the dinModel / mlpModel JSON layout."""
+    def Marshal(self, optimizer=False) -> bytes:
+        """din.go:62-80 / dnn.go:49-61: the dinModel / mlpModel JSON layout.  optimizer=True adds the keys a resume
+        needs and the reference's JSON lacks ("adamStep", "<tensor>_m", "<tensor>_v"); Go's json.Unmarshal ignores
+        unknown keys, so the file stays loadable by NewDinNetFromJson / NewYoutubeDnnFromJson there."""
         d = {"uProfileDim": self.uProfileDim, "uBehaviorSize": self.uBehaviorSize, "uBehaviorDim": self.uBehaviorDim,
              "iFeatureDim": self.iFeatureDim, "cFeatureDim": self.cFeatureDim}
         for n in self.Learnable():
             d[n] = [float(x) for x in self.get_weights(n).ravel()]
+        if optimizer:
+            d["adamStep"] = self.step
+            for n in self.Learnable():
+                d[n + "_m"] = [float(x) for x in self.get_moments(n, 0).ravel()]
+                d[n + "_v"] = [float(x) for x in self.get_moments(n, 1).ravel()]
         return json.dumps(d).encode()
 
     def close(self):
@@ -133,6 +163,11 @@ def _from_json(cls, data):
     m = cls(d["uProfileDim"], d["uBehaviorSize"], d["uBehaviorDim"], d["iFeatureDim"], d["cFeatureDim"])
     for n in m.Learnable():
         m.set_weights(n, np.asarray(d[n], np.float32))
+    if "adamStep" in d:  # written by Marshal(optimizer=True): resume Adam where it stopped
+        for n in m.Learnable():
+            m.set_moments(n, 0, np.asarray(d[n + "_m"], np.float32))
+            m.set_moments(n, 1, np.asarray(d[n + "_v"], np.float32))
+        m.step = d["adamStep"]
     return m  # d0 = d1 = 0 like the Go constructors-from-JSON (din.go:136-147): no dropout at predict
 
 

@@ -76,6 +76,14 @@ int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, si
 int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n);
 /* resets the Adam moments and the step counter (a fresh gorgonia AdamSolver, model.go:88) */
 int goctr_model_reset_optimizer(goctr_model* m);
+/* Optimizer state for checkpoint / resume ("dinModel JSON ... with optimizer state added for resume";
+ * the reference's din.go:41-80 / dnn.go:38-61 JSON holds weights only, so a resumed model.Train there restarts Adam
+ * from zero moments).  which: 0 = first moment, 1 = second moment; same shapes as goctr_model_get_weights.
+ * step = Adam iteration count = dropout stream position. */
+int goctr_model_get_moments(goctr_model* m, int tensor_id, int which, float* host, size_t n);
+int goctr_model_set_moments(goctr_model* m, int tensor_id, int which, const float* host, size_t n);
+int goctr_model_get_step(goctr_model* m, uint32_t* step);
+int goctr_model_set_step(goctr_model* m, uint32_t step);
 
 typedef struct {
   int batch;       /* batchSize  (model.go:28) */
@@ -225,7 +233,7 @@ int goctr_mlp_predict(goctr_mlp* p, const float* X, int64_t rows, float* y_out);
 typedef struct {
   int dim, window;       /* wordemb.go:9 arguments */
   int optimizer;         /* 0 = hierarchical softmax (wordemb.go:13), 1 = negative sampling */
-  int model;             /* 0 = skip-gram (wordemb.go:12) */
+  int model;             /* 0 = skip-gram (wordemb.go:12, model.go:48-78), 1 = cbow (model.go:96-148) */
   int neg_samples;       /* options.go:51 */
   double init_lr, min_lr;     /* options.go:42,49 */
   int64_t update_lr_batch;    /* options.go:55 */

@@ -51,6 +51,56 @@ def test_deterministic_bit_exact(oracle, opt, dim):
     assert np.array_equal(m.export_f32(), rp.astype(np.float32))          # GenEmbeddingMap32 narrowing
 
 
+@pytest.mark.parametrize("opt", ["hs", "ns"])
+@pytest.mark.parametrize("dim", [16, 10])
+def test_cbow_deterministic_bit_exact(oracle, opt, dim):
+    """cbow.trainOne (model.go:96-148): aggregate / one optim call / update, the window shrink drawn twice"""
+    from goctr_amd import embedding as ge
+    rng = np.random.default_rng(7)
+    V, n = 40, 3000
+    doc = corpus(rng, V, n)
+    counts = np.bincount(doc, minlength=V) + 1
+    keep = (rng.random(n) < 0.9).astype(np.uint8)
+    p0 = (rng.random((V, dim)) - 0.5) / dim
+    aux0 = (rng.random((V, dim)) - 0.5) / dim if opt == "ns" else None
+    m = ge.Word2Vec(dim=dim, optimizer=opt, deterministic=True, model="cbow", update_lr_batch=500)
+    m.create(counts, p0, aux0)
+    lr = m.train_pass(doc, n, keep, lr=0.025)
+    cfg = oracle.w2v_cfg(dim=dim, optimizer=opt, model="cbow", update_lr_batch=500)
+    paths = oracle.huffman_paths(counts)
+    rp = p0.copy()
+    raux = aux0.copy() if aux0 is not None else np.zeros((V - 1, dim))
+    rlr, _ = oracle.w2v_train_slice(cfg, doc, 0, n, keep, rp, raux, paths, oracle.sigmoid_table(), oracle.Lcg(1),
+                                    0.025, 0, n)
+    assert not np.array_equal(rp, p0)
+    assert np.array_equal(m.get_param(), rp)         # bit-exact float64
+    assert np.array_equal(m.get_aux(), raux)
+    assert lr == rlr
+
+
+def test_cbow_hogwild_learns_cooccurrence():
+    from goctr_amd import embedding as ge
+    rng = np.random.default_rng(3)
+    V, dim = 200, 16
+    sessions = []
+    for _ in range(4000):
+        g = rng.integers(0, 2)
+        sessions.append(rng.integers(g * 100, g * 100 + 100, size=50))
+    doc = np.concatenate(sessions).astype(np.int32)
+    counts = np.bincount(doc, minlength=V)
+    m = ge.Word2Vec(dim=dim, deterministic=False, streams=512, rng=np.random.default_rng(4), model="cbow")
+    m.create(counts)
+    for _ in range(3):
+        m.train_pass(doc, doc.size, None, lr=0.025)
+    P = m.get_param()
+    assert np.all(np.isfinite(P))
+    Pn = P / np.linalg.norm(P, axis=1, keepdims=True)
+    S = Pn @ Pn.T
+    within = (S[:100, :100].sum() - 100) / (100 * 99)
+    across = S[:100, 100:].mean()
+    assert within > across + 0.2
+
+
 def test_deterministic_lr_schedule_and_second_iteration(oracle):
     from goctr_amd import embedding as ge
     rng = np.random.default_rng(2)
