@@ -63,6 +63,9 @@ SYMBOLS = [
     "goctr_w2v_get_paths", "goctr_w2v_train", "goctr_w2v_upload_doc", "goctr_w2v_train_resident",
     "goctr_w2v_export_f32", "goctr_searcher_create", "goctr_searcher_destroy", "goctr_searcher_search",
     "goctr_ubcache_create", "goctr_ubcache_destroy", "goctr_ubcache_get", "goctr_dataset_create_keys", "goctr_dataset_get_ids",
+    "goctr_corpus_create", "goctr_corpus_destroy", "goctr_corpus_append", "goctr_corpus_build", "goctr_corpus_info",
+    "goctr_corpus_get_dictionary", "goctr_corpus_get_doc", "goctr_w2v_create_from_corpus", "goctr_w2v_use_corpus",
+    "goctr_w2v_get_keep_mask",
 ]
 
 _lib = None

@@ -22,6 +22,7 @@
 #include <numeric>
 
 #include "common.h"
+#include "corpus.h"
 
 using namespace goctr;
 
@@ -373,6 +374,25 @@ struct goctr_w2v {
 
 namespace {
 
+// Subsampler (modelutil/subsample/subsample.go:28-52): samples[id] = max(0, 1 - sqrt(threshold / cfs[id])) (raw counts,
+// quirk Q14); a word is trained when samples[id] > u, u uniform in [0,1).  The reference draws u from Go's global
+// math/rand stream, which cannot be regenerated outside Go; here u is a counter-based hash of (seed, position), so the
+// mask is reproducible and the doc never leaves HBM.  Division and square root are correctly rounded on both sides, so
+// samples[] itself is bit-identical.
+__global__ void w2v_subsample_kernel(const int* doc, long long n, const long long* cfs, double threshold,
+                                     unsigned long long seed, unsigned char* keep) {
+  const long long pos = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n) return;
+  double z = 1.0 - __dsqrt_rn(__ddiv_rn(threshold, (double)cfs[doc[pos]]));
+  if (z < 0) z = 0;
+  unsigned long long x = seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(pos + 1);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+  x ^= x >> 31;
+  const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+  keep[pos] = z > u ? 1 : 0;
+}
+
 // data-parallel exchange (item2vec row): every rank trains its own corpus shard on a full replica; after
 // the pass the ranks' parameter DELTAS are summed (what Hogwild's shared matrices do with the threads' updates) and
 // applied to the common starting point, so all replicas agree again:  p = p0 + sum_r (p_r - p0)
@@ -542,6 +562,53 @@ int goctr_w2v_train(goctr_w2v* w, const int32_t* doc, int64_t n_words, int64_t c
                     double* lr) {
   if (goctr_w2v_upload_doc(w, doc, n_words, keep_mask)) return -1;
   return goctr_w2v_train_resident(w, corpus_len, lr);
+}
+
+// word2vec.Train's prelude over a device-resident corpus (word2vec.go:90-135): the model is sized by the corpus'
+// dictionary, the Huffman tree / NS table come from its cfs.
+int goctr_w2v_create_from_corpus(const goctr_w2v_cfg* cfg, goctr_corpus* c, goctr_w2v** out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(cfg && c && out, "goctr_w2v_create_from_corpus: null argument");
+  std::vector<int64_t> cfs;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    GOCTR_CHECK(c->built, "goctr_w2v_create_from_corpus: call goctr_corpus_build first");
+    cfs.resize((size_t)c->V);
+    if (c->cfs.download(reinterpret_cast<long long*>(cfs.data()), cfs.size())) return -1;
+  }
+  return goctr_w2v_create(cfg, (int64_t)cfs.size(), cfs.data(), out);
+}
+
+// The training doc of one iteration = the corpus' IndexedDoc (device-to-device) + a fresh subsampling mask.
+int goctr_w2v_use_corpus(goctr_w2v* w, goctr_corpus* c, double subsample_threshold, uint64_t seed) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(w && c, "goctr_w2v_use_corpus: null argument");
+  std::lock_guard<std::mutex> lk(w->mu);
+  std::lock_guard<std::mutex> lk2(c->mu);
+  GOCTR_CHECK(c->built && c->V == w->V, "goctr_w2v_use_corpus: corpus not built or dictionary size %lld != model V %lld",
+              (long long)c->V, (long long)w->V);
+  GOCTR_CHECK(c->n_indexed > 0, "goctr_w2v_use_corpus: every word was filtered out");
+  const long long n = c->n_indexed;
+  hipStream_t s = engine().stream;
+  if (w->doc.ensure((size_t)n, false)) return -1;
+  GOCTR_HIP(hipMemcpyAsync(w->doc.p, c->indexed.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
+  w->has_keep = subsample_threshold >= 0;
+  if (w->has_keep) {
+    if (w->keep.ensure((size_t)n, false)) return -1;
+    hipLaunchKernelGGL(w2v_subsample_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, w->doc.p, n, c->cfs.p,
+                       subsample_threshold, (unsigned long long)seed, w->keep.p);
+    GOCTR_HIP(hipGetLastError());
+  }
+  w->n_words = n;
+  return 0;
+}
+
+int goctr_w2v_get_keep_mask(goctr_w2v* w, uint8_t* keep, int64_t n) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(w && keep, "goctr_w2v_get_keep_mask: null argument");
+  std::lock_guard<std::mutex> lk(w->mu);
+  GOCTR_CHECK(w->has_keep && n == w->n_words, "goctr_w2v_get_keep_mask: no mask resident or %lld != %lld words", (long long)n, (long long)w->n_words);
+  return w->keep.download(keep, (size_t)n);
 }
 
 int goctr_w2v_export_f32(goctr_w2v* w, float* out) {

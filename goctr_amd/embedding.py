@@ -163,6 +163,33 @@ class Word2Vec:
             self.train_pass(doc, len(self.idoc), keep)
         return self
 
+    def TrainIds(self, batches, capacity_words, seed=0):
+        """word2vec.Train (word2vec.go:90-175) for integer tokens with everything resident: the token batches go to
+        HBM as they arrive, dictionary / IndexedDoc / subsampling masks are built there (csrc/corpus.hip) and only the
+        counts come back (for the host-side Huffman build)."""
+        from .corpus import Corpus
+        cps = Corpus(capacity_words, self.min_count, self.max_count).Load(batches)
+        self.corpus = cps
+        capi.init()
+        self.close()
+        self.V = cps.V
+        self._h = C.c_void_p()
+        cfg = self._cfg()
+        capi.check(capi.load().goctr_w2v_create_from_corpus(C.byref(cfg), cps._h, C.byref(self._h)))
+        self.set_param((self.rng.random((self.V, self.dim)) - 0.5) / self.dim)          # word2vec.go:103-111
+        if self.optimizer != "hs":
+            self.set_aux((self.rng.random((self.V, self.dim)) - 0.5) / self.dim)        # optimizer.go:38-48
+        for it in range(self.iter):
+            capi.check(capi.load().goctr_w2v_use_corpus(self._h, cps._h, C.c_double(self.threshold),
+                                                        C.c_uint64(seed + it)))
+            self.train_resident(cps.Len())
+        return self
+
+    def keep_mask(self, n):
+        km = np.empty(n, np.uint8)
+        capi.check(capi.load().goctr_w2v_get_keep_mask(self._h, capi.ptr(km, C.c_uint8), C.c_int64(n)))
+        return km
+
     def WordVector(self):
         return self.get_param()                                             # HS: param rows (word2vec.go:249-271)
 
@@ -186,6 +213,13 @@ class Word2Vec:
             self.close()
         except Exception:
             pass
+
+
+def TrainEmbeddingIds(batches, capacity_words, window: int, dim: int, iter: int, seed=0, **kw) -> Word2Vec:
+    """TrainEmbedding (wordemb.go:9-32) over batches of int64 item ids instead of a channel of their decimal strings;
+    GenEmbeddingMap32's keys are then `mod.corpus.Dictionary()[0]`."""
+    mod = Word2Vec(window=window, dim=dim, iter=iter, optimizer="hs", **kw)
+    return mod.TrainIds(batches, capacity_words, seed)
 
 
 def TrainEmbedding(inputCh, window: int, dim: int, iter: int, **kw) -> Word2Vec:

@@ -263,6 +263,30 @@ int goctr_w2v_train_resident(goctr_w2v* w, int64_t corpus_len, double* lr);
 /* GenEmbeddingMap32 (word2vec.go:298-324): param rows narrowed to float32 */
 int goctr_w2v_export_f32(goctr_w2v* w, float* out /*[V,dim]*/);
 
+/* ---------------------------------------------------------------- corpus / dictionary --------- */
+/* replaces memory.New + Corpus.Load (feature/embedding/corpus/memory/memory.go:36-102), dictionary.Add
+ * (corpus/dictionary/dictionary.go:70-81) and Corpus.IndexedDoc with the MaxCount / MinCount filters
+ * (memory.go:53-62, corpus/cpsutil/cpsutil.go:58-78) for INTEGER tokens: go-ctr's item2vec words are decimal item
+ * ids (ItemSeqGenerator, example/movielens/feature.go:78; recommend/rcmd.go:539).  A token's id is its rank by first
+ * appearance, cfs[id] its count - exactly the reference's numbering.  INT64_MIN is reserved. */
+typedef struct goctr_corpus goctr_corpus;
+int goctr_corpus_create(int64_t capacity_words /* < 2^31 */, goctr_corpus** out);
+void goctr_corpus_destroy(goctr_corpus* c);
+/* one ItemSeqGenerator batch, in stream order (may be called many times before build) */
+int goctr_corpus_append(goctr_corpus* c, const int64_t* keys, int64_t n);
+/* min_count / max_count: options.go MinCount (default 5) / MaxCount (default -1 = off) */
+int goctr_corpus_build(goctr_corpus* c, int64_t min_count, int64_t max_count);
+/* n_words = Corpus.Len(), V = Dictionary.Len(), n_indexed = len(IndexedDoc()); any pointer may be NULL */
+int goctr_corpus_info(goctr_corpus* c, int64_t* n_words, int64_t* V, int64_t* n_indexed);
+int goctr_corpus_get_dictionary(goctr_corpus* c, int64_t* id2key /*[V] or NULL*/, int64_t* cfs /*[V] or NULL*/);
+int goctr_corpus_get_doc(goctr_corpus* c, int32_t* idoc /*[n_words] or NULL*/, int32_t* indexed /*[n_indexed] or NULL*/);
+/* word2vec.Train's prelude (word2vec.go:90-135) over a built corpus; param / aux still come from set_param / set_aux */
+int goctr_w2v_create_from_corpus(const goctr_w2v_cfg* cfg, goctr_corpus* c, goctr_w2v** out);
+/* make the corpus' IndexedDoc the resident training doc (device to device) with a fresh subsampling mask
+ * (subsample.go:28-52; threshold < 0: no subsampling).  Follow with goctr_w2v_train_resident(w, n_words, &lr). */
+int goctr_w2v_use_corpus(goctr_w2v* w, goctr_corpus* c, double subsample_threshold, uint64_t seed);
+int goctr_w2v_get_keep_mask(goctr_w2v* w, uint8_t* keep, int64_t n);
+
 /* ---------------------------------------------------------------- embedding k-NN search
  * Replaces search.Searcher (feature/embedding/search/search.go:52-134): brute-force cosine top-k over all items,
  * float64.  Results are bit-identical to the reference loop: the k best by (similarity descending, item index

@@ -269,4 +269,10 @@ void orc_assemble_keys(const int64_t* off, const int32_t* seq_items, const int64
 #ifdef __cplusplus
 }
 #endif
+/* ---- corpus load / dictionary / IndexedDoc / subsampler table (orc_corpus.c): memory.go:53-102, dictionary.go:70-81,
+ * cpsutil.go:58-78, subsample.go:28-43 ---- */
+int64_t orc_corpus_build(const int64_t* keys, int64_t n, int64_t min_count, int64_t max_count, int32_t* idoc,
+                         int64_t* id2key, int64_t* cfs, int32_t* indexed, int64_t* n_indexed);
+void orc_subsample_probs(const int64_t* cfs, int64_t V, double threshold, double* samples);
+
 #endif

@@ -557,3 +557,27 @@ def assemble_keys(off, seq_items, seq_ts, user_table, item_table, users, items, 
                             C.c_int(it.shape[1]), _p(users, C.c_int32), _p(items, C.c_int32), _p(ts, C.c_int64),
                             C.c_int64(rows), C.c_int(T), _p(ub, C.c_int32), _p(uf, C.c_float), _p(cf, C.c_float))
     return ub, uf, cf
+
+
+# ---------------------------------------------------------------- corpus / dictionary --
+def corpus_build(keys, min_count=5, max_count=-1):
+    """(idoc, id2key, cfs, indexed): memory.go:53-102 + dictionary.go:70-81 for integer tokens"""
+    keys = np.ascontiguousarray(keys, np.int64)
+    n = keys.size
+    idoc = np.empty(n, np.int32)
+    id2key = np.empty(n, np.int64)
+    cfs = np.empty(n, np.int64)
+    indexed = np.empty(n, np.int32)
+    m = C.c_int64(0)
+    lib().orc_corpus_build.restype = C.c_int64
+    V = lib().orc_corpus_build(_p(keys, C.c_int64), C.c_int64(n), C.c_int64(min_count), C.c_int64(max_count),
+                               _p(idoc, C.c_int32), _p(id2key, C.c_int64), _p(cfs, C.c_int64), _p(indexed, C.c_int32),
+                               C.byref(m))
+    return idoc, id2key[:V].copy(), cfs[:V].copy(), indexed[:m.value].copy()
+
+
+def subsample_probs(cfs, threshold=1e-3):
+    cfs = np.ascontiguousarray(cfs, np.int64)
+    out = np.empty(cfs.size, np.float64)
+    lib().orc_subsample_probs(_p(cfs, C.c_int64), C.c_int64(cfs.size), C.c_double(threshold), _p(out, C.c_double))
+    return out

@@ -172,3 +172,49 @@ def test_ubcache_filter_kats(oracle):
     # nothing at or before max_ts -> empty; duplicates of the boundary timestamp are all kept
     assert oracle.ubcache_filter([9, 8, 7], [1, 2, 3], 5, 2).size == 0
     assert oracle.ubcache_filter([9, 7, 7, 7, 3], [1, 2, 3, 4, 5], 7, 2).tolist() == [2, 3]
+
+
+# ---------------------------------------------------------------- corpus load / dictionary
+def test_corpus_dictionary_hand_derived(oracle):
+    # dictionary.go:70-81: ids by first appearance, cfs = counts; memory.go:85-88: idoc = id of every word
+    keys = [50, 30, 50, 70, 30, 50, -4, 70, 50]
+    idoc, id2key, cfs, indexed = oracle.corpus_build(keys, min_count=-1, max_count=-1)
+    assert idoc.tolist() == [0, 1, 0, 2, 1, 0, 3, 2, 0]
+    assert id2key.tolist() == [50, 30, 70, -4] and cfs.tolist() == [4, 2, 2, 1]
+    assert indexed.tolist() == idoc.tolist()                         # both filters off (v < 0 / v <= 0)
+    # MinCount(2): drops freq < 2 (cpsutil.go:72-76); MaxCount(3): drops 3 < freq (cpsutil.go:64-68)
+    assert oracle.corpus_build(keys, 2, -1)[3].tolist() == [0, 1, 0, 2, 1, 0, 2, 0]
+    assert oracle.corpus_build(keys, -1, 3)[3].tolist() == [1, 2, 1, 3, 2]
+    assert oracle.corpus_build(keys, 2, 3)[3].tolist() == [1, 2, 1, 2]
+    # MinCount(0) is "on" (0 <= v) but drops nothing (freq < 0 never holds); MaxCount(0) is off
+    assert oracle.corpus_build(keys, 0, 0)[3].tolist() == idoc.tolist()
+    # a filter can empty the doc; the dictionary still holds every word
+    i2, k2, c2, x2 = oracle.corpus_build(keys, 100, -1)
+    assert x2.size == 0 and k2.size == 4
+
+
+def test_corpus_matches_python_dict(oracle):
+    rng = np.random.default_rng(0)
+    keys = rng.zipf(1.3, size=20000) * 7 - 3
+    idoc, id2key, cfs, indexed = oracle.corpus_build(keys, 5, 400)
+    w2id, counts = {}, []
+    ref = []
+    for w in keys.tolist():
+        if w in w2id:
+            counts[w2id[w]] += 1
+        else:
+            w2id[w] = len(counts)
+            counts.append(1)
+        ref.append(w2id[w])
+    assert idoc.tolist() == ref and cfs.tolist() == counts
+    assert [w2id[k] for k in id2key.tolist()] == list(range(len(counts)))
+    keep = [i for i in ref if not (counts[i] > 400 or counts[i] < 5)]
+    assert indexed.tolist() == keep
+
+
+def test_subsample_probs(oracle):
+    # subsample.go:28-43: z = 1 - sqrt(t / freq), clamped at 0 (raw counts, quirk Q14)
+    p = oracle.subsample_probs([1, 4, 1000, 10 ** 6], 1e-3)
+    assert p[0] == 1.0 - np.sqrt(1e-3) and p[1] == 1.0 - np.sqrt(1e-3 / 4.0)
+    assert p[3] == 1.0 - np.sqrt(1e-3 / 1e6)
+    assert oracle.subsample_probs([1, 2], 4.0).tolist() == [0.0, 0.0]
