@@ -275,4 +275,10 @@ int64_t orc_corpus_build(const int64_t* keys, int64_t n, int64_t min_count, int6
                          int64_t* id2key, int64_t* cfs, int32_t* indexed, int64_t* n_indexed);
 void orc_subsample_probs(const int64_t* cfs, int64_t V, double threshold, double* samples);
 
+/* ---- trainable-embedding EXTENSION (orc_embtrain.c): float64 loss and its gradient with respect to the embedding
+ * rows; no reference counterpart (embeddings are frozen there), validated by finite differences ---- */
+double orc_embtrain_loss_grad(const orc_ctr_cfg* cfg, const orc_ctr_weights* w, const double* E, int64_t V,
+                              const int32_t* ub_ids, const int32_t* item_ids, const float* ufeat, const float* cfeat,
+                              const float* Y, int B, int valid, const orc_dropout* drop, double* dE /* [V,D] or NULL */);
+
 #endif

@@ -285,6 +285,26 @@ class CtrModel:
         d.step = drop.get("step", 0)
         return d, keep
 
+    def emb_loss_grad(self, E, ub_ids, item_ids, user_feat, ctx_feat, Y, B=None, drop=None, want_grad=True):
+        """trainable-embedding EXTENSION (orc_embtrain.c): float64 (loss, dE [V,D])"""
+        E = np.ascontiguousarray(E, np.float64)
+        ub_ids = np.ascontiguousarray(ub_ids, np.int32)
+        item_ids = np.ascontiguousarray(item_ids, np.int32)
+        uf = np.ascontiguousarray(user_feat, np.float32)
+        cf = np.ascontiguousarray(ctx_feat, np.float32)
+        Y = np.ascontiguousarray(Y, np.float32)
+        valid = ub_ids.shape[0]
+        B = B or valid
+        dE = np.empty_like(E) if want_grad else None
+        d, _keep = self._drop(drop)
+        w = self._w()
+        lib().orc_embtrain_loss_grad.restype = C.c_double
+        loss = lib().orc_embtrain_loss_grad(C.byref(self.cfg), C.byref(w), _p(E, C.c_double), C.c_int64(E.shape[0]),
+                                            _p(ub_ids, C.c_int32), _p(item_ids, C.c_int32), _p(uf, C.c_float),
+                                            _p(cf, C.c_float), _p(Y, C.c_float), C.c_int(B), C.c_int(valid),
+                                            C.byref(d) if d is not None else None, _p(dE, C.c_double))
+        return (loss, dE) if want_grad else loss
+
     def forward(self, X, B=None, drop=None, want_internals=False):
         X = np.ascontiguousarray(X, np.float32)
         valid = X.shape[0]
