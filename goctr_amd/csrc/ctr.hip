@@ -12,6 +12,8 @@
 
 #include "common.h"
 #include "ctr_chain.h"
+#include "emb_train.h"
+#include "scan.h"
 #include "ctr_kernels.h"
 #include "mfma_gemm.h"
 
@@ -68,6 +70,13 @@ struct goctr_model {
   std::mutex mu;
   StepGraph graph;
   int attp_blocks = 0;
+  // trainable-embedding extension (emb_train.h): off unless goctr_model_set_embedding_training(lr > 0)
+  float emb_lr = 0.f;
+  long long emb_V = 0; int emb_B = 0;
+  DevBuf<float> dpv, W0pvT;
+  DevBuf<unsigned int> emb_mark, emb_rank, emb_tiles;
+  DevBuf<unsigned long long> emb_total;
+  DevBuf<long long> emb_accum;
 };
 
 namespace {
@@ -413,6 +422,49 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
 // backward part up to and including the slab reduce: kernels 5-12
 AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc);
 
+// Sparse embedding update of one step (emb_train.h).  Runs after every reader of the table in this step (attn_fwd,
+// attn_bwd's re-gather) and before the step state advances.
+int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepState* st) {
+  const goctr_ctr_cfg& c = m->cfg;
+  Engine& e = engine();
+  GOCTR_CHECK(src.id_mode, "embedding training needs an id-mode dataset (the dense TrainSample rows carry no ids)");
+  GOCTR_CHECK(c.D <= 64, "embedding training supports D <= 64 (got %d)", c.D);
+  const int Np = round_up(2 * c.D, 16);
+  const long long V = src.V;
+  const long long cap = std::min<long long>(V, (long long)B * (c.T + 1));
+  if (m->emb_V != V || m->emb_B != B) {
+    if (m->dpv.alloc((size_t)B * Np) || m->W0pvT.alloc((size_t)m->H1p * Np) || m->emb_mark.alloc((size_t)V) ||
+        m->emb_rank.alloc((size_t)V, false) || m->emb_total.alloc(1) || m->emb_accum.alloc((size_t)cap * c.D))
+      return -1;
+    m->emb_V = V; m->emb_B = B;
+  }
+  EmbTrainArgs a{};
+  a.src = src; a.st = st; a.B = B; a.T = c.T; a.D = c.D; a.kind = c.kind; a.att = c.att;
+  a.dpv = m->dpv.p; a.ldp = Np; a.gate = m->gate.p; a.wgt = m->wgt.p; a.att0 = m->W.p + m->offa;
+  a.emb = const_cast<float*>(src.emb); a.V = V;
+  a.mark = m->emb_mark.p; a.rank = m->emb_rank.p; a.accum = m->emb_accum.p; a.lr = m->emb_lr;
+  hipStream_t s = e.stream;
+  {
+  ProfScope ps(GOCTR_K_EMB_TRAIN);
+  hipLaunchKernelGGL(emb_mark_kernel, dim3((unsigned)cdiv((long long)B * (c.T + 1), 256)), dim3(256), 0, s, a);
+  GOCTR_HIP(hipGetLastError());
+  if (exclusive_scan(m->emb_mark.p, V, m->emb_rank.p, m->emb_tiles, m->emb_total.p)) return -1;
+  hipLaunchKernelGGL(w0pv_transpose_kernel, dim3((unsigned)cdiv((long long)m->H1p * Np, 256)), dim3(256), 0, s, m->W.p, m->H1p,
+                     c.U, 2 * c.D, Np, m->W0pvT.p);
+  GOCTR_HIP(hipGetLastError());
+  }
+  EpiStore sp{m->dpv.p, Np};
+  if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
+  ProfScope ps(GOCTR_K_EMB_TRAIN);
+  const dim3 gb((unsigned)cdiv(B, 4));
+  if (c.D <= 16) hipLaunchKernelGGL(emb_grad_kernel<16>, gb, dim3(256), 0, s, a);
+  else if (c.D <= 32) hipLaunchKernelGGL(emb_grad_kernel<32>, gb, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(emb_grad_kernel<64>, gb, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(emb_apply_kernel, dim3((unsigned)cdiv(V, 256)), dim3(256), 0, s, a);
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
 // backward part up to and including the slab reduce (optionally fused with Adam on a single GPU)
 int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, bool advance,
                     bool fuse_update = false) {
@@ -499,6 +551,8 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
         launch_tn(GOCTR_K_DW2, m->ones16.p, 16, 1, m->attp.p, m->Tp, m->Tp / 16, B, rpw, m->slabs3.p, (size_t)16 * m->Tp))
       return -1;
   }
+
+  if (m->emb_lr > 0.f && launch_emb_train(m, src, B, st)) return -1;
 
   ReduceArgs ra{};
   ra.seg[0] = {m->slabs0.p, S, (unsigned long long)m->Ip * m->H1p, 0, m->Ip * m->H1p};
@@ -888,6 +942,23 @@ int goctr_model_set_step(goctr_model* m, uint32_t step) {
   GOCTR_CHECK(m, "goctr_model_set_step: null argument");
   std::lock_guard<std::mutex> lk(m->mu);
   return set_state(m, step, 0, 0, 1);
+}
+
+int goctr_model_set_embedding_training(goctr_model* m, double lr) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && lr >= 0 && lr == lr, "goctr_model_set_embedding_training: bad arguments");
+  std::lock_guard<std::mutex> lk(m->mu);
+  GOCTR_CHECK(lr == 0 || m->cfg.D <= 64, "embedding training supports D <= 64 (got %d)", m->cfg.D);
+  GOCTR_CHECK(lr == 0 || !engine().comm_active(), "embedding training is single-GPU in this build (the sparse exchange is not implemented)");
+  m->emb_lr = (float)lr;
+  m->graph.destroy();
+  return 0;
+}
+
+int goctr_emb_get_rows(goctr_emb* e, int64_t first, int64_t n, float* host_rows) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(e && host_rows && first >= 0 && n >= 0 && first + n <= e->V, "goctr_emb_get_rows: range out of bounds");
+  return n ? e->rows.download(host_rows, (size_t)n * e->D, (size_t)first * e->D) : 0;
 }
 
 int goctr_model_reset_optimizer(goctr_model* m) {

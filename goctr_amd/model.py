@@ -97,6 +97,12 @@ class _CtrNet:
     def step(self, v):
         capi.check(capi.load().goctr_model_set_step(self._h, C.c_uint32(int(v))))
 
+    def set_embedding_training(self, lr):
+        """EXTENSION (no reference counterpart: go-ctr trains with frozen embeddings): lr > 0 lets the following training
+        steps on id-mode datasets also update the EmbeddingTable rows by SGD scatter-add; 0 switches it off."""
+        capi.check(capi.load().goctr_model_set_embedding_training(self._h, C.c_double(lr)))
+        return self
+
     def init_gaussian(self, rng):
         """G.Gaussian(0, 1) weights, att0 = 1 (din.go:181-191; dnn.go:125-127)."""
         for n in ("mlp0", "mlp1", "mlp2"):
@@ -256,6 +262,12 @@ class EmbeddingTable:
         capi.init()
         capi.check(capi.load().goctr_emb_create(C.c_int64(self.V), C.c_int(self.D), capi.ptr(rows, C.c_float),
                                                 C.byref(self._h)))
+
+    def get_rows(self, first=0, n=None):
+        n = self.V - first if n is None else n
+        out = np.empty((n, self.D), np.float32)
+        capi.check(capi.load().goctr_emb_get_rows(self._h, C.c_int64(first), C.c_int64(n), capi.ptr(out, C.c_float)))
+        return out
 
     def gather_rows(self, ub_ids, item_ids, user_feat, ctx_feat):
         """GetSampleVector's row assembly (rcmd.go:497-533) on the device; bit-exact copies."""

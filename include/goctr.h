@@ -74,6 +74,11 @@ void goctr_model_destroy(goctr_model* m);
  * W1 [H1,H2], W2 [H2,1], att0 [1,T];  replaces Marshal / NewDinNetFromJson (din.go:62,82) */
 int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, size_t n);
 int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n);
+/* EXTENSION with no reference counterpart (the reference trains with frozen embeddings, din.go:161-169 /
+ * dnn.go:152-154; SURVEY F3, 8(e) "Trainable embeddings"): lr > 0 makes every following training step on an id-mode
+ * dataset also update the rows of the goctr_emb table it is given,  E[id] -= lr * dCost/dE[id]  (plain SGD
+ * scatter-add, deterministic).  lr = 0 (the default) restores the reference's semantics.  Single-GPU; D <= 64. */
+int goctr_model_set_embedding_training(goctr_model* m, double lr);
 /* resets the Adam moments and the step counter (a fresh gorgonia AdamSolver, model.go:88) */
 int goctr_model_reset_optimizer(goctr_model* m);
 /* Optimizer state for checkpoint / resume ("dinModel JSON ... with optimizer state added for resume";
@@ -126,6 +131,7 @@ int goctr_loss_grad_dense(goctr_model* m, const float* X, const float* Y, int va
  * host-side string-map gather of recommend.GetSampleVector (rcmd.go:462-536). */
 int goctr_emb_create(int64_t V, int D, const float* host_rows /* [V,D] or NULL = zeros */, goctr_emb** out);
 int goctr_emb_set_rows(goctr_emb* e, int64_t first, int64_t n, const float* host_rows);
+int goctr_emb_get_rows(goctr_emb* e, int64_t first, int64_t n, float* host_rows);
 void goctr_emb_destroy(goctr_emb* e);
 /* standalone gather = the row-assembly half of GetSampleVector (rcmd.go:497-533): out row =
  * [user | emb[ub_ids[0..T)] | emb[item] | ctx]; id < 0 or >= V => zero row.  Device-resident
@@ -180,7 +186,7 @@ int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int ba
  * While enabled the step runs eagerly (no hipGraph) with an event pair around every launch. */
 enum { GOCTR_K_ATTN_FWD = 0, GOCTR_K_GEMM_FWD0, GOCTR_K_GEMM_FWD1, GOCTR_K_GEMM_OUT, GOCTR_K_BWD_DZ1,
        GOCTR_K_BWD_DZ0, GOCTR_K_BWD_DP, GOCTR_K_ATTN_BWD, GOCTR_K_DW0, GOCTR_K_DW1, GOCTR_K_DW2,
-       GOCTR_K_REDUCE, GOCTR_K_ALLREDUCE, GOCTR_K_ADAM, GOCTR_K_CHAIN, GOCTR_K_COUNT };
+       GOCTR_K_REDUCE, GOCTR_K_ALLREDUCE, GOCTR_K_ADAM, GOCTR_K_CHAIN, GOCTR_K_EMB_TRAIN, GOCTR_K_COUNT };
 int goctr_prof_enable(int on);
 int goctr_prof_reset(void);
 /* total milliseconds and launch count per kernel family since the last reset */

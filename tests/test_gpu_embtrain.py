@@ -1,0 +1,131 @@
+"""GPU: trainable-embedding EXTENSION (csrc/emb_train.h) against its float64 oracle (oracle/orc_embtrain.c, checked
+by finite differences in tests/test_oracle_embtrain.py).  go-ctr itself keeps the embeddings frozen, so
+this is parity with the build's own restatement, tolerance 1e-4 of the largest row update (float32 forward/backward
+vs float64), plus exact properties: untouched rows keep their bits, the update is bit-reproducible, lr = 0 is the
+reference's frozen behaviour."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(oracle, kind, att, U, T, D, Cc, V, rows, seed):
+    from goctr_amd import model as gm
+    rng = np.random.default_rng(seed)
+    okind = oracle.DIN if kind == "din" else oracle.YOUTUBE
+    om = oracle.CtrModel(okind, U, T, D, Cc, att=att)
+    om.W0[:] = rng.standard_normal(om.W0.shape) * 0.2
+    om.W1[:] = rng.standard_normal(om.W1.shape) * 0.2
+    om.W2[:] = rng.standard_normal(om.W2.shape) * 0.3
+    om.att0[:] = 1.0 + 0.3 * rng.standard_normal(T)
+    cls = gm.DinNet if kind == "din" else gm.YoutubeDnn
+    m = cls(U, T, D, D, Cc, att=att)
+    for n, w in (("mlp0", om.W0), ("mlp1", om.W1), ("mlp2", om.W2)):
+        m.set_weights(n, w)
+    if kind == "din":
+        m.set_weights("att0", om.att0)
+    E = (rng.standard_normal((V, D)) * 0.5).astype(np.float32)
+    ub = rng.integers(-3, V + 2, size=(rows, T)).astype(np.int32)      # empty and out-of-range slots
+    ub[0, :T - 1] = ub[0, T - 1]                                      # one id several times in a history
+    items = rng.integers(0, V, size=rows).astype(np.int32)
+    ub[1, 0] = items[1]
+    items[2] = -1
+    uf = rng.random((rows, U), dtype=np.float32)
+    cf = rng.random((rows, Cc), dtype=np.float32)
+    y = (rng.random(rows) < 0.5).astype(np.float32)
+    return om, m, E, ub, items, uf, cf, y
+
+
+@pytest.mark.parametrize("kind,att,D,T", [("youtube", 0, 16, 10), ("din", 0, 16, 10), ("din", 1, 16, 10),
+                                           ("youtube", 0, 64, 50), ("din", 0, 64, 7), ("din", 0, 24, 13),
+                                           ("din", 1, 5, 3)])
+def test_one_step_matches_oracle(oracle, kind, att, D, T):
+    from goctr_amd import capi, model as gm
+    U, Cc, V, B = 52, 53, 300, 256
+    rows = B - 37                                                       # a padded tail inside the batch
+    om, m, E, ub, items, uf, cf, y = _setup(oracle, kind, att, U, T, D, Cc, V, rows, seed=D + T)
+    lr = 0.5
+    loss, dE = om.emb_loss_grad(E.astype(np.float64), ub, items, uf, cf, y, B=B)
+    tab = gm.EmbeddingTable(E)
+    ds = gm.Dataset.ids(ub, items, uf, cf, y)
+    cfg = capi.default_train_cfg(batch=B, epochs=1)
+    m.set_embedding_training(lr)
+    costs = gm.train_steps(m, ds, cfg, 1, emb=tab, want_costs=True)
+    capi.sync()
+    got = tab.get_rows()
+    want = E.astype(np.float64) - lr * dE
+    upd = np.abs(lr * dE).max()
+    assert upd > 1e-5
+    assert np.abs(got - want).max() <= 1e-4 * upd + 1e-7
+    assert abs(float(costs[0]) - loss) < 1e-5 * max(1.0, abs(loss))
+    touched = np.zeros(V, bool)
+    touched[ub[(ub >= 0) & (ub < V)]] = True
+    touched[items[items >= 0]] = True
+    assert np.array_equal(got[~touched], E[~touched])                   # untouched rows keep their bits
+
+
+def test_reproducible_and_off_by_default(oracle):
+    from goctr_amd import capi, model as gm
+    U, T, D, Cc, V, B = 52, 20, 16, 53, 200, 512
+    om, m, E, ub, items, uf, cf, y = _setup(oracle, "din", 0, U, T, D, Cc, V, 3 * B, seed=1)
+    ds = gm.Dataset.ids(ub, items, uf, cf, y)
+    cfg = capi.default_train_cfg(batch=B, epochs=1)
+    res = []
+    for lr in (0.0, 0.1, 0.1):
+        m2 = gm.DinNet(U, T, D, D, Cc)
+        for n in ("mlp0", "mlp1", "mlp2", "att0"):
+            m2.set_weights(n, m.get_weights(n))
+        tab = gm.EmbeddingTable(E)
+        if lr:
+            m2.set_embedding_training(lr)
+        c = gm.train_steps(m2, ds, cfg, 6, emb=tab, want_costs=True)     # two passes over three batches
+        capi.sync()
+        res.append((tab.get_rows(), m2.get_weights("mlp0"), c))
+    assert np.array_equal(res[0][0], E)                                 # frozen unless switched on
+    assert not np.array_equal(res[1][0], E)
+    assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1], res[2][1])   # bit-reproducible
+    assert np.array_equal(res[1][2], res[2][2])
+
+
+def test_training_embeddings_lowers_the_loss(oracle):
+    """labels that depend on the candidate item only through its id: frozen random embeddings cannot express them
+    well, trained ones can"""
+    from goctr_amd import capi, model as gm
+    rng = np.random.default_rng(0)
+    U, T, D, Cc, V, B = 4, 5, 16, 4, 64, 1024
+    rows = 8 * B
+    items = rng.integers(0, V, size=rows).astype(np.int32)
+    ub = rng.integers(0, V, size=(rows, T)).astype(np.int32)
+    y = (items % 2).astype(np.float32)
+    uf = rng.random((rows, U), dtype=np.float32)
+    cf = rng.random((rows, Cc), dtype=np.float32)
+    E = (rng.standard_normal((V, D)) * 0.05).astype(np.float32)
+    ds = gm.Dataset.ids(ub, items, uf, cf, y)
+    cfg = capi.default_train_cfg(batch=B, epochs=1)
+    final = {}
+    for lr in (0.0, 20.0):
+        m = gm.YoutubeDnn(U, T, D, D, Cc)
+        r = np.random.default_rng(3)
+        for n in ("mlp0", "mlp1", "mlp2"):
+            m.set_weights(n, (r.standard_normal(m._shape(n)) * 0.1).astype(np.float32))
+        tab = gm.EmbeddingTable(E)
+        m.set_embedding_training(lr)
+        c = gm.train_steps(m, ds, cfg, 160, emb=tab, want_costs=True)
+        capi.sync()
+        assert np.all(np.isfinite(c))
+        final[lr] = float(np.mean(c[-8:]))
+    assert final[20.0] < 0.6 * final[0.0]
+
+
+def test_errors():
+    from goctr_amd import capi, model as gm
+    m = gm.DinNet(4, 3, 128, 128, 4)
+    with pytest.raises(capi.GoctrError):
+        m.set_embedding_training(0.1)                                    # D > 64
+    m = gm.DinNet(4, 3, 8, 8, 4).init_gaussian(np.random.default_rng(0))
+    m.set_embedding_training(0.1)
+    X = np.random.default_rng(0).random((32, 4 + 3 * 8 + 8 + 4), dtype=np.float32)
+    from goctr_amd.recommend import SampleInfo
+    ds = gm.Dataset.dense(X, np.zeros(32, np.float32), SampleInfo.from_dims(4, 3, 8, 4))
+    with pytest.raises(capi.GoctrError):
+        gm.train_steps(m, ds, capi.default_train_cfg(batch=32, epochs=1), 1)        # dense rows carry no ids
