@@ -324,6 +324,9 @@ def main():
     ap.add_argument("--workload", default="din", choices=["din", "youtube", "mlp", "item2vec", "knn"],
                     help="din = BASELINE configs[2] (the headline metric, default); youtube = configs[3] per-GPU slice "
                          "(10M x 64 table: the HBM-bound gather); mlp = configs[1]; item2vec = configs[4] per-GPU slice")
+    ap.add_argument("--train-emb", type=float, default=0.0, metavar="LR",
+                    help="din / youtube: also train the embedding table (EXTENSION with no reference counterpart: SGD "
+                         "scatter-add, csrc/emb_train.h).  Off by default: the headline metric keeps the reference's frozen table")
     args = ap.parse_args()
     if args.workload == "mlp":
         return bench_mlp(args)
@@ -383,6 +386,8 @@ def main():
     m = (gm.YoutubeDnn if c["KIND"] == "youtube" else gm.DinNet)(c["U"], c["T"], c["D"], c["D"], c["C"])
     init_weights(m, 1)                                   # same weights on every rank
     cfg = capi.default_train_cfg(batch=c["B"], epochs=1)
+    if args.train_emb > 0:
+        m.set_embedding_training(args.train_emb)
 
     # ---- training samples/sec: W warm-up steps, then exactly K timed steps
     gm.train_steps(m, ds, cfg, args.warmup, emb=tab)
@@ -417,6 +422,10 @@ def main():
                    "global_batch": c["B"] * world, "parallelism": f"dp{world}", "resident_rows_per_gpu": args.rows},
         "recommend_qps": round(qps, 1), "recommend_batch": c["PRED_B"],
     }
+    if args.train_emb > 0:
+        out["config"]["workload"] += (f"; EXTENSION: embedding table trained too (SGD scatter-add, lr {args.train_emb}; "
+                                      "the reference keeps it frozen)")
+        out["config"]["train_embeddings"] = True
 
     if args.host_rows and rank == 0:
         # model.Predict's own calling convention (model.go:242): X [rows, XCols] float32 in host memory, y back to the host

@@ -61,6 +61,18 @@ int comm_allreduce_f32(float* dev, size_t n) {
   GOCTR_NCCL(g_rccl.AllReduce(dev, dev, n, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, e.stream));
   return 0;
 }
+int comm_allreduce_u32_max(unsigned int* dev, size_t n) {
+  Engine& e = engine();
+  if (!e.comm_active()) return 0;
+  GOCTR_NCCL(g_rccl.AllReduce(dev, dev, n, ncclUint32, ncclMax, (ncclComm_t)e.nccl_comm, e.stream));
+  return 0;
+}
+int comm_allreduce_i64_sum(long long* dev, size_t n) {
+  Engine& e = engine();
+  if (!e.comm_active()) return 0;
+  GOCTR_NCCL(g_rccl.AllReduce(dev, dev, n, ncclInt64, ncclSum, (ncclComm_t)e.nccl_comm, e.stream));
+  return 0;
+}
 int comm_allreduce_f64_dev(double* dev, size_t n) {
   Engine& e = engine();
   if (!e.comm_active()) return 0;

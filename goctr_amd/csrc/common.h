@@ -120,5 +120,7 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // collective hook (comm.hip): in-place sum over ranks on the engine stream; no-op when world == 1
 int comm_allreduce_f32(float* dev, size_t n);
 int comm_allreduce_f64_dev(double* dev, size_t n);
+int comm_allreduce_u32_max(unsigned int* dev, size_t n);   // sparse embedding update: union of the ranks' touched ids
+int comm_allreduce_i64_sum(long long* dev, size_t n);      // ... and the exact (fixed-point) sum of their row gradients
 
 }  // namespace goctr

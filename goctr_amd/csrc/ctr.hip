@@ -77,6 +77,7 @@ struct goctr_model {
   DevBuf<unsigned int> emb_mark, emb_rank, emb_tiles;
   DevBuf<unsigned long long> emb_total;
   DevBuf<long long> emb_accum;
+  DevBuf<int> emb_slot_id;
 };
 
 namespace {
@@ -245,7 +246,7 @@ int init_kernel_attrs() {
                           allow_big_lds(gemm_nn_kernel<float, E, 4>) || allow_big_lds(gemm_nn_kernel<float, E, 7>))
   if (GOCTR_NN_ATTR(EpiSigDrop) || GOCTR_NN_ATTR(EpiOut) || GOCTR_NN_ATTR(EpiDSig) || GOCTR_NN_ATTR(EpiStore) ||
       allow_big_lds(ctr_chain_kernel<7, 5, 0>) || allow_big_lds(ctr_chain_kernel<7, 5, 1>) ||
-      allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(ctr_fwd16_kernel<4, 5>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
+      allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(ctr_fwd16_kernel<4, 5>) || allow_big_lds(emb_grad_kernel<16>) || allow_big_lds(emb_grad_kernel<32>) || allow_big_lds(emb_grad_kernel<64>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>)) return -1;
   done = true;
   return 0;
@@ -431,10 +432,10 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   GOCTR_CHECK(c.D <= 64, "embedding training supports D <= 64 (got %d)", c.D);
   const int Np = round_up(2 * c.D, 16);
   const long long V = src.V;
-  const long long cap = std::min<long long>(V, (long long)B * (c.T + 1));
+  const long long cap = std::min<long long>(V, (long long)B * (c.T + 1) * e.world);   // the UNION of all ranks' ids gets slots
   if (m->emb_V != V || m->emb_B != B) {
     if (m->dpv.alloc((size_t)B * Np) || m->W0pvT.alloc((size_t)m->H1p * Np) || m->emb_mark.alloc((size_t)V) ||
-        m->emb_rank.alloc((size_t)V, false) || m->emb_total.alloc(1) || m->emb_accum.alloc((size_t)cap * c.D))
+        m->emb_rank.alloc((size_t)V, false) || m->emb_total.alloc(1) || m->emb_accum.alloc((size_t)cap * c.D) || m->emb_slot_id.alloc((size_t)cap, false))
       return -1;
     m->emb_V = V; m->emb_B = B;
   }
@@ -448,7 +449,11 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   ProfScope ps(GOCTR_K_EMB_TRAIN);
   hipLaunchKernelGGL(emb_mark_kernel, dim3((unsigned)cdiv((long long)B * (c.T + 1), 256)), dim3(256), 0, s, a);
   GOCTR_HIP(hipGetLastError());
-  if (exclusive_scan(m->emb_mark.p, V, m->emb_rank.p, m->emb_tiles, m->emb_total.p)) return -1;
+  // data parallel (replicated table): every rank numbers the union of the touched ids, so slot u means the same id
+  // everywhere and the ranks' fixed-point accumulators can be summed element-wise — an integer sum, hence exact and
+  // order-independent: the replicas stay bit-identical.
+  if (comm_allreduce_u32_max(m->emb_mark.p, (size_t)V)) return -1;
+  if (exclusive_scan_sink(m->emb_mark.p, V, m->emb_tiles, m->emb_total.p, EmbRankSink{m->emb_mark.p, m->emb_rank.p, m->emb_slot_id.p})) return -1;
   hipLaunchKernelGGL(w0pv_transpose_kernel, dim3((unsigned)cdiv((long long)m->H1p * Np, 256)), dim3(256), 0, s, m->W.p, m->H1p,
                      c.U, 2 * c.D, Np, m->W0pvT.p);
   GOCTR_HIP(hipGetLastError());
@@ -456,11 +461,23 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   EpiStore sp{m->dpv.p, Np};
   if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
   ProfScope ps(GOCTR_K_EMB_TRAIN);
-  const dim3 gb((unsigned)cdiv(B, 4));
-  if (c.D <= 16) hipLaunchKernelGGL(emb_grad_kernel<16>, gb, dim3(256), 0, s, a);
-  else if (c.D <= 32) hipLaunchKernelGGL(emb_grad_kernel<32>, gb, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(emb_grad_kernel<64>, gb, dim3(256), 0, s, a);
-  hipLaunchKernelGGL(emb_apply_kernel, dim3((unsigned)cdiv(V, 256)), dim3(256), 0, s, a);
+  // two 1024-thread workgroups per CU, each with a <= 72 KB LDS cache of hot rows
+  int nslot = 1;
+  while ((size_t)nslot * 2 * (c.D * sizeof(long long) + sizeof(int)) <= 72u * 1024u) nslot *= 2;
+  if (env_int("GOCTR_EMB_NSLOT", 0) > 0) nslot = env_int("GOCTR_EMB_NSLOT", 0);   // (experiments: power of two)
+  const size_t lds = (size_t)nslot * (c.D * sizeof(long long) + sizeof(int));
+  const int cus = e.compute_units > 0 ? e.compute_units : 256;
+  const dim3 gb((unsigned)std::min<long long>(cdiv(B, EMB_GRAD_THREADS / 64), 2 * cus));
+  if (c.D <= 16) hipLaunchKernelGGL(emb_grad_kernel<16>, gb, dim3(EMB_GRAD_THREADS), lds, s, a, nslot);
+  else if (c.D <= 32) hipLaunchKernelGGL(emb_grad_kernel<32>, gb, dim3(EMB_GRAD_THREADS), lds, s, a, nslot);
+  else hipLaunchKernelGGL(emb_grad_kernel<64>, gb, dim3(EMB_GRAD_THREADS), lds, s, a, nslot);
+  if (e.comm_active()) {
+    unsigned long long n_union = 0;
+    if (m->emb_total.download(&n_union, 1)) return -1;    // (host sync: the exchange is sized by the union, not by its bound)
+    if (comm_allreduce_i64_sum(m->emb_accum.p, (size_t)n_union * c.D)) return -1;
+  }
+  hipLaunchKernelGGL(emb_apply_kernel, dim3((unsigned)std::min<long long>(cdiv(cap * c.D, 256), 16 * cus)), dim3(256), 0, s, a,
+                     m->emb_slot_id.p, m->emb_total.p);
   GOCTR_HIP(hipGetLastError());
   return 0;
 }
@@ -705,7 +722,8 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
   if (ensure_workspace(m, B)) return -1;
   RowSource src = make_source(d, emb);
   StepOpts o = opts_from(tc);
-  const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0;
+  // (with a communicator the sparse embedding exchange sizes a collective from a device counter: eager steps)
+  const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0 && !(e.comm_active() && m->emb_lr > 0.f);
   if (use_graph) {
     if (!graph_matches(m->graph, d, emb, B, o) && build_graph(m, d, emb, src, B, o)) return -1;
     for (int s = 0; s < n_steps; ++s) {
@@ -949,7 +967,6 @@ int goctr_model_set_embedding_training(goctr_model* m, double lr) {
   GOCTR_CHECK(m && lr >= 0 && lr == lr, "goctr_model_set_embedding_training: bad arguments");
   std::lock_guard<std::mutex> lk(m->mu);
   GOCTR_CHECK(lr == 0 || m->cfg.D <= 64, "embedding training supports D <= 64 (got %d)", m->cfg.D);
-  GOCTR_CHECK(lr == 0 || !engine().comm_active(), "embedding training is single-GPU in this build (the sparse exchange is not implemented)");
   m->emb_lr = (float)lr;
   m->graph.destroy();
   return 0;

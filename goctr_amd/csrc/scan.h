@@ -30,11 +30,27 @@ __device__ __forceinline__ unsigned int block_exclusive_scan(unsigned int v, uns
   return base + inc - v;
 }
 
+// A tile is SCAN_SUB sub-tiles of SCAN_BLOCK * 4 items; thread t of sub-tile j owns items 4 t .. 4 t + 3 of it, fetched with
+// one 16-byte load (a wavefront reads 1 KiB contiguous).
+constexpr int SCAN_SUB = SCAN_ITEMS / 4;
+
+__device__ __forceinline__ uint4 scan_load4(const unsigned int* in, long long i, long long n) {
+  if (i + 3 < n) return *reinterpret_cast<const uint4*>(in + i);
+  uint4 v{0u, 0u, 0u, 0u};
+  if (i < n) v.x = in[i];
+  if (i + 1 < n) v.y = in[i + 1];
+  if (i + 2 < n) v.z = in[i + 2];
+  return v;
+}
+
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_sums_kernel(const unsigned int* in, long long n, unsigned int* tile_sum) {
-  const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
+  const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * 4;
   unsigned int s = 0;
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) s += base + k < n ? in[base + k] : 0u;
+  for (int j = 0; j < SCAN_SUB; ++j) {
+    const uint4 v = scan_load4(in, base + (long long)j * SCAN_BLOCK * 4, n);
+    s += v.x + v.y + v.z + v.w;
+  }
   unsigned int tot;
   block_exclusive_scan(s, &tot);
   if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
@@ -54,32 +70,51 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_offsets_kernel(unsigned 
   if (threadIdx.x == 0) *total = carry;
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const unsigned int* in, long long n, const unsigned int* tile_off, unsigned int* out) {
-  const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * SCAN_ITEMS;
-  unsigned int v[SCAN_ITEMS], s = 0;
+// sink(i, value, rank) sees every element once with its exclusive prefix sum
+template <class Sink>
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const unsigned int* in, long long n, const unsigned int* tile_off, Sink sink) {
+  const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * 4;
+  uint4 v[SCAN_SUB];
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) { v[k] = base + k < n ? in[base + k] : 0u; s += v[k]; }
-  unsigned int tot;
-  unsigned int run = tile_off[blockIdx.x] + block_exclusive_scan(s, &tot);
+  for (int j = 0; j < SCAN_SUB; ++j) v[j] = scan_load4(in, base + (long long)j * SCAN_BLOCK * 4, n);
+  unsigned int carry = tile_off[blockIdx.x];
 #pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    if (base + k < n) out[base + k] = run;
-    run += v[k];
+  for (int j = 0; j < SCAN_SUB; ++j) {
+    const long long i = base + (long long)j * SCAN_BLOCK * 4;
+    unsigned int tot;
+    unsigned int run = carry + block_exclusive_scan(v[j].x + v[j].y + v[j].z + v[j].w, &tot);
+    carry += tot;
+    if (i < n) sink(i, v[j].x, run);
+    run += v[j].x;
+    if (i + 1 < n) sink(i + 1, v[j].y, run);
+    run += v[j].y;
+    if (i + 2 < n) sink(i + 2, v[j].z, run);
+    run += v[j].z;
+    if (i + 3 < n) sink(i + 3, v[j].w, run);
   }
 }
 
-int exclusive_scan(const unsigned int* in, long long n, unsigned int* out, DevBuf<unsigned int>& tiles_buf,
-                   unsigned long long* total_dev) {
+struct ScanStore {
+  unsigned int* out;
+  __device__ __forceinline__ void operator()(long long i, unsigned int, unsigned int rank) const { out[i] = rank; }
+};
+
+template <class Sink>
+int exclusive_scan_sink(const unsigned int* in, long long n, DevBuf<unsigned int>& tiles_buf, unsigned long long* total_dev, Sink sink) {
   const long long tiles = cdiv(n, SCAN_TILE);
   if (tiles_buf.ensure((size_t)tiles, false)) return -1;
   hipStream_t s = engine().stream;
   hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, s, in, n, tiles_buf.p);
   hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, tiles_buf.p, tiles, total_dev);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, s, in, n, tiles_buf.p, out);
+  hipLaunchKernelGGL((scan_apply_kernel<Sink>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, s, in, n, tiles_buf.p, sink);
   GOCTR_HIP(hipGetLastError());
   return 0;
 }
 
+int exclusive_scan(const unsigned int* in, long long n, unsigned int* out, DevBuf<unsigned int>& tiles_buf,
+                   unsigned long long* total_dev) {
+  return exclusive_scan_sink(in, n, tiles_buf, total_dev, ScanStore{out});
+}
 
 }  // namespace
 }  // namespace goctr

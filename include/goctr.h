@@ -77,7 +77,8 @@ int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n
 /* EXTENSION with no reference counterpart (the reference trains with frozen embeddings, din.go:161-169 /
  * dnn.go:152-154; SURVEY F3, 8(e) "Trainable embeddings"): lr > 0 makes every following training step on an id-mode
  * dataset also update the rows of the goctr_emb table it is given,  E[id] -= lr * dCost/dE[id]  (plain SGD
- * scatter-add, deterministic).  lr = 0 (the default) restores the reference's semantics.  Single-GPU; D <= 64. */
+ * scatter-add, deterministic).  lr = 0 (the default) restores the reference's semantics.  D <= 64.  With a communicator
+ * the table is replicated: the ranks exchange the union of touched ids and the exact sum of their row gradients. */
 int goctr_model_set_embedding_training(goctr_model* m, double lr);
 /* resets the Adam moments and the step counter (a fresh gorgonia AdamSolver, model.go:88) */
 int goctr_model_reset_optimizer(goctr_model* m);

@@ -174,3 +174,74 @@ def test_mlp_sharded_gradient_world2(tmp_path):
     mp.spawn(_mlp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     err, scale = np.load(out)
     assert scale > 1e-3 and err <= 1e-14 * max(1.0, scale)
+
+
+# ---------------------------------------------------------------- trainable-embedding extension, world 2
+def _emb_case():
+    rng = np.random.default_rng(21)
+    Bg, Ue, Te, De, Ce, V = 8, 5, 6, 8, 4, 19
+    ub = rng.integers(-1, V, size=(Bg, Te)).astype(np.int32)
+    items = rng.integers(0, V, size=Bg).astype(np.int32)
+    uf = rng.random((Bg, Ue), dtype=np.float32)
+    cf = rng.random((Bg, Ce), dtype=np.float32)
+    y = (rng.random(Bg) < 0.5).astype(np.float32)
+    E = rng.standard_normal((V, De)) * 0.5
+    return Bg, Ue, Te, De, Ce, V, ub, items, uf, cf, y, E
+
+
+def _emb_model(pyoracle, Ue, Te, De, Ce):
+    m = pyoracle.CtrModel(pyoracle.DIN, Ue, Te, De, Ce, H1=16, H2=8)
+    rng = np.random.default_rng(2)
+    for w in (m.W0, m.W1, m.W2):
+        w[:] = (rng.standard_normal(w.shape) * 0.3).astype(np.float32)
+    return m
+
+
+def _emb_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pyoracle
+    Bg, Ue, Te, De, Ce, V, ub, items, uf, cf, y, E = _emb_case()
+    m = _emb_model(pyoracle, Ue, Te, De, Ce)
+    n = Bg // world
+    sl = slice(rank * n, (rank + 1) * n)
+    # the device's exchange (csrc/emb_train.h + launch_emb_train): marks -> MAX, slots = exclusive scan of the union,
+    # row gradients scaled by 1/B_global, accumulated in 2^-44 fixed point -> integer SUM
+    _, dE = m.emb_loss_grad(E, ub[sl], items[sl], uf[sl], cf[sl], y[sl])             # mean over n local rows
+    dE = dE * (n / Bg)
+    mark = torch.from_numpy((np.abs(dE).sum(axis=1) > 0).astype(np.int32))
+    local_touched = mark.clone()
+    dist.all_reduce(mark, op=dist.ReduceOp.MAX)
+    slot = np.cumsum(mark.numpy()) - mark.numpy()
+    n_union = int(mark.sum())
+    acc = np.zeros((n_union, De), np.int64)
+    for i in np.nonzero(local_touched.numpy())[0]:
+        acc[slot[i]] = np.rint(dE[i] * 2.0 ** 44).astype(np.int64)
+    t = torch.from_numpy(acc)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    upd = np.zeros_like(E)
+    upd[np.nonzero(mark.numpy())[0]] = t.numpy().astype(np.float64) * 2.0 ** -44
+    if rank == 0:
+        out.put(upd)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_embedding_sparse_exchange_world2(oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_emb_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    upd = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    Bg, Ue, Te, De, Ce, V, ub, items, uf, cf, y, E = _emb_case()
+    _, full = _emb_model(oracle, Ue, Te, De, Ce).emb_loss_grad(E, ub, items, uf, cf, y)
+    assert np.abs(full).max() > 1e-4
+    assert np.abs(upd - full).max() <= 2.0 ** -43 * 2 + 1e-12      # exact up to the fixed-point rounding of each rank

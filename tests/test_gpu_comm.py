@@ -141,3 +141,50 @@ def test_mlp_data_parallel_step_one_rank(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(np.load(out))
     assert np.isfinite(res[0]).all() and np.array_equal(res[0], res[1])
+
+
+EMB_SCRIPT = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %(root)r)
+from goctr_amd import capi, model as gm
+capi.init(0)
+L = capi.load()
+if %(comm)d:
+    idbuf = (C.c_uint8 * 128)()
+    capi.check(L.goctr_comm_unique_id(idbuf))
+    capi.check(L.goctr_comm_init(C.c_int(0), C.c_int(1), idbuf))
+rng = np.random.default_rng(5)
+rows, U, T, D, Cc, V = 2048, 52, 20, 16, 53, 300
+emb = (rng.standard_normal((V, D)) * 0.25).astype(np.float32)
+ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
+it = rng.integers(0, V, size=rows).astype(np.int32)
+uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+y = (rng.random(rows) < 0.5).astype(np.float32)
+tab = gm.EmbeddingTable(emb); ds = gm.Dataset.ids(ub, it, uf, cf, y)
+m = gm.DinNet(U, T, D, D, Cc).init_gaussian(np.random.default_rng(1))
+m.set_embedding_training(0.5)
+cfg = capi.default_train_cfg(batch=512, epochs=1)
+gm.train_steps(m, ds, cfg, 5, emb=tab)
+capi.sync()
+out = np.concatenate([m.get_weights(n).ravel() for n in ("mlp0", "mlp1", "mlp2", "att0")] + [tab.get_rows().ravel()])
+np.save(%(out)r, out)
+if %(comm)d:
+    capi.check(L.goctr_comm_destroy())
+'''
+
+
+def test_embedding_training_exchange_one_rank(tmp_path):
+    """the sparse embedding exchange (ncclAllReduce MAX over the touched-id marks, ncclAllReduce SUM over the int64
+    fixed-point accumulators, eager steps) with a one-rank communicator: both collectives are the identity and the sum
+    is an integer sum, so table and weights must equal the single-GPU graph-replayed run bit for bit"""
+    res = []
+    for comm in (0, 1):
+        out = str(tmp_path / f"emb_{comm}.npy")
+        env = dict(os.environ)
+        env["GOCTR_FORCE_COMM"] = str(comm)
+        r = subprocess.run([sys.executable, "-c", EMB_SCRIPT % dict(root=ROOT, comm=comm, out=out)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    assert np.isfinite(res[0]).all()
+    assert np.array_equal(res[0], res[1])
