@@ -77,6 +77,13 @@ class CtrNet {  // the device twin of model.Model (model.go:16-25)
   CtrNet& operator=(const CtrNet&) = delete;
   goctr_model* Vm() const { return h_; }
   void SetWeights(int tensor, const std::vector<float>& w) { check(goctr_model_set_weights(h_, tensor, w.data(), w.size())); }
+  // checkpoint / resume: Adam moments (which = 0 first, 1 second) and the step counter
+  void SetMoments(int tensor, int which, const std::vector<float>& w) { check(goctr_model_set_moments(h_, tensor, which, w.data(), w.size())); }
+  void GetMoments(int tensor, int which, std::vector<float>& w) const { check(goctr_model_get_moments(h_, tensor, which, w.data(), w.size())); }
+  uint32_t Step() const { uint32_t s = 0; check(goctr_model_get_step(h_, &s)); return s; }
+  void SetStep(uint32_t s) { check(goctr_model_set_step(h_, s)); }
+  // EXTENSION (no reference counterpart): lr > 0 trains the embedding table too (SGD scatter-add)
+  void SetEmbeddingTraining(double lr) { check(goctr_model_set_embedding_training(h_, lr)); }
   std::vector<float> GetWeights(int tensor) const {
     const int I = U + 2 * D + C;
     const size_t n = tensor == GOCTR_W0 ? (size_t)I * mlp0_1 : tensor == GOCTR_W1 ? (size_t)mlp0_1 * mlp1_2
@@ -214,6 +221,46 @@ inline Model TrainEmbedding(const std::vector<int64_t>& counts, const std::vecto
   m.vectors.resize(counts.size() * (size_t)dim);
   check(goctr_w2v_export_f32(h, m.vectors.data()));
   goctr_w2v_destroy(h);
+  return m;
+}
+
+// The same with the corpus load on the device (memory.go:76-102, dictionary.go:70-81, memory.go:53-62): the caller hands
+// over the ItemSeqGenerator batches as int64 item ids; `ids` of the result is Dictionary.id2word.
+struct IdModel : Model { std::vector<int64_t> ids; };
+inline IdModel TrainEmbeddingIds(const std::vector<std::vector<int64_t>>& batches, int window, int dim, int iter,
+                                 int64_t min_count = 5, int64_t max_count = -1, double subsample = 1e-3, uint64_t seed = 1) {
+  check(goctr_init(0));
+  int64_t cap = 0;
+  for (const auto& b : batches) cap += (int64_t)b.size();
+  goctr_corpus* c = nullptr;
+  check(goctr_corpus_create(std::max<int64_t>(cap, 1), &c));
+  for (const auto& b : batches) check(goctr_corpus_append(c, b.data(), (int64_t)b.size()));
+  check(goctr_corpus_build(c, min_count, max_count));
+  int64_t n_words = 0, V = 0;
+  check(goctr_corpus_info(c, &n_words, &V, nullptr));
+  goctr_w2v_cfg cfg;
+  goctr_w2v_cfg_default(&cfg);
+  cfg.dim = dim; cfg.window = window;
+  goctr_w2v* h = nullptr;
+  check(goctr_w2v_create_from_corpus(&cfg, c, &h));
+  std::mt19937_64 g(seed);
+  std::uniform_real_distribution<double> ud(0.0, 1.0);
+  std::vector<double> param((size_t)V * (size_t)dim);
+  for (auto& v : param) v = (ud(g) - 0.5) / dim;
+  check(goctr_w2v_set_param(h, param.data()));
+  double lr = cfg.init_lr;
+  for (int it = 0; it < iter; ++it) {
+    check(goctr_w2v_use_corpus(h, c, subsample, seed + (uint64_t)it));
+    check(goctr_w2v_train_resident(h, n_words, &lr));
+  }
+  IdModel m;
+  m.V = V; m.dim = dim;
+  m.ids.resize((size_t)V);
+  check(goctr_corpus_get_dictionary(c, m.ids.data(), nullptr));
+  m.vectors.resize((size_t)V * (size_t)dim);
+  check(goctr_w2v_export_f32(h, m.vectors.data()));
+  goctr_w2v_destroy(h);
+  goctr_corpus_destroy(c);
   return m;
 }
 }  // namespace embedding
