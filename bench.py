@@ -60,14 +60,14 @@ def synth(rows: int, seed: int):
     return emb, ub, it, uf, cf, y
 
 
-def init_weights(m, seed):
+def init_weights(m, seed, scale=1.0):
     from goctr_amd import model as gm  # noqa: F401
     rng = np.random.default_rng(seed)
     I = CFG["U"] + 2 * CFG["D"] + CFG["C"]
     # random-init weights of the reference architecture (N(0,1) like din.go:187-191)
-    m.set_weights("mlp0", rng.standard_normal((I, CFG["H1"])).astype(np.float32))
-    m.set_weights("mlp1", rng.standard_normal((CFG["H1"], CFG["H2"])).astype(np.float32))
-    m.set_weights("mlp2", rng.standard_normal((CFG["H2"], 1)).astype(np.float32))
+    m.set_weights("mlp0", (rng.standard_normal((I, CFG["H1"])) * scale).astype(np.float32))
+    m.set_weights("mlp1", (rng.standard_normal((CFG["H1"], CFG["H2"])) * scale).astype(np.float32))
+    m.set_weights("mlp2", (rng.standard_normal((CFG["H2"], 1)) * scale).astype(np.float32))
 
 
 def kernel_work():
@@ -384,7 +384,10 @@ def main():
     tab = gm.EmbeddingTable(emb)
     ds = gm.Dataset.ids(ub, it, uf, cf, y)
     m = (gm.YoutubeDnn if c["KIND"] == "youtube" else gm.DinNet)(c["U"], c["T"], c["D"], c["D"], c["C"])
-    init_weights(m, 1)                                   # same weights on every rank
+    # same weights on every rank.  With --train-emb the weights are 0.05 N(0,1): the reference's N(0,1) init saturates the
+    # sigmoids, most row gradients underflow to exactly 0 and the scatter-add (which skips zeros) would look cheaper than
+    # it is on a model that is actually learning
+    init_weights(m, 1, 0.05 if args.train_emb > 0 else 1.0)
     cfg = capi.default_train_cfg(batch=c["B"], epochs=1)
     if args.train_emb > 0:
         m.set_embedding_training(args.train_emb)
@@ -424,7 +427,7 @@ def main():
     }
     if args.train_emb > 0:
         out["config"]["workload"] += (f"; EXTENSION: embedding table trained too (SGD scatter-add, lr {args.train_emb}; "
-                                      "the reference keeps it frozen)")
+                                      "the reference keeps it frozen; weights 0.05 N(0,1) so that the row gradients are non-zero)")
         out["config"]["train_embeddings"] = True
 
     if args.host_rows and rank == 0:

@@ -246,7 +246,9 @@ int init_kernel_attrs() {
                           allow_big_lds(gemm_nn_kernel<float, E, 4>) || allow_big_lds(gemm_nn_kernel<float, E, 7>))
   if (GOCTR_NN_ATTR(EpiSigDrop) || GOCTR_NN_ATTR(EpiOut) || GOCTR_NN_ATTR(EpiDSig) || GOCTR_NN_ATTR(EpiStore) ||
       allow_big_lds(ctr_chain_kernel<7, 5, 0>) || allow_big_lds(ctr_chain_kernel<7, 5, 1>) ||
-      allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(ctr_fwd16_kernel<4, 5>) || allow_big_lds(emb_grad_kernel<16>) || allow_big_lds(emb_grad_kernel<32>) || allow_big_lds(emb_grad_kernel<64>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
+      allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(ctr_fwd16_kernel<4, 5>) || allow_big_lds(emb_grad_kernel<16, 0, true>) || allow_big_lds(emb_grad_kernel<16, 1, true>) || allow_big_lds(emb_grad_kernel<16, 2, true>) || allow_big_lds(emb_grad_kernel<32, 0, true>) ||
+      allow_big_lds(emb_grad_kernel<32, 1, true>) || allow_big_lds(emb_grad_kernel<32, 2, true>) || allow_big_lds(emb_grad_kernel<64, 0, true>) || allow_big_lds(emb_grad_kernel<64, 1, true>) ||
+      allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>)) return -1;
   done = true;
   return 0;
@@ -423,6 +425,18 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
 // backward part up to and including the slab reduce: kernels 5-12
 AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc);
 
+template <int GS, bool CACHE>
+void launch_emb_grad2(int mode, dim3 gb, size_t lds, hipStream_t s, const EmbTrainArgs& a, int nslot) {
+  if (mode == 0) hipLaunchKernelGGL((emb_grad_kernel<GS, 0, CACHE>), gb, dim3(EMB_GRAD_THREADS), lds, s, a, nslot);
+  else if (mode == 1) hipLaunchKernelGGL((emb_grad_kernel<GS, 1, CACHE>), gb, dim3(EMB_GRAD_THREADS), lds, s, a, nslot);
+  else hipLaunchKernelGGL((emb_grad_kernel<GS, 2, CACHE>), gb, dim3(EMB_GRAD_THREADS), lds, s, a, nslot);
+}
+template <int GS>
+void launch_emb_grad(int mode, bool cache, dim3 gb, size_t lds, hipStream_t s, const EmbTrainArgs& a, int nslot) {
+  if (cache) launch_emb_grad2<GS, true>(mode, gb, lds, s, a, nslot);
+  else launch_emb_grad2<GS, false>(mode, gb, 0, s, a, nslot);
+}
+
 // Sparse embedding update of one step (emb_train.h).  Runs after every reader of the table in this step (attn_fwd,
 // attn_bwd's re-gather) and before the step state advances.
 int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepState* st) {
@@ -443,7 +457,7 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   a.src = src; a.st = st; a.B = B; a.T = c.T; a.D = c.D; a.kind = c.kind; a.att = c.att;
   a.dpv = m->dpv.p; a.ldp = Np; a.gate = m->gate.p; a.wgt = m->wgt.p; a.att0 = m->W.p + m->offa;
   a.emb = const_cast<float*>(src.emb); a.V = V;
-  a.mark = m->emb_mark.p; a.rank = m->emb_rank.p; a.accum = m->emb_accum.p; a.lr = m->emb_lr;
+  a.mark = m->emb_mark.p; a.rank = m->emb_rank.p; a.accum = m->emb_accum.p; a.lr = m->emb_lr; a.dbg = env_int("GOCTR_EMB_DBG", 0);
   hipStream_t s = e.stream;
   {
   ProfScope ps(GOCTR_K_EMB_TRAIN);
@@ -461,16 +475,21 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   EpiStore sp{m->dpv.p, Np};
   if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
   ProfScope ps(GOCTR_K_EMB_TRAIN);
-  // two 1024-thread workgroups per CU, each with a <= 72 KB LDS cache of hot rows
+  // one 1024-thread workgroup per CU (the kernel's register count allows no second one) with a <= 136 KB LDS cache of hot rows
   int nslot = 1;
-  while ((size_t)nslot * 2 * (c.D * sizeof(long long) + sizeof(int)) <= 72u * 1024u) nslot *= 2;
+  while ((size_t)nslot * 2 * (c.D * sizeof(long long) + sizeof(int)) <= 136u * 1024u) nslot *= 2;
   if (env_int("GOCTR_EMB_NSLOT", 0) > 0) nslot = env_int("GOCTR_EMB_NSLOT", 0);   // (experiments: power of two)
   const size_t lds = (size_t)nslot * (c.D * sizeof(long long) + sizeof(int));
   const int cus = e.compute_units > 0 ? e.compute_units : 256;
-  const dim3 gb((unsigned)std::min<long long>(cdiv(B, EMB_GRAD_THREADS / 64), 2 * cus));
-  if (c.D <= 16) hipLaunchKernelGGL(emb_grad_kernel<16>, gb, dim3(EMB_GRAD_THREADS), lds, s, a, nslot);
-  else if (c.D <= 32) hipLaunchKernelGGL(emb_grad_kernel<32>, gb, dim3(EMB_GRAD_THREADS), lds, s, a, nslot);
-  else hipLaunchKernelGGL(emb_grad_kernel<64>, gb, dim3(EMB_GRAD_THREADS), lds, s, a, nslot);
+  const dim3 gb((unsigned)std::min<long long>(cdiv(B, EMB_GRAD_THREADS / 64), cus));
+  const int mode = c.kind != GOCTR_DIN ? 0 : (c.att == GOCTR_ATT_COSINE ? 1 : 2);
+  // GOCTR_EMB_CACHE=0 (experiments) sends every add straight to HBM: 5x slower at cfg3 AND at cfg4 — a Zipfian head is
+  // hot in a 10^7-row vocabulary too
+  const bool cache = env_int("GOCTR_EMB_CACHE", 1) != 0;
+  const dim3 gg = cache ? gb : dim3((unsigned)std::min<long long>(cdiv(B, EMB_GRAD_THREADS / 64), 8 * cus));
+  if (c.D <= 16) launch_emb_grad<16>(mode, cache, gg, lds, s, a, nslot);
+  else if (c.D <= 32) launch_emb_grad<32>(mode, cache, gg, lds, s, a, nslot);
+  else launch_emb_grad<64>(mode, cache, gg, lds, s, a, nslot);
   if (e.comm_active()) {
     unsigned long long n_union = 0;
     if (m->emb_total.download(&n_union, 1)) return -1;    // (host sync: the exchange is sized by the union, not by its bound)

@@ -44,6 +44,7 @@ struct EmbTrainArgs {
   const unsigned int* rank;        // [V]
   long long* accum;                // [min(V, B (T+1)), D]
   float lr;
+  int dbg;                         // timing experiments only (GOCTR_EMB_DBG): 1 skip the flush, 2 skip cache misses, 4 skip LDS adds
 };
 
 __global__ void emb_mark_kernel(EmbTrainArgs a) {
@@ -72,7 +73,30 @@ __device__ __forceinline__ float emb_group_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ long long emb_fix(float g) { return __double2ll_rn((double)g * EMB_FIX_SCALE); }
+// integer twin of group_sum (ctr_kernels.h): DPP inside a 16-lane row, LDS crossbar only across rows
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int GS>
+__device__ __forceinline__ int emb_group_sum_int(int v) {
+  if (GS >= 2) v += dpp_i32<0xB1>(v);
+  if (GS >= 4) v += dpp_i32<0x4E>(v);
+  if (GS >= 8) v += dpp_i32<0x141>(v);
+  if (GS >= 16) v += dpp_i32<0x140>(v);
+  if (GS >= 32) v += __shfl_xor(v, 16, 64);
+  if (GS >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// rint(g * 2^44) without float64 / 64-bit conversions (both are multi-instruction sequences here): g 2^20 = hi + rem with hi
+// = rint(g 2^20) and rem exact in float32, so g 2^44 = hi 2^24 + rem 2^24 exactly and rint() only touches the second term.
+// |g| is clamped to 2^10 (a row gradient of that size is a diverged run anyway).
+__device__ __forceinline__ long long emb_fix(float g) {
+  g = g == g ? fminf(fmaxf(g, -1024.0f), 1024.0f) : 0.0f;       // (a NaN gradient updates nothing)
+  const float s = g * 1048576.0f;
+  const float hi = rintf(s);
+  const float lo = rintf((s - hi) * 16777216.0f);
+  return ((long long)(int)hi << 24) + (long long)(int)lo;
+}
 
 // LDS staging of hot rows: item popularity is Zipfian, and global atomics on one row serialise (the same effect as in
 // the dictionary build, corpus.hip).  Each workgroup owns a direct-mapped cache of NSLOT rows of 64-bit accumulators in
@@ -85,101 +109,160 @@ struct EmbCache {
   int nslot;         // power of two
 };
 
-template <int GS>
-__device__ __forceinline__ void emb_accumulate(const EmbTrainArgs& a, const EmbCache& c, int id, int l, bool act, float g) {
-  const unsigned int slot = ((unsigned int)id * 2654435761u >> 7) & (unsigned int)(c.nslot - 1);
-  int tag = 0;
-  if (l == 0) {
-    tag = c.tag[slot];
-    if (tag == -1) {
-      const int old = atomicCAS(&c.tag[slot], -1, id);
-      tag = old == -1 ? id : old;
-    }
+// cache lookup of one id by the lane group's lane 0: returns the slot's owner after trying to claim an empty slot
+__device__ __forceinline__ int emb_cache_claim(const EmbCache& c, unsigned int slot, int id) {
+  int tag = c.tag[slot];
+  if (tag == -1) {
+    const int old = atomicCAS(&c.tag[slot], -1, id);
+    tag = old == -1 ? id : old;
   }
-  tag = __shfl(tag, (threadIdx.x & 63) / GS * GS, 64);       // the group's lane 0
-  if (!act) return;
-  const long long q = emb_fix(g);
-  if (q == 0) return;
-  if (tag == id) atomicAdd(reinterpret_cast<unsigned long long*>(c.acc + (size_t)slot * a.D + l), (unsigned long long)q);
-  else atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)a.rank[id] * a.D + l), (unsigned long long)q);
+  return tag;
 }
 
-// One wavefront per sample at a time, 64 / GS lane groups; a group owns slots t = grp, grp + NG, ...; lane l of a
-// group owns embedding component l (D <= GS <= 64).  Workgroup w takes samples 16 w .. 16 w + 15, then strides by the grid.
-constexpr int EMB_GRAD_THREADS = 1024;   // 16 wavefronts share one cache; two workgroups per CU hide the id -> row -> atomic latency chain
+__device__ __forceinline__ unsigned int emb_cache_slot(const EmbCache& c, int id) {
+  return ((unsigned int)id * 2654435761u >> 7) & (unsigned int)(c.nslot - 1);
+}
 
-template <int GS>
+__device__ __forceinline__ void emb_add(const EmbTrainArgs& a, const EmbCache& c, int id, unsigned int slot, int tag, int l, float g) {
+  const long long q = emb_fix(g);
+  if (q == 0) return;
+  if (tag == id) { if (!(a.dbg & 4)) atomicAdd(reinterpret_cast<unsigned long long*>(c.acc + (size_t)slot * a.D + l), (unsigned long long)q); }
+  else if (!(a.dbg & 2)) atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)a.rank[id] * a.D + l), (unsigned long long)q);
+}
+
+constexpr int EMB_PASS = 4;               // rows a lane group has in flight
+constexpr int EMB_GRAD_THREADS = 1024;   // 16 wavefronts share one cache, one workgroup per CU
+
+// MODE: 0 = YouTube mean pooling, 1 = DIN cosine, 2 = DIN euclid — compile-time, like the attention kernels: run-time mode
+// branches inside the unrolled stages put a branch (and a wait) around every shuffle.
+// CACHE: false = no LDS staging (vocabularies much larger than the batch: almost every lookup would miss, and the
+// claim + broadcast per slot is pure overhead)
+template <int GS, int MODE, bool CACHE>
 __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs a, int nslot) {
   extern __shared__ __attribute__((aligned(16))) unsigned char emb_smem[];
   EmbCache c;
   c.nslot = nslot;
   c.acc = reinterpret_cast<long long*>(emb_smem);
   c.tag = reinterpret_cast<int*>(emb_smem + (size_t)nslot * a.D * sizeof(long long));
-  for (int i = threadIdx.x; i < nslot * a.D; i += EMB_GRAD_THREADS) c.acc[i] = 0;
-  for (int i = threadIdx.x; i < nslot; i += EMB_GRAD_THREADS) c.tag[i] = -1;
-  __syncthreads();
+  if (CACHE) {
+    for (int i = threadIdx.x; i < nslot * a.D; i += EMB_GRAD_THREADS) c.acc[i] = 0;
+    for (int i = threadIdx.x; i < nslot; i += EMB_GRAD_THREADS) c.tag[i] = -1;
+    __syncthreads();
+  }
   constexpr int NG = 64 / GS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l = lane % GS, grp = lane / GS;
   const int D = a.D, T = a.T;
   const bool act = l < D;
-  const bool din = a.kind == GOCTR_DIN, cosine = a.att == GOCTR_ATT_COSINE;
+  constexpr bool din = MODE != 0, cosine = MODE == 1;
   const float invT = 1.0f / (float)T;
   constexpr int WPB = EMB_GRAD_THREADS / 64;
-  for (int b = blockIdx.x * WPB + wave; b < a.B; b += gridDim.x * WPB) {
+  for (int b = blockIdx.x * WPB + wave; b < ((a.dbg & 8) ? 0 : a.B); b += gridDim.x * WPB) {
     const long long gr = a.st->batch_idx * (long long)a.B + b;
     if (gr >= a.src.rows) continue;                                 // padded row: no ids (wave-uniform)
     const int item = a.src.item_ids[gr];
     const bool item_ok = item >= 0 && item < a.V;
     const float v = (act && item_ok) ? a.emb[(long long)item * D + l] : 0.f;
     const float dp = act ? a.dpv[(size_t)b * a.ldp + l] : 0.f;
-    const float nv = sqrtf(emb_group_sum<GS>(v * v));
+    const float nv = sqrtf(group_sum<GS>(v * v));
+    const float inv_nv = nv > 0.f ? 1.0f / nv : 0.f;
     float dv = 0.f;
-    // software pipeline: the next slot's id and row are requested before this slot's arithmetic and atomics
-    int id_n = grp < T ? a.src.ub_ids[gr * T + grp] : -1;
-    float x_n = (act && id_n >= 0 && id_n < a.V) ? a.emb[(long long)id_n * D + l] : 0.f;
-    for (int t = grp; t < T; t += NG) {
-      const int id = id_n;
-      const float x = x_n;
-      id_n = t + NG < T ? a.src.ub_ids[gr * T + t + NG] : -1;
-      x_n = (act && id_n >= 0 && id_n < a.V) ? a.emb[(long long)id_n * D + l] : 0.f;
-      if (id < 0 || id >= a.V) continue;                            // (group-uniform)
-      float dx;
-      if (din) {
-        const float g = a.gate[(size_t)b * T + t];
-        dx = g * invT * dp;
-        const float q = emb_group_sum<GS>(dp * x) * invT * g * (1.0f - g) * a.att0[t];
-        if (cosine) {
-          const float sxx = emb_group_sum<GS>(x * x), sxy = emb_group_sum<GS>(x * v);
-          const float nx = sqrtf(sxx), den = nx * nv + 1e-8f;
-          const float cx = nx > 0.f ? sxy * nv / (nx * den * den) : 0.f;
-          const float cv = nv > 0.f ? sxy * nx / (nv * den * den) : 0.f;
-          dx += q * 0.5f * (v / den - cx * x);
-          dv += q * 0.5f * (x / den - cv * v);
-        } else {
-          const float df = x - v;
-          const float r = sqrtf(emb_group_sum<GS>(act ? df * df : 0.f));
-          if (r > 0.f) {
-            dx -= q * df / r;
-            dv += q * df / r;
+    // Memory chain per sample: ids + gates (one coalesced load each) -> all rows of a pass -> arithmetic; a pass is
+    // EMB_PASS slots per lane group, their row loads are issued back to back before any of them is used.
+    for (int tb = 0; tb < T; tb += 64) {
+      // the rows of pass p + 1 are requested before pass p is worked on (two passes in flight)
+      auto load_pass = [&](int pb, int (&ids)[EMB_PASS], float (&xs)[EMB_PASS]) {
+#pragma unroll
+        for (int k = 0; k < EMB_PASS; ++k) {
+          const int sl = pb + k * NG + grp;                         // slot within this 64-chunk
+          const bool in = sl < 64 && tb + sl < T;
+          const int id = in ? a.src.ub_ids[gr * T + tb + sl] : -1;   // one address per lane group: a broadcast load
+          ids[k] = (id >= 0 && id < a.V) ? id : -1;
+          xs[k] = (act && ids[k] >= 0 && !(a.dbg & 64)) ? a.emb[(long long)ids[k] * D + l] : 0.f;
+        }
+      };
+      int ids[EMB_PASS];
+      float xs[EMB_PASS];
+      load_pass(0, ids, xs);
+      for (int pb = 0; pb < 64 && tb + pb < T; pb += EMB_PASS * NG) {
+        int idn[EMB_PASS];
+        float xn[EMB_PASS];
+        load_pass(pb + EMB_PASS * NG, idn, xn);                     // (past the end: every slot comes back as -1, no loads)
+        // every stage runs over all slots of the pass before the next one starts, so the LDS-crossbar shuffles and the
+        // cache lookups of different slots are in flight together instead of one dependent chain per slot
+        float g[EMB_PASS], att[EMB_PASS], s0[EMB_PASS], s1[EMB_PASS], s2[EMB_PASS];
+        int tag[EMB_PASS];
+#pragma unroll
+        for (int k = 0; k < EMB_PASS; ++k) {
+          const int sl = pb + k * NG + grp;
+          const bool in = sl < 64 && tb + sl < T;
+          g[k] = (din && in) ? a.gate[(size_t)b * T + tb + sl] : 1.0f;
+          att[k] = (din && in) ? a.att0[tb + sl] : 0.f;
+          tag[k] = (CACHE && l == 0 && ids[k] >= 0 && !(a.dbg & 32)) ? emb_cache_claim(c, emb_cache_slot(c, ids[k]), ids[k]) : -1;
+          const float df = xs[k] - v;
+          s0[k] = dp * xs[k];
+          s1[k] = cosine ? xs[k] * xs[k] : (act ? df * df : 0.f);
+          s2[k] = xs[k] * v;
+        }
+        if (din) {
+#pragma unroll
+          for (int k = 0; k < EMB_PASS; ++k) {                      // DPP sums (VALU): the LDS crossbar is the scarce unit here
+            s0[k] = group_sum<GS>(s0[k]);
+            s1[k] = group_sum<GS>(s1[k]);
+            if (cosine) s2[k] = group_sum<GS>(s2[k]);
           }
         }
-      } else {
-        dx = invT * dp;
+#pragma unroll
+        for (int k = 0; k < EMB_PASS; ++k) tag[k] = CACHE ? emb_group_sum_int<GS>(l == 0 ? tag[k] + 1 : 0) - 1 : -1;   // broadcast of the group's lane 0
+#pragma unroll
+        for (int k = 0; k < EMB_PASS; ++k) {
+          const int id = ids[k];
+          if (id < 0 || (a.dbg & 16)) continue;                     // (group-uniform)
+          const float x = xs[k];
+          float dx;
+          if (din) {
+            dx = g[k] * invT * dp;
+            const float q = s0[k] * invT * g[k] * (1.0f - g[k]) * att[k];
+            if (cosine) {
+              const float sxx = s1[k], sxy = s2[k];
+              // reciprocals by v_rcp_f32 / v_rsq_f32 (1 ulp): the kernel is VALU-bound and an IEEE division is ~10 instructions
+              const float inx = sxx > 0.f ? __frsqrt_rn(sxx) : 0.f, nx = sxx * inx;
+              const float iden = __frcp_rn(nx * nv + 1e-8f);
+              const float h = 0.5f * q * iden, sc = sxy * iden;
+              dx += h * (v - sc * nv * inx * x);
+              dv += h * (x - sc * nx * inv_nv * v);
+            } else {
+              const float df = x - v;
+              const float ir = s1[k] > 0.f ? __frsqrt_rn(s1[k]) : 0.f;
+              dx -= q * df * ir;
+              dv += q * df * ir;
+            }
+          } else {
+            dx = invT * dp;
+          }
+          if (act) emb_add(a, c, id, emb_cache_slot(c, id), tag[k], l, dx);
+        }
+#pragma unroll
+        for (int k = 0; k < EMB_PASS; ++k) { ids[k] = idn[k]; xs[k] = xn[k]; }
       }
-      emb_accumulate<GS>(a, c, id, l, act, dx);
     }
     // candidate item: h0's item segment + the attention terms of every slot (sum over the lane groups)
 #pragma unroll
     for (int o = GS; o < 64; o <<= 1) dv += __shfl_xor(dv, o, 64);
-    if (grp == 0 && item_ok) emb_accumulate<GS>(a, c, item, l, act, dv + (act ? a.dpv[(size_t)b * a.ldp + D + l] : 0.f));
+    if (grp == 0 && item_ok) {
+      const unsigned int slot = emb_cache_slot(c, item);
+      int tg = (CACHE && l == 0) ? emb_cache_claim(c, slot, item) : -1;
+      if (CACHE) tg = emb_group_sum_int<GS>(l == 0 ? tg + 1 : 0) - 1;
+      if (act) emb_add(a, c, item, slot, tg, l, dv + a.dpv[(size_t)b * a.ldp + D + l]);
+    }
   }
+  if (!CACHE) return;
   __syncthreads();
   // flush the cached rows: one HBM atomic per (row, component) per workgroup
   for (int i = threadIdx.x; i < nslot * D; i += EMB_GRAD_THREADS) {
     const int tag = c.tag[i / D];
     const long long q = c.acc[i];
-    if (tag >= 0 && q) atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)a.rank[tag] * D + i % D), (unsigned long long)q);
+    if (tag >= 0 && q && !(a.dbg & 1)) atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)a.rank[tag] * D + i % D), (unsigned long long)q);
   }
 }
 
