@@ -461,13 +461,18 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   hipStream_t s = e.stream;
   {
   ProfScope ps(GOCTR_K_EMB_TRAIN);
-  hipLaunchKernelGGL(emb_mark_kernel, dim3((unsigned)cdiv((long long)B * (c.T + 1), 256)), dim3(256), 0, s, a);
+  // ids with a single occurrence are applied in place (emb_train.h); only without a communicator (another rank may touch
+  // the id too) and when the vocabulary is larger than the batch's id count (otherwise hardly any id is single)
+  const long long pairs = (long long)B * (c.T + 1);
+  const int singles = env_int("GOCTR_EMB_SINGLES", (!e.comm_active() && V > pairs) ? 1 : 0) != 0 && !e.comm_active();
+  hipLaunchKernelGGL(emb_mark_kernel, dim3((unsigned)cdiv(pairs, 256)), dim3(256), 0, s, a, singles);
+  if (singles) hipLaunchKernelGGL(emb_mark2_kernel, dim3((unsigned)cdiv(pairs, 256)), dim3(256), 0, s, a);
   GOCTR_HIP(hipGetLastError());
   // data parallel (replicated table): every rank numbers the union of the touched ids, so slot u means the same id
   // everywhere and the ranks' fixed-point accumulators can be summed element-wise — an integer sum, hence exact and
   // order-independent: the replicas stay bit-identical.
   if (comm_allreduce_u32_max(m->emb_mark.p, (size_t)V)) return -1;
-  if (exclusive_scan_sink(m->emb_mark.p, V, m->emb_tiles, m->emb_total.p, EmbRankSink{m->emb_mark.p, m->emb_rank.p, m->emb_slot_id.p})) return -1;
+  if (exclusive_scan_sink(m->emb_mark.p, V, m->emb_tiles, m->emb_total.p, EmbMultiMap{}, EmbRankSink{m->emb_mark.p, m->emb_rank.p, m->emb_slot_id.p})) return -1;
   hipLaunchKernelGGL(w0pv_transpose_kernel, dim3((unsigned)cdiv((long long)m->H1p * Np, 256)), dim3(256), 0, s, m->W.p, m->H1p,
                      c.U, 2 * c.D, Np, m->W0pvT.p);
   GOCTR_HIP(hipGetLastError());
@@ -475,14 +480,17 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   EpiStore sp{m->dpv.p, Np};
   if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
   ProfScope ps(GOCTR_K_EMB_TRAIN);
-  // one 1024-thread workgroup per CU (the kernel's register count allows no second one) with a <= 136 KB LDS cache of hot rows
+  // attention modes: one 1024-thread workgroup per CU (~90 VGPRs allow no second one) with a <= 136 KB LDS cache of hot
+  // rows; mean pooling fits two per CU (GOCTR_EMB_WGS=2, <= 72 KB each) but measured no faster (184 vs 178 us at cfg4)
+  const int mode = c.kind != GOCTR_DIN ? 0 : (c.att == GOCTR_ATT_COSINE ? 1 : 2);
+  const int wg_per_cu = mode == 0 ? env_int("GOCTR_EMB_WGS", 1) : 1;
+  const size_t budget = wg_per_cu > 1 ? 72u * 1024u : 136u * 1024u;
   int nslot = 1;
-  while ((size_t)nslot * 2 * (c.D * sizeof(long long) + sizeof(int)) <= 136u * 1024u) nslot *= 2;
+  while ((size_t)nslot * 2 * (c.D * sizeof(long long) + sizeof(int)) <= budget) nslot *= 2;
   if (env_int("GOCTR_EMB_NSLOT", 0) > 0) nslot = env_int("GOCTR_EMB_NSLOT", 0);   // (experiments: power of two)
   const size_t lds = (size_t)nslot * (c.D * sizeof(long long) + sizeof(int));
   const int cus = e.compute_units > 0 ? e.compute_units : 256;
-  const dim3 gb((unsigned)std::min<long long>(cdiv(B, EMB_GRAD_THREADS / 64), cus));
-  const int mode = c.kind != GOCTR_DIN ? 0 : (c.att == GOCTR_ATT_COSINE ? 1 : 2);
+  const dim3 gb((unsigned)std::min<long long>(cdiv(B, EMB_GRAD_THREADS / 64), (long long)wg_per_cu * cus));
   // GOCTR_EMB_CACHE=0 (experiments) sends every add straight to HBM: 5x slower at cfg3 AND at cfg4 — a Zipfian head is
   // hot in a 10^7-row vocabulary too
   const bool cache = env_int("GOCTR_EMB_CACHE", 1) != 0;

@@ -12,8 +12,9 @@
 //     E[id] -= lr * (sum of the row gradients of every occurrence of id in the batch)
 //
 // Launch sequence per step (all on the step's stream, inside the step's hipGraph):
-//   emb_mark      mark[id] = 1 for every id the batch touches                         (B (T+1) ids)
-//   scan x3       rank = exclusive prefix sum of mark over the vocabulary: the touched ids get dense slots 0..n-1 in
+//   emb_mark(2)   which ids does the batch touch, and (single GPU, vocabulary larger than the batch's id count) which of
+//                 them exactly once: those rows are updated in place by emb_grad, no accumulator, no emb_apply work
+//   scan x3       rank = exclusive prefix sum over the vocabulary: the ids that accumulate get dense slots 0..n-1 in
 //                 ASCENDING ID ORDER (deterministic numbering, no hashing, no sort); the last pass also writes the
 //                 slot -> id list and clears the marks
 //   w0pv_t, gemm  dpv[B, 2D] = dz0 . W0[U : U+2D, :]^T   (MFMA; dz0 is what the chain kernel already stored)
@@ -47,15 +48,32 @@ struct EmbTrainArgs {
   int dbg;                         // timing experiments only (GOCTR_EMB_DBG): 1 skip the flush, 2 skip cache misses, 4 skip LDS adds
 };
 
-__global__ void emb_mark_kernel(EmbTrainArgs a) {
-  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+constexpr unsigned int EMB_MULTI = 0xFFFFFFFFu;
+
+// mark[id]: 0 = untouched, EMB_MULTI = accumulate (gets a slot), p + 1 = touched by pair p only ("single").
+// singles == 0: every touched id is EMB_MULTI.  singles == 1: first pass — the last writer's pair index stays;
+// second pass (emb_mark2) — a pair that does not find its own index there knows the id has at least two pairs and
+// overwrites it with EMB_MULTI.  Which pair wins the first pass is arbitrary, the outcome is not: EMB_MULTI iff >= 2 pairs.
+__device__ __forceinline__ int emb_pair_id(const EmbTrainArgs& a, long long p) {
   const int per = a.T + 1;
-  if (p >= (long long)a.B * per) return;
+  if (p >= (long long)a.B * per) return -1;
   const int b = (int)(p / per), t = (int)(p % per);
   const long long gr = a.st->batch_idx * (long long)a.B + b;
-  if (gr >= a.src.rows) return;                                   // padded row: no ids
+  if (gr >= a.src.rows) return -1;                                // padded row: no ids
   const int id = t < a.T ? a.src.ub_ids[gr * a.T + t] : a.src.item_ids[gr];
-  if (id >= 0 && id < a.V) a.mark[id] = 1u;                       // idempotent: racing writers store the same value
+  return (id >= 0 && id < a.V) ? id : -1;
+}
+
+__global__ void emb_mark_kernel(EmbTrainArgs a, int singles) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int id = emb_pair_id(a, p);
+  if (id >= 0) a.mark[id] = singles ? (unsigned int)p + 1u : EMB_MULTI;
+}
+
+__global__ void emb_mark2_kernel(EmbTrainArgs a) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int id = emb_pair_id(a, p);
+  if (id >= 0 && a.mark[id] != (unsigned int)p + 1u) a.mark[id] = EMB_MULTI;
 }
 
 // W0pvT[k][n] = W0[U + n][k], n < 2D (zero beyond): the B operand of dpv = dz0 . W0[U:U+2D, :]^T
@@ -103,18 +121,23 @@ __device__ __forceinline__ long long emb_fix(float g) {
 // LDS: the first id that hashes to a slot claims it; its later occurrences inside this workgroup are LDS atomics, every
 // other id of that slot goes straight to HBM.  A workgroup walks B / gridDim.x samples, so a row that is hot in the
 // batch is hot in every workgroup and reaches HBM once per workgroup instead of once per occurrence.
+// (explicit LDS address space: through generic pointers the compiler falls back to flat atomics with a run-time
+// "is it LDS?" test, which this toolchain then fails to encode)
+typedef __attribute__((address_space(3))) int emb_lds_int;
+typedef __attribute__((address_space(3))) unsigned long long emb_lds_u64;
 struct EmbCache {
-  int* tag;          // [NSLOT] id or -1
-  long long* acc;    // [NSLOT, D]
-  int nslot;         // power of two
+  emb_lds_int* tag;      // [NSLOT] id or -1
+  emb_lds_u64* acc;      // [NSLOT, D]
+  int nslot;             // power of two
 };
 
 // cache lookup of one id by the lane group's lane 0: returns the slot's owner after trying to claim an empty slot
 __device__ __forceinline__ int emb_cache_claim(const EmbCache& c, unsigned int slot, int id) {
   int tag = c.tag[slot];
   if (tag == -1) {
-    const int old = atomicCAS(&c.tag[slot], -1, id);
-    tag = old == -1 ? id : old;
+    int expected = -1;
+    __hip_atomic_compare_exchange_strong(c.tag + slot, &expected, id, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    tag = expected == -1 ? id : expected;
   }
   return tag;
 }
@@ -123,10 +146,19 @@ __device__ __forceinline__ unsigned int emb_cache_slot(const EmbCache& c, int id
   return ((unsigned int)id * 2654435761u >> 7) & (unsigned int)(c.nslot - 1);
 }
 
+// An id with one occurrence in the batch needs no accumulator: its row is updated in place by the lane that holds it
+// (nobody else reads that row in this step), with the same 2^-44 rounding as the accumulate path so that both give the
+// same bits.
+__device__ __forceinline__ void emb_apply_single(const EmbTrainArgs& a, int id, int l, float row, float g) {
+  const long long q = emb_fix(g);
+  a.emb[(long long)id * a.D + l] = row - a.lr * (float)((double)q * EMB_FIX_INV);
+  if (l == 0) a.mark[id] = 0u;
+}
+
 __device__ __forceinline__ void emb_add(const EmbTrainArgs& a, const EmbCache& c, int id, unsigned int slot, int tag, int l, float g) {
   const long long q = emb_fix(g);
   if (q == 0) return;
-  if (tag == id) { if (!(a.dbg & 4)) atomicAdd(reinterpret_cast<unsigned long long*>(c.acc + (size_t)slot * a.D + l), (unsigned long long)q); }
+  if (tag == id) { if (!(a.dbg & 4)) __hip_atomic_fetch_add(c.acc + (size_t)slot * a.D + l, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   else if (!(a.dbg & 2)) atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)a.rank[id] * a.D + l), (unsigned long long)q);
 }
 
@@ -142,8 +174,8 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
   extern __shared__ __attribute__((aligned(16))) unsigned char emb_smem[];
   EmbCache c;
   c.nslot = nslot;
-  c.acc = reinterpret_cast<long long*>(emb_smem);
-  c.tag = reinterpret_cast<int*>(emb_smem + (size_t)nslot * a.D * sizeof(long long));
+  c.acc = (emb_lds_u64*)emb_smem;
+  c.tag = (emb_lds_int*)(emb_smem + (size_t)nslot * a.D * sizeof(long long));
   if (CACHE) {
     for (int i = threadIdx.x; i < nslot * a.D; i += EMB_GRAD_THREADS) c.acc[i] = 0;
     for (int i = threadIdx.x; i < nslot; i += EMB_GRAD_THREADS) c.tag[i] = -1;
@@ -155,6 +187,9 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
   const int D = a.D, T = a.T;
   const bool act = l < D;
   constexpr bool din = MODE != 0, cosine = MODE == 1;
+  // slots a lane group has in flight: the mean-pooling mode has no per-slot arithmetic to hide the id -> row latency
+  // behind (and needs few registers), the attention modes are issue-bound
+  constexpr int PASS = MODE == 0 ? 8 : EMB_PASS;
   const float invT = 1.0f / (float)T;
   constexpr int WPB = EMB_GRAD_THREADS / 64;
   for (int b = blockIdx.x * WPB + wave; b < ((a.dbg & 8) ? 0 : a.B); b += gridDim.x * WPB) {
@@ -168,37 +203,52 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
     const float inv_nv = nv > 0.f ? 1.0f / nv : 0.f;
     float dv = 0.f;
     // Memory chain per sample: ids + gates (one coalesced load each) -> all rows of a pass -> arithmetic; a pass is
-    // EMB_PASS slots per lane group, their row loads are issued back to back before any of them is used.
+    // PASS slots per lane group, their row loads are issued back to back before any of them is used.
     for (int tb = 0; tb < T; tb += 64) {
-      // the rows of pass p + 1 are requested before pass p is worked on (two passes in flight)
-      auto load_pass = [&](int pb, int (&ids)[EMB_PASS], float (&xs)[EMB_PASS]) {
+      // One group per wavefront (D > 32): the ids and their marks of 64 slots arrive with ONE coalesced load and ONE gather
+      // (lane j fetches slot j's) and are handed out by v_readlane — as broadcast loads every slot would cost the
+      // wavefront two dependent memory round trips of its own, and with 16 wavefronts per CU that latency is the kernel.
+      int myid = -1;
+      unsigned int mymark = 0u;
+      if (NG == 1) {
+        const int tl = tb + lane;
+        const int id = tl < T ? a.src.ub_ids[gr * T + tl] : -1;
+        myid = (id >= 0 && id < a.V) ? id : -1;
+        mymark = myid >= 0 ? a.mark[myid] : 0u;
+      }
+      auto load_pass = [&](int pb, int (&ids)[PASS], float (&xs)[PASS], unsigned int (&mk)[PASS]) {
 #pragma unroll
-        for (int k = 0; k < EMB_PASS; ++k) {
+        for (int k = 0; k < PASS; ++k) {
           const int sl = pb + k * NG + grp;                         // slot within this 64-chunk
           const bool in = sl < 64 && tb + sl < T;
-          const int id = in ? a.src.ub_ids[gr * T + tb + sl] : -1;   // one address per lane group: a broadcast load
-          ids[k] = (id >= 0 && id < a.V) ? id : -1;
+          if (NG == 1) {
+            const int sel = __builtin_amdgcn_readfirstlane((pb + k) & 63);   // (uniform by construction; makes it an SGPR)
+            ids[k] = in ? __builtin_amdgcn_readlane(myid, sel) : -1;
+            mk[k] = in ? (unsigned int)__builtin_amdgcn_readlane((int)mymark, sel) : 0u;
+          } else {
+            const int id = in ? a.src.ub_ids[gr * T + tb + sl] : -1;   // one address per lane group: a broadcast load
+            ids[k] = (id >= 0 && id < a.V) ? id : -1;
+            mk[k] = ids[k] >= 0 ? a.mark[ids[k]] : 0u;              // != 0: this pair is the id's only occurrence
+          }
           xs[k] = (act && ids[k] >= 0 && !(a.dbg & 64)) ? a.emb[(long long)ids[k] * D + l] : 0.f;
         }
       };
-      int ids[EMB_PASS];
-      float xs[EMB_PASS];
-      load_pass(0, ids, xs);
-      for (int pb = 0; pb < 64 && tb + pb < T; pb += EMB_PASS * NG) {
-        int idn[EMB_PASS];
-        float xn[EMB_PASS];
-        load_pass(pb + EMB_PASS * NG, idn, xn);                     // (past the end: every slot comes back as -1, no loads)
+      for (int pb = 0; pb < 64 && tb + pb < T; pb += PASS * NG) {
+        int ids[PASS];
+        float xs[PASS];
+        unsigned int mk[PASS];
+        load_pass(pb, ids, xs, mk);     // (requesting the next pass here as well was measured: no gain, the kernel is issue-bound)
         // every stage runs over all slots of the pass before the next one starts, so the LDS-crossbar shuffles and the
         // cache lookups of different slots are in flight together instead of one dependent chain per slot
-        float g[EMB_PASS], att[EMB_PASS], s0[EMB_PASS], s1[EMB_PASS], s2[EMB_PASS];
-        int tag[EMB_PASS];
+        float g[PASS], att[PASS], s0[PASS], s1[PASS], s2[PASS];
+        int tag[PASS];
 #pragma unroll
-        for (int k = 0; k < EMB_PASS; ++k) {
+        for (int k = 0; k < PASS; ++k) {
           const int sl = pb + k * NG + grp;
           const bool in = sl < 64 && tb + sl < T;
           g[k] = (din && in) ? a.gate[(size_t)b * T + tb + sl] : 1.0f;
           att[k] = (din && in) ? a.att0[tb + sl] : 0.f;
-          tag[k] = (CACHE && l == 0 && ids[k] >= 0 && !(a.dbg & 32)) ? emb_cache_claim(c, emb_cache_slot(c, ids[k]), ids[k]) : -1;
+          tag[k] = (CACHE && l == 0 && ids[k] >= 0 && mk[k] == 0u && !(a.dbg & 32)) ? emb_cache_claim(c, emb_cache_slot(c, ids[k]), ids[k]) : -1;
           const float df = xs[k] - v;
           s0[k] = dp * xs[k];
           s1[k] = cosine ? xs[k] * xs[k] : (act ? df * df : 0.f);
@@ -206,16 +256,16 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
         }
         if (din) {
 #pragma unroll
-          for (int k = 0; k < EMB_PASS; ++k) {                      // DPP sums (VALU): the LDS crossbar is the scarce unit here
+          for (int k = 0; k < PASS; ++k) {                      // DPP sums (VALU): the LDS crossbar is the scarce unit here
             s0[k] = group_sum<GS>(s0[k]);
             s1[k] = group_sum<GS>(s1[k]);
             if (cosine) s2[k] = group_sum<GS>(s2[k]);
           }
         }
 #pragma unroll
-        for (int k = 0; k < EMB_PASS; ++k) tag[k] = CACHE ? emb_group_sum_int<GS>(l == 0 ? tag[k] + 1 : 0) - 1 : -1;   // broadcast of the group's lane 0
+        for (int k = 0; k < PASS; ++k) tag[k] = CACHE ? emb_group_sum_int<GS>(l == 0 ? tag[k] + 1 : 0) - 1 : -1;   // broadcast of the group's lane 0
 #pragma unroll
-        for (int k = 0; k < EMB_PASS; ++k) {
+        for (int k = 0; k < PASS; ++k) {
           const int id = ids[k];
           if (id < 0 || (a.dbg & 16)) continue;                     // (group-uniform)
           const float x = xs[k];
@@ -240,20 +290,26 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
           } else {
             dx = invT * dp;
           }
-          if (act) emb_add(a, c, id, emb_cache_slot(c, id), tag[k], l, dx);
+          if (act) {
+            if (mk[k]) emb_apply_single(a, id, l, x, dx);
+            else emb_add(a, c, id, emb_cache_slot(c, id), tag[k], l, dx);
+          }
         }
-#pragma unroll
-        for (int k = 0; k < EMB_PASS; ++k) { ids[k] = idn[k]; xs[k] = xn[k]; }
       }
     }
     // candidate item: h0's item segment + the attention terms of every slot (sum over the lane groups)
 #pragma unroll
     for (int o = GS; o < 64; o <<= 1) dv += __shfl_xor(dv, o, 64);
     if (grp == 0 && item_ok) {
+      const bool single = a.mark[item] != 0u;
       const unsigned int slot = emb_cache_slot(c, item);
-      int tg = (CACHE && l == 0) ? emb_cache_claim(c, slot, item) : -1;
+      int tg = (CACHE && l == 0 && !single) ? emb_cache_claim(c, slot, item) : -1;
       if (CACHE) tg = emb_group_sum_int<GS>(l == 0 ? tg + 1 : 0) - 1;
-      if (act) emb_add(a, c, item, slot, tg, l, dv + a.dpv[(size_t)b * a.ldp + D + l]);
+      if (act) {
+        const float gsum = dv + a.dpv[(size_t)b * a.ldp + D + l];
+        if (single) emb_apply_single(a, item, l, v, gsum);
+        else emb_add(a, c, item, slot, tg, l, gsum);
+      }
     }
   }
   if (!CACHE) return;
@@ -261,17 +317,20 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
   // flush the cached rows: one HBM atomic per (row, component) per workgroup
   for (int i = threadIdx.x; i < nslot * D; i += EMB_GRAD_THREADS) {
     const int tag = c.tag[i / D];
-    const long long q = c.acc[i];
+    const long long q = (long long)c.acc[i];
     if (tag >= 0 && q && !(a.dbg & 1)) atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)a.rank[tag] * D + i % D), (unsigned long long)q);
   }
 }
 
 // Sink of the rank scan (scan.h): rank of every id, slot -> id list of the touched ones (ascending ids), and the marks
 // are cleared for the next step in the same pass.
+struct EmbMultiMap {
+  __device__ __forceinline__ unsigned int operator()(unsigned int v) const { return v == EMB_MULTI ? 1u : 0u; }
+};
 struct EmbRankSink {
   unsigned int* mark; unsigned int* rank; int* slot_id;
   __device__ __forceinline__ void operator()(long long id, unsigned int m, unsigned int r) const {
-    if (m) { rank[id] = r; slot_id[r] = (int)id; mark[id] = 0u; }
+    if (m == EMB_MULTI) { rank[id] = r; slot_id[r] = (int)id; mark[id] = 0u; }     // (a single keeps its mark until emb_grad has applied it)
   }
 };
 

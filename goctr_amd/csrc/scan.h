@@ -43,13 +43,19 @@ __device__ __forceinline__ uint4 scan_load4(const unsigned int* in, long long i,
   return v;
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_sums_kernel(const unsigned int* in, long long n, unsigned int* tile_sum) {
+struct ScanIdentity {
+  __device__ __forceinline__ unsigned int operator()(unsigned int v) const { return v; }
+};
+
+// map(v) is what gets summed (identity for 0 / 1 flags)
+template <class Map>
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_sums_kernel(const unsigned int* in, long long n, unsigned int* tile_sum, Map map) {
   const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * 4;
   unsigned int s = 0;
 #pragma unroll
   for (int j = 0; j < SCAN_SUB; ++j) {
     const uint4 v = scan_load4(in, base + (long long)j * SCAN_BLOCK * 4, n);
-    s += v.x + v.y + v.z + v.w;
+    s += map(v.x) + map(v.y) + map(v.z) + map(v.w);
   }
   unsigned int tot;
   block_exclusive_scan(s, &tot);
@@ -71,8 +77,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_tile_offsets_kernel(unsigned 
 }
 
 // sink(i, value, rank) sees every element once with its exclusive prefix sum
-template <class Sink>
-__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const unsigned int* in, long long n, const unsigned int* tile_off, Sink sink) {
+template <class Map, class Sink>
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const unsigned int* in, long long n, const unsigned int* tile_off, Map map, Sink sink) {
   const long long base = (long long)blockIdx.x * SCAN_TILE + (long long)threadIdx.x * 4;
   uint4 v[SCAN_SUB];
 #pragma unroll
@@ -82,14 +88,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const unsigned i
   for (int j = 0; j < SCAN_SUB; ++j) {
     const long long i = base + (long long)j * SCAN_BLOCK * 4;
     unsigned int tot;
-    unsigned int run = carry + block_exclusive_scan(v[j].x + v[j].y + v[j].z + v[j].w, &tot);
+    unsigned int run = carry + block_exclusive_scan(map(v[j].x) + map(v[j].y) + map(v[j].z) + map(v[j].w), &tot);
     carry += tot;
     if (i < n) sink(i, v[j].x, run);
-    run += v[j].x;
+    run += map(v[j].x);
     if (i + 1 < n) sink(i + 1, v[j].y, run);
-    run += v[j].y;
+    run += map(v[j].y);
     if (i + 2 < n) sink(i + 2, v[j].z, run);
-    run += v[j].z;
+    run += map(v[j].z);
     if (i + 3 < n) sink(i + 3, v[j].w, run);
   }
 }
@@ -99,21 +105,21 @@ struct ScanStore {
   __device__ __forceinline__ void operator()(long long i, unsigned int, unsigned int rank) const { out[i] = rank; }
 };
 
-template <class Sink>
-int exclusive_scan_sink(const unsigned int* in, long long n, DevBuf<unsigned int>& tiles_buf, unsigned long long* total_dev, Sink sink) {
+template <class Map, class Sink>
+int exclusive_scan_sink(const unsigned int* in, long long n, DevBuf<unsigned int>& tiles_buf, unsigned long long* total_dev, Map map, Sink sink) {
   const long long tiles = cdiv(n, SCAN_TILE);
   if (tiles_buf.ensure((size_t)tiles, false)) return -1;
   hipStream_t s = engine().stream;
-  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, s, in, n, tiles_buf.p);
+  hipLaunchKernelGGL((scan_tile_sums_kernel<Map>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, s, in, n, tiles_buf.p, map);
   hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, tiles_buf.p, tiles, total_dev);
-  hipLaunchKernelGGL((scan_apply_kernel<Sink>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, s, in, n, tiles_buf.p, sink);
+  hipLaunchKernelGGL((scan_apply_kernel<Map, Sink>), dim3((unsigned)tiles), dim3(SCAN_BLOCK), 0, s, in, n, tiles_buf.p, map, sink);
   GOCTR_HIP(hipGetLastError());
   return 0;
 }
 
 int exclusive_scan(const unsigned int* in, long long n, unsigned int* out, DevBuf<unsigned int>& tiles_buf,
                    unsigned long long* total_dev) {
-  return exclusive_scan_sink(in, n, tiles_buf, total_dev, ScanStore{out});
+  return exclusive_scan_sink(in, n, tiles_buf, total_dev, ScanIdentity{}, ScanStore{out});
 }
 
 }  // namespace

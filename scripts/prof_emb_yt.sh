@@ -1,0 +1,9 @@
+# emb_grad timing experiments on the YouTube cfg4 step (GOCTR_EMB_DBG bits: 1 no flush, 2 no miss atomics, 4 no LDS adds, 16 no arithmetic/adds, 32 no cache claims, 64 no row loads)
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+for dbg in 0; do
+  rm -rf /tmp/pe_$dbg
+  GOCTR_EMB_DBG=$dbg timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pe_$dbg -- python $R/bench.py --workload youtube --train-emb 0.01 --steps 30 --warmup 5 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+  f=$(find /tmp/pe_$dbg -name "*kernel_stats.csv" | head -1)
+  echo "dbg=$dbg: $(grep emb_grad $f | awk -F, '{print $(NF-4)}')"
+done

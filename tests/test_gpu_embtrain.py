@@ -64,6 +64,75 @@ def test_one_step_matches_oracle(oracle, kind, att, D, T):
     assert np.array_equal(got[~touched], E[~touched])                   # untouched rows keep their bits
 
 
+SINGLES_SCRIPT = r'''
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from goctr_amd import capi, model as gm
+rng = np.random.default_rng(4)
+U, T, D, Cc, V, B, rows = 8, 12, 16, 6, 40000, 256, 700
+E = (rng.standard_normal((V, D)) * 0.5).astype(np.float32)
+ub = ((rng.zipf(1.3, size=(rows, T)) - 1) %% V).astype(np.int32)        # a hot head and a long tail of singles
+ub[rng.random((rows, T)) < 0.2] = -1
+items = rng.integers(0, V, size=rows).astype(np.int32)
+uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+y = (rng.random(rows) < 0.5).astype(np.float32)
+m = gm.DinNet(U, T, D, D, Cc)
+r = np.random.default_rng(1)
+for n in ("mlp0", "mlp1", "mlp2"):
+    m.set_weights(n, (r.standard_normal(m._shape(n)) * 0.2).astype(np.float32))
+m.set_embedding_training(0.5)
+tab = gm.EmbeddingTable(E); ds = gm.Dataset.ids(ub, items, uf, cf, y)
+c = gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1), 5, emb=tab, want_costs=True)   # 3 batches, wraps around
+capi.sync()
+np.save(%(out)r, np.concatenate([tab.get_rows().ravel(), m.get_weights("mlp0").ravel(), c]))
+'''
+
+
+def test_single_occurrence_ids_in_place_equals_accumulate_path(tmp_path):
+    """vocabulary larger than the batch's id count: ids with one occurrence are updated in place by emb_grad
+    (GOCTR_EMB_SINGLES default 1 there), all others through the fixed-point accumulators; forcing everything through
+    the accumulators must give the same bits"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for singles in ("1", "0"):
+        out = str(tmp_path / f"s{singles}.npy")
+        env = dict(os.environ, GOCTR_EMB_SINGLES=singles)
+        r = subprocess.run([sys.executable, "-c", SINGLES_SCRIPT % dict(root=root, out=out)], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    assert np.isfinite(res[0]).all()
+    assert np.array_equal(res[0], res[1])
+
+
+def test_one_step_matches_oracle_large_vocabulary(oracle):
+    """same check as test_one_step_matches_oracle with V >> B (T+1): the in-place path for single ids is on"""
+    from goctr_amd import capi, model as gm
+    U, Cc, V, B, T, D = 52, 53, 60000, 256, 10, 16
+    rows = B - 11
+    om, m, E, ub, items, uf, cf, y = _setup(oracle, "din", 0, U, T, D, Cc, V, rows, seed=77)
+    ub[5:40] = (ub[5:40] % 50)                                          # plus a block of heavily repeated ids
+    lr = 0.5
+    loss, dE = om.emb_loss_grad(E.astype(np.float64), ub, items, uf, cf, y, B=B)
+    tab = gm.EmbeddingTable(E)
+    ds = gm.Dataset.ids(ub, items, uf, cf, y)
+    m.set_embedding_training(lr)
+    gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1), 1, emb=tab)
+    capi.sync()
+    got = tab.get_rows()
+    upd = np.abs(lr * dE).max()
+    assert np.abs(got - (E.astype(np.float64) - lr * dE)).max() <= 1e-4 * upd + 1e-7
+    touched = np.zeros(V, bool)
+    touched[ub[(ub >= 0) & (ub < V)]] = True
+    touched[items[items >= 0]] = True
+    assert np.array_equal(got[~touched], E[~touched])
+    # a second step on the same batch works from clean marks (nothing stale from the in-place path)
+    gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1), 1, emb=tab)
+    capi.sync()
+    assert np.isfinite(tab.get_rows()).all() and np.array_equal(tab.get_rows()[~touched], E[~touched])
+
+
 def test_reproducible_and_off_by_default(oracle):
     from goctr_amd import capi, model as gm
     U, T, D, Cc, V, B = 52, 20, 16, 53, 200, 512
