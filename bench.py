@@ -422,6 +422,9 @@ def main():
                                 if c["KIND"] == "youtube" else
                                 "BASELINE configs[2]: DIN cosine attention, T=50, D=16, U=52, C=53, vocab 26744, "
                                 "batch 8192 per GPU, id mode (keys + table resident in HBM)"),
+                   "numerics": ("float32 in, float32 out; forward / backward-data GEMMs on v_mfma_f32_16x16x4_f32, weight-gradient GEMMs on "
+                                "the 6-product bf16 split with float32 accumulation (measured MORE accurate than the f32 MFMA: "
+                                "2.8e-8 vs 1.3e-7 of sum|ab|, scripts/ubench/bf16x3.hip; GOCTR_TN_F32=1 selects the f32 MFMA body)"),
                    "global_batch": c["B"] * world, "parallelism": f"dp{world}", "resident_rows_per_gpu": args.rows},
         "recommend_qps": round(qps, 1), "recommend_batch": c["PRED_B"],
     }

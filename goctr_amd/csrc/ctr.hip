@@ -249,7 +249,8 @@ int init_kernel_attrs() {
       allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(ctr_fwd16_kernel<4, 5>) || allow_big_lds(emb_grad_kernel<16, 0, true>) || allow_big_lds(emb_grad_kernel<16, 1, true>) || allow_big_lds(emb_grad_kernel<16, 2, true>) || allow_big_lds(emb_grad_kernel<32, 0, true>) ||
       allow_big_lds(emb_grad_kernel<32, 1, true>) || allow_big_lds(emb_grad_kernel<32, 2, true>) || allow_big_lds(emb_grad_kernel<64, 0, true>) || allow_big_lds(emb_grad_kernel<64, 1, true>) ||
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
-      allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>)) return -1;
+      allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
+      allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>)) return -1;
   done = true;
   return 0;
 }
@@ -574,10 +575,20 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     tm.dbg = dbg ? tndbg.p : nullptr;
     {
       ProfScope ps(GOCTR_K_DW0);
-      hipLaunchKernelGGL((gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>), dim3((unsigned)nblk), dim3(256), lds_tm, e.stream, tm);
+      // default: the 6-product bf16 split (mfma_gemm.h); GOCTR_TN_F32=1 selects the v_mfma_f32_16x16x4_f32 body
+      if (env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32)
+        hipLaunchKernelGGL((gemm_tn_multi_x3_kernel<3, 4>), dim3((unsigned)nblk), dim3(512), gemm_tn_multi_x3_lds_bytes<3>(nt_max), e.stream, tm);
+      else
+        hipLaunchKernelGGL((gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>), dim3((unsigned)nblk), dim3(256), lds_tm, e.stream, tm);
       GOCTR_HIP(hipGetLastError());
     }
-    if (dbg) {
+    if (dbg && env_int("GOCTR_TN_F32", 0) == 0) {
+      unsigned long long h[16];
+      if (tndbg.download(h, 16)) return -1;
+      fprintf(stderr, "dW x3 wg 0: multiplier wave: wait for chunk 0 %lld, in MFMA sections %lld, loop total %lld, epilogue %lld | stager wave: first chunk %lld, "
+              "staging sections %lld, total %lld, chunks %lld (s_memtime ticks)\n", (long long)h[0], (long long)h[1], (long long)h[2], (long long)h[3],
+              (long long)h[8], (long long)h[9], (long long)h[10], (long long)h[11]);
+    } else if (dbg) {
       unsigned long long h[16];
       if (tndbg.download(h, 16)) return -1;
       for (int w = 0; w < 2; ++w)

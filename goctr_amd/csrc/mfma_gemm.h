@@ -513,4 +513,248 @@ inline size_t gemm_tn_multi_lds_bytes(int nt_max) {
 template <int KTW, int CH>
 inline bool gemm_tn_multi_fits(int nt_max) { return nt_max <= 16; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same weight-gradient kernel on the 6-product bf16 split (scripts/ubench/bf16x3.hip): every float32
+// operand value x is staged as three bf16 planes  x = hi + mid + lo  (each the round-to-nearest-even bf16 of what the
+// previous ones left), and  a*b  is taken as  hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid)  on
+// v_mfma_f32_16x16x32_bf16 with float32 accumulation — the dropped terms are below 2^-32 |a b|.  Measured against float64
+// it is MORE accurate than v_mfma_f32_16x16x4_f32 on this path's operands (2.8e-8 vs 1.3e-7 relative to sum |a b|), it
+// issues 1.4x faster, and unlike the f32-input MFMA it does not block the SIMD for the other wavefronts' staging work.
+// One MFMA covers the whole 32-row chunk (k-depth 32): per chunk and tile pair 6 MFMAs instead of 8.
+// LDS: per column and plane CHB = 40 bf16 (80 B: the 16-byte reads of 16 lanes fall in distinct 16-byte bank groups).
+typedef __bf16 tn_bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 tn_bf4 __attribute__((ext_vector_type(4)));
+
+typedef __bf16 tn_bf2 __attribute__((ext_vector_type(2)));
+typedef float tn_f2 __attribute__((ext_vector_type(2)));
+// two values at a time: v_cvt_pk_bf16_f32 rounds both (RNE) and leaves them packed the way the LDS strips want them
+// (consecutive rows adjacent); widening a packed bf16 back to float32 is a shift / a mask.
+__device__ __forceinline__ void tn_split3_pk(float x0, float x1, unsigned int& hi, unsigned int& mid, unsigned int& lo) {
+  hi = __builtin_bit_cast(unsigned int, __builtin_convertvector(tn_f2{x0, x1}, tn_bf2));
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xFFFF0000u);
+  mid = __builtin_bit_cast(unsigned int, __builtin_convertvector(tn_f2{r0, r1}, tn_bf2));
+  const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xFFFF0000u);
+  lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(tn_f2{s0, s1}, tn_bf2));
+}
+
+template <int KTW, int NTW>
+__device__ __forceinline__ void tn_multi_body_x3(const TnMulti& a, const TnProblem& P, int kb, int split, unsigned char* smem) {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  typedef float vec_t __attribute__((ext_vector_type(4)));
+  constexpr int CH = 32, CHB = 40;        // rows per chunk; bf16 per LDS strip column
+  constexpr int MAXB = ((CH / 4) * (KTW * 4 + 16 * 4) + 255) / 256;
+  const int kb0 = kb * KTW;
+  int kb_t = P.KT - kb0; if (kb_t > KTW) kb_t = KTW;
+  const int nb_t = P.NT;
+  const int Kc = kb_t * 16, Nc = nb_t * 16;
+  const int kv = Kc >> 2, nv = Nc >> 2;
+  // LDS (bf16 units): [buf][plane][col][CHB], A columns first (KTW*16 of them), then the D columns
+  __bf16* base = reinterpret_cast<__bf16*>(smem);
+  const int cols = KTW * 16 + Nc;
+  const int plane = cols * CHB, bufsz = 3 * plane;
+
+  // 8 wavefronts: 0-3 multiply (NTW tiles of D each), 4-7 stage — one of each kind per SIMD, so that the bf16 MFMAs of
+  // the one run under the float32 -> 3 x bf16 splitting, global loads and LDS writes of the other.
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m_begin = split * P.rows;
+  int m_end = m_begin + P.rows;
+  if (m_end > a.M) m_end = a.M;
+  if (m_begin >= m_end) return;            // (workgroup-uniform)
+  const int nchunks = (m_end - m_begin + CH - 1) / CH;
+
+  typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+  const int nA = (CH / 4) * kv, nAll = nA + (CH / 4) * nv;
+  // block b = (column group cg, row group r) with r fastest: the 8 lanes of a column group write 64 contiguous bytes of a
+  // strip (cg-fastest put 16 lanes on the same LDS banks), and a wavefront's loads still touch 16 cache lines
+  auto slot_of = [&](int b, const float*& src, int& ldv, int& rgv, int& lo) {
+    src = P.A; ldv = P.lda; rgv = 0; lo = -1;
+    if (b < nA) {
+      const int cg = b >> 3, r = b & 7;
+      rgv = r; ldv = P.lda;
+      src = P.A + kb0 * 16 + cg * 4;
+      lo = (cg * 4) * CHB + 4 * r;
+    } else if (b < nAll) {
+      const int bb = b - nA;
+      const int cg = bb >> 3, r = bb & 7;
+      rgv = r; ldv = P.ldd;
+      src = P.D + cg * 4;
+      lo = (KTW * 16 + cg * 4) * CHB + 4 * r;
+    }
+  };
+  auto store_block = [&](__bf16* d, int left, const vec_t (&v)[4]) {     // 4 rows x 4 columns -> 3 planes, zero past `left` rows
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float x0 = left > 0 ? v[0][c] : 0.f, x1 = left > 1 ? v[1][c] : 0.f;
+      const float x2 = left > 2 ? v[2][c] : 0.f, x3 = left > 3 ? v[3][c] : 0.f;
+      unsigned int h0, m0_, l0, h1, m1, l1;
+      tn_split3_pk(x0, x1, h0, m0_, l0);
+      tn_split3_pk(x2, x3, h1, m1, l1);
+      *reinterpret_cast<u2*>(d + c * CHB) = u2{h0, h1};
+      *reinterpret_cast<u2*>(d + plane + c * CHB) = u2{m0_, m1};
+      *reinterpret_cast<u2*>(d + 2 * plane + c * CHB) = u2{l0, l1};
+    }
+  };
+  // chunk 0 -> buffer 0 by all 512 threads (the multipliers have nothing else to do yet)
+  auto stage_first = [&]() {
+    for (int b = tid; b < nAll; b += 512) {
+      const float* src; int ldv, rgv, lo;
+      slot_of(b, src, ldv, rgv, lo);
+      vec_t v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int rr = m_begin + 4 * rgv + r;
+        rr = rr < m_end ? rr : m_end - 1;
+        v[r] = *reinterpret_cast<const vec_t*>(src + (size_t)rr * ldv);
+      }
+      store_block(base + lo, m_end - (m_begin + 4 * rgv), v);
+    }
+  };
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------------ stagers
+    const int stid = tid - 256;
+    const float* gsrc[MAXB]; int ld[MAXB]; int rg[MAXB]; int lofs[MAXB];   // lofs: bf16 offset inside a plane; < 0 unused
+#pragma unroll
+    for (int s = 0; s < MAXB; ++s) slot_of(stid + s * 256, gsrc[s], ld[s], rg[s], lofs[s]);
+    // loads are unconditional (rows past the slab's end re-read its last row and are zeroed at the LDS write)
+    auto gload = [&](int m0, vec_t (&st)[MAXB][4]) {
+#pragma unroll
+      for (int s = 0; s < MAXB; ++s) {
+        if (s * 256 < nAll) {                                // (uniform: slots past the problem's block count are not loaded)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int rr = m0 + 4 * rg[s] + r;
+            rr = rr < m_end ? rr : m_end - 1;
+            st[s][r] = *reinterpret_cast<const vec_t*>(gsrc[s] + (size_t)rr * ld[s]);
+          }
+        }
+      }
+    };
+    auto lstore = [&](int buf, int m0, const vec_t (&st)[MAXB][4]) {
+      const bool whole = m0 + CH <= m_end;                   // whole chunk inside the slab (uniform): nothing to zero
+#pragma unroll
+      for (int s = 0; s < MAXB; ++s)
+        if (s * 256 < nAll && lofs[s] >= 0)
+          store_block(base + buf * bufsz + lofs[s], whole ? 4 : m_end - (m0 + 4 * rg[s]), st[s]);
+    };
+    // chunk c is written while chunk c - 1 is multiplied; its global loads were issued one iteration earlier (two ahead
+    // was measured: the extra loads only lengthen the start).  Chunk 0 was staged by all 8 wavefronts (below).
+    unsigned long long tS0 = 0, tS1 = 0, tSt = 0, tS2 = 0;
+    if (a.dbg) tS0 = __builtin_amdgcn_s_memtime();
+    vec_t st0[MAXB][4], st1[MAXB][4];
+    if (nchunks > 1) gload(m_begin + CH, st1);
+    stage_first();
+    __syncthreads();                                       // chunk 0 is in LDS
+    if (a.dbg) tS1 = __builtin_amdgcn_s_memtime();
+    for (int c = 1; c <= nchunks; ++c) {
+      unsigned long long t0 = 0;
+      if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
+      if (c < nchunks) {
+#pragma unroll
+        for (int s = 0; s < MAXB; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st0[s][r] = st1[s][r];
+        if (c + 1 < nchunks) gload(m_begin + (c + 1) * CH, st1);
+        lstore(c & 1, m_begin + c * CH, st0);
+      }
+      if (a.dbg) tSt += __builtin_amdgcn_s_memtime() - t0;
+      __syncthreads();                                     // chunk c written, chunk c - 1 consumed
+    }
+    if (a.dbg && tid == 256 && blockIdx.x == 0) {
+      tS2 = __builtin_amdgcn_s_memtime();
+      a.dbg[8] = tS1 - tS0; a.dbg[9] = tSt; a.dbg[10] = tS2 - tS0; a.dbg[11] = nchunks;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- multipliers
+  const int wn = wave;
+  const int i = lane & 15, q = lane >> 4;
+  const int nt0 = wn * NTW;
+  int ncnt = nb_t - nt0; ncnt = ncnt < 0 ? 0 : (ncnt > NTW ? NTW : ncnt);
+  acc_t ah[KTW][NTW], ac[KTW][NTW];       // hi*hi, and everything else
+#pragma unroll
+  for (int e = 0; e < KTW; ++e)
+#pragma unroll
+    for (int f = 0; f < NTW; ++f) { ah[e][f] = acc_t{0, 0, 0, 0}; ac[e][f] = acc_t{0, 0, 0, 0}; }
+  int aofs[KTW], dofs[NTW];
+#pragma unroll
+  for (int e = 0; e < KTW; ++e) { int c = e * 16 + i; c = c < Kc ? c : Kc - 1; aofs[e] = c * CHB + 8 * q; }
+#pragma unroll
+  for (int f = 0; f < NTW; ++f) { int c = (nt0 + f) * 16 + i; c = c < Nc ? c : Nc - 1; dofs[f] = (KTW * 16 + c) * CHB + 8 * q; }
+
+  unsigned long long tC0 = 0, tC1 = 0, tCm = 0, tC2 = 0;
+  if (a.dbg) tC0 = __builtin_amdgcn_s_memtime();
+  stage_first();
+  __syncthreads();                                         // chunk 0 is in LDS
+  if (a.dbg) tC1 = __builtin_amdgcn_s_memtime();
+  for (int c = 0; c < nchunks; ++c) {
+    unsigned long long t0 = 0;
+    if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
+    const __bf16* bs = base + (c & 1) * bufsz;
+    tn_bf8 av[3][KTW], dv[3][NTW];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int e = 0; e < KTW; ++e) av[pl][e] = *reinterpret_cast<const tn_bf8*>(bs + pl * plane + aofs[e]);
+#pragma unroll
+      for (int f = 0; f < NTW; ++f) dv[pl][f] = *reinterpret_cast<const tn_bf8*>(bs + pl * plane + dofs[f]);
+    }
+#pragma unroll
+    for (int e = 0; e < KTW; ++e)
+#pragma unroll
+      for (int f = 0; f < NTW; ++f) {
+        // smallest terms first inside the correction accumulator
+        ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2][e], dv[0][f], ac[e][f], 0, 0, 0);
+        ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][e], dv[2][f], ac[e][f], 0, 0, 0);
+        ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1][e], dv[1][f], ac[e][f], 0, 0, 0);
+        ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1][e], dv[0][f], ac[e][f], 0, 0, 0);
+        ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][e], dv[1][f], ac[e][f], 0, 0, 0);
+        ah[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][e], dv[0][f], ah[e][f], 0, 0, 0);
+      }
+    if (a.dbg) tCm += __builtin_amdgcn_s_memtime() - t0;
+    __syncthreads();                                       // chunk c consumed, chunk c + 1 written
+  }
+  if (a.dbg) tC2 = __builtin_amdgcn_s_memtime();
+
+  float* out = P.slabs + (size_t)split * P.slab_stride;
+#pragma unroll
+  for (int e = 0; e < KTW; ++e) {
+#pragma unroll
+    for (int f = 0; f < NTW; ++f) {
+      if (e < kb_t && f < ncnt) {
+        const int k = (kb0 + e) * 16 + 4 * q, n = (nt0 + f) * 16 + i;
+        const acc_t v = ac[e][f] + ah[e][f];
+        if (P.transpose_out) {
+          *reinterpret_cast<acc_t*>(out + (size_t)n * P.ld_out + k) = v;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[(size_t)(k + r) * P.ld_out + n] = v[r];
+        }
+      }
+    }
+  }
+  if (a.dbg && tid == 0 && blockIdx.x == 0) {
+    a.dbg[0] = tC1 - tC0; a.dbg[1] = tCm; a.dbg[2] = tC2 - tC1; a.dbg[3] = __builtin_amdgcn_s_memtime() - tC2;
+  }
+}
+
+template <int KTW, int NTW>
+__global__ __launch_bounds__(512) void gemm_tn_multi_x3_kernel(TnMulti a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) if (k < a.np && (int)blockIdx.x >= a.p[k].first) pi = k;
+  const TnProblem& P = a.p[pi];
+  const int local = blockIdx.x - P.first;
+  const int kb = local / P.S, split = local - kb * P.S;
+  if (P.KT == 1) tn_multi_body_x3<1, NTW>(a, P, kb, split, goctr_smem);
+  else tn_multi_body_x3<KTW, NTW>(a, P, kb, split, goctr_smem);
+}
+template <int KTW>
+inline size_t gemm_tn_multi_x3_lds_bytes(int nt_max) {
+  return sizeof(__bf16) * 2 * 3 * 40 * (size_t)(KTW * 16 + nt_max * 16);
+}
+
 }  // namespace goctr
