@@ -538,12 +538,18 @@ struct AdamArgs {
 __host__ __device__ inline size_t img_index(int k, int n, int N) { return ((size_t)(k >> 2) * N + n) * 4 + (k & 3); }
 
 // one parameter's gorgonia-order Adam update (+ transposed operand copies)
+// w0 / m0 / v0: the element's weight and moments, loaded by the caller (the fused kernel requests them before it walks
+// the gradient slabs, so that they do not cost a second memory round trip after the reduction)
+__device__ __forceinline__ void adam_apply_pre(const AdamArgs& a, int idx, float g, float corr1, float corr2, float w0, float m0, float v0);
 __device__ __forceinline__ void adam_apply(const AdamArgs& a, int idx, float g, float corr1, float corr2) {
+  adam_apply_pre(a, idx, g, corr1, corr2, a.W[idx], a.Mo[idx], a.Vo[idx]);
+}
+__device__ __forceinline__ void adam_apply_pre(const AdamArgs& a, int idx, float g, float corr1, float corr2, float w0, float m0, float v0) {
   const float b1 = (float)a.beta1, b2 = (float)a.beta2;
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   const float l2 = (float)a.l2, eps = (float)a.eps, neg_eta = (float)(-a.lr);
   const float one_per_batch = 1.0f / (float)a.bglobal;
-  float w = a.W[idx];
+  float w = w0;
   if (a.l2_first) {
     if (l2 != 0.f) g = g + w * l2;
     if (a.div_by_batch && a.bglobal > 1) g = g * one_per_batch;
@@ -553,8 +559,8 @@ __device__ __forceinline__ void adam_apply(const AdamArgs& a, int idx, float g, 
   }
   const float t1 = omb1 * g;
   const float g2 = (g * g) * omb2;
-  const float m = b1 * a.Mo[idx] + t1;
-  const float v = b2 * a.Vo[idx] + g2;
+  const float m = b1 * m0 + t1;
+  const float v = b2 * v0 + g2;
   a.Mo[idx] = m; a.Vo[idx] = v;
   const float mhat = m * corr1;
   const float vhat = v * corr2;
@@ -615,14 +621,11 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(ReduceAdamArgs p) {
       advance_state(a.st, a.st_out);
     }
   } else {
-    if (threadIdx.x == 0) {
-      const double it = (double)a.st->gstep + 1.0;  // this step's iteration number
-      corr[0] = 1.0f / (float)(1.0 - pow(p.ad.beta1, it));
-      corr[1] = 1.0f / (float)(1.0 - pow(p.ad.beta2, it));
-    }
-    __syncthreads();
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int e0 = (gid >> 3) * 4, pl = gid & 7;
+    const bool mine = pl < 4 && e0 + pl < a.nflat;           // lanes 0..3 of a group own one parameter each
+    float w0 = 0.f, m0 = 0.f, v0 = 0.f;
+    if (mine) { w0 = p.ad.W[e0 + pl]; m0 = p.ad.Mo[e0 + pl]; v0 = p.ad.Vo[e0 + pl]; }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (e0 < a.nflat) {
 #pragma unroll
@@ -645,10 +648,17 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(ReduceAdamArgs p) {
       acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
       acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
     }
+    // the bias corrections (two float64 pow calls on one thread) are computed while the slab loads above are in flight
+    if (threadIdx.x == 0) {
+      const double it = (double)a.st->gstep + 1.0;  // this step's iteration number
+      corr[0] = 1.0f / (float)(1.0 - pow(p.ad.beta1, it));
+      corr[1] = 1.0f / (float)(1.0 - pow(p.ad.beta2, it));
+    }
+    __syncthreads();
     // after the butterfly all 8 lanes hold the sums: lanes 0..3 of the group update one element each
-    if (pl < 4 && e0 + pl < a.nflat) {
+    if (mine) {
       const float g = pl == 0 ? acc.x : (pl == 1 ? acc.y : (pl == 2 ? acc.z : acc.w));
-      adam_apply(p.ad, e0 + pl, g, corr[0], corr[1]);
+      adam_apply_pre(p.ad, e0 + pl, g, corr[0], corr[1], w0, m0, v0);
     }
   }
 }
