@@ -446,6 +446,23 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
 // backward part up to and including the slab reduce: kernels 5-12
 AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc);
 
+// Buffers of the sparse embedding update.  Allocated (and zeroed) BEFORE a step is captured into a hipGraph: a
+// hipMemsetAsync issued during capture becomes a graph node and would re-zero hundreds of MB on every replay.
+int ensure_emb_workspace(goctr_model* m, long long V, int B) {
+  if (m->emb_lr <= 0.f || (m->emb_V == V && m->emb_B == B)) return 0;
+  const goctr_ctr_cfg& c = m->cfg;
+  const int Np = round_up(2 * c.D, 16);
+  const long long cap = std::min<long long>(V, (long long)B * (c.T + 1) * engine().world);
+  if (m->dpv.alloc((size_t)B * Np) || m->W0pvT.alloc((size_t)m->H1p * Np) || m->emb_mark.alloc((size_t)V) ||
+      m->emb_rank.alloc((size_t)V, false) || m->emb_total.alloc(1) || m->emb_accum.alloc((size_t)cap * c.D) ||
+      m->emb_slot_id.alloc((size_t)cap, false) || m->emb_tiles.alloc((size_t)cdiv(V, SCAN_TILE), false))
+    return -1;
+  GOCTR_HIP(hipStreamSynchronize(engine().stream));
+  m->emb_V = V; m->emb_B = B;
+  m->graph.destroy();
+  return 0;
+}
+
 template <int GS, bool CACHE>
 void launch_emb_grad2(int mode, dim3 gb, size_t lds, hipStream_t s, const EmbTrainArgs& a, int nslot) {
   if (mode == 0) hipLaunchKernelGGL((emb_grad_kernel<GS, 0, CACHE>), gb, dim3(EMB_GRAD_THREADS), lds, s, a, nslot);
@@ -468,12 +485,7 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   const int Np = round_up(2 * c.D, 16);
   const long long V = src.V;
   const long long cap = std::min<long long>(V, (long long)B * (c.T + 1) * e.world);   // the UNION of all ranks' ids gets slots
-  if (m->emb_V != V || m->emb_B != B) {
-    if (m->dpv.alloc((size_t)B * Np) || m->W0pvT.alloc((size_t)m->H1p * Np) || m->emb_mark.alloc((size_t)V) ||
-        m->emb_rank.alloc((size_t)V, false) || m->emb_total.alloc(1) || m->emb_accum.alloc((size_t)cap * c.D) || m->emb_slot_id.alloc((size_t)cap, false))
-      return -1;
-    m->emb_V = V; m->emb_B = B;
-  }
+  GOCTR_CHECK(m->emb_V == V && m->emb_B == B, "embedding-training workspace not prepared (ensure_emb_workspace)");
   EmbTrainArgs a{};
   a.src = src; a.st = st; a.B = B; a.T = c.T; a.D = c.D; a.kind = c.kind; a.att = c.att;
   a.dpv = m->dpv.p; a.ldp = Np; a.gate = m->gate.p; a.wgt = m->wgt.p; a.att0 = m->W.p + m->offa;
@@ -782,6 +794,10 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
   if (ensure_workspace(m, B)) return -1;
   RowSource src = make_source(d, emb);
   StepOpts o = opts_from(tc);
+  if (m->emb_lr > 0.f) {
+    GOCTR_CHECK(src.id_mode, "embedding training needs an id-mode dataset (the dense TrainSample rows carry no ids)");
+    if (ensure_emb_workspace(m, src.V, B)) return -1;
+  }
   // (with a communicator the sparse embedding exchange sizes a collective from a device counter: eager steps)
   const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0 && !(e.comm_active() && m->emb_lr > 0.f);
   if (n_steps > 0) m->pred_img_valid = false;             // (graph replays update the weights without passing launch_adam)
