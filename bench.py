@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- go-ctr hot path on MI355X: DIN training samples/sec (+ recommend QPS).
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 either launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU; RANK / LOCAL_RANK /
+WORLD_SIZE from the env) or, with no launcher around it, `python bench.py --gpus N` spawns its N ranks itself
+(goctr_amd/launch.py).  The control plane (RCCL unique id, barrier, max over ranks) is a Unix-socket rendezvous:
+no torch in the harness.
 A "step" = one pass of the hot path (gather + attention + 3-layer MLP forward, BCE, backward, Adam)
 over one batch of synthetic MovieLens-20M-shaped input, BASELINE.json config 3:
 DIN cosine attention, T=50, D=16, U=52, C=53, batch 8192 per GPU, item vocab 26 744, ids + embedding
@@ -153,16 +156,76 @@ def cpu_baseline(budget_s=15.0):
     kind = pyoracle.YOUTUBE if c["KIND"] == "youtube" else pyoracle.DIN
     m = pyoracle.CtrModel(kind, c["U"], c["T"], c["D"], c["C"]).init_gaussian(np.random.default_rng(1))
     t0 = time.perf_counter()
-    m.train(X, y, batch=c["B"], epochs=1)          # one step (also warms the caches)
+    pd = 0.003 if c["KIND"] == "youtube" else 0.005
+    m.train(X, y, batch=c["B"], epochs=1, drop_mode=2, p0=pd, p1=pd, seed=42)          # one step (also warms the caches)
     one = time.perf_counter() - t0
     steps = int(max(2, min(200, budget_s / max(one, 1e-3))))
     t0 = time.perf_counter()
-    m.train(X, y, batch=c["B"], epochs=steps)      # rows == batch => epochs == steps
+    m.train(X, y, batch=c["B"], epochs=steps, drop_mode=2, p0=pd, p1=pd, seed=42)      # rows == batch => epochs == steps
     dt = time.perf_counter() - t0
     return {"value": round(steps * rows / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{steps} {c['KIND']} training steps at batch {rows} (dense TrainSample rows, T=50, D={c['D']}), "
                       f"oracle/orc_ctr.c with {cores} OpenMP threads (= the container's CPU quota; "
                       f"{os.cpu_count()} logical CPUs visible), {dt:.1f} s"}
+
+
+def serving_qps(m, tab, emb, ub, it, uf, cf, n=1 << 16, reps=5):
+    """recommend QPS through the drop-in boundary as a Go host would drive it ("with and without host row
+    assembly"), PCIe-inclusive, rank 0 only:
+      recommend_qps_keys       recommend.BatchPredict on the device (goctr_batch_predict): n sample keys (16 B each) in HOST
+                               memory -> behaviour-cache lookup + row assembly + predict on the GPU -> n scores back
+      recommend_qps_host_rows  model.Predict's own convention (goctr_predict_dense): n dense [XCols] float32 rows in HOST
+                               memory (assembled beforehand, untimed, by the product's own gather) -> scores back"""
+    import ctypes as C
+    from goctr_amd import capi, model as gm, recommend as gr
+    L = capi.load()
+    c = CFG
+    rng = np.random.default_rng(5)
+    res = {}
+    # --- keys: a behaviour cache of 8192 users (histories of 20..120 items, newest first), feature tables for every user / item
+    n_users, V = 8192, c["V"]
+    lens = rng.integers(20, 121, size=n_users)
+    off = np.zeros(n_users + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    seq_items = ((rng.zipf(1.05, size=int(off[-1])) - 1) % V).astype(np.int32)
+    seq_ts = np.concatenate([np.sort(rng.integers(1, 1 << 30, size=k))[::-1] for k in lens]).astype(np.int64)
+    ut = rng.random((n_users, c["U"]), dtype=np.float32)
+    itab = rng.random((V, c["C"]), dtype=np.float32)
+    ubc, rs = C.c_void_p(), C.c_void_p()
+    capi.check(L.goctr_ubcache_create(C.c_int64(n_users), capi.ptr(off, C.c_int64), capi.ptr(seq_items, C.c_int32),
+                                      capi.ptr(seq_ts, C.c_int64), C.byref(ubc)))
+    capi.check(L.goctr_recsys_create(ubc, tab._h, capi.ptr(ut, C.c_float), C.c_int64(n_users), C.c_int(c["U"]),
+                                     capi.ptr(itab, C.c_float), C.c_int64(V), C.c_int(c["C"]), C.byref(rs)))
+    users = rng.integers(0, n_users, size=n).astype(np.int32)
+    items = ((rng.zipf(1.05, size=n) - 1) % V).astype(np.int32)
+    ts = rng.integers(1, 1 << 30, size=n).astype(np.int64)
+    scores = np.empty(n, np.float32)
+
+    def call():
+        capi.check(L.goctr_batch_predict(m._h, rs, capi.ptr(users, C.c_int32), capi.ptr(items, C.c_int32), capi.ptr(ts, C.c_int64),
+                                         C.c_int64(n), C.c_int(c["PRED_B"]), capi.ptr(scores, C.c_float), None, None))
+    call()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    dtk = (time.perf_counter() - t0) / reps
+    res["recommend_qps_keys"] = round(n / dtk, 1)
+    res["keys_note"] = (f"goctr_batch_predict: {n} (user, item, ts) keys = {n * 16 / 1e6:.1f} MB over PCIe per call, device-side "
+                        f"ubcache lookup + row assembly + predict at batch {c['PRED_B']}, scores back: {dtk * 1e3:.2f} ms per call")
+    L.goctr_recsys_destroy(rs)
+    L.goctr_ubcache_destroy(ubc)
+    # --- dense rows in host memory
+    X = tab.gather_rows(ub[:n], it[:n], uf[:n], cf[:n])      # (the product's own gather, goctr_gather_rows; untimed)
+    si = gr.SampleInfo.from_dims(c["U"], c["T"], c["D"], c["C"])
+    gm.Predict(m, X.shape[0], c["PRED_B"], si, X)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        gm.Predict(m, X.shape[0], c["PRED_B"], si, X)
+    dth = (time.perf_counter() - t0) / 3
+    res["recommend_qps_host_rows"] = round(X.shape[0] / dth, 1)
+    res["host_rows_note"] = (f"goctr_predict_dense: {X.shape[0]} dense rows x {X.shape[1]} f32 = {X.nbytes / 1e6:.0f} MB over PCIe per call, "
+                             f"predict, y back: {dth * 1e3:.1f} ms per call")
+    return res
 
 
 def _emit(out):
@@ -318,9 +381,9 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 18, help="resident sample rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--host-rows", action="store_true",
-                    help="also time the drop-in boundary as the reference drives it: dense TrainSample rows handed over in HOST "
-                         "memory (goctr_predict_dense: PCIe copy + predict + copy back); reported as recommend_qps_host_rows")
+    ap.add_argument("--no-serving", action="store_true",
+                    help="skip the two boundary-inclusive recommend QPS figures (recommend_qps_keys: goctr_batch_predict from sample "
+                         "keys; recommend_qps_host_rows: goctr_predict_dense from dense TrainSample rows in HOST memory)")
     ap.add_argument("--workload", default="din", choices=["din", "youtube", "mlp", "item2vec", "knn"],
                     help="din = BASELINE configs[2] (the headline metric, default); youtube = configs[3] per-GPU slice "
                          "(10M x 64 table: the HBM-bound gather); mlp = configs[1]; item2vec = configs[4] per-GPU slice")
@@ -338,46 +401,28 @@ def main():
         # BASELINE configs[3] / SURVEY 8(d) cfg4: YouTube-DNN, V = 10^7, D = 64, B = 16384 per GPU
         CFG.update(D=64, V=10_000_000, B=16384, KIND="youtube")
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from goctr_amd import launch
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher around us: become one.  Rank 0 prints the JSON line.
+        sys.exit(launch.spawn_local(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                    timeout=float(os.environ.get("GOCTR_BENCH_TIMEOUT", "1800"))))
+    rank, world, local_rank = launch.env_rank()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # control plane only (rendezvous / barrier / max); data plane is RCCL in the .so
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks", file=sys.stderr)
+        sys.exit(2)
 
     from goctr_amd import capi, model as gm
-    capi.init(local_rank)
+    capi.init(local_rank)             # (fails loudly here, before any rank waits on another, when there is no GPU)
     L = capi.load()
-    if world > 1:
-        import ctypes as C
-        import torch
-        idbuf = (C.c_uint8 * 128)()
-        if rank == 0:
-            capi.check(L.goctr_comm_unique_id(idbuf))
-        t = torch.tensor(list(idbuf), dtype=torch.uint8)
-        dist.broadcast(t, src=0)
-        idbuf = (C.c_uint8 * 128)(*t.tolist())
-        capi.check(L.goctr_comm_init(C.c_int(rank), C.c_int(world), idbuf))
+    rdv = launch.Rendezvous(rank, world)
+    rccl_world = launch.init_comm(rdv, local_rank)
 
     def barrier():
         capi.sync()
-        if dist is not None:
-            dist.barrier()
+        rdv.barrier()
 
     def max_over_ranks(x: float) -> float:
-        if dist is None:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return rdv.max(x)
 
     c = CFG
     emb, ub, it, uf, cf, y = synth(args.rows, 42 + rank)
@@ -388,7 +433,12 @@ def main():
     # sigmoids, most row gradients underflow to exactly 0 and the scatter-add (which skips zeros) would look cheaper than
     # it is on a model that is actually learning
     init_weights(m, 1, 0.05 if args.train_emb > 0 else 1.0)
-    cfg = capi.default_train_cfg(batch=c["B"], epochs=1)
+    # the reference ALWAYS trains with Dropout (0.005 DIN, din.go:204-205,307-312; 0.003 YouTube, dnn.go:136-137): the timed
+    # step applies it too (counter-hash masks; GOCTR_BENCH_DROPOUT=0 for A/B experiments only)
+    pdrop = 0.003 if c["KIND"] == "youtube" else 0.005
+    cfg = capi.default_train_cfg(batch=c["B"], epochs=1, dropout_mode=2, p0=pdrop, p1=pdrop, seed=42)
+    if os.environ.get("GOCTR_BENCH_DROPOUT", "1") == "0":
+        cfg.dropout_mode = 0
     if args.train_emb > 0:
         m.set_embedding_training(args.train_emb)
 
@@ -398,7 +448,9 @@ def main():
     t0 = time.perf_counter()
     gm.train_steps(m, ds, cfg, args.steps, first_batch=args.warmup, emb=tab)
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    dt_local = time.perf_counter() - t0
+    per_rank_ms = [round(x / args.steps * 1e3, 4) for x in rdv.allgather(dt_local)]
+    dt = max_over_ranks(dt_local)
     samples_per_s = args.steps * c["B"] * world / dt
 
     # ---- recommend QPS: rows scored per second through the predict path (PredBatch 4096)
@@ -421,33 +473,22 @@ def main():
                                 "(2.56 GB table replicated per GPU, frozen = reference semantics), batch 16384 per GPU, id mode"
                                 if c["KIND"] == "youtube" else
                                 "BASELINE configs[2]: DIN cosine attention, T=50, D=16, U=52, C=53, vocab 26744, "
-                                "batch 8192 per GPU, id mode (keys + table resident in HBM)"),
+                                "batch 8192 per GPU, id mode (keys + table resident in HBM)") +
+                               (f"; Dropout({pdrop}) on both hidden layers like the reference" if cfg.dropout_mode else "; dropout OFF (experiment)"),
                    "numerics": ("float32 in, float32 out; forward / backward-data GEMMs on v_mfma_f32_16x16x4_f32, weight-gradient GEMMs on "
                                 "the 6-product bf16 split with float32 accumulation (measured MORE accurate than the f32 MFMA: "
                                 "2.8e-8 vs 1.3e-7 of sum|ab|, scripts/ubench/bf16x3.hip; GOCTR_TN_F32=1 selects the f32 MFMA body)"),
                    "global_batch": c["B"] * world, "parallelism": f"dp{world}", "resident_rows_per_gpu": args.rows},
         "recommend_qps": round(qps, 1), "recommend_batch": c["PRED_B"],
+        "rccl_world": rccl_world, "per_rank_ms_per_step": per_rank_ms,
     }
     if args.train_emb > 0:
         out["config"]["workload"] += (f"; EXTENSION: embedding table trained too (SGD scatter-add, lr {args.train_emb}; "
                                       "the reference keeps it frozen; weights 0.05 N(0,1) so that the row gradients are non-zero)")
         out["config"]["train_embeddings"] = True
 
-    if args.host_rows and rank == 0:
-        # model.Predict's own calling convention (model.go:242): X [rows, XCols] float32 in host memory, y back to the host
-        from oracle import pyoracle           # (only to assemble dense rows from the synthetic keys; not timed)
-        from goctr_amd import recommend as gr
-        n = 1 << 16
-        X = pyoracle.assemble_rows(emb, ub[:n], it[:n], uf[:n], cf[:n])
-        si = gr.SampleInfo.from_dims(c["U"], c["T"], c["D"], c["C"])
-        gm.Predict(m, n, c["PRED_B"], si, X)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            gm.Predict(m, n, c["PRED_B"], si, X)
-        dth = (time.perf_counter() - t0) / 3
-        out["recommend_qps_host_rows"] = round(n / dth, 1)
-        out["host_rows_note"] = (f"{n} dense rows x {X.shape[1]} f32 = {X.nbytes / 1e6:.0f} MB over PCIe per call, predict, "
-                                 f"y back: {dth * 1e3:.1f} ms per call")
+    if rank == 0 and not args.no_serving:
+        out.update(serving_qps(m, tab, emb, ub, it, uf, cf))
 
     # ---- roofline: instrumented re-run of the same K steps (eager, hipEvent pair per launch)
     if not args.no_roofline:
@@ -479,17 +520,16 @@ def main():
                     grl["traffic"], grl["traffic_source"] = pmc_traffic("attn_fwd")
                 out["gather_roofline"] = grl
             out["kernels"] = table
-    if dist is not None:
-        dist.barrier()
+    rdv.barrier()
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
+        print(json.dumps(out), flush=True)
+    rdv.barrier()
+    if world > 1:
         L.goctr_comm_destroy()
-        dist.destroy_process_group()
+    rdv.close()
 
 
 if __name__ == "__main__":

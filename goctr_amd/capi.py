@@ -63,6 +63,7 @@ SYMBOLS = [
     "goctr_w2v_get_paths", "goctr_w2v_train", "goctr_w2v_upload_doc", "goctr_w2v_train_resident",
     "goctr_w2v_export_f32", "goctr_searcher_create", "goctr_searcher_destroy", "goctr_searcher_search",
     "goctr_ubcache_create", "goctr_ubcache_destroy", "goctr_ubcache_get", "goctr_dataset_create_keys", "goctr_dataset_get_ids",
+    "goctr_recsys_create", "goctr_recsys_destroy", "goctr_batch_predict", "goctr_rank",
     "goctr_corpus_create", "goctr_corpus_destroy", "goctr_corpus_append", "goctr_corpus_build", "goctr_corpus_info",
     "goctr_corpus_get_dictionary", "goctr_corpus_get_doc", "goctr_w2v_create_from_corpus", "goctr_w2v_use_corpus",
     "goctr_w2v_get_keep_mask",
@@ -84,7 +85,7 @@ def load() -> C.CDLL:
         _lib.goctr_prof_name.restype = C.c_char_p
         _lib.goctr_mlp_nparams.restype = C.c_size_t
         for name in ("goctr_model_destroy", "goctr_emb_destroy", "goctr_dataset_destroy", "goctr_mlp_destroy",
-                     "goctr_w2v_destroy", "goctr_searcher_destroy", "goctr_ubcache_destroy", "goctr_train_cfg_default", "goctr_mlp_cfg_default",
+                     "goctr_w2v_destroy", "goctr_searcher_destroy", "goctr_ubcache_destroy", "goctr_recsys_destroy", "goctr_train_cfg_default", "goctr_mlp_cfg_default",
                      "goctr_w2v_cfg_default"):
             getattr(_lib, name).restype = None
     return _lib

@@ -87,7 +87,7 @@ using namespace goctr;
 extern "C" {
 
 int goctr_comm_unique_id(uint8_t id[128]) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   if (load_rccl()) return -1;
   ncclUniqueId u;
@@ -97,7 +97,7 @@ int goctr_comm_unique_id(uint8_t id[128]) {
 }
 
 int goctr_comm_init(int rank, int world, const uint8_t id[128]) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(world >= 1 && rank >= 0 && rank < world, "goctr_comm_init: bad rank %d / world %d", rank, world);
   Engine& e = engine();
   if (e.nccl_comm) goctr_comm_destroy();
@@ -120,7 +120,7 @@ int goctr_comm_world(int* rank, int* world) {
 }
 
 int goctr_comm_allreduce_f64(double* v, int n) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   Engine& e = engine();
   if (!e.comm_active()) return 0;
   DevBuf<double> d;
@@ -130,6 +130,7 @@ int goctr_comm_allreduce_f64(double* v, int n) {
 }
 
 int goctr_comm_destroy(void) {
+  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
   Engine& e = engine();
   if (e.nccl_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)e.nccl_comm);
   e.nccl_comm = nullptr; e.rank = 0; e.world = 1;

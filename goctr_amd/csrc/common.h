@@ -59,6 +59,19 @@ struct Engine {
 Engine& engine();
 int require_engine();  // 0 if goctr_init succeeded, else sets the error and returns -1
 
+// Every C-ABI entry point that touches the device starts with GOCTR_ENTER(): the engine has ONE submission stream
+// (and captures step graphs on it), so calls from different host threads -- goroutines of a cgo host, e.g. concurrent
+// PredictAbstract.Predict from gin handlers, recommend/api.go:106-131 -- are serialised engine-wide, whatever handles
+// they use.  Recursive: entry points call each other (goctr_train_dense -> goctr_dataset_create_dense -> ...).
+std::recursive_mutex& engine_mutex();
+#define GOCTR_ENTER()                              \
+  if (::goctr::require_engine()) return -1;        \
+  std::lock_guard<std::recursive_mutex> _goctr_engine_lock(::goctr::engine_mutex())
+
+// generation ids for handles whose device pointers get baked into captured graphs (a freed handle's host address may be
+// handed out again by malloc; its uid never is)
+uint64_t next_uid();
+
 // timing scope used around every launch of a kernel family when profiling is on
 struct ProfScope {
   int id; bool on; hipEvent_t a = nullptr, b = nullptr;

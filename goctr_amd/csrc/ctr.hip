@@ -21,11 +21,13 @@
 using namespace goctr;
 
 struct goctr_emb {
+  const uint64_t uid = next_uid();   // what a captured step graph is keyed on (never reused, unlike the host address)
   int64_t V = 0; int D = 0;
   DevBuf<float> rows;
 };
 
 struct goctr_dataset {
+  const uint64_t uid = next_uid();
   bool id_mode = false;
   int64_t rows = 0;
   bool has_y = false;
@@ -41,7 +43,9 @@ struct StepGraph {
   // b[] only when a communicator splits the step (all-reduce between reduce and Adam).
   hipGraphExec_t a[2] = {nullptr, nullptr}, b[2] = {nullptr, nullptr};
   // cache key
-  const void* ds = nullptr; const void* emb = nullptr; int B = 0; int mode = 0; float p0 = 0, p1 = 0;
+  // (the captured launches bake in the dataset's / table's device pointers and row count: keyed on the handles'
+  // generation ids, not their host addresses -- malloc readily hands a destroyed dataset's address to the next one)
+  uint64_t ds = 0, emb = 0; int B = 0; int mode = 0; float p0 = 0, p1 = 0;
   uint32_t seed = 0; double lr = 0, l2 = 0, b1 = 0, b2 = 0, eps = 0; int flags = 0; int world = 1; bool comm = false;
   void destroy() {
     for (int k = 0; k < 2; ++k) {
@@ -63,6 +67,7 @@ struct goctr_model {
   int wsB = 0, tnS = 0;
   DevBuf<float> h0, P0, A0, P1, A1, yhat, lossrow, dz2, dz1, dz0, dp, gate, wgt, slabs0, slabs1, slabs2, attp;
   DevBuf<float> mask0, mask1, slabs3, ones16;
+  DevBuf<float> yall;          // scores of a whole predict call (one device-to-host copy at the end)
   DevBuf<StepState> st, pst;   // st: two ping-pong slots, stp = the one the next step reads
   int stp = 0;
   StepState* st_cur() { return st.p + stp; }
@@ -76,7 +81,7 @@ struct goctr_model {
   bool pred_img_valid = false;
   // trainable-embedding extension (emb_train.h): off unless goctr_model_set_embedding_training(lr > 0)
   float emb_lr = 0.f;
-  long long emb_V = 0; int emb_B = 0;
+  long long emb_V = 0; int emb_B = 0, emb_world = 0; bool emb_comm = false;
   DevBuf<float> dpv, W0pvT;
   DevBuf<unsigned int> emb_mark, emb_rank, emb_tiles;
   DevBuf<unsigned long long> emb_total;
@@ -449,7 +454,9 @@ AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc);
 // Buffers of the sparse embedding update.  Allocated (and zeroed) BEFORE a step is captured into a hipGraph: a
 // hipMemsetAsync issued during capture becomes a graph node and would re-zero hundreds of MB on every replay.
 int ensure_emb_workspace(goctr_model* m, long long V, int B) {
-  if (m->emb_lr <= 0.f || (m->emb_V == V && m->emb_B == B)) return 0;
+  // (the accumulators are sized for the UNION of all ranks' ids: a communicator created after the first step changes it)
+  if (m->emb_lr <= 0.f || (m->emb_V == V && m->emb_B == B && m->emb_world == engine().world &&
+                           m->emb_comm == engine().comm_active())) return 0;
   const goctr_ctr_cfg& c = m->cfg;
   const int Np = round_up(2 * c.D, 16);
   const long long cap = std::min<long long>(V, (long long)B * (c.T + 1) * engine().world);
@@ -458,7 +465,7 @@ int ensure_emb_workspace(goctr_model* m, long long V, int B) {
       m->emb_slot_id.alloc((size_t)cap, false) || m->emb_tiles.alloc((size_t)cdiv(V, SCAN_TILE), false))
     return -1;
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
-  m->emb_V = V; m->emb_B = B;
+  m->emb_V = V; m->emb_B = B; m->emb_world = engine().world; m->emb_comm = engine().comm_active();
   m->graph.destroy();
   return 0;
 }
@@ -485,7 +492,8 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   const int Np = round_up(2 * c.D, 16);
   const long long V = src.V;
   const long long cap = std::min<long long>(V, (long long)B * (c.T + 1) * e.world);   // the UNION of all ranks' ids gets slots
-  GOCTR_CHECK(m->emb_V == V && m->emb_B == B, "embedding-training workspace not prepared (ensure_emb_workspace)");
+  GOCTR_CHECK(m->emb_V == V && m->emb_B == B && m->emb_world == e.world && m->emb_comm == e.comm_active(),
+              "embedding-training workspace not prepared (ensure_emb_workspace)");
   EmbTrainArgs a{};
   a.src = src; a.st = st; a.B = B; a.T = c.T; a.D = c.D; a.kind = c.kind; a.att = c.att;
   a.dpv = m->dpv.p; a.ldp = Np; a.gate = m->gate.p; a.wgt = m->wgt.p; a.att0 = m->W.p + m->offa;
@@ -710,7 +718,7 @@ int train_step_eager(goctr_model* m, const RowSource& src, int B, const StepOpts
 }
 
 bool graph_matches(const StepGraph& g, const goctr_dataset* d, const goctr_emb* e, int B, const StepOpts& o) {
-  return g.a[0] && g.a[1] && g.ds == d && g.emb == e && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
+  return g.a[0] && g.a[1] && g.ds == d->uid && g.emb == (e ? e->uid : 0) && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
          g.seed == o.seed && g.lr == o.tc->lr && g.l2 == o.tc->l2 && g.b1 == o.tc->beta1 && g.b2 == o.tc->beta2 &&
          g.eps == o.tc->eps && g.flags == o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div &&
          g.world == engine().world && g.comm == engine().comm_active();
@@ -746,7 +754,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   }
   m->stp = stp_now;
   StepGraph& sg = m->graph;
-  sg.ds = d; sg.emb = emb; sg.B = B; sg.mode = o.drop_mode; sg.p0 = o.p0; sg.p1 = o.p1; sg.seed = o.seed;
+  sg.ds = d->uid; sg.emb = emb ? emb->uid : 0; sg.B = B; sg.mode = o.drop_mode; sg.p0 = o.p0; sg.p1 = o.p1; sg.seed = o.seed;
   sg.lr = o.tc->lr; sg.l2 = o.tc->l2; sg.b1 = o.tc->beta1; sg.b2 = o.tc->beta2; sg.eps = o.tc->eps;
   sg.flags = o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div; sg.world = e.world; sg.comm = e.comm_active();
   return 0;
@@ -925,11 +933,11 @@ void goctr_train_cfg_default(goctr_train_cfg* c) {
   c->lr = 0.01; c->l2 = 0.0001;                           // model.go:88
   c->beta1 = 0.9; c->beta2 = 0.999; c->eps = 1e-8;
   c->adam_div_by_batch = 1; c->adam_l2_before_batch_div = 1;
-  c->dropout_mode = 0; c->p0 = 0.005f; c->p1 = 0.005f; c->seed = 42;
+  c->dropout_mode = 2; c->p0 = 0.005f; c->p1 = 0.005f; c->seed = 42;   // din.go:204-205,307-312: Dropout is always on
 }
 
 int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(cfg && out, "goctr_model_create: null argument");
   GOCTR_CHECK(cfg->kind == GOCTR_DIN || cfg->kind == GOCTR_YOUTUBE, "unknown model kind %d", cfg->kind);
   GOCTR_CHECK(cfg->U >= 0 && cfg->T > 0 && cfg->D > 0 && cfg->C >= 0 && cfg->H1 > 0 && cfg->H2 > 0, "bad model dims");
@@ -955,19 +963,21 @@ int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
 
 void goctr_model_destroy(goctr_model* m) {
   if (!m) return;
+  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
+  if (engine().inited) (void)hipStreamSynchronize(engine().stream);
   m->graph.destroy();
   delete m;
 }
 
 int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, size_t n) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && host, "goctr_model_set_weights: null argument");
   std::lock_guard<std::mutex> lk(m->mu);
   return upload_padded_weights(m, tensor_id, host, n);
 }
 
 int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && host, "goctr_model_get_weights: null argument");
   std::lock_guard<std::mutex> lk(m->mu);
   return download_padded(m, m->W.p, tensor_id, host, n);
@@ -1009,14 +1019,14 @@ int upload_padded_flat(goctr_model* m, float* flat_dev, int tensor_id, const flo
 }
 
 int goctr_model_get_moments(goctr_model* m, int tensor_id, int which, float* host, size_t n) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && host && (which == 0 || which == 1), "goctr_model_get_moments: bad argument");
   std::lock_guard<std::mutex> lk(m->mu);
   return download_padded(m, which ? m->Vo.p : m->Mo.p, tensor_id, host, n);
 }
 
 int goctr_model_set_moments(goctr_model* m, int tensor_id, int which, const float* host, size_t n) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && host && (which == 0 || which == 1), "goctr_model_set_moments: bad argument");
   std::lock_guard<std::mutex> lk(m->mu);
   return upload_padded_flat(m, which ? m->Vo.p : m->Mo.p, tensor_id, host, n);
@@ -1024,7 +1034,7 @@ int goctr_model_set_moments(goctr_model* m, int tensor_id, int which, const floa
 
 // Global step counter: Adam's iteration number and the dropout stream position.
 int goctr_model_get_step(goctr_model* m, uint32_t* step) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && step, "goctr_model_get_step: null argument");
   std::lock_guard<std::mutex> lk(m->mu);
   StepState s;
@@ -1034,14 +1044,14 @@ int goctr_model_get_step(goctr_model* m, uint32_t* step) {
 }
 
 int goctr_model_set_step(goctr_model* m, uint32_t step) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m, "goctr_model_set_step: null argument");
   std::lock_guard<std::mutex> lk(m->mu);
   return set_state(m, step, 0, 0, 1);
 }
 
 int goctr_model_set_embedding_training(goctr_model* m, double lr) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && lr >= 0 && lr == lr, "goctr_model_set_embedding_training: bad arguments");
   std::lock_guard<std::mutex> lk(m->mu);
   GOCTR_CHECK(lr == 0 || m->cfg.D <= 64, "embedding training supports D <= 64 (got %d)", m->cfg.D);
@@ -1051,13 +1061,13 @@ int goctr_model_set_embedding_training(goctr_model* m, double lr) {
 }
 
 int goctr_emb_get_rows(goctr_emb* e, int64_t first, int64_t n, float* host_rows) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(e && host_rows && first >= 0 && n >= 0 && first + n <= e->V, "goctr_emb_get_rows: range out of bounds");
   return n ? e->rows.download(host_rows, (size_t)n * e->D, (size_t)first * e->D) : 0;
 }
 
 int goctr_model_reset_optimizer(goctr_model* m) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   std::lock_guard<std::mutex> lk(m->mu);
   GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
   GOCTR_HIP(hipMemsetAsync(m->Vo.p, 0, sizeof(float) * m->nflat, engine().stream));
@@ -1066,7 +1076,7 @@ int goctr_model_reset_optimizer(goctr_model* m) {
 
 // ------------------------------------------------------------------ embedding table / gather
 int goctr_emb_create(int64_t V, int D, const float* host_rows, goctr_emb** out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(V > 0 && D > 0 && out, "goctr_emb_create: bad arguments");
   std::unique_ptr<goctr_emb> e(new goctr_emb);
   e->V = V; e->D = D;
@@ -1076,15 +1086,20 @@ int goctr_emb_create(int64_t V, int D, const float* host_rows, goctr_emb** out) 
   return 0;
 }
 int goctr_emb_set_rows(goctr_emb* e, int64_t first, int64_t n, const float* host_rows) {
-  if (require_engine()) return -1;
-  GOCTR_CHECK(e && host_rows && first >= 0 && first + n <= e->V, "goctr_emb_set_rows: range out of bounds");
-  return e->rows.upload(host_rows, (size_t)n * e->D, (size_t)first * e->D);
+  GOCTR_ENTER();
+  GOCTR_CHECK(e && host_rows && first >= 0 && n >= 0 && first + n <= e->V, "goctr_emb_set_rows: range out of bounds");
+  return n ? e->rows.upload(host_rows, (size_t)n * e->D, (size_t)first * e->D) : 0;
 }
-void goctr_emb_destroy(goctr_emb* e) { delete e; }
+void goctr_emb_destroy(goctr_emb* e) {
+  if (!e) return;
+  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
+  if (engine().inited) (void)hipStreamSynchronize(engine().stream);
+  delete e;
+}
 
 int goctr_gather_rows(goctr_emb* e, const int32_t* ub_ids, const int32_t* item_ids, const float* user_feat, int U,
                       const float* ctx_feat, int C, int T, int64_t rows, float* X_out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(e && X_out && rows >= 0, "goctr_gather_rows: bad arguments");
   if (rows == 0) return 0;
   const int xcols = U + T * e->D + e->D + C;
@@ -1103,7 +1118,7 @@ int goctr_gather_rows(goctr_emb* e, const int32_t* ub_ids, const int32_t* item_i
 // ------------------------------------------------------------------ datasets
 int goctr_dataset_create_dense(const float* X, const float* Y, int64_t rows, int xcols, const int ranges[8],
                                goctr_dataset** out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(X && rows > 0 && xcols > 0 && ranges && out, "goctr_dataset_create_dense: bad arguments");
   std::unique_ptr<goctr_dataset> d(new goctr_dataset);
   d->id_mode = false; d->rows = rows; d->xcols = xcols;
@@ -1116,7 +1131,7 @@ int goctr_dataset_create_dense(const float* X, const float* Y, int64_t rows, int
 
 int goctr_dataset_create_ids(const int32_t* ub_ids, const int32_t* item_ids, const float* user_feat, int U,
                              const float* ctx_feat, int C, int T, const float* Y, int64_t rows, goctr_dataset** out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(ub_ids && item_ids && rows > 0 && T > 0 && out, "goctr_dataset_create_ids: bad arguments");
   std::unique_ptr<goctr_dataset> d(new goctr_dataset);
   d->id_mode = true; d->rows = rows; d->U = U; d->C = C; d->T = T;
@@ -1128,7 +1143,12 @@ int goctr_dataset_create_ids(const int32_t* ub_ids, const int32_t* item_ids, con
   *out = d.release();
   return 0;
 }
-void goctr_dataset_destroy(goctr_dataset* d) { delete d; }
+void goctr_dataset_destroy(goctr_dataset* d) {
+  if (!d) return;
+  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
+  if (engine().inited) (void)hipStreamSynchronize(engine().stream);   // queued (asynchronous) steps may still read the rows
+  delete d;
+}
 
 }  // extern "C"
 
@@ -1151,14 +1171,28 @@ __global__ __launch_bounds__(256) void assemble_keys_kernel(const long long* __r
                                                             const int32_t* __restrict__ users, const int32_t* __restrict__ items,
                                                             const long long* __restrict__ ts, long long rows, int T,
                                                             int32_t* __restrict__ ub_ids, float* __restrict__ ufeat,
-                                                            float* __restrict__ cfeat) {
+                                                            float* __restrict__ cfeat, int32_t* __restrict__ item_out,
+                                                            unsigned char* __restrict__ failed) {
   const int lane = threadIdx.x & 63;
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wavefront per sample
   if (r >= rows) return;
   const int u = users[r];
-  const bool uok = u >= 0 && u < n_users;
+  bool uok = u >= 0 && u < n_users;
+  if (failed) {
+    // BatchPredict (rcmd.go:291-307): a key whose GetUserFeature / GetItemFeature fails is scored as the ALL-zero row
+    // (user features, behaviours, item embedding and item features alike)
+    const int it = items[r];
+    const bool ok = uok && it >= 0 && it < n_items;
+    if (lane == 0) { failed[r] = ok ? 0 : 1; item_out[r] = ok ? it : -1; }
+    if (!ok) {
+      for (int j = lane; j < T; j += 64) ub_ids[r * T + j] = -1;
+      for (int j = lane; j < U; j += 64) ufeat[r * U + j] = 0.f;
+      for (int j = lane; j < C; j += 64) cfeat[r * C + j] = 0.f;
+      return;
+    }
+  }
   long long first = 0, cnt = 0;
-  const long long b = uok ? off[u] : 0, len = uok ? off[u + 1] - b : 0;
+  const long long b = (uok && off) ? off[u] : 0, len = (uok && off) ? off[u + 1] - b : 0;   // off == NULL: no behaviour cache
   if (len > 0) {
     long long mts = ts ? ts[r] : 0;
     if (mts == 0) mts = seq_ts[b];                       // cache.go:72-74
@@ -1185,7 +1219,7 @@ __global__ __launch_bounds__(256) void assemble_keys_kernel(const long long* __r
 extern "C" {
 
 int goctr_ubcache_create(int64_t n_users, const int64_t* off, const int32_t* items, const int64_t* ts, goctr_ubcache** out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(n_users > 0 && off && out && off[0] == 0, "goctr_ubcache_create: bad arguments");
   const int64_t nnz = off[n_users];
   GOCTR_CHECK(nnz >= 0 && (nnz == 0 || (items && ts)), "goctr_ubcache_create: sequences missing");
@@ -1207,7 +1241,7 @@ int goctr_ubcache_create(int64_t n_users, const int64_t* off, const int32_t* ite
 void goctr_ubcache_destroy(goctr_ubcache* c) { delete c; }
 
 int goctr_ubcache_get(goctr_ubcache* c, const int32_t* users, const int64_t* max_ts, int64_t rows, int T, int32_t* out_ids) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(c && users && out_ids && rows > 0 && T > 0, "goctr_ubcache_get: bad arguments");
   DevBuf<int32_t> du, dout; DevBuf<long long> dts;
   std::vector<long long> t(rows, 0);
@@ -1216,7 +1250,8 @@ int goctr_ubcache_get(goctr_ubcache* c, const int32_t* users, const int64_t* max
       dout.alloc((size_t)rows * T, false)) return -1;
   hipLaunchKernelGGL(assemble_keys_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, engine().stream, c->off.p, c->items.p,
                      c->ts.p, (long long)c->n_users, (const float*)nullptr, 0, (const float*)nullptr, 0LL, 0, du.p,
-                     (const int32_t*)nullptr, dts.p, (long long)rows, T, dout.p, (float*)nullptr, (float*)nullptr);
+                     (const int32_t*)nullptr, dts.p, (long long)rows, T, dout.p, (float*)nullptr, (float*)nullptr,
+                     (int32_t*)nullptr, (unsigned char*)nullptr);
   GOCTR_HIP(hipGetLastError());
   return dout.download(out_ids, (size_t)rows * T);
 }
@@ -1224,8 +1259,9 @@ int goctr_ubcache_get(goctr_ubcache* c, const int32_t* users, const int64_t* max
 int goctr_dataset_create_keys(goctr_ubcache* c, const float* user_table, int64_t n_users, int U, const float* item_table,
                               int64_t n_items, int C, const int32_t* users, const int32_t* items, const int64_t* ts,
                               const float* Y, int64_t rows, int T, goctr_dataset** out) {
-  if (require_engine()) return -1;
-  GOCTR_CHECK(c && users && items && rows > 0 && T > 0 && out, "goctr_dataset_create_keys: bad arguments");
+  GOCTR_ENTER();
+  GOCTR_CHECK(c && users && items && rows > 0 && T > 0 && out && n_items >= 0 && U >= 0 && C >= 0,
+              "goctr_dataset_create_keys: bad arguments");
   GOCTR_CHECK(n_users == c->n_users, "goctr_dataset_create_keys: user table has %lld rows, the behaviour cache %lld users",
               (long long)n_users, (long long)c->n_users);
   GOCTR_CHECK((U == 0 || user_table) && (C == 0 || item_table), "goctr_dataset_create_keys: feature table missing");
@@ -1241,7 +1277,7 @@ int goctr_dataset_create_keys(goctr_ubcache* c, const float* user_table, int64_t
   if (d->ufeat.alloc((size_t)rows * U, false) || d->cfeat.alloc((size_t)rows * C, false)) return -1;
   hipLaunchKernelGGL(assemble_keys_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, engine().stream, c->off.p, c->items.p,
                      c->ts.p, (long long)c->n_users, dut.p, U, dit.p, (long long)n_items, C, du.p, d->item_ids.p, dts.p,
-                     (long long)rows, T, d->ub_ids.p, d->ufeat.p, d->cfeat.p);
+                     (long long)rows, T, d->ub_ids.p, d->ufeat.p, d->cfeat.p, (int32_t*)nullptr, (unsigned char*)nullptr);
   GOCTR_HIP(hipGetLastError());
   GOCTR_HIP(hipStreamSynchronize(engine().stream));   // the temporaries above are released on return
   if (Y) { if (d->Y.alloc(rows, false) || d->Y.upload(Y, rows)) return -1; d->has_y = true; }
@@ -1251,7 +1287,7 @@ int goctr_dataset_create_keys(goctr_ubcache* c, const float* user_table, int64_t
 
 // read back the assembled keys of an id-mode dataset (tests, debugging)
 int goctr_dataset_get_ids(goctr_dataset* d, int32_t* ub_ids, float* user_feat, float* ctx_feat) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(d && d->id_mode, "goctr_dataset_get_ids: not an id-mode dataset");
   if (ub_ids && d->ub_ids.download(ub_ids, (size_t)d->rows * d->T)) return -1;
   if (user_feat && d->U && d->ufeat.download(user_feat, (size_t)d->rows * d->U)) return -1;
@@ -1266,7 +1302,7 @@ extern "C" {
 // ------------------------------------------------------------------ training
 int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,
                       int64_t first_batch, int n_steps, float* costs) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && d && cfg && cfg->batch > 0 && n_steps >= 0, "goctr_train_steps: bad arguments");
   GOCTR_CHECK(d->has_y, "goctr_train_steps: dataset has no labels");
   GOCTR_CHECK(cfg->dropout_mode == 0 || cfg->dropout_mode == 2, "multi-step training supports dropout_mode 0 or 2");
@@ -1287,7 +1323,7 @@ int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const go
 
 int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,
                         float* epoch_costs, int* epochs_run) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && d && cfg && cfg->batch > 0 && cfg->epochs >= 0, "goctr_train_dataset: bad arguments");
   GOCTR_CHECK(d->has_y, "goctr_train_dataset: dataset has no labels");
   GOCTR_CHECK(cfg->dropout_mode == 0 || cfg->dropout_mode == 2, "multi-step training supports dropout_mode 0 or 2");
@@ -1297,6 +1333,15 @@ int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const 
   GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
   GOCTR_HIP(hipMemsetAsync(m->Vo.p, 0, sizeof(float) * m->nflat, engine().stream));
   const long long nb = cdiv(d->rows, cfg->batch);
+  if (engine().comm_active()) {
+    // every rank issues one all-reduce per batch: unequal shard sizes would leave the shorter ranks' peers hanging
+    double v[2] = {(double)nb, (double)nb * (double)nb};
+    if (goctr_comm_allreduce_f64(v, 2)) return -1;
+    const double w = (double)engine().world;
+    GOCTR_CHECK(v[0] == w * (double)nb && v[1] == w * (double)nb * (double)nb,
+                "goctr_train_dataset: the ranks' shards have different batch counts (this rank: %lld batches of %d); "
+                "shard the rows so that every rank steps the same number of times", nb, cfg->batch);
+  }
   if (set_state(m, 0, 0, 0, nb)) return -1;
   float best = 3.402823466e+38f;  // math.MaxFloat32 (model.go:103)
   int no_improve = 0, e = 0;
@@ -1323,12 +1368,17 @@ int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const 
 
 int goctr_train_dense(goctr_model* m, const float* X, const float* Y, int64_t rows, int xcols, const int ranges[8],
                       const goctr_train_cfg* cfg, float* epoch_costs, int* epochs_run) {
+  GOCTR_ENTER();
   goctr_dataset* d = nullptr;
+  GOCTR_CHECK(m && cfg, "goctr_train_dense: null argument");
   GOCTR_CHECK(Y != nullptr, "goctr_train_dense: labels required");
   if (goctr_dataset_create_dense(X, Y, rows, xcols, ranges, &d)) return -1;
   int rc = goctr_train_dataset(m, nullptr, d, cfg, epoch_costs, epochs_run);
   if (!rc) rc = goctr_sync();
-  m->graph.destroy();  // the graph holds pointers into the temporary dataset
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->graph.destroy();  // (keyed on the dataset's generation id, so it could never be replayed again anyway)
+  }
   goctr_dataset_destroy(d);
   return rc;
 }
@@ -1336,7 +1386,7 @@ int goctr_train_dense(goctr_model* m, const float* X, const float* Y, int64_t ro
 int goctr_loss_grad_dense(goctr_model* m, const float* X, const float* Y, int valid, int B, int xcols,
                           const int ranges[8], const goctr_train_cfg* cfg, uint32_t step, const float* m0,
                           const float* m1, float* cost, float* gW0, float* gW1, float* gW2, float* gatt0, float* y_out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && X && Y && cfg && valid > 0 && valid <= B, "goctr_loss_grad_dense: bad arguments");
   goctr_dataset* d = nullptr;
   if (goctr_dataset_create_dense(X, Y, valid, xcols, ranges, &d)) return -1;
@@ -1353,6 +1403,10 @@ int goctr_loss_grad_dense(goctr_model* m, const float* X, const float* Y, int va
   }
   StepState saved;
   if (get_state(m, &saved)) return -1;
+  struct Restore {   // the caller's step counter / dropout stream position survives every exit path
+    goctr_model* m; const StepState& s; bool armed = true;
+    ~Restore() { if (armed) (void)set_state(m, s.gstep, s.slot, s.batch_idx, s.n_batches); }
+  } restore{m, saved};
   if (set_state(m, step, 0, 0, 1)) return -1;
   RowSource src = make_source(d, nullptr);
   int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, false);
@@ -1371,6 +1425,7 @@ int goctr_loss_grad_dense(goctr_model* m, const float* X, const float* Y, int va
     *cost = -(s / (float)(B * engine().world));
   }
   if (y_out && m->yhat.download(y_out, B)) return -1;
+  restore.armed = false;
   return set_state(m, saved.gstep, saved.slot, saved.batch_idx, saved.n_batches);
 }
 
@@ -1386,6 +1441,7 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
   // per-batch states are written up front so that no host stack memory is read asynchronously
   const int64_t CH = 4096;
   if (m->pst.ensure((size_t)std::min<int64_t>(n_batches, CH), false)) return -1;
+  if (y_host && m->yall.ensure((size_t)d->rows, false)) return -1;
   std::vector<StepState> hs;
   for (int64_t k0 = 0; k0 < n_batches; k0 += CH) {
     const int64_t cnt = std::min<int64_t>(CH, n_batches - k0);
@@ -1397,16 +1453,23 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
       if (y_host) {
         const long long b = hs[k].batch_idx;
         const long long start = b * batch, end = std::min<long long>(start + batch, d->rows);
-        if (m->yhat.download(y_host + start, (size_t)(end - start))) return -1;  // first end-start outputs (model.go:344-347)
+        // first end-start outputs (model.go:344-347), collected on the device: one copy to the host per call
+        GOCTR_HIP(hipMemcpyAsync(m->yall.p + start, m->yhat.p, sizeof(float) * (size_t)(end - start), hipMemcpyDeviceToDevice,
+                                 engine().stream));
       }
     }
     if (k0 + CH < n_batches) GOCTR_HIP(hipStreamSynchronize(engine().stream));  // before the states are overwritten
+  }
+  if (y_host) {
+    // (callers always score from batch 0: every row of [0, min(rows, n_batches * batch)) was written above)
+    const long long n = std::min<long long>(d->rows, n_batches * (long long)batch);
+    if (m->yall.download(y_host, (size_t)n)) return -1;
   }
   return 0;
 }
 
 int goctr_predict_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, float* y_out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && d && y_out && batch > 0, "goctr_predict_dataset: bad arguments");
   std::lock_guard<std::mutex> lk(m->mu);
   return predict_batches(m, emb, d, batch, 0, cdiv(d->rows, batch), y_out);
@@ -1414,7 +1477,7 @@ int goctr_predict_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int 
 
 int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, int64_t first_batch,
                         int n_batches) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && d && batch > 0 && n_batches >= 0, "goctr_predict_steps: bad arguments");
   std::lock_guard<std::mutex> lk(m->mu);
   return predict_batches(m, emb, d, batch, first_batch, n_batches, nullptr);
@@ -1422,7 +1485,7 @@ int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int ba
 
 int goctr_predict_dense(goctr_model* m, const float* X, int64_t rows, int xcols, const int ranges[8], int batch,
                         float* y_out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(m && X && y_out && rows >= 0 && batch > 0, "goctr_predict_dense: bad arguments");
   if (rows == 0) return 0;
   goctr_dataset* d = nullptr;
@@ -1430,6 +1493,104 @@ int goctr_predict_dense(goctr_model* m, const float* X, int64_t rows, int xcols,
   int rc = goctr_predict_dataset(m, nullptr, d, batch, y_out);
   goctr_dataset_destroy(d);
   return rc;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ recommend.BatchPredict / Rank
+// recommend/rcmd.go:248-337: sample keys -> GetSampleVector rows -> PredictAbstract.Predict -> scores.  Everything
+// GetSampleVector reads per key (rcmd.go:462-536) is resident in HBM: the user / item feature tables (the contents of
+// UserFeatureCache / ItemFeatureCache), the behaviour cache and the item-embedding table, so one call is: copy the keys
+// (16 B each), one assembly launch, the predict launches, copy the scores back.
+struct goctr_recsys {
+  goctr_ubcache* ub = nullptr;    // not owned
+  goctr_emb* emb = nullptr;       // not owned
+  int64_t n_users = 0, n_items = 0; int U = 0, C = 0;
+  DevBuf<float> user_table, item_table;
+  // per-call scratch, grown on demand: the keys and the id-mode rows assembled from them
+  int64_t cap = 0; int capT = 0;
+  DevBuf<int32_t> users, items; DevBuf<long long> ts; DevBuf<unsigned char> failed;
+  goctr_dataset scratch;
+  std::mutex mu;
+};
+
+extern "C" {
+
+int goctr_recsys_create(goctr_ubcache* c, goctr_emb* emb, const float* user_table, int64_t n_users, int U,
+                        const float* item_table, int64_t n_items, int C, goctr_recsys** out) {
+  GOCTR_ENTER();
+  GOCTR_CHECK(emb && out && n_users > 0 && n_items > 0 && U >= 0 && C >= 0, "goctr_recsys_create: bad arguments");
+  GOCTR_CHECK((U == 0 || user_table) && (C == 0 || item_table), "goctr_recsys_create: feature table missing");
+  GOCTR_CHECK(!c || c->n_users == n_users, "goctr_recsys_create: user table has %lld rows, the behaviour cache %lld users",
+              (long long)n_users, c ? (long long)c->n_users : 0LL);
+  std::unique_ptr<goctr_recsys> r(new goctr_recsys);
+  r->ub = c; r->emb = emb; r->n_users = n_users; r->n_items = n_items; r->U = U; r->C = C;
+  if (r->user_table.alloc((size_t)n_users * U, false) || (U && r->user_table.upload(user_table, (size_t)n_users * U))) return -1;
+  if (r->item_table.alloc((size_t)n_items * C, false) || (C && r->item_table.upload(item_table, (size_t)n_items * C))) return -1;
+  *out = r.release();
+  return 0;
+}
+
+void goctr_recsys_destroy(goctr_recsys* r) {
+  if (!r) return;
+  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
+  if (engine().inited) (void)hipStreamSynchronize(engine().stream);
+  delete r;
+}
+
+int goctr_batch_predict(goctr_model* m, goctr_recsys* r, const int32_t* users, const int32_t* items, const int64_t* ts,
+                        int64_t n, int batch, float* scores, uint8_t* failed, int64_t* n_failed) {
+  GOCTR_ENTER();
+  GOCTR_CHECK(m && r && users && items && scores && n >= 0 && batch > 0, "goctr_batch_predict: bad arguments");
+  if (n_failed) *n_failed = 0;
+  if (n == 0) return 0;
+  // rcmd.go:293-296: a failing FIRST key aborts the call (there is no row width to build a zero row from yet)
+  GOCTR_CHECK(users[0] >= 0 && users[0] < r->n_users && items[0] >= 0 && items[0] < r->n_items,
+              "get sample vector error: first key (user %d, item %d) has no features", users[0], items[0]);
+  std::lock_guard<std::mutex> lk(r->mu);
+  const int T = m->cfg.T;
+  goctr_dataset& d = r->scratch;
+  if (n > r->cap || T != r->capT) {
+    const int64_t cap = std::max<int64_t>(n, 2 * r->cap);
+    GOCTR_HIP(hipStreamSynchronize(engine().stream));
+    if (r->users.alloc(cap, false) || r->items.alloc(cap, false) || r->ts.alloc(cap, false) || r->failed.alloc(cap, false) ||
+        d.ub_ids.alloc((size_t)cap * T, false) || d.item_ids.alloc(cap, false) || d.ufeat.alloc((size_t)cap * r->U, false) ||
+        d.cfeat.alloc((size_t)cap * r->C, false)) return -1;
+    r->cap = cap; r->capT = T;
+  }
+  d.id_mode = true; d.rows = n; d.U = r->U; d.C = r->C; d.T = T; d.has_y = false;
+  std::vector<long long> t(n, 0);
+  if (ts) for (int64_t i = 0; i < n; ++i) t[i] = ts[i];
+  if (r->users.upload(users, n) || r->items.upload(items, n) || r->ts.upload(t.data(), n)) return -1;
+  const goctr_ubcache* c = r->ub;
+  hipLaunchKernelGGL(assemble_keys_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, engine().stream,
+                     c ? c->off.p : (const long long*)nullptr, c ? c->items.p : (const int32_t*)nullptr,
+                     c ? c->ts.p : (const long long*)nullptr, (long long)r->n_users, r->user_table.p, r->U, r->item_table.p,
+                     (long long)r->n_items, r->C, r->users.p, r->items.p, r->ts.p, (long long)n, T, d.ub_ids.p, d.ufeat.p,
+                     d.cfeat.p, d.item_ids.p, r->failed.p);
+  GOCTR_HIP(hipGetLastError());
+  {
+    std::lock_guard<std::mutex> lm(m->mu);
+    if (predict_batches(m, r->emb, &d, batch, 0, cdiv(n, batch), scores)) return -1;
+  }
+  if (failed || n_failed) {
+    std::vector<unsigned char> f(n);
+    if (r->failed.download(f.data(), n)) return -1;
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < n; ++i) cnt += f[i] != 0;
+    if (failed) memcpy(failed, f.data(), n);
+    if (n_failed) *n_failed = cnt;
+  }
+  return 0;
+}
+
+int goctr_rank(goctr_model* m, goctr_recsys* r, int32_t user, const int32_t* items, int64_t n, int64_t ts, int batch,
+               float* scores, uint8_t* failed, int64_t* n_failed) {
+  GOCTR_ENTER();
+  GOCTR_CHECK(items && n >= 0, "goctr_rank: bad arguments");
+  std::vector<int32_t> u((size_t)n, user);
+  std::vector<int64_t> t((size_t)n, ts);
+  return goctr_batch_predict(m, r, u.data(), items, t.data(), n, batch, scores, failed, n_failed);
 }
 
 }  // extern "C"

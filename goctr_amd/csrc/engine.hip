@@ -2,6 +2,7 @@
 // per-kernel timers.  (No reference counterpart: go-ctr has no device runtime)
 #include "common.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <map>
 
@@ -21,6 +22,16 @@ void set_error(const char* fmt, ...) {
 Engine& engine() {
   static Engine e;
   return e;
+}
+
+std::recursive_mutex& engine_mutex() {
+  static std::recursive_mutex mu;
+  return mu;
+}
+
+uint64_t next_uid() {
+  static std::atomic<uint64_t> n{1};
+  return n.fetch_add(1);
 }
 
 int require_engine() {
@@ -153,6 +164,7 @@ int goctr_device_count(int* n) {
 }
 
 int goctr_init(int device_ordinal) {
+  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
   Engine& e = engine();
   int n = 0;
   goctr_device_count(&n);
@@ -178,14 +190,14 @@ int goctr_init(int device_ordinal) {
 }
 
 int goctr_sync(void) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
   GOCTR_HIP(hipDeviceSynchronize());
   return 0;
 }
 
 int goctr_device_info(char* name, size_t cap, int* cus, int64_t* hbm) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   hipDeviceProp_t prop;
   GOCTR_HIP(hipGetDeviceProperties(&prop, engine().device));
   if (name && cap) snprintf(name, cap, "%s (%s)", prop.name, prop.gcnArchName);
@@ -195,19 +207,19 @@ int goctr_device_info(char* name, size_t cap, int* cus, int64_t* hbm) {
 }
 
 int goctr_prof_enable(int on) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   prof_flush();
   engine().prof = on != 0;
   return 0;
 }
 int goctr_prof_reset(void) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   prof_flush();
   for (int i = 0; i < GOCTR_K_COUNT; ++i) { engine().prof_ms[i] = 0; engine().prof_n[i] = 0; }
   return 0;
 }
 int goctr_prof_get(int id, double* ms, int64_t* n) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(id >= 0 && id < GOCTR_K_COUNT, "goctr_prof_get: bad kernel id %d", id);
   prof_flush();
   if (ms) *ms = engine().prof_ms[id];

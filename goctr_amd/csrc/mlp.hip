@@ -961,7 +961,7 @@ void goctr_mlp_cfg_default(goctr_mlp_cfg* c) {
 }
 
 int goctr_mlp_create(const goctr_mlp_cfg* cfg, goctr_mlp** out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(cfg && out && cfg->n_layers >= 2 && cfg->n_layers <= 8, "goctr_mlp_create: n_layers must be 2..8");
   // validateHyperparameters panics on these (basemlp64.go:625-673)
   GOCTR_CHECK(cfg->activation >= 0 && cfg->activation <= 3, "unknown activation %d", cfg->activation);
@@ -995,7 +995,7 @@ void goctr_mlp_destroy(goctr_mlp* p) { delete p; }
 size_t goctr_mlp_nparams(const goctr_mlp* p) { return p ? (size_t)p->nparams : 0; }
 
 int goctr_mlp_set_params(goctr_mlp* p, const double* theta, size_t n) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(p && theta && n == (size_t)p->nparams, "goctr_mlp_set_params: expected %lld values", p ? p->nparams : 0);
   std::lock_guard<std::mutex> lk(p->mu);
   std::vector<double> w((size_t)p->nflat, 0.0);
@@ -1042,14 +1042,14 @@ static int unpack(goctr_mlp* p, const DevBuf<double>& src, double* theta) {
 }
 
 int goctr_mlp_get_params(goctr_mlp* p, double* theta, size_t n) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(p && theta && n == (size_t)p->nparams, "goctr_mlp_get_params: expected %lld values", p ? p->nparams : 0);
   std::lock_guard<std::mutex> lk(p->mu);
   return unpack(p, p->W, theta);
 }
 
 int goctr_mlp_loss_grad(goctr_mlp* p, const double* X, const double* Y, int n, double* loss, double* grads) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(p && X && Y && n > 0, "goctr_mlp_loss_grad: bad arguments");
   std::lock_guard<std::mutex> lk(p->mu);
   if (ensure_ws(p, n)) return -1;
@@ -1071,7 +1071,7 @@ int goctr_mlp_loss_grad(goctr_mlp* p, const double* X, const double* Y, int n, d
 }
 
 int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(p && X && Y && rows > 0, "goctr_mlp_upload: bad arguments");
   std::lock_guard<std::mutex> lk(p->mu);
   const int F = p->units[0], no = p->units[p->nl];
@@ -1083,7 +1083,7 @@ int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows)
 }
 
 int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(p && p->rows > 0 && n_steps >= 0, "goctr_mlp_train_steps: upload rows first");
   std::lock_guard<std::mutex> lk(p->mu);
   const long long nb = p->rows / p->cfg.batch;
@@ -1121,7 +1121,7 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
 
 int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, const int32_t* perm, double* loss_curve,
                   int* iters_run) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(p && X && Y && rows > 0, "goctr_mlp_fit: bad arguments");
   GOCTR_CHECK(rows % p->cfg.batch == 0, "goctr_mlp_fit: rows (%lld) must be a multiple of batch (%d) -- the reference "
               "leaves stale rows in a short last batch (basemlp64.go:800-802)", (long long)rows, p->cfg.batch);
@@ -1156,7 +1156,7 @@ int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, co
 }
 
 int goctr_mlp_predict(goctr_mlp* p, const float* X, int64_t rows, float* y_out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(p && X && y_out && rows >= 0, "goctr_mlp_predict: bad arguments");
   if (rows == 0) return 0;
   std::lock_guard<std::mutex> lk(p->mu);

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const double* __restrict
 extern "C" {
 
 int goctr_searcher_create(const double* items, int64_t V, int D, goctr_searcher** out) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(items && out && V > 0 && D > 0, "goctr_searcher_create: bad arguments");
   GOCTR_CHECK(D <= 1024, "goctr_searcher_create: dim %d > 1024", D);
   GOCTR_CHECK(cdiv(V, KNN_TILE) <= 8192, "goctr_searcher_create: more than %d items", 8192 * KNN_TILE);
@@ -317,7 +317,7 @@ void goctr_searcher_destroy(goctr_searcher* s) { delete s; }
 
 int goctr_searcher_search(goctr_searcher* s, const double* queries, int Q, int k, const int64_t* ignore, int64_t* out_idx,
                           double* out_sim, int* out_count) {
-  if (require_engine()) return -1;
+  GOCTR_ENTER();
   GOCTR_CHECK(s && queries && out_idx && out_sim && out_count, "goctr_searcher_search: null argument");
   GOCTR_CHECK(Q > 0 && k > 0 && k <= KNN_MAX_K, "goctr_searcher_search: Q %d, k %d (k <= %d)", Q, k, KNN_MAX_K);
   std::lock_guard<std::mutex> lk(s->mu);

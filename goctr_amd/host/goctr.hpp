@@ -134,6 +134,61 @@ inline std::vector<float> Predict(CtrNet& m, int numExamples, int batchSize, con
 }
 }  // namespace model
 
+namespace recommend {
+// rcmd.go:65-71, 118-121
+struct Sample { int UserId = 0, ItemId = 0; float Label = 0; int64_t Timestamp = 0; };
+struct ItemScore { int ItemId = 0; float Score = 0; };
+
+// What GetSampleVector reads per key (rcmd.go:462-536), resident in HBM: user / item feature tables (rows = dense user /
+// item index), the behaviour cache CSR (feature/ubcache/cache.go) and the item-embedding table.  Serving side of the
+// drop-in: BatchPredict / Rank (rcmd.go:277-337, 248-275) hand the device KEYS, not 281-wide rows.
+class RecSys {
+ public:
+  RecSys(const std::vector<int64_t>& ub_off, const std::vector<int32_t>& ub_items, const std::vector<int64_t>& ub_ts,
+         const std::vector<float>& user_table, int U, const std::vector<float>& item_table, int C,
+         const std::vector<float>& item_emb, int D) {
+    check(goctr_init(0));
+    const int64_t n_users = (int64_t)ub_off.size() - 1, n_items = C ? (int64_t)item_table.size() / C : 0;
+    check(goctr_ubcache_create(n_users, ub_off.data(), ub_items.data(), ub_ts.data(), &ub_));
+    check(goctr_emb_create((int64_t)item_emb.size() / D, D, item_emb.data(), &emb_));
+    check(goctr_recsys_create(ub_, emb_, user_table.data(), n_users, U, item_table.data(), n_items, C, &h_));
+  }
+  ~RecSys() { goctr_recsys_destroy(h_); goctr_emb_destroy(emb_); goctr_ubcache_destroy(ub_); }
+  RecSys(const RecSys&) = delete;
+  RecSys& operator=(const RecSys&) = delete;
+  goctr_recsys* handle() const { return h_; }
+  goctr_emb* embedding() const { return emb_; }
+
+ private:
+  goctr_ubcache* ub_ = nullptr; goctr_emb* emb_ = nullptr; goctr_recsys* h_ = nullptr;
+};
+
+// rcmd.go:277-337.  Throws when the first key fails (rcmd.go:293-296) and -- the reference's named-result quirk -- when
+// the last one does (rcmd.go:291,325-336); keys failing in between score as the all-zero row (rcmd.go:299-302).
+inline std::vector<float> BatchPredict(model::CtrNet& net, RecSys& rs, const std::vector<Sample>& keys, int predBatch = 4096) {
+  const int64_t n = (int64_t)keys.size();
+  std::vector<int32_t> u((size_t)n), it((size_t)n);
+  std::vector<int64_t> ts((size_t)n);
+  for (int64_t i = 0; i < n; ++i) { u[i] = keys[i].UserId; it[i] = keys[i].ItemId; ts[i] = keys[i].Timestamp; }
+  std::vector<float> y((size_t)n);
+  std::vector<uint8_t> failed((size_t)n);
+  check(goctr_batch_predict(net.Vm(), rs.handle(), u.data(), it.data(), ts.data(), n, predBatch, y.data(), failed.data(), nullptr));
+  if (n && failed[(size_t)n - 1]) throw std::runtime_error("get sample vector error: last key has no features");
+  return y;
+}
+
+// rcmd.go:248-275
+inline std::vector<ItemScore> Rank(model::CtrNet& net, RecSys& rs, int userId, const std::vector<int>& itemIds, int64_t now,
+                                   int predBatch = 4096) {
+  std::vector<Sample> keys(itemIds.size());
+  for (size_t i = 0; i < itemIds.size(); ++i) keys[i] = Sample{userId, itemIds[i], 0.f, now};
+  auto y = BatchPredict(net, rs, keys, predBatch);
+  std::vector<ItemScore> out(itemIds.size());
+  for (size_t i = 0; i < itemIds.size(); ++i) out[i] = ItemScore{itemIds[i], y[i]};
+  return out;
+}
+}  // namespace recommend
+
 namespace din {
 struct DinNet : model::CtrNet {
   DinNet(int U, int T, int D, int iD, int C) : CtrNet(GOCTR_DIN, U, T, D, iD, C) {}

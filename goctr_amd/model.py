@@ -188,16 +188,18 @@ def NewYoutubeDnnFromJson(data: bytes) -> YoutubeDnn:
 
 
 def Train(uProfileDim, uBehaviorSize, uBehaviorDim, iFeatureDim, cFeatureDim, numExamples, batchSize, epochs,
-          earlyStop, si: SampleInfo, inputs: np.ndarray, targets: np.ndarray, m: _CtrNet, dropout_seed=None):
+          earlyStop, si: SampleInfo, inputs: np.ndarray, targets: np.ndarray, m: _CtrNet, dropout_seed=42):
     """model.go:27-213.  ``inputs`` [numExamples, XCols] float32, ``targets`` [numExamples(,1)].
     Returns the per-epoch costs (the Go version only logs them: model.go:205).
-    Dropout (m.d0 / m.d1) runs as a counter-hash mask on the device when ``dropout_seed`` is given;
-    the reference draws its masks from Go's math/rand, which cannot be reproduced without Go."""
+    Like the reference, training applies Dropout(m.d0) / Dropout(m.d1) whenever the model carries non-zero rates
+    (NewDinNet: 0.005, din.go:204-205,307-312; NewYoutubeDnn: 0.003): a counter-hash mask stream on the device, seeded
+    by ``dropout_seed``.  The reference draws its masks from Go's math/rand, which cannot be reproduced without Go, so
+    the mask BITS are unpinned; the distribution is the same.  ``dropout_seed=None`` is the explicit opt-out."""
     X = capi.f32(inputs)
     Y = capi.f32(targets).ravel()
     if X.shape[0] != numExamples or Y.shape[0] != numExamples:
         raise ValueError("numExamples does not match inputs/targets")
-    cfg = capi.default_train_cfg(batch=batchSize, epochs=epochs, early_stop=earlyStop)
+    cfg = capi.default_train_cfg(batch=batchSize, epochs=epochs, early_stop=earlyStop, dropout_mode=0)
     if dropout_seed is not None and (m.d0 > 0 or m.d1 > 0):
         cfg.dropout_mode, cfg.p0, cfg.p1, cfg.seed = 2, m.d0, m.d1, dropout_seed
     costs = np.zeros(max(epochs, 1), np.float32)
@@ -236,7 +238,7 @@ def loss_grad(m: _CtrNet, si: SampleInfo, X, Y, B=None, cfg=None, step=0, m0=Non
     Y = capi.f32(Y).ravel()
     valid = X.shape[0]
     B = B or valid
-    cfg = cfg or capi.default_train_cfg(batch=B)
+    cfg = cfg or capi.default_train_cfg(batch=B, dropout_mode=0)
     g = {n: np.zeros(m._shape(n), np.float32) for n in ("mlp0", "mlp1", "mlp2", "att0")}
     y = np.zeros(B, np.float32)
     cost = C.c_float(0)

@@ -1,10 +1,27 @@
-"""Host mirror of the parts of go-ctr's ``recommend`` package that sit either side of the hot path
-(reference: recommend/rcmd.go).  Names and field meaning follow the Go types."""
+"""Host mirror of go-ctr's ``recommend`` package around the hot path (reference: recommend/rcmd.go).
+
+Names, argument order and error behaviour follow the Go code:
+
+    Sample / ItemScore / SampleInfo / TrainSample      rcmd.go:56-71,118-137
+    Fitter / PredictAbstract                           rcmd.go:87-97
+    GetSample                                          rcmd.go:339-460   (keys -> training rows; failing keys dropped)
+    Train                                              rcmd.go:187-246
+    BatchPredict / Rank                                rcmd.go:277-337, 248-275
+
+The reference assembles every row on the host (string-keyed map lookups per embedding).  Here a
+``DeviceRecSys`` keeps what GetSampleVector reads -- user / item feature tables, the behaviour cache, the item-embedding
+table -- resident in HBM and hands the device (user, item, timestamp) KEYS: goctr_dataset_create_keys for training,
+goctr_batch_predict / goctr_rank for serving.  All arithmetic is behind include/goctr.h.
+"""
 from __future__ import annotations
 
+import ctypes as C
+import time
 from dataclasses import dataclass, field
 
 import numpy as np
+
+from . import capi
 
 # recommend/rcmd.go:19-28
 SampleAssembler = 16
@@ -42,6 +59,22 @@ class TrainSample:
     Info: SampleInfo = field(default_factory=SampleInfo)
 
 
+@dataclass
+class Sample:
+    """recommend/rcmd.go:65-71"""
+    UserId: int
+    ItemId: int
+    Label: float = 0.0
+    Timestamp: int = 0
+
+
+@dataclass
+class ItemScore:
+    """recommend/rcmd.go:118-121"""
+    ItemId: int
+    Score: float
+
+
 class PredictAbstract:
     """recommend/rcmd.go:87-89"""
 
@@ -54,3 +87,188 @@ class Fitter:
 
     def Fit(self, sample: TrainSample) -> PredictAbstract:
         raise NotImplementedError
+
+
+class SampleVectorError(RuntimeError):
+    """GetSampleVector's error (rcmd.go:478-491): a key whose user or item has no features"""
+
+
+class DeviceRecSys:
+    """What the reference's RecSys plug-in + its caches provide per key (rcmd.go:462-536), resident in HBM.
+
+    user_features : {userId: feature vector [U]}   (GetUserFeature, UserFeatureCache)
+    item_features : {itemId: feature vector [C]}   (GetItemFeature, ItemFeatureCache)
+    item_embedding: {itemId: vector [D]}           (itemEmbeddingMap, rcmd.go:31-32; an item without one scores with zeros,
+                                                    rcmd.go:504-507)
+    ubcache       : goctr_amd.ubcache.UserBehaviorCache or None (the recSys does not implement UserBehavior, rcmd.go:512)
+
+    Ids are arbitrary ints like in the reference; the dense row indices the device tables use are internal.
+    """
+
+    def __init__(self, user_features: dict, item_features: dict, item_embedding: dict, ubcache=None, T=UserBehaviorLen):
+        from . import model as gm
+        self.T = T
+        self.ubcache = ubcache
+        # dense user order = the behaviour cache's CSR order, users known only to the feature table appended
+        if ubcache is not None:
+            base = ubcache.user_index()
+            self._uidx = dict(base)
+        else:
+            self._uidx = {}
+        n_cache = len(self._uidx)
+        for u in sorted(user_features):
+            if int(u) not in self._uidx:
+                if ubcache is not None:
+                    # a user with features but no cached behaviour: the reference's GetUserBehavior would fail the key
+                    # (rcmd.go:528-531); keep the behaviour cache and the user table the same set
+                    raise KeyError(f"user {u} has features but no behaviour sequence in the cache")
+                self._uidx[int(u)] = len(self._uidx)
+        self.U = len(next(iter(user_features.values())))
+        self.C = len(next(iter(item_features.values())))
+        self.D = len(next(iter(item_embedding.values())))
+        ut = np.zeros((len(self._uidx), self.U), np.float32)
+        self._has_user = np.zeros(len(self._uidx), bool)
+        for u, v in user_features.items():
+            ut[self._uidx[int(u)]] = v
+            self._has_user[self._uidx[int(u)]] = True
+        del n_cache
+        # dense item order: every item that has features first (rows of the feature table), then embedding-only items
+        self._iidx = {int(i): k for k, i in enumerate(sorted(item_features))}
+        n_feat = len(self._iidx)
+        for i in sorted(item_embedding):
+            if int(i) not in self._iidx:
+                self._iidx[int(i)] = len(self._iidx)
+        it = np.zeros((n_feat, self.C), np.float32)
+        for i, v in item_features.items():
+            it[self._iidx[int(i)]] = v
+        emb = np.zeros((len(self._iidx), self.D), np.float32)
+        for i, v in item_embedding.items():
+            emb[self._iidx[int(i)]] = v
+        self.user_table, self.item_table = ut, it
+        self.emb = gm.EmbeddingTable(emb)
+        if ubcache is not None:
+            self._remap_cache_items()
+        self._h = C.c_void_p()
+        capi.check(capi.load().goctr_recsys_create(
+            self._ub_h, self.emb._h, capi.ptr(ut, C.c_float), C.c_int64(ut.shape[0]), C.c_int(self.U),
+            capi.ptr(it, C.c_float), C.c_int64(it.shape[0]), C.c_int(self.C), C.byref(self._h)))
+
+    def _remap_cache_items(self):
+        """the device CSR holds dense item indices (an item unknown to every table -> -1 = zero row)"""
+        from .ubcache import TimeSeq, UserBehaviorCache
+        dense = UserBehaviorCache()
+        for u, seq in self.ubcache.ub.items():
+            dense.Set(u, TimeSeq(list(seq.Ts), [self._iidx.get(int(i), -1) for i in seq.Items]))
+        self._dense_cache = dense
+        assert dense.user_index() == {u: k for u, k in self._uidx.items() if k < len(dense.ub)}
+
+    @property
+    def _ub_h(self):
+        return self._dense_cache.device() if self.ubcache is not None else None
+
+    def user_index(self, userId) -> int:
+        """dense row of a user; -1 = GetUserFeature would fail"""
+        k = self._uidx.get(int(userId), -1)
+        return k if k >= 0 and self._has_user[k] else -1
+
+    def item_index(self, itemId) -> int:
+        """dense row of an item; a row beyond the feature table = GetItemFeature would fail"""
+        k = self._iidx.get(int(itemId), -1)
+        return k if 0 <= k < self.item_table.shape[0] else -1
+
+    def keys(self, samples):
+        users = np.array([self.user_index(s.UserId) for s in samples], np.int32)
+        items = np.array([self.item_index(s.ItemId) for s in samples], np.int32)
+        ts = np.array([s.Timestamp for s in samples], np.int64)
+        return users, items, ts
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.load().goctr_recsys_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def GetSample(recSys: DeviceRecSys, samples):
+    """rcmd.go:339-460 with the row assembly on the device: returns (model.Dataset of id-mode rows, SampleInfo, kept).
+    Keys whose GetSampleVector would fail are dropped like rcmd.go:379-382; ``kept`` lists the surviving positions."""
+    from . import model as gm
+    users, items, ts = recSys.keys(samples)
+    kept = np.flatnonzero((users >= 0) & (items >= 0))
+    if kept.size == 0:
+        raise SampleVectorError("no sample has both user and item features")
+    y = np.array([samples[i].Label for i in kept], np.float32)
+    ds = gm.Dataset.keys(recSys._dense_cache if recSys.ubcache is not None else _EmptyCache(recSys), recSys.user_table,
+                         recSys.item_table, users[kept], items[kept], ts[kept], y, recSys.T)
+    return ds, SampleInfo.from_dims(recSys.U, recSys.T, recSys.D, recSys.C), kept
+
+
+class _EmptyCache:
+    """stand-in behaviour cache with empty sequences (the recSys has no UserBehavior interface)"""
+
+    def __init__(self, recSys):
+        from .ubcache import TimeSeq, UserBehaviorCache
+        self._c = UserBehaviorCache()
+        for u in recSys._uidx:
+            self._c.Set(u, TimeSeq([], []))
+
+    def device(self):
+        return self._c.device()
+
+
+class Predictor:
+    """what recommend.Train returns (rcmd.go:233-241): the recSys + the trained PredictAbstract"""
+
+    def __init__(self, recSys: DeviceRecSys, net, predBatchSize=4096):
+        self.recSys, self.net, self.PredBatchSize = recSys, net, predBatchSize
+
+
+def Train(recSys: DeviceRecSys, samples, net, batchSize=200, epochs=200, earlyStop=20, dropout_seed=42, predBatchSize=4096):
+    """rcmd.go:187-246 for a DIN / YouTube net (``net`` = model.NewDinNet(...) / NewYoutubeDnn(...)): GetSample ->
+    model.Train -> Predictor.  Returns (Predictor, per-epoch costs)."""
+    from . import model as gm
+    ds, _si, _kept = GetSample(recSys, samples)
+    cfg = capi.default_train_cfg(batch=batchSize, epochs=epochs, early_stop=earlyStop, dropout_mode=0)
+    if dropout_seed is not None and (net.d0 > 0 or net.d1 > 0):
+        cfg.dropout_mode, cfg.p0, cfg.p1, cfg.seed = 2, net.d0, net.d1, dropout_seed
+    costs = gm.train_dataset(net, ds, cfg, emb=recSys.emb)
+    return Predictor(recSys, net, predBatchSize), costs
+
+
+def BatchPredict(model: Predictor, sampleKeys):
+    """rcmd.go:277-337: scores [n, 1] float32 for n Sample keys.
+
+    Error behaviour of the reference, kept: a failing FIRST key raises (rcmd.go:293-296); a failing later key is scored
+    as the all-zero row (rcmd.go:297-302); and because the named result ``err`` is never cleared (rcmd.go:291), a failing
+    LAST key makes BatchPredict return y *and* a non-nil error -- here: the scores are attached to the exception."""
+    rs = model.recSys
+    n = len(sampleKeys)
+    users, items, ts = rs.keys(sampleKeys)
+    y = np.zeros(n, np.float32)
+    failed = np.zeros(n, np.uint8)
+    nf = C.c_int64(0)
+    try:
+        capi.check(capi.load().goctr_batch_predict(model.net._h, rs._h, capi.ptr(users, C.c_int32), capi.ptr(items, C.c_int32),
+                                                   capi.ptr(ts, C.c_int64), C.c_int64(n), C.c_int(model.PredBatchSize),
+                                                   capi.ptr(y, C.c_float), capi.ptr(failed, C.c_uint8), C.byref(nf)))
+    except capi.GoctrError as e:
+        raise SampleVectorError(str(e)) from None
+    y = y.reshape(n, 1)
+    if n and failed[-1]:
+        err = SampleVectorError(f"get sample vector error: key {n - 1} (user {sampleKeys[-1].UserId}, item "
+                                f"{sampleKeys[-1].ItemId}) has no features")
+        err.y = y
+        raise err
+    return y
+
+
+def Rank(model: Predictor, userId: int, itemIds, now=None):
+    """rcmd.go:248-275: [ItemScore] in the order of itemIds; every key carries the same time.Now().Unix()"""
+    ts = int(time.time()) if now is None else int(now)
+    y = BatchPredict(model, [Sample(userId, i, 0.0, ts) for i in itemIds])      # (an error drops the scores, :258-260)
+    return [ItemScore(int(i), float(y[k, 0])) for k, i in enumerate(itemIds)]

@@ -9,7 +9,9 @@
  *   - no callback into the host language, no host pointer retained after a call returns;
  *   - host buffers are row-major, float32 for DIN / YouTube (gorgonia tensor.Float32,
  *     model/model.go:14), float64 for the sklearn-port MLP and item2vec (as in the reference);
- *   - one handle is used by one thread at a time (an internal mutex serialises per handle);
+ *   - any host thread may call any entry point on any handle: the engine owns ONE submission stream, so calls are
+ *     serialised engine-wide by an internal lock (concurrent PredictAbstract.Predict from gin handler goroutines,
+ *     recommend/api.go:106-131, is safe; the calls queue behind each other);
  *   - there is NO CPU fallback: without a HIP device every compute entry point fails loudly.
  */
 #ifndef GOCTR_H
@@ -99,7 +101,9 @@ typedef struct {
   double beta1, beta2, eps;        /* gorgonia Adam defaults .9 .999 1e-8 */
   int adam_div_by_batch;           /* WithBatchSize(B): 1 (model.go:88) */
   int adam_l2_before_batch_div;    /* gorgonia order, 1 */
-  int dropout_mode;                /* 0 off, 1 explicit masks (single-step entry only), 2 counter-hash */
+  int dropout_mode;                /* 0 off, 1 explicit masks (single-step entry only), 2 counter-hash (default: the
+                                      reference ALWAYS trains with Dropout, din.go:307-312 / dnn.go:173-175; its masks
+                                      come from Go's math/rand, so mask bits are unpinned, the distribution is not) */
   float p0, p1;                    /* 0.005/0.005 DIN (din.go:204-205), 0.003/0.003 YouTube (dnn.go:136-137) */
   uint32_t seed;
 } goctr_train_cfg;
@@ -167,6 +171,28 @@ int goctr_dataset_create_keys(goctr_ubcache* c, const float* user_table /*[n_use
                               const int32_t* items, const int64_t* ts, const float* Y /* may be NULL */, int64_t rows, int T,
                               goctr_dataset** out);
 int goctr_dataset_get_ids(goctr_dataset* d, int32_t* ub_ids, float* user_feat, float* ctx_feat);
+
+/* ---- recommend.BatchPredict / Rank (recommend/rcmd.go:277-337, 248-275) over resident feature tables.
+ * A goctr_recsys bundles what GetSampleVector (rcmd.go:462-536) reads per key: the user / item feature tables (the
+ * contents of UserFeatureCache / ItemFeatureCache, rcmd.go:474-491; rows indexed by DENSE user / item index), the behaviour
+ * cache (may be NULL: the recSys does not implement UserBehavior, rcmd.go:512 => zero behaviours) and the item-embedding
+ * table (itemEmbeddingMap; item index == embedding row, a row >= V is "embedding not found" => zeros, rcmd.go:504-507).
+ * The cache and the embedding table are borrowed, not owned. */
+typedef struct goctr_recsys goctr_recsys;
+int goctr_recsys_create(goctr_ubcache* c, goctr_emb* emb, const float* user_table /*[n_users,U]*/, int64_t n_users, int U,
+                        const float* item_table /*[n_items,C]*/, int64_t n_items, int C, goctr_recsys** out);
+void goctr_recsys_destroy(goctr_recsys* r);
+/* BatchPredict (rcmd.go:277-337): n sample keys (user index, item index, timestamp; ts may be NULL = 0) -> scores [n].
+ * A key whose user or item has no feature row (index outside the table = GetUserFeature / GetItemFeature error) is
+ * scored as the ALL-ZERO row (rcmd.go:299-302) and flagged in failed[i] (may be NULL); *n_failed (may be NULL) counts
+ * them.  If the FIRST key fails the call fails like rcmd.go:293-296.  Reference quirk kept for the host mirror: when
+ * the LAST key fails, BatchPredict returns y together with a non-nil err (the named result is never cleared,
+ * rcmd.go:291,325-336) and Rank then drops the scores (rcmd.go:258-260) -- check failed[n-1]. */
+int goctr_batch_predict(goctr_model* m, goctr_recsys* r, const int32_t* users, const int32_t* items, const int64_t* ts,
+                        int64_t n, int batch, float* scores, uint8_t* failed, int64_t* n_failed);
+/* Rank (rcmd.go:248-275): one user, n candidate items, one timestamp (time.Now().Unix() there) */
+int goctr_rank(goctr_model* m, goctr_recsys* r, int32_t user, const int32_t* items, int64_t n, int64_t ts, int batch,
+               float* scores, uint8_t* failed, int64_t* n_failed);
 
 /* model.Train's epoch loop over a resident dataset (emb == NULL for dense datasets). */
 int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,

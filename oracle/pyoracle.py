@@ -340,6 +340,74 @@ class CtrModel:
                                        C.byref(d) if d is not None else None, C.byref(gw), _p(y, C.c_float))
         return float(cost), g, y
 
+    def loss_grad_f64(self, X, Y, B=None):
+        """FLOAT64 evaluation (numpy) of the same graph as orc_ctr.c's fwd_row / orc_ctr_loss_grad (din.go:219-323,
+        dnn.go:162-184, activation.go:23-83, cost.go:9-17; no dropout) on the float32 inputs and weights: the truth
+        that bounds the float32 summation-order error of both the float32 oracle and the device.  The BCE constant is
+        float32(1 + 1e-8) == 1 like in the reference (quirk Q2).  Returns (cost, grads dict, y)."""
+        c = self.cfg
+        U, T, D, Cc = c.U, c.T, c.D, c.C
+        X = np.asarray(X, np.float64)
+        valid = X.shape[0]
+        B = B or valid
+        if B > valid:
+            X = np.vstack([X, np.zeros((B - valid, X.shape[1]))])
+        yv = np.zeros(B)
+        yv[:valid] = np.asarray(Y, np.float64).ravel()
+        W0, W1, W2, att0 = (np.asarray(a, np.float64) for a in (self.W0, self.W1, self.W2, self.att0))
+
+        def sigm(x):                                  # gorgonia's float32 sigmoid clamps, evaluated in float64
+            out = 1.0 / (1.0 + np.exp(-np.clip(x, -88.0, 15.0)))
+            return np.where(x < -88.0, 0.0, np.where(x > 15.0, 1.0, out))
+
+        u, ub = X[:, :U], X[:, U:U + T * D].reshape(B, T, D)
+        v, cx = X[:, U + T * D:U + T * D + D], X[:, U + T * D + D:U + T * D + D + Cc]
+        if c.kind == DIN:
+            if c.att == ATT_COSINE:
+                sxx, sxy = (ub * ub).sum(-1), (ub * v[:, None, :]).sum(-1)
+                yn = np.sqrt((v * v).sum(-1))
+                wv = (sxy / (np.sqrt(sxx) * yn[:, None] + 1e-8) + 1.0) / 2.0
+            else:
+                wv = 1.0 - np.sqrt(((ub - v[:, None, :]) ** 2).sum(-1))
+            g = sigm(wv * att0[None, :])
+        else:
+            wv = np.zeros((B, T))
+            g = np.ones((B, T))
+        p = (g[..., None] * ub).sum(1) / T
+        h0 = np.concatenate([u, p, v, cx], axis=1)
+        A0 = sigm(h0 @ W0)
+        A1 = sigm(A0 @ W1)
+        y = sigm(A1 @ W2).ravel()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cost = -np.mean(yv * np.log(y) + (1.0 - yv) * np.log(1.0 - y))
+            dy = -((yv / y) - ((1.0 - yv) / (1.0 - y))) / B
+        d2 = dy * (y * (1.0 - y))
+        dz1 = (d2[:, None] * W2.T) * (A1 * (1.0 - A1))
+        dz0 = (dz1 @ W1.T) * (A0 * (1.0 - A0))
+        grads = dict(W0=h0.T @ dz0, W1=A0.T @ dz1, W2=(A1.T @ d2).reshape(-1, 1), att0=np.zeros(T))
+        if c.kind == DIN:
+            dpT = dz0 @ W0[U:U + D].T / T
+            dg = (dpT[:, None, :] * ub).sum(-1)
+            grads["att0"] = (dg * (g * (1.0 - g)) * wv).sum(0)
+        return float(cost), grads, y
+
+    def adam_step(self, grads, state=None, adam=None, batch=1):
+        """ONE gorgonia AdamSolver.Step (orc_ctr_adam_step) on this model's weights with the given float32 gradients
+        (dict W0/W1/W2/att0; consumed: the solver zeroes them).  state: dict of moments + 'iter' (created when None)."""
+        ac = adam or default_adam()
+        if state is None:
+            state = dict(iter=0)
+            for k, w in (("0", self.W0), ("1", self.W1), ("2", self.W2), ("a", self.att0)):
+                state["m" + k] = np.zeros_like(w)
+                state["v" + k] = np.zeros_like(w)
+        g = {k: np.ascontiguousarray(grads[k], np.float32).reshape(getattr(self, k).shape).copy() for k in ("W0", "W1", "W2", "att0")}
+        gw = CtrWeights(*[_p(g[k], C.c_float) for k in ("W0", "W1", "W2", "att0")])
+        st = AdamState(*[_p(state[n], C.c_float) for n in ("m0", "v0", "m1", "v1", "m2", "v2", "ma", "va")], state["iter"])
+        w = self._w()
+        lib().orc_ctr_adam_step(C.byref(self.cfg), C.byref(w), C.byref(gw), C.byref(st), C.byref(ac), C.c_int(batch))
+        state["iter"] = st.iter
+        return state
+
     def train(self, X, Y, batch, epochs, early_stop=0, adam=None, drop_mode=0, p0=0.0, p1=0.0, seed=0):
         X = np.ascontiguousarray(X, np.float32)
         Y = np.ascontiguousarray(Y, np.float32).ravel()
@@ -577,6 +645,25 @@ def assemble_keys(off, seq_items, seq_ts, user_table, item_table, users, items, 
                             C.c_int(it.shape[1]), _p(users, C.c_int32), _p(items, C.c_int32), _p(ts, C.c_int64),
                             C.c_int64(rows), C.c_int(T), _p(ub, C.c_int32), _p(uf, C.c_float), _p(cf, C.c_float))
     return ub, uf, cf
+
+
+def batch_predict_rows(emb, off, seq_items, seq_ts, user_table, item_table, users, items, ts, T):
+    """recommend.BatchPredict's row assembly (rcmd.go:277-325) in id form: X [n, XCols] float32 and failed [n].
+    A key whose user / item has no feature row (GetUserFeature / GetItemFeature error, rcmd.go:474-491) becomes the
+    ALL-zero row (rcmd.go:299-302); a failing FIRST key raises (rcmd.go:293-296).  The caller scores X with
+    CtrModel.predict (recSys.Predict, rcmd.go:327).  The reference's `err` of the LAST key leaks into the return value
+    (named result, rcmd.go:291): callers check failed[-1]."""
+    users = np.ascontiguousarray(users, np.int32)
+    items = np.ascontiguousarray(items, np.int32)
+    ut = np.ascontiguousarray(user_table, np.float32)
+    it = np.ascontiguousarray(item_table, np.float32)
+    failed = (users < 0) | (users >= ut.shape[0]) | (items < 0) | (items >= it.shape[0])
+    if users.size and failed[0]:
+        raise ValueError("get sample vector error: first key has no features")
+    ub, uf, cf = assemble_keys(off, seq_items, seq_ts, ut, it, users, items, ts, T)
+    X = assemble_rows(emb, ub, items, uf, cf)
+    X[failed] = 0.0
+    return X, failed.astype(np.uint8)
 
 
 # ---------------------------------------------------------------- corpus / dictionary --

@@ -83,7 +83,7 @@ def test_dataset_from_keys_equals_dataset_from_ids(oracle):
     w = []
     for ds in (ds_k, ds_i):
         m = gm.DinNet(U, T, D, D, Cc).init_gaussian(np.random.default_rng(1))
-        cfg = capi.default_train_cfg(batch=512, epochs=1)
+        cfg = capi.default_train_cfg(batch=512, epochs=1, dropout_mode=0)
         gm.train_steps(m, ds, cfg, 4, emb=tab)
         capi.sync()
         w.append(np.concatenate([m.get_weights(n).ravel() for n in ("mlp0", "mlp1", "mlp2", "att0")]))

@@ -32,7 +32,7 @@ uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=
 y = (rng.random(rows) < 0.5).astype(np.float32)
 tab = gm.EmbeddingTable(emb); ds = gm.Dataset.ids(ub, it, uf, cf, y)
 m = gm.DinNet(U, T, D, D, Cc).init_gaussian(np.random.default_rng(1))
-cfg = capi.default_train_cfg(batch=1024, epochs=1)
+cfg = capi.default_train_cfg(batch=1024, epochs=1, dropout_mode=0)
 gm.train_steps(m, ds, cfg, 7, emb=tab)          # odd count: both graph parities are replayed
 capi.sync()
 out = np.concatenate([m.get_weights(n).ravel() for n in ("mlp0", "mlp1", "mlp2", "att0")])
@@ -163,7 +163,7 @@ y = (rng.random(rows) < 0.5).astype(np.float32)
 tab = gm.EmbeddingTable(emb); ds = gm.Dataset.ids(ub, it, uf, cf, y)
 m = gm.DinNet(U, T, D, D, Cc).init_gaussian(np.random.default_rng(1))
 m.set_embedding_training(0.5)
-cfg = capi.default_train_cfg(batch=512, epochs=1)
+cfg = capi.default_train_cfg(batch=512, epochs=1, dropout_mode=0)
 gm.train_steps(m, ds, cfg, 5, emb=tab)
 capi.sync()
 out = np.concatenate([m.get_weights(n).ravel() for n in ("mlp0", "mlp1", "mlp2", "att0")] + [tab.get_rows().ravel()])

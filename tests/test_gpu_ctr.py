@@ -1,8 +1,10 @@
 """GPU parity tests for the DIN / YouTube-DNN path: every call goes through the C-ABI
 (include/goctr.h via goctr_amd.capi) and is compared with the CPU oracle on the same seeded inputs.
 Tolerances: bit-exact for the gather (copies), 1e-5 absolute on logits / loss (BASELINE.json
-north_star), gradients 1e-6 + 2e-4*max|g| (float32 summation order differs: MFMA k-order vs the
-oracle's sequential loops)."""
+north_star).  Gradients are bounded against a FLOAT64 evaluation of the same graph: the device may be at
+most twice as far from that truth as the float32 oracle itself is (float32 summation order differs: MFMA
+k-order and slab sums vs the oracle's sequential loops; the weight-gradient GEMM runs on the 6-product bf16
+split).  The dropout cases, which the float64 evaluation does not cover, keep 1e-6 + 2e-4*max|g| vs the oracle."""
 import os
 
 import numpy as np
@@ -16,6 +18,12 @@ LOSS_TOL = 1e-5
 
 def grad_close(g, ref):
     return np.max(np.abs(g - ref)) <= 1e-6 + 2e-4 * np.max(np.abs(ref))
+
+
+def grad_bound(g_dev, g_orc, g64):
+    """|g_dev - truth|_max <= 2 |g_orc32 - truth|_max + one float32 ulp of the largest entry"""
+    g_dev, g_orc, g64 = (np.asarray(a, np.float64).ravel() for a in (g_dev, g_orc, g64))
+    return np.max(np.abs(g_dev - g64)) <= 2 * np.max(np.abs(g_orc - g64)) + 6e-8 * np.max(np.abs(g64))
 
 
 def make_data(rng, rows, U, T, D, Cc, pad_frac=0.3):
@@ -114,9 +122,12 @@ def test_loss_and_grads(oracle, kind, att, dims, B, valid):
     rcost, rg, ry = om.loss_grad(X, Y, B=B)           # padded rows count (quirk Q3)
     assert np.max(np.abs(y - ry)) <= LOGIT_TOL
     assert abs(cost - rcost) <= LOSS_TOL
-    assert grad_close(g["mlp0"], rg["W0"]) and grad_close(g["mlp1"], rg["W1"]) and grad_close(g["mlp2"], rg["W2"])
+    c64, g64, y64 = om.loss_grad_f64(X, Y, B=B)       # float64 truth of the same graph
+    assert abs(cost - c64) <= LOSS_TOL and np.max(np.abs(y - y64)) <= LOGIT_TOL
+    assert grad_bound(g["mlp0"], rg["W0"], g64["W0"]) and grad_bound(g["mlp1"], rg["W1"], g64["W1"])
+    assert grad_bound(g["mlp2"], rg["W2"], g64["W2"])
     if kind == 0:
-        assert grad_close(g["att0"].ravel(), rg["att0"])
+        assert grad_bound(g["att0"], rg["att0"], g64["att0"])
 
 
 def test_loss_and_grads_reference_init(oracle):
@@ -215,7 +226,7 @@ def test_id_mode_equals_dense_mode(oracle, kind):
     ds = gm.Dataset.ids(ub, it, uf, cf, Y)
     y = gm.predict_dataset(dm, ds, B, emb=tab)
     assert np.max(np.abs(y - om.predict(X, B))) <= LOGIT_TOL
-    cfg = capi.default_train_cfg(batch=B, epochs=2, early_stop=0)
+    cfg = capi.default_train_cfg(batch=B, epochs=2, early_stop=0, dropout_mode=0)
     costs = gm.train_dataset(dm, ds, cfg, emb=tab)
     ref = om.train(X, Y, batch=B, epochs=2)
     assert np.max(np.abs(costs - ref)) <= 5e-5
@@ -231,7 +242,7 @@ def test_graph_replay_equals_eager(oracle):
         os.environ["GOCTR_NO_GRAPH"] = no_graph
         om, dm, si = pair(oracle, 0, U, T, D, Cc, np.random.default_rng(11), scale=0.15)
         ds = gm.Dataset.dense(X, Y, si)
-        cfg = capi.default_train_cfg(batch=200, epochs=1)
+        cfg = capi.default_train_cfg(batch=200, epochs=1, dropout_mode=0)
         costs = gm.train_steps(dm, ds, cfg, 7, want_costs=True)
         res.append((costs, dm.get_weights("mlp0")))
     os.environ.pop("GOCTR_NO_GRAPH")
@@ -260,7 +271,7 @@ def test_full_size_properties_cfg3():
         m.set_weights("mlp0", (r.standard_normal((U + 2 * D + Cc, 200)) * 0.1).astype(np.float32))
         m.set_weights("mlp1", (r.standard_normal((200, 80)) * 0.1).astype(np.float32))
         m.set_weights("mlp2", (r.standard_normal((80, 1)) * 0.1).astype(np.float32))
-        cfg = capi.default_train_cfg(batch=B, epochs=1)
+        cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0)
         costs = gm.train_steps(m, ds, cfg, 40, emb=tab, want_costs=True)
         return costs, m.get_weights("mlp0"), gm.predict_dataset(m, ds, 4096, emb=tab)
 
@@ -323,7 +334,7 @@ def test_id_mode_shape_sweep(oracle, kind, att, U, T, D, Cc):
     ds = gm.Dataset.ids(ub, it, uf, cf, Y)
     y = gm.predict_dataset(dm, ds, B, emb=tab)
     assert np.max(np.abs(y - om.predict(X, B))) <= LOGIT_TOL
-    cfg = capi.default_train_cfg(batch=B, epochs=2, early_stop=0)
+    cfg = capi.default_train_cfg(batch=B, epochs=2, early_stop=0, dropout_mode=0)
     costs = gm.train_dataset(dm, ds, cfg, emb=tab)
     ref = om.train(X, Y, batch=B, epochs=2)
     assert np.max(np.abs(costs - ref)) <= 5e-5
@@ -374,3 +385,85 @@ def test_predict_bf16_split_kernel_opt_in(tmp_path):
     r = subprocess.run([sys.executable, "-c", X3_SCRIPT % dict(root=root)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
     assert "MAXERR" in r.stdout
+
+
+def test_graph_is_rebuilt_for_a_new_dataset_at_a_reused_address(oracle):
+    """the cached step graph bakes in the dataset's device pointers and row count: it must be keyed on the dataset's
+    generation, not on the host address of its handle (malloc readily returns a freed handle's address).  Train on
+    dataset A, destroy it, create B (different size) -- repeatedly, so that an address is reused -- and compare every
+    run with the eager path"""
+    from goctr_amd import capi, model as gm
+    U, T, D, Cc, B = 52, 10, 16, 53, 128
+    rng = np.random.default_rng(21)
+    sets = [make_data(rng, rows, U, T, D, Cc) for rows in (640, 384, 896, 384, 640, 256)]
+    res = []
+    for no_graph in ("0", "1"):
+        os.environ["GOCTR_NO_GRAPH"] = no_graph
+        om, dm, si = pair(oracle, 0, U, T, D, Cc, np.random.default_rng(22), scale=0.15)
+        cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0)
+        costs, handles = [], set()
+        for X, Y in sets:
+            ds = gm.Dataset.dense(X, Y, si)
+            handles.add(ds._h.value)
+            costs.append(gm.train_steps(dm, ds, cfg, 4, want_costs=True))
+            ds.close()                                      # goctr_dataset_destroy: the next create may reuse the address
+        res.append((np.concatenate(costs), dm.get_weights("mlp0"), len(handles)))
+    os.environ.pop("GOCTR_NO_GRAPH")
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    # and against the oracle: the same sequence of 24 steps
+    om, dm, si = pair(oracle, 0, U, T, D, Cc, np.random.default_rng(22), scale=0.15)
+    ref = []
+    st = None
+    for X, Y in sets:
+        for b in range(4):
+            nb = -(-X.shape[0] // B)
+            lo = (b % nb) * B
+            c, g, _ = om.loss_grad(X[lo:lo + B], Y[lo:lo + B], B=B)
+            st = om.adam_step(g, state=st, batch=B)
+            ref.append(c)
+    assert np.max(np.abs(res[0][0] - np.array(ref, np.float32))) <= 5e-5
+
+
+def test_concurrent_handles_from_several_threads(oracle):
+    """include/goctr.h: any host thread may call any handle (goroutines of a cgo host; PredictAbstract.Predict is called
+    concurrently from gin handlers, recommend/api.go:106-131).  Two threads predict on their own models while a third
+    trains a third model (captures and replays step graphs on the engine's stream): every result equals the
+    single-threaded one"""
+    import threading
+    from goctr_amd import capi, model as gm
+    U, T, D, Cc = 52, 10, 16, 53
+    rng = np.random.default_rng(23)
+    X, Y = make_data(rng, 2000, U, T, D, Cc)
+    pairs = [pair(oracle, k % 2, U, T, D, Cc, np.random.default_rng(30 + k), scale=0.15) for k in range(3)]
+    si = pairs[0][2]
+    want_pred = [gm.Predict(pairs[k][1], 2000, 256, si, X) for k in range(2)]
+    ds = gm.Dataset.dense(X, Y, si)
+    cfg = capi.default_train_cfg(batch=200, epochs=1, dropout_mode=0)
+    # single-threaded reference for the trainer: a twin of model 2
+    twin = pair(oracle, 0, U, T, D, Cc, np.random.default_rng(32), scale=0.15)[1]
+    want_costs = np.concatenate([gm.train_steps(twin, ds, cfg, 5, first_batch=5 * r, want_costs=True) for r in range(6)])
+    out, errs = {}, []
+
+    def predictor(k):
+        try:
+            out[k] = [gm.Predict(pairs[k][1], 2000, 256, si, X) for _ in range(12)]
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    def trainer():
+        try:
+            out["t"] = np.concatenate([gm.train_steps(pairs[2][1], ds, cfg, 5, first_batch=5 * r, want_costs=True) for r in range(6)])
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=predictor, args=(0,)), threading.Thread(target=predictor, args=(1,)),
+          threading.Thread(target=trainer)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(2):
+        assert all(np.array_equal(y, want_pred[k]) for y in out[k])
+    assert np.array_equal(out["t"], want_costs)
+    assert np.array_equal(pairs[2][1].get_weights("mlp0"), twin.get_weights("mlp0"))

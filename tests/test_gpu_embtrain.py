@@ -48,7 +48,7 @@ def test_one_step_matches_oracle(oracle, kind, att, D, T):
     loss, dE = om.emb_loss_grad(E.astype(np.float64), ub, items, uf, cf, y, B=B)
     tab = gm.EmbeddingTable(E)
     ds = gm.Dataset.ids(ub, items, uf, cf, y)
-    cfg = capi.default_train_cfg(batch=B, epochs=1)
+    cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0)
     m.set_embedding_training(lr)
     costs = gm.train_steps(m, ds, cfg, 1, emb=tab, want_costs=True)
     capi.sync()
@@ -82,7 +82,7 @@ for n in ("mlp0", "mlp1", "mlp2"):
     m.set_weights(n, (r.standard_normal(m._shape(n)) * 0.2).astype(np.float32))
 m.set_embedding_training(0.5)
 tab = gm.EmbeddingTable(E); ds = gm.Dataset.ids(ub, items, uf, cf, y)
-c = gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1), 5, emb=tab, want_costs=True)   # 3 batches, wraps around
+c = gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0), 5, emb=tab, want_costs=True)   # 3 batches, wraps around
 capi.sync()
 np.save(%(out)r, np.concatenate([tab.get_rows().ravel(), m.get_weights("mlp0").ravel(), c]))
 '''
@@ -118,7 +118,7 @@ def test_one_step_matches_oracle_large_vocabulary(oracle):
     tab = gm.EmbeddingTable(E)
     ds = gm.Dataset.ids(ub, items, uf, cf, y)
     m.set_embedding_training(lr)
-    gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1), 1, emb=tab)
+    gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0), 1, emb=tab)
     capi.sync()
     got = tab.get_rows()
     upd = np.abs(lr * dE).max()
@@ -128,7 +128,7 @@ def test_one_step_matches_oracle_large_vocabulary(oracle):
     touched[items[items >= 0]] = True
     assert np.array_equal(got[~touched], E[~touched])
     # a second step on the same batch works from clean marks (nothing stale from the in-place path)
-    gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1), 1, emb=tab)
+    gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0), 1, emb=tab)
     capi.sync()
     assert np.isfinite(tab.get_rows()).all() and np.array_equal(tab.get_rows()[~touched], E[~touched])
 
@@ -138,7 +138,7 @@ def test_reproducible_and_off_by_default(oracle):
     U, T, D, Cc, V, B = 52, 20, 16, 53, 200, 512
     om, m, E, ub, items, uf, cf, y = _setup(oracle, "din", 0, U, T, D, Cc, V, 3 * B, seed=1)
     ds = gm.Dataset.ids(ub, items, uf, cf, y)
-    cfg = capi.default_train_cfg(batch=B, epochs=1)
+    cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0)
     res = []
     for lr in (0.0, 0.1, 0.1):
         m2 = gm.DinNet(U, T, D, D, Cc)
@@ -170,7 +170,7 @@ def test_training_embeddings_lowers_the_loss(oracle):
     cf = rng.random((rows, Cc), dtype=np.float32)
     E = (rng.standard_normal((V, D)) * 0.05).astype(np.float32)
     ds = gm.Dataset.ids(ub, items, uf, cf, y)
-    cfg = capi.default_train_cfg(batch=B, epochs=1)
+    cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0)
     final = {}
     for lr in (0.0, 20.0):
         m = gm.YoutubeDnn(U, T, D, D, Cc)
@@ -197,4 +197,4 @@ def test_errors():
     from goctr_amd.recommend import SampleInfo
     ds = gm.Dataset.dense(X, np.zeros(32, np.float32), SampleInfo.from_dims(4, 3, 8, 4))
     with pytest.raises(capi.GoctrError):
-        gm.train_steps(m, ds, capi.default_train_cfg(batch=32, epochs=1), 1)        # dense rows carry no ids
+        gm.train_steps(m, ds, capi.default_train_cfg(batch=32, epochs=1, dropout_mode=0), 1)        # dense rows carry no ids

@@ -1,0 +1,179 @@
+"""Full-size parity: ONE step of every BASELINE configuration at the shape bench.py measures, against the CPU oracle.
+
+The reduced-size tests (test_gpu_ctr.py, test_gpu_mlp.py) cover every code path; these cover the sizes at which the
+launch geometry differs -- B = 8192 / 16384 rows means 256+ chain workgroups, 44 weight-gradient slabs and the
+one-workgroup-per-CU sizing -- and the 2.56 GB table of cfg4.  Bars (BASELINE.json north_star): gather bit-exact,
+logits / loss <= 1e-5 absolute.  Gradients are bounded against a FLOAT64 evaluation of the same graph
+(pyoracle.CtrModel.loss_grad_f64): the device may be at most twice as far from the truth as the float32 oracle is --
+the float32 oracle's own summation-order error is the yard-stick, not an ad-hoc tolerance.  That bound is what
+entitles the 6-product bf16 split of the weight-gradient GEMM (csrc/mfma_gemm.h) to call itself float32.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-5
+LOSS_TOL = 1e-5
+
+
+def zipf_ids(rng, V, shape):
+    return ((rng.zipf(1.05, size=shape) - 1) % V).astype(np.int32)
+
+
+def synth(rng, rows, U, T, D, Cc, V, emb_scale=0.25):
+    """bench.py's synthetic MovieLens-shaped keys: Zipf(1.05) ids, 20 % padded slots, U(0,1) side features"""
+    ub = zipf_ids(rng, V, (rows, T))
+    ub[rng.random((rows, T)) < 0.2] = -1
+    it = zipf_ids(rng, V, rows)
+    uf = rng.random((rows, U), dtype=np.float32)
+    cf = rng.random((rows, Cc), dtype=np.float32)
+    y = (rng.random(rows) < 0.5).astype(np.float32)
+    emb = rng.random((V, D), dtype=np.float32)
+    emb -= 0.5
+    emb *= 2 * emb_scale
+    return emb, ub, it, uf, cf, y
+
+
+def models(oracle, kind, U, T, D, Cc, rng, scale):
+    from goctr_amd import model as gm
+    om = oracle.CtrModel(kind, U, T, D, Cc)
+    om.W0[:] = (rng.standard_normal(om.W0.shape) * scale).astype(np.float32)
+    om.W1[:] = (rng.standard_normal(om.W1.shape) * scale).astype(np.float32)
+    om.W2[:] = (rng.standard_normal(om.W2.shape) * scale).astype(np.float32)
+    if kind == 0:
+        om.att0[:] = (1 + 0.3 * rng.standard_normal(T)).astype(np.float32)
+    dm = (gm.DinNet if kind == 0 else gm.YoutubeDnn)(U, T, D, D, Cc)
+    for n, w in (("mlp0", om.W0), ("mlp1", om.W1), ("mlp2", om.W2)):
+        dm.set_weights(n, w)
+    if kind == 0:
+        dm.set_weights("att0", om.att0)
+    return om, dm
+
+
+def grad_bound(name, g_dev, g_orc, g64):
+    """|g_dev - truth| <= 2 |g_orc32 - truth| (max norm, per tensor; + one float32 ulp of the largest entry)"""
+    g_dev, g_orc, g64 = (np.asarray(a, np.float64).ravel() for a in (g_dev, g_orc, g64))
+    e_dev, e_orc = np.max(np.abs(g_dev - g64)), np.max(np.abs(g_orc - g64))
+    ulp = 6e-8 * np.max(np.abs(g64))
+    assert e_dev <= 2 * e_orc + ulp, f"{name}: device {e_dev:.3e} from the float64 truth, float32 oracle {e_orc:.3e}"
+    # and in the mean: the device must not be systematically worse either
+    r_dev, r_orc = np.sqrt(np.mean((g_dev - g64) ** 2)), np.sqrt(np.mean((g_orc - g64) ** 2))
+    assert r_dev <= 2 * r_orc + ulp, f"{name}: rms device {r_dev:.3e} vs oracle {r_orc:.3e}"
+    return e_dev, e_orc
+
+
+def one_step_checks(oracle, kind, U, T, D, Cc, V, B, seed, drop):
+    from goctr_amd import capi, model as gm
+    from goctr_amd.recommend import SampleInfo
+    rng = np.random.default_rng(seed)
+    emb, ub, it, uf, cf, Y = synth(rng, B, U, T, D, Cc, V)
+    om, dm = models(oracle, kind, U, T, D, Cc, rng, 0.15)
+    si = SampleInfo.from_dims(U, T, D, Cc)
+    tab = gm.EmbeddingTable(emb)
+    ds = gm.Dataset.ids(ub, it, uf, cf, Y)
+
+    # gather: bit-exact, on a slice (the full [B, XCols] matrix is what the oracle assembles next anyway)
+    X = oracle.assemble_rows(emb, ub, it, uf, cf)
+    assert np.array_equal(tab.gather_rows(ub[:512], it[:512], uf[:512], cf[:512]), X[:512])
+
+    # logits through the predict path at the bench's predict batch, id mode
+    y = gm.predict_dataset(dm, ds, 4096, emb=tab)
+    ry = om.predict(X, 4096)
+    assert np.max(np.abs(y - ry)) <= LOGIT_TOL
+
+    # loss + gradients of the full batch (dense rows: the parity entry), against oracle and float64 truth
+    cost, g, yb = gm.loss_grad(dm, si, X, Y, B=B)
+    rcost, rg, ryb = om.loss_grad(X, Y, B=B)
+    c64, g64, y64 = om.loss_grad_f64(X, Y, B=B)
+    assert np.max(np.abs(yb - ryb)) <= LOGIT_TOL and abs(cost - rcost) <= LOSS_TOL
+    assert abs(cost - c64) <= LOSS_TOL and np.max(np.abs(yb - y64)) <= LOGIT_TOL
+    pairs = [("mlp0", "W0"), ("mlp1", "W1"), ("mlp2", "W2")] + ([("att0", "att0")] if kind == 0 else [])
+    for dn, on in pairs:
+        grad_bound(on, g[dn], rg[on], g64[on])
+
+    # Adam: the device's update of ITS gradient must be the oracle's AdamSolver.Step of that same gradient
+    dsd = gm.Dataset.dense(X, Y, si)
+    cfg0 = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0)
+    c_dense = gm.train_steps(dm, dsd, cfg0, 1, want_costs=True)
+    assert abs(c_dense[0] - rcost) <= LOSS_TOL
+    ref = oracle.CtrModel(kind, U, T, D, Cc)
+    for a in ("W0", "W1", "W2", "att0"):
+        getattr(ref, a)[:] = getattr(om, a)
+    ref.adam_step(dict(W0=g["mlp0"], W1=g["mlp1"], W2=g["mlp2"], att0=g["att0"].ravel()), batch=B)
+    for dn, on in pairs:
+        d = np.abs(dm.get_weights(dn).ravel() - getattr(ref, on).ravel())
+        assert np.max(d) <= 2e-7, (dn, float(np.max(d)))
+
+    # the step the bench times: id mode, graph-replayed, with the reference's dropout when asked; weights after the step
+    # against the oracle's own step.  (An element whose total gradient passes within float32 noise of zero gets an
+    # ill-conditioned first Adam update, +-lr: hence the quantile next to the max.)
+    om2, dm2 = models(oracle, kind, U, T, D, Cc, np.random.default_rng(seed + 1), 0.15)
+    cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=2 if drop else 0, p0=0.005, p1=0.005, seed=77)
+    c_id = gm.train_steps(dm2, ds, cfg, 1, emb=tab, want_costs=True)
+    ref_costs = om2.train(X, Y, batch=B, epochs=1, drop_mode=2 if drop else 0, p0=0.005, p1=0.005, seed=77)
+    assert abs(c_id[0] - ref_costs[0]) <= LOSS_TOL
+    for dn, on in pairs:
+        d = np.abs(dm2.get_weights(dn).ravel() - getattr(om2, on).ravel())
+        assert np.quantile(d, 0.999) <= 1e-5 and np.max(d) <= 2.1e-2, (dn, float(np.quantile(d, 0.999)), float(np.max(d)))
+    # and the next predict sees the updated weights
+    assert np.max(np.abs(gm.predict_dataset(dm2, ds, 4096, emb=tab) - om2.predict(X, 4096))) <= 5e-5
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_cfg3_din_full_size_step_vs_oracle(oracle, drop):
+    """BASELINE configs[2] at its stated size: DIN cosine, T = 50, D = 16, vocab 26 744, batch 8192 (bench.py default)"""
+    one_step_checks(oracle, 0, 52, 50, 16, 53, 26744, 8192, 100, drop)
+
+
+def test_cfg3_din_euclid_full_size_step_vs_oracle(oracle):
+    from goctr_amd import model as gm
+    from goctr_amd.recommend import SampleInfo
+    U, T, D, Cc, V, B = 52, 50, 16, 53, 26744, 8192
+    rng = np.random.default_rng(101)
+    emb, ub, it, uf, cf, Y = synth(rng, B, U, T, D, Cc, V)
+    om = oracle.CtrModel(0, U, T, D, Cc, att=1)
+    om.W0[:] = (rng.standard_normal(om.W0.shape) * 0.15).astype(np.float32)
+    om.W1[:] = (rng.standard_normal(om.W1.shape) * 0.15).astype(np.float32)
+    om.W2[:] = (rng.standard_normal(om.W2.shape) * 0.15).astype(np.float32)
+    dm = gm.DinNet(U, T, D, D, Cc, att=1)
+    for n, w in (("mlp0", om.W0), ("mlp1", om.W1), ("mlp2", om.W2), ("att0", om.att0)):
+        dm.set_weights(n, w)
+    X = oracle.assemble_rows(emb, ub, it, uf, cf)
+    si = SampleInfo.from_dims(U, T, D, Cc)
+    cost, g, y = gm.loss_grad(dm, si, X, Y, B=B)
+    rcost, rg, ry = om.loss_grad(X, Y, B=B)
+    c64, g64, y64 = om.loss_grad_f64(X, Y, B=B)
+    assert np.max(np.abs(y - ry)) <= LOGIT_TOL and abs(cost - rcost) <= LOSS_TOL
+    for dn, on in (("mlp0", "W0"), ("mlp1", "W1"), ("mlp2", "W2"), ("att0", "att0")):
+        grad_bound(on, g[dn], rg[on], g64[on])
+
+
+def test_cfg4_youtube_full_size_step_vs_oracle(oracle):
+    """BASELINE configs[3] per-GPU slice at its stated size: YouTube-DNN, vocab 10^7 x 64-d (2.56 GB table), batch 16384"""
+    one_step_checks(oracle, 1, 52, 50, 64, 53, 10_000_000, 16384, 102, True)
+
+
+def test_cfg2_mlp_full_size_step_vs_oracle(oracle):
+    """BASELINE configs[1] at its stated size: sklearn-port MLP [281,100,1] relu/adam, batch 4096, float64: loss and
+    packed gradients of one full batch at 1e-9 relative, then 4 updates (per-parameter Adam, quirk Q7) vs the oracle"""
+    from goctr_amd import mlp as gmlp
+    rng = np.random.default_rng(103)
+    units, B = [281, 100, 1], 4096
+    X = rng.random((4 * B, 281), dtype=np.float32)
+    Y = (X[:, 0] + X[:, 5] * X[:, 9] > 1.0).astype(np.float32).reshape(-1, 1)
+    clf = gmlp.MLPClassifier([100], "relu", "adam", 1e-5)
+    clf.BatchSize, clf.MaxIter, clf.Tol, clf.Shuffle = B, 1, -1.0, False
+    theta0 = clf.init_params(units, rng)
+    clf.create(units, B, theta0.copy())
+    loss, g = clf.loss_grad(X[:B].astype(np.float64), Y[:B].astype(np.float64))
+    cfg = oracle.mlp_cfg(units, "relu", alpha=1e-5)
+    rloss, rg = oracle.mlp_loss_grad(cfg, theta0.copy(), X[:B].astype(np.float64), Y[:B].astype(np.float64))
+    assert loss == pytest.approx(rloss, rel=1e-9)
+    assert np.max(np.abs(g - rg)) <= 1e-9 * np.max(np.abs(rg)) + 1e-15
+    clf.Fit(X, Y, theta0=theta0.copy(), perm=np.arange(4 * B, dtype=np.int32)[None, :])
+    theta = theta0.copy()
+    ref = oracle.mlp_fit(cfg, theta, oracle.MlpOptimizer("adam", theta.size), X.astype(np.float64), Y.astype(np.float64), B, 1,
+                         tol=-1.0, perm=np.arange(4 * B, dtype=np.int32)[None, :])
+    assert clf.LossCurve[0] == pytest.approx(ref[0], rel=1e-8)
+    assert np.max(np.abs(clf.get_params() - theta)) <= 1e-7 * np.max(np.abs(theta)) + 1e-10

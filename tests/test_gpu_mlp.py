@@ -138,3 +138,29 @@ def test_full_size_cfg2_properties():
     clf.train_steps(200)
     l1, _ = clf.loss_grad(X[:4096], Y[:4096])
     assert np.isfinite(l1) and l1 < l0
+
+
+def test_reference_nn_forward_kat():
+    """the reference-held 3-3-3 forward vector (nn/network_test.go:25-83, tests/golden/ref_kats.json) through the device
+    MLP: units [3,3,3], relu hidden, logistic output = the KAT's ReLU and Sigmoid layers; float32 out (mlp.go:33-38)"""
+    import json, os
+    from goctr_amd import mlp as gmlp
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_kats.json")))["nn_forward"]
+    parts = []
+    for layer in k["weights_layer_neuron_input"][:2]:
+        W = np.asarray(layer, np.float64).T
+        parts += [np.full(W.shape[1], k["bias"]), W.ravel()]
+    theta = np.concatenate(parts)
+    clf = gmlp.MLPClassifier([3], "relu", "adam", 1e-4)
+    clf.create([3, 3, 3], 8, theta)
+    x = np.asarray([k["input"]] * 5, np.float32)
+    y = clf.Predict(x)
+    # inputs are narrowed to float32 at the boundary (0.1f, 0.2f, 0.7f), outputs too: a few float32 ulps
+    assert y.shape == (5, 3) and np.max(np.abs(y - np.asarray(k["expected"][1]))) <= 2e-7
+    # the float64 entry: loss/grad path sees the exact inputs -> compare the activations through the loss instead
+    Y = np.asarray([[1.0, 0.0, 1.0]])
+    loss, _ = clf.loss_grad(np.asarray([k["input"]], np.float64), Y)
+    p = np.asarray(k["expected"][1])
+    ref = -(Y * np.log(p) + (1 - Y) * np.log(1 - p)).sum() + 0.5 * 1e-4 * sum(
+        (np.asarray(l, np.float64) ** 2).sum() for l in k["weights_layer_neuron_input"][:2])
+    assert loss == pytest.approx(ref, rel=1e-9)

@@ -218,3 +218,31 @@ def test_subsample_probs(oracle):
     assert p[0] == 1.0 - np.sqrt(1e-3) and p[1] == 1.0 - np.sqrt(1e-3 / 4.0)
     assert p[3] == 1.0 - np.sqrt(1e-3 / 1e6)
     assert oracle.subsample_probs([1, 2], 4.0).tolist() == [0.0, 0.0]
+
+
+def _nn_forward_theta():
+    """packed [b0 | W0 | b1 | W1] (basemlp64.go:432-463) from the KAT's per-neuron input weights (W[in k][out j] =
+    weights[layer][neuron j][input k]) for the first two layers of nn/network_test.go's 3-3-3 net"""
+    k = KATS["nn_forward"]
+    parts = []
+    for layer in k["weights_layer_neuron_input"][:2]:
+        W = np.asarray(layer, np.float64).T                      # [in, out]
+        parts += [np.full(W.shape[1], k["bias"]), W.ravel()]
+    return np.concatenate(parts)
+
+
+def test_nn_forward_kat_pins_the_mlp_forward(oracle):
+    """nn/network_test.go:25-83: ReLU layer -> Sigmoid layer of the literal 3-3-3 net = the sklearn-port forward
+    (basemlp64.go:259-274) with units [3,3,3], relu hidden, logistic output; the softmax row is checked on top"""
+    k = KATS["nn_forward"]
+    x = np.asarray([k["input"]], np.float64)
+    theta = _nn_forward_theta()
+    hid = oracle.mlp_predict(oracle.mlp_cfg([3, 3], "identity"), theta[:12], x)      # logistic(W0 x + 1)
+    out = oracle.mlp_predict(oracle.mlp_cfg([3, 3, 3], "relu"), theta, x)[0]
+    assert np.allclose(out, k["expected"][1], rtol=k["rel_tol"], atol=0)
+    # layer 0 pre-activation through the logistic output: logit(hid) == expected[0] (all positive, so relu is identity)
+    assert np.allclose(np.log(hid[0] / (1 - hid[0])), k["expected"][0], rtol=1e-10, atol=0)
+    W2 = np.asarray(k["weights_layer_neuron_input"][2], np.float64).T
+    z = out @ W2 + k["bias"]
+    sm = np.exp(z - z.max()); sm /= sm.sum()
+    assert np.allclose(sm, k["expected"][2], rtol=k["rel_tol"], atol=0)
