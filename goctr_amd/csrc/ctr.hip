@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "ctr_chain.h"
+#include "ctr_chain_x3.h"
 #include "ctr_fwd_x3.h"
 #include "emb_train.h"
 #include "scan.h"
@@ -62,6 +63,15 @@ struct goctr_model {
   int off1 = 0, off2 = 0, offa = 0, nflat = 0;
   DevBuf<float> W, G, Mo, Vo, W1T, W2T, W0sT;
   DevBuf<float> Wimg;   // LDS images of W0 | W1 | W1^T | W0[U:U+D,:]^T (ctr_chain.h), kept in sync by Adam
+  // bf16-plane fragment images of the 6-product-split training chain (ctr_chain_x3.h), kept in sync by the Adam kernels
+  DevBuf<unsigned short> Wx3; int x3_nch0 = 0;
+  CxImages x3_images() {
+    CxImages im{nullptr, nullptr, nullptr, nullptr, 0};
+    if (!x3_nch0) return im;
+    im.nch0 = x3_nch0;
+    im.img0 = Wx3.p; im.img1 = im.img0 + cx_img0_elems(x3_nch0); im.img2 = im.img1 + cx_img1_elems(); im.img3 = im.img2 + cx_img2_elems();
+    return im;
+  }
   float* img(int which) { return Wimg.p + (which == 0 ? 0 : which == 1 ? off1 : which == 2 ? off1 + H1p * H2p : off1 + 2 * H1p * H2p); }
   // per-batch workspace
   int wsB = 0, tnS = 0;
@@ -259,7 +269,8 @@ int init_kernel_attrs() {
       allow_big_lds(emb_grad_kernel<32, 1, true>) || allow_big_lds(emb_grad_kernel<32, 2, true>) || allow_big_lds(emb_grad_kernel<64, 0, true>) || allow_big_lds(emb_grad_kernel<64, 1, true>) ||
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
-      allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>)) return -1;
+      allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
+      allow_big_lds(ctr_chain_x3_kernel<15>)) return -1;
   done = true;
   return 0;
 }
@@ -360,7 +371,70 @@ bool chain_ok(const goctr_model* m) {
          env_int("GOCTR_NO_CHAIN", 0) == 0;
 }
 
+// the bf16-split training chain (ctr_chain_x3.h) covers the reference's hidden widths with Ip in {144, 240} (cfg3 DIN /
+// the MovieLens-100k defaults, cfg4 YouTube) and the small test shape Ip = 32; hash dropout or none
+bool chain_x3_shape_ok(const goctr_model* m) {
+  const int nch0 = m->Ip / 16;
+  return m->H1p == 208 && m->H2p == 80 && (nch0 == 2 || nch0 == 9 || nch0 == 15) &&
+         (m->cfg.kind != GOCTR_DIN || m->Dp <= 32);
+}
+bool chain_x3_ok(const goctr_model* m, const StepOpts& o) {
+  return m->x3_nch0 != 0 && o.train && o.drop_mode != 1 && env_int("GOCTR_CHAIN_X3", 1) != 0;
+}
+
+int rebuild_x3_images(goctr_model* m) {
+  if (!m->x3_nch0) return 0;
+  hipLaunchKernelGGL(x3_build_images_kernel, dim3((unsigned)cdiv(m->off2, 256)), dim3(256), 0, engine().stream, m->W.p, m->off1, m->off2,
+                     m->H1p, m->H2p, m->cfg.U, m->cfg.D, m->x3_images());
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int NCH0>
+void launch_chain_x3_n(const ChainX3Args& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((ctr_chain_x3_kernel<NCH0>), grid, dim3(512), chain_x3_lds_bytes<NCH0>(), s, a);
+}
+
+int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st) {
+  const goctr_ctr_cfg& c = m->cfg;
+  Engine& e = engine();
+  const uint32_t row_off = (uint32_t)(e.rank * B);
+  const bool drop = o.drop_mode == 2;
+  const CxImages im = m->x3_images();
+  ChainX3Args a{};
+  a.h0 = m->h0.p; a.Ip = m->Ip;
+  a.img0 = im.img0; a.img1 = im.img1; a.img2 = im.img2; a.img3 = im.img3; a.w2 = m->W2T.p;
+  a.H1 = c.H1; a.H2 = c.H2; a.H1p = m->H1p; a.H2p = m->H2p; a.Dp = m->Dp; a.B = B; a.kind = c.kind;
+  a.d0 = DropCfg{drop && o.p0 > 0 ? 2 : 0, o.p0, nullptr, c.H1, o.seed, 0u, row_off};
+  a.d1 = DropCfg{drop && o.p1 > 0 ? 2 : 0, o.p1, nullptr, c.H2, o.seed, 1u, row_off};
+  a.st = st; a.Y = src.Y; a.rows = src.rows; a.inv_bglobal = 1.0f / (float)(B * e.world);
+  a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;
+  a.yhat = m->yhat.p; a.lossrow = m->lossrow.p;
+  static DevBuf<unsigned long long> dbgbuf;
+  const bool dbg = env_int("GOCTR_CHAIN_DBG", 0) != 0;
+  if (dbg && !dbgbuf.p && dbgbuf.alloc(8 * CX_NSTAMP)) return -1;
+  a.dbg = dbg ? dbgbuf.p : nullptr;
+  ProfScope ps(GOCTR_K_CHAIN);
+  const dim3 grid((unsigned)cdiv(B, 32));
+  switch (m->x3_nch0) {
+    case 2: launch_chain_x3_n<2>(a, grid, e.active); break;
+    case 9: launch_chain_x3_n<9>(a, grid, e.active); break;
+    default: launch_chain_x3_n<15>(a, grid, e.active); break;
+  }
+  GOCTR_HIP(hipGetLastError());
+  if (dbg) {
+    unsigned long long h[CX_NSTAMP];
+    if (dbgbuf.download(h, CX_NSTAMP)) return -1;
+    fprintf(stderr, "chain_x3 phases (s_memtime ticks): h0 split+barrier %lld | F0(+epi tile0) %lld | F1(+epi tile1) %lld | xchg barrier %lld | epi1+z2+dz1 %lld | B0(+epi) %lld | dp %lld + xchg %lld | total %lld\n",
+            (long long)(h[1] - h[0]), (long long)(h[2] - h[1]), (long long)(h[4] - h[2]), (long long)(h[5] - h[4]), (long long)(h[6] - h[5]),
+            (long long)(h[7] - h[6]), (long long)(h[8] - h[7]), (long long)(h[9] > h[8] ? h[9] - h[8] : 0),
+            (long long)((h[9] > h[8] ? h[9] : h[8]) - h[0]));
+  }
+  return 0;
+}
+
 int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st) {
+  if (chain_x3_ok(m, o)) return launch_chain_x3(m, src, B, o, st);
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
   const uint32_t row_off = (uint32_t)(e.rank * B);
@@ -686,6 +760,7 @@ AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc) {
   a.Ip = m->Ip; a.H1p = m->H1p; a.H2p = m->H2p; a.Dp = m->Dp; a.U = m->cfg.U; a.D = m->cfg.D;
   a.W1T = m->W1T.p; a.W2T = m->W2T.p; a.W0sT = m->W0sT.p;
   a.W0i = m->img(0); a.W1i = m->img(1); a.W1Ti = m->img(2); a.W0sTi = m->img(3);
+  a.x3 = m->x3_images();
   a.lr = tc.lr; a.l2 = tc.l2; a.beta1 = tc.beta1; a.beta2 = tc.beta2; a.eps = tc.eps;
   a.div_by_batch = tc.adam_div_by_batch; a.l2_first = tc.adam_l2_before_batch_div;
   a.bglobal = B * e.world; a.st = m->st_cur(); a.costs = m->costs.p;
@@ -953,6 +1028,10 @@ int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
   if (m->W.alloc(m->nflat) || m->G.alloc((size_t)m->nflat + 1) || m->Mo.alloc(m->nflat) || m->Vo.alloc(m->nflat)) return -1;
   if (m->W1T.alloc((size_t)m->H2p * m->H1p) || m->W2T.alloc((size_t)16 * m->H2p) || m->W0sT.alloc((size_t)m->H1p * m->Dp)) return -1;
   if (m->Wimg.alloc((size_t)m->off1 + 2 * (size_t)m->H1p * m->H2p + (size_t)m->H1p * m->Dp)) return -1;
+  if (chain_x3_shape_ok(m.get())) {
+    m->x3_nch0 = m->Ip / 16;
+    if (m->Wx3.alloc(cx_images_elems(m->x3_nch0))) return -1;      // zero = the images of all-zero weights
+  }
   if (m->st.alloc(2) || m->costs.alloc(COST_RING)) return -1;
   std::vector<float> ones(cfg->T, 1.0f);  // din.go:181 att0 = 1
   if (upload_padded_weights(m.get(), GOCTR_ATT0, ones.data(), ones.size())) return -1;
@@ -973,7 +1052,8 @@ int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, si
   GOCTR_ENTER();
   GOCTR_CHECK(m && host, "goctr_model_set_weights: null argument");
   std::lock_guard<std::mutex> lk(m->mu);
-  return upload_padded_weights(m, tensor_id, host, n);
+  if (upload_padded_weights(m, tensor_id, host, n)) return -1;
+  return (tensor_id == GOCTR_W0 || tensor_id == GOCTR_W1) ? rebuild_x3_images(m) : 0;
 }
 
 int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n) {

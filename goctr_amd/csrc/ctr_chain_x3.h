@@ -1,0 +1,472 @@
+// ctr_chain_x3.h -- the fused per-row-tile chain of the DIN / YouTube TRAINING step on the 6-product bf16 split:
+//
+//   h0 -> sigma(h0.W0) -> drop -> sigma(.W1) -> drop -> sigma(.W2) -> BCE term, dz2 -> dz1 -> dz0 -> dp
+//   (model/din/din.go:301-315, model/cost.go:9-17 and their hand-derived backward)
+//
+// Same function as ctr_chain.h (which stays for predict, explicit dropout masks and odd shapes); what changes is the
+// arithmetic unit and, with it, the whole data flow:
+//
+// * Every float32 value x is the exact sum of three bf16 planes (x = hi + mid + lo, round-to-nearest splits) and a
+//   product a*b is taken as hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid) on v_mfma_f32_32x32x16_bf16 with two
+//   float32 accumulators (the small terms apart).  Measured against float64 this is MORE accurate than the f32-input
+//   MFMA it replaces (tests bound it by the float32 oracle's own error), the six bf16 MFMAs cost 6 x 32
+//   cycles per 32x32x16 block where v_mfma_f32_16x16x4_f32 costs 16 x 32, and -- unlike the f32-input MFMA on gfx950 --
+//   they run UNDER the other wavefronts' loads and VALU work instead of blocking the SIMD.
+// * Workgroup = 32 batch rows x 8 wavefronts (two per SIMD).  Products are computed TRANSPOSED, Z^T = W^T . X^T, so a
+//   wavefront's accumulators hold Z[row = lane % 32][16 features of a 32-feature tile]: exactly the B-operand fragments
+//   (k permuted, the weight images are laid out to match) of the NEXT product.  Wavefront w owns H1 tile w (layer 0 and
+//   its backward: N split; 7 tiles, the eighth wavefront only helps with the elementwise work) and therefore a seventh
+//   of the K range of the layer-1 / dp products (K split); the partial Z1 / dp meet in LDS (reduce-scatter).
+// * Why two wavefronts per SIMD: a CDNA wavefront issues at most one instruction every four cycles, of whatever kind;
+//   with one wavefront per SIMD (the first version of this kernel: 4 x 350 registers) every s_mov and ds_read costs
+//   the same issue slot as a VALU or MFMA instruction and the kernel ran at instruction-count x 4 cycles (MFMA time
+//   completely hidden, scripts/ubench/chain_x3_bench.hip).  Two wavefronts co-issue different instruction kinds.
+// * With the rows of a workgroup in ONE wavefront's lanes no weight element is shared between wavefronts: the A
+//   operands go straight from L2 into registers (global_load_dwordx4 of ready-made fragment images, 1 KiB per wave
+//   instruction, three 16-k chunks ahead) -- no LDS staging, no loader wavefronts, no per-operand barriers.  All 256
+//   workgroups stream the same 470 KB of images: L2 hits (scripts/ubench/l2_stream.hip: 55 B/clk/CU, 29 TB/s aggregate).
+//
+// Weight images (bf16 planes, written by the Adam kernel / x3_build_images_kernel, index functions in ctr_x3_images.h):
+//   IMG0  W0   for F0:  [H1 tile t][k chunk c][plane][lane = 32 kg + m][8]   = W0[16c + 8kg + s][32t + m]
+//   IMG1  W1   for F1:  [H1 chunk cc][H2 tile u][plane][lane = 32 kg + m][8] = W1[perm(cc, kg, s)][32u + m]
+//   IMG2  W1^T for B0:  [H1 tile t][H2 chunk c][plane][lane = 32 kg + m][8]  = W1[32t + m][16c + 8kg + s]
+//   IMG3  W0[U:U+D]^T for dp: [H1 chunk cc][plane][lane = 32 kg + d][8]      = W0[U + d][perm(cc, kg, s)]
+// perm(cc, kg, s) = the H1 feature a lane holds at accumulator position: 32 (cc / 2) + 8 (2 (cc % 2) + s / 4) + 4 kg + s % 4.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/goctr.h"
+#include "ctr_chain.h"
+#include "ctr_kernels.h"
+#include "mfma_gemm.h"
+
+namespace goctr {
+
+struct ChainX3Args {
+  const float* h0; int Ip;                 // [B, Ip] float32 (attn_fwd)
+  const unsigned short* img0; const unsigned short* img1; const unsigned short* img2; const unsigned short* img3;
+  const float* w2;                         // the output unit's weight column, contiguous [H2p]
+  int H1, H2, H1p, H2p, Dp, B; int kind;
+  DropCfg d0, d1; const StepState* st;
+  const float* Y; long long rows; float inv_bglobal;
+  float* A0; float* A1; float* dz0; float* dz1; float* dz2; float* dp; float* yhat; float* lossrow;
+  unsigned long long* dbg;
+};
+
+constexpr int CX_NSTAMP = 16;
+
+template <int NCH0>
+inline size_t chain_x3_lds_bytes() {
+  // h0 fragment image | Z1 / dp exchange (8 partials) | dz1 fragment image | z2 partials
+  return (size_t)NCH0 * 3 * 1024 + (size_t)8 * CX_NU * 4 * 1024 + (size_t)CX_NCH2 * 3 * 1024 + 8 * 32 * 4;
+}
+
+// Experiment switches of scripts/ubench/chain_x3_bench.hip (never set in the library build): CX_EXP bit 0 = no A-operand
+// loads after the first ring fill, bit 1 = no jobs under the MFMAs, bit 2 = no MFMAs.  Results are wrong, timings tell
+// which resource bounds a phase.
+#ifndef CX_EXP
+#define CX_EXP 0
+#endif
+// 6-product bf16-split MFMA step for one 32x32x16 block: ah += hi*hi ; ac += everything else (smallest terms first)
+#define CX_MMA6(AH, AC, A, B)                                                         \
+  do {                                                                                \
+    AC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], B[0], AC, 0, 0, 0);            \
+    AC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[2], AC, 0, 0, 0);            \
+    AC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[1], AC, 0, 0, 0);            \
+    AC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], B[0], AC, 0, 0, 0);            \
+    AC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[1], AC, 0, 0, 0);            \
+    AH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], B[0], AH, 0, 0, 0);            \
+  } while (0)
+#if CX_EXP & 4
+#undef CX_MMA6
+#define CX_MMA6(AH, AC, A, B) do { AC[0] += (float)A[0][0] + (float)B[1][1]; AH[1] += (float)A[2][0] + (float)B[0][1] + (float)A[1][3] + (float)B[2][2]; } while (0)
+#endif
+
+// 8 consecutive accumulator values -> the three planes of one B-operand fragment (slot s = position)
+__device__ __forceinline__ void cx_split8(const float* v, cx_bf8 (&out)[3]) {
+  unsigned int h[4], m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tn_split3_pk(v[2 * j], v[2 * j + 1], h[j], m[j], l[j]);
+  out[0] = __builtin_bit_cast(cx_bf8, cx_u4{h[0], h[1], h[2], h[3]});
+  out[1] = __builtin_bit_cast(cx_bf8, cx_u4{m[0], m[1], m[2], m[3]});
+  out[2] = __builtin_bit_cast(cx_bf8, cx_u4{l[0], l[1], l[2], l[3]});
+}
+
+// Keep bits of one layer as this lane sees them.  Bit `slot` set <=> the element is a real column (not padding) AND kept
+// by the dropout hash (bit-identical to dropout_keep() / oracle orc_dropout_keep; without dropout: just "real column").
+// The scale factor of an element is then  bit ? 1 / keep : 0  in the forward and in the backward pass.
+//   * the three hash rounds that do not depend on the column are done once per lane (hrow); the column term
+//     col * 0x85EBCA6B is (lane part) + (compile-time part): one add per element instead of a multiply;
+//   * `u < keep` with u = (h >> 8) * 2^-24 is the integer comparison (h >> 8) < ceil(keep * 2^24) (both sides exact).
+struct CxDrop {
+  uint32_t hrow, thr, bits, cbase; float kv; bool on;
+  __device__ __forceinline__ void init(const DropCfg& d, const StepState* st, int row, int col_lane) {
+    on = d.mode == 2; bits = 0;
+    const float keep = on ? 1.0f - d.p : 1.0f;
+    kv = 1.0f / keep;
+    uint32_t h = mix32(d.seed ^ 0x9E3779B9u);
+    h = mix32(h ^ (st->gstep * 2u + d.layer));
+    hrow = mix32(h ^ (d.row_off + (uint32_t)row));
+    thr = on ? (uint32_t)ceilf(keep * 16777216.0f) : 0x1000000u;    // off: every 24-bit draw is below the threshold
+    cbase = (uint32_t)col_lane * 0x85EBCA6Bu + 0xC2B2AE35u;
+  }
+  // element at column col_lane + col_const (col_const a compile-time constant), remembered as bit `slot`.  Branch-free
+  // (the hash is drawn even when dropout is off: these instructions ride under MFMAs and a branch would split the
+  // scheduling region they have to share with them)
+  __device__ __forceinline__ void draw(int col_const, int slot, bool valid) {
+    const bool k = valid & ((mix32(hrow ^ (cbase + (uint32_t)col_const * 0x85EBCA6Bu)) >> 8) < thr);
+    bits |= k ? (1u << slot) : 0u;
+  }
+  __device__ __forceinline__ float factor(int slot) const { return (bits >> slot) & 1u ? kv : 0.0f; }
+};
+
+template <int NCH0>
+__global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char cx_smem[];
+  unsigned char* const h0img = cx_smem;                                         // [NCH0][3][64 lanes][16 B]
+  float* const xch = reinterpret_cast<float*>(cx_smem + (size_t)NCH0 * 3 * 1024);   // [8 waves][NU][4 g][64][4]
+  unsigned char* const dz1img = reinterpret_cast<unsigned char*>(xch) + (size_t)8 * CX_NU * 4 * 1024;   // [NCH2][3][64][16 B]
+  float* const z2p = reinterpret_cast<float*>(dz1img + (size_t)CX_NCH2 * 3 * 1024);                     // [8][32]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  const int row = blockIdx.x * 32 + n;
+  const bool vrow = row < a.B;
+  const int rowc = vrow ? row : a.B - 1;
+  const int H1p = a.H1p, H2p = a.H2p, Ip = a.Ip;
+  const bool own = w < CX_NT0;                 // wavefront 7 has no H1 tile: it multiplies tile 6 again, keep bits 0
+  const int tt = own ? w : CX_NT0 - 1;
+  const bool din = a.kind == GOCTR_DIN;
+
+  unsigned long long ts[CX_NSTAMP];
+#pragma unroll
+  for (int k = 0; k < CX_NSTAMP; ++k) ts[k] = 0;
+  auto stamp = [&](int k) { if (a.dbg) ts[k] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
+
+  // ---------------------------------------------------------------- h0 rows of this wavefront's chunks: first loads out
+  // chunk c is split by wavefront c % 8: lane (n, h) owns h0[row n][16c + 8h .. + 8]
+  constexpr int NHQ = (NCH0 + 7) / 8;
+  cx_f4 hv[NHQ][2];
+  {
+    const float* hp = a.h0 + (size_t)rowc * Ip + 8 * h;
+#pragma unroll
+    for (int cq = 0; cq < NHQ; ++cq) {
+      const int c = cq * 8 + w < NCH0 ? cq * 8 + w : NCH0 - 1;
+      if (CX_EXP & 8) { hv[cq][0] = cx_f4{(float)c, 1.f, (float)lane, 2.f}; hv[cq][1] = hv[cq][0]; continue; }   // (experiment: no h0 loads)
+      hv[cq][0] = *reinterpret_cast<const cx_f4*>(hp + c * 16);
+      hv[cq][1] = *reinterpret_cast<const cx_f4*>(hp + c * 16 + 4);
+    }
+  }
+  // ---------------------------------------------------------------- A-operand streams (global -> registers)
+  const cx_u4* const g0 = reinterpret_cast<const cx_u4*>(a.img0) + lane;        // + (((t*NCH0 + c)*3 + p) * 64)
+  const cx_u4* const g1 = reinterpret_cast<const cx_u4*>(a.img1) + lane;        // + (((cc*NU + u)*3 + p) * 64)
+  const cx_u4* const g2 = reinterpret_cast<const cx_u4*>(a.img2) + lane;        // + (((t*NCH2 + c)*3 + p) * 64)
+  const cx_u4* const g3 = reinterpret_cast<const cx_u4*>(a.img3) + lane;        // + ((cc*3 + p) * 64)
+
+  constexpr int CX_PF0 = NCH0 < 6 ? NCH0 : 6;
+  cx_u4 ra0[CX_PF0][3];
+  auto load0 = [&](int c, int slot) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) ra0[slot][p] = *(g0 + (size_t)((tt * NCH0 + c) * 3 + p) * 64);
+  };
+#pragma unroll
+  for (int c = 0; c < CX_PF0; ++c) load0(c, c);
+
+  float y = 0.f;
+  {
+    const long long gr = a.st->batch_idx * (long long)a.B + row;
+    y = (a.Y && vrow && gr < a.rows) ? a.Y[gr] : 0.f;
+  }
+  // layer-1 columns this wavefront finishes after the exchange: group (u = w / 4, g = w % 4) and, for wavefronts 0..3,
+  // (u = 2, g = w):  f = 32 u + 8 g + 4 h + r
+  const int fA = 32 * (w >> 2) + 8 * (w & 3) + 4 * h, fB = 64 + 8 * (w & 3) + 4 * h;
+  const bool hasB = w < 4;
+  CxDrop dr0, dr1;
+  dr0.init(a.d0, a.st, row, 32 * tt + 4 * h);
+  dr1.init(a.d1, a.st, row, 0);
+
+  // h0 -> bf16 planes, B-fragment image in LDS
+#pragma unroll
+  for (int cq = 0; cq < NHQ; ++cq) {
+    const int c = cq * 8 + w;
+    if (c < NCH0) {
+      float v[8] = {hv[cq][0][0], hv[cq][0][1], hv[cq][0][2], hv[cq][0][3], hv[cq][1][0], hv[cq][1][1], hv[cq][1][2], hv[cq][1][3]};
+      if (!vrow) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+      cx_bf8 pl[3];
+      cx_split8(v, pl);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<cx_bf8*>(h0img + ((size_t)(c * 3 + p) * 64 + lane) * 16) = pl[p];
+    }
+  }
+  __syncthreads();                                            // (1) h0 image complete
+  stamp(1);
+
+  // ---------------------------------------------------------------- F0: Z0^T = W0^T . h0^T  (tile tt)
+  cx_acc ah0, ac0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { ah0[i] = 0.f; ac0[i] = 0.f; }
+  // keep bits ride under the MFMAs (they depend on nothing computed here): 16 of layer 0 (slot i: column
+  // 32 tt + 8 (i / 4) + 4 h + i % 4), then 8 of layer 1 (slots 0..3: fA + r, slots 4..7: fB + r)
+  auto draw_job = [&](int e) {
+    if (e < 16) {
+      const int cc = 8 * (e >> 2) + (e & 3);
+      dr0.draw(cc, e, own && 32 * tt + 4 * h + cc < a.H1);
+    } else if (e < 24) {
+      const int r = e & 3;
+      const bool second = e >= 20;
+      const int f = (second ? fB : fA) + r;
+      // (the column is not lane part + constant here: hash the full column)
+      const bool k = (f < a.H2 && (!second || hasB)) &
+                     ((mix32(dr1.hrow ^ ((uint32_t)f * 0x85EBCA6Bu + 0xC2B2AE35u)) >> 8) < dr1.thr);
+      dr1.bits |= k ? (1u << (e - 16)) : 0u;
+    }
+  };
+  constexpr int QDRAW = (24 + NCH0 - 1) / NCH0;
+  // F1 A operands: [chunk j][u][plane] of this wavefront's two chunks cc = 2 tt + j.  The A-operand stream does not
+  // stop at a product's end: once F0's ring stops refilling, its slots go to the first pieces of the next operand
+  cx_u4 ra1[2][CX_NU][3];
+  auto load1_piece = [&](int k) {      // k = 0 .. 5: (j, u) = (k / 3, k % 3)
+    const int j = k / CX_NU, u = k - j * CX_NU;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) ra1[j][u][p] = *(g1 + (size_t)(((2 * tt + j) * CX_NU + u) * 3 + p) * 64);
+  };
+#pragma unroll
+  for (int c = 0; c < NCH0; ++c) {
+    cx_bf8 bf[3], af[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const cx_bf8*>(h0img + ((size_t)(c * 3 + p) * 64 + lane) * 16);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra0[c % CX_PF0][p]);
+    if (!(CX_EXP & 1) && c + CX_PF0 < NCH0) load0(c + CX_PF0, c % CX_PF0);
+    else if (c + CX_PF0 - NCH0 < 2 * CX_NU) load1_piece(c + CX_PF0 - NCH0);
+    CX_MMA6(ah0, ac0, af, bf);
+    if (!(CX_EXP & 2)) {
+#pragma unroll
+      for (int e = c * QDRAW; e < (c + 1) * QDRAW && e < 24; ++e) draw_job(e);
+    }
+    // keep this chunk's draws with this chunk's MFMAs (instruction selection otherwise sinks them all behind the last
+    // MFMA, where nothing hides them): the empty asm makes the bits so far an input of an ordered statement
+    asm volatile("" : "+v"(dr0.bits), "+v"(dr1.bits));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  stamp(2);
+
+#pragma unroll
+  for (int k = CX_PF0; k < 2 * CX_NU; ++k) load1_piece(k);     // (pieces a short F0 had no room for)
+
+  // ---------------------------------------------------------------- layer-0 epilogue: sigmoid, dropout, A0 (registers + HBM)
+  float p0[16];             // pre-dropout sigmoid (for the backward)
+  float a0[16];             // post-dropout activation
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float s = chain_sigm(ah0[i] + ac0[i]);
+    p0[i] = s;
+    a0[i] = s * dr0.factor(i);
+  }
+  if (vrow && own) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f = 32 * tt + 8 * g + 4 * h;
+      if (f < H1p) *reinterpret_cast<cx_f4*>(a.A0 + (size_t)row * H1p + f) = cx_f4{a0[4 * g], a0[4 * g + 1], a0[4 * g + 2], a0[4 * g + 3]};
+    }
+  }
+  stamp(3);
+
+  // ---------------------------------------------------------------- F1: partial Z1^T = W1^T[:, own K] . A0^T[own K]
+  cx_acc ah1[CX_NU], ac1[CX_NU];
+#pragma unroll
+  for (int u = 0; u < CX_NU; ++u)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ah1[u][i] = 0.f; ac1[u][i] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    cx_bf8 bf[3];
+    cx_split8(&a0[8 * j], bf);
+#pragma unroll
+    for (int u = 0; u < CX_NU; ++u) {
+      cx_bf8 af[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra1[j][u][p]);
+      CX_MMA6(ah1[u], ac1[u], af, bf);
+    }
+  }
+  stamp(4);
+  // B0 A operands in flight while the exchanges run: [chunk c][plane]
+  cx_u4 ra2[CX_NCH2][3];
+#pragma unroll
+  for (int c = 0; c < CX_NCH2; ++c)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) ra2[c][p] = *(g2 + (size_t)((tt * CX_NCH2 + c) * 3 + p) * 64);
+
+  // ---------------------------------------------------------------- exchange 1: reduce-scatter of the partial Z1
+  if (own) {
+    float* xw = xch + ((size_t)(w * CX_NU) * 4 * 64 + lane) * 4;
+#pragma unroll
+    for (int u = 0; u < CX_NU; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<cx_f4*>(xw + (size_t)(u * 4 + g) * 256) =
+            cx_f4{ah1[u][4 * g] + ac1[u][4 * g], ah1[u][4 * g + 1] + ac1[u][4 * g + 1], ah1[u][4 * g + 2] + ac1[u][4 * g + 2],
+                  ah1[u][4 * g + 3] + ac1[u][4 * g + 3]};
+  }
+  __syncthreads();                                            // (2) partial Z1 visible
+  stamp(5);
+  // this wavefront finishes group A = (u = w / 4, g = w % 4) and, wavefronts 0..3, group B = (u = 2, g = w)
+  float s1[2][4], w2v[2][4];
+  float part = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int u = k == 0 ? (w >> 2) : 2, g = w & 3;
+    const int f0 = k == 0 ? fA : fB;
+    const bool act = (k == 0 || hasB) && f0 < H2p;            // (wave-uniform except through h: f0 < H2p is per lane)
+    cx_f4 z = cx_f4{0.f, 0.f, 0.f, 0.f};
+    if (k == 0 || hasB) {
+#pragma unroll
+      for (int ws = 0; ws < CX_NT0; ++ws)   // fixed wavefront order: bitwise reproducible
+        z += *reinterpret_cast<const cx_f4*>(xch + ((size_t)((ws * CX_NU + u) * 4 + g) * 64 + lane) * 4);
+    }
+    cx_f4 wv = cx_f4{0.f, 0.f, 0.f, 0.f};
+    if (act) wv = *reinterpret_cast<const cx_f4*>(a.w2 + f0);
+    float a1v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = chain_sigm(z[r]);
+      s1[k][r] = s;
+      a1v[r] = s * dr1.factor(k * 4 + r);
+      w2v[k][r] = wv[r];
+      part += a1v[r] * wv[r];
+    }
+    if (vrow && act) *reinterpret_cast<cx_f4*>(a.A1 + (size_t)row * H2p + f0) = cx_f4{a1v[0], a1v[1], a1v[2], a1v[3]};
+  }
+  // ---------------------------------------------------------------- output unit: z2 = sum over the 8 x 2 partials
+  part += __shfl_xor(part, 32, 64);
+  if (h == 0) z2p[w * 32 + n] = part;
+  __syncthreads();                                            // (3) z2 partials visible
+  float z2 = z2p[n];
+#pragma unroll
+  for (int ws = 1; ws < 8; ++ws) z2 += z2p[ws * 32 + n];
+  const float yh = sigm_out(z2);
+  const bool writer = w == 0 && h == 0 && vrow;
+  const float one_eps = (float)(1.0 + 1e-8);
+  const float dy = -((y / yh) - ((1.0f - y) / (one_eps - yh))) * a.inv_bglobal;
+  const float d2 = dy * (yh * (1.0f - yh));
+  if (writer) {
+    a.yhat[row] = yh;
+    a.lossrow[row] = logf(yh) * y + logf(one_eps - yh) * (1.0f - y);
+    a.dz2[(size_t)row * 16] = d2;
+  }
+  // dz1 of the own features: HBM (for dW1 / dW2) and, as bf16 planes, the B-fragment image of the next product
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int f0 = k == 0 ? fA : fB;
+    const bool act = (k == 0 || hasB) && f0 < H2p;
+    float dz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float s = s1[k][r];
+      dz[r] = ((d2 * w2v[k][r]) * dr1.factor(k * 4 + r)) * (s * (1.0f - s));
+    }
+    if (act) {
+      if (vrow) *reinterpret_cast<cx_f4*>(a.dz1 + (size_t)row * H2p + f0) = cx_f4{dz[0], dz[1], dz[2], dz[3]};
+      unsigned int hh[2], mm[2], ll[2];
+      tn_split3_pk(dz[0], dz[1], hh[0], mm[0], ll[0]);
+      tn_split3_pk(dz[2], dz[3], hh[1], mm[1], ll[1]);
+      // natural H2 order: chunk c = f0 / 16, kg = (f0 / 8) & 1, slots 4h .. 4h + 3
+      const int c = f0 >> 4, kg = (f0 >> 3) & 1;
+      unsigned char* d = dz1img + ((size_t)(c * 3) * 64 + kg * 32 + n) * 16 + h * 8;
+      *reinterpret_cast<cx_u2*>(d) = cx_u2{hh[0], hh[1]};
+      *reinterpret_cast<cx_u2*>(d + 1024) = cx_u2{mm[0], mm[1]};
+      *reinterpret_cast<cx_u2*>(d + 2048) = cx_u2{ll[0], ll[1]};
+    }
+  }
+  // dp A operands (DIN): [chunk j][plane] of the own chunks
+  cx_u4 ra3[2][3];
+  if (din) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ra3[j][p] = *(g3 + (size_t)((2 * tt + j) * 3 + p) * 64);
+  }
+  __syncthreads();                                            // (4) dz1 image complete
+  stamp(6);
+
+  // ---------------------------------------------------------------- B0: dz0^T = W1 . dz1^T  (tile tt, K = H2)
+  cx_acc ahb, acb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { ahb[i] = 0.f; acb[i] = 0.f; }
+#pragma unroll
+  for (int c = 0; c < CX_NCH2; ++c) {
+    cx_bf8 bf[3], af[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const cx_bf8*>(dz1img + ((size_t)(c * 3 + p) * 64 + lane) * 16);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra2[c][p]);
+    CX_MMA6(ahb, acb, af, bf);
+  }
+  stamp(7);
+  float dzv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float s = p0[i];
+    dzv[i] = ((ahb[i] + acb[i]) * dr0.factor(i)) * (s * (1.0f - s));     // factor == 0 on pad columns / wavefront 7
+  }
+  if (vrow && own) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f = 32 * tt + 8 * g + 4 * h;
+      if (f < H1p) *reinterpret_cast<cx_f4*>(a.dz0 + (size_t)row * H1p + f) = cx_f4{dzv[4 * g], dzv[4 * g + 1], dzv[4 * g + 2], dzv[4 * g + 3]};
+    }
+  }
+  if (!din) {
+    stamp(8);
+    if (a.dbg && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < CX_NSTAMP; ++k) a.dbg[w * CX_NSTAMP + k] = ts[k];
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------- BP: partial dp^T = W0[U:U+D, own K] . dz0^T[own K]
+  cx_acc ahp, acp;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { ahp[i] = 0.f; acp[i] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    cx_bf8 bf[3], af[3];
+    cx_split8(&dzv[8 * j], bf);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra3[j][p]);
+    CX_MMA6(ahp, acp, af, bf);
+  }
+  stamp(8);
+  // exchange 2 (the Z1 area is free since barrier 3): d = 8g + 4h + r < Dp <= 32; wavefront g finishes group g
+  if (own) {
+    float* xw = xch + ((size_t)w * 4 * 64 + lane) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<cx_f4*>(xw + (size_t)g * 256) = cx_f4{ahp[4 * g] + acp[4 * g], ahp[4 * g + 1] + acp[4 * g + 1],
+                                                               ahp[4 * g + 2] + acp[4 * g + 2], ahp[4 * g + 3] + acp[4 * g + 3]};
+  }
+  __syncthreads();                                            // (5) partial dp visible
+  if (w < 4) {
+    const int d0 = 8 * w + 4 * h;
+    if (d0 < a.Dp) {
+      cx_f4 z = cx_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ws = 0; ws < CX_NT0; ++ws) z += *reinterpret_cast<const cx_f4*>(xch + ((size_t)(ws * 4 + w) * 64 + lane) * 4);
+      if (vrow) *reinterpret_cast<cx_f4*>(a.dp + (size_t)row * a.Dp + d0) = z;
+    }
+  }
+  stamp(9);
+  if (a.dbg && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < CX_NSTAMP; ++k) a.dbg[w * CX_NSTAMP + k] = ts[k];
+  }
+}
+
+}  // namespace goctr

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "ctr_x3_images.h"
+
 namespace goctr {
 
 // Per-step values that change between replays of the captured step graph live in device memory so
@@ -527,6 +529,7 @@ struct AdamArgs {
   int Ip, H1p, H2p, Dp, U, D;
   float* W1T; float* W2T; float* W0sT;  // transposed copies used by the backward-data GEMMs
   float* W0i; float* W1i; float* W1Ti; float* W0sTi;  // LDS images [K/4][N][4] read by the chain kernel
+  CxImages x3;               // bf16-plane fragment images of the 6-product-split chain kernel (img0 == null: not kept)
   double lr, l2, beta1, beta2, eps;
   int div_by_batch, l2_first;
   int bglobal;
@@ -585,6 +588,7 @@ __device__ __forceinline__ void adam_apply_pre(const AdamArgs& a, int idx, float
     const int r = k / 16, c = k - r * 16;
     a.W2T[(size_t)c * a.H2p + r] = w;
   }
+  cx_scatter_weight(a.x3, w, idx, a.off1, a.off2, a.H1p, a.H2p, a.U, a.D);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
