@@ -13,7 +13,6 @@
 #include "common.h"
 #include "ctr_chain.h"
 #include "ctr_chain_x3.h"
-#include "ctr_fwd_x3.h"
 #include "emb_train.h"
 #include "scan.h"
 #include "ctr_kernels.h"
@@ -86,9 +85,6 @@ struct goctr_model {
   std::mutex mu;
   StepGraph graph;
   int attp_blocks = 0;
-  // bf16-split operand images of the predict kernel (ctr_fwd_x3.h), rebuilt lazily after the weights changed
-  DevBuf<unsigned short> W0x3, W1x3;
-  bool pred_img_valid = false;
   // trainable-embedding extension (emb_train.h): off unless goctr_model_set_embedding_training(lr > 0)
   float emb_lr = 0.f;
   long long emb_V = 0; int emb_B = 0, emb_world = 0; bool emb_comm = false;
@@ -265,7 +261,7 @@ int init_kernel_attrs() {
                           allow_big_lds(gemm_nn_kernel<float, E, 4>) || allow_big_lds(gemm_nn_kernel<float, E, 7>))
   if (GOCTR_NN_ATTR(EpiSigDrop) || GOCTR_NN_ATTR(EpiOut) || GOCTR_NN_ATTR(EpiDSig) || GOCTR_NN_ATTR(EpiStore) ||
       allow_big_lds(ctr_chain_kernel<7, 5, 0>) || allow_big_lds(ctr_chain_kernel<7, 5, 1>) ||
-      allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(ctr_fwd16_kernel<4, 5>) || allow_big_lds(ctr_fwd16_x3_kernel<5>) || allow_big_lds(emb_grad_kernel<16, 0, true>) || allow_big_lds(emb_grad_kernel<16, 1, true>) || allow_big_lds(emb_grad_kernel<16, 2, true>) || allow_big_lds(emb_grad_kernel<32, 0, true>) ||
+      allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(ctr_fwd16_kernel<4, 5>) || allow_big_lds(emb_grad_kernel<16, 0, true>) || allow_big_lds(emb_grad_kernel<16, 1, true>) || allow_big_lds(emb_grad_kernel<16, 2, true>) || allow_big_lds(emb_grad_kernel<32, 0, true>) ||
       allow_big_lds(emb_grad_kernel<32, 1, true>) || allow_big_lds(emb_grad_kernel<32, 2, true>) || allow_big_lds(emb_grad_kernel<64, 0, true>) || allow_big_lds(emb_grad_kernel<64, 1, true>) ||
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
@@ -460,23 +456,7 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
   const int dmode = (a.d0.mode || a.d1.mode) ? o.drop_mode : 0;
   // forward only and too few rows to give every CU a 32-row workgroup: 16-row workgroups, H1 split over 4 wavefronts
   if (!o.train && cdiv(B, 32) < e.compute_units && env_int("GOCTR_NO_FWD16", 0) == 0) {
-    if (env_int("GOCTR_FWD_X3", 0) != 0) {
-      // opt-in: the bf16-split kernel (ctr_fwd_x3.h); its operand images follow the weights lazily.  Parity-green, but
-      // measured SLOWER than the f32 kernel (220 vs 249 M rows/s): a 16-row workgroup is bound by pulling the weights
-      // out of L2 (256 workgroups x 186 KB), and three bf16 planes are 1.5x the bytes of one float32 image.
-      const int nc0 = fx_w0_chunks(m->Ip), ncc = fx_w1_chunks(m->H1p);
-      if (!m->pred_img_valid) {
-        if (m->W0x3.ensure(fx_w0_bytes(m->Ip, m->H1p) / 2, false) || m->W1x3.ensure(fx_w1_bytes(m->H1p, m->H2p) / 2, false)) return -1;
-        const long long n = ((long long)nc0 * (m->H1p / 16) + (long long)ncc * (m->H2p / 16)) * 512;
-        hipLaunchKernelGGL(fx_build_images_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, e.active, m->W.p, m->Ip, m->H1p, m->H2p,
-                           m->off1, m->W0x3.p, m->W1x3.p, nc0, ncc);
-        m->pred_img_valid = true;
-      }
-      hipLaunchKernelGGL((ctr_fwd16_x3_kernel<5>), dim3((unsigned)cdiv(B, 16)), dim3(512), fx_lds_bytes(m->H1p, m->H2p), e.active, a,
-                         m->W0x3.p, m->W1x3.p, nc0, ncc);
-    } else {
-      hipLaunchKernelGGL((ctr_fwd16_kernel<4, 5>), dim3((unsigned)cdiv(B, 16)), dim3(512), lds, e.active, a);
-    }
+    hipLaunchKernelGGL((ctr_fwd16_kernel<4, 5>), dim3((unsigned)cdiv(B, 16)), dim3(512), lds, e.active, a);
   } else
   if (dmode == 0) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 0>), grid, dim3(512), lds, e.active, a);
   else if (dmode == 1) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 1>), grid, dim3(512), lds, e.active, a);
@@ -734,7 +714,6 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   }
   ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st_cur(); ra.st_out = m->st_next(); ra.advance = advance ? 1 : 0;
   if (fuse_update) {
-    m->pred_img_valid = false;
     ReduceAdamArgs p{};
     p.r = ra; p.ad = make_adam_args(m, B, *o.tc);
     ProfScope ps(GOCTR_K_REDUCE);
@@ -768,7 +747,6 @@ AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc) {
 }
 
 int launch_adam(goctr_model* m, int B, const goctr_train_cfg& tc) {
-  m->pred_img_valid = false;
   AdamArgs a = make_adam_args(m, B, tc);
   ProfScope ps(GOCTR_K_ADAM);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdiv(m->nflat, 256)), dim3(256), 0, engine().stream, a);
@@ -883,7 +861,6 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
   }
   // (with a communicator the sparse embedding exchange sizes a collective from a device counter: eager steps)
   const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0 && !(e.comm_active() && m->emb_lr > 0.f);
-  if (n_steps > 0) m->pred_img_valid = false;             // (graph replays update the weights without passing launch_adam)
   if (use_graph) {
     if (!graph_matches(m->graph, d, emb, B, o) && build_graph(m, d, emb, src, B, o)) return -1;
     for (int s = 0; s < n_steps; ++s) {
@@ -904,7 +881,6 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
 
 int upload_padded_weights(goctr_model* m, int tensor_id, const float* host, size_t n) {
   const goctr_ctr_cfg& c = m->cfg;
-  m->pred_img_valid = false;
   std::vector<float> buf;
   Engine& e = engine();
   auto up = [&](float* dst, const std::vector<float>& v) -> int {

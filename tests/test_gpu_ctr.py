@@ -342,51 +342,6 @@ def test_id_mode_shape_sweep(oracle, kind, att, U, T, D, Cc):
         assert np.max(np.abs(dm.get_weights(name) - w)) <= 2e-4 * max(1.0, np.max(np.abs(w)))
 
 
-X3_SCRIPT = r'''
-import sys, numpy as np
-sys.path.insert(0, %(root)r)
-from goctr_amd import capi, model as gm
-from oracle import pyoracle
-rng = np.random.default_rng(3)
-U, T, D, Cc, V, rows = 52, 50, 16, 53, 400, 1000
-om = pyoracle.CtrModel(pyoracle.DIN, U, T, D, Cc).init_gaussian(np.random.default_rng(1))
-om.W0 *= 0.1; om.W1 *= 0.2
-m = gm.DinNet(U, T, D, D, Cc)
-for n, w in (("mlp0", om.W0), ("mlp1", om.W1), ("mlp2", om.W2), ("att0", om.att0)):
-    m.set_weights(n, w)
-emb = (rng.standard_normal((V, D)) * 0.25).astype(np.float32)
-ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
-it = rng.integers(0, V, size=rows).astype(np.int32)
-uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
-tab = gm.EmbeddingTable(emb); ds = gm.Dataset.ids(ub, it, uf, cf, None)
-got = gm.predict_dataset(m, ds, 256, emb=tab)
-want = om.forward(pyoracle.assemble_rows(emb, ub, it, uf, cf), B=None)
-want = want[0] if isinstance(want, tuple) else want
-err = float(np.abs(got - np.asarray(want).ravel()[:rows]).max())
-print("MAXERR", err)
-assert err <= 1e-5, err
-# the images follow the weights: change them and predict again
-om.W1 *= 0.5
-m.set_weights("mlp1", om.W1)
-got2 = gm.predict_dataset(m, ds, 256, emb=tab)
-want2 = om.forward(pyoracle.assemble_rows(emb, ub, it, uf, cf), B=None)
-want2 = want2[0] if isinstance(want2, tuple) else want2
-assert float(np.abs(got2 - np.asarray(want2).ravel()[:rows]).max()) <= 1e-5
-assert float(np.abs(got2 - got).max()) > 1e-4
-'''
-
-
-def test_predict_bf16_split_kernel_opt_in(tmp_path):
-    """GOCTR_FWD_X3=1: the forward-only kernel on the 6-product bf16 split (ctr_fwd_x3.h; opt-in because it measured
-    slower) must meet the same 1e-5 bar against the oracle, and its operand images must follow weight updates"""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GOCTR_FWD_X3="1")
-    r = subprocess.run([sys.executable, "-c", X3_SCRIPT % dict(root=root)], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
-    assert "MAXERR" in r.stdout
-
-
 def test_graph_is_rebuilt_for_a_new_dataset_at_a_reused_address(oracle):
     """the cached step graph bakes in the dataset's device pointers and row count: it must be keyed on the dataset's
     generation, not on the host address of its handle (malloc readily returns a freed handle's address).  Train on
