@@ -108,19 +108,46 @@ def roofline_obj(kind, work, avg_ms):
             "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
-    (profiles/*_pmc_traffic.json, written by scripts/prof_summarize.py from separate --pmc FETCH_SIZE /
-    WRITE_SIZE passes over this same command); None when no summary is committed."""
+L2_PEAK_GBS = 34500.0        # MI355X_MICROARCH.md "L2": ~34.5 TB/s aggregate
+
+
+def pmc_entry(workload, kernel):
+    """The rocprofv3 PMC summary of `kernel` in `workload` (din / youtube / mlp / item2vec): memory-side bytes per launch
+    (separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x 2 as MI355X_MICROARCH.md prescribes for gfx950), L2 hit rate,
+    rocprofv3's own average duration -- from the newest committed profiles/*_<workload>_pmc_traffic.json, which
+    scripts/prof_workload.sh + scripts/prof_summarize.py wrote from THIS command.  The counters cannot be collected
+    inside the benchmark run itself (they need rocprofv3 around the process), so the file names its commit: a kernel
+    changed after that commit makes the figure stale.  ({} when no summary is committed.)"""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"*_{workload}_pmc_traffic.json")))
     if not files:
-        return None, None
+        return {}
     try:
-        t = json.load(open(files[-1]))["per_launch"].get(kernel)
-        return (round(t["hbm_bytes"]) if t else None), os.path.basename(files[-1])
+        d = json.load(open(files[-1]))
+        t = dict(d["per_launch"].get(kernel) or {})
+        if t:
+            t["source"] = os.path.basename(files[-1])
+            t["commit"] = d.get("commit")
+        return t
     except Exception:
-        return None, None
+        return {}
+
+
+def with_traffic(rl, workload, kernel, avg_ms=None):
+    """fill roofline.traffic (+ provenance, L2 hit rate) from the committed PMC summary; with avg_ms also the memory-side
+    rate that traffic means at the duration measured live in this run"""
+    t = pmc_entry(workload, kernel)
+    if not t:
+        return rl
+    rl["traffic"] = round(t["hbm_bytes"])
+    rl["traffic_source"], rl["traffic_commit"] = t["source"], t["commit"]
+    if t.get("l2_hit_rate") is not None:
+        rl["l2_hit_rate"] = t["l2_hit_rate"]
+    if t.get("avg_us_rocprof"):
+        rl["avg_us_rocprofv3"] = t["avg_us_rocprof"]
+    if avg_ms:
+        rl["hbm_side_GBs"] = round(t["hbm_bytes"] / (avg_ms * 1e-3) / 1e9, 1)
+    return rl
 
 
 def usable_cores() -> int:
@@ -262,6 +289,19 @@ def bench_mlp(args):
            "roofline": {"bound": "mfma", "achieved": round(flops / (dt / args.steps) / 1e12, 3), "peak": FP64_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": round(flops / (dt / args.steps) / 1e12 / FP64_MFMA_PEAK_TF, 4),
                         "traffic": None, "kernel": "whole step (all launches; launch-latency bound at this size)"}}
+    # memory-side bytes of the step's five launches (PMC summary of this command), and the longest kernel on its own
+    per = {k: pmc_entry("mlp", k) for k in ("mlp_gather_kernel", "mlp_fwd_kernel", "mlp_bwd_hidden_kernel", "mlp_tn64_kernel",
+                                           "mlp_reduce_update_kernel")}
+    if all(per.values()):
+        out["roofline"]["traffic"] = round(sum(v["hbm_bytes"] for v in per.values()))
+        out["roofline"]["traffic_source"] = per["mlp_fwd_kernel"]["source"]
+        out["roofline"]["traffic_commit"] = per["mlp_fwd_kernel"]["commit"]
+        out["kernels_rocprofv3_us"] = {k: v.get("avg_us_rocprof") for k, v in per.items()}
+        tn = per["mlp_tn64_kernel"]
+        out["dominant_kernel"] = {"kernel": "mlp_tn64_kernel (weight-gradient GEMM, f64 MFMA)", "flops": 2.0 * B * (F + 1) * H,
+                                  "avg_us_rocprofv3": tn.get("avg_us_rocprof"),
+                                  "frac_of_f64_mfma_peak": round(2.0 * B * (F + 1) * H / (tn["avg_us_rocprof"] * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF, 4)
+                                  if tn.get("avg_us_rocprof") else None}
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         cfg = pyoracle.mlp_cfg(units, "relu", alpha=1e-5)
@@ -309,10 +349,18 @@ def bench_item2vec(args):
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4]: SkipGram+HS, window 5, D=16, V=10681, Zipf(1.0), 10^7-word corpus "
                                   "resident in HBM, one pass per step, Hogwild (32768 streams)", "parallelism": "dp1"},
-           "roofline": {"bound": "hbm", "achieved": round(wps * bytes_per_word / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(wps * bytes_per_word / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel": "w2v hogwild kernel (algorithmic row read-modify-write bytes; the 2.7 MB of parameters "
-                                  "are L2/MALL resident)"}}
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "kernel": "w2v_hogwild_kernel"}}
+    # The updater is a read-modify-write walk over 2.7 MB of parameters: they live in L2 (hit rate in the PMC summary), so
+    # the HBM roof is the wrong yard-stick.  Reported: the memory-side rate (PMC bytes / pass) against HBM, and the
+    # algorithmic row traffic (19 968 B per word) against the L2 roof.
+    rl = with_traffic(out["roofline"], "item2vec", "w2v_hogwild_kernel", dt / steps * 1e3)
+    if rl.get("traffic"):
+        rl["achieved"] = rl.pop("hbm_side_GBs")
+        rl["frac"] = round(rl["achieved"] / HBM_PEAK_GBS, 4)
+    rl["l2"] = {"achieved": round(wps * bytes_per_word / 1e9, 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
+                "frac": round(wps * bytes_per_word / 1e9 / L2_PEAK_GBS, 4), "hit_rate": rl.get("l2_hit_rate"),
+                "note": "algorithmic read-modify-write bytes per word x words/s; latency- and atomics-bound, not bandwidth-bound"}
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         cores = usable_cores()
@@ -482,6 +530,8 @@ def main():
         "recommend_qps": round(qps, 1), "recommend_batch": c["PRED_B"],
         "rccl_world": rccl_world, "per_rank_ms_per_step": per_rank_ms,
     }
+    if args.train_emb > 0 and world > 1:
+        out["sparse_exchange_bytes_per_step_per_rank"] = m.sparse_exchange_bytes()
     if args.train_emb > 0:
         out["config"]["workload"] += (f"; EXTENSION: embedding table trained too (SGD scatter-add, lr {args.train_emb}; "
                                       "the reference keeps it frozen; weights 0.05 N(0,1) so that the row gradients are non-zero)")
@@ -506,18 +556,29 @@ def main():
             table = {k: {"avg_us": round(ms / n * 1e3, 2), "launches": n} for k, (ms, n) in prof.items() if n}
             dom = max((k for k in table if k in work), key=lambda k: prof[k][0])
             kind, w = work[dom]
+            wl = "youtube" if c["KIND"] == "youtube" else "din"
             rl = roofline_obj(kind, w, prof[dom][0] / prof[dom][1])
             rl["kernel"] = dom
-            if c["KIND"] == "din":     # the committed PMC passes were taken on this workload
-                rl["traffic"], rl["traffic_source"] = pmc_traffic(dom)
-                rl["algorithmic_bytes"] = chain_algorithmic_bytes() if dom == "chain" else None
+            rl = with_traffic(rl, wl, dom, prof[dom][0] / prof[dom][1])
+            rl["algorithmic_bytes"] = chain_algorithmic_bytes() if dom == "chain" and wl == "din" else None
             out["roofline"] = rl
-            if "attn_fwd" in table:       # (the DIN cfg3 step fuses the gather into the chain kernel: no separate launch)
+            if "attn_fwd" in table:
+                # the gather against the HBM roof, MEMORY-SIDE: bytes the memory system served per launch (PMC) over the
+                # duration measured live here.  The algorithmic bytes (every row and id of every sample) are reported
+                # next to it; at cfg3 the 1.7 MB table is L2-resident and the kernel is VALU-bound, at cfg4 (2.56 GB
+                # table) the Zipf-hot rows still hit in L2, so the algorithmic rate overstates what HBM delivers.
                 gk, gw = work["attn_fwd"]
-                grl = roofline_obj(gk, gw, prof["attn_fwd"][0] / prof["attn_fwd"][1])
+                gms = prof["attn_fwd"][0] / prof["attn_fwd"][1]
+                grl = roofline_obj(gk, gw, gms)
                 grl["kernel"] = "attn_fwd (embedding gather + attention pooling)"
-                if c["KIND"] == "din":
-                    grl["traffic"], grl["traffic_source"] = pmc_traffic("attn_fwd")
+                grl["algorithmic_GBs"] = grl["achieved"]
+                grl = with_traffic(grl, wl, "attn_fwd", gms)
+                if grl.get("hbm_side_GBs"):
+                    grl["achieved"] = grl.pop("hbm_side_GBs")
+                    grl["frac"] = round(grl["achieved"] / HBM_PEAK_GBS, 4)
+                    grl["basis"] = "memory-side bytes (PMC FETCH_SIZE x 2 + WRITE_SIZE) / live hipEvent duration"
+                else:
+                    grl["basis"] = "algorithmic bytes (no PMC summary committed for this workload)"
                 out["gather_roofline"] = grl
             out["kernels"] = table
     rdv.barrier()

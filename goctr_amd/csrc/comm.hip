@@ -19,6 +19,11 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -38,6 +43,11 @@ int load_rccl() {
   GOCTR_SYM(GetUniqueId, "ncclGetUniqueId");
   GOCTR_SYM(CommInitRank, "ncclCommInitRank");
   GOCTR_SYM(AllReduce, "ncclAllReduce");
+  GOCTR_SYM(AllGather, "ncclAllGather");
+  GOCTR_SYM(Send, "ncclSend");
+  GOCTR_SYM(Recv, "ncclRecv");
+  GOCTR_SYM(GroupStart, "ncclGroupStart");
+  GOCTR_SYM(GroupEnd, "ncclGroupEnd");
   GOCTR_SYM(CommDestroy, "ncclCommDestroy");
   GOCTR_SYM(GetErrorString, "ncclGetErrorString");
 #undef GOCTR_SYM
@@ -61,18 +71,31 @@ int comm_allreduce_f32(float* dev, size_t n) {
   GOCTR_NCCL(g_rccl.AllReduce(dev, dev, n, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, e.stream));
   return 0;
 }
-int comm_allreduce_u32_max(unsigned int* dev, size_t n) {
+// all-gather of n int32 per rank (recv = [world][n])
+int comm_allgather_i32(const int* send, int* recv, size_t n) {
   Engine& e = engine();
-  if (!e.comm_active()) return 0;
-  GOCTR_NCCL(g_rccl.AllReduce(dev, dev, n, ncclUint32, ncclMax, (ncclComm_t)e.nccl_comm, e.stream));
+  GOCTR_CHECK(e.comm_active(), "comm_allgather_i32: no communicator");
+  GOCTR_NCCL(g_rccl.AllGather(send, recv, n, ncclInt32, (ncclComm_t)e.nccl_comm, e.stream));
   return 0;
 }
-int comm_allreduce_i64_sum(long long* dev, size_t n) {
+// One grouped exchange: for every peer p, send_cnt[p] elements from send + send_off[p] and recv_cnt[p] elements into
+// recv + recv_off[p] (offsets and counts in elements of `bytes_per_elem` bytes, which must be 4 or 8) -- an all-to-all-v
+// built from ncclSend / ncclRecv pairs inside one group (point-to-point over xGMI, including the self pair).
+int comm_alltoallv(const void* send, const size_t* send_off, const size_t* send_cnt, void* recv, const size_t* recv_off,
+                   const size_t* recv_cnt, int bytes_per_elem) {
   Engine& e = engine();
-  if (!e.comm_active()) return 0;
-  GOCTR_NCCL(g_rccl.AllReduce(dev, dev, n, ncclInt64, ncclSum, (ncclComm_t)e.nccl_comm, e.stream));
+  GOCTR_CHECK(e.comm_active(), "comm_alltoallv: no communicator");
+  GOCTR_CHECK(bytes_per_elem == 4 || bytes_per_elem == 8, "comm_alltoallv: element size %d", bytes_per_elem);
+  const ncclDataType_t ty = bytes_per_elem == 4 ? ncclInt32 : ncclInt64;
+  GOCTR_NCCL(g_rccl.GroupStart());
+  for (int p = 0; p < e.world; ++p) {
+    if (send_cnt[p]) GOCTR_NCCL(g_rccl.Send(static_cast<const char*>(send) + send_off[p] * bytes_per_elem, send_cnt[p], ty, p, (ncclComm_t)e.nccl_comm, e.stream));
+    if (recv_cnt[p]) GOCTR_NCCL(g_rccl.Recv(static_cast<char*>(recv) + recv_off[p] * bytes_per_elem, recv_cnt[p], ty, p, (ncclComm_t)e.nccl_comm, e.stream));
+  }
+  GOCTR_NCCL(g_rccl.GroupEnd());
   return 0;
 }
+
 int comm_allreduce_f64_dev(double* dev, size_t n) {
   Engine& e = engine();
   if (!e.comm_active()) return 0;

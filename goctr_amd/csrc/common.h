@@ -133,7 +133,9 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // collective hook (comm.hip): in-place sum over ranks on the engine stream; no-op when world == 1
 int comm_allreduce_f32(float* dev, size_t n);
 int comm_allreduce_f64_dev(double* dev, size_t n);
-int comm_allreduce_u32_max(unsigned int* dev, size_t n);   // sparse embedding update: union of the ranks' touched ids
-int comm_allreduce_i64_sum(long long* dev, size_t n);      // ... and the exact (fixed-point) sum of their row gradients
+// sparse embedding update (bucketed exchange, emb_train.h): counts all-gather + all-to-all-v of ids / rows
+int comm_allgather_i32(const int* send, int* recv, size_t n);
+int comm_alltoallv(const void* send, const size_t* send_off, const size_t* send_cnt, void* recv, const size_t* recv_off,
+                   const size_t* recv_cnt, int bytes_per_elem);
 
 }  // namespace goctr

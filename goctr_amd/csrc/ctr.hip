@@ -93,6 +93,13 @@ struct goctr_model {
   DevBuf<unsigned long long> emb_total;
   DevBuf<long long> emb_accum;
   DevBuf<int> emb_slot_id;
+  long long emb_Vw = 0;           // rows of one owner's bucket in the (owner-major) mark / rank index space
+  // bucketed exchange (data parallel): bucket bounds / counts, received pairs, the owner's reduction, the gathered deltas
+  DevBuf<int> ex_off, ex_cnt, ex_allcnt, ex_rids, ex_red_ids, ex_nred, ex_allnred, ex_gids;
+  DevBuf<long long> ex_rrows, ex_red;
+  DevBuf<float> ex_delta, ex_gdelta;
+  DevBuf<unsigned long long> ex_red_total;
+  double ex_bytes_last = 0;       // bytes this rank SENT in the last step's exchange
 };
 
 namespace {
@@ -508,18 +515,26 @@ AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc);
 // Buffers of the sparse embedding update.  Allocated (and zeroed) BEFORE a step is captured into a hipGraph: a
 // hipMemsetAsync issued during capture becomes a graph node and would re-zero hundreds of MB on every replay.
 int ensure_emb_workspace(goctr_model* m, long long V, int B) {
-  // (the accumulators are sized for the UNION of all ranks' ids: a communicator created after the first step changes it)
+  // (the accumulators are sized for this rank's own ids; a communicator created after the first step changes the index space)
   if (m->emb_lr <= 0.f || (m->emb_V == V && m->emb_B == B && m->emb_world == engine().world &&
                            m->emb_comm == engine().comm_active())) return 0;
   const goctr_ctr_cfg& c = m->cfg;
   const int Np = round_up(2 * c.D, 16);
-  const long long cap = std::min<long long>(V, (long long)B * (c.T + 1) * engine().world);
-  if (m->dpv.alloc((size_t)B * Np) || m->W0pvT.alloc((size_t)m->H1p * Np) || m->emb_mark.alloc((size_t)V) ||
-      m->emb_rank.alloc((size_t)V, false) || m->emb_total.alloc(1) || m->emb_accum.alloc((size_t)cap * c.D) ||
-      m->emb_slot_id.alloc((size_t)cap, false) || m->emb_tiles.alloc((size_t)cdiv(V, SCAN_TILE), false))
+  const int W = engine().comm_active() ? engine().world : 1;
+  const long long Vw = round_up((int)cdiv(V, W), 4);
+  const long long Vp = Vw * W;                                        // owner-major index space (emb_train.h: emb_pidx)
+  const long long cap = std::min<long long>(V, (long long)B * (c.T + 1));
+  if (m->dpv.alloc((size_t)B * Np) || m->W0pvT.alloc((size_t)m->H1p * Np) || m->emb_mark.alloc((size_t)Vp) ||
+      m->emb_rank.alloc((size_t)Vp, false) || m->emb_total.alloc(1) || m->emb_accum.alloc((size_t)cap * c.D) ||
+      m->emb_slot_id.alloc((size_t)cap, false) || m->emb_tiles.alloc((size_t)cdiv(Vp, SCAN_TILE), false))
     return -1;
+  if (engine().comm_active()) {
+    if (m->ex_off.alloc(W + 1) || m->ex_cnt.alloc(W) || m->ex_allcnt.alloc((size_t)W * W) || m->ex_nred.alloc(1) ||
+        m->ex_allnred.alloc(W) || m->ex_red_total.alloc(1)) return -1;
+    // (the data buffers grow on demand: their sizes follow the ids the batches actually touch)
+  }
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
-  m->emb_V = V; m->emb_B = B; m->emb_world = engine().world; m->emb_comm = engine().comm_active();
+  m->emb_V = V; m->emb_B = B; m->emb_world = engine().world; m->emb_comm = engine().comm_active(); m->emb_Vw = Vw;
   m->graph.destroy();
   return 0;
 }
@@ -538,6 +553,80 @@ void launch_emb_grad(int mode, bool cache, dim3 gb, size_t lds, hipStream_t s, c
 
 // Sparse embedding update of one step (emb_train.h).  Runs after every reader of the table in this step (attn_fwd,
 // attn_bwd's re-gather) and before the step state advances.
+// Bucketed exchange of one step's sparse row gradients (emb_train.h): all-to-all of the (id,
+// fixed-point row) pairs to their owners (id % world), exact owner-side sums, all-gather of (id, delta), every replica
+// applies every delta.  Two small host read-backs size the transfers (the counts are data dependent), so these steps run
+// eagerly; the traffic is proportional to the ids the batches touch, not to the vocabulary.
+int launch_emb_exchange(goctr_model* m, const EmbTrainArgs& a) {
+  Engine& e = engine();
+  const int W = e.world, r = e.rank, D = a.D;
+  hipStream_t s = e.stream;
+  hipLaunchKernelGGL(emb_bucket_bounds_kernel, dim3(1), dim3(64), 0, s, m->emb_slot_id.p, m->emb_total.p, W, m->ex_off.p, m->ex_cnt.p);
+  GOCTR_HIP(hipGetLastError());
+  if (comm_allgather_i32(m->ex_cnt.p, m->ex_allcnt.p, (size_t)W)) return -1;
+  std::vector<int> off(W + 1), allcnt((size_t)W * W);
+  if (m->ex_off.download(off.data(), W + 1) || m->ex_allcnt.download(allcnt.data(), (size_t)W * W)) return -1;   // (host sync 1)
+  std::vector<size_t> so(W), sc(W), ro(W), rc(W);
+  size_t nrecv = 0;
+  for (int p = 0; p < W; ++p) {
+    so[p] = (size_t)off[p]; sc[p] = (size_t)(off[p + 1] - off[p]);
+    ro[p] = nrecv; rc[p] = (size_t)allcnt[(size_t)p * W + r]; nrecv += rc[p];
+  }
+  if (m->ex_rids.ensure(nrecv, false) || m->ex_rrows.ensure(nrecv * D, false)) return -1;
+  if (comm_alltoallv(m->emb_slot_id.p, so.data(), sc.data(), m->ex_rids.p, ro.data(), rc.data(), 4)) return -1;
+  std::vector<size_t> soD(W), scD(W), roD(W), rcD(W);
+  for (int p = 0; p < W; ++p) { soD[p] = so[p] * D; scD[p] = sc[p] * D; roD[p] = ro[p] * D; rcD[p] = rc[p] * D; }
+  if (comm_alltoallv(m->emb_accum.p, soD.data(), scD.data(), m->ex_rrows.p, roD.data(), rcD.data(), 8)) return -1;
+  double sent = 0;
+  for (int p = 0; p < W; ++p) sent += (double)sc[p] * (4 + 8.0 * D);
+  // the local accumulators are done with (sent): clear them for the next step
+  GOCTR_HIP(hipMemsetAsync(m->emb_accum.p, 0, sizeof(long long) * (size_t)off[W] * D, s));
+  // owner side: unique ids of my bucket -> dense slots (ascending id), exact sums
+  const size_t cap_red = std::min<size_t>((size_t)m->emb_Vw, nrecv);
+  if (m->ex_red.n < cap_red * D || !m->ex_red.p) { if (m->ex_red.alloc(std::max<size_t>(cap_red * D, 1))) return -1; }   // (zeroed; kept zero by emb_delta)
+  if (m->ex_red_ids.ensure(std::max<size_t>(cap_red, 1), false) || m->ex_delta.ensure(std::max<size_t>(cap_red * D, 1), false)) return -1;
+  if (nrecv) {
+    hipLaunchKernelGGL(emb_recv_mark_kernel, dim3((unsigned)cdiv((long long)nrecv, 256)), dim3(256), 0, s, m->ex_rids.p, (long long)nrecv, W,
+                       m->emb_Vw, m->emb_mark.p);
+    GOCTR_HIP(hipGetLastError());
+  }
+  if (exclusive_scan_sink(m->emb_mark.p + (size_t)r * m->emb_Vw, m->emb_Vw, m->emb_tiles, m->ex_red_total.p, EmbMultiMap{},
+                          EmbRankSink{m->emb_mark.p, m->emb_rank.p, m->ex_red_ids.p, W, m->emb_Vw, (long long)r * m->emb_Vw})) return -1;
+  if (nrecv) {
+    hipLaunchKernelGGL(emb_recv_accumulate_kernel, dim3((unsigned)cdiv((long long)nrecv * D, 256)), dim3(256), 0, s, m->ex_rids.p,
+                       m->ex_rrows.p, (long long)nrecv, D, W, m->emb_Vw, m->emb_rank.p, m->ex_red.p);
+    GOCTR_HIP(hipGetLastError());
+  }
+  const int cus = e.compute_units > 0 ? e.compute_units : 256;
+  hipLaunchKernelGGL(emb_delta_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(cdiv((long long)cap_red * D, 256), 1), 16 * cus)),
+                     dim3(256), 0, s, m->ex_red.p, m->ex_red_total.p, D, a.lr, m->ex_delta.p);
+  GOCTR_HIP(hipGetLastError());
+  // all-gather of (ids, deltas): counts first
+  hipLaunchKernelGGL(emb_count_to_i32_kernel, dim3(1), dim3(1), 0, s, m->ex_red_total.p, m->ex_nred.p);
+  GOCTR_HIP(hipGetLastError());
+  if (comm_allgather_i32(m->ex_nred.p, m->ex_allnred.p, 1)) return -1;
+  std::vector<int> nred(W);
+  if (m->ex_allnred.download(nred.data(), W)) return -1;                                                           // (host sync 2)
+  std::vector<size_t> go(W), gc(W), zo(W, 0), mine(W);
+  size_t ng = 0;
+  for (int p = 0; p < W; ++p) { go[p] = ng; gc[p] = (size_t)nred[p]; ng += gc[p]; mine[p] = (size_t)nred[r]; }
+  if (m->ex_gids.ensure(std::max<size_t>(ng, 1), false) || m->ex_gdelta.ensure(std::max<size_t>(ng * D, 1), false)) return -1;
+  if (comm_alltoallv(m->ex_red_ids.p, zo.data(), mine.data(), m->ex_gids.p, go.data(), gc.data(), 4)) return -1;
+  std::vector<size_t> goD(W), gcD(W), mineD(W);
+  for (int p = 0; p < W; ++p) { goD[p] = go[p] * D; gcD[p] = gc[p] * D; mineD[p] = mine[p] * D; }
+  if (comm_alltoallv(m->ex_delta.p, zo.data(), mineD.data(), m->ex_gdelta.p, goD.data(), gcD.data(), 4)) return -1;
+  sent += (double)W * nred[r] * (4 + 4.0 * D);
+  m->ex_bytes_last = sent;
+  if (ng) {
+    hipLaunchKernelGGL(emb_apply_gathered_kernel, dim3((unsigned)std::min<long long>(cdiv((long long)ng * D, 256), 16 * cus)), dim3(256), 0, s,
+                       a.emb, m->ex_gids.p, m->ex_gdelta.p, (long long)ng, D);
+    GOCTR_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+// Sparse embedding update of one step (emb_train.h).  Runs after every reader of the table in this step (attn_fwd,
+// attn_bwd's re-gather) and before the step state advances.
 int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepState* st) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
@@ -545,14 +634,16 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   GOCTR_CHECK(c.D <= 64, "embedding training supports D <= 64 (got %d)", c.D);
   const int Np = round_up(2 * c.D, 16);
   const long long V = src.V;
-  const long long cap = std::min<long long>(V, (long long)B * (c.T + 1) * e.world);   // the UNION of all ranks' ids gets slots
+  const long long cap = std::min<long long>(V, (long long)B * (c.T + 1));
   GOCTR_CHECK(m->emb_V == V && m->emb_B == B && m->emb_world == e.world && m->emb_comm == e.comm_active(),
               "embedding-training workspace not prepared (ensure_emb_workspace)");
+  const int W = e.comm_active() ? e.world : 1;
   EmbTrainArgs a{};
   a.src = src; a.st = st; a.B = B; a.T = c.T; a.D = c.D; a.kind = c.kind; a.att = c.att;
   a.dpv = m->dpv.p; a.ldp = Np; a.gate = m->gate.p; a.wgt = m->wgt.p; a.att0 = m->W.p + m->offa;
   a.emb = const_cast<float*>(src.emb); a.V = V;
   a.mark = m->emb_mark.p; a.rank = m->emb_rank.p; a.accum = m->emb_accum.p; a.lr = m->emb_lr; a.dbg = env_int("GOCTR_EMB_DBG", 0);
+  a.W = W; a.Vw = m->emb_Vw;
   hipStream_t s = e.stream;
   {
   ProfScope ps(GOCTR_K_EMB_TRAIN);
@@ -563,11 +654,10 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   hipLaunchKernelGGL(emb_mark_kernel, dim3((unsigned)cdiv(pairs, 256)), dim3(256), 0, s, a, singles);
   if (singles) hipLaunchKernelGGL(emb_mark2_kernel, dim3((unsigned)cdiv(pairs, 256)), dim3(256), 0, s, a);
   GOCTR_HIP(hipGetLastError());
-  // data parallel (replicated table): every rank numbers the union of the touched ids, so slot u means the same id
-  // everywhere and the ranks' fixed-point accumulators can be summed element-wise — an integer sum, hence exact and
-  // order-independent: the replicas stay bit-identical.
-  if (comm_allreduce_u32_max(m->emb_mark.p, (size_t)V)) return -1;
-  if (exclusive_scan_sink(m->emb_mark.p, V, m->emb_tiles, m->emb_total.p, EmbMultiMap{}, EmbRankSink{m->emb_mark.p, m->emb_rank.p, m->emb_slot_id.p})) return -1;
+  // rank scan over the owner-major index space: this rank's touched ids get dense slots, bucket after bucket (owner =
+  // id % world), ascending ids inside a bucket
+  if (exclusive_scan_sink(m->emb_mark.p, m->emb_Vw * W, m->emb_tiles, m->emb_total.p, EmbMultiMap{},
+                          EmbRankSink{m->emb_mark.p, m->emb_rank.p, m->emb_slot_id.p, W, m->emb_Vw, 0})) return -1;
   hipLaunchKernelGGL(w0pv_transpose_kernel, dim3((unsigned)cdiv((long long)m->H1p * Np, 256)), dim3(256), 0, s, m->W.p, m->H1p,
                      c.U, 2 * c.D, Np, m->W0pvT.p);
   GOCTR_HIP(hipGetLastError());
@@ -593,11 +683,7 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   if (c.D <= 16) launch_emb_grad<16>(mode, cache, gg, lds, s, a, nslot);
   else if (c.D <= 32) launch_emb_grad<32>(mode, cache, gg, lds, s, a, nslot);
   else launch_emb_grad<64>(mode, cache, gg, lds, s, a, nslot);
-  if (e.comm_active()) {
-    unsigned long long n_union = 0;
-    if (m->emb_total.download(&n_union, 1)) return -1;    // (host sync: the exchange is sized by the union, not by its bound)
-    if (comm_allreduce_i64_sum(m->emb_accum.p, (size_t)n_union * c.D)) return -1;
-  }
+  if (e.comm_active()) return launch_emb_exchange(m, a);
   hipLaunchKernelGGL(emb_apply_kernel, dim3((unsigned)std::min<long long>(cdiv(cap * c.D, 256), 16 * cus)), dim3(256), 0, s, a,
                      m->emb_slot_id.p, m->emb_total.p);
   GOCTR_HIP(hipGetLastError());
@@ -1113,6 +1199,14 @@ int goctr_model_set_embedding_training(goctr_model* m, double lr) {
   GOCTR_CHECK(lr == 0 || m->cfg.D <= 64, "embedding training supports D <= 64 (got %d)", m->cfg.D);
   m->emb_lr = (float)lr;
   m->graph.destroy();
+  return 0;
+}
+
+int goctr_model_sparse_exchange_bytes(goctr_model* m, double* bytes) {
+  GOCTR_ENTER();
+  GOCTR_CHECK(m && bytes, "goctr_model_sparse_exchange_bytes: null argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  *bytes = engine().comm_active() ? m->ex_bytes_last : 0.0;
   return 0;
 }
 

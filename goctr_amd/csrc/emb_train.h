@@ -41,14 +41,25 @@ struct EmbTrainArgs {
   const float* dpv; int ldp;       // [B, ldp]: columns 0..D-1 = d cost / d pooled, D..2D-1 = d cost / d item embedding
   const float* gate; const float* wgt; const float* att0;
   float* emb; long long V;
-  unsigned int* mark;              // [V]
-  const unsigned int* rank;        // [V]
+  unsigned int* mark;              // [W * Vw], indexed by emb_pidx(id)
+  const unsigned int* rank;        // [W * Vw], indexed by emb_pidx(id)
+  // Data parallel (W ranks, replicated table): the mark / rank arrays are indexed OWNER-MAJOR, pidx(id) = (id % W) * Vw +
+  // id / W with Vw = round_up(ceil(V / W), 4), so that the rank scan numbers the touched ids bucket after bucket
+  // (owner = id % W) in ascending id order: a rank's gradient rows for owner o are one contiguous range of accum --
+  // the send buffer of the bucketed exchange (ctr.hip: launch_emb_exchange), no packing pass.  W == 1: pidx(id) == id.
+  int W; long long Vw;
   long long* accum;                // [min(V, B (T+1)), D]
   float lr;
   int dbg;                         // timing experiments only (GOCTR_EMB_DBG): 1 skip the flush, 2 skip cache misses, 4 skip LDS adds
 };
 
 constexpr unsigned int EMB_MULTI = 0xFFFFFFFFu;
+
+__device__ __forceinline__ long long emb_pidx(const EmbTrainArgs& a, int id) {
+  if (a.W == 1) return id;
+  const int q = id / a.W;
+  return (long long)(id - q * a.W) * a.Vw + q;
+}
 
 // mark[id]: 0 = untouched, EMB_MULTI = accumulate (gets a slot), p + 1 = touched by pair p only ("single").
 // singles == 0: every touched id is EMB_MULTI.  singles == 1: first pass — the last writer's pair index stays;
@@ -67,13 +78,13 @@ __device__ __forceinline__ int emb_pair_id(const EmbTrainArgs& a, long long p) {
 __global__ void emb_mark_kernel(EmbTrainArgs a, int singles) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   const int id = emb_pair_id(a, p);
-  if (id >= 0) a.mark[id] = singles ? (unsigned int)p + 1u : EMB_MULTI;
+  if (id >= 0) a.mark[emb_pidx(a, id)] = singles ? (unsigned int)p + 1u : EMB_MULTI;
 }
 
 __global__ void emb_mark2_kernel(EmbTrainArgs a) {
   const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
   const int id = emb_pair_id(a, p);
-  if (id >= 0 && a.mark[id] != (unsigned int)p + 1u) a.mark[id] = EMB_MULTI;
+  if (id >= 0 && a.mark[emb_pidx(a, id)] != (unsigned int)p + 1u) a.mark[emb_pidx(a, id)] = EMB_MULTI;
 }
 
 // W0pvT[k][n] = W0[U + n][k], n < 2D (zero beyond): the B operand of dpv = dz0 . W0[U:U+2D, :]^T
@@ -152,14 +163,14 @@ __device__ __forceinline__ unsigned int emb_cache_slot(const EmbCache& c, int id
 __device__ __forceinline__ void emb_apply_single(const EmbTrainArgs& a, int id, int l, float row, float g) {
   const long long q = emb_fix(g);
   a.emb[(long long)id * a.D + l] = row - a.lr * (float)((double)q * EMB_FIX_INV);
-  if (l == 0) a.mark[id] = 0u;
+  if (l == 0) a.mark[emb_pidx(a, id)] = 0u;
 }
 
 __device__ __forceinline__ void emb_add(const EmbTrainArgs& a, const EmbCache& c, int id, unsigned int slot, int tag, int l, float g) {
   const long long q = emb_fix(g);
   if (q == 0) return;
   if (tag == id) { if (!(a.dbg & 4)) __hip_atomic_fetch_add(c.acc + (size_t)slot * a.D + l, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-  else if (!(a.dbg & 2)) atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)a.rank[id] * a.D + l), (unsigned long long)q);
+  else if (!(a.dbg & 2)) atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)a.rank[emb_pidx(a, id)] * a.D + l), (unsigned long long)q);
 }
 
 constexpr int EMB_PASS = 4;               // rows a lane group has in flight
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
         const int tl = tb + lane;
         const int id = tl < T ? a.src.ub_ids[gr * T + tl] : -1;
         myid = (id >= 0 && id < a.V) ? id : -1;
-        mymark = myid >= 0 ? a.mark[myid] : 0u;
+        mymark = myid >= 0 ? a.mark[emb_pidx(a, myid)] : 0u;
       }
       auto load_pass = [&](int pb, int (&ids)[PASS], float (&xs)[PASS], unsigned int (&mk)[PASS]) {
 #pragma unroll
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
           } else {
             const int id = in ? a.src.ub_ids[gr * T + tb + sl] : -1;   // one address per lane group: a broadcast load
             ids[k] = (id >= 0 && id < a.V) ? id : -1;
-            mk[k] = ids[k] >= 0 ? a.mark[ids[k]] : 0u;              // != 0: this pair is the id's only occurrence
+            mk[k] = ids[k] >= 0 ? a.mark[emb_pidx(a, ids[k])] : 0u;   // != 0: this pair is the id's only occurrence
           }
           xs[k] = (act && ids[k] >= 0 && !(a.dbg & 64)) ? a.emb[(long long)ids[k] * D + l] : 0.f;
         }
@@ -301,7 +312,7 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
 #pragma unroll
     for (int o = GS; o < 64; o <<= 1) dv += __shfl_xor(dv, o, 64);
     if (grp == 0 && item_ok) {
-      const bool single = a.mark[item] != 0u;
+      const bool single = a.mark[emb_pidx(a, item)] != 0u;
       const unsigned int slot = emb_cache_slot(c, item);
       int tg = (CACHE && l == 0 && !single) ? emb_cache_claim(c, slot, item) : -1;
       if (CACHE) tg = emb_group_sum_int<GS>(l == 0 ? tg + 1 : 0) - 1;
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
   for (int i = threadIdx.x; i < nslot * D; i += EMB_GRAD_THREADS) {
     const int tag = c.tag[i / D];
     const long long q = (long long)c.acc[i];
-    if (tag >= 0 && q && !(a.dbg & 1)) atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)a.rank[tag] * D + i % D), (unsigned long long)q);
+    if (tag >= 0 && q && !(a.dbg & 1)) atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)a.rank[emb_pidx(a, tag)] * D + i % D), (unsigned long long)q);
   }
 }
 
@@ -329,10 +340,79 @@ struct EmbMultiMap {
 };
 struct EmbRankSink {
   unsigned int* mark; unsigned int* rank; int* slot_id;
-  __device__ __forceinline__ void operator()(long long id, unsigned int m, unsigned int r) const {
-    if (m == EMB_MULTI) { rank[id] = r; slot_id[r] = (int)id; mark[id] = 0u; }     // (a single keeps its mark until emb_grad has applied it)
+  int W; long long Vw; long long base;    // the scanned range starts at permuted index `base` (owner-side scans cover one bucket)
+  __device__ __forceinline__ void operator()(long long i, unsigned int m, unsigned int r) const {
+    if (m == EMB_MULTI) {     // (a single keeps its mark until emb_grad has applied it)
+      const long long pi = base + i;
+      const long long id = W == 1 ? pi : (pi % Vw) * W + pi / Vw;
+      rank[pi] = r; slot_id[r] = (int)id; mark[pi] = 0u;
+    }
   }
 };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Bucketed exchange of the sparse row gradients (data parallel, replicated table).  Owner of an
+// id = id % W.  After the local rank scan a rank's rows for owner o are accum[off[o] .. off[o+1]) (ids ascending):
+//   1. all-to-all of (ids, 64-bit fixed-point rows), exact counts;
+//   2. the owner marks the received ids inside ITS bucket of the mark array, scans that bucket -> dense slots of the
+//      unique ids, and adds every received row into red[slot] -- integer adds, exact and order-independent;
+//   3. delta = lr * float(sum) (the expression emb_apply uses), ids + deltas all-gathered;
+//   4. every rank subtracts every delta from its replica: the replicas stay bit-identical.
+// Traffic is proportional to the ids the batch touches, not to the vocabulary.
+
+// off[o] = first slot whose owner is >= o (slot_id is sorted by (owner, id)); off[W] = n
+__global__ void emb_bucket_bounds_kernel(const int* slot_id, const unsigned long long* n_slots, int W, int* off, int* cnt) {
+  const int o = threadIdx.x;
+  const long long n = (long long)*n_slots;
+  if (o > W) return;
+  long long lo = 0, hi = n;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (slot_id[mid] % W >= o) hi = mid; else lo = mid + 1;
+  }
+  off[o] = (int)lo;
+  __syncthreads();
+  if (o < W) cnt[o] = off[o + 1] - off[o];
+}
+
+// owner side: mark the received ids (all of them fall into this rank's bucket)
+__global__ void emb_recv_mark_kernel(const int* rids, long long n, int W, long long Vw, unsigned int* mark) {
+  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int id = rids[k];
+  mark[(long long)(id % W) * Vw + id / W] = EMB_MULTI;
+}
+
+// owner side: red[rank[pidx(id_k)]][l] += rows[k][l]
+__global__ void emb_recv_accumulate_kernel(const int* rids, const long long* rows, long long n, int D, int W, long long Vw,
+                                           const unsigned int* rank, long long* red) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * D) return;
+  const long long k = i / D;
+  const int l = (int)(i - k * D), id = rids[k];
+  const long long q = rows[i];
+  if (q) atomicAdd(reinterpret_cast<unsigned long long*>(red + (long long)rank[(long long)(id % W) * Vw + id / W] * D + l), (unsigned long long)q);
+}
+
+// owner side: delta = lr * float(sum) (emb_apply's expression), red cleared behind
+__global__ void emb_delta_kernel(long long* red, const unsigned long long* n_red, int D, float lr, float* delta) {
+  const long long n = (long long)*n_red * D;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long q = red[i];
+    red[i] = 0;
+    delta[i] = lr * (float)((double)q * EMB_FIX_INV);
+  }
+}
+
+__global__ void emb_count_to_i32_kernel(const unsigned long long* n, int* out) { *out = (int)*n; }
+
+// every rank: E[id] -= delta for the gathered (id, delta) lists of all owners (ids are unique across the lists)
+__global__ void emb_apply_gathered_kernel(float* emb, const int* ids, const float* delta, long long n, int D) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n * D; i += (long long)gridDim.x * 256) {
+    const float d = delta[i];
+    if (d != 0.f) emb[(long long)ids[i / D] * D + i % D] -= d;
+  }
+}
 
 // E[id] -= lr * accum, accum cleared behind; grid-stride over (slot, component), n = the scan's total
 __global__ void emb_apply_kernel(EmbTrainArgs a, const int* slot_id, const unsigned long long* n_slots) {

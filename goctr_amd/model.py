@@ -103,6 +103,12 @@ class _CtrNet:
         capi.check(capi.load().goctr_model_set_embedding_training(self._h, C.c_double(lr)))
         return self
 
+    def sparse_exchange_bytes(self):
+        """bytes this rank sent in the last step's sparse-gradient exchange (0 without a communicator)"""
+        v = C.c_double(0)
+        capi.check(capi.load().goctr_model_sparse_exchange_bytes(self._h, C.byref(v)))
+        return v.value
+
     def init_gaussian(self, rng):
         """G.Gaussian(0, 1) weights, att0 = 1 (din.go:181-191; dnn.go:125-127)."""
         for n in ("mlp0", "mlp1", "mlp2"):

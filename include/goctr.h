@@ -80,8 +80,13 @@ int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n
  * dnn.go:152-154; SURVEY F3, 8(e) "Trainable embeddings"): lr > 0 makes every following training step on an id-mode
  * dataset also update the rows of the goctr_emb table it is given,  E[id] -= lr * dCost/dE[id]  (plain SGD
  * scatter-add, deterministic).  lr = 0 (the default) restores the reference's semantics.  D <= 64.  With a communicator
- * the table is replicated: the ranks exchange the union of touched ids and the exact sum of their row gradients. */
+ * the table is replicated and the row gradients take a bucketed exchange: owner = id % world, all-to-all
+ * of the deduplicated (id, fixed-point row) pairs, exact owner-side sums, all-gather of (id, delta) -- traffic
+ * proportional to the ids the batches touch; the replicas stay bit-identical. */
 int goctr_model_set_embedding_training(goctr_model* m, double lr);
+/* bytes this rank SENT in the last step's sparse-gradient exchange (ids + 64-bit fixed-point rows to their owners, then
+ * the owners' (id, delta) lists to every rank; self included); 0 without a communicator */
+int goctr_model_sparse_exchange_bytes(goctr_model* m, double* bytes);
 /* resets the Adam moments and the step counter (a fresh gorgonia AdamSolver, model.go:88) */
 int goctr_model_reset_optimizer(goctr_model* m);
 /* Optimizer state for checkpoint / resume ("dinModel JSON ... with optimizer state added for resume";

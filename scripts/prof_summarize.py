@@ -16,15 +16,21 @@ import os
 import shutil
 import sys
 
-SHORT = {"reduce_adam_kernel": "reduce", "attn_fwd_kernel": "attn_fwd", "ctr_chain_kernel": "chain", "attn_bwd_kernel": "attn_bwd",
-         "gemm_tn_multi_x3_kernel": "dW0", "gemm_tn_multi_kernel": "dW0", "ctr_fwd16_kernel": "fwd16", "reduce_kernel": "reduce", "adam_kernel": "adam",
-         "gemm_nn_kernel": "gemm_nn", "gemm_tn_kernel": "gemm_tn"}
+SHORT = {"reduce_adam_kernel": "reduce", "attn_fwd_kernel": "attn_fwd", "ctr_chain_x3_kernel": "chain", "ctr_chain_kernel": "chain",
+         "attn_bwd_kernel": "attn_bwd", "gemm_tn_multi_x3_kernel": "dW0", "gemm_tn_multi_kernel": "dW0", "ctr_fwd16_kernel": "fwd16",
+         "reduce_kernel": "reduce", "adam_kernel": "adam", "gemm_nn_kernel": "gemm_nn", "gemm_tn_kernel": "gemm_tn"}
 
 
 def short(name):
+    """bench.py's family name for the DIN / YouTube step kernels; any other kernel of the library keeps its own
+    function name (goctr::mlp_fwd_kernel<...>(...) -> mlp_fwd_kernel)"""
     for k, v in SHORT.items():
         if k in name:
             return v
+    import re
+    m = re.search(r"(?:goctr::)?([A-Za-z_][A-Za-z0-9_]*)\s*(?:<|\()", name.replace("void ", ""))
+    if m and ("goctr" in name or m.group(1).endswith("_kernel")):
+        return m.group(1)
     return None
 
 
@@ -32,11 +38,11 @@ def main():
     tag = sys.argv[1]
     src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/p"
     os.makedirs("profiles", exist_ok=True)
-    stats = glob.glob(f"{src}/kt/*/*_kernel_stats.csv")[0]
+    stats = (glob.glob(f"{src}/kt/*/*_kernel_stats.csv") + glob.glob(f"{src}/kt/**/*_kernel_stats.csv", recursive=True))[0]
     shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
     if os.path.exists(f"{src}/kt_bench.json"):
         shutil.copy(f"{src}/kt_bench.json", f"profiles/{tag}_bench_under_rocprof.json")
-    trace = glob.glob(f"{src}/kt/*/*_kernel_trace.csv")[0]
+    trace = (glob.glob(f"{src}/kt/*/*_kernel_trace.csv") + glob.glob(f"{src}/kt/**/*_kernel_trace.csv", recursive=True))[0]
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
         s = short(r["Kernel_Name"])
@@ -97,9 +103,34 @@ def main():
                              "1024 SIMDs) / (SQ_BUSY_CYCLES / 32 SEs)", "per_launch": sq},
                   open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
         print(json.dumps({k: (v.get("mfma_busy_pct"), v.get("mfma_flops_f32"), v.get("kernel_cycles")) for k, v in sq.items()}))
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, GOCTR_NO_GRAPH=1), "
-                     "bench.py cfg3 training launches; FETCH_SIZE x2 (gfx950 correction), KiB -> bytes",
-           "per_launch": traffic}
+    # L2 pass: hit rate per kernel (MI355X_MICROARCH.md "L2": TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum))
+    l2f = glob.glob(f"{src}/l2/*/*_counter_collection.csv")
+    if l2f:
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(l2f[0])):
+            sname = short(r["Kernel_Name"])
+            if sname:
+                acc[(sname, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for (sname, g), v in acc.items():
+            if g != max(gg for (ss, gg) in acc if ss == sname):
+                continue
+            hit, miss = (sum(v.get(c, [0.0])) / max(1, len(v.get(c, [0.0]))) for c in ("TCC_HIT_sum", "TCC_MISS_sum"))
+            t = traffic.setdefault(sname, {})
+            t["l2_hits"], t["l2_misses"] = hit, miss
+            t["l2_hit_rate"] = round(hit / (hit + miss), 4) if hit + miss > 0 else None
+    # durations next to the byte counts, so that a reader (bench.py) can turn them into GB/s without the trace file
+    for sname, lst in grids.items():
+        if sname in traffic:
+            traffic[sname]["avg_us_rocprof"] = round(max(lst)[1], 3)     # the largest grid = the training launch
+    import subprocess
+    try:
+        head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        head = None
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, GOCTR_NO_GRAPH=1: eager steps), training "
+                     "launches (largest grid of each kernel); FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md 'HBM'), KiB -> "
+                     "bytes; l2_* from a --pmc TCC_HIT_sum TCC_MISS_sum pass",
+           "commit": head, "per_launch": traffic}
     json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
     print(open(f"profiles/{tag}_kernel_trace_by_grid.txt").read())
     print(json.dumps({k: round(v["hbm_bytes"] / 1e6, 2) for k, v in traffic.items()}))

@@ -208,40 +208,98 @@ def _emb_worker(rank, world, port, out):
     m = _emb_model(pyoracle, Ue, Te, De, Ce)
     n = Bg // world
     sl = slice(rank * n, (rank + 1) * n)
-    # the device's exchange (csrc/emb_train.h + launch_emb_train): marks -> MAX, slots = exclusive scan of the union,
-    # row gradients scaled by 1/B_global, accumulated in 2^-44 fixed point -> integer SUM
+    W, r = world, rank
+    # The device's bucketed exchange (csrc/emb_train.h + ctr.hip launch_emb_exchange), step by step in numpy:
+    #  0. local row gradients scaled by 1/B_global, 2^-44 fixed point, one accumulator row per touched id
     _, dE = m.emb_loss_grad(E, ub[sl], items[sl], uf[sl], cf[sl], y[sl])             # mean over n local rows
     dE = dE * (n / Bg)
-    mark = torch.from_numpy((np.abs(dE).sum(axis=1) > 0).astype(np.int32))
-    local_touched = mark.clone()
-    dist.all_reduce(mark, op=dist.ReduceOp.MAX)
-    slot = np.cumsum(mark.numpy()) - mark.numpy()
-    n_union = int(mark.sum())
-    acc = np.zeros((n_union, De), np.int64)
-    for i in np.nonzero(local_touched.numpy())[0]:
-        acc[slot[i]] = np.rint(dE[i] * 2.0 ** 44).astype(np.int64)
-    t = torch.from_numpy(acc)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    upd = np.zeros_like(E)
-    upd[np.nonzero(mark.numpy())[0]] = t.numpy().astype(np.float64) * 2.0 ** -44
-    if rank == 0:
-        out.put(upd)
+    ids_b = np.concatenate([ub[sl].ravel(), items[sl]])
+    touched = np.unique(ids_b[(ids_b >= 0) & (ids_b < V)])
+    #  1. owner-major numbering: pidx(id) = (id % W) * Vw + id / W; slots = touched ids in ascending pidx order, so the
+    #     rows for owner o are one contiguous range
+    Vw = -(-(-(-V // W)) // 4) * 4
+    pidx = (touched % W) * Vw + touched // W
+    order = np.argsort(pidx, kind="stable")
+    slot_id = touched[order]
+    accum = np.rint(dE[slot_id] * 2.0 ** 44).astype(np.int64)
+    off = np.searchsorted(slot_id % W, np.arange(W + 1), side="left")             # emb_bucket_bounds_kernel
+    cnt = np.diff(off).astype(np.int32)
+    assert np.all(np.diff(slot_id % W) >= 0) and all(np.all(np.diff(slot_id[off[o]:off[o + 1]]) > 0) for o in range(W))
+    #  2. counts all-gather, then all-to-all-v of (ids, rows) to the owners
+    allcnt = [torch.zeros(W, dtype=torch.int32) for _ in range(W)]
+    dist.all_gather(allcnt, torch.from_numpy(cnt))
+    allcnt = np.stack([t.numpy() for t in allcnt])                                   # [src][owner]
+    send_ids = [torch.from_numpy(slot_id[off[o]:off[o + 1]].astype(np.int32).copy()) for o in range(W)]
+    send_rows = [torch.from_numpy(accum[off[o]:off[o + 1]].copy()) for o in range(W)]
+    recv_ids = [torch.zeros(int(allcnt[s_, r]), dtype=torch.int32) for s_ in range(W)]
+    recv_rows = [torch.zeros((int(allcnt[s_, r]), De), dtype=torch.int64) for s_ in range(W)]
+    reqs = []
+    for p in range(W):                                    # gloo has no all_to_all: pairwise isend / irecv (self: copy)
+        if p == r:
+            recv_ids[r].copy_(send_ids[r]); recv_rows[r].copy_(send_rows[r])
+            continue
+        reqs += [dist.isend(send_ids[p], p, tag=1), dist.isend(send_rows[p], p, tag=2),
+                 dist.irecv(recv_ids[p], p, tag=1), dist.irecv(recv_rows[p], p, tag=2)]
+    for q in reqs:
+        q.wait()
+    rids = np.concatenate([t.numpy() for t in recv_ids]).astype(np.int64)
+    rrows = np.concatenate([t.numpy() for t in recv_rows]) if rids.size else np.zeros((0, De), np.int64)
+    assert np.all(rids % W == r)
+    #  3. owner: unique ids of my bucket in ascending order (the bucket scan), exact integer sums, delta = lr * float(sum)
+    red_ids = np.unique(rids)
+    red = np.zeros((red_ids.size, De), np.int64)
+    np.add.at(red, np.searchsorted(red_ids, rids), rrows)
+    lr = np.float32(0.05)
+    delta = (lr * (red.astype(np.float64) * 2.0 ** -44).astype(np.float32)).astype(np.float32)
+    #  4. all-gather of (ids, deltas); every replica applies every delta
+    nred = [torch.zeros(1, dtype=torch.int32) for _ in range(W)]
+    dist.all_gather(nred, torch.tensor([red_ids.size], dtype=torch.int32))
+    nred = [int(t.item()) for t in nred]
+    g_ids, g_delta = [], []
+    for s_ in range(W):
+        ti = torch.from_numpy(red_ids.astype(np.int32).copy()) if s_ == r else torch.zeros(nred[s_], dtype=torch.int32)
+        td = torch.from_numpy(delta.copy()) if s_ == r else torch.zeros((nred[s_], De), dtype=torch.float32)
+        dist.broadcast(ti, src=s_)
+        dist.broadcast(td, src=s_)
+        g_ids.append(ti.numpy()); g_delta.append(td.numpy())
+    g_ids = np.concatenate(g_ids); g_delta = np.concatenate(g_delta)
+    assert np.unique(g_ids).size == g_ids.size               # every id has exactly one owner
+    E32 = E.astype(np.float32)
+    new = E32.copy()
+    new[g_ids] = E32[g_ids] - g_delta
+    sent = float(sum(int(cnt[o]) * (4 + 8 * De) for o in range(W)) + W * red_ids.size * (4 + 4 * De))
+    out.put((rank, new, float(lr), sent))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_embedding_sparse_exchange_world2(oracle):
+@pytest.mark.parametrize("world", [2, 4])
+def test_embedding_sparse_exchange_bucketed(oracle, world):
+    """owner = id % world, all-to-all of the deduplicated (id, fixed-point row) pairs, exact
+    owner-side sums, all-gather of (id, delta): every replica ends up with the SAME bits, equal to one SGD step on the
+    full batch's oracle gradient up to the 2^-44 rounding of each rank's contribution"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_emb_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_emb_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    upd = q.get(timeout=120)
+    got = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     Bg, Ue, Te, De, Ce, V, ub, items, uf, cf, y, E = _emb_case()
     _, full = _emb_model(oracle, Ue, Te, De, Ce).emb_loss_grad(E, ub, items, uf, cf, y)
     assert np.abs(full).max() > 1e-4
-    assert np.abs(upd - full).max() <= 2.0 ** -43 * 2 + 1e-12      # exact up to the fixed-point rounding of each rank
+    tables = {r: t for r, t, _, _ in got}
+    lr = got[0][2]
+    for r in range(1, world):
+        assert np.array_equal(tables[0], tables[r])                                   # replicas bit-identical
+    want = E.astype(np.float32).astype(np.float64) - lr * full
+    # per element: world contributions rounded to 2^-44 each, one float32 rounding of the delta, one of the subtraction
+    assert np.abs(tables[0] - want).max() <= lr * (world * 2.0 ** -44 + 2.0 ** -23 * np.abs(full).max()) + 2.0 ** -23 * np.abs(want).max()
+    touched = np.unique(np.concatenate([ub.ravel(), items]))
+    touched = touched[touched >= 0]
+    untouched = np.setdiff1d(np.arange(V), touched)
+    assert np.array_equal(tables[0][untouched], E.astype(np.float32)[untouched])     # untouched rows keep their bits
+    assert all(s > 0 for _, _, _, s in got)

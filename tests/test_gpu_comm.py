@@ -168,15 +168,21 @@ gm.train_steps(m, ds, cfg, 5, emb=tab)
 capi.sync()
 out = np.concatenate([m.get_weights(n).ravel() for n in ("mlp0", "mlp1", "mlp2", "att0")] + [tab.get_rows().ravel()])
 np.save(%(out)r, out)
+nb = m.sparse_exchange_bytes()
+# the last step's batch touches n ids: n x (4 + 8 D) bytes to the owner + n x (4 + 4 D) gathered back (world 1: all to self)
+ids = np.concatenate([ub[0:512].ravel(), it[0:512]])           # (5 steps over 4 batches: the last one is batch 0 again)
+n = np.unique(ids[ids >= 0]).size
+assert nb == (n * (4 + 8 * D) + n * (4 + 4 * D) if %(comm)d else 0), (nb, n)
 if %(comm)d:
     capi.check(L.goctr_comm_destroy())
 '''
 
 
 def test_embedding_training_exchange_one_rank(tmp_path):
-    """the sparse embedding exchange (ncclAllReduce MAX over the touched-id marks, ncclAllReduce SUM over the int64
-    fixed-point accumulators, eager steps) with a one-rank communicator: both collectives are the identity and the sum
-    is an integer sum, so table and weights must equal the single-GPU graph-replayed run bit for bit"""
+    """the bucketed sparse embedding exchange (counts all-gather, grouped ncclSend / ncclRecv of (id, fixed-point row) pairs to
+    the owners, owner-side integer sums, all-gather of (id, delta); eager steps) with a one-rank communicator: every
+    transfer is a self send and the sums are integer sums, so table and weights must equal the single-GPU graph-replayed
+    run bit for bit; the bytes the exchange reports are exactly the touched ids' payload"""
     res = []
     for comm in (0, 1):
         out = str(tmp_path / f"emb_{comm}.npy")
