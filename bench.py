@@ -320,8 +320,9 @@ def bench_mlp(args):
 
 def bench_item2vec(args):
     """BASELINE configs[4] / SURVEY 8(d) cfg5: SkipGram + hierarchical softmax, window 5, D = 16 float64, V = 10 681,
-    Zipf(1.0) 10^7-word corpus resident in HBM; a step = one pass over the corpus (Hogwild kernel, 32768 streams =
-    305-word slices; the reference slices the corpus over runtime.NumCPU() goroutines, options.go:41)."""
+    Zipf(1.0) 10^7-word corpus resident in HBM; a step = one pass over the corpus (Hogwild kernel: the doc is cut into 16
+    slices like the reference cuts it over runtime.NumCPU() goroutines, options.go:41 -- windows are clipped at those
+    16 ends only -- and every slice is walked by 2048 lane groups, 32768 workers in all)."""
     from goctr_amd import capi, embedding as ge
     capi.init(0)
     V, dim, n, streams = 10681, 16, 10_000_000, 32768
@@ -330,7 +331,7 @@ def bench_item2vec(args):
     p /= p.sum()
     doc = rng.choice(V, size=n, p=p).astype(np.int32)
     counts = np.bincount(doc, minlength=V) + 1
-    m = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=False, streams=streams)
+    m = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=False, streams=streams, slices=16)
     m.create(counts)
     m.upload_doc(doc)
     steps, warm = max(1, args.steps // 20), max(1, args.warmup // 20)
@@ -348,7 +349,8 @@ def bench_item2vec(args):
            "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4]: SkipGram+HS, window 5, D=16, V=10681, Zipf(1.0), 10^7-word corpus "
-                                  "resident in HBM, one pass per step, Hogwild (32768 streams)", "parallelism": "dp1"},
+                                  "resident in HBM, one pass per step, Hogwild: 16 slices (window clipping as in the reference) x "
+                                  "2048 workers, hot rows cached in LDS and averaged, cold rows device-scope atomics", "parallelism": "dp1"},
            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "kernel": "w2v_hogwild_kernel"}}
     # The updater is a read-modify-write walk over 2.7 MB of parameters: they live in L2 (hit rate in the PMC summary), so

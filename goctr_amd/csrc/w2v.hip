@@ -12,8 +12,12 @@
 //                  is summed in the reference's j = 0..dim-1 order (v_readlane broadcast) so every float64
 //                  is bit-identical to a single-goroutine run of the reference algorithm.
 //   hogwild        `streams` lane-groups (dim rounded up to a power of two lanes each) walk contiguous
-//                  slices of the doc concurrently and update the shared vectors without synchronisation,
-//                  exactly the reference's goroutine scheme (word2vec.go:151-175) with ~10^4 "goroutines".
+//                  pieces of the doc concurrently and update the shared vectors without synchronisation:
+//                  the reference's goroutine scheme (word2vec.go:151-175) with ~10^4 "goroutines".  The doc
+//                  is cut into `slices` (IndexPerThread, the reference: runtime.NumCPU() of them) and every
+//                  slice is shared by streams / slices workers: a worker's windows reach into its
+//                  neighbours' pieces and are clipped only at the SLICE ends (quirk Q18), so the number of
+//                  clipped windows is the reference's whatever parallelism the GPU needs.
 //                  The learning-rate observer is replaced by a per-stream estimate of the global word
 //                  count (no per-word channel send / atomic).
 #include <algorithm>
@@ -63,23 +67,36 @@ __device__ __forceinline__ double seq_sum(double v, int dim) {
   return s;
 }
 
+// Hogwild's shared vectors are read and updated by workgroups on all 8 XCDs, whose L2s are not coherent with each other
+// (MI355X_MICROARCH.md "Correctness boundaries"): a plain load keeps hitting the XCD's own stale line for as long as the
+// 2.7 MB of parameters stay L2-resident (= the whole pass), and a plain read-modify-write store loses every update that
+// raced with it.  So: device-scope loads (sc1) and device-scope atomic adds -- an update is never lost, and a reader sees
+// what the other XCDs have contributed so far, which is what the reference's goroutines get from a coherent CPU cache.
+__device__ __forceinline__ double hog_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hog_add(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// the deterministic single-wavefront pass keeps plain accesses (one wavefront, program order: bit-exact vs the oracle)
+template <bool HOG> __device__ __forceinline__ double w2v_ld(const double* p) { return HOG ? hog_load(p) : *p; }
+template <bool HOG> __device__ __forceinline__ void w2v_upd(double* p, double old, double delta) {
+  if (HOG) hog_add(p, delta); else *p = old + delta;
+}
+
 // One optimizer call (optimizer.go:52-91 / :107-129) for the lane that owns component l of the vectors:
 // ctx = that component of the input vector, tmp accumulates the component of the input's update.
 // `sum` is the inner-product reduction (sequential for the deterministic mode, butterfly for Hogwild).
-template <class Sum>
+template <bool HOG, class Sum>
 __device__ __forceinline__ void w2v_optim(const W2vDev& a, const double* tab, int id, double lr, double ctx, double& tmp,
                                           unsigned long long& next, bool act, int l, Sum sum) {
   const int dim = a.dim;
   if (a.optimizer == 0) {
     for (long long i = a.path_off[id]; i < a.path_off[id + 1]; ++i) {
       double* pvp = a.aux + (long long)a.path_nodes[i] * dim + l;
-      double pv = act ? *pvp : 0.0;
+      const double pv = act ? w2v_ld<HOG>(pvp) : 0.0;
       const double inner = sum(ctx * pv);
       if (inner <= -6.0 || inner >= 6.0) break;  // quirk Q13: `return`
       const double g = (1.0 - (double)a.path_codes[i] - sig_lookup(tab, inner)) * lr;
       tmp += g * pv;
-      pv += g * ctx;
-      if (act) *pvp = pv;
+      if (act) w2v_upd<HOG>(pvp, pv, g * ctx);
     }
   } else {
     for (int n = -1; n < a.neg; ++n) {
@@ -91,15 +108,14 @@ __device__ __forceinline__ void w2v_optim(const W2vDev& a, const double* tab, in
         if (id == picked) continue;
       }
       double* rp = a.aux + (long long)picked * dim + l;
-      double rnd = act ? *rp : 0.0;
+      const double rnd = act ? w2v_ld<HOG>(rp) : 0.0;
       const double inner = sum(rnd * ctx);
       double g;
       if (inner <= -6.0) g = ((double)(label - 0)) * lr;
       else if (inner >= 6.0) g = ((double)(label - 1)) * lr;
       else g = ((double)label - sig_lookup(tab, inner)) * lr;
       tmp += g * rnd;
-      rnd += g * ctx;
-      if (act) *rp = rnd;
+      if (act) w2v_upd<HOG>(rp, rnd, g * ctx);
     }
   }
 }
@@ -107,25 +123,28 @@ __device__ __forceinline__ void w2v_optim(const W2vDev& a, const double* tab, in
 // cbow.trainOne (model.go:96-148): aggregate the window's vectors, one optimizer call on the aggregate, add its
 // update to every window vector.  The window shrink is drawn twice (once in the aggregate pass, once in the update
 // pass — `dowith` calls NextRandom each time), so the two passes may cover different windows.
-template <class Sum>
-__device__ __forceinline__ void w2v_cbow_one(const W2vDev& a, const double* tab, const int* doc, long long len, long long pos,
-                                             double lr, unsigned long long& next, bool act, int l, Sum sum) {
+template <bool HOG, class Sum>
+__device__ __forceinline__ void w2v_cbow_one(const W2vDev& a, const double* tab, const int* doc, long long cmin, long long cmax,
+                                             long long pos, double lr, unsigned long long& next, bool act, int l, Sum sum) {
   const int dim = a.dim, win = a.window;
   double agg = 0.0, tmp = 0.0;
   int del = lcg_next(next, win);
   for (int w = del; w < win * 2 + 1 - del; ++w) {
     if (w == win) continue;
     const long long c = pos - win + w;
-    if (c < 0 || c >= len) continue;
-    if (act) agg += a.param[(long long)doc[c] * dim + l];
+    if (c < cmin || c >= cmax) continue;
+    if (act) agg += w2v_ld<HOG>(a.param + (long long)doc[c] * dim + l);
   }
-  w2v_optim(a, tab, doc[pos], lr, agg, tmp, next, act, l, sum);
+  w2v_optim<HOG>(a, tab, doc[pos], lr, agg, tmp, next, act, l, sum);
   del = lcg_next(next, win);
   for (int w = del; w < win * 2 + 1 - del; ++w) {
     if (w == win) continue;
     const long long c = pos - win + w;
-    if (c < 0 || c >= len) continue;
-    if (act) a.param[(long long)doc[c] * dim + l] += tmp;   // a word twice in the window gets the update twice
+    if (c < cmin || c >= cmax) continue;
+    if (act) {   // a word twice in the window gets the update twice
+      double* wp = a.param + (long long)doc[c] * dim + l;
+      w2v_upd<HOG>(wp, HOG ? 0.0 : *wp, tmp);
+    }
   }
 }
 
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(64) void w2v_deterministic_kernel(W2vDev a) {
     const int id = a.doc[pos];
     if (a.model == 1) {
       if (!a.keep || a.keep[pos]) {
-        w2v_cbow_one(a, tab, a.doc, a.n_words, pos, lr, next, act, lane, [&](double v) { return seq_sum(v, dim); });
+        w2v_cbow_one<false>(a, tab, a.doc, 0, a.n_words, pos, lr, next, act, lane, [&](double v) { return seq_sum(v, dim); });
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       }
     } else if (!a.keep || a.keep[pos]) {
@@ -209,17 +228,84 @@ __device__ __forceinline__ double group_sum64(double v) {
   return v;
 }
 
-// ---- hogwild: one lane-group (GS lanes) per stream = per contiguous doc slice (IndexPerThread,
-// modelutil.go:32-41).  Window clipping is against the slice (quirk Q18).
+// ---- hogwild: one lane-group (GS lanes) per stream = per contiguous piece [slice_idx[g], slice_idx[g+1]) of the doc;
+// window clipping is against the SLICE (IndexPerThread, modelutil.go:32-41; quirk Q18) the piece belongs to,
+// [clip_lo[g], clip_hi[g]).
+//
+// Hot rows live in LDS.  Every update walks the Huffman path from the root, and item popularity is
+// Zipfian: the few hundred heaviest inner nodes and most frequent words take most of the read-modify-writes.  As
+// device-scope atomics on a handful of cache lines those serialise (measured: 4.3 M words/s with every access at device
+// scope); as plain stores they are lost (and stale: the XCDs' L2s are not coherent), which is what cost the first
+// version 5 % of HS loss against the oracle's 16-thread run.  So each workgroup keeps a private copy of the HOT_ROWS
+// heaviest node vectors and most frequent word vectors in LDS -- read and updated there by its 1024 / GS lane groups,
+// racing like the reference's goroutines do -- and every `merge_every` words folds its accumulated delta into the global
+// row (device-scope atomic add) and takes the other workgroups' contributions back (device-scope load).  The delta
+// enters scaled by 1 / workgroups, i.e. the replicas of a hot row are AVERAGED: summing them was measured to diverge
+// (HS loss 18 .. 680 instead of 0.56) -- a row that takes a share p of all updates sees  rate x p x latency  of them
+// concurrently, and SGD on one vector is only stable up to ~100 stale updates at lr 0.025; the root (p = 1) would need
+// 20 ns visibility.  Averaging costs the hot rows nothing they need (they see 10^5 .. 10^7 updates each) and measured
+// 0.565 vs the oracle's 0.559 (16 threads) at 10^7 words; cold rows -- few updates each, none to waste -- take the
+// exact path: device-scope load + atomic add straight to memory.
+constexpr int HOG_THREADS = 1024;
+constexpr int HOG_HOT_DOUBLES = 2048;     // doubles per cached table: 2 tables x (copy + base) x 16 KB + 8 KB sigmoid table = 72 KB
+
+struct HogHot {
+  const int* word_slot;     // [V] slot of a hot word in the LDS cache or -1
+  const int* word_id;       // [n_words_hot] slot -> word
+  int n_nodes, n_words;     // rows cached of aux (the LAST n_nodes rows = the heaviest Huffman nodes) and of param
+  long long node0;          // first cached aux row
+  int merge_every;          // words per lane group between merges
+  double merge_scale;       // a workgroup's delta enters the global row times this (1 / workgroups: the replicas are averaged)
+  long long max_len;        // longest piece (uniform loop bound: every thread meets every barrier)
+};
+
 template <int GS>
-__global__ __launch_bounds__(256) void w2v_hogwild_kernel(W2vDev a, int streams, const long long* slice_idx) {
+__global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, int streams, const long long* slice_idx, const long long* clip_lo,
+                                                                  const long long* clip_hi, HogHot hot) {
   __shared__ double tab[1000];
-  for (int i = threadIdx.x; i < 1000; i += 256) tab[i] = a.sigtab[i];
+  __shared__ double locN[HOG_HOT_DOUBLES], baseN[HOG_HOT_DOUBLES], locW[HOG_HOT_DOUBLES], baseW[HOG_HOT_DOUBLES];
+  const int dim = a.dim, win = a.window;
+  for (int i = threadIdx.x; i < 1000; i += HOG_THREADS) tab[i] = a.sigtab[i];
+  // fill the caches (row stride GS doubles)
+  for (int i = threadIdx.x; i < hot.n_nodes * GS; i += HOG_THREADS) {
+    const int r = i / GS, c = i % GS;
+    const double v = c < dim ? hog_load(a.aux + (hot.node0 + r) * dim + c) : 0.0;
+    locN[i] = v; baseN[i] = v;
+  }
+  for (int i = threadIdx.x; i < hot.n_words * GS; i += HOG_THREADS) {
+    const int r = i / GS, c = i % GS;
+    const double v = c < dim ? hog_load(a.param + (long long)hot.word_id[r] * dim + c) : 0.0;
+    locW[i] = v; baseW[i] = v;
+  }
   __syncthreads();
-  constexpr int GPB = 256 / GS;  // groups per block
+  // add this workgroup's delta to the global rows, take the others' contributions back
+  auto merge = [&]() {
+    __syncthreads();
+    for (int i = threadIdx.x; i < hot.n_nodes * GS; i += HOG_THREADS) {
+      const int r = i / GS, c = i % GS;
+      if (c < dim) {
+        double* gp = a.aux + (hot.node0 + r) * dim + c;
+        const double d = (locN[i] - baseN[i]) * hot.merge_scale;
+        if (d != 0.0) hog_add(gp, d);
+        const double v = hog_load(gp);
+        locN[i] = v; baseN[i] = v;
+      }
+    }
+    for (int i = threadIdx.x; i < hot.n_words * GS; i += HOG_THREADS) {
+      const int r = i / GS, c = i % GS;
+      if (c < dim) {
+        double* gp = a.param + (long long)hot.word_id[r] * dim + c;
+        const double d = (locW[i] - baseW[i]) * hot.merge_scale;
+        if (d != 0.0) hog_add(gp, d);
+        const double v = hog_load(gp);
+        locW[i] = v; baseW[i] = v;
+      }
+    }
+    __syncthreads();
+  };
+  constexpr int GPB = HOG_THREADS / GS;  // groups per block
   const int g = blockIdx.x * GPB + threadIdx.x / GS;
   const int l = threadIdx.x % GS;
-  const int dim = a.dim, win = a.window;
   const bool act = l < dim && g < streams;
   const int gs = g < streams ? g : streams - 1;
   const long long lo = slice_idx[gs], hi = g < streams ? slice_idx[gs + 1] : lo;  // idle groups run 0 words
@@ -229,69 +315,84 @@ __global__ __launch_bounds__(256) void w2v_hogwild_kernel(W2vDev a, int streams,
   long long cnt = 0;
   const int* doc = a.doc + lo;
   const long long len = hi - lo;
-  for (long long pos = 0; pos < len; ++pos) {
-    const int id = doc[pos];
-    if (a.model == 1) {
-      if (!a.keep || a.keep[lo + pos])
-        w2v_cbow_one(a, tab, doc, len, pos, lr, next, act, l, [&](double v) { return group_sum64<GS>(v); });
-    } else if (!a.keep || a.keep[lo + pos]) {
-      const int del = lcg_next(next, win);
-      for (int w = del; w < win * 2 + 1 - del; ++w) {
-        if (w == win) continue;
-        const long long c = pos - win + w;
-        if (c < 0 || c >= len) continue;
-        double* ctxp = a.param + (long long)doc[c] * dim + l;
-        double ctx = act ? *ctxp : 0.0, tmp = 0.0;
-        if (a.optimizer == 0) {
-          const long long p0 = a.path_off[id], p1 = a.path_off[id + 1];
-          double* pvp = p0 < p1 ? a.aux + (long long)a.path_nodes[p0] * dim + l : nullptr;
-          double pv = (act && pvp) ? *pvp : 0.0;
-          for (long long i = p0; i < p1; ++i) {
-            // prefetch the next node vector while this one is processed (the path is known up front)
-            double* nvp = i + 1 < p1 ? a.aux + (long long)a.path_nodes[i + 1] * dim + l : nullptr;
-            const double nv = (act && nvp) ? *nvp : 0.0;
-            const double inner = group_sum64<GS>(ctx * pv);
-            if (inner <= -6.0 || inner >= 6.0) break;
-            const double gg = (1.0 - (double)a.path_codes[i] - sig_lookup(tab, inner)) * lr;
-            tmp += gg * pv;
-            pv += gg * ctx;
-            if (act) *pvp = pv;
-            pvp = nvp; pv = nv;
-          }
-        } else {
-          for (int n = -1; n < a.neg; ++n) {
-            int label, picked;
-            if (n == -1) { label = 1; picked = id; }
-            else {
-              label = 0;
-              picked = lcg_next(next, (int)a.V);
-              if (id == picked) continue;
+  const long long cmin = clip_lo[gs] - lo, cmax = clip_hi[gs] - lo;   // window positions allowed, relative to this piece
+  // vector component l of a word / of an inner node (HS) -- LDS when hot, device-scope memory access otherwise
+  auto word_slot = [&](int id) { return hot.n_words ? hot.word_slot[id] : -1; };
+  auto ld_word = [&](int id, int slot) { return slot >= 0 ? locW[slot * GS + l] : hog_load(a.param + (long long)id * dim + l); };
+  auto add_word = [&](int id, int slot, double v) {
+    if (slot >= 0) locW[slot * GS + l] += v; else hog_add(a.param + (long long)id * dim + l, v);
+  };
+  auto ld_node = [&](int nd) {
+    return nd >= hot.node0 ? locN[(nd - (int)hot.node0) * GS + l] : hog_load(a.aux + (long long)nd * dim + l);
+  };
+  auto add_node = [&](int nd, double v) {
+    if (nd >= hot.node0) locN[(nd - (int)hot.node0) * GS + l] += v; else hog_add(a.aux + (long long)nd * dim + l, v);
+  };
+  for (long long pos = 0; pos < hot.max_len; ++pos) {
+    if (pos < len) {
+      const int id = doc[pos];
+      if (a.model == 1) {
+        if (!a.keep || a.keep[lo + pos])
+          w2v_cbow_one<true>(a, tab, doc, cmin, cmax, pos, lr, next, act, l, [&](double v) { return group_sum64<GS>(v); });
+      } else if (!a.keep || a.keep[lo + pos]) {
+        const int del = lcg_next(next, win);
+        for (int w = del; w < win * 2 + 1 - del; ++w) {
+          if (w == win) continue;
+          const long long c = pos - win + w;
+          if (c < cmin || c >= cmax) continue;
+          const int cid = doc[c];
+          const int cslot = word_slot(cid);
+          double ctx = act ? ld_word(cid, cslot) : 0.0, tmp = 0.0;
+          if (a.optimizer == 0) {
+            const long long p0 = a.path_off[id], p1 = a.path_off[id + 1];
+            int nd = p0 < p1 ? a.path_nodes[p0] : 0;
+            double pv = (act && p0 < p1) ? ld_node(nd) : 0.0;
+            for (long long i = p0; i < p1; ++i) {
+              // request the next node vector while this one is processed (the path is known up front)
+              const int nnd = i + 1 < p1 ? a.path_nodes[i + 1] : nd;
+              const double nv = (act && i + 1 < p1) ? ld_node(nnd) : 0.0;
+              const double inner = group_sum64<GS>(ctx * pv);
+              if (inner <= -6.0 || inner >= 6.0) break;
+              const double gg = (1.0 - (double)a.path_codes[i] - sig_lookup(tab, inner)) * lr;
+              tmp += gg * pv;
+              if (act) add_node(nd, gg * ctx);          // pv += g * ctx (optimizer.go:125)
+              nd = nnd; pv = nv;
             }
-            double* rp = a.aux + (long long)picked * dim + l;
-            double rnd = act ? *rp : 0.0;
-            const double inner = group_sum64<GS>(rnd * ctx);
-            double gg;
-            if (inner <= -6.0) gg = ((double)(label - 0)) * lr;
-            else if (inner >= 6.0) gg = ((double)(label - 1)) * lr;
-            else gg = ((double)label - sig_lookup(tab, inner)) * lr;
-            tmp += gg * rnd;
-            rnd += gg * ctx;
-            if (act) *rp = rnd;
+          } else {
+            for (int n = -1; n < a.neg; ++n) {
+              int label, picked;
+              if (n == -1) { label = 1; picked = id; }
+              else {
+                label = 0;
+                picked = lcg_next(next, (int)a.V);
+                if (id == picked) continue;
+              }
+              double* rp = a.aux + (long long)picked * dim + l;   // (negatives are uniform draws: no hot rows to cache)
+              double rnd = act ? hog_load(rp) : 0.0;
+              const double inner = group_sum64<GS>(rnd * ctx);
+              double gg;
+              if (inner <= -6.0) gg = ((double)(label - 0)) * lr;
+              else if (inner >= 6.0) gg = ((double)(label - 1)) * lr;
+              else gg = ((double)label - sig_lookup(tab, inner)) * lr;
+              tmp += gg * rnd;
+              if (act) hog_add(rp, gg * ctx);
+            }
           }
+          if (act) add_word(cid, cslot, tmp);            // ctx += tmp (model.go:74-76)
         }
-        ctx += tmp;
-        if (act) *ctxp = ctx;
+      }
+      ++cnt;
+      // observer estimate: all streams advance at the same rate => global count ~= cnt * streams
+      const long long est = cnt * (long long)streams, prev = (cnt - 1) * (long long)streams;
+      if (est / a.update_lr_batch != prev / a.update_lr_batch) {
+        const long long at = est / a.update_lr_batch * a.update_lr_batch;
+        if (lr < a.min_lr) lr = a.min_lr;
+        else lr = a.init_lr * (1.0 - (double)at / (double)a.corpus_len);
       }
     }
-    ++cnt;
-    // observer estimate: all streams advance at the same rate => global count ~= cnt * streams
-    const long long est = cnt * (long long)streams, prev = (cnt - 1) * (long long)streams;
-    if (est / a.update_lr_batch != prev / a.update_lr_batch) {
-      const long long at = est / a.update_lr_batch * a.update_lr_batch;
-      if (lr < a.min_lr) lr = a.min_lr;
-      else lr = a.init_lr * (1.0 - (double)at / (double)a.corpus_len);
-    }
+    if ((pos + 1) % hot.merge_every == 0) merge();
   }
+  merge();
   if (g == 0 && l == 0) *a.trained = a.n_words;
   if (g == streams - 1 && l == 0) *a.lr = lr;  // the lr the last words saw
 }
@@ -363,8 +464,10 @@ struct goctr_w2v {
   int64_t V = 0;
   int64_t aux_rows = 0;
   DevBuf<double> param, aux, sigtab, lr, snap_param, snap_aux;   // snap_*: the pass's starting point (multi-GPU exchange)
-  DevBuf<long long> path_off, trained, slice_idx;
-  DevBuf<int> path_nodes, doc;
+  DevBuf<long long> path_off, trained, slice_idx, clip_lo, clip_hi;
+  DevBuf<int> path_nodes, doc, hot_word_slot, hot_word_id;   // hot_*: the most frequent words, cached in LDS by the Hogwild kernel
+  int n_hot_words = 0;
+  std::vector<long long> h_counts;
   DevBuf<unsigned char> path_codes, keep;
   DevBuf<unsigned long long> lcg;
   std::vector<long long> h_off; std::vector<int> h_nodes; std::vector<unsigned char> h_codes;
@@ -420,6 +523,11 @@ int exchange_deltas(goctr_w2v* w) {
   return 0;
 }
 
+int env_int_w2v(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
 int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
   Engine& e = engine();
   GOCTR_CHECK(w->n_words > 0, "goctr_w2v: no doc uploaded");
@@ -445,13 +553,53 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
   } else {
     int streams = w->cfg.streams > 0 ? w->cfg.streams : 8192;
     if ((int64_t)streams > w->n_words) streams = (int)w->n_words;
-    // IndexPerThread (modelutil.go:32-41)
-    std::vector<long long> idx((size_t)streams + 1);
-    idx[0] = 0; idx[streams] = w->n_words;
-    for (int i = 1; i < streams; ++i) idx[i] = idx[i - 1] + (long long)std::trunc((double)((w->n_words + i) / streams));
+    // slices = the reference's goroutines (window-clipping units); 0: one slice per stream (every piece clips its own windows)
+    int slices = w->cfg.slices > 0 ? std::min(w->cfg.slices, streams) : streams;
+    const int per = streams / slices;                 // workers per slice (the last slice takes the remainder)
+    // IndexPerThread (modelutil.go:32-41) over the slices, then each slice cut evenly among its workers
+    std::vector<long long> sidx((size_t)slices + 1);
+    sidx[0] = 0; sidx[slices] = w->n_words;
+    for (int i = 1; i < slices; ++i) sidx[i] = sidx[i - 1] + (long long)std::trunc((double)((w->n_words + i) / slices));
+    std::vector<long long> idx((size_t)streams + 1), clo((size_t)streams), chi((size_t)streams);
+    int g = 0;
+    for (int sl = 0; sl < slices; ++sl) {
+      const int nw = sl + 1 < slices ? per : streams - g;
+      const long long a0 = sidx[sl], a1 = sidx[sl + 1];
+      for (int k = 0; k < nw; ++k, ++g) {
+        idx[g] = a0 + (a1 - a0) * k / nw;
+        clo[g] = a0; chi[g] = a1;
+      }
+    }
+    idx[streams] = w->n_words;
     if (w->slice_idx.alloc(idx.size(), false) || w->slice_idx.upload(idx.data(), idx.size())) return -1;
+    if (w->clip_lo.alloc(clo.size(), false) || w->clip_lo.upload(clo.data(), clo.size())) return -1;
+    if (w->clip_hi.alloc(chi.size(), false) || w->clip_hi.upload(chi.data(), chi.size())) return -1;
     const int dim = w->cfg.dim;
-#define GOCTR_HOG(GS) hipLaunchKernelGGL((w2v_hogwild_kernel<GS>), dim3((unsigned)cdiv(streams, 256 / GS)), dim3(256), 0, e.stream, a, streams, w->slice_idx.p)
+    const int GSr = dim <= 8 ? 8 : dim <= 16 ? 16 : dim <= 32 ? 32 : 64;
+    // hot rows cached in LDS per workgroup: the heaviest Huffman nodes are the LAST merges (weights are non-decreasing
+    // along the merge order), the hottest words the most frequent ones (ties: lower id first)
+    const int rows_cached = env_int_w2v("GOCTR_W2V_HOT", 1) ? HOG_HOT_DOUBLES / GSr : 0;
+    HogHot hot{};
+    hot.n_nodes = w->cfg.optimizer == 0 ? (int)std::min<int64_t>(rows_cached, w->aux_rows) : 0;
+    hot.node0 = w->aux_rows - hot.n_nodes;
+    if (w->n_hot_words != std::min<int64_t>(rows_cached, w->V) || !w->hot_word_slot.p) {
+      const int nh = (int)std::min<int64_t>(rows_cached, w->V);
+      std::vector<int> order((size_t)w->V), slot((size_t)w->V, -1), ids((size_t)std::max(nh, 1), 0);
+      std::iota(order.begin(), order.end(), 0);
+      if (!w->h_counts.empty())
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w->h_counts[x] > w->h_counts[y]; });
+      for (int k = 0; k < nh; ++k) { slot[order[k]] = k; ids[k] = order[k]; }
+      if (w->hot_word_slot.alloc(slot.size(), false) || w->hot_word_slot.upload(slot.data(), slot.size())) return -1;
+      if (w->hot_word_id.alloc(ids.size(), false) || w->hot_word_id.upload(ids.data(), ids.size())) return -1;
+      w->n_hot_words = nh;
+    }
+    hot.n_words = w->n_hot_words; hot.word_slot = w->hot_word_slot.p; hot.word_id = w->hot_word_id.p;
+    hot.merge_every = std::max(1, env_int_w2v("GOCTR_W2V_MERGE", 16));
+    const int nwg = (int)cdiv(streams, HOG_THREADS / GSr);
+    hot.merge_scale = env_int_w2v("GOCTR_W2V_AVG", 1) ? 1.0 / (double)nwg : 1.0;
+    hot.max_len = 0;
+    for (int k = 0; k < streams; ++k) hot.max_len = std::max(hot.max_len, idx[k + 1] - idx[k]);
+#define GOCTR_HOG(GS) hipLaunchKernelGGL((w2v_hogwild_kernel<GS>), dim3((unsigned)cdiv(streams, HOG_THREADS / GS)), dim3(HOG_THREADS), 0, e.stream, a, streams, w->slice_idx.p, w->clip_lo.p, w->clip_hi.p, hot)
     if (dim <= 8) GOCTR_HOG(8);
     else if (dim <= 16) GOCTR_HOG(16);
     else if (dim <= 32) GOCTR_HOG(32);
@@ -472,7 +620,7 @@ void goctr_w2v_cfg_default(goctr_w2v_cfg* c) {
   memset(c, 0, sizeof *c);  // options.go:38-58 + wordemb.go:10-18
   c->dim = 16; c->window = 5; c->optimizer = 0; c->model = 0; c->neg_samples = 5;
   c->init_lr = 0.025; c->min_lr = 0.025 * 1.0e-4; c->update_lr_batch = 100000; c->max_depth = 100;
-  c->deterministic = 0; c->streams = 8192;
+  c->deterministic = 0; c->streams = 8192; c->slices = 16;
 }
 
 int goctr_w2v_create(const goctr_w2v_cfg* cfg, int64_t V, const int64_t* counts, goctr_w2v** out) {
@@ -485,6 +633,7 @@ int goctr_w2v_create(const goctr_w2v_cfg* cfg, int64_t V, const int64_t* counts,
   std::unique_ptr<goctr_w2v> w(new goctr_w2v);
   w->cfg = *cfg; w->V = V;
   build_huffman(counts, V, cfg->max_depth, w->h_off, w->h_nodes, w->h_codes);
+  w->h_counts.assign(counts, counts + V);
   w->aux_rows = cfg->optimizer == 0 ? std::max<int64_t>(V - 1, 1) : V;
   if (w->param.alloc((size_t)V * cfg->dim) || w->aux.alloc((size_t)w->aux_rows * cfg->dim)) return -1;
   if (w->path_off.alloc(w->h_off.size(), false) || w->path_off.upload(w->h_off.data(), w->h_off.size())) return -1;

@@ -40,13 +40,14 @@ class Word2Vec:
     """embedding/model.Model (model/model.go:24-31) backed by the device engine."""
 
     def __init__(self, window=5, dim=16, iter=1, optimizer="hs", min_count=5, max_count=-1, init_lr=0.025,
-                 subsample_threshold=1e-3, deterministic=False, streams=8192, update_lr_batch=100000, rng=None,
+                 subsample_threshold=1e-3, deterministic=False, streams=8192, slices=16, update_lr_batch=100000, rng=None,
                  model="skipgram"):
         # options.go:38-58 defaults; wordemb.go:10-18 fixes SkipGram + HS + DocInMemory
         self.window, self.dim, self.iter, self.optimizer = window, dim, iter, optimizer
         self.min_count, self.max_count, self.init_lr = min_count, max_count, init_lr
         self.threshold = subsample_threshold
         self.deterministic, self.streams = deterministic, streams
+        self.slices = slices          # the reference's goroutine count (window-clipping units); workers = streams
         self.update_lr_batch = update_lr_batch
         self.model = model                                                  # options.go ModelType: skipgram | cbow
         self.rng = rng or np.random.default_rng()
@@ -77,7 +78,7 @@ class Word2Vec:
         c.model = 0 if self.model == "skipgram" else 1
         c.init_lr, c.min_lr = self.init_lr, self.init_lr * 1.0e-4           # options.go:42,49
         c.update_lr_batch = self.update_lr_batch
-        c.deterministic, c.streams = int(self.deterministic), self.streams
+        c.deterministic, c.streams, c.slices = int(self.deterministic), self.streams, self.slices
         return c
 
     def create(self, counts, param0=None, aux0=None):

@@ -277,7 +277,10 @@ typedef struct {
   int64_t update_lr_batch;    /* options.go:55 */
   int max_depth;              /* options.go:46 */
   int deterministic;     /* 1: single stream, bit-exact vs the oracle; 0: Hogwild over `streams` slices */
-  int streams;           /* Hogwild slices (the reference uses runtime.NumCPU(), options.go:41) */
+  int streams;           /* Hogwild workers: lane groups that walk the doc concurrently (the GPU needs ~10^4 of them) */
+  int slices;            /* the reference's goroutines (runtime.NumCPU(), options.go:41; default 16): the doc is cut into
+                            `slices` by IndexPerThread (modelutil.go:32-41) and windows are clipped at SLICE ends only
+                            (quirk Q18); every slice is shared by streams / slices workers.  0 = one slice per worker */
 } goctr_w2v_cfg;
 void goctr_w2v_cfg_default(goctr_w2v_cfg* c);
 /* counts [V] = dictionary cfs (dictionary.go:70-81); builds the Huffman tree on the host with the
