@@ -410,6 +410,7 @@ def bench_knn(args):
                         "frac": round(scan / HBM_PEAK_GBS, 4), "traffic": None,
                         "kernel": "knn_tile_kernel (algorithmic: every query scans V*D*8 bytes; the 128 MB table is MALL-resident "
                                   "across the 64 queries of a call)"}}
+    out["roofline"] = with_traffic(out["roofline"], "knn", "knn_tile_kernel", dt / steps * 1e3)
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         norms = np.sqrt((items * items).sum(1))
@@ -563,6 +564,10 @@ def main():
             rl["kernel"] = dom
             rl = with_traffic(rl, wl, dom, prof[dom][0] / prof[dom][1])
             rl["algorithmic_bytes"] = chain_algorithmic_bytes() if dom == "chain" and wl == "din" else None
+            rl["duration_basis"] = ("hipEvent pair around every launch of an eager re-run of the K steps (includes the launch gap: "
+                                    "reads ~2-3 us above rocprofv3's kernel duration)")
+            if rl.get("avg_us_rocprofv3"):      # the same work over rocprofv3's own average duration of that kernel (committed summary)
+                rl["frac_at_rocprofv3_duration"] = round(w / (rl["avg_us_rocprofv3"] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4)
             out["roofline"] = rl
             if "attn_fwd" in table:
                 # the gather against the HBM roof, MEMORY-SIDE: bytes the memory system served per launch (PMC) over the
