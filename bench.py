@@ -557,16 +557,28 @@ def main():
             capi.prof_enable(False)
             work = kernel_work()
             table = {k: {"avg_us": round(ms / n * 1e3, 2), "launches": n} for k, (ms, n) in prof.items() if n}
+            wl = "youtube" if c["KIND"] == "youtube" else "din"
+            if args.train_emb > 0:
+                wl += "emb"                      # profiles/r02_{dinemb,youtubeemb}_*: the same command with --train-emb
+                # algorithmic bytes of the sparse row update per launch: every (sample, slot) pair reads its row and the
+                # sample's dpv / gate terms and adds a D-wide int64 row; priced like the gather, on memory-side bytes
+                work["emb_grad"] = ("hbm", c["B"] * (c["T"] + 1) * (c["D"] * 4 + c["D"] * 8 + 4))
             dom = max((k for k in table if k in work), key=lambda k: prof[k][0])
             kind, w = work[dom]
-            wl = "youtube" if c["KIND"] == "youtube" else "din"
             rl = roofline_obj(kind, w, prof[dom][0] / prof[dom][1])
             rl["kernel"] = dom
-            rl = with_traffic(rl, wl, dom, prof[dom][0] / prof[dom][1])
+            rl = with_traffic(rl, wl, dom + "_kernel" if dom == "emb_grad" else dom, prof[dom][0] / prof[dom][1])
+            if dom == "emb_grad":
+                rl["algorithmic_GBs"] = rl["achieved"]
+                if rl.get("hbm_side_GBs"):
+                    rl["achieved"] = rl.pop("hbm_side_GBs")
+                    rl["frac"] = round(rl["achieved"] / HBM_PEAK_GBS, 4)
+                rl["note"] = ("sparse scatter-add: LDS-cached hot rows + 64-bit fixed-point atomics; contention- and issue-bound, "
+                              "not bandwidth-bound (DESIGN 4.10)")
             rl["algorithmic_bytes"] = chain_algorithmic_bytes() if dom == "chain" and wl == "din" else None
             rl["duration_basis"] = ("hipEvent pair around every launch of an eager re-run of the K steps (includes the launch gap: "
                                     "reads ~2-3 us above rocprofv3's kernel duration)")
-            if rl.get("avg_us_rocprofv3"):      # the same work over rocprofv3's own average duration of that kernel (committed summary)
+            if rl.get("avg_us_rocprofv3") and kind == "mfma":      # the same work over rocprofv3's own average duration of that kernel (committed summary)
                 rl["frac_at_rocprofv3_duration"] = round(w / (rl["avg_us_rocprofv3"] * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4)
             out["roofline"] = rl
             if "attn_fwd" in table:

@@ -42,6 +42,12 @@ struct StepGraph {
   // One captured step per ping-pong parity of the step state (a step reads slot p and writes slot p^1).
   // b[] only when a communicator splits the step (all-reduce between reduce and Adam).
   hipGraphExec_t a[2] = {nullptr, nullptr}, b[2] = {nullptr, nullptr};
+  // multi[p]: multi_steps (even) consecutive steps starting at parity p in ONE graph (single GPU): the boundary between
+  // two graph launches costs about two kernel-to-kernel edges; every per-step scalar is device state, so nothing else changes
+  // (built together with a[]: a first call in a timed region must not pay for a capture).  Two sizes, 8 and 2.
+  static constexpr int kMulti[2] = {8, 2};
+  hipGraphExec_t multi[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [size][parity]
+  bool multi_on = false;
   // cache key
   // (the captured launches bake in the dataset's / table's device pointers and row count: keyed on the handles'
   // generation ids, not their host addresses -- malloc readily hands a destroyed dataset's address to the next one)
@@ -51,8 +57,10 @@ struct StepGraph {
     for (int k = 0; k < 2; ++k) {
       if (a[k]) (void)hipGraphExecDestroy(a[k]);
       if (b[k]) (void)hipGraphExecDestroy(b[k]);
+      for (int z = 0; z < 2; ++z) { if (multi[z][k]) (void)hipGraphExecDestroy(multi[z][k]); multi[z][k] = nullptr; }
       a[k] = b[k] = nullptr;
     }
+    multi_on = false;
   }
 };
 
@@ -664,7 +672,6 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   }
   EpiStore sp{m->dpv.p, Np};
   if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
-  ProfScope ps(GOCTR_K_EMB_TRAIN);
   // attention modes: one 1024-thread workgroup per CU (~90 VGPRs allow no second one) with a <= 136 KB LDS cache of hot
   // rows; mean pooling fits two per CU (GOCTR_EMB_WGS=2, <= 72 KB each) but measured no faster (184 vs 178 us at cfg4)
   const int mode = c.kind != GOCTR_DIN ? 0 : (c.att == GOCTR_ATT_COSINE ? 1 : 2);
@@ -680,10 +687,14 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   // hot in a 10^7-row vocabulary too
   const bool cache = env_int("GOCTR_EMB_CACHE", 1) != 0;
   const dim3 gg = cache ? gb : dim3((unsigned)std::min<long long>(cdiv(B, EMB_GRAD_THREADS / 64), 8 * cus));
-  if (c.D <= 16) launch_emb_grad<16>(mode, cache, gg, lds, s, a, nslot);
-  else if (c.D <= 32) launch_emb_grad<32>(mode, cache, gg, lds, s, a, nslot);
-  else launch_emb_grad<64>(mode, cache, gg, lds, s, a, nslot);
+  {
+    ProfScope ps(GOCTR_K_EMB_GRAD);
+    if (c.D <= 16) launch_emb_grad<16>(mode, cache, gg, lds, s, a, nslot);
+    else if (c.D <= 32) launch_emb_grad<32>(mode, cache, gg, lds, s, a, nslot);
+    else launch_emb_grad<64>(mode, cache, gg, lds, s, a, nslot);
+  }
   if (e.comm_active()) return launch_emb_exchange(m, a);
+  ProfScope ps(GOCTR_K_EMB_TRAIN);
   hipLaunchKernelGGL(emb_apply_kernel, dim3((unsigned)std::min<long long>(cdiv(cap * c.D, 256), 16 * cus)), dim3(256), 0, s, a,
                      m->emb_slot_id.p, m->emb_total.p);
   GOCTR_HIP(hipGetLastError());
@@ -899,10 +910,47 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   return 0;
 }
 
+// kMulti[z] (even) consecutive steps starting at either parity as one graph each (no communicator: nothing splits the step)
+int build_multi_graphs(goctr_model* m, const RowSource& src, int B, const StepOpts& o) {
+  Engine& e = engine();
+  StepGraph& sg = m->graph;
+  const int stp_now = m->stp;
+  const bool fuse = env_int("GOCTR_FUSED_UPDATE", 1) != 0;
+  for (int z = 0; z < 2; ++z)
+    for (int par = 0; par < 2; ++par) {
+      m->stp = par;
+      hipGraph_t g = nullptr;
+      GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+      int rc = 0;
+      for (int k = 0; k < StepGraph::kMulti[z] && !rc; ++k) {   // launch_backward flips m->stp: the captured steps alternate
+        rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse);
+        if (!rc && !fuse) rc = launch_adam(m, B, *o.tc);
+      }
+      const hipError_t ce = hipStreamEndCapture(e.stream, &g);
+      m->stp = stp_now;
+      if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
+      GOCTR_HIP(ce);
+      GOCTR_HIP(hipGraphInstantiate(&sg.multi[z][par], g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+    }
+  sg.multi_on = true;
+  return 0;
+}
+
 int set_state(goctr_model* m, unsigned gstep, unsigned slot, long long batch_idx, long long n_batches) {
   StepState s{gstep, slot, batch_idx, n_batches};
   GOCTR_HIP(hipMemcpyAsync(m->st_cur(), &s, sizeof s, hipMemcpyHostToDevice, engine().stream));
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
+  return 0;
+}
+
+// point the running state at another batch of another dataset without a host round trip (gstep stays on the device)
+__global__ void step_state_retarget_kernel(StepState* st, long long batch_idx, long long n_batches) {
+  st->slot = 0; st->batch_idx = batch_idx; st->n_batches = n_batches;
+}
+int retarget_state(goctr_model* m, long long batch_idx, long long n_batches) {
+  hipLaunchKernelGGL(step_state_retarget_kernel, dim3(1), dim3(1), 0, engine().stream, m->st_cur(), batch_idx, n_batches);
+  GOCTR_HIP(hipGetLastError());
   return 0;
 }
 
@@ -949,7 +997,15 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
   const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0 && !(e.comm_active() && m->emb_lr > 0.f);
   if (use_graph) {
     if (!graph_matches(m->graph, d, emb, B, o) && build_graph(m, d, emb, src, B, o)) return -1;
-    for (int s = 0; s < n_steps; ++s) {
+    int s = 0;
+    if (!e.comm_active() && env_int("GOCTR_GRAPH_STEPS", 1) != 0) {
+      if (!m->graph.multi_on && build_multi_graphs(m, src, B, o)) return -1;
+      // (long graphs first: a short one in front was measured slower at 20 steps per call, 66 vs 63.5 us per step)
+      for (int z = 0; z < 2; ++z)            // even step counts: the parity is the same after each launch
+        for (; s + StepGraph::kMulti[z] <= n_steps; s += StepGraph::kMulti[z])
+          GOCTR_HIP(hipGraphLaunch(m->graph.multi[z][m->stp], e.stream));
+    }
+    for (; s < n_steps; ++s) {
       const int par = m->stp;
       GOCTR_HIP(hipGraphLaunch(m->graph.a[par], e.stream));
       m->stp ^= 1;
@@ -1459,10 +1515,8 @@ int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const go
   GOCTR_CHECK(n_steps <= COST_RING, "n_steps > %d per call", COST_RING);
   std::lock_guard<std::mutex> lk(m->mu);
   if (check_dataset(m, d, emb)) return -1;
-  StepState s;
-  if (get_state(m, &s)) return -1;
   const long long nb = cdiv(d->rows, cfg->batch);
-  if (set_state(m, s.gstep, 0, first_batch % nb, nb)) return -1;
+  if (retarget_state(m, first_batch % nb, nb)) return -1;      // no host synchronisation on this path
   if (run_steps(m, emb, d, cfg, n_steps)) return -1;
   if (costs) {
     GOCTR_HIP(hipStreamSynchronize(engine().stream));

@@ -44,7 +44,7 @@ int require_engine() {
 
 static const char* kNames[GOCTR_K_COUNT] = {
     "attn_fwd", "gemm_fwd0", "gemm_fwd1", "gemm_out", "bwd_dz1", "bwd_dz0", "bwd_dp",
-    "attn_bwd", "dW0", "dW1", "dW2", "reduce", "allreduce", "adam", "chain", "emb_train"};
+    "attn_bwd", "dW0", "dW1", "dW2", "reduce", "allreduce", "adam", "chain", "emb_train", "emb_grad"};
 
 ProfScope::ProfScope(int kernel_id) : id(kernel_id), on(engine().prof) {
   if (!on) return;

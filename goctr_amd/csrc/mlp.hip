@@ -144,6 +144,9 @@ struct MlpLayerDesc {
   long long poff;             // offset of [b | W] of this layer in the packed (reference) order
   const double* slabs; int nslabs;
   double* WT;                 // [upo][upi] transposed copy without the bias row
+  int coop;                   // single-output layer with many slabs (mlp_chain_kernel: one per 16 rows): the upo threads of
+                              // a parameter row split the slabs (thread c sums slabs c, c + upo, ...) and thread 0 adds
+                              // the upo partials in order
 };
 struct MlpReduceArgs {
   MlpLayerDesc L[7]; int nl;
@@ -218,6 +221,43 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     return;
   }
   double sq = 0;
+  double coop_sum = 0; bool coop_have = false;
+  if (a.mode == 0 || a.mode == 3) {
+    __shared__ double red2[256];
+    double part = 0; bool lead = false; int upo = 1;
+    if (idx < a.nflat) {
+      int l = 0;
+#pragma unroll
+      for (int k = 1; k < 7; ++k) if (k < a.nl && idx >= a.L[k].woff) l = k;
+      const MlpLayerDesc& d = a.L[l];
+      if (d.coop) {
+        const long long e = idx - d.woff;
+        const int r = (int)(e / d.upo), c = (int)(e - (long long)r * d.upo);
+        if (r <= d.fi) {
+          const size_t sstr = (size_t)d.upi;                     // dense slabs [slab][upi] of the single output column
+          const double* sp = d.slabs + r;
+          for (int j0 = c; j0 < d.nslabs; j0 += 16 * d.upo) {     // 16 loads in flight, summed in ascending order
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int j = j0 + u * d.upo;
+              const double x = sp[(size_t)(j < d.nslabs ? j : d.nslabs - 1) * sstr];   // unconditional load, clamped address
+              v[u] = j < d.nslabs ? x : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) part += v[u];
+          }
+          lead = c == 0; upo = d.upo;
+        }
+      }
+    }
+    red2[threadIdx.x] = part;
+    __syncthreads();
+    if (lead) {
+      for (int k = 0; k < upo; ++k) coop_sum += red2[threadIdx.x + k];
+      coop_have = true;
+    }
+  }
   if (a.mode == 2) {          // (re)build the partial sums of squares of the current weights
     if (idx < a.nflat) {
       int l = 0;
@@ -239,17 +279,20 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     const bool is_w = r < d.fi && c < d.fo, is_b = r == d.fi && c < d.fo;
     if (is_w || is_b) {
       double s = 0;
+      if (coop_have) s = coop_sum;
+      else
       if (a.mode != 1) {   // same left-to-right order as a plain loop, but 8 loads in flight at a time
         const size_t sstr = (size_t)d.upi * d.upo;
-        int j = 0;
-        for (; j + 8 <= d.nslabs; j += 8) {
-          double v[8];
+        for (int j0 = 0; j0 < d.nslabs; j0 += 48) {           // unconditional loads (clamped), all in flight at once
+          double v[48];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = d.slabs[(size_t)(j + u) * sstr + e];
+          for (int u = 0; u < 48; ++u) {
+            const int j = j0 + u;
+            v[u] = d.slabs[(size_t)(j < d.nslabs ? j : d.nslabs - 1) * sstr + e];
+          }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) s += v[u];
+          for (int u = 0; u < 48; ++u) s += (j0 + u < d.nslabs) ? v[u] : 0.0;
         }
-        for (; j < d.nslabs; ++j) s += d.slabs[(size_t)j * sstr + e];
       }
       const double w = a.W[idx];
       double g;
@@ -522,6 +565,268 @@ __global__ __launch_bounds__(256) void mlp_bwd_hidden_kernel(const double* __res
   }
 }
 
+// ---------------------------------------------------------------- the training step's row chain of a [F, H, 1] net
+// gather + widen (mlp.go:46-59) -> hidden layer -> output unit -> log-loss term -> delta -> hidden delta -> partial
+// gradient of the output unit's weights, ONE launch (was mlp_gather + mlp_fwd + mlp_bwd_hidden).  Everything after the
+// first product is local to a batch row once a workgroup owns ALL hidden columns of its rows, so:
+//   workgroup = 16 batch rows, wavefront g = hidden columns [32 g, 32 g + 32)  (ng = up1 / 32 wavefronts, <= 4);
+//   Z^T[h][row] on v_mfma_f64_16x16x4_f64 like mlp_fwd_kernel, but the whole first weight block (up0 x up1 doubles, 240 KB
+//   at cfg2) does not fit in LDS next to nothing, and with 16 rows per workgroup nothing is shared between wavefronts
+//   anyway: the A fragments stream L2 -> registers from the same image mlp_fwd_kernel copies to LDS (a lane's two
+//   16-byte reads per tile and chunk; 16 lanes = 256 contiguous bytes), six chunks ahead; the row's k-fragments come
+//   straight from the resident float32 rows through the permutation (one 16-byte load per 16-k chunk, widened in
+//   registers) and are written out once as the float64 operand A0 of the weight-gradient GEMM;
+//   the output pre-activation is summed over the wavefronts in LDS in the same fixed order as mlp_bwd_hidden_kernel
+//   does over zpart, so the two paths agree bit for bit on z, delta and the loss terms;
+//   dW2 leaves as ONE slab per workgroup (sum over its 16 rows, butterfly over the row lanes); mlp_reduce_update_kernel
+//   sums those with 16 threads per parameter (MlpLayerDesc::coop).
+// sum over the 16 lanes of a DPP row (the 16 batch rows of a tile), every lane gets it: VALU lane exchanges, two 32-bit
+// moves per step, instead of ds_bpermute round trips through the LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);   // row_half_mirror
+  v += dpp_f64<0x140>(v);   // row_mirror
+  return v;
+}
+
+struct MlpChainArgs {
+  const float* X; const float* Y; const int* perm;
+  const MlpState* st; MlpState* st_step; long long start_fixed; int use_state; int batch;
+  int n, F, up0, units1, up1, upL, act;
+  const double* W0img; const double* W2;
+  double* A0; double* D1; double* A2; double* D2; double* lossterm; double* slab1;
+  unsigned long long* dbg;    // GOCTR_MLP_DBG: cycle stamps of workgroup 0, [wave][5]
+};
+
+// NFULL >= 0: the number of full 16-k chunks of a row (F / 16) is a compile-time constant and the product loop is
+// straight-line code (no selects, no clamps, accumulators never leave the AGPRs); NFULL < 0: run-time loop, any F.
+template <int ACT, int NFULL>
+__global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainArgs a) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // rows of F floats are only 4-byte aligned
+  __shared__ double zp[4][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ng = (int)(blockDim.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  unsigned long long ts[5] = {0, 0, 0, 0, 0};
+  if (a.dbg) ts[0] = __builtin_amdgcn_s_memtime();
+  if (a.st_step && blockIdx.x == 0 && tid == 0) *a.st_step = *a.st;   // freeze the step's state (see mlp_gather_kernel)
+  const int F = a.F, up0 = a.up0, up1 = a.up1, upL = a.upL;
+  const int nch = up0 >> 4, nfull = F >> 4;        // chunks of 16 k; the last one holds the row's tail, the ones column, zeros
+  // the weight stream does not depend on the rows: its first R chunks are in flight while the state -> permutation -> row
+  // chain of dependent loads (three memory latencies) resolves
+  const double* wp = a.W0img + (size_t)g * up0 * 32 + ((size_t)q * 64 + i) * 2;   // (k/4 = 4c + q, plane 0, column i)
+  constexpr int R = 6;
+  f4u xr[R];
+  d2 wr[R][4];
+#pragma unroll
+  for (int c = 0; c < R; ++c) {
+    const int cw = c < nch ? c : nch - 1;
+    const double* w = wp + (size_t)cw * 512;
+    wr[c][0] = *reinterpret_cast<const d2*>(w); wr[c][1] = *reinterpret_cast<const d2*>(w + 64);
+    wr[c][2] = *reinterpret_cast<const d2*>(w + 32); wr[c][3] = *reinterpret_cast<const d2*>(w + 96);
+  }
+  double w2v[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 32 * g + 16 * t + q + 4 * r;
+      w2v[t][r] = a.W2[(size_t)(h < up1 ? h : up1 - 1) * upL];
+      w2v[t][r] = h < up1 ? w2v[t][r] : 0.0;
+    }
+  const long long start = a.use_state ? a.st->batch_idx * (long long)a.batch : a.start_fixed;
+  const int row = blockIdx.x * 16 + i;
+  const bool vrow = row < a.n;
+  const long long pos = start + (vrow ? row : a.n - 1);
+  const long long src = a.perm ? a.perm[pos] : pos;
+  const float* xrow = a.X + src * F;
+  const float* xp = nfull > 0 ? xrow + 4 * q : reinterpret_cast<const float*>(a.W0img);
+#pragma unroll
+  for (int c = 0; c < R; ++c) {
+    const int cx = c < nfull ? c : (nfull > 0 ? nfull - 1 : 0);
+    xr[c] = *reinterpret_cast<const f4u*>(xp + cx * 16);
+  }
+  // the tail chunk of the row: k < F from the row, k == F the ones column, zeros behind (unconditional loads, clamped)
+  double xt[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = nfull * 16 + 4 * q + e;
+    const float v = xrow[k < F ? k : F - 1];
+    xt[e] = k < F ? (double)v : (k == F ? 1.0 : 0.0);
+  }
+  const double yv = (double)a.Y[src];
+  d4 acc[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}}, acd[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+  if (a.dbg) ts[1] = __builtin_amdgcn_s_memtime();
+  if constexpr (NFULL >= 0) {
+    // f64 MFMAs do not overlap with other VALU work of the wavefront (DESIGN 4.1 measured the same for f32): every select,
+    // clamp and accumulator copy of the run-time loop below costs issue time on top of the 64 cycles per MFMA
+    constexpr int NCH = NFULL + 1;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int j = c % R;
+      d2 xa, xb;
+      if (c < NFULL) {
+        const f4u xf = xr[j];
+        xa.x = (double)xf.x; xa.y = (double)xf.y; xb.x = (double)xf.z; xb.y = (double)xf.w;
+      } else {
+        xa.x = xt[0]; xa.y = xt[1]; xb.x = xt[2]; xb.y = xt[3];
+      }
+      const d2 w0a = wr[j][0], w0b = wr[j][1], w1a = wr[j][2], w1b = wr[j][3];
+      if (c + R < NFULL) xr[j] = *reinterpret_cast<const f4u*>(xp + (c + R) * 16);
+      if (c + R < NCH) {
+        const double* w = wp + (size_t)(c + R) * 512;
+        wr[j][0] = *reinterpret_cast<const d2*>(w); wr[j][1] = *reinterpret_cast<const d2*>(w + 64);
+        wr[j][2] = *reinterpret_cast<const d2*>(w + 32); wr[j][3] = *reinterpret_cast<const d2*>(w + 96);
+      }
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0a.x, xa.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1a.x, xa.x, acc[1], 0, 0, 0);
+      acd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0b.x, xb.x, acd[0], 0, 0, 0);
+      acd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1b.x, xb.x, acd[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0a.y, xa.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1a.y, xa.y, acc[1], 0, 0, 0);
+      acd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0b.y, xb.y, acd[0], 0, 0, 0);
+      acd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1b.y, xb.y, acd[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);     // keep the refills where they are: hoisted, they would need a register per chunk
+    }
+  } else {
+  for (int c0 = 0; c0 < nch; c0 += R) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int c = c0 + j;
+      const bool full = c < nfull, tail = c == nfull;
+      const f4u xf = xr[j];
+      d2 xa, xb;
+      xa.x = full ? (double)xf.x : (tail ? xt[0] : 0.0); xa.y = full ? (double)xf.y : (tail ? xt[1] : 0.0);
+      xb.x = full ? (double)xf.z : (tail ? xt[2] : 0.0); xb.y = full ? (double)xf.w : (tail ? xt[3] : 0.0);
+      const d2 w0a = wr[j][0], w0b = wr[j][1], w1a = wr[j][2], w1b = wr[j][3];
+      {
+        int cx = c + R; cx = cx < nfull ? cx : (nfull > 0 ? nfull - 1 : 0);
+        xr[j] = *reinterpret_cast<const f4u*>(xp + cx * 16);
+        int cw = c + R; cw = cw < nch ? cw : nch - 1;
+        const double* w = wp + (size_t)cw * 512;
+        wr[j][0] = *reinterpret_cast<const d2*>(w); wr[j][1] = *reinterpret_cast<const d2*>(w + 64);
+        wr[j][2] = *reinterpret_cast<const d2*>(w + 32); wr[j][3] = *reinterpret_cast<const d2*>(w + 96);
+      }
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0a.x, xa.x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1a.x, xa.x, acc[1], 0, 0, 0);
+      acd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0b.x, xb.x, acd[0], 0, 0, 0);
+      acd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1b.x, xb.x, acd[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0a.y, xa.y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1a.y, xa.y, acc[1], 0, 0, 0);
+      acd[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w0b.y, xb.y, acd[0], 0, 0, 0);
+      acd[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w1b.y, xb.y, acd[1], 0, 0, 0);
+    }
+  }
+  }
+  acc[0] += acd[0]; acc[1] += acd[1];
+  if (a.dbg) ts[2] = __builtin_amdgcn_s_memtime();
+  // second read of the row for the A0 copy at the end (chunk c belongs to wavefront c % ng): issued here, consumed after the
+  // epilogue; the ring's registers are free now
+  constexpr int NS = 6;
+  f4u xs[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int c = g + k * ng;
+    xs[k] = *reinterpret_cast<const f4u*>(xp + (c < nfull ? c : (nfull > 0 ? nfull - 1 : 0)) * 16);
+  }
+  // accumulator of lane (row = i, q): Z[row][32 g + 16 t + q + 4 r]
+  double av[2][4];
+  double part = 0;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 32 * g + 16 * t + q + 4 * r;
+      double v = 0;
+      if (h < a.units1) v = act_fwd(ACT, acc[t][r]);
+      else if (h == a.units1) v = 1.0;
+      av[t][r] = v;
+      if (h < up1) part += v * w2v[t][r];
+    }
+  part += __shfl_xor(part, 16, 64);
+  part += __shfl_xor(part, 32, 64);
+  if (q == 0) zp[g][i] = part;
+  __syncthreads();
+  if (a.dbg) ts[3] = __builtin_amdgcn_s_memtime();
+  double z = 0;
+  for (int gg = 0; gg < ng; ++gg) z += zp[gg][i];
+  const double hh = 1 / (1 + exp(-z));
+  const double dl = vrow ? hh - yv : 0.0;
+  if (g == 0 && q == 0 && vrow) {
+    const double hmin = 4.9406564584124654e-324, hmax = 0.99999999999999989;  // Nextafter(0,1), Nextafter(1,0)
+    const double hc = hh < hmin ? hmin : (hh > hmax ? hmax : hh);
+    a.A2[(size_t)row * upL] = hh;
+    a.D2[(size_t)row * upL] = dl;
+    a.lossterm[(size_t)row * upL] = -yv * log(hc) - (1 - yv) * log1p(-hc);
+  }
+  double* slab = a.slab1 + (size_t)blockIdx.x * up1;       // dense: [workgroup][up1]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int h = 32 * g + 16 * t + q + 4 * r;
+      double d = 0;
+      if (h < a.units1) {
+        const double s = dl * w2v[t][r];
+        const double v = av[t][r];
+        switch (ACT) {
+          case GOCTR_ACT_LOGISTIC: d = s * (v * (1 - v)); break;
+          case GOCTR_ACT_TANH: d = s * (1 - v * v); break;
+          case GOCTR_ACT_RELU: d = v == 0 ? 0 : s; break;  // quirk Q12
+          default: d = s;
+        }
+      }
+      if (h < up1 && vrow) a.D1[(size_t)row * up1 + h] = d;
+      const double gsum = row16_sum(av[t][r] * dl);   // dW2[h] = sum_r A1[r][h] * delta[r]   (row `units1` = the intercept)
+      if (i == 0 && h < up1) slab[h] = gsum;
+    }
+  // the float64 operand A0 of the weight-gradient GEMM: chunk c of the row is written by wavefront c % ng from a second
+  // read of the row (L2 hits now).  Not inside the MFMA loop: guarded stores there cost accumulator copies (see
+  // mlp_fwd_kernel); not before it: the stores would wait for the row's first, cold reads
+  if (vrow) {
+    double* a0row = a.A0 + (size_t)row * up0 + 4 * q;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int c = g + k * ng;
+      if (c < nch) {
+        const bool full = c < nfull, tail = c == nfull;
+        d2 xa, xb;
+        xa.x = full ? (double)xs[k].x : (tail ? xt[0] : 0.0); xa.y = full ? (double)xs[k].y : (tail ? xt[1] : 0.0);
+        xb.x = full ? (double)xs[k].z : (tail ? xt[2] : 0.0); xb.y = full ? (double)xs[k].w : (tail ? xt[3] : 0.0);
+        *reinterpret_cast<d2*>(a0row + c * 16) = xa;
+        *reinterpret_cast<d2*>(a0row + c * 16 + 2) = xb;
+      }
+    }
+    for (int c = g + NS * ng; c < nch; c += ng) {
+      d2 xa, xb;
+      if (c < nfull) {
+        const f4u xf = *reinterpret_cast<const f4u*>(xp + c * 16);
+        xa.x = (double)xf.x; xa.y = (double)xf.y; xb.x = (double)xf.z; xb.y = (double)xf.w;
+      } else {
+        const bool tail = c == nfull;
+        xa.x = tail ? xt[0] : 0.0; xa.y = tail ? xt[1] : 0.0; xb.x = tail ? xt[2] : 0.0; xb.y = tail ? xt[3] : 0.0;
+      }
+      *reinterpret_cast<d2*>(a0row + c * 16) = xa;
+      *reinterpret_cast<d2*>(a0row + c * 16 + 2) = xb;
+    }
+  }
+  if (a.dbg && blockIdx.x == 0 && lane == 0) {
+    ts[4] = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < 5; ++k) a.dbg[g * 5 + k] = ts[k] - ts[0];
+  }
+}
+
 // ---------------------------------------------------------------- weight-gradient GEMM, float64 (csrc/mfma_gemm.h
 // gemm_tn_multi_kernel's design with v_mfma_f64_16x16x4_f64):  slab[k][n] = sum over the slab's rows m of
 // A[m][k] * D[m][n].  Workgroup = one block of 3 16-column tiles of A, all tiles of D (2 per wavefront), one slab of
@@ -737,6 +1042,9 @@ struct goctr_mlp {
   long long nflat = 0, nparams = 0;
   DevBuf<double> W, G, Mo, Vo, Vel, WT[7], bn[7];
   bool fused_fwd_done = false;
+  bool chain_done = false;       // the step's rows went through mlp_chain_kernel: D[1], D[2], lossterm and slabs[1] are ready
+  // mlp_chain_kernel: the [F, H, 1] shape of the fused forward, plus what the cooperative slab sum of the output layer needs
+  bool chain_ok() const { return fused_ok() && 256 % up[2] == 0 && woff[1] % up[2] == 0; }
   DevBuf<double> W0img, zpart;   // fused [F,H,1] forward: LDS image of the first weight block, per-group output partials
   bool fused_ok() const { return nl == 2 && units[2] == 1 && !cfg.batch_normalize && up[1] <= 128 && up[0] <= 16 * 24; }
   // batch workspace
@@ -746,8 +1054,9 @@ struct goctr_mlp {
   // resident rows
   DevBuf<float> Xr, Yr; int64_t rows = 0; DevBuf<int> perm;
   hipGraphExec_t step_graph = nullptr; int64_t step_graph_rows = 0; bool step_graph_perm = false;   // resident training step
+  hipGraphExec_t multi_graph[2] = {nullptr, nullptr};           // the same step captured 8 / 2 times back to back
   const void* step_graph_x = nullptr; const void* step_graph_y = nullptr; const void* step_graph_p = nullptr; const void* step_graph_w = nullptr;
-  ~goctr_mlp() { if (step_graph) (void)hipGraphExecDestroy(step_graph); }
+  ~goctr_mlp() { if (step_graph) (void)hipGraphExecDestroy(step_graph); for (auto g : multi_graph) if (g) (void)hipGraphExecDestroy(g); }
   std::mutex mu;
 };
 
@@ -780,8 +1089,11 @@ int ensure_ws(goctr_mlp* p, int n) {
     if (i > 0 && p->D[i].alloc((size_t)n * p->up[i])) return -1;
   }
   if (p->Yb.alloc((size_t)n * p->up[p->nl]) || p->lossterm.alloc((size_t)n * p->up[p->nl])) return -1;
-  for (int l = 0; l < p->nl; ++l)
-    if (p->slabs[l].alloc((size_t)p->S * p->up[l] * p->up[l + 1])) return -1;
+  for (int l = 0; l < p->nl; ++l) {
+    // mlp_chain_kernel leaves one slab of the output layer's gradient per 16 rows
+    const size_t ns = l == 1 && p->chain_ok() ? std::max<size_t>((size_t)p->S, (size_t)cdiv(n, 16)) : (size_t)p->S;
+    if (p->slabs[l].alloc(ns * p->up[l] * p->up[l + 1])) return -1;
+  }
   p->wsN = n;
   return 0;
 }
@@ -835,12 +1147,14 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   if (p->cfg.weight_decay > 0) {  // basemlp64.go:342-346 (applied before the forward pass by the caller order)
   }
   const int upL = p->up[L], no = p->units[L];
-  if (!p->fused_fwd_done)
+  const bool chain = p->chain_done;
+  p->chain_done = false;
+  if (!p->fused_fwd_done && !chain)
   hipLaunchKernelGGL(mlp_delta_last_kernel, dim3((unsigned)cdiv((int64_t)n * upL, 256)), dim3(256), 0, e.stream,
                      p->A[L].p, p->Yb.p, n, no, upL, p->D[L].p, p->lossterm.p);
   GOCTR_HIP(hipGetLastError());
-  const bool fused_bwd = p->fused_fwd_done && up1_le128(p);
-  if (fused_bwd) {
+  const bool fused_bwd = chain || (p->fused_fwd_done && up1_le128(p));
+  if (fused_bwd && !chain) {
     const int rows = tn_rows64(p, n);
     hipLaunchKernelGGL(mlp_bwd_hidden_kernel, dim3((unsigned)cdiv(n, rows), (unsigned)cdiv(p->up[1], 32)), dim3(256),
                        sizeof(double) * ((size_t)rows + 256), e.stream, p->A[1].p, p->D[2].p,
@@ -861,7 +1175,8 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   a.nl = L;
   for (int l = 0; l < L; ++l)
     a.L[l] = {p->units[l], p->units[l + 1], p->up[l], p->up[l + 1], p->woff[l], p->poff[l], p->slabs[l].p,
-              (int)cdiv(n, tn_rows64(p, n)), p->WT[l].p};
+              (int)cdiv(n, tn_rows64(p, n)), p->WT[l].p, 0};
+  if (chain) { a.L[1].nslabs = (int)cdiv(n, 16); a.L[1].coop = env_int_mlp("GOCTR_MLP_COOP", 1); }
   a.nflat = p->nflat; a.nparams = p->nparams;
   a.W = p->W.p; a.G = p->G.p; a.Mo = p->Mo.p; a.Vo = p->Vo.p; a.Vel = p->Vel.p;
   a.alpha = p->cfg.alpha; a.n = n; a.solver = p->cfg.solver; a.do_update = do_update ? 1 : 0;
@@ -897,7 +1212,7 @@ int refresh_sumsq(goctr_mlp* p, const MlpState* st) {
   MlpReduceArgs a{};
   a.nl = p->nl;
   for (int l = 0; l < p->nl; ++l)
-    a.L[l] = {p->units[l], p->units[l + 1], p->up[l], p->up[l + 1], p->woff[l], p->poff[l], nullptr, 0, nullptr};
+    a.L[l] = {p->units[l], p->units[l + 1], p->up[l], p->up[l + 1], p->woff[l], p->poff[l], nullptr, 0, nullptr, 0};
   a.nflat = p->nflat; a.nparams = p->nparams; a.W = p->W.p; a.st = st; a.sumsq_part = p->sumsq_part.p;
   a.mode = 2; a.nblk = (int)cdiv(p->nflat, 256);
   hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(a.nblk), dim3(256), 0, engine().stream, a);
@@ -930,6 +1245,16 @@ int set_mstate(goctr_mlp* p, long long t, long long b, long long nb, unsigned sl
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
   return p->W.p ? refresh_sumsq(p, p->st.p) : 0;   // the penalty sums live under the parity of t
 }
+__global__ void mlp_state_retarget_kernel(MlpState* st, MlpState* st_step, long long batch_idx, long long n_batches) {
+  st->batch_idx = batch_idx; st->n_batches = n_batches; st->slot = 0;
+  *st_step = *st;
+}
+// another batch cursor, same step counter (so the penalty sums keep their parity): no host round trip
+int retarget_mstate(goctr_mlp* p, long long b, long long nb) {
+  hipLaunchKernelGGL(mlp_state_retarget_kernel, dim3(1), dim3(1), 0, engine().stream, p->st.p, p->st_step.p, b, nb);
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
 int get_mstate(goctr_mlp* p, MlpState* s) {
   GOCTR_HIP(hipMemcpyAsync(s, p->st.p, sizeof *s, hipMemcpyDeviceToHost, engine().stream));
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
@@ -940,6 +1265,50 @@ int get_mstate(goctr_mlp* p, MlpState* s) {
 int train_step_resident(goctr_mlp* p, bool use_state, long long start) {
   const int B = p->cfg.batch, L = p->nl;
   if (weight_decay(p)) return -1;
+  if (p->chain_ok() && p->W0img.p && env_int_mlp("GOCTR_MLP_CHAIN", 1) != 0 && env_int_mlp("GOCTR_MLP_NO_FUSED", 0) == 0) {
+    MlpChainArgs c{};
+    c.X = p->Xr.p; c.Y = p->Yr.p; c.perm = p->perm.n > 1 ? p->perm.p : nullptr;
+    c.st = p->st.p; c.st_step = p->st_step.p; c.start_fixed = start; c.use_state = use_state ? 1 : 0; c.batch = B;
+    c.n = B; c.F = p->units[0]; c.up0 = p->up[0]; c.units1 = p->units[1]; c.up1 = p->up[1]; c.upL = p->up[2];
+    c.act = p->cfg.activation; c.W0img = p->W0img.p; c.W2 = p->W.p + p->woff[1];
+    c.A0 = p->A[0].p; c.D1 = p->D[1].p; c.A2 = p->A[2].p; c.D2 = p->D[2].p; c.lossterm = p->lossterm.p; c.slab1 = p->slabs[1].p;
+    const int ng = (int)cdiv(p->up[1], 32);
+    static DevBuf<unsigned long long> dbgb;
+    const bool dbg = env_int_mlp("GOCTR_MLP_DBG", 0) != 0;
+    if (dbg && !dbgb.p && dbgb.alloc(20)) return -1;
+    c.dbg = dbg ? dbgb.p : nullptr;
+    const dim3 cg((unsigned)cdiv(B, 16)), cb(64 * ng);
+    // F = 281 (BASELINE configs[1], the MovieLens feature row of example/movielens) gets the straight-line product loop
+    const bool s17 = (p->units[0] >> 4) == 17 && env_int_mlp("GOCTR_MLP_CHAIN_STATIC", 1) != 0;
+    switch (p->cfg.activation) {
+      case GOCTR_ACT_LOGISTIC:
+        if (s17) hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_LOGISTIC, 17>), cg, cb, 0, engine().stream, c);
+        else hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_LOGISTIC, -1>), cg, cb, 0, engine().stream, c);
+        break;
+      case GOCTR_ACT_TANH:
+        if (s17) hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_TANH, 17>), cg, cb, 0, engine().stream, c);
+        else hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_TANH, -1>), cg, cb, 0, engine().stream, c);
+        break;
+      case GOCTR_ACT_RELU:
+        if (s17) hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_RELU, 17>), cg, cb, 0, engine().stream, c);
+        else hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_RELU, -1>), cg, cb, 0, engine().stream, c);
+        break;
+      default:
+        if (s17) hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_IDENTITY, 17>), cg, cb, 0, engine().stream, c);
+        else hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_IDENTITY, -1>), cg, cb, 0, engine().stream, c);
+        break;
+    }
+    GOCTR_HIP(hipGetLastError());
+    if (dbg) {
+      unsigned long long h[20];
+      if (dbgb.download(h, 20)) return -1;
+      for (int w = 0; w < ng; ++w)
+        fprintf(stderr, "mlp_chain wave %d: prologue %llu, products %llu, activation + z exchange %llu, tail %llu cycles\n", w,
+                h[w * 5 + 1], h[w * 5 + 2] - h[w * 5 + 1], h[w * 5 + 3] - h[w * 5 + 2], h[w * 5 + 4] - h[w * 5 + 3]);
+    }
+    p->fused_fwd_done = false; p->chain_done = true;
+    return backward(p, B, true, true);
+  }
   hipLaunchKernelGGL(mlp_gather_kernel, dim3(B), dim3(256), 0, engine().stream, p->Xr.p, p->Yr.p,
                      p->perm.n > 1 ? p->perm.p : nullptr, p->st.p, start, use_state ? 1 : 0, B, p->units[0], p->up[0],
                      p->units[L], p->up[L], p->A[0].p, p->Yb.p, p->st_step.p);
@@ -1088,9 +1457,7 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
   std::lock_guard<std::mutex> lk(p->mu);
   const long long nb = p->rows / p->cfg.batch;
   GOCTR_CHECK(nb > 0, "fewer rows than one batch");
-  MlpState s;
-  if (get_mstate(p, &s)) return -1;
-  if (set_mstate(p, s.t, first_batch % nb, nb, 0)) return -1;
+  if (retarget_mstate(p, first_batch % nb, nb)) return -1;
   // every per-step scalar lives in the device MlpState, so one captured step replays for all of them
   Engine& e = engine();
   const bool use_graph = !e.prof && !e.comm_active() && env_int_mlp("GOCTR_NO_GRAPH", 0) == 0 && n_steps > 1;
@@ -1100,6 +1467,7 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
     if (!p->step_graph || p->step_graph_rows != p->rows || p->step_graph_perm != (p->perm.n > 1) ||
         p->step_graph_x != p->Xr.p || p->step_graph_y != p->Yr.p || p->step_graph_p != p->perm.p || p->step_graph_w != p->W0img.p) {
       if (p->step_graph) { (void)hipGraphExecDestroy(p->step_graph); p->step_graph = nullptr; }
+      for (auto& mg : p->multi_graph) { if (mg) (void)hipGraphExecDestroy(mg); mg = nullptr; }
       hipGraph_t g = nullptr;
       GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
       const int rc = train_step_resident(p, true, 0);
@@ -1111,7 +1479,29 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
       p->step_graph_rows = p->rows; p->step_graph_perm = p->perm.n > 1;
       p->step_graph_x = p->Xr.p; p->step_graph_y = p->Yr.p; p->step_graph_p = p->perm.p; p->step_graph_w = p->W0img.p;
     }
-    for (int i = 0; i < n_steps; ++i) GOCTR_HIP(hipGraphLaunch(p->step_graph, e.stream));
+    // every per-step scalar is device state, so a graph may as well hold several steps: one graph launch per 8 (2) steps
+    // instead of one per step (the boundary between two graph launches costs about two kernel-to-kernel edges inside one).
+    // Built with the single-step graph, so that a first call inside a timed region does not pay for a capture.
+    static const int kMulti[2] = {8, 2};
+    int i = 0;
+    if (env_int_mlp("GOCTR_MLP_GRAPH_STEPS", 1) != 0) {
+      for (int z = 0; z < 2; ++z) {
+        if (!p->multi_graph[z]) {
+          hipGraph_t g = nullptr;
+          GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+          int rc = 0;
+          for (int k = 0; k < kMulti[z] && !rc; ++k) rc = train_step_resident(p, true, 0);
+          const hipError_t ce = hipStreamEndCapture(e.stream, &g);
+          if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
+          GOCTR_HIP(ce);
+          GOCTR_HIP(hipGraphInstantiate(&p->multi_graph[z], g, nullptr, nullptr, 0));
+          (void)hipGraphDestroy(g);
+        }
+      }
+      for (int z = 0; z < 2; ++z)
+        for (; i + kMulti[z] <= n_steps; i += kMulti[z]) GOCTR_HIP(hipGraphLaunch(p->multi_graph[z], e.stream));
+    }
+    for (; i < n_steps; ++i) GOCTR_HIP(hipGraphLaunch(p->step_graph, e.stream));
     return 0;
   }
   for (int i = 0; i < n_steps; ++i)

@@ -218,7 +218,7 @@ int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int ba
  * While enabled the step runs eagerly (no hipGraph) with an event pair around every launch. */
 enum { GOCTR_K_ATTN_FWD = 0, GOCTR_K_GEMM_FWD0, GOCTR_K_GEMM_FWD1, GOCTR_K_GEMM_OUT, GOCTR_K_BWD_DZ1,
        GOCTR_K_BWD_DZ0, GOCTR_K_BWD_DP, GOCTR_K_ATTN_BWD, GOCTR_K_DW0, GOCTR_K_DW1, GOCTR_K_DW2,
-       GOCTR_K_REDUCE, GOCTR_K_ALLREDUCE, GOCTR_K_ADAM, GOCTR_K_CHAIN, GOCTR_K_EMB_TRAIN, GOCTR_K_COUNT };
+       GOCTR_K_REDUCE, GOCTR_K_ALLREDUCE, GOCTR_K_ADAM, GOCTR_K_CHAIN, GOCTR_K_EMB_TRAIN, GOCTR_K_EMB_GRAD, GOCTR_K_COUNT };
 int goctr_prof_enable(int on);
 int goctr_prof_reset(void);
 /* total milliseconds and launch count per kernel family since the last reset */
