@@ -288,20 +288,23 @@ def bench_mlp(args):
                       "global_batch": B, "parallelism": "dp1"},
            "roofline": {"bound": "mfma", "achieved": round(flops / (dt / args.steps) / 1e12, 3), "peak": FP64_MFMA_PEAK_TF,
                         "unit": "TFLOP/s", "frac": round(flops / (dt / args.steps) / 1e12 / FP64_MFMA_PEAK_TF, 4),
-                        "traffic": None, "kernel": "whole step (all launches; launch-latency bound at this size)"}}
-    # memory-side bytes of the step's five launches (PMC summary of this command), and the longest kernel on its own
-    per = {k: pmc_entry("mlp", k) for k in ("mlp_gather_kernel", "mlp_fwd_kernel", "mlp_bwd_hidden_kernel", "mlp_tn64_kernel",
-                                           "mlp_reduce_update_kernel")}
+                        "traffic": None, "kernel": "whole step (3 launches; latency-bound at this size: see dominant_kernel)"}}
+    # memory-side bytes of the step's three launches (PMC summary of this command), and the longest kernel on its own
+    names = ("mlp_chain_kernel", "mlp_tn64_kernel", "mlp_reduce_update_kernel")
+    per = {k: pmc_entry("mlp", k) for k in names}
     if all(per.values()):
         out["roofline"]["traffic"] = round(sum(v["hbm_bytes"] for v in per.values()))
-        out["roofline"]["traffic_source"] = per["mlp_fwd_kernel"]["source"]
-        out["roofline"]["traffic_commit"] = per["mlp_fwd_kernel"]["commit"]
+        out["roofline"]["traffic_source"] = per[names[0]]["source"]
+        out["roofline"]["traffic_commit"] = per[names[0]]["commit"]
         out["kernels_rocprofv3_us"] = {k: v.get("avg_us_rocprof") for k, v in per.items()}
-        tn = per["mlp_tn64_kernel"]
-        out["dominant_kernel"] = {"kernel": "mlp_tn64_kernel (weight-gradient GEMM, f64 MFMA)", "flops": 2.0 * B * (F + 1) * H,
-                                  "avg_us_rocprofv3": tn.get("avg_us_rocprof"),
-                                  "frac_of_f64_mfma_peak": round(2.0 * B * (F + 1) * H / (tn["avg_us_rocprof"] * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF, 4)
-                                  if tn.get("avg_us_rocprof") else None}
+        # both GEMM-carrying kernels do 2 B (F+1) H flops (the chain kernel: the hidden layer; tn64: its weight gradient)
+        gf = 2.0 * B * (F + 1) * H
+        dom = max(("mlp_chain_kernel", "mlp_tn64_kernel"), key=lambda k: per[k].get("avg_us_rocprof") or 0.0)
+        t = per[dom].get("avg_us_rocprof")
+        out["dominant_kernel"] = {"kernel": dom + (" (gather + hidden layer + output unit + deltas, f64 MFMA)" if dom == "mlp_chain_kernel"
+                                                   else " (weight-gradient GEMM, f64 MFMA)"),
+                                  "flops": gf, "avg_us_rocprofv3": t, "traffic": round(per[dom]["hbm_bytes"]),
+                                  "frac_of_f64_mfma_peak": round(gf / (t * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF, 4) if t else None}
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         cfg = pyoracle.mlp_cfg(units, "relu", alpha=1e-5)
@@ -526,9 +529,12 @@ def main():
                                 "BASELINE configs[2]: DIN cosine attention, T=50, D=16, U=52, C=53, vocab 26744, "
                                 "batch 8192 per GPU, id mode (keys + table resident in HBM)") +
                                (f"; Dropout({pdrop}) on both hidden layers like the reference" if cfg.dropout_mode else "; dropout OFF (experiment)"),
-                   "numerics": ("float32 in, float32 out; forward / backward-data GEMMs on v_mfma_f32_16x16x4_f32, weight-gradient GEMMs on "
-                                "the 6-product bf16 split with float32 accumulation (measured MORE accurate than the f32 MFMA: "
-                                "2.8e-8 vs 1.3e-7 of sum|ab|, scripts/ubench/bf16x3.hip; GOCTR_TN_F32=1 selects the f32 MFMA body)"),
+                   "numerics": ("float32 in, float32 out; every GEMM of the training step (layer chain and weight gradients) on the "
+                                "6-product bf16 split with float32 accumulation -- each float32 operand is the exact sum of three bf16 "
+                                "planes, a*b = hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid); measured MORE accurate than the "
+                                "f32 MFMA (2.8e-8 vs 1.3e-7 of sum|ab|, scripts/ubench/bf16x3.hip) and bounded in tests/ by the float32 "
+                                "oracle's own error against a float64 evaluation; predict runs on v_mfma_f32_16x16x4_f32 "
+                                "(GOCTR_CHAIN_X3=0 / GOCTR_TN_F32=1 select the f32 MFMA bodies for training too)"),
                    "global_batch": c["B"] * world, "parallelism": f"dp{world}", "resident_rows_per_gpu": args.rows},
         "recommend_qps": round(qps, 1), "recommend_batch": c["PRED_B"],
         "rccl_world": rccl_world, "per_rank_ms_per_step": per_rank_ms,

@@ -44,9 +44,10 @@ struct StepGraph {
   hipGraphExec_t a[2] = {nullptr, nullptr}, b[2] = {nullptr, nullptr};
   // multi[p]: multi_steps (even) consecutive steps starting at parity p in ONE graph (single GPU): the boundary between
   // two graph launches costs about two kernel-to-kernel edges; every per-step scalar is device state, so nothing else changes
-  // (built together with a[]: a first call in a timed region must not pay for a capture).  Two sizes, 8 and 2.
-  static constexpr int kMulti[2] = {8, 2};
-  hipGraphExec_t multi[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [size][parity]
+  // (built together with a[]: a first call in a timed region must not pay for a capture)
+  static constexpr int kNMulti = 3;
+  int kMulti[kNMulti] = {16, 4, 2};                                        // even, descending (GOCTR_GRAPH_SIZES=a,b,c: experiments)
+  hipGraphExec_t multi[kNMulti][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [size][parity]
   bool multi_on = false;
   // cache key
   // (the captured launches bake in the dataset's / table's device pointers and row count: keyed on the handles'
@@ -57,7 +58,7 @@ struct StepGraph {
     for (int k = 0; k < 2; ++k) {
       if (a[k]) (void)hipGraphExecDestroy(a[k]);
       if (b[k]) (void)hipGraphExecDestroy(b[k]);
-      for (int z = 0; z < 2; ++z) { if (multi[z][k]) (void)hipGraphExecDestroy(multi[z][k]); multi[z][k] = nullptr; }
+      for (int z = 0; z < kNMulti; ++z) { if (multi[z][k]) (void)hipGraphExecDestroy(multi[z][k]); multi[z][k] = nullptr; }
       a[k] = b[k] = nullptr;
     }
     multi_on = false;
@@ -916,13 +917,18 @@ int build_multi_graphs(goctr_model* m, const RowSource& src, int B, const StepOp
   StepGraph& sg = m->graph;
   const int stp_now = m->stp;
   const bool fuse = env_int("GOCTR_FUSED_UPDATE", 1) != 0;
-  for (int z = 0; z < 2; ++z)
-    for (int par = 0; par < 2; ++par) {
+  if (const char* v = getenv("GOCTR_GRAPH_SIZES")) {
+    int x[3] = {0, 0, 0};
+    if (sscanf(v, "%d,%d,%d", &x[0], &x[1], &x[2]) >= 1)
+      for (int z = 0; z < StepGraph::kNMulti; ++z) sg.kMulti[z] = x[z] & ~1;
+  }
+  for (int z = 0; z < StepGraph::kNMulti; ++z)
+    for (int par = 0; par < 2 && sg.kMulti[z] >= 2; ++par) {
       m->stp = par;
       hipGraph_t g = nullptr;
       GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
       int rc = 0;
-      for (int k = 0; k < StepGraph::kMulti[z] && !rc; ++k) {   // launch_backward flips m->stp: the captured steps alternate
+      for (int k = 0; k < sg.kMulti[z] && !rc; ++k) {   // launch_backward flips m->stp: the captured steps alternate
         rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse);
         if (!rc && !fuse) rc = launch_adam(m, B, *o.tc);
       }
@@ -1001,9 +1007,10 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
     if (!e.comm_active() && env_int("GOCTR_GRAPH_STEPS", 1) != 0) {
       if (!m->graph.multi_on && build_multi_graphs(m, src, B, o)) return -1;
       // (long graphs first: a short one in front was measured slower at 20 steps per call, 66 vs 63.5 us per step)
-      for (int z = 0; z < 2; ++z)            // even step counts: the parity is the same after each launch
-        for (; s + StepGraph::kMulti[z] <= n_steps; s += StepGraph::kMulti[z])
-          GOCTR_HIP(hipGraphLaunch(m->graph.multi[z][m->stp], e.stream));
+      for (int z = 0; z < StepGraph::kNMulti; ++z) {   // even step counts: the parity is the same after each launch
+        const int sz = m->graph.kMulti[z];
+        for (; sz >= 2 && s + sz <= n_steps; s += sz) GOCTR_HIP(hipGraphLaunch(m->graph.multi[z][m->stp], e.stream));
+      }
     }
     for (; s < n_steps; ++s) {
       const int par = m->stp;

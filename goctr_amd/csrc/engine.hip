@@ -172,6 +172,15 @@ int goctr_init(int device_ordinal) {
   GOCTR_CHECK(device_ordinal >= 0 && device_ordinal < n, "goctr_init: device %d out of range (have %d)", device_ordinal, n);
   if (e.inited && e.device == device_ordinal) return 0;
   GOCTR_HIP(hipSetDevice(device_ordinal));
+  {
+    // GOCTR_SYNC=spin|yield|block (experiments): how the host waits in goctr_sync / blocking copies
+    const char* sm = getenv("GOCTR_SYNC");
+    if (sm && *sm) {
+      const unsigned f = sm[0] == 's' ? hipDeviceScheduleSpin : (sm[0] == 'y' ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync);
+      (void)hipSetDeviceFlags(f);
+      (void)hipGetLastError();
+    }
+  }
   hipDeviceProp_t prop;
   GOCTR_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   GOCTR_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
