@@ -146,6 +146,47 @@ TnSchedule tn_schedule(const goctr_model* m, int B) {
   t.rows_light = round_up(rows * lf / 10, 4); t.S_light = (int)cdiv(B, t.rows_light);
   return t;
 }
+// The wide-block weight-gradient kernel (mfma_gemm.h, gemm_tn_multi_x3w_kernel): shapes it covers and its slab heights.
+// Workgroups of the two heavy problems stage different numbers of operand columns per chunk (the stagers bound the chunk
+// time), so each problem gets its own slab height, in whole 32-row chunks: the pair (c0, c1) that minimises the longest
+// workgroup subject to one workgroup per CU.
+struct TnWide { bool ok; int ktw0, kblocks0, nbt; int rows0, S0, rows1, S1, rowsL, SL; };
+TnWide tn_schedule_wide(const goctr_model* m, int B) {
+  TnWide w{};
+  const int kt0 = m->Ip / 16, nt = m->H1p / 16, kt1 = m->H2p / 16;
+  w.ok = (kt0 == 9 || kt0 == 15) && kt1 == 5 && nt > 8 && nt <= 16 && env_int("GOCTR_TN_WIDE", 1) != 0;
+  if (!w.ok) return w;
+  w.ktw0 = kt0 == 9 ? 9 : 8; w.kblocks0 = (int)cdiv(kt0, w.ktw0); w.nbt = (int)cdiv(nt, 2);
+  const int cols0 = w.ktw0 * 16 + w.nbt * 16, cols1 = kt1 * 16 + w.nbt * 16;
+  const int colsL = 16 + kt1 * 16;
+  const int blocks0 = w.kblocks0 * 2, blocks1 = 2, light = m->cfg.kind == GOCTR_DIN ? 2 : 1;
+  const int cus = engine().compute_units > 0 ? engine().compute_units : 256;
+  // cost of a workgroup in "staged columns": chunks x columns per chunk + a fixed part (start, first chunk, slab stores)
+  const int fix0 = env_int("GOCTR_TN_FIX0", 512), fix1 = env_int("GOCTR_TN_FIX1", 384), fixL = 384;
+  long best = -1; int bc0 = 0, bc1 = 0, brl = 0;
+  const int cmax = (int)cdiv(B, 32);
+  for (int c0 = 1; c0 <= cmax; ++c0)
+    for (int c1 = 1; c1 <= cmax; ++c1) {
+      long t = std::max((long)c0 * cols0 + fix0, (long)c1 * cols1 + fix1);
+      if (best >= 0 && t >= best) continue;
+      // the one-tile problems take what is left of the chip; their slab height follows
+      const long heavy = (long)blocks0 * cdiv(B, c0 * 32) + (long)blocks1 * cdiv(B, c1 * 32);
+      const long left = (cus - heavy) / light;
+      if (left < 1) continue;
+      const int rl = std::max(32, round_up((int)cdiv(B, left), 4));     // (the slab buffers hold ceil(B / 32) slabs)
+      t = std::max(t, (long)cdiv(rl, 32) * colsL + fixL);
+      if (best >= 0 && t >= best) continue;
+      best = t; bc0 = c0; bc1 = c1; brl = rl;
+    }
+  if (best < 0) { bc0 = bc1 = cmax; brl = B; }
+  if (env_int("GOCTR_TN_C0", 0) > 0) bc0 = env_int("GOCTR_TN_C0", 0);     // (experiments)
+  if (env_int("GOCTR_TN_C1", 0) > 0) bc1 = env_int("GOCTR_TN_C1", 0);
+  if (env_int("GOCTR_TN_RL", 0) > 0) brl = std::max(32, round_up(env_int("GOCTR_TN_RL", 0), 4));
+  w.rows0 = bc0 * 32; w.S0 = (int)cdiv(B, w.rows0);
+  w.rows1 = bc1 * 32; w.S1 = (int)cdiv(B, w.rows1);
+  w.rowsL = brl; w.SL = (int)cdiv(B, w.rowsL);
+  return w;
+}
 int tn_max_slabs(int B) { return (int)cdiv(B, 32); }
 
 int ensure_workspace(goctr_model* m, int B) {
@@ -281,7 +322,7 @@ int init_kernel_attrs() {
       allow_big_lds(emb_grad_kernel<32, 1, true>) || allow_big_lds(emb_grad_kernel<32, 2, true>) || allow_big_lds(emb_grad_kernel<64, 0, true>) || allow_big_lds(emb_grad_kernel<64, 1, true>) ||
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
-      allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
+      allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(gemm_tn_multi_x3w_kernel<9, 5>) || allow_big_lds(gemm_tn_multi_x3w_kernel<8, 5>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
       allow_big_lds(ctr_chain_x3_kernel<15>)) return -1;
   done = true;
   return 0;
@@ -743,7 +784,47 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   if (m->H2p / 16 > nt_max) nt_max = m->H2p / 16;
   if (c.kind == GOCTR_DIN && m->Tp / 16 > nt_max) nt_max = m->Tp / 16;
   const bool multi = nt_max <= 16 && gemm_tn_multi_fits<3, GOCTR_TN_CH>(nt_max) && env_int("GOCTR_NO_TNMULTI", 0) == 0;
-  if (multi) {
+  const TnWide tw = (multi && env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32) ? tn_schedule_wide(m, B) : TnWide{};
+  int S0 = S, S1 = S, SLx = SL;      // slabs per segment, for the reduce below
+  if (multi && tw.ok) {
+    TnMulti tm{};
+    tm.M = B; tm.np = 3;
+    const int b0 = tw.kblocks0 * 2 * tw.S0, b1 = 2 * tw.S1;
+    tm.p[0] = {m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, m->slabs0.p,
+               (unsigned long long)m->Ip * m->H1p, 0, m->H1p, 0, tw.rows0, tw.S0, 2, tw.nbt};
+    tm.p[1] = {m->dz1.p, m->H2p, m->H2p / 16, A0, m->H1p, m->H1p / 16, m->slabs1.p,
+               (unsigned long long)m->H1p * m->H2p, 1, m->H2p, b0, tw.rows1, tw.S1, 2, tw.nbt};
+    tm.p[2] = {m->dz2.p, 16, 1, A1, m->H2p, m->H2p / 16, m->slabs2.p, (unsigned long long)m->H2p * 16, 1, 16,
+               b0 + b1, tw.rowsL, tw.SL, 0, 0};
+    int nblk = b0 + b1 + tw.SL;
+    if (c.kind == GOCTR_DIN) {  // datt0 = ones^T . dgs  (column sums over the batch)
+      tm.p[3] = {m->ones16.p, 16, 1, m->attp.p, m->Tp, m->Tp / 16, m->slabs3.p, (unsigned long long)16 * m->Tp, 0, m->Tp,
+                 nblk, tw.rowsL, tw.SL, 0, 0};
+      tm.np = 4;
+      nblk += tw.SL;
+    }
+    static DevBuf<unsigned long long> tndbgw;
+    const bool dbg = env_int("GOCTR_TN_DBG", 0) != 0;
+    if (dbg && !tndbgw.p && tndbgw.alloc(16)) return -1;
+    tm.dbg = dbg ? tndbgw.p : nullptr;
+    {
+      ProfScope ps(GOCTR_K_DW0);
+      if (tw.ktw0 == 9)
+        hipLaunchKernelGGL((gemm_tn_multi_x3w_kernel<9, 5>), dim3((unsigned)nblk), dim3(512), gemm_tn_multi_x3w_lds_bytes<9>(), e.stream, tm);
+      else
+        hipLaunchKernelGGL((gemm_tn_multi_x3w_kernel<8, 5>), dim3((unsigned)nblk), dim3(512), gemm_tn_multi_x3w_lds_bytes<8>(), e.stream, tm);
+      GOCTR_HIP(hipGetLastError());
+    }
+    if (dbg) {
+      unsigned long long h[16];
+      if (tndbgw.download(h, 16)) return -1;
+      fprintf(stderr, "dW x3w (rows %d/%d/%d, %d workgroups) wg 0: multiplier wave: wait for chunk 0 %lld, in MFMA sections %lld, loop total %lld, "
+              "epilogue %lld | stager wave: first chunk %lld, staging sections %lld, total %lld, chunks %lld (s_memtime ticks)\n",
+              tw.rows0, tw.rows1, tw.rowsL, nblk, (long long)h[0], (long long)h[1], (long long)h[2], (long long)h[3], (long long)h[8],
+              (long long)h[9], (long long)h[10], (long long)h[11]);
+    }
+    S0 = tw.S0; S1 = tw.S1; SLx = tw.SL;
+  } else if (multi) {
     TnMulti tm{};
     tm.M = B; tm.np = 3;
     const int kb0 = (int)cdiv(m->Ip / 16, 3), kb1 = (int)cdiv(m->H2p / 16, 3), kb2 = 1;
@@ -802,12 +883,12 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   if (m->emb_lr > 0.f && launch_emb_train(m, src, B, st)) return -1;
 
   ReduceArgs ra{};
-  ra.seg[0] = {m->slabs0.p, S, (unsigned long long)m->Ip * m->H1p, 0, m->Ip * m->H1p};
-  ra.seg[1] = {m->slabs1.p, S, (unsigned long long)m->H1p * m->H2p, m->off1, m->H1p * m->H2p};
-  ra.seg[2] = {m->slabs2.p, multi ? SL : S, (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
+  ra.seg[0] = {m->slabs0.p, S0, (unsigned long long)m->Ip * m->H1p, 0, m->Ip * m->H1p};
+  ra.seg[1] = {m->slabs1.p, S1, (unsigned long long)m->H1p * m->H2p, m->off1, m->H1p * m->H2p};
+  ra.seg[2] = {m->slabs2.p, multi ? SLx : S, (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
   ra.nseg = 3;
   if (c.kind == GOCTR_DIN) {
-    ra.seg[3] = {m->slabs3.p, multi ? SL : S, (unsigned long long)16 * m->Tp, m->offa, m->Tp};
+    ra.seg[3] = {m->slabs3.p, multi ? SLx : S, (unsigned long long)16 * m->Tp, m->offa, m->Tp};
     ra.nseg = 4;
   }
   ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st_cur(); ra.st_out = m->st_next(); ra.advance = advance ? 1 : 0;

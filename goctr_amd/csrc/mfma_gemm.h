@@ -331,6 +331,8 @@ struct TnProblem {
   int first;   // first blockIdx.x of this problem; it owns kblocks*S blocks
   int rows;    // batch rows per workgroup (slab height) of this problem
   int S;       // slabs = ceil(M / rows)
+  int nnb;     // (x3 wide blocks) n-blocks per k-block: the D tiles are split into nnb groups of nbt tiles; 0 = one group
+  int nbt;
 };
 struct TnMulti { TnProblem p[4]; int np; int M; unsigned long long* dbg; };
 
@@ -537,15 +539,17 @@ __device__ __forceinline__ void tn_split3_pk(float x0, float x1, unsigned int& h
   lo = __builtin_bit_cast(unsigned int, __builtin_convertvector(tn_f2{s0, s1}, tn_bf2));
 }
 
+// (n0t, nb_t): the block's D tiles [n0t, n0t + nb_t), nb_t <= 4 * NTW.  KTW > 3 ("wide" blocks, round 2): the A fragments
+// of one tile at a time stream through registers (KTW * NTW * 8 accumulator registers leave no room for all of them).
 template <int KTW, int NTW>
-__device__ __forceinline__ void tn_multi_body_x3(const TnMulti& a, const TnProblem& P, int kb, int split, unsigned char* smem) {
+__device__ __forceinline__ void tn_multi_body_x3(const TnMulti& a, const TnProblem& P, int kb, int n0t, int nb_t, int split,
+                                                 unsigned char* smem) {
   typedef float acc_t __attribute__((ext_vector_type(4)));
   typedef float vec_t __attribute__((ext_vector_type(4)));
   constexpr int CH = 32, CHB = 40;        // rows per chunk; bf16 per LDS strip column
-  constexpr int MAXB = ((CH / 4) * (KTW * 4 + 16 * 4) + 255) / 256;
+  constexpr int MAXB = ((CH / 4) * (KTW * 4 + 4 * NTW * 4) + 255) / 256;
   const int kb0 = kb * KTW;
   int kb_t = P.KT - kb0; if (kb_t > KTW) kb_t = KTW;
-  const int nb_t = P.NT;
   const int Kc = kb_t * 16, Nc = nb_t * 16;
   const int kv = Kc >> 2, nv = Nc >> 2;
   // LDS (bf16 units): [buf][plane][col][CHB], A columns first (KTW*16 of them), then the D columns
@@ -578,7 +582,7 @@ __device__ __forceinline__ void tn_multi_body_x3(const TnMulti& a, const TnProbl
       const int bb = b - nA;
       const int cg = bb >> 3, r = bb & 7;
       rgv = r; ldv = P.ldd;
-      src = P.D + cg * 4;
+      src = P.D + n0t * 16 + cg * 4;
       lo = (KTW * 16 + cg * 4) * CHB + 4 * r;
     }
   };
@@ -693,44 +697,76 @@ __device__ __forceinline__ void tn_multi_body_x3(const TnMulti& a, const TnProbl
     unsigned long long t0 = 0;
     if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
     const __bf16* bs = base + (c & 1) * bufsz;
-    tn_bf8 av[3][KTW], dv[3][NTW];
+    if constexpr (KTW <= 3) {
+      tn_bf8 av[3][KTW], dv[3][NTW];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int e = 0; e < KTW; ++e) av[pl][e] = *reinterpret_cast<const tn_bf8*>(bs + pl * plane + aofs[e]);
+        for (int e = 0; e < KTW; ++e) av[pl][e] = *reinterpret_cast<const tn_bf8*>(bs + pl * plane + aofs[e]);
 #pragma unroll
-      for (int f = 0; f < NTW; ++f) dv[pl][f] = *reinterpret_cast<const tn_bf8*>(bs + pl * plane + dofs[f]);
-    }
-#pragma unroll
-    for (int e = 0; e < KTW; ++e)
-#pragma unroll
-      for (int f = 0; f < NTW; ++f) {
-        // smallest terms first inside the correction accumulator
-        ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2][e], dv[0][f], ac[e][f], 0, 0, 0);
-        ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][e], dv[2][f], ac[e][f], 0, 0, 0);
-        ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1][e], dv[1][f], ac[e][f], 0, 0, 0);
-        ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1][e], dv[0][f], ac[e][f], 0, 0, 0);
-        ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][e], dv[1][f], ac[e][f], 0, 0, 0);
-        ah[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][e], dv[0][f], ah[e][f], 0, 0, 0);
+        for (int f = 0; f < NTW; ++f) dv[pl][f] = *reinterpret_cast<const tn_bf8*>(bs + pl * plane + dofs[f]);
       }
+#pragma unroll
+      for (int e = 0; e < KTW; ++e)
+#pragma unroll
+        for (int f = 0; f < NTW; ++f) {
+          // smallest terms first inside the correction accumulator
+          ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2][e], dv[0][f], ac[e][f], 0, 0, 0);
+          ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][e], dv[2][f], ac[e][f], 0, 0, 0);
+          ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1][e], dv[1][f], ac[e][f], 0, 0, 0);
+          ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1][e], dv[0][f], ac[e][f], 0, 0, 0);
+          ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][e], dv[1][f], ac[e][f], 0, 0, 0);
+          ah[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0][e], dv[0][f], ah[e][f], 0, 0, 0);
+        }
+    } else {
+      tn_bf8 dv[3][NTW], av[3], an[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int f = 0; f < NTW; ++f) dv[pl][f] = *reinterpret_cast<const tn_bf8*>(bs + pl * plane + dofs[f]);
+        an[pl] = *reinterpret_cast<const tn_bf8*>(bs + pl * plane + aofs[0]);
+      }
+#pragma unroll
+      for (int e = 0; e < KTW; ++e) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          av[pl] = an[pl];
+          if (e + 1 < KTW) an[pl] = *reinterpret_cast<const tn_bf8*>(bs + pl * plane + aofs[e + 1]);   // the next tile's fragments
+        }
+#pragma unroll
+        for (int f = 0; f < NTW; ++f) {
+          ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[2], dv[0][f], ac[e][f], 0, 0, 0);
+          ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], dv[2][f], ac[e][f], 0, 0, 0);
+          ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], dv[1][f], ac[e][f], 0, 0, 0);
+          ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[1], dv[0][f], ac[e][f], 0, 0, 0);
+          ac[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], dv[1][f], ac[e][f], 0, 0, 0);
+          ah[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[0], dv[0][f], ah[e][f], 0, 0, 0);
+        }
+      }
+    }
     if (a.dbg) tCm += __builtin_amdgcn_s_memtime() - t0;
     __syncthreads();                                       // chunk c consumed, chunk c + 1 written
   }
   if (a.dbg) tC2 = __builtin_amdgcn_s_memtime();
 
+  // slab stores: wave-uniform base + 32-bit element offsets (a slab is < 2^31 bytes): one integer add per store instead of
+  // a 64-bit multiply-add chain (the epilogue of a 9 x 2-tile wavefront took 5.1 k cycles of address arithmetic)
   float* out = P.slabs + (size_t)split * P.slab_stride;
+  const unsigned ldo = (unsigned)P.ld_out;
+  const unsigned k0 = (unsigned)(kb0 * 16 + 4 * q), n0 = (unsigned)((n0t + nt0) * 16 + i);
+  const unsigned o_n = k0 * ldo + n0, o_t = n0 * ldo + k0;
 #pragma unroll
   for (int e = 0; e < KTW; ++e) {
 #pragma unroll
     for (int f = 0; f < NTW; ++f) {
       if (e < kb_t && f < ncnt) {
-        const int k = (kb0 + e) * 16 + 4 * q, n = (nt0 + f) * 16 + i;
         const acc_t v = ac[e][f] + ah[e][f];
         if (P.transpose_out) {
-          *reinterpret_cast<acc_t*>(out + (size_t)n * P.ld_out + k) = v;
+          *reinterpret_cast<acc_t*>(out + (o_t + (unsigned)(f * 16) * ldo + (unsigned)(e * 16))) = v;
         } else {
+          const unsigned o = o_n + (unsigned)(e * 16) * ldo + (unsigned)(f * 16);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) out[(size_t)(k + r) * P.ld_out + n] = v[r];
+          for (int r = 0; r < 4; ++r) out[o + (unsigned)r * ldo] = v[r];
         }
       }
     }
@@ -749,8 +785,35 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_x3_kernel(TnMulti a) {
   const TnProblem& P = a.p[pi];
   const int local = blockIdx.x - P.first;
   const int kb = local / P.S, split = local - kb * P.S;
-  if (P.KT == 1) tn_multi_body_x3<1, NTW>(a, P, kb, split, goctr_smem);
-  else tn_multi_body_x3<KTW, NTW>(a, P, kb, split, goctr_smem);
+  if (P.KT == 1) tn_multi_body_x3<1, NTW>(a, P, kb, 0, P.NT, split, goctr_smem);
+  else tn_multi_body_x3<KTW, NTW>(a, P, kb, 0, P.NT, split, goctr_smem);
+}
+
+// Round 2: wide blocks.  Problem 0 (dW0) takes ALL its A tiles (KTW0 = 9 DIN / 8 per k-block YouTube) and problem 1 (dW1,
+// posed transposed) all its KTW1 = 5 against HALF of the D tiles (two n-blocks of <= 8 tiles, 2 per multiplying wavefront):
+// per slab the workgroups stage 496 + 368 operand columns instead of 768 + 496 (every D column was staged once per
+// 3-tile k-block: dz0 three times, A0 twice), and the slabs of the two problems get their own heights so that the
+// differently sized blocks cost the same.  One-tile problems keep the <1, 4> body.
+template <int KTW0, int KTW1>
+__global__ __launch_bounds__(512) void gemm_tn_multi_x3w_kernel(TnMulti a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
+  int pi = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) if (k < a.np && (int)blockIdx.x >= a.p[k].first) pi = k;
+  const TnProblem& P = a.p[pi];
+  const int local = blockIdx.x - P.first;
+  const int blk = local / P.S, split = local - blk * P.S;
+  if (P.KT == 1) { tn_multi_body_x3<1, 4>(a, P, blk, 0, P.NT, split, goctr_smem); return; }
+  const int nnb = P.nnb > 0 ? P.nnb : 1;
+  const int kb = blk / nnb, nb = blk - kb * nnb;
+  const int n0t = nb * P.nbt;
+  int nb_t = P.NT - n0t; if (nb_t > P.nbt) nb_t = P.nbt;
+  if (pi == 0) tn_multi_body_x3<KTW0, 2>(a, P, kb, n0t, nb_t, split, goctr_smem);
+  else tn_multi_body_x3<KTW1, 2>(a, P, kb, n0t, nb_t, split, goctr_smem);
+}
+template <int KTW>
+inline size_t gemm_tn_multi_x3w_lds_bytes() {
+  return sizeof(__bf16) * 2 * 3 * 40 * (size_t)(KTW * 16 + 8 * 16);
 }
 template <int KTW>
 inline size_t gemm_tn_multi_x3_lds_bytes(int nt_max) {
