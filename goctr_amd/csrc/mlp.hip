@@ -834,8 +834,9 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainArgs a) {
 // clamped row, zeroed when written), transposes them in registers and writes the columns as 16-byte stores into
 // column-major LDS strips T[col][m] (stride CH + 2 doubles = 16 B mod 128 B); two ds_read_b128 then hold the 4
 // consecutive rows a lane feeds to 4 MFMAs.
-constexpr int TN64_CH = 32, TN64_CHS = TN64_CH + 2, TN64_KTW = 3, TN64_NTW = 2;
+constexpr int TN64_CH = 32, TN64_CHS = TN64_CH + 2, TN64_NTW = 2;
 
+template <int TN64_KTW>
 __global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restrict__ A, int lda, int KT,
                                                           const double* __restrict__ Dm, int ldd, int NT, int M, int rows,
                                                           double* __restrict__ slabs, size_t slab_stride) {
@@ -998,13 +999,22 @@ int launch_nn64(const double* A, int lda, const double* Bm, int ldb, int M, int 
   return 0;
 }
 
+// A tiles per workgroup of mlp_tn64_kernel: 3; GOCTR_MLP_TN_KTW=2 (78 KB of LDS: two workgroups fit a CU) exists for the
+// experiment "one workgroup's start-up, first loads and slab stores under the other's MFMAs" -- measured slower at cfg2
+// (45.4 vs 42.3 us per step with two per CU, 42.8 with one): co-resident f64-MFMA workgroups serialise
+int tn64_ktw() { return env_int_mlp("GOCTR_MLP_TN_KTW", 3) == 2 ? 2 : 3; }
 int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int NT, int M, int rows_per_wg,
                 double* slabs) {
   if (NT <= 8 && env_int_mlp("GOCTR_MLP_OLD_TN", 0) == 0) {
     const int Sn = (int)cdiv(M, rows_per_wg);
-    const size_t lds = sizeof(double) * 2 * TN64_CHS * (size_t)(TN64_KTW * 16 + NT * 16);
-    hipLaunchKernelGGL(mlp_tn64_kernel, dim3(Sn, (unsigned)cdiv(KT, TN64_KTW)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
-                       ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16);
+    const int ktw = tn64_ktw();
+    const size_t lds = sizeof(double) * 2 * TN64_CHS * (size_t)(ktw * 16 + NT * 16);
+    if (ktw == 2)
+      hipLaunchKernelGGL(mlp_tn64_kernel<2>, dim3(Sn, (unsigned)cdiv(KT, 2)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
+                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16);
+    else
+      hipLaunchKernelGGL(mlp_tn64_kernel<3>, dim3(Sn, (unsigned)cdiv(KT, 3)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
+                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16);
     GOCTR_HIP(hipGetLastError());
     return 0;
   }
@@ -1027,7 +1037,7 @@ int init_attrs64() {
   if (allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 1>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 2>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 4>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 1>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 2>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 4>) ||
-      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_tn64_kernel) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
+      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_tn64_kernel<3>) || allow_big_lds(mlp_tn64_kernel<2>) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
   done = true;
   return 0;
 }
@@ -1069,10 +1079,11 @@ int tn_rows64(const goctr_mlp* p, int n) {
   int kb = 1;   // workgroups per slab of the widest layer (see launch_tn64)
   for (int l = 0; l < p->nl; ++l) {
     const int KT = p->up[l] / 16, NT = p->up[l + 1] / 16;
-    const int k = NT <= 8 ? (int)cdiv(KT, 3) : (int)cdiv(KT, KT >= 6 ? 6 : 3) * (int)cdiv(NT, NT >= 3 ? 4 : 2);
+    const int k = NT <= 8 ? (int)cdiv(KT, tn64_ktw()) : (int)cdiv(KT, KT >= 6 ? 6 : 3) * (int)cdiv(NT, NT >= 3 ? 4 : 2);
     if (k > kb) kb = k;
   }
   int cus = engine().compute_units > 0 ? engine().compute_units : 256;
+  cus *= env_int_mlp("GOCTR_MLP_TN_WGS_PER_CU", 1);
   const int S = cus / kb > 0 ? cus / kb : 1;
   int rows = (int)cdiv(n, S);
   rows = rows < 32 ? 32 : round_up(rows, 2);

@@ -17,7 +17,7 @@ import shutil
 import sys
 
 SHORT = {"reduce_adam_kernel": "reduce", "attn_fwd_kernel": "attn_fwd", "ctr_chain_x3_kernel": "chain", "ctr_chain_kernel": "chain",
-         "attn_bwd_kernel": "attn_bwd", "gemm_tn_multi_x3_kernel": "dW0", "gemm_tn_multi_kernel": "dW0", "ctr_fwd16_kernel": "fwd16",
+         "attn_bwd_kernel": "attn_bwd", "gemm_tn_multi_x3w_kernel": "dW0", "gemm_tn_multi_x3_kernel": "dW0", "gemm_tn_multi_kernel": "dW0", "ctr_fwd16_kernel": "fwd16",
          "reduce_kernel": "reduce", "adam_kernel": "adam", "gemm_nn_kernel": "gemm_nn", "gemm_tn_kernel": "gemm_tn"}
 
 
@@ -38,11 +38,13 @@ def main():
     tag = sys.argv[1]
     src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/p"
     os.makedirs("profiles", exist_ok=True)
-    stats = (glob.glob(f"{src}/kt/*/*_kernel_stats.csv") + glob.glob(f"{src}/kt/**/*_kernel_stats.csv", recursive=True))[0]
+    # gpurun merges a call's files INTO gpurun_out/: an earlier run's CSVs (other pid prefix) may still lie beside the new ones
+    newest = lambda files: max(files, key=os.path.getmtime)
+    stats = newest(glob.glob(f"{src}/kt/*/*_kernel_stats.csv") + glob.glob(f"{src}/kt/**/*_kernel_stats.csv", recursive=True))
     shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
     if os.path.exists(f"{src}/kt_bench.json"):
         shutil.copy(f"{src}/kt_bench.json", f"profiles/{tag}_bench_under_rocprof.json")
-    trace = (glob.glob(f"{src}/kt/*/*_kernel_trace.csv") + glob.glob(f"{src}/kt/**/*_kernel_trace.csv", recursive=True))[0]
+    trace = newest(glob.glob(f"{src}/kt/*/*_kernel_trace.csv") + glob.glob(f"{src}/kt/**/*_kernel_trace.csv", recursive=True))
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(trace)):
         s = short(r["Kernel_Name"])
@@ -62,7 +64,7 @@ def main():
         if not files:
             continue
         acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(files[0])):
+        for r in csv.DictReader(open(newest(files))):
             s = short(r["Kernel_Name"])
             if s:
                 acc[(s, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
@@ -82,7 +84,7 @@ def main():
     sq = {}
     if sqf:
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(sqf[0])):
+        for r in csv.DictReader(open(newest(sqf))):
             sname = short(r["Kernel_Name"])
             if sname:
                 acc[(sname, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -107,7 +109,7 @@ def main():
     l2f = glob.glob(f"{src}/l2/*/*_counter_collection.csv")
     if l2f:
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(l2f[0])):
+        for r in csv.DictReader(open(newest(l2f))):
             sname = short(r["Kernel_Name"])
             if sname:
                 acc[(sname, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
