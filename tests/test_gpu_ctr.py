@@ -232,7 +232,8 @@ def test_id_mode_equals_dense_mode(oracle, kind):
     assert np.max(np.abs(costs - ref)) <= 5e-5
 
 
-def test_graph_replay_equals_eager(oracle):
+@pytest.mark.parametrize("steps", [7, 39])     # 4 + 2 + 1 and 16 + 16 + 4 + 2 + 1 steps per graph launch (ctr.hip run_steps)
+def test_graph_replay_equals_eager(oracle, steps):
     from goctr_amd import capi, model as gm
     U, T, D, Cc = 52, 10, 16, 53
     rng = np.random.default_rng(10)
@@ -243,7 +244,7 @@ def test_graph_replay_equals_eager(oracle):
         om, dm, si = pair(oracle, 0, U, T, D, Cc, np.random.default_rng(11), scale=0.15)
         ds = gm.Dataset.dense(X, Y, si)
         cfg = capi.default_train_cfg(batch=200, epochs=1, dropout_mode=0)
-        costs = gm.train_steps(dm, ds, cfg, 7, want_costs=True)
+        costs = gm.train_steps(dm, ds, cfg, steps, want_costs=True)
         res.append((costs, dm.get_weights("mlp0")))
     os.environ.pop("GOCTR_NO_GRAPH")
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])   # deterministic

@@ -140,6 +140,27 @@ def test_full_size_cfg2_properties():
     assert np.isfinite(l1) and l1 < l0
 
 
+def test_multi_step_graphs_equal_eager_steps():
+    """goctr_mlp_train_steps replays graphs of 8 / 2 / 1 steps; the same 27 steps launched kernel by kernel must leave the
+    same bits (both the straight-line F = 281 chain kernel and the run-time loop one)"""
+    import os
+    from goctr_amd import mlp as gmlp
+    for F, H, B in ((281, 100, 512), (37, 12, 96)):
+        rng = np.random.default_rng(16)
+        X, Y = make(rng, 8 * B, F)
+        res = []
+        for no_graph in ("0", "1"):
+            os.environ["GOCTR_NO_GRAPH"] = no_graph
+            clf = gmlp.MLPClassifier([H], "relu", "adam", 1e-5)
+            units = [F, H, 1]
+            clf.create(units, B, clf.init_params(units, np.random.default_rng(17)))
+            clf.upload(X, Y)
+            clf.train_steps(27)
+            res.append(clf.get_params())
+        os.environ.pop("GOCTR_NO_GRAPH")
+        assert np.array_equal(res[0], res[1])
+
+
 def test_reference_nn_forward_kat():
     """the reference-held 3-3-3 forward vector (nn/network_test.go:25-83, tests/golden/ref_kats.json) through the device
     MLP: units [3,3,3], relu hidden, logistic output = the KAT's ReLU and Sigmoid layers; float32 out (mlp.go:33-38)"""
