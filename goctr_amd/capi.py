@@ -150,7 +150,7 @@ def default_train_cfg(**kw) -> TrainCfg:
     return c
 
 
-PROF_COUNT = 16
+PROF_COUNT = 17          # GOCTR_K_COUNT (include/goctr.h)
 
 
 def prof_enable(on: bool):

@@ -144,3 +144,14 @@ def test_cpp_host_mirror_runs_on_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "epochs 5" in r.stdout and "n 118" in r.stdout
+
+
+def test_profiler_family_count_matches_the_header():
+    """capi.PROF_COUNT mirrors the GOCTR_K_* enum of include/goctr.h (a family added there must be visible to bench.py)"""
+    import re
+    from goctr_amd import capi
+    text = open(os.path.join(os.path.dirname(__file__), "..", "include", "goctr.h")).read()
+    m = re.search(r"enum\s*\{\s*(GOCTR_K_ATTN_FWD[^}]*GOCTR_K_COUNT)\s*\}", text, re.S)
+    assert m
+    names = [x.strip().split("=")[0].strip() for x in m.group(1).split(",") if x.strip()]
+    assert names[-1] == "GOCTR_K_COUNT" and capi.PROF_COUNT == len(names) - 1
