@@ -54,6 +54,7 @@ struct StepGraph {
   // generation ids, not their host addresses -- malloc readily hands a destroyed dataset's address to the next one)
   uint64_t ds = 0, emb = 0; int B = 0; int mode = 0; float p0 = 0, p1 = 0;
   uint32_t seed = 0; double lr = 0, l2 = 0, b1 = 0, b2 = 0, eps = 0; int flags = 0; int world = 1; bool comm = false;
+  bool pipelined = false;   // the captured steps are pipelined (StepOpts::pipelined): a replay needs h0 of its first step
   void destroy() {
     for (int k = 0; k < 2; ++k) {
       if (a[k]) (void)hipGraphExecDestroy(a[k]);
@@ -85,6 +86,7 @@ struct goctr_model {
   int wsB = 0, tnS = 0;
   DevBuf<float> h0, P0, A0, P1, A1, yhat, lossrow, dz2, dz1, dz0, dp, gate, wgt, slabs0, slabs1, slabs2, attp;
   DevBuf<float> mask0, mask1, slabs3, ones16;
+  DevBuf<unsigned int> ra_flag;   // pipelined steps: gstep + 1 of the last step whose att0 update is visible device-wide (reduce_attn_kernel)
   DevBuf<float> yall;          // scores of a whole predict call (one device-to-host copy at the end)
   DevBuf<StepState> st, pst;   // st: two ping-pong slots, stp = the one the next step reads
   int stp = 0;
@@ -206,6 +208,7 @@ int ensure_workspace(goctr_model* m, int B) {
   if (m->dp.alloc((size_t)B * m->Dp)) return -1;
   if (m->gate.alloc((size_t)B * m->cfg.T)) return -1;
   if (m->wgt.alloc((size_t)B * m->cfg.T)) return -1;
+  if (m->ra_flag.alloc(1)) return -1;
   if (m->slabs0.alloc((size_t)S * m->Ip * m->H1p)) return -1;
   if (m->slabs1.alloc((size_t)S * m->H1p * m->H2p)) return -1;
   if (m->slabs2.alloc((size_t)S * m->H2p * 16)) return -1;
@@ -413,6 +416,9 @@ struct StepOpts {
   bool update = true;       // false: stop after the reduce (parity entry)
   int drop_mode = 0; float p0 = 0, p1 = 0; uint32_t seed = 0;
   const goctr_train_cfg* tc = nullptr;
+  // pipelined steps (graph replay, single GPU): a step's h0 was computed by the PREVIOUS step's last launch
+  // (reduce_attn_kernel, ctr_kernels.h) -- launch_forward skips attn_fwd, launch_backward ends with the merged launch
+  bool pipelined = false;
 };
 
 // the fused chain kernel covers the reference's fixed hidden widths (200 -> 13 tiles, 80 -> 5 tiles)
@@ -532,14 +538,61 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
 }
 
 // forward part: kernels 1-4
+AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st) {
+  const goctr_ctr_cfg& c = m->cfg;
+  AttnArgs aa{};
+  aa.src = src; aa.st = st; aa.B = B; aa.U = c.U; aa.T = c.T; aa.D = c.D; aa.C = c.C; aa.Ip = m->Ip;
+  aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = m->h0.p; aa.gate = m->gate.p; aa.wgt = m->wgt.p;
+  aa.Tp_att = m->Tp;
+  return aa;
+}
+
+// the compile-time mode launch_attn_fwd picks for this model's rows, or 0; `groups` = lanes per embedding row
+int attn_fast_mode(const goctr_model* m, const RowSource& src, int* groups) {
+  const goctr_ctr_cfg& c = m->cfg;
+  const bool vec4 = src.id_mode && c.D % 4 == 0;
+  const int g = vec4 ? c.D / 4 : c.D;
+  if (groups) *groups = g;
+  return !(vec4 && g * 4 == c.D && (g & (g - 1)) == 0) ? 0 : c.kind != GOCTR_DIN ? 1 : (c.att == GOCTR_ATT_COSINE ? 2 : 3);
+}
+// can the steps of a graph be pipelined (reduce_attn_kernel)?  Single GPU, fused update, the fused chain, D = 16 or 64 rows
+bool pipeline_ok(const goctr_model* m, const RowSource& src) {
+  int groups = 0;
+  const int fast = attn_fast_mode(m, src, &groups);
+  // (DIN: one reduce block must own the whole att0 segment -- it publishes the flag the attention workgroups wait for)
+  const bool one_block = m->cfg.kind != GOCTR_DIN || (m->offa * 2) / 256 == ((m->offa + m->Tp) * 2 - 1) / 256;
+  return fast != 0 && (groups == 4 || groups == 16) && one_block && chain_ok(m) && !engine().comm_active() &&
+         env_int("GOCTR_FUSED_UPDATE", 1) != 0 && env_int("GOCTR_PIPELINE", 1) != 0;
+}
+
+int launch_reduce_attn(goctr_model* m, const RowSource& src, int B, const ReduceAdamArgs& p) {
+  int groups = 0;
+  const int fast = attn_fast_mode(m, src, &groups);
+  const AttnArgs aa = make_attn_args(m, src, B, p.r.st);
+  const int nred = (int)cdiv((int64_t)m->nflat * 2, 256) + 1;
+  const dim3 grid((unsigned)(nred + cdiv(B, 4))), blk(256);
+  hipStream_t st = engine().active;
+#define GOCTR_RA(L)                                                                                        \
+  do {                                                                                                     \
+    if (fast == 1) hipLaunchKernelGGL((reduce_attn_kernel<4, L, 1>), grid, blk, 0, st, p, aa, nred);       \
+    else if (fast == 2) hipLaunchKernelGGL((reduce_attn_kernel<4, L, 2>), grid, blk, 0, st, p, aa, nred);  \
+    else hipLaunchKernelGGL((reduce_attn_kernel<4, L, 3>), grid, blk, 0, st, p, aa, nred);                 \
+  } while (0)
+  if (groups == 4) GOCTR_RA(4);
+  else GOCTR_RA(16);
+#undef GOCTR_RA
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st_override = nullptr) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
   const StepState* st = st_override ? st_override : m->st_cur();
-  AttnArgs aa{};
-  aa.src = src; aa.st = st; aa.B = B; aa.U = c.U; aa.T = c.T; aa.D = c.D; aa.C = c.C; aa.Ip = m->Ip;
-  aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = m->h0.p; aa.gate = m->gate.p; aa.wgt = m->wgt.p;
-  if (launch_attn_fwd(aa)) return -1;
+  if (!o.pipelined) {
+    const AttnArgs aa = make_attn_args(m, src, B, st);
+    if (launch_attn_fwd(aa)) return -1;
+  }
   if (chain_ok(m)) return launch_chain(m, src, B, o, st);  // layers + (when training) backward-data, fused
 
   const int bglobal = B * e.world;
@@ -895,9 +948,14 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   if (fuse_update) {
     ReduceAdamArgs p{};
     p.r = ra; p.ad = make_adam_args(m, B, *o.tc);
+    p.ra_flag = m->ra_flag.p; p.ra_block = (o.pipelined && c.kind == GOCTR_DIN) ? (m->offa * 2) / 256 : -1;
     ProfScope ps(GOCTR_K_REDUCE);
-    hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)cdiv((int64_t)m->nflat * 2, 256) + 1), dim3(256), 0, e.stream, p);
-    GOCTR_HIP(hipGetLastError());
+    if (o.pipelined) {
+      if (launch_reduce_attn(m, src, B, p)) return -1;     // + attn_fwd of the next step's batch
+    } else {
+      hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)cdiv((int64_t)m->nflat * 2, 256) + 1), dim3(256), 0, e.stream, p);
+      GOCTR_HIP(hipGetLastError());
+    }
     m->stp ^= 1;   // the step is closed: later launches read the slot just written
     return 0;
   }
@@ -953,7 +1011,7 @@ bool graph_matches(const StepGraph& g, const goctr_dataset* d, const goctr_emb* 
   return g.a[0] && g.a[1] && g.ds == d->uid && g.emb == (e ? e->uid : 0) && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
          g.seed == o.seed && g.lr == o.tc->lr && g.l2 == o.tc->l2 && g.b1 == o.tc->beta1 && g.b2 == o.tc->beta2 &&
          g.eps == o.tc->eps && g.flags == o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div &&
-         g.world == engine().world && g.comm == engine().comm_active();
+         g.world == engine().world && g.comm == engine().comm_active() && g.pipelined == o.pipelined;
 }
 
 int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, const RowSource& src, int B,
@@ -989,6 +1047,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   sg.ds = d->uid; sg.emb = emb ? emb->uid : 0; sg.B = B; sg.mode = o.drop_mode; sg.p0 = o.p0; sg.p1 = o.p1; sg.seed = o.seed;
   sg.lr = o.tc->lr; sg.l2 = o.tc->l2; sg.b1 = o.tc->beta1; sg.b2 = o.tc->beta2; sg.eps = o.tc->eps;
   sg.flags = o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div; sg.world = e.world; sg.comm = e.comm_active();
+  sg.pipelined = o.pipelined;
   return 0;
 }
 
@@ -1026,6 +1085,7 @@ int build_multi_graphs(goctr_model* m, const RowSource& src, int B, const StepOp
 
 int set_state(goctr_model* m, unsigned gstep, unsigned slot, long long batch_idx, long long n_batches) {
   StepState s{gstep, slot, batch_idx, n_batches};
+  if (m->ra_flag.p) GOCTR_HIP(hipMemsetAsync(m->ra_flag.p, 0, sizeof(unsigned int), engine().stream));   // (gstep may jump: no stale match)
   GOCTR_HIP(hipMemcpyAsync(m->st_cur(), &s, sizeof s, hipMemcpyHostToDevice, engine().stream));
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
   return 0;
@@ -1083,7 +1143,14 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
   // (with a communicator the sparse embedding exchange sizes a collective from a device counter: eager steps)
   const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0 && !(e.comm_active() && m->emb_lr > 0.f);
   if (use_graph) {
+    o.pipelined = pipeline_ok(m, src);
     if (!graph_matches(m->graph, d, emb, B, o) && build_graph(m, d, emb, src, B, o)) return -1;
+    if (o.pipelined && n_steps > 0) {
+      // the first step's h0: nobody computed it yet (every later step gets it from its predecessor's last launch; the
+      // last step computes one nobody uses -- a call costs one attn_fwd more than its steps need)
+      const AttnArgs aa = make_attn_args(m, src, B, m->st_cur());
+      if (launch_attn_fwd(aa)) return -1;
+    }
     int s = 0;
     if (!e.comm_active() && env_int("GOCTR_GRAPH_STEPS", 1) != 0) {
       if (!m->graph.multi_on && build_multi_graphs(m, src, B, o)) return -1;

@@ -84,6 +84,7 @@ struct AttnArgs {
   float* h0;    // [B, Ip]
   float* gate;  // [B, T]
   float* wgt;   // [B, T]
+  int Tp_att;   // (reduce_attn_kernel) padded length of the att0 segment of the flat parameter buffer
 };
 
 // DPP lane exchanges (VALU, no LDS crossbar): quad_perm / row_half_mirror / row_mirror / row_ror
@@ -152,8 +153,15 @@ __device__ __forceinline__ void load_row_nn(const float* row, int d0, int D, boo
 // compile time (YouTube mean pooling / DIN cosine / DIN euclid): the kernel is VALU-bound (rocprofv3: ~500 VALU
 // instructions per sample against 10 loads and 6 stores), and run-time mode branches inside its unrolled loops cost
 // more instructions than the arithmetic they select.
+// (body: workgroup `blk` of the launch, the batch the step works on, the attention weights -- the merged
+// reduce_attn_kernel below passes the NEXT step's batch index and weights it derived itself)
+// what a workgroup of reduce_attn_kernel needs to pick up the attention weights its launch's reduce part is writing:
+// the block that owns att0 publishes `expect` in *flag (device scope) once its stores are out (null: plain attn_fwd)
+struct RaCtx { const unsigned int* flag; unsigned int expect; const float* att0; };
+
 template <int VEC, int LPR, int FAST>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long long batch_idx, const float* att0w,
+                                              const RaCtx* ra = nullptr) {
   const bool idm = FAST ? true : (bool)a.src.id_mode;
   const bool din = FAST ? FAST >= 2 : a.kind == GOCTR_DIN;
   const bool cosine = FAST ? FAST == 2 : a.att == GOCTR_ATT_COSINE;
@@ -161,10 +169,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   constexpr int NPB = LPR < 4 ? LPR : 4;  // passes per block; NPB*RPP <= 64
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the sample's base addresses live in SGPRs
-  const int b = blockIdx.x * 4 + wave;
+  const int b = blk * 4 + wave;
   if (b >= a.B) return;
   const RowSource& s = a.src;
-  const long long gr = a.st->batch_idx * (long long)a.B + b;
+  const long long gr = batch_idx * (long long)a.B + b;
   const bool valid = gr < s.rows;
   const int dl = lane % LPR, rl = lane / LPR;
   const int d0 = dl * VEC;
@@ -240,7 +248,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         w_l = 1.0f - sqrtf(s0);
       }
       const int tl = tb + lane;
-      g_l = sigm_hidden(w_l * ((lane < NPB * RPP && tl < T) ? a.att0[tl] : 0.f));
+      float aw = 0.f;
+      if (ra) {
+        // merged kernel: the weights are being written by the att0 block of this very launch (dispatched before any
+        // attention workgroup, so it is resident); wait for its flag, then read them past the non-coherent L2.  Relaxed
+        // device-scope loads throughout: they go to memory themselves, and an acquire per poll would invalidate the L2
+        // of 8192 polling wavefronts' XCDs over and over
+        bool ok = true;
+        if (tb == 0) {
+          unsigned int spins = 0;
+          while (__hip_atomic_load(ra->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ra->expect && ++spins < (1u << 22))
+            __builtin_amdgcn_s_sleep(1);
+          ok = spins < (1u << 22);           // (a wait that ran out poisons the step -- NaN costs -- instead of hanging the GPU)
+        }
+        if (lane < NPB * RPP && tl < T) aw = __hip_atomic_load(ra->att0 + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) aw = __builtin_nanf("");
+      } else if (lane < NPB * RPP && tl < T) {
+        aw = att0w[tl];
+      }
+      g_l = sigm_hidden(w_l * aw);
     }
     if (lane < NPB * RPP && tb + lane < T) {
       a.gate[(size_t)b * T + tb + lane] = g_l;
@@ -289,6 +315,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     hrow[j] = valid ? (idm ? s.ufeat[gr * a.U + j] : s.X[gr * (long long)s.xcols + s.r_u + j]) : 0.f;
   for (int j = lane + 128; j < a.C; j += 64)
     hrow[a.U + 2 * D + j] = valid ? (idm ? s.cfeat[gr * a.C + j] : s.X[gr * (long long)s.xcols + s.r_c + j]) : 0.f;
+}
+
+template <int VEC, int LPR, int FAST>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x, a.st->batch_idx, a.att0);
 }
 
 // ---------------------------------------------------------------- attention backward (att0 grad)
@@ -547,27 +578,34 @@ __device__ __forceinline__ void adam_apply_pre(const AdamArgs& a, int idx, float
 __device__ __forceinline__ void adam_apply(const AdamArgs& a, int idx, float g, float corr1, float corr2) {
   adam_apply_pre(a, idx, g, corr1, corr2, a.W[idx], a.Mo[idx], a.Vo[idx]);
 }
-__device__ __forceinline__ void adam_apply_pre(const AdamArgs& a, int idx, float g, float corr1, float corr2, float w0, float m0, float v0) {
+// the arithmetic of one element's update, without side effects (reduce_attn_kernel recomputes the attention weights of
+// the next step with it: same expressions, same bits)
+__device__ __forceinline__ float adam_new_weight(const AdamArgs& a, float g, float corr1, float corr2, float w0, float m0, float v0,
+                                                 float& m, float& v) {
   const float b1 = (float)a.beta1, b2 = (float)a.beta2;
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   const float l2 = (float)a.l2, eps = (float)a.eps, neg_eta = (float)(-a.lr);
   const float one_per_batch = 1.0f / (float)a.bglobal;
-  float w = w0;
   if (a.l2_first) {
-    if (l2 != 0.f) g = g + w * l2;
+    if (l2 != 0.f) g = g + w0 * l2;
     if (a.div_by_batch && a.bglobal > 1) g = g * one_per_batch;
   } else {
     if (a.div_by_batch && a.bglobal > 1) g = g * one_per_batch;
-    if (l2 != 0.f) g = g + w * l2;
+    if (l2 != 0.f) g = g + w0 * l2;
   }
   const float t1 = omb1 * g;
   const float g2 = (g * g) * omb2;
-  const float m = b1 * m0 + t1;
-  const float v = b2 * v0 + g2;
-  a.Mo[idx] = m; a.Vo[idx] = v;
+  m = b1 * m0 + t1;
+  v = b2 * v0 + g2;
   const float mhat = m * corr1;
   const float vhat = v * corr2;
-  w = w + (neg_eta * mhat) / (sqrtf(vhat) + eps);
+  return w0 + (neg_eta * mhat) / (sqrtf(vhat) + eps);
+}
+__device__ __forceinline__ void adam_apply_pre(const AdamArgs& a, int idx, float g, float corr1, float corr2, float w0, float m0, float v0) {
+  float w = w0;
+  float m, v;
+  w = adam_new_weight(a, g, corr1, corr2, w0, m0, v0, m, v);
+  a.Mo[idx] = m; a.Vo[idx] = v;
   a.W[idx] = w;
   // keep the transposed operand copies in sync
   if (idx < a.off1) {
@@ -611,13 +649,45 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
 }
 
 // Single-GPU fast path: slab reduce + Adam + BCE sum + step advance in ONE launch.
-struct ReduceAdamArgs { ReduceArgs r; AdamArgs ad; };
+struct ReduceAdamArgs {
+  ReduceArgs r; AdamArgs ad;
+  unsigned int* ra_flag; int ra_block;    // reduce_attn_kernel: block ra_block owns the att0 segment and publishes gstep + 1 (-1: none)
+};
 
-__global__ __launch_bounds__(256) void reduce_adam_kernel(ReduceAdamArgs p) {
+// sum of one float4 parameter group (elements e0 .. e0 + 3) over the slabs of its segment: the 8 lanes of the group take a
+// contiguous eighth of the slabs each, a xor-butterfly leaves the total in all of them.  Every lane of the 8 must call it.
+template <int UNROLL>     // (loads in flight per lane; the order of the adds, and so the result, does not depend on it)
+__device__ __forceinline__ float4 slab_group_sum(const ReduceArgs& a, int e0, int pl) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e0 < a.nflat) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < a.nseg && e0 >= a.seg[k].begin && e0 < a.seg[k].begin + a.seg[k].len) {
+        const int spp = (a.seg[k].nslabs + 7) >> 3;
+        int lo = pl * spp, hi = lo + spp;
+        if (hi > a.seg[k].nslabs) hi = a.seg[k].nslabs;
+        const float* base = a.seg[k].slabs + (e0 - a.seg[k].begin);
+#pragma unroll UNROLL
+        for (int j = lo; j < hi; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(base + (size_t)j * a.seg[k].stride);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int blk, int nblk) {
   const ReduceArgs& a = p.r;
   __shared__ float corr[2];
   __shared__ float red[256];
-  if (blockIdx.x == gridDim.x - 1) {   // the loss block runs beside the gradient blocks
+  if (blk == nblk - 1) {   // the loss block runs beside the gradient blocks
     loss_sum_block(a.lossrow, a.B, red);
     if (threadIdx.x == 0) {
       a.G[a.nflat] = red[0];
@@ -625,33 +695,12 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(ReduceAdamArgs p) {
       advance_state(a.st, a.st_out);
     }
   } else {
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int gid = blk * 256 + threadIdx.x;
     const int e0 = (gid >> 3) * 4, pl = gid & 7;
     const bool mine = pl < 4 && e0 + pl < a.nflat;           // lanes 0..3 of a group own one parameter each
     float w0 = 0.f, m0 = 0.f, v0 = 0.f;
     if (mine) { w0 = p.ad.W[e0 + pl]; m0 = p.ad.Mo[e0 + pl]; v0 = p.ad.Vo[e0 + pl]; }
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e0 < a.nflat) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (k < a.nseg && e0 >= a.seg[k].begin && e0 < a.seg[k].begin + a.seg[k].len) {
-          const int spp = (a.seg[k].nslabs + 7) >> 3;
-          int lo = pl * spp, hi = lo + spp;
-          if (hi > a.seg[k].nslabs) hi = a.seg[k].nslabs;
-          const float* base = a.seg[k].slabs + (e0 - a.seg[k].begin);
-#pragma unroll 8
-          for (int j = lo; j < hi; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)j * a.seg[k].stride);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-      acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
-      acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
-    }
+    const float4 acc = slab_group_sum<8>(a, e0, pl);
     // the bias corrections (two float64 pow calls on one thread) are computed while the slab loads above are in flight
     if (threadIdx.x == 0) {
       const double it = (double)a.st->gstep + 1.0;  // this step's iteration number
@@ -664,7 +713,39 @@ __global__ __launch_bounds__(256) void reduce_adam_kernel(ReduceAdamArgs p) {
       const float g = pl == 0 ? acc.x : (pl == 1 ? acc.y : (pl == 2 ? acc.z : acc.w));
       adam_apply_pre(p.ad, e0 + pl, g, corr[0], corr[1], w0, m0, v0);
     }
+    if (blk == p.ra_block) {
+      // the attention workgroups of this launch wait for the new att0: make the stores visible device-wide, then say so
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __threadfence();
+        __hip_atomic_store(p.ra_flag, a.st->gstep + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void reduce_adam_kernel(ReduceAdamArgs p) {
+  reduce_adam_body(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---------------------------------------------------------------- the step's last launch merged with the NEXT step's first
+// reduce_adam (blocks [0, nred)) beside attn_fwd of the following batch (the other blocks).  The two do not depend on each
+// other -- except through the step state (the attention part derives the next batch cursor itself, like advance_state) and
+// the attention weights att0 (T floats, DIN): the reduce block that owns them publishes a flag after its Adam update and an
+// attention wavefront waits for it right before its gate, ~2 us into its life (the reduce blocks have the lowest block
+// indices: they are resident before any attention workgroup is dispatched; the wait is bounded all the same).  The eight
+// L2s are not coherent: release fence + device-scope flag on the writer's side, device-scope loads of the 50 floats on the
+// reader's.  reduce_adam is a latency chain on a few hundred small workgroups and attn_fwd one on 2048: side by side they
+// cost little more than the longer one, and the step loses a launch boundary.
+// tests/test_gpu_ctr.py::test_graph_replay_equals_eager compares this (graph) path with the unmerged eager one bit by bit.
+template <int VEC, int LPR, int FAST>
+__global__ __launch_bounds__(256) void reduce_attn_kernel(ReduceAdamArgs p, AttnArgs a, int nred) {
+  if ((int)blockIdx.x < nred) { reduce_adam_body(p, (int)blockIdx.x, nred); return; }
+  const ReduceArgs& r = p.r;
+  long long nb = r.st->batch_idx + 1;                          // advance_state()'s cursor
+  if (nb >= r.st->n_batches) nb = 0;
+  const RaCtx ctx{p.ra_flag, r.st->gstep + 1u, a.att0};
+  attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x - nred, nb, a.att0, FAST >= 2 ? &ctx : nullptr);
 }
 
 // ---------------------------------------------------------------- standalone gather (bit-exact)
