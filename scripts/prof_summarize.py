@@ -18,7 +18,7 @@ import sys
 
 SHORT = {"reduce_adam_kernel": "reduce", "attn_fwd_kernel": "attn_fwd", "ctr_chain_x3_kernel": "chain", "ctr_chain_kernel": "chain",
          "attn_bwd_kernel": "attn_bwd", "gemm_tn_multi_x3w_kernel": "dW0", "gemm_tn_multi_x3_kernel": "dW0", "gemm_tn_multi_kernel": "dW0", "ctr_fwd16_kernel": "fwd16",
-         "reduce_kernel": "reduce", "adam_kernel": "adam", "gemm_nn_kernel": "gemm_nn", "gemm_tn_kernel": "gemm_tn"}
+         "reduce_attn_kernel": "reduce_attn", "reduce_adam_kernel": "reduce", "reduce_kernel": "reduce", "adam_kernel": "adam", "gemm_nn_kernel": "gemm_nn", "gemm_tn_kernel": "gemm_tn"}
 
 
 def short(name):
