@@ -86,6 +86,9 @@ struct goctr_model {
   int wsB = 0, tnS = 0;
   DevBuf<float> h0, P0, A0, P1, A1, yhat, lossrow, dz2, dz1, dz0, dp, gate, wgt, slabs0, slabs1, slabs2, attp;
   DevBuf<float> mask0, mask1, slabs3, ones16;
+  size_t gw_stride = 0;           // floats between the two parity copies of gate / wgt
+  float* gate_p(int par) { return gate.p + (size_t)par * gw_stride; }
+  float* wgt_p(int par) { return wgt.p + (size_t)par * gw_stride; }
   DevBuf<unsigned int> ra_flag;   // pipelined steps: gstep + 1 of the last step whose att0 update is visible device-wide (reduce_attn_kernel)
   DevBuf<float> yall;          // scores of a whole predict call (one device-to-host copy at the end)
   DevBuf<StepState> st, pst;   // st: two ping-pong slots, stp = the one the next step reads
@@ -206,8 +209,11 @@ int ensure_workspace(goctr_model* m, int B) {
   if (m->dz1.alloc((size_t)B * m->H2p)) return -1;
   if (m->dz0.alloc((size_t)B * m->H1p)) return -1;
   if (m->dp.alloc((size_t)B * m->Dp)) return -1;
-  if (m->gate.alloc((size_t)B * m->cfg.T)) return -1;
-  if (m->wgt.alloc((size_t)B * m->cfg.T)) return -1;
+  // two copies, by the parity of the step state: in pipelined graphs the next step's attn_fwd writes its gates while this
+  // step's backward still reads its own
+  if (m->gate.alloc((size_t)2 * B * m->cfg.T)) return -1;
+  if (m->wgt.alloc((size_t)2 * B * m->cfg.T)) return -1;
+  m->gw_stride = (size_t)B * m->cfg.T;
   if (m->ra_flag.alloc(1)) return -1;
   if (m->slabs0.alloc((size_t)S * m->Ip * m->H1p)) return -1;
   if (m->slabs1.alloc((size_t)S * m->H1p * m->H2p)) return -1;
@@ -538,11 +544,12 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
 }
 
 // forward part: kernels 1-4
-AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st) {
+// `par`: which copy of gate / wgt the launch writes (the parity of the step the gather belongs to)
+AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, int par) {
   const goctr_ctr_cfg& c = m->cfg;
   AttnArgs aa{};
   aa.src = src; aa.st = st; aa.B = B; aa.U = c.U; aa.T = c.T; aa.D = c.D; aa.C = c.C; aa.Ip = m->Ip;
-  aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = m->h0.p; aa.gate = m->gate.p; aa.wgt = m->wgt.p;
+  aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = m->h0.p; aa.gate = m->gate_p(par); aa.wgt = m->wgt_p(par);
   aa.Tp_att = m->Tp;
   return aa;
 }
@@ -568,7 +575,7 @@ bool pipeline_ok(const goctr_model* m, const RowSource& src) {
 int launch_reduce_attn(goctr_model* m, const RowSource& src, int B, const ReduceAdamArgs& p) {
   int groups = 0;
   const int fast = attn_fast_mode(m, src, &groups);
-  const AttnArgs aa = make_attn_args(m, src, B, p.r.st);
+  const AttnArgs aa = make_attn_args(m, src, B, p.r.st, m->stp ^ 1);      // the NEXT step's gates
   const int nred = (int)cdiv((int64_t)m->nflat * 2, 256) + 1;
   const dim3 grid((unsigned)(nred + cdiv(B, 4))), blk(256);
   hipStream_t st = engine().active;
@@ -590,7 +597,7 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
   Engine& e = engine();
   const StepState* st = st_override ? st_override : m->st_cur();
   if (!o.pipelined) {
-    const AttnArgs aa = make_attn_args(m, src, B, st);
+    const AttnArgs aa = make_attn_args(m, src, B, st, m->stp);
     if (launch_attn_fwd(aa)) return -1;
   }
   if (chain_ok(m)) return launch_chain(m, src, B, o, st);  // layers + (when training) backward-data, fused
@@ -743,7 +750,7 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   const int W = e.comm_active() ? e.world : 1;
   EmbTrainArgs a{};
   a.src = src; a.st = st; a.B = B; a.T = c.T; a.D = c.D; a.kind = c.kind; a.att = c.att;
-  a.dpv = m->dpv.p; a.ldp = Np; a.gate = m->gate.p; a.wgt = m->wgt.p; a.att0 = m->W.p + m->offa;
+  a.dpv = m->dpv.p; a.ldp = Np; a.gate = m->gate_p(m->stp); a.wgt = m->wgt_p(m->stp); a.att0 = m->W.p + m->offa;
   a.emb = const_cast<float*>(src.emb); a.V = V;
   a.mark = m->emb_mark.p; a.rank = m->emb_rank.p; a.accum = m->emb_accum.p; a.lr = m->emb_lr; a.dbg = env_int("GOCTR_EMB_DBG", 0);
   a.W = W; a.Vw = m->emb_Vw;
@@ -827,7 +834,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     }
     AttnBwdArgs ab{};
     ab.src = src; ab.st = st; ab.B = B; ab.T = c.T; ab.D = c.D; ab.Dp = m->Dp; ab.Tp = m->Tp;
-    ab.dp = m->dp.p; ab.gate = m->gate.p; ab.wgt = m->wgt.p; ab.partial = m->attp.p;
+    ab.dp = m->dp.p; ab.gate = m->gate_p(m->stp); ab.wgt = m->wgt_p(m->stp); ab.partial = m->attp.p;
     if (launch_attn_bwd(ab, (int)cdiv(B, ATTN_BWD_WAVES))) return -1;
   }
 
@@ -1148,7 +1155,7 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
     if (o.pipelined && n_steps > 0) {
       // the first step's h0: nobody computed it yet (every later step gets it from its predecessor's last launch; the
       // last step computes one nobody uses -- a call costs one attn_fwd more than its steps need)
-      const AttnArgs aa = make_attn_args(m, src, B, m->st_cur());
+      const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
       if (launch_attn_fwd(aa)) return -1;
     }
     int s = 0;
