@@ -1147,6 +1147,10 @@ int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_trai
     GOCTR_CHECK(src.id_mode, "embedding training needs an id-mode dataset (the dense TrainSample rows carry no ids)");
     if (ensure_emb_workspace(m, src.V, B)) return -1;
   }
+  // the bias corrections of the state the call starts from (ctr_kernels.h: StepState::corr1/2); later states get theirs from
+  // the loss block of the step before them
+  hipLaunchKernelGGL(step_state_corr_kernel, dim3(1), dim3(1), 0, e.stream, m->st_cur(), o.tc->beta1, o.tc->beta2);
+  GOCTR_HIP(hipGetLastError());
   // (with a communicator the sparse embedding exchange sizes a collective from a device counter: eager steps)
   const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0 && !(e.comm_active() && m->emb_lr > 0.f);
   if (use_graph) {

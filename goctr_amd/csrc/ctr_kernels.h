@@ -22,7 +22,16 @@ struct StepState {
   unsigned int slot;      // next cost slot
   long long batch_idx;    // batch of the dataset the current step works on
   long long n_batches;
+  // Adam's bias corrections of THIS step, 1 / (1 - beta^(gstep + 1)): two float64 pow calls that took 2.8 us of the reduce
+  // blocks' critical path when each of them made them itself.  Written by whoever writes the state: the previous step's
+  // loss block, or step_state_corr_kernel at the start of a call (same device pow, same bits).
+  float corr1, corr2;
 };
+__device__ __forceinline__ void state_corrections(StepState& s, double beta1, double beta2) {
+  const double it = (double)s.gstep + 1.0;
+  s.corr1 = 1.0f / (float)(1.0 - pow(beta1, it));
+  s.corr2 = 1.0f / (float)(1.0 - pow(beta2, it));
+}
 
 constexpr int COST_RING = 1 << 16;
 
@@ -656,23 +665,39 @@ struct ReduceAdamArgs {
 
 // sum of one float4 parameter group (elements e0 .. e0 + 3) over the slabs of its segment: the 8 lanes of the group take a
 // contiguous eighth of the slabs each, a xor-butterfly leaves the total in all of them.  Every lane of the 8 must call it.
-template <int UNROLL>     // (loads in flight per lane; the order of the adds, and so the result, does not depend on it)
+// Up to 8 slabs per lane are loaded before the first add (one memory latency); the adds keep the order of the plain loop.
 __device__ __forceinline__ float4 slab_group_sum(const ReduceArgs& a, int e0, int pl) {
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* base = a.seg[0].slabs;
+  unsigned long long stride = 0;
+  int lo = 0, hi = 0;
   if (e0 < a.nflat) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (k < a.nseg && e0 >= a.seg[k].begin && e0 < a.seg[k].begin + a.seg[k].len) {
         const int spp = (a.seg[k].nslabs + 7) >> 3;
-        int lo = pl * spp, hi = lo + spp;
+        lo = pl * spp; hi = lo + spp;
         if (hi > a.seg[k].nslabs) hi = a.seg[k].nslabs;
-        const float* base = a.seg[k].slabs + (e0 - a.seg[k].begin);
-#pragma unroll UNROLL
-        for (int j = lo; j < hi; ++j) {
-          const float4 v = *reinterpret_cast<const float4*>(base + (size_t)j * a.seg[k].stride);
-          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
+        base = a.seg[k].slabs + (e0 - a.seg[k].begin);
+        stride = a.seg[k].stride;
       }
+    }
+  }
+  if (__all(hi - lo <= 8)) {                                  // (wave-uniform choice of the path)
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = lo + u < hi ? lo + u : (hi > lo ? hi - 1 : 0);
+      v[u] = (hi > lo) ? *reinterpret_cast<const float4*>(base + (size_t)j * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (lo + u < hi) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  } else {
+#pragma unroll 8
+    for (int j = lo; j < hi; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)j * stride);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
 #pragma unroll
@@ -683,16 +708,26 @@ __device__ __forceinline__ float4 slab_group_sum(const ReduceArgs& a, int e0, in
   return acc;
 }
 
-__device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int blk, int nblk) {
+__device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int blk_in, int nblk) {
   const ReduceArgs& a = p.r;
-  __shared__ float corr[2];
+  // merged launch: the block that owns att0 trades places with block 0 -- dispatched first, its loads are not queued behind
+  // the 10 MB of slab reads of the other 376 blocks
+  const int blk = p.ra_block < 0 ? blk_in : (blk_in == 0 ? p.ra_block : (blk_in == p.ra_block ? 0 : blk_in));
   __shared__ float red[256];
   if (blk == nblk - 1) {   // the loss block runs beside the gradient blocks
+    // the next step's state, bias corrections included (thread 0's pow calls run under the loss rows' load latency)
+    StepState ns = *a.st;
+    if (threadIdx.x == 0) {
+      ns.gstep += 1; ns.slot += 1;
+      const long long nb = ns.batch_idx + 1;
+      ns.batch_idx = nb >= ns.n_batches ? 0 : nb;
+      state_corrections(ns, p.ad.beta1, p.ad.beta2);
+    }
     loss_sum_block(a.lossrow, a.B, red);
     if (threadIdx.x == 0) {
       a.G[a.nflat] = red[0];
       p.ad.costs[a.st->slot % COST_RING] = -(red[0] / (float)p.ad.bglobal);   // cost.go:15 Neg(Mean(...))
-      advance_state(a.st, a.st_out);
+      *a.st_out = ns;
     }
   } else {
     const int gid = blk * 256 + threadIdx.x;
@@ -700,18 +735,12 @@ __device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int bl
     const bool mine = pl < 4 && e0 + pl < a.nflat;           // lanes 0..3 of a group own one parameter each
     float w0 = 0.f, m0 = 0.f, v0 = 0.f;
     if (mine) { w0 = p.ad.W[e0 + pl]; m0 = p.ad.Mo[e0 + pl]; v0 = p.ad.Vo[e0 + pl]; }
-    const float4 acc = slab_group_sum<8>(a, e0, pl);
-    // the bias corrections (two float64 pow calls on one thread) are computed while the slab loads above are in flight
-    if (threadIdx.x == 0) {
-      const double it = (double)a.st->gstep + 1.0;  // this step's iteration number
-      corr[0] = 1.0f / (float)(1.0 - pow(p.ad.beta1, it));
-      corr[1] = 1.0f / (float)(1.0 - pow(p.ad.beta2, it));
-    }
-    __syncthreads();
+    const float corr1 = a.st->corr1, corr2 = a.st->corr2;    // (the step's bias corrections travel with its state)
+    const float4 acc = slab_group_sum(a, e0, pl);
     // after the butterfly all 8 lanes hold the sums: lanes 0..3 of the group update one element each
     if (mine) {
       const float g = pl == 0 ? acc.x : (pl == 1 ? acc.y : (pl == 2 ? acc.z : acc.w));
-      adam_apply_pre(p.ad, e0 + pl, g, corr[0], corr[1], w0, m0, v0);
+      adam_apply_pre(p.ad, e0 + pl, g, corr1, corr2, w0, m0, v0);
     }
     if (blk == p.ra_block) {
       // the attention workgroups of this launch wait for the new att0.  A release fence here would write back every dirty
@@ -727,6 +756,14 @@ __device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int bl
       if (threadIdx.x == 0) __hip_atomic_store(p.ra_flag, a.st->gstep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// the bias corrections of the state a call starts from (set_state / a restored checkpoint / a retargeted cursor leave them
+// to this launch; inside a call every step's loss block writes the next state's)
+__global__ void step_state_corr_kernel(StepState* st, double beta1, double beta2) {
+  StepState s = *st;
+  state_corrections(s, beta1, beta2);
+  st->corr1 = s.corr1; st->corr2 = s.corr2;
 }
 
 __global__ __launch_bounds__(256) void reduce_adam_kernel(ReduceAdamArgs p) {
