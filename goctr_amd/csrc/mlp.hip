@@ -157,6 +157,7 @@ struct MlpReduceArgs {
   // optimizer
   int solver; int do_update;
   double lr_init, beta1, beta2, eps, momentum; int nesterov;
+  double pow_skip1, pow_skip2;   // exponents beyond which beta^ex < 2^-55 (a factor 2 inside the bound that matters)
   double weight_decay;
   const MlpState* st;         // the step's frozen state (mlp_gather_kernel / mlp_copy_f64_kernel)
   MlpState* st_master;        // advanced by the loss block when `advance`
@@ -312,7 +313,9 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
           a.Mo[idx] = m; a.Vo[idx] = v;
           // quirk Q7: beta powers advance once per parameter: exponent (t-1)*n + i + 1
           const double ex = (double)((a.st->t) * a.nparams + pidx + 1);
-          const double b1t = pow(a.beta1, ex), b2t = pow(a.beta2, ex);
+          // beta^ex < 2^-54 makes (1 - beta^ex) round to exactly 1: the two pow calls (most of this thread's instructions)
+          // are only made where they can change a bit -- after t * n passes a few tens of thousands, nowhere
+          const double b1t = ex > a.pow_skip1 ? 0.0 : pow(a.beta1, ex), b2t = ex > a.pow_skip2 ? 0.0 : pow(a.beta2, ex);
           const double lr = a.lr_init * sqrt(1 - b2t) / (1. - b1t);
           wn = w + (-lr * m / (sqrt(v) + a.eps));
         } else {
@@ -1192,6 +1195,10 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   a.W = p->W.p; a.G = p->G.p; a.Mo = p->Mo.p; a.Vo = p->Vo.p; a.Vel = p->Vel.p;
   a.alpha = p->cfg.alpha; a.n = n; a.solver = p->cfg.solver; a.do_update = do_update ? 1 : 0;
   a.lr_init = p->cfg.lr_init; a.beta1 = p->cfg.beta1; a.beta2 = p->cfg.beta2; a.eps = p->cfg.eps;
+  {
+    auto skip = [](double beta) { return (beta > 0.0 && beta < 1.0) ? 55.0 * 0.6931471805599453 / -std::log(beta) : 1e300; };
+    a.pow_skip1 = skip(a.beta1); a.pow_skip2 = skip(a.beta2);
+  }
   a.momentum = p->cfg.momentum; a.nesterov = p->cfg.nesterov; a.weight_decay = p->cfg.weight_decay;
   a.st = p->st_step.p; a.st_master = p->st.p; a.sumsq_part = p->sumsq_part.p;
   a.W0img = p->fused_ok() ? p->W0img.p : nullptr; a.up1_img = p->up[1];
