@@ -993,7 +993,7 @@ AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc) {
 int launch_adam(goctr_model* m, int B, const goctr_train_cfg& tc) {
   AdamArgs a = make_adam_args(m, B, tc);
   ProfScope ps(GOCTR_K_ADAM);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdiv(m->nflat, 256)), dim3(256), 0, engine().stream, a);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)cdiv(m->nflat, 256) + 1), dim3(256), 0, engine().stream, a);   // (+ the block that prepares the next step's bias corrections)
   GOCTR_HIP(hipGetLastError());
   return 0;
 }

@@ -26,6 +26,8 @@ struct StepState {
   // blocks' critical path when each of them made them itself.  Written by whoever writes the state: the previous step's
   // loss block, or step_state_corr_kernel at the start of a call (same device pow, same bits).
   float corr1, corr2;
+  float pcorr1, pcorr2;   // the corrections of the step BEFORE this state: what the split path's adam_kernel applies (it runs
+                          // after the reduce has already advanced the state)
 };
 __device__ __forceinline__ void state_corrections(StepState& s, double beta1, double beta2) {
   const double it = (double)s.gstep + 1.0;
@@ -494,6 +496,7 @@ __device__ __forceinline__ void advance_state(const StepState* in, StepState* ou
   s.slot += 1;
   const long long nb = s.batch_idx + 1;
   s.batch_idx = nb >= s.n_batches ? 0 : nb;
+  s.pcorr1 = in->corr1; s.pcorr2 = in->corr2;     // (corr1 / corr2 of the new state: adam_kernel's extra block)
   *out = s;
 }
 
@@ -638,15 +641,20 @@ __device__ __forceinline__ void adam_apply_pre(const AdamArgs& a, int idx, float
   cx_scatter_weight(a.x3, w, idx, a.off1, a.off2, a.H1p, a.H2p, a.U, a.D);
 }
 
+// (split path: the reduce kernel has already advanced the state.  This step's bias corrections are the new state's pcorr;
+// one extra block computes the new state's own -- the next step's -- off everybody's critical path)
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  __shared__ float corr[2];
-  if (threadIdx.x == 0) {
-    const double it = (double)a.st->gstep;  // already incremented by the reduce kernel
-    corr[0] = 1.0f / (float)(1.0 - pow(a.beta1, it));
-    corr[1] = 1.0f / (float)(1.0 - pow(a.beta2, it));
+  if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x == 0) {
+      StepState* w = const_cast<StepState*>(a.st);
+      StepState t = *w;
+      state_corrections(t, a.beta1, a.beta2);
+      w->corr1 = t.corr1; w->corr2 = t.corr2;
+    }
+    return;
   }
-  __syncthreads();
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const float corr[2] = {a.st->pcorr1, a.st->pcorr2};
   if (idx == 0) {
     const float s = a.G[a.nflat];
     a.costs[(a.st->slot - 1u) % COST_RING] = -(s / (float)a.bglobal);  // cost.go:15 Neg(Mean(...))
@@ -721,6 +729,7 @@ __device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int bl
       ns.gstep += 1; ns.slot += 1;
       const long long nb = ns.batch_idx + 1;
       ns.batch_idx = nb >= ns.n_batches ? 0 : nb;
+      ns.pcorr1 = ns.corr1; ns.pcorr2 = ns.corr2;
       state_corrections(ns, p.ad.beta1, p.ad.beta2);
     }
     loss_sum_block(a.lossrow, a.B, red);
