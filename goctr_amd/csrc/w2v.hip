@@ -259,6 +259,8 @@ struct HogHot {
   long long max_len;        // longest piece (uniform loop bound: every thread meets every barrier)
 };
 
+constexpr int HOG_PF = 4;   // node vectors of a Huffman path in flight per lane group
+
 template <int GS>
 __global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, int streams, const long long* slice_idx, const long long* clip_lo,
                                                                   const long long* clip_hi, HogHot hot) {
@@ -336,27 +338,70 @@ __global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, i
           w2v_cbow_one<true>(a, tab, doc, cmin, cmax, pos, lr, next, act, l, [&](double v) { return group_sum64<GS>(v); });
       } else if (!a.keep || a.keep[lo + pos]) {
         const int del = lcg_next(next, win);
-        for (int w = del; w < win * 2 + 1 - del; ++w) {
-          if (w == win) continue;
-          const long long c = pos - win + w;
-          if (c < cmin || c >= cmax) continue;
-          const int cid = doc[c];
-          const int cslot = word_slot(cid);
-          double ctx = act ? ld_word(cid, cslot) : 0.0, tmp = 0.0;
+        // every pair of this position walks the SAME Huffman path (the centre word's): its first GS nodes are fetched once
+        const long long hp0 = a.optimizer == 0 ? a.path_off[id] : 0, hp1 = a.optimizer == 0 ? a.path_off[id + 1] : 0;
+        const int hn0 = (int)(hp1 - hp0 < GS ? hp1 - hp0 : GS);
+        const int h_nd0 = l < hn0 ? a.path_nodes[hp0 + l] : 0;
+        const int h_code0 = l < hn0 ? (int)a.path_codes[hp0 + l] : 0;
+        // ... and the context vector of the NEXT pair is requested before the current pair's walk starts
+        auto next_ctx = [&](int w_from, int& w_out, int& cid_out, int& cslot_out, double& v_out) {
+          w_out = win * 2 + 1;
+          for (int w = w_from; w < win * 2 + 1 - del; ++w) {
+            if (w == win) continue;
+            const long long c = pos - win + w;
+            if (c < cmin || c >= cmax) continue;
+            w_out = w; cid_out = doc[c]; cslot_out = word_slot(cid_out);
+            v_out = act ? ld_word(cid_out, cslot_out) : 0.0;
+            return;
+          }
+        };
+        int w_n = 0, cid_n = 0, cslot_n = -1; double ctx_n = 0.0;
+        next_ctx(del, w_n, cid_n, cslot_n, ctx_n);
+        while (w_n < win * 2 + 1 - del) {
+          const int cid = cid_n, cslot = cslot_n;
+          double ctx = ctx_n, tmp = 0.0;
+          {
+            // (a repeated context word in the window must see the previous pair's update: then the row is re-read after it)
+            int w2 = 0, cid2 = 0, cslot2 = -1; double v2 = 0.0;
+            next_ctx(w_n + 1, w2, cid2, cslot2, v2);
+            w_n = w2; cid_n = cid2; cslot_n = cslot2; ctx_n = v2;
+          }
           if (a.optimizer == 0) {
-            const long long p0 = a.path_off[id], p1 = a.path_off[id + 1];
-            int nd = p0 < p1 ? a.path_nodes[p0] : 0;
-            double pv = (act && p0 < p1) ? ld_node(nd) : 0.0;
-            for (long long i = p0; i < p1; ++i) {
-              // request the next node vector while this one is processed (the path is known up front)
-              const int nnd = i + 1 < p1 ? a.path_nodes[i + 1] : nd;
-              const double nv = (act && i + 1 < p1) ? ld_node(nnd) : 0.0;
-              const double inner = group_sum64<GS>(ctx * pv);
-              if (inner <= -6.0 || inner >= 6.0) break;
-              const double gg = (1.0 - (double)a.path_codes[i] - sig_lookup(tab, inner)) * lr;
-              tmp += gg * pv;
-              if (act) add_node(nd, gg * ctx);          // pv += g * ctx (optimizer.go:125)
-              nd = nnd; pv = nv;
+            // The path is known up front: its node ids and codes arrive with ONE coalesced load per GS nodes (lane k of the
+            // group holds node k, handed round by shuffle), and the node vectors are requested HOG_PF nodes ahead -- a
+            // device-scope load of a cold node takes microseconds, and with one node in flight the walk ran at one such
+            // latency per node.  (The nodes of a path are distinct, so reading ahead skips no update of this walk.)
+            const long long p0 = hp0, p1 = hp1;
+            const int gbase = (int)(threadIdx.x & 63) & ~(GS - 1);
+            for (long long c0 = p0; c0 < p1; c0 += GS) {
+              const int n = (int)(p1 - c0 < GS ? p1 - c0 : GS);
+              const int my_nd = c0 == p0 ? h_nd0 : (l < n ? a.path_nodes[c0 + l] : 0);
+              const int my_code = c0 == p0 ? h_code0 : (l < n ? (int)a.path_codes[c0 + l] : 0);
+              double pf[HOG_PF];
+#pragma unroll
+              for (int k = 0; k < HOG_PF; ++k) {
+                const int ndk = __shfl(my_nd, gbase + (k < n ? k : 0), 64);
+                pf[k] = (act && k < n) ? ld_node(ndk) : 0.0;
+              }
+              bool stop = false;
+              for (int i = 0; i < n; ++i) {
+                const int nd = __shfl(my_nd, gbase + i, 64);
+                const int code = __shfl(my_code, gbase + i, 64);
+                const double pv = pf[0];
+#pragma unroll
+                for (int k = 0; k + 1 < HOG_PF; ++k) pf[k] = pf[k + 1];
+                {
+                  const int ia = i + HOG_PF;
+                  const int nda = __shfl(my_nd, gbase + (ia < n ? ia : 0), 64);
+                  pf[HOG_PF - 1] = (act && ia < n) ? ld_node(nda) : 0.0;
+                }
+                const double inner = group_sum64<GS>(ctx * pv);
+                if (inner <= -6.0 || inner >= 6.0) { stop = true; break; }
+                const double gg = (1.0 - (double)code - sig_lookup(tab, inner)) * lr;
+                tmp += gg * pv;
+                if (act) add_node(nd, gg * ctx);          // pv += g * ctx (optimizer.go:125)
+              }
+              if (stop) break;
             }
           } else {
             for (int n = -1; n < a.neg; ++n) {
@@ -379,6 +424,7 @@ __global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, i
             }
           }
           if (act) add_word(cid, cslot, tmp);            // ctx += tmp (model.go:74-76)
+          if (w_n < win * 2 + 1 - del && cid_n == cid && act) ctx_n = ld_word(cid_n, cslot_n);   // same word again: re-read
         }
       }
       ++cnt;
