@@ -215,20 +215,34 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
 #pragma unroll
   for (int e = 0; e < VEC; ++e) psum[e] = 0.f;
 
-  for (int tb = 0; tb < T; tb += NPB * RPP) {
-    int myid = -1;
-    if (idm && valid && lane < NPB * RPP && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
-    float x[NPB][VEC];
+  // The ids of 64 slots arrive with one load; the rows are fetched NPB * RPP slots at a time, and with wide rows (D = 64:
+  // 16 slots per block, 4 blocks per sample) the NEXT block's rows are requested before this block is pooled -- a sample
+  // was a chain of four (ids, rows) round trips before, now it is ids + rows + three overlapped row fetches.
+  constexpr int SLOTS = NPB * RPP;
+  for (int tb0 = 0; tb0 < T; tb0 += 64) {
+  int ids64 = -1;
+  if (idm && valid && tb0 + lane < T) ids64 = s.ub_ids[gr * T + tb0 + lane];
+  auto load_block = [&](int tbx, float (&xx)[NPB][VEC]) {
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
-      const int t = tb + p * RPP + rl;
+      const int t = tbx + p * RPP + rl;
       if (idm) {
-        const int id = __shfl(myid, p * RPP + rl, 64);
-        load_row_nn<VEC>(s.emb + (long long)((t < T && id >= 0 && id < s.V) ? id : s.V) * D, d0, D, full, x[p]);
+        const int id = __shfl(ids64, (tbx - tb0) + p * RPP + rl, 64);
+        load_row_nn<VEC>(s.emb + (long long)((t < T && id >= 0 && id < s.V) ? id : s.V) * D, d0, D, full, xx[p]);
       } else {
-        load_row<VEC>((valid && t < T) ? s.X + gr * (long long)s.xcols + s.r_ub + t * D : nullptr, d0, D, x[p]);
+        load_row<VEC>((valid && t < T) ? s.X + gr * (long long)s.xcols + s.r_ub + t * D : nullptr, d0, D, xx[p]);
       }
     }
+  };
+  float xn[NPB][VEC];
+  load_block(tb0, xn);
+  for (int tb = tb0; tb < T && tb < tb0 + 64; tb += SLOTS) {
+    float x[NPB][VEC];
+#pragma unroll
+    for (int p = 0; p < NPB; ++p)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) x[p][e] = xn[p][e];
+    if (SLOTS < 64 && tb + SLOTS < T && tb + SLOTS < tb0 + 64) load_block(tb + SLOTS, xn);
     // Row sums of every pass first; then slot tb + L's similarity / gate is computed ONCE, in lane L (the lanes of a
     // row group would otherwise all repeat the same sqrt / divide / exp once per pass), which also leaves gate and
     // weight in the layout of one coalesced store; the gate travels back to the row groups by shuffle.
@@ -292,6 +306,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
         for (int e = 0; e < VEC; ++e) psum[e] += g * x[p][e];
       }
     }
+  }
   }
   // mean over T as a multiply by 1/T (one division per sample instead of one per column; <= 1 ulp from x / T)
   const float invT = 1.0f / (float)T;
