@@ -234,15 +234,16 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
       }
     }
   };
-  float xn[NPB][VEC];
-  load_block(tb0, xn);
-  for (int tb = tb0; tb < T && tb < tb0 + 64; tb += SLOTS) {
-    float x[NPB][VEC];
+  constexpr int NB = 64 / SLOTS;
+  float xb[NB][NPB][VEC];
 #pragma unroll
-    for (int p = 0; p < NPB; ++p)
+  for (int k = 0; k < NB; ++k)
+    if (k == 0 || tb0 + k * SLOTS < T) load_block(tb0 + k * SLOTS, xb[k]);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) x[p][e] = xn[p][e];
-    if (SLOTS < 64 && tb + SLOTS < T && tb + SLOTS < tb0 + 64) load_block(tb + SLOTS, xn);
+  for (int k = 0; k < NB; ++k) {
+    const int tb = tb0 + k * SLOTS;
+    if (tb >= T) break;
+    float (&x)[NPB][VEC] = xb[k];
     // Row sums of every pass first; then slot tb + L's similarity / gate is computed ONCE, in lane L (the lanes of a
     // row group would otherwise all repeat the same sqrt / divide / exp once per pass), which also leaves gate and
     // weight in the layout of one coalesced store; the gate travels back to the row groups by shuffle.
