@@ -1804,8 +1804,11 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
                            int64_t n_batches, float* y_host) {
   if (check_dataset(m, d, emb)) return -1;
   // Rows are scored independently of their batch, so G consecutive batches can share launches (one gather and one forward
-  // chain over G * batch rows): same scores bit for bit, fewer and fuller launches.  PredBatchSize keeps its meaning at the
-  // boundary -- which rows a call covers and how the short last batch is padded (model.go:337-347).
+  // chain over G * batch rows): fewer and fuller launches.  PredBatchSize keeps its meaning at the boundary -- which rows a
+  // call covers and how the short last batch is padded (model.go:337-347).  The scores agree with one-batch launches to
+  // float32 rounding, not bit for bit: 16 384 rows take the 32-row-tile forward kernel, 4096 rows the 16-row-tile one
+  // (322 instead of 418 M rows/s if the latter scored the groups too), and the two add the partial products of layer 1 in
+  // different orders (tests/test_gpu_ctr.py bounds the difference; both are inside the 1e-5 parity bar vs the oracle).
   // Measured at DIN cfg3, PredBatchSize 4096: 250 / 351 / 416 / 444 M rows/s at G = 1 / 2 / 4 / 8 (GOCTR_PRED_GROUP).
   const int G = std::max(1, env_int("GOCTR_PRED_GROUP", 4));
   if (ensure_workspace(m, batch * G)) return -1;

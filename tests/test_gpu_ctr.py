@@ -423,3 +423,35 @@ def test_concurrent_handles_from_several_threads(oracle):
         assert all(np.array_equal(y, want_pred[k]) for y in out[k])
     assert np.array_equal(out["t"], want_costs)
     assert np.array_equal(pairs[2][1].get_weights("mlp0"), twin.get_weights("mlp0"))
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_grouped_predict_launches_give_identical_scores(oracle, kind):
+    """goctr_predict_* scores GOCTR_PRED_GROUP consecutive PredBatchSize batches per launch: every row is scored whatever the
+    grouping (rows not a multiple of the batch, a batch count not a multiple of the group), and the scores agree to float32
+    rounding -- the grouped launches take the 32-row-tile forward kernel, single batches the 16-row-tile one"""
+    from goctr_amd import capi, model as gm
+    U, T, D, Cc, V, rows, PB = 52, 50, 16 if kind == 0 else 64, 53, 3000, 4096 * 5 + 777, 4096
+    rng = np.random.default_rng(31)
+    emb = (rng.standard_normal((V, D)) * 0.3).astype(np.float32)
+    ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
+    it = rng.integers(0, V, size=rows).astype(np.int32)
+    uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+    tab = gm.EmbeddingTable(emb)
+    ds = gm.Dataset.ids(ub, it, uf, cf, None)
+    m = (gm.DinNet if kind == 0 else gm.YoutubeDnn)(U, T, D, D, Cc)
+    r = np.random.default_rng(32)
+    m.set_weights("mlp0", (r.standard_normal((U + 2 * D + Cc, 200)) * 0.1).astype(np.float32))
+    m.set_weights("mlp1", (r.standard_normal((200, 80)) * 0.1).astype(np.float32))
+    m.set_weights("mlp2", (r.standard_normal((80, 1)) * 0.1).astype(np.float32))
+    res = []
+    for g in ("1", "4", "3"):
+        os.environ["GOCTR_PRED_GROUP"] = g
+        res.append(gm.predict_dataset(m, ds, PB, emb=tab))
+    os.environ.pop("GOCTR_PRED_GROUP")
+    assert res[0].shape == (rows,) and np.all((res[0] > 0) & (res[0] < 1))
+    assert np.max(np.abs(res[0] - res[1])) <= 2e-6 and np.max(np.abs(res[0] - res[2])) <= 2e-6
+    os.environ["GOCTR_PRED_GROUP"] = "4"
+    again = gm.predict_dataset(m, ds, PB, emb=tab)
+    os.environ.pop("GOCTR_PRED_GROUP")
+    assert np.array_equal(again, res[1])                                         # the same grouping: the same bits
