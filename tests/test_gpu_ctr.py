@@ -455,3 +455,33 @@ def test_grouped_predict_launches_give_identical_scores(oracle, kind):
     again = gm.predict_dataset(m, ds, PB, emb=tab)
     os.environ.pop("GOCTR_PRED_GROUP")
     assert np.array_equal(again, res[1])                                         # the same grouping: the same bits
+
+
+def test_predict_between_training_calls_leaves_training_untouched(oracle):
+    """a predict whose (grouped) launches need a larger workspace reallocates it and drops the captured step graphs: the
+    next training call must rebuild them and land on the same bits as a run without the predict in between"""
+    from goctr_amd import capi, model as gm
+    U, T, D, Cc, V, rows, B = 52, 50, 16, 53, 2000, 2000, 200
+    rng = np.random.default_rng(41)
+    emb = (rng.standard_normal((V, D)) * 0.3).astype(np.float32)
+    ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
+    it = rng.integers(0, V, size=rows).astype(np.int32)
+    uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+    Y = (uf[:, 0] > 0.5).astype(np.float32)
+    tab = gm.EmbeddingTable(emb)
+    ds = gm.Dataset.ids(ub, it, uf, cf, Y)
+    res = []
+    for interrupt in (False, True):
+        m = gm.DinNet(U, T, D, D, Cc)
+        r = np.random.default_rng(42)
+        m.set_weights("mlp0", (r.standard_normal((U + 2 * D + Cc, 200)) * 0.1).astype(np.float32))
+        m.set_weights("mlp1", (r.standard_normal((200, 80)) * 0.1).astype(np.float32))
+        m.set_weights("mlp2", (r.standard_normal((80, 1)) * 0.1).astype(np.float32))
+        cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=2, p0=0.005, p1=0.005, seed=7)
+        gm.train_steps(m, ds, cfg, 5, emb=tab)
+        if interrupt:
+            y = gm.predict_dataset(m, ds, 4096, emb=tab)
+            assert y.shape == (rows,) and np.all(np.isfinite(y))
+        gm.train_steps(m, ds, cfg, 6, first_batch=5, emb=tab)
+        res.append((m.get_weights("mlp0"), m.get_weights("att0")))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
