@@ -1810,7 +1810,8 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
   // (322 instead of 418 M rows/s if the latter scored the groups too), and the two add the partial products of layer 1 in
   // different orders (tests/test_gpu_ctr.py bounds the difference; both are inside the 1e-5 parity bar vs the oracle).
   // Measured at DIN cfg3, PredBatchSize 4096: 250 / 351 / 416 / 444 M rows/s at G = 1 / 2 / 4 / 8 (GOCTR_PRED_GROUP).
-  const int G = std::max(1, env_int("GOCTR_PRED_GROUP", 4));
+  int G = std::max(1, env_int("GOCTR_PRED_GROUP", 4));
+  while (G > 1 && (long long)batch * G > 32768) G /= 2;     // (a launch of 32 768 rows fills the chip; the workspace grows with G)
   if (ensure_workspace(m, batch * G)) return -1;
   RowSource src = make_source(d, emb);
   StepOpts o;
