@@ -332,7 +332,8 @@ int init_kernel_attrs() {
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
       allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(gemm_tn_multi_x3w_kernel<9, 5>) || allow_big_lds(gemm_tn_multi_x3w_kernel<8, 5>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
-      allow_big_lds(ctr_chain_x3_kernel<15>)) return -1;
+      allow_big_lds(ctr_chain_x3_kernel<15>) || allow_big_lds(ctr_chain_x3_kernel<2, true>) || allow_big_lds(ctr_chain_x3_kernel<9, true>) ||
+      allow_big_lds(ctr_chain_x3_kernel<15, true>)) return -1;
   done = true;
   return 0;
 }
@@ -443,8 +444,13 @@ bool chain_x3_shape_ok(const goctr_model* m) {
   return m->H1p == 208 && m->H2p == 80 && (nch0 == 2 || nch0 == 9 || nch0 == 15) &&
          (m->cfg.kind != GOCTR_DIN || m->Dp <= 32);
 }
-bool chain_x3_ok(const goctr_model* m, const StepOpts& o) {
-  return m->x3_nch0 != 0 && o.train && o.drop_mode != 1 && env_int("GOCTR_CHAIN_X3", 1) != 0;
+// training steps, and predict launches large enough to give every CU a 32-row tile (the forward-only variant; smaller
+// predict launches are latency-bound and keep ctr_fwd16_kernel)
+bool chain_x3_ok(const goctr_model* m, const StepOpts& o, int B) {
+  if (m->x3_nch0 == 0 || env_int("GOCTR_CHAIN_X3", 1) == 0) return false;
+  if (o.train) return o.drop_mode != 1;
+  const int cus = engine().compute_units > 0 ? engine().compute_units : 256;
+  return cdiv(B, 32) >= cus && env_int("GOCTR_PREDICT_X3", 1) != 0;
 }
 
 int rebuild_x3_images(goctr_model* m) {
@@ -456,8 +462,9 @@ int rebuild_x3_images(goctr_model* m) {
 }
 
 template <int NCH0>
-void launch_chain_x3_n(const ChainX3Args& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((ctr_chain_x3_kernel<NCH0>), grid, dim3(512), chain_x3_lds_bytes<NCH0>(), s, a);
+void launch_chain_x3_n(const ChainX3Args& a, dim3 grid, hipStream_t s, bool fwd) {
+  if (fwd) hipLaunchKernelGGL((ctr_chain_x3_kernel<NCH0, true>), grid, dim3(512), chain_x3_lds_bytes<NCH0>(), s, a);
+  else hipLaunchKernelGGL((ctr_chain_x3_kernel<NCH0, false>), grid, dim3(512), chain_x3_lds_bytes<NCH0>(), s, a);
 }
 
 int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st) {
@@ -482,9 +489,9 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   ProfScope ps(GOCTR_K_CHAIN);
   const dim3 grid((unsigned)cdiv(B, 32));
   switch (m->x3_nch0) {
-    case 2: launch_chain_x3_n<2>(a, grid, e.active); break;
-    case 9: launch_chain_x3_n<9>(a, grid, e.active); break;
-    default: launch_chain_x3_n<15>(a, grid, e.active); break;
+    case 2: launch_chain_x3_n<2>(a, grid, e.active, !o.train); break;
+    case 9: launch_chain_x3_n<9>(a, grid, e.active, !o.train); break;
+    default: launch_chain_x3_n<15>(a, grid, e.active, !o.train); break;
   }
   GOCTR_HIP(hipGetLastError());
   if (dbg) {
@@ -499,7 +506,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
 }
 
 int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st) {
-  if (chain_x3_ok(m, o)) return launch_chain_x3(m, src, B, o, st);
+  if (chain_x3_ok(m, o, B)) return launch_chain_x3(m, src, B, o, st);
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
   const uint32_t row_off = (uint32_t)(e.rank * B);

@@ -120,7 +120,9 @@ struct CxDrop {
   __device__ __forceinline__ float factor(int slot) const { return (bits >> slot) & 1u ? kv : 0.0f; }
 };
 
-template <int NCH0>
+// FWD: forward only (predict at launch sizes that give every CU a 32-row tile: the products and epilogues up to the output
+// unit, no activations or deltas stored, no backward operands requested)
+template <int NCH0, bool FWD = false>
 __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cx_smem[];
   unsigned char* const h0img = cx_smem;                                         // [NCH0][3][64 lanes][16 B]
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   for (int c = 0; c < CX_PF0; ++c) load0(c, c);
 
   float y = 0.f;
-  {
+  if (!FWD) {
     const long long gr = a.st->batch_idx * (long long)a.B + row;
     y = (a.Y && vrow && gr < a.rows) ? a.Y[gr] : 0.f;
   }
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     p0[i] = s;
     a0[i] = s * dr0.factor(i);
   }
-  if (vrow && own) {
+  if (!FWD && vrow && own) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int f = 32 * tt + 8 * g + 4 * h;
@@ -298,10 +300,12 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   stamp(4);
   // B0 A operands in flight while the exchanges run: [chunk c][plane]
   cx_u4 ra2[CX_NCH2][3];
+  if (!FWD) {
 #pragma unroll
-  for (int c = 0; c < CX_NCH2; ++c)
+    for (int c = 0; c < CX_NCH2; ++c)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) ra2[c][p] = *(g2 + (size_t)((tt * CX_NCH2 + c) * 3 + p) * 64);
+      for (int p = 0; p < 3; ++p) ra2[c][p] = *(g2 + (size_t)((tt * CX_NCH2 + c) * 3 + p) * 64);
+  }
 
   // ---------------------------------------------------------------- exchange 1: reduce-scatter of the partial Z1
   if (own) {
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
       w2v[k][r] = wv[r];
       part += a1v[r] * wv[r];
     }
-    if (vrow && act) *reinterpret_cast<cx_f4*>(a.A1 + (size_t)row * H2p + f0) = cx_f4{a1v[0], a1v[1], a1v[2], a1v[3]};
+    if (!FWD && vrow && act) *reinterpret_cast<cx_f4*>(a.A1 + (size_t)row * H2p + f0) = cx_f4{a1v[0], a1v[1], a1v[2], a1v[3]};
   }
   // ---------------------------------------------------------------- output unit: z2 = sum over the 8 x 2 partials
   part += __shfl_xor(part, 32, 64);
@@ -352,6 +356,10 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   for (int ws = 1; ws < 8; ++ws) z2 += z2p[ws * 32 + n];
   const float yh = sigm_out(z2);
   const bool writer = w == 0 && h == 0 && vrow;
+  if (FWD) {
+    if (writer) a.yhat[row] = yh;
+    return;
+  }
   const float one_eps = (float)(1.0 + 1e-8);
   const float dy = -((y / yh) - ((1.0f - y) / (one_eps - yh))) * a.inv_bglobal;
   const float d2 = dy * (yh * (1.0f - yh));
