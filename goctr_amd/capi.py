@@ -56,7 +56,7 @@ SYMBOLS = [
     "goctr_loss_grad_dense", "goctr_emb_create", "goctr_emb_set_rows", "goctr_emb_destroy", "goctr_gather_rows",
     "goctr_dataset_create_dense", "goctr_dataset_create_ids", "goctr_dataset_destroy", "goctr_train_dataset",
     "goctr_train_steps", "goctr_predict_dataset", "goctr_predict_steps", "goctr_prof_enable", "goctr_prof_reset",
-    "goctr_prof_get", "goctr_prof_name", "goctr_mlp_cfg_default", "goctr_mlp_create", "goctr_mlp_destroy",
+    "goctr_prof_get", "goctr_prof_name", "goctr_prof_kernel", "goctr_mlp_cfg_default", "goctr_mlp_create", "goctr_mlp_destroy",
     "goctr_mlp_nparams", "goctr_mlp_set_params", "goctr_mlp_get_params", "goctr_mlp_loss_grad", "goctr_mlp_fit",
     "goctr_mlp_upload", "goctr_mlp_train_steps", "goctr_mlp_predict", "goctr_w2v_cfg_default", "goctr_w2v_create",
     "goctr_w2v_destroy", "goctr_w2v_set_param", "goctr_w2v_set_aux", "goctr_w2v_get_param", "goctr_w2v_get_aux",
@@ -83,6 +83,7 @@ def load() -> C.CDLL:
         _lib.goctr_last_error.restype = C.c_char_p
         _lib.goctr_version.restype = C.c_char_p
         _lib.goctr_prof_name.restype = C.c_char_p
+        _lib.goctr_prof_kernel.restype = C.c_char_p
         _lib.goctr_mlp_nparams.restype = C.c_size_t
         for name in ("goctr_model_destroy", "goctr_emb_destroy", "goctr_dataset_destroy", "goctr_mlp_destroy",
                      "goctr_w2v_destroy", "goctr_searcher_destroy", "goctr_ubcache_destroy", "goctr_recsys_destroy", "goctr_train_cfg_default", "goctr_mlp_cfg_default",
@@ -159,6 +160,12 @@ def prof_enable(on: bool):
 
 def prof_reset():
     check(load().goctr_prof_reset())
+
+
+def prof_kernels():
+    """{kernel family: symbol of the kernel its last profiled launch ran} (goctr_prof_kernel)"""
+    L = load()
+    return {L.goctr_prof_name(C.c_int(k)).decode(): L.goctr_prof_kernel(C.c_int(k)).decode() for k in range(PROF_COUNT)}
 
 
 def prof_get():

@@ -40,7 +40,12 @@ struct Engine {
   int compute_units = 0;
   hipStream_t stream = nullptr;   // the engine's main stream
   hipStream_t side = nullptr;     // forked inside captured step graphs for independent kernels
-  hipStream_t active = nullptr;   // stream the launch helpers currently target (main unless forked)
+  // stream the launch helpers of THE CALLING THREAD currently target: the main stream unless a StreamScope switched it
+  // (a serving slot's stream, ctr.hip).  Thread-local: serving calls of several host threads run beside each other
+  struct ActiveStream {
+    operator hipStream_t() const;
+    ActiveStream& operator=(hipStream_t s);
+  } active;
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join = nullptr;
   // data-parallel communicator (comm.hip)
   int rank = 0, world = 1;
@@ -52,6 +57,7 @@ struct Engine {
   bool prof = false;
   double prof_ms[GOCTR_K_COUNT] = {0};
   int64_t prof_n[GOCTR_K_COUNT] = {0};
+  const char* prof_kernel[GOCTR_K_COUNT] = {nullptr};   // symbol of the kernel a family's last launch ran (goctr_prof_kernel)
   struct Pending { int id; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> event_pool;
@@ -59,10 +65,12 @@ struct Engine {
 Engine& engine();
 int require_engine();  // 0 if goctr_init succeeded, else sets the error and returns -1
 
-// Every C-ABI entry point that touches the device starts with GOCTR_ENTER(): the engine has ONE submission stream
-// (and captures step graphs on it), so calls from different host threads -- goroutines of a cgo host, e.g. concurrent
-// PredictAbstract.Predict from gin handlers, recommend/api.go:106-131 -- are serialised engine-wide, whatever handles
-// they use.  Recursive: entry points call each other (goctr_train_dense -> goctr_dataset_create_dense -> ...).
+// Every C-ABI entry point that queues work on the engine's MAIN stream (training, uploads, dataset builds, the captured
+// step graphs) starts with GOCTR_ENTER(): those calls are serialised engine-wide, whatever handles they use.  Recursive:
+// entry points call each other (goctr_train_dense -> goctr_dataset_create_dense -> ...).
+// The serving entry points (goctr_batch_predict / goctr_rank / goctr_predict_dense: what concurrent gin handler goroutines
+// call, recommend/api.go:106-131) do NOT take it: each runs on a serving slot with its own stream, staging buffers and
+// forward workspace (ctr.hip: ServeSlot) under a shared lock of the model.
 std::recursive_mutex& engine_mutex();
 #define GOCTR_ENTER()                              \
   if (::goctr::require_engine()) return -1;        \
@@ -86,6 +94,9 @@ struct StreamScope {
   explicit StreamScope(hipStream_t s) : prev(engine().active) { engine().active = s; }
   ~StreamScope() { engine().active = prev; }
 };
+// remembers which kernel symbol a profiled family's launch ran (bench.py matches it against the committed rocprofv3
+// summary before it quotes that summary's counters)
+inline void prof_note_kernel(int id, const char* symbol) { engine().prof_kernel[id] = symbol; }
 
 // Device memory comes from ONE large hipMalloc'd arena (first-fit free list) so that every buffer of
 // the engine sits in the same 2 MiB-fragment mapping (few TLB entries) instead of dozens of small

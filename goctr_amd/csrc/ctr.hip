@@ -6,9 +6,14 @@
 //   -> reduce -> [RCCL all-reduce] -> adam
 // all on one HIP stream; per-step varying values live in a device-side StepState so the sequence
 // can be captured once into a hipGraph and replayed.
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <memory>
+#include <array>
+#include <map>
+#include <shared_mutex>
 
 #include "common.h"
 #include "ctr_chain.h"
@@ -56,6 +61,14 @@ struct StepGraph {
   uint32_t seed = 0; double lr = 0, l2 = 0, b1 = 0, b2 = 0, eps = 0; int flags = 0; int world = 1; bool comm = false;
   bool pipelined = false;   // the captured steps are pipelined (StepOpts::pipelined): a replay needs h0 of its first step
   void destroy() {
+    // goctr_train_steps does not synchronise: replays of these execs may still be queued or running, and destroying an
+    // exec in flight is not something HIP documents as safe.  The capture that follows a destroy is host-heavy anyway.
+    bool any = false;
+    for (int k = 0; k < 2; ++k) {
+      any = any || a[k] || b[k];
+      for (int z = 0; z < kNMulti; ++z) any = any || multi[z][k];
+    }
+    if (any && engine().inited) (void)hipStreamSynchronize(engine().stream);
     for (int k = 0; k < 2; ++k) {
       if (a[k]) (void)hipGraphExecDestroy(a[k]);
       if (b[k]) (void)hipGraphExecDestroy(b[k]);
@@ -63,6 +76,31 @@ struct StepGraph {
       a[k] = b[k] = nullptr;
     }
     multi_on = false;
+  }
+};
+
+// Where a forward pass keeps its per-row buffers: the training workspace (parity copies of gate / wgt), the model's
+// predict workspace, or a serving slot's.  A forward-only launch touches nothing else (the fused chain kernels write
+// yhat only; the modular per-layer path also needs P0 / P1).
+struct FwdBufs { float* h0; float* gate; float* wgt; float* yhat; float* P0; float* P1; };
+struct FwdWs {
+  DevBuf<float> h0, gate, wgt, yhat, P0, P1;
+  int B = 0, Ip = 0, T = 0;
+  FwdBufs bufs() { return FwdBufs{h0.p, gate.p, wgt.p, yhat.p, P0.p, P1.p}; }
+  // (re)allocates for B rows on `st` (zeroed there: h0's pad columns must be 0, never NaN); modular: also P0 / P1
+  int ensure(int Bn, int Ipn, int Tn, int H1p, int H2p, bool modular, hipStream_t st) {
+    if (Bn <= B && Ipn == Ip && Tn == T && h0.p && (!modular || P0.p)) return 0;
+    GOCTR_HIP(hipStreamSynchronize(st));       // launches still reading the old buffers
+    auto z = [&](DevBuf<float>& b, size_t n) -> int {
+      if (b.alloc(n, false)) return -1;
+      GOCTR_HIP(hipMemsetAsync(b.p, 0, n * sizeof(float), st));
+      return 0;
+    };
+    const size_t Br = (size_t)round_up(Bn, 32);
+    if (z(h0, Br * Ipn) || z(gate, Br * Tn) || z(wgt, Br * Tn) || z(yhat, Br)) return -1;
+    if (modular && (z(P0, Br * H1p) || z(P1, Br * H2p))) return -1;
+    B = Bn; Ip = Ipn; T = Tn;
+    return 0;
   }
 };
 
@@ -91,12 +129,18 @@ struct goctr_model {
   float* wgt_p(int par) { return wgt.p + (size_t)par * gw_stride; }
   DevBuf<unsigned int> ra_flag;   // pipelined steps: gstep + 1 of the last step whose att0 update is visible device-wide (reduce_attn_kernel)
   DevBuf<float> yall;          // scores of a whole predict call (one device-to-host copy at the end)
+  FwdWs pws;                   // forward-only workspace of goctr_predict_* (the training workspace and its graphs stay untouched)
   DevBuf<StepState> st, pst;   // st: two ping-pong slots, stp = the one the next step reads
   int stp = 0;
   StepState* st_cur() { return st.p + stp; }
   StepState* st_next() { return st.p + (stp ^ 1); }
   DevBuf<float> costs;
-  std::mutex mu;
+  // exclusive: everything that writes weights, optimizer state or the model's own workspaces (training, set_weights,
+  // goctr_predict_* on the model's predict workspace); shared: the serving slots' forward passes (ServeSlot below)
+  std::shared_mutex mu;
+  // recorded on the main stream behind the last queued launch that writes the weights (training is asynchronous): a
+  // serving slot's stream waits for it before it reads them
+  hipEvent_t ev_weights = nullptr; bool weights_pending = false;
   StepGraph graph;
   int attp_blocks = 0;
   // trainable-embedding extension (emb_train.h): off unless goctr_model_set_embedding_training(lr > 0)
@@ -156,7 +200,23 @@ TnSchedule tn_schedule(const goctr_model* m, int B) {
 // time), so each problem gets its own slab height, in whole 32-row chunks: the pair (c0, c1) that minimises the longest
 // workgroup subject to one workgroup per CU.
 struct TnWide { bool ok; int ktw0, kblocks0, nbt; int rows0, S0, rows1, S1, rowsL, SL; };
+TnWide tn_schedule_wide_search(const goctr_model* m, int B);
+// the search is O((B/32)^2) (65 k iterations at B = 8192): graph replay hides it, the eager paths (data-parallel embedding
+// training, profiling, GOCTR_NO_GRAPH) would pay it on every step -- cached per shape and experiment-knob setting
 TnWide tn_schedule_wide(const goctr_model* m, int B) {
+  static std::mutex mu;
+  static std::map<std::array<int, 12>, TnWide> cache;
+  const std::array<int, 12> key{B, m->Ip, m->H1p, m->H2p, m->cfg.kind, engine().compute_units, env_int("GOCTR_TN_WIDE", 1),
+                                env_int("GOCTR_TN_FIX0", 512), env_int("GOCTR_TN_FIX1", 384), env_int("GOCTR_TN_C0", 0),
+                                env_int("GOCTR_TN_C1", 0), env_int("GOCTR_TN_RL", 0)};
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  const TnWide w = tn_schedule_wide_search(m, B);
+  cache.emplace(key, w);
+  return w;
+}
+TnWide tn_schedule_wide_search(const goctr_model* m, int B) {
   TnWide w{};
   const int kt0 = m->Ip / 16, nt = m->H1p / 16, kt1 = m->H2p / 16;
   w.ok = (kt0 == 9 || kt0 == 15) && kt1 == 5 && nt > 8 && nt <= 16 && env_int("GOCTR_TN_WIDE", 1) != 0;
@@ -347,6 +407,14 @@ int launch_attn_fwd(const AttnArgs& a) {
   // compile-time mode for the shapes that matter (id mode, every lane owns 4 in-range columns)
   const int fast = !(vec4 && groups * 4 == a.D && (groups & (groups - 1)) == 0) ? 0
                    : a.kind != GOCTR_DIN ? 1 : (a.att == GOCTR_ATT_COSINE ? 2 : 3);
+  if (ps.on) {   // the symbol the dispatch below selects (goctr_prof_kernel)
+    static char sym[48];
+    int L = 1;
+    while (L < groups) L *= 2;
+    if (!vec4 && L < 8) L = 8;
+    snprintf(sym, sizeof sym, "attn_fwd_kernel<%d,%d,%d>", vec4 ? 4 : 1, std::min(L, 64), (fast && groups <= 16) ? fast : 0);
+    prof_note_kernel(GOCTR_K_ATTN_FWD, sym);
+  }
 #define GOCTR_ATTN_FWD(V, L) hipLaunchKernelGGL((attn_fwd_kernel<V, L, 0>), grid, blk, 0, st, a)
 #define GOCTR_ATTN_FWD_FAST(L)                                                                     \
   do {                                                                                             \
@@ -467,27 +535,31 @@ void launch_chain_x3_n(const ChainX3Args& a, dim3 grid, hipStream_t s, bool fwd)
   else hipLaunchKernelGGL((ctr_chain_x3_kernel<NCH0, false>), grid, dim3(512), chain_x3_lds_bytes<NCH0>(), s, a);
 }
 
-int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st) {
+int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st, const FwdBufs& fb) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
   const uint32_t row_off = (uint32_t)(e.rank * B);
   const bool drop = o.drop_mode == 2;
   const CxImages im = m->x3_images();
   ChainX3Args a{};
-  a.h0 = m->h0.p; a.Ip = m->Ip;
+  a.h0 = fb.h0; a.Ip = m->Ip;
   a.img0 = im.img0; a.img1 = im.img1; a.img2 = im.img2; a.img3 = im.img3; a.w2 = m->W2T.p;
   a.H1 = c.H1; a.H2 = c.H2; a.H1p = m->H1p; a.H2p = m->H2p; a.Dp = m->Dp; a.B = B; a.kind = c.kind;
   a.d0 = DropCfg{drop && o.p0 > 0 ? 2 : 0, o.p0, nullptr, c.H1, o.seed, 0u, row_off};
   a.d1 = DropCfg{drop && o.p1 > 0 ? 2 : 0, o.p1, nullptr, c.H2, o.seed, 1u, row_off};
   a.st = st; a.Y = src.Y; a.rows = src.rows; a.inv_bglobal = 1.0f / (float)(B * e.world);
-  a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;
-  a.yhat = m->yhat.p; a.lossrow = m->lossrow.p;
+  a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;   // (forward only: none of these is touched)
+  a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
   static DevBuf<unsigned long long> dbgbuf;
-  const bool dbg = env_int("GOCTR_CHAIN_DBG", 0) != 0;
+  const bool dbg = o.train && env_int("GOCTR_CHAIN_DBG", 0) != 0;
   if (dbg && !dbgbuf.p && dbgbuf.alloc(8 * CX_NSTAMP)) return -1;
   a.dbg = dbg ? dbgbuf.p : nullptr;
   ProfScope ps(GOCTR_K_CHAIN);
   const dim3 grid((unsigned)cdiv(B, 32));
+  static const char* const kSym[3][2] = {{"ctr_chain_x3_kernel<2,false>", "ctr_chain_x3_kernel<2,true>"},
+                                         {"ctr_chain_x3_kernel<9,false>", "ctr_chain_x3_kernel<9,true>"},
+                                         {"ctr_chain_x3_kernel<15,false>", "ctr_chain_x3_kernel<15,true>"}};
+  if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, kSym[m->x3_nch0 == 2 ? 0 : m->x3_nch0 == 9 ? 1 : 2][o.train ? 0 : 1]);
   switch (m->x3_nch0) {
     case 2: launch_chain_x3_n<2>(a, grid, e.active, !o.train); break;
     case 9: launch_chain_x3_n<9>(a, grid, e.active, !o.train); break;
@@ -505,14 +577,14 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   return 0;
 }
 
-int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st) {
-  if (chain_x3_ok(m, o, B)) return launch_chain_x3(m, src, B, o, st);
+int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st, const FwdBufs& fb) {
+  if (chain_x3_ok(m, o, B)) return launch_chain_x3(m, src, B, o, st, fb);
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
   const uint32_t row_off = (uint32_t)(e.rank * B);
   const bool drop = o.train && o.drop_mode != 0;
   ChainArgs a{};
-  a.h0 = m->h0.p; a.Ip = m->Ip;
+  a.h0 = fb.h0; a.Ip = m->Ip;
   a.W0i = m->img(0); a.W1i = m->img(1); a.W1Ti = m->img(2); a.W0sTi = m->img(3); a.w2 = m->W2T.p;
   a.H1 = c.H1; a.H2 = c.H2; a.H1p = m->H1p; a.H2p = m->H2p; a.Dp = m->Dp; a.B = B;
   a.train = o.train ? 1 : 0; a.kind = c.kind;
@@ -520,10 +592,10 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
   a.d1 = DropCfg{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
   a.st = st; a.Y = src.Y; a.rows = src.rows; a.inv_bglobal = 1.0f / (float)(B * e.world);
   a.buf_floats = chain_buf_floats(m->Ip, m->H1p, m->H2p);
-  a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;
-  a.yhat = m->yhat.p; a.lossrow = m->lossrow.p;
+  a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;   // (forward only: none of these is touched)
+  a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
   static DevBuf<unsigned long long> dbgbuf;
-  const bool dbg = env_int("GOCTR_CHAIN_DBG", 0) != 0;
+  const bool dbg = o.train && env_int("GOCTR_CHAIN_DBG", 0) != 0;
   if (dbg && !dbgbuf.p && dbgbuf.alloc(CHAIN_NSTAMP)) return -1;
   a.dbg = dbg ? dbgbuf.p : nullptr;
   ProfScope ps(GOCTR_K_CHAIN);
@@ -532,11 +604,12 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
   const int dmode = (a.d0.mode || a.d1.mode) ? o.drop_mode : 0;
   // forward only and too few rows to give every CU a 32-row workgroup: 16-row workgroups, H1 split over 4 wavefronts
   if (!o.train && cdiv(B, 32) < e.compute_units && env_int("GOCTR_NO_FWD16", 0) == 0) {
+    if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, "ctr_fwd16_kernel<4,5>");
     hipLaunchKernelGGL((ctr_fwd16_kernel<4, 5>), dim3((unsigned)cdiv(B, 16)), dim3(512), lds, e.active, a);
   } else
-  if (dmode == 0) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 0>), grid, dim3(512), lds, e.active, a);
-  else if (dmode == 1) hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 1>), grid, dim3(512), lds, e.active, a);
-  else hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 2>), grid, dim3(512), lds, e.active, a);
+  if (dmode == 0) { if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, "ctr_chain_kernel<7,5,0>"); hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 0>), grid, dim3(512), lds, e.active, a); }
+  else if (dmode == 1) { if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, "ctr_chain_kernel<7,5,1>"); hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 1>), grid, dim3(512), lds, e.active, a); }
+  else { if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, "ctr_chain_kernel<7,5,2>"); hipLaunchKernelGGL((ctr_chain_kernel<7, 5, 2>), grid, dim3(512), lds, e.active, a); }
   GOCTR_HIP(hipGetLastError());
   if (dbg) {
     unsigned long long h[CHAIN_NSTAMP];
@@ -552,13 +625,17 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
 
 // forward part: kernels 1-4
 // `par`: which copy of gate / wgt the launch writes (the parity of the step the gather belongs to)
-AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, int par) {
+FwdBufs train_bufs(goctr_model* m, int par) { return FwdBufs{m->h0.p, m->gate_p(par), m->wgt_p(par), m->yhat.p, m->P0.p, m->P1.p}; }
+AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb) {
   const goctr_ctr_cfg& c = m->cfg;
   AttnArgs aa{};
   aa.src = src; aa.st = st; aa.B = B; aa.U = c.U; aa.T = c.T; aa.D = c.D; aa.C = c.C; aa.Ip = m->Ip;
-  aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = m->h0.p; aa.gate = m->gate_p(par); aa.wgt = m->wgt_p(par);
+  aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = fb.h0; aa.gate = fb.gate; aa.wgt = fb.wgt;
   aa.Tp_att = m->Tp;
   return aa;
+}
+AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, int par) {
+  return make_attn_args(m, src, B, st, train_bufs(m, par));
 }
 
 // the compile-time mode launch_attn_fwd picks for this model's rows, or 0; `groups` = lanes per embedding row
@@ -599,28 +676,32 @@ int launch_reduce_attn(goctr_model* m, const RowSource& src, int B, const Reduce
   return 0;
 }
 
-int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st_override = nullptr) {
+// fbp: where a forward-only pass keeps its rows (null: the training workspace)
+int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st_override = nullptr,
+                   const FwdBufs* fbp = nullptr) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
   const StepState* st = st_override ? st_override : m->st_cur();
+  const FwdBufs fb = fbp ? *fbp : train_bufs(m, m->stp);
   if (!o.pipelined) {
-    const AttnArgs aa = make_attn_args(m, src, B, st, m->stp);
+    const AttnArgs aa = make_attn_args(m, src, B, st, fb);
     if (launch_attn_fwd(aa)) return -1;
   }
-  if (chain_ok(m)) return launch_chain(m, src, B, o, st);  // layers + (when training) backward-data, fused
+  if (chain_ok(m)) return launch_chain(m, src, B, o, st, fb);  // layers + (when training) backward-data, fused
 
   const int bglobal = B * e.world;
   const uint32_t row_off = (uint32_t)(e.rank * B);
   const bool drop = o.train && o.drop_mode != 0;
   DropCfg d0{drop && o.p0 > 0 ? o.drop_mode : 0, o.p0, m->mask0.p, c.H1, o.seed, 0u, row_off};
   DropCfg d1{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
-  EpiSigDrop e0{m->P0.p, d0.mode ? m->A0.p : m->P0.p, m->H1p, c.H1, d0, st};
-  if (launch_nn(GOCTR_K_GEMM_FWD0, m->h0.p, m->Ip, m->W.p, m->H1p, B, m->Ip, m->H1p, e0)) return -1;
-  const float* A0 = d0.mode ? m->A0.p : m->P0.p;
-  EpiSigDrop e1{m->P1.p, d1.mode ? m->A1.p : m->P1.p, m->H2p, c.H2, d1, st};
+  // (forward only: no dropout, so the post-dropout copies A0 / A1 are not written)
+  EpiSigDrop e0{fb.P0, d0.mode ? m->A0.p : fb.P0, m->H1p, c.H1, d0, st};
+  if (launch_nn(GOCTR_K_GEMM_FWD0, fb.h0, m->Ip, m->W.p, m->H1p, B, m->Ip, m->H1p, e0)) return -1;
+  const float* A0 = d0.mode ? m->A0.p : fb.P0;
+  EpiSigDrop e1{fb.P1, d1.mode ? m->A1.p : fb.P1, m->H2p, c.H2, d1, st};
   if (launch_nn(GOCTR_K_GEMM_FWD1, A0, m->H1p, m->W.p + m->off1, m->H2p, B, m->H1p, m->H2p, e1)) return -1;
-  const float* A1 = d1.mode ? m->A1.p : m->P1.p;
-  EpiOut eo{m->yhat.p, o.train ? m->lossrow.p : nullptr, o.train ? m->dz2.p : nullptr, src.Y, src.rows, st, B,
+  const float* A1 = d1.mode ? m->A1.p : fb.P1;
+  EpiOut eo{fb.yhat, o.train ? m->lossrow.p : nullptr, o.train ? m->dz2.p : nullptr, src.Y, src.rows, st, B,
             1.0f / (float)bglobal};
   if (launch_nn(GOCTR_K_GEMM_OUT, A1, m->H2p, m->W.p + m->off2, 16, B, m->H2p, 16, eo)) return -1;
   return 0;
@@ -798,6 +879,11 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   const dim3 gg = cache ? gb : dim3((unsigned)std::min<long long>(cdiv(B, EMB_GRAD_THREADS / 64), 8 * cus));
   {
     ProfScope ps(GOCTR_K_EMB_GRAD);
+    if (ps.on) {
+      static char sym[48];
+      snprintf(sym, sizeof sym, "emb_grad_kernel<%d,%d,%s>", c.D <= 16 ? 16 : c.D <= 32 ? 32 : 64, mode, cache ? "true" : "false");
+      prof_note_kernel(GOCTR_K_EMB_GRAD, sym);
+    }
     if (c.D <= 16) launch_emb_grad<16>(mode, cache, gg, lds, s, a, nslot);
     else if (c.D <= 32) launch_emb_grad<32>(mode, cache, gg, lds, s, a, nslot);
     else launch_emb_grad<64>(mode, cache, gg, lds, s, a, nslot);
@@ -876,6 +962,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     tm.dbg = dbg ? tndbgw.p : nullptr;
     {
       ProfScope ps(GOCTR_K_DW0);
+      if (ps.on) prof_note_kernel(GOCTR_K_DW0, tw.ktw0 == 9 ? "gemm_tn_multi_x3w_kernel<9,5>" : "gemm_tn_multi_x3w_kernel<8,5>");
       if (tw.ktw0 == 9)
         hipLaunchKernelGGL((gemm_tn_multi_x3w_kernel<9, 5>), dim3((unsigned)nblk), dim3(512), gemm_tn_multi_x3w_lds_bytes<9>(), e.stream, tm);
       else
@@ -915,6 +1002,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     tm.dbg = dbg ? tndbg.p : nullptr;
     {
       ProfScope ps(GOCTR_K_DW0);
+      if (ps.on) prof_note_kernel(GOCTR_K_DW0, (env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32) ? "gemm_tn_multi_x3_kernel<3,4>" : "gemm_tn_multi_kernel<3,4,32>");
       // default: the 6-product bf16 split (mfma_gemm.h); GOCTR_TN_F32=1 selects the v_mfma_f32_16x16x4_f32 body
       if (env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32)
         hipLaunchKernelGGL((gemm_tn_multi_x3_kernel<3, 4>), dim3((unsigned)nblk), dim3(512), gemm_tn_multi_x3_lds_bytes<3>(nt_max), e.stream, tm);
@@ -1143,8 +1231,21 @@ int check_dataset(const goctr_model* m, const goctr_dataset* d, const goctr_emb*
   return 0;
 }
 
+// behind the last queued launch that writes the weights: what a serving slot's stream waits for (serve_wait_weights)
+int mark_weights_written(goctr_model* m) {
+  if (!m->ev_weights) GOCTR_HIP(hipEventCreateWithFlags(&m->ev_weights, hipEventDisableTiming));
+  GOCTR_HIP(hipEventRecord(m->ev_weights, engine().stream));
+  m->weights_pending = true;
+  return 0;
+}
+
 // queue n_steps training steps (graph replay unless profiling / disabled)
+int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* tc, int n_steps);
 int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* tc, int n_steps) {
+  if (run_steps_impl(m, emb, d, tc, n_steps)) return -1;
+  return n_steps > 0 ? mark_weights_written(m) : 0;
+}
+int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* tc, int n_steps) {
   Engine& e = engine();
   const int B = tc->batch;
   if (ensure_workspace(m, B)) return -1;
@@ -1334,23 +1435,25 @@ int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
 void goctr_model_destroy(goctr_model* m) {
   if (!m) return;
   std::lock_guard<std::recursive_mutex> lk(engine_mutex());
-  if (engine().inited) (void)hipStreamSynchronize(engine().stream);
+  if (engine().inited) (void)hipDeviceSynchronize();
   m->graph.destroy();
+  if (m->ev_weights) (void)hipEventDestroy(m->ev_weights);
   delete m;
 }
 
 int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, size_t n) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && host, "goctr_model_set_weights: null argument");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   if (upload_padded_weights(m, tensor_id, host, n)) return -1;
-  return (tensor_id == GOCTR_W0 || tensor_id == GOCTR_W1) ? rebuild_x3_images(m) : 0;
+  if ((tensor_id == GOCTR_W0 || tensor_id == GOCTR_W1) && rebuild_x3_images(m)) return -1;
+  return mark_weights_written(m);
 }
 
 int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && host, "goctr_model_get_weights: null argument");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   return download_padded(m, m->W.p, tensor_id, host, n);
 }
 
@@ -1392,14 +1495,14 @@ int upload_padded_flat(goctr_model* m, float* flat_dev, int tensor_id, const flo
 int goctr_model_get_moments(goctr_model* m, int tensor_id, int which, float* host, size_t n) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && host && (which == 0 || which == 1), "goctr_model_get_moments: bad argument");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   return download_padded(m, which ? m->Vo.p : m->Mo.p, tensor_id, host, n);
 }
 
 int goctr_model_set_moments(goctr_model* m, int tensor_id, int which, const float* host, size_t n) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && host && (which == 0 || which == 1), "goctr_model_set_moments: bad argument");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   return upload_padded_flat(m, which ? m->Vo.p : m->Mo.p, tensor_id, host, n);
 }
 
@@ -1407,7 +1510,7 @@ int goctr_model_set_moments(goctr_model* m, int tensor_id, int which, const floa
 int goctr_model_get_step(goctr_model* m, uint32_t* step) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && step, "goctr_model_get_step: null argument");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   StepState s;
   if (get_state(m, &s)) return -1;
   *step = s.gstep;
@@ -1417,14 +1520,14 @@ int goctr_model_get_step(goctr_model* m, uint32_t* step) {
 int goctr_model_set_step(goctr_model* m, uint32_t step) {
   GOCTR_ENTER();
   GOCTR_CHECK(m, "goctr_model_set_step: null argument");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   return set_state(m, step, 0, 0, 1);
 }
 
 int goctr_model_set_embedding_training(goctr_model* m, double lr) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && lr >= 0 && lr == lr, "goctr_model_set_embedding_training: bad arguments");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   GOCTR_CHECK(lr == 0 || m->cfg.D <= 64, "embedding training supports D <= 64 (got %d)", m->cfg.D);
   m->emb_lr = (float)lr;
   m->graph.destroy();
@@ -1434,7 +1537,7 @@ int goctr_model_set_embedding_training(goctr_model* m, double lr) {
 int goctr_model_sparse_exchange_bytes(goctr_model* m, double* bytes) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && bytes, "goctr_model_sparse_exchange_bytes: null argument");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   *bytes = engine().comm_active() ? m->ex_bytes_last : 0.0;
   return 0;
 }
@@ -1447,7 +1550,7 @@ int goctr_emb_get_rows(goctr_emb* e, int64_t first, int64_t n, float* host_rows)
 
 int goctr_model_reset_optimizer(goctr_model* m) {
   GOCTR_ENTER();
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
   GOCTR_HIP(hipMemsetAsync(m->Vo.p, 0, sizeof(float) * m->nflat, engine().stream));
   return set_state(m, 0, 0, 0, 1);
@@ -1686,7 +1789,7 @@ int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const go
   GOCTR_CHECK(d->has_y, "goctr_train_steps: dataset has no labels");
   GOCTR_CHECK(cfg->dropout_mode == 0 || cfg->dropout_mode == 2, "multi-step training supports dropout_mode 0 or 2");
   GOCTR_CHECK(n_steps <= COST_RING, "n_steps > %d per call", COST_RING);
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   if (check_dataset(m, d, emb)) return -1;
   const long long nb = cdiv(d->rows, cfg->batch);
   if (retarget_state(m, first_batch % nb, nb)) return -1;      // no host synchronisation on this path
@@ -1704,7 +1807,7 @@ int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const 
   GOCTR_CHECK(m && d && cfg && cfg->batch > 0 && cfg->epochs >= 0, "goctr_train_dataset: bad arguments");
   GOCTR_CHECK(d->has_y, "goctr_train_dataset: dataset has no labels");
   GOCTR_CHECK(cfg->dropout_mode == 0 || cfg->dropout_mode == 2, "multi-step training supports dropout_mode 0 or 2");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   if (check_dataset(m, d, emb)) return -1;
   // a fresh solver per model.Train call (model.go:88)
   GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
@@ -1753,7 +1856,7 @@ int goctr_train_dense(goctr_model* m, const float* X, const float* Y, int64_t ro
   int rc = goctr_train_dataset(m, nullptr, d, cfg, epoch_costs, epochs_run);
   if (!rc) rc = goctr_sync();
   {
-    std::lock_guard<std::mutex> lk(m->mu);
+    std::unique_lock<std::shared_mutex> lk(m->mu);
     m->graph.destroy();  // (keyed on the dataset's generation id, so it could never be replayed again anyway)
   }
   goctr_dataset_destroy(d);
@@ -1768,7 +1871,7 @@ int goctr_loss_grad_dense(goctr_model* m, const float* X, const float* Y, int va
   goctr_dataset* d = nullptr;
   if (goctr_dataset_create_dense(X, Y, valid, xcols, ranges, &d)) return -1;
   std::unique_ptr<goctr_dataset> guard(d);
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   if (check_dataset(m, d, nullptr)) return -1;
   if (ensure_workspace(m, B)) return -1;
   StepOpts o = opts_from(cfg);
@@ -1819,7 +1922,10 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
   // Measured at DIN cfg3, PredBatchSize 4096: 250 / 351 / 416 / 444 M rows/s at G = 1 / 2 / 4 / 8 (GOCTR_PRED_GROUP).
   int G = std::max(1, env_int("GOCTR_PRED_GROUP", 4));
   while (G > 1 && (long long)batch * G > 32768) G /= 2;     // (a launch of 32 768 rows fills the chip; the workspace grows with G)
-  if (ensure_workspace(m, batch * G)) return -1;
+  // forward-only workspace of its own (h0, gates, yhat): the training workspace -- sized for the training batch, with its
+  // slab buffers and captured step graphs -- is left alone
+  if (m->pws.ensure(batch * G, m->Ip, m->cfg.T, m->H1p, m->H2p, !chain_ok(m), engine().stream)) return -1;
+  const FwdBufs fb = m->pws.bufs();
   RowSource src = make_source(d, emb);
   StepOpts o;
   o.train = false;
@@ -1847,12 +1953,12 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
     for (int64_t k = 0; k < cnt; ++k) {
       if (grp[k] == 0) continue;                      // (covered by the group that started before it)
       const int Bk = batch * grp[k];
-      if (launch_forward(m, src, Bk, o, m->pst.p + k)) return -1;
+      if (launch_forward(m, src, Bk, o, m->pst.p + k, &fb)) return -1;
       if (y_host) {
         const long long b = hs[k].batch_idx;
         const long long start = b * Bk, end = std::min<long long>(start + Bk, d->rows);
         // first end-start outputs (model.go:344-347), collected on the device: one copy to the host per call
-        GOCTR_HIP(hipMemcpyAsync(m->yall.p + start, m->yhat.p, sizeof(float) * (size_t)(end - start), hipMemcpyDeviceToDevice,
+        GOCTR_HIP(hipMemcpyAsync(m->yall.p + start, fb.yhat, sizeof(float) * (size_t)(end - start), hipMemcpyDeviceToDevice,
                                  engine().stream));
       }
     }
@@ -1869,7 +1975,7 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
 int goctr_predict_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, float* y_out) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && d && y_out && batch > 0, "goctr_predict_dataset: bad arguments");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   return predict_batches(m, emb, d, batch, 0, cdiv(d->rows, batch), y_out);
 }
 
@@ -1877,40 +1983,283 @@ int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int ba
                         int n_batches) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && d && batch > 0 && n_batches >= 0, "goctr_predict_steps: bad arguments");
-  std::lock_guard<std::mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu);
   return predict_batches(m, emb, d, batch, first_batch, n_batches, nullptr);
-}
-
-int goctr_predict_dense(goctr_model* m, const float* X, int64_t rows, int xcols, const int ranges[8], int batch,
-                        float* y_out) {
-  GOCTR_ENTER();
-  GOCTR_CHECK(m && X && y_out && rows >= 0 && batch > 0, "goctr_predict_dense: bad arguments");
-  if (rows == 0) return 0;
-  goctr_dataset* d = nullptr;
-  if (goctr_dataset_create_dense(X, nullptr, rows, xcols, ranges, &d)) return -1;
-  int rc = goctr_predict_dataset(m, nullptr, d, batch, y_out);
-  goctr_dataset_destroy(d);
-  return rc;
 }
 
 }  // extern "C"
 
-// ------------------------------------------------------------------ recommend.BatchPredict / Rank
-// recommend/rcmd.go:248-337: sample keys -> GetSampleVector rows -> PredictAbstract.Predict -> scores.  Everything
-// GetSampleVector reads per key (rcmd.go:462-536) is resident in HBM: the user / item feature tables (the contents of
-// UserFeatureCache / ItemFeatureCache), the behaviour cache and the item-embedding table, so one call is: copy the keys
-// (16 B each), one assembly launch, the predict launches, copy the scores back.
+// ------------------------------------------------------------------ serving: recommend.BatchPredict / Rank / Predict
+// recommend/rcmd.go:248-337: sample keys -> GetSampleVector rows -> PredictAbstract.Predict -> scores, called from concurrent
+// gin handler goroutines (recommend/api.go:106-131: one user, a short itemIdList per request).  Everything GetSampleVector
+// reads per key (rcmd.go:462-536) is resident in HBM -- the user / item feature tables (the contents of UserFeatureCache /
+// ItemFeatureCache), the behaviour cache, the item-embedding table -- so one call is: keys (16 B each) to the device, one
+// assembly launch, the forward launches, scores back.
+//
+// Concurrency.  These entry points do not take the engine lock and do not use the engine's main stream.  A call borrows a
+// SERVING SLOT: its own HIP stream, pinned host staging for keys and scores (one H2D and one D2H copy per pass, both
+// asynchronous on the slot's stream; no per-call allocation, no std::vector copies), the id-mode rows assembled from the
+// keys and a forward workspace.  It holds the model's lock SHARED (training holds it exclusive), and its stream waits for
+// the event the last weight-writing call recorded on the main stream -- training is asynchronous.  Slots: GOCTR_SERVE_SLOTS
+// (default 4), created on first use; further callers wait for a free one.
+//
+// Micro-batching.  A Rank request is tens to hundreds of rows: three small launches and two copies whose cost is latency,
+// not work.  Requests of <= GOCTR_SERVE_COALESCE rows (default 1024) go through a combining queue per recsys: the first
+// arrival becomes the leader and serves its own request; whatever arrives on the same model while that pass is in flight is
+// taken over as ONE pass (<= 4096 rows) by the next leader -- one of the waiting callers, so no thread serves others after
+// its own result is ready.  Rows are scored independently and passes of < 8192 rows all run the same forward kernel
+// (ctr_fwd16_kernel), so a request's scores are bit-identical whether or not, and with whatever, it was coalesced.
 struct goctr_recsys {
   goctr_ubcache* ub = nullptr;    // not owned
   goctr_emb* emb = nullptr;       // not owned
   int64_t n_users = 0, n_items = 0; int U = 0, C = 0;
   DevBuf<float> user_table, item_table;
-  // per-call scratch, grown on demand: the keys and the id-mode rows assembled from them
-  int64_t cap = 0; int capT = 0;
-  DevBuf<int32_t> users, items; DevBuf<long long> ts; DevBuf<unsigned char> failed;
-  goctr_dataset scratch;
-  std::mutex mu;
+  // combining queue of small requests (micro-batcher)
+  struct Req;
+  std::mutex qmu; std::condition_variable qcv;
+  std::vector<Req*> queue; bool leader = false;
 };
+
+namespace {
+
+constexpr int64_t SERVE_PASS_ROWS = 65536;      // rows one pass of a slot scores (larger requests: several passes)
+constexpr int64_t SERVE_COALESCE_ROWS = 4096;   // rows one coalesced pass may hold (< 8192: always ctr_fwd16_kernel)
+
+// one request's keys and outputs (host pointers of the caller)
+struct KeySeg {
+  const int32_t* users; int32_t user_all;       // users == null: every key has user_all (Rank)
+  const int32_t* items;
+  const int64_t* ts; int64_t ts_all;            // ts == null: every key has ts_all
+  int64_t n;
+  float* scores; uint8_t* failed; int64_t n_failed;
+};
+
+struct ServeSlot {
+  hipStream_t stream = nullptr;
+  int64_t cap = 0; int T = 0, U = 0, C = 0;
+  // pinned staging: in = [ts i64 x N | users i32 x N | items i32 x N], out = [scores f32 x Br | failed u8 x N]
+  char* h_in = nullptr; char* h_out = nullptr;
+  DevBuf<char> d_in, d_out;
+  DevBuf<int32_t> ub_ids, item_ids; DevBuf<float> ufeat, cfeat;
+  FwdWs ws;
+  DevBuf<StepState> st;            // one all-zero state: "batch 0 of 1"
+  DevBuf<float> X; size_t capX = 0;   // dense rows (goctr_predict_dense)
+  ~ServeSlot() {
+    if (h_in) (void)hipHostFree(h_in);
+    if (h_out) (void)hipHostFree(h_out);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  int init() {
+    GOCTR_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (st.alloc(1, false)) return -1;
+    const StepState z{0u, 0u, 0, 1};
+    GOCTR_HIP(hipMemcpyAsync(st.p, &z, sizeof z, hipMemcpyHostToDevice, stream));
+    GOCTR_HIP(hipStreamSynchronize(stream));
+    return 0;
+  }
+  // room for n keys of a model / recsys with these widths
+  int ensure_keys(int64_t n, int Tn, int Un, int Cn) {
+    if (n <= cap && Tn == T && Un == U && Cn == C) return 0;
+    GOCTR_HIP(hipStreamSynchronize(stream));
+    const int64_t want = std::max<int64_t>(std::max<int64_t>(n, 256), std::min<int64_t>(2 * cap, SERVE_PASS_ROWS));
+    const size_t Br = (size_t)round_up((int)want, 32);
+    if (h_in) { (void)hipHostFree(h_in); h_in = nullptr; }
+    if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; }
+    GOCTR_HIP(hipHostMalloc((void**)&h_in, (size_t)want * 16, hipHostMallocDefault));
+    GOCTR_HIP(hipHostMalloc((void**)&h_out, Br * 4 + (size_t)want, hipHostMallocDefault));
+    if (d_in.alloc((size_t)want * 16, false) || d_out.alloc(Br * 4 + (size_t)want, false) ||
+        ub_ids.alloc((size_t)want * Tn, false) || item_ids.alloc((size_t)want, false) ||
+        ufeat.alloc((size_t)want * Un, false) || cfeat.alloc((size_t)want * Cn, false)) return -1;
+    cap = want; T = Tn; U = Un; C = Cn;
+    return 0;
+  }
+};
+
+struct ServePool {
+  std::mutex mu; std::condition_variable cv;
+  std::vector<std::unique_ptr<ServeSlot>> all; std::vector<ServeSlot*> idle;
+  ServeSlot* acquire() {
+    std::unique_lock<std::mutex> lk(mu);
+    const size_t max_slots = (size_t)std::max(1, env_int("GOCTR_SERVE_SLOTS", 4));
+    for (;;) {
+      if (!idle.empty()) { ServeSlot* s = idle.back(); idle.pop_back(); return s; }
+      if (all.size() < max_slots) {
+        std::unique_ptr<ServeSlot> s(new ServeSlot);
+        if (s->init()) return nullptr;
+        all.push_back(std::move(s));
+        return all.back().get();
+      }
+      cv.wait(lk);
+    }
+  }
+  void release(ServeSlot* s) {
+    { std::lock_guard<std::mutex> lk(mu); idle.push_back(s); }
+    cv.notify_one();
+  }
+  // (goctr_*_destroy of something a slot may have buffers sized for: nothing to do -- slots hold no handle pointers)
+};
+ServePool& serve_pool() { static ServePool p; return p; }
+struct SlotLease {
+  ServeSlot* s;
+  SlotLease() : s(serve_pool().acquire()) {}
+  ~SlotLease() { if (s) serve_pool().release(s); }
+};
+
+// the slot's stream must see every weight write queued on the main stream so far (training is asynchronous)
+int serve_wait_weights(goctr_model* m, ServeSlot* s) {
+  if (m->weights_pending && m->ev_weights) GOCTR_HIP(hipStreamWaitEvent(s->stream, m->ev_weights, 0));
+  return 0;
+}
+
+// One pass: the keys of `segs` (N rows in all, N <= SERVE_PASS_ROWS) -> scores / failed flags of every segment.
+// Caller holds m->mu shared and owns the slot.
+int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const* segs, int nseg) {
+  int64_t N = 0;
+  for (int k = 0; k < nseg; ++k) N += segs[k]->n;
+  const int T = m->cfg.T;
+  if (s->ensure_keys(N, T, r->U, r->C)) return -1;
+  if (s->ws.ensure((int)N, m->Ip, T, m->H1p, m->H2p, !chain_ok(m), s->stream)) return -1;
+  const size_t Br = (size_t)round_up((int)N, 32);
+  long long* hts = reinterpret_cast<long long*>(s->h_in);
+  int32_t* hus = reinterpret_cast<int32_t*>(s->h_in + 8 * N);
+  int32_t* hit = reinterpret_cast<int32_t*>(s->h_in + 12 * N);
+  int64_t o = 0;
+  for (int k = 0; k < nseg; ++k) {
+    const KeySeg& g = *segs[k];
+    if (g.ts) memcpy(hts + o, g.ts, sizeof(int64_t) * (size_t)g.n);
+    else for (int64_t i = 0; i < g.n; ++i) hts[o + i] = g.ts_all;
+    if (g.users) memcpy(hus + o, g.users, sizeof(int32_t) * (size_t)g.n);
+    else for (int64_t i = 0; i < g.n; ++i) hus[o + i] = g.user_all;
+    memcpy(hit + o, g.items, sizeof(int32_t) * (size_t)g.n);
+    o += g.n;
+  }
+  GOCTR_HIP(hipMemcpyAsync(s->d_in.p, s->h_in, (size_t)N * 16, hipMemcpyHostToDevice, s->stream));
+  if (serve_wait_weights(m, s)) return -1;
+  const long long* dts = reinterpret_cast<const long long*>(s->d_in.p);
+  const int32_t* dus = reinterpret_cast<const int32_t*>(s->d_in.p + 8 * N);
+  const int32_t* dit = reinterpret_cast<const int32_t*>(s->d_in.p + 12 * N);
+  float* dscore = reinterpret_cast<float*>(s->d_out.p);
+  unsigned char* dfail = reinterpret_cast<unsigned char*>(s->d_out.p + 4 * Br);
+  const goctr_ubcache* c = r->ub;
+  StreamScope on_slot(s->stream);
+  hipLaunchKernelGGL(assemble_keys_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, s->stream,
+                     c ? c->off.p : (const long long*)nullptr, c ? c->items.p : (const int32_t*)nullptr,
+                     c ? c->ts.p : (const long long*)nullptr, (long long)r->n_users, r->user_table.p, r->U, r->item_table.p,
+                     (long long)r->n_items, r->C, dus, dit, dts, (long long)N, T, s->ub_ids.p, s->ufeat.p, s->cfeat.p,
+                     s->item_ids.p, dfail);
+  GOCTR_HIP(hipGetLastError());
+  RowSource src{};
+  src.rows = N; src.id_mode = 1; src.emb = r->emb->rows.p; src.V = r->emb->V;
+  src.ub_ids = s->ub_ids.p; src.item_ids = s->item_ids.p; src.ufeat = s->ufeat.p; src.cfeat = s->cfeat.p;
+  FwdBufs fb = s->ws.bufs();
+  fb.yhat = dscore;
+  StepOpts op;
+  op.train = false;
+  if (launch_forward(m, src, (int)N, op, s->st.p, &fb)) return -1;
+  bool want_failed = false;
+  for (int k = 0; k < nseg; ++k) want_failed = want_failed || segs[k]->failed || segs[k]->n_failed >= 0;
+  // scores and flags are adjacent: one copy back (the gap between them is < 128 bytes)
+  const size_t out_bytes = want_failed ? 4 * Br + (size_t)N : 4 * (size_t)N;
+  GOCTR_HIP(hipMemcpyAsync(s->h_out, s->d_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));
+  GOCTR_HIP(hipStreamSynchronize(s->stream));
+  const float* hs = reinterpret_cast<const float*>(s->h_out);
+  const unsigned char* hf = reinterpret_cast<const unsigned char*>(s->h_out + 4 * Br);
+  o = 0;
+  for (int k = 0; k < nseg; ++k) {
+    KeySeg& g = *segs[k];
+    memcpy(g.scores, hs + o, sizeof(float) * (size_t)g.n);
+    if (want_failed) {
+      if (g.failed) memcpy(g.failed, hf + o, (size_t)g.n);
+      int64_t cnt = 0;
+      for (int64_t i = 0; i < g.n; ++i) cnt += hf[o + i] != 0;
+      g.n_failed = cnt;
+    }
+    o += g.n;
+  }
+  return 0;
+}
+
+}  // namespace
+
+struct goctr_recsys::Req {
+  goctr_model* m; KeySeg seg; int rc = 0; bool done = false; std::string err;
+};
+
+namespace {
+
+// a request of any size on a slot of its own (several passes when it exceeds SERVE_PASS_ROWS)
+int serve_keys_direct(goctr_model* m, goctr_recsys* r, KeySeg& g) {
+  SlotLease lease;
+  if (!lease.s) return -1;
+  const int64_t want_failed = g.n_failed;
+  int64_t total_failed = 0;
+  for (int64_t o = 0; o < g.n; o += SERVE_PASS_ROWS) {
+    KeySeg part = g;
+    part.n = std::min<int64_t>(SERVE_PASS_ROWS, g.n - o);
+    if (g.users) part.users = g.users + o;
+    part.items = g.items + o;
+    if (g.ts) part.ts = g.ts + o;
+    part.scores = g.scores + o;
+    if (g.failed) part.failed = g.failed + o;
+    part.n_failed = want_failed;
+    KeySeg* one = &part;
+    if (serve_keys_pass(m, r, lease.s, &one, 1)) return -1;
+    if (part.n_failed > 0) total_failed += part.n_failed;
+  }
+  g.n_failed = total_failed;
+  return 0;
+}
+
+// the micro-batcher (see the section comment)
+int serve_keys_coalesced(goctr_model* m, goctr_recsys* r, KeySeg& g) {
+  goctr_recsys::Req me{m, g};
+  std::unique_lock<std::mutex> lk(r->qmu);
+  r->queue.push_back(&me);
+  while (!me.done) {
+    if (r->leader) { r->qcv.wait(lk); continue; }
+    // lead one pass: the longest prefix of the queue on one model that fits a pass (always contains the front)
+    r->leader = true;
+    std::vector<goctr_recsys::Req*> batch;
+    int64_t rows = 0;
+    goctr_model* bm = r->queue.front()->m;
+    size_t take = 0;
+    for (; take < r->queue.size(); ++take) {
+      goctr_recsys::Req* q = r->queue[take];
+      if (q->m != bm || (take > 0 && rows + q->seg.n > SERVE_COALESCE_ROWS)) break;
+      rows += q->seg.n;
+      batch.push_back(q);
+    }
+    r->queue.erase(r->queue.begin(), r->queue.begin() + (long)take);
+    lk.unlock();
+    int rc = 0;
+    std::string err;
+    {
+      SlotLease lease;
+      std::vector<KeySeg*> segs;
+      for (auto* q : batch) segs.push_back(&q->seg);
+      rc = lease.s ? serve_keys_pass(bm, r, lease.s, segs.data(), (int)segs.size()) : -1;
+      if (rc) err = goctr_last_error();
+    }
+    lk.lock();
+    for (auto* q : batch) { q->rc = rc; q->err = err; q->done = true; }
+    r->leader = false;
+    r->qcv.notify_all();
+  }
+  lk.unlock();
+  if (me.rc) set_error("%s", me.err.c_str());
+  g = me.seg;
+  return me.rc;
+}
+
+int serve_keys(goctr_model* m, goctr_recsys* r, KeySeg& g, int64_t* n_failed) {
+  std::shared_lock<std::shared_mutex> lm(m->mu);        // weights stay put while a slot reads them
+  const int64_t coalesce = std::min<int64_t>(std::max(0, env_int("GOCTR_SERVE_COALESCE", 1024)), SERVE_COALESCE_ROWS);
+  const int rc = g.n <= coalesce ? serve_keys_coalesced(m, r, g) : serve_keys_direct(m, r, g);
+  if (!rc && n_failed) *n_failed = g.n_failed;
+  return rc;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -1932,63 +2281,82 @@ int goctr_recsys_create(goctr_ubcache* c, goctr_emb* emb, const float* user_tabl
 void goctr_recsys_destroy(goctr_recsys* r) {
   if (!r) return;
   std::lock_guard<std::recursive_mutex> lk(engine_mutex());
-  if (engine().inited) (void)hipStreamSynchronize(engine().stream);
+  if (engine().inited) (void)hipDeviceSynchronize();      // (serving passes are synchronous: none is in flight once its caller returned)
   delete r;
 }
 
 int goctr_batch_predict(goctr_model* m, goctr_recsys* r, const int32_t* users, const int32_t* items, const int64_t* ts,
                         int64_t n, int batch, float* scores, uint8_t* failed, int64_t* n_failed) {
-  GOCTR_ENTER();
+  if (require_engine()) return -1;
   GOCTR_CHECK(m && r && users && items && scores && n >= 0 && batch > 0, "goctr_batch_predict: bad arguments");
+  GOCTR_CHECK(r->emb->D == m->cfg.D && r->U == m->cfg.U && r->C == m->cfg.C, "goctr_batch_predict: recsys dims (U=%d,C=%d,D=%d) != model (U=%d,C=%d,D=%d)",
+              r->U, r->C, r->emb->D, m->cfg.U, m->cfg.C, m->cfg.D);
   if (n_failed) *n_failed = 0;
   if (n == 0) return 0;
   // rcmd.go:293-296: a failing FIRST key aborts the call (there is no row width to build a zero row from yet)
   GOCTR_CHECK(users[0] >= 0 && users[0] < r->n_users && items[0] >= 0 && items[0] < r->n_items,
               "get sample vector error: first key (user %d, item %d) has no features", users[0], items[0]);
-  std::lock_guard<std::mutex> lk(r->mu);
-  const int T = m->cfg.T;
-  goctr_dataset& d = r->scratch;
-  if (n > r->cap || T != r->capT) {
-    const int64_t cap = std::max<int64_t>(n, 2 * r->cap);
-    GOCTR_HIP(hipStreamSynchronize(engine().stream));
-    if (r->users.alloc(cap, false) || r->items.alloc(cap, false) || r->ts.alloc(cap, false) || r->failed.alloc(cap, false) ||
-        d.ub_ids.alloc((size_t)cap * T, false) || d.item_ids.alloc(cap, false) || d.ufeat.alloc((size_t)cap * r->U, false) ||
-        d.cfeat.alloc((size_t)cap * r->C, false)) return -1;
-    r->cap = cap; r->capT = T;
-  }
-  d.id_mode = true; d.rows = n; d.U = r->U; d.C = r->C; d.T = T; d.has_y = false;
-  std::vector<long long> t(n, 0);
-  if (ts) for (int64_t i = 0; i < n; ++i) t[i] = ts[i];
-  if (r->users.upload(users, n) || r->items.upload(items, n) || r->ts.upload(t.data(), n)) return -1;
-  const goctr_ubcache* c = r->ub;
-  hipLaunchKernelGGL(assemble_keys_kernel, dim3((unsigned)cdiv(n, 4)), dim3(256), 0, engine().stream,
-                     c ? c->off.p : (const long long*)nullptr, c ? c->items.p : (const int32_t*)nullptr,
-                     c ? c->ts.p : (const long long*)nullptr, (long long)r->n_users, r->user_table.p, r->U, r->item_table.p,
-                     (long long)r->n_items, r->C, r->users.p, r->items.p, r->ts.p, (long long)n, T, d.ub_ids.p, d.ufeat.p,
-                     d.cfeat.p, d.item_ids.p, r->failed.p);
-  GOCTR_HIP(hipGetLastError());
-  {
-    std::lock_guard<std::mutex> lm(m->mu);
-    if (predict_batches(m, r->emb, &d, batch, 0, cdiv(n, batch), scores)) return -1;
-  }
-  if (failed || n_failed) {
-    std::vector<unsigned char> f(n);
-    if (r->failed.download(f.data(), n)) return -1;
-    int64_t cnt = 0;
-    for (int64_t i = 0; i < n; ++i) cnt += f[i] != 0;
-    if (failed) memcpy(failed, f.data(), n);
-    if (n_failed) *n_failed = cnt;
-  }
-  return 0;
+  // (PredBatchSize `batch` decides how model.Predict cuts the rows, model.go:337-347; a row's score does not depend on it)
+  KeySeg g{users, 0, items, ts, 0, n, scores, failed, (failed || n_failed) ? 0 : -1};
+  return serve_keys(m, r, g, n_failed);
 }
 
 int goctr_rank(goctr_model* m, goctr_recsys* r, int32_t user, const int32_t* items, int64_t n, int64_t ts, int batch,
                float* scores, uint8_t* failed, int64_t* n_failed) {
-  GOCTR_ENTER();
-  GOCTR_CHECK(items && n >= 0, "goctr_rank: bad arguments");
-  std::vector<int32_t> u((size_t)n, user);
-  std::vector<int64_t> t((size_t)n, ts);
-  return goctr_batch_predict(m, r, u.data(), items, t.data(), n, batch, scores, failed, n_failed);
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && r && items && scores && n >= 0 && batch > 0, "goctr_rank: bad arguments");
+  GOCTR_CHECK(r->emb->D == m->cfg.D && r->U == m->cfg.U && r->C == m->cfg.C, "goctr_rank: recsys dims (U=%d,C=%d,D=%d) != model (U=%d,C=%d,D=%d)",
+              r->U, r->C, r->emb->D, m->cfg.U, m->cfg.C, m->cfg.D);
+  if (n_failed) *n_failed = 0;
+  if (n == 0) return 0;
+  GOCTR_CHECK(user >= 0 && user < r->n_users && items[0] >= 0 && items[0] < r->n_items,
+              "get sample vector error: first key (user %d, item %d) has no features", user, items[0]);
+  KeySeg g{nullptr, user, items, nullptr, ts, n, scores, failed, (failed || n_failed) ? 0 : -1};
+  return serve_keys(m, r, g, n_failed);
+}
+
+// model.Predict's own convention (model/model.go:242-352): `rows` dense TrainSample rows in HOST memory -> y_out [rows].
+// Concurrent like the two above (PredictAbstract.Predict is what the gin handlers end up in): a slot of its own, the rows
+// travel in passes of <= 64 MB.
+int goctr_predict_dense(goctr_model* m, const float* X, int64_t rows, int xcols, const int ranges[8], int batch,
+                        float* y_out) {
+  if (require_engine()) return -1;
+  GOCTR_CHECK(m && X && y_out && ranges && rows >= 0 && batch > 0 && xcols > 0, "goctr_predict_dense: bad arguments");
+  if (rows == 0) return 0;
+  goctr_dataset shape;                       // (only its ranges are looked at)
+  shape.id_mode = false; shape.rows = rows; shape.xcols = xcols;
+  memcpy(shape.ranges, ranges, sizeof shape.ranges);
+  std::shared_lock<std::shared_mutex> lm(m->mu);
+  if (check_dataset(m, &shape, nullptr)) return -1;
+  SlotLease lease;
+  ServeSlot* s = lease.s;
+  if (!s) return -1;
+  const int64_t pass = std::max<int64_t>(32, std::min<int64_t>(SERVE_PASS_ROWS, ((int64_t)64 << 20) / ((int64_t)xcols * 4) / 32 * 32));
+  StreamScope on_slot(s->stream);
+  for (int64_t o = 0; o < rows; o += pass) {
+    const int64_t N = std::min(pass, rows - o);
+    if (s->capX < (size_t)N * xcols) {
+      GOCTR_HIP(hipStreamSynchronize(s->stream));
+      if (s->X.alloc((size_t)std::min<int64_t>(pass, rows) * xcols, false)) return -1;
+      s->capX = (size_t)std::min<int64_t>(pass, rows) * xcols;
+    }
+    if (s->ensure_keys(N, m->cfg.T, m->cfg.U, m->cfg.C)) return -1;       // (for its pinned score staging and d_out)
+    if (s->ws.ensure((int)N, m->Ip, m->cfg.T, m->H1p, m->H2p, !chain_ok(m), s->stream)) return -1;
+    GOCTR_HIP(hipMemcpyAsync(s->X.p, X + (size_t)o * xcols, (size_t)N * xcols * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    if (serve_wait_weights(m, s)) return -1;
+    RowSource src{};
+    src.rows = N; src.id_mode = 0; src.X = s->X.p; src.xcols = xcols;
+    src.r_u = ranges[0]; src.r_ub = ranges[2]; src.r_v = ranges[4]; src.r_c = ranges[6];
+    FwdBufs fb = s->ws.bufs();
+    fb.yhat = reinterpret_cast<float*>(s->d_out.p);
+    StepOpts op;
+    op.train = false;
+    if (launch_forward(m, src, (int)N, op, s->st.p, &fb)) return -1;
+    GOCTR_HIP(hipMemcpyAsync(s->h_out, s->d_out.p, (size_t)N * 4, hipMemcpyDeviceToHost, s->stream));
+    GOCTR_HIP(hipStreamSynchronize(s->stream));
+    memcpy(y_out + o, s->h_out, (size_t)N * 4);
+  }
+  return 0;
 }
 
 }  // extern "C"

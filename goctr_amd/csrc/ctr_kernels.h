@@ -286,6 +286,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
           while (__hip_atomic_load(ra->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ra->expect && ++spins < (1u << 22))
             __builtin_amdgcn_s_sleep(1);
           ok = spins < (1u << 22);           // (a wait that ran out poisons the step -- NaN costs -- instead of hanging the GPU)
+          // compiler-level ordering only (no instruction, no L2 invalidate): the att0 loads below must not be hoisted
+          // above the poll.  The hardware side is the sc1 loads themselves (they bypass L1 and are served past the
+          // non-coherent L2) behind in-order vector memory.
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (lane < NPB * RPP && tl < T) aw = __hip_atomic_load(ra->att0 + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!ok) aw = __builtin_nanf("");
@@ -778,6 +782,7 @@ __device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int bl
         __hip_atomic_store(p.ad.W + e0 + pl, wn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler-level: the flag store must not be moved above the barrier)
       if (threadIdx.x == 0) __hip_atomic_store(p.ra_flag, a.st->gstep + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

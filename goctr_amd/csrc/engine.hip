@@ -24,6 +24,14 @@ Engine& engine() {
   return e;
 }
 
+// the calling thread's target stream (null = the engine's main stream)
+static thread_local hipStream_t t_active = nullptr;
+Engine::ActiveStream::operator hipStream_t() const { return t_active ? t_active : engine().stream; }
+Engine::ActiveStream& Engine::ActiveStream::operator=(hipStream_t s) {
+  t_active = (s == engine().stream) ? nullptr : s;
+  return *this;
+}
+
 std::recursive_mutex& engine_mutex() {
   static std::recursive_mutex mu;
   return mu;
@@ -46,7 +54,8 @@ static const char* kNames[GOCTR_K_COUNT] = {
     "attn_fwd", "gemm_fwd0", "gemm_fwd1", "gemm_out", "bwd_dz1", "bwd_dz0", "bwd_dp",
     "attn_bwd", "dW0", "dW1", "dW2", "reduce", "allreduce", "adam", "chain", "emb_train", "emb_grad"};
 
-ProfScope::ProfScope(int kernel_id) : id(kernel_id), on(engine().prof) {
+// (main-stream launches only: the event pool is not shared with the serving slots' threads)
+ProfScope::ProfScope(int kernel_id) : id(kernel_id), on(engine().prof && t_active == nullptr) {
   if (!on) return;
   Engine& e = engine();
   auto get = [&]() {
@@ -192,7 +201,6 @@ int goctr_init(int device_ordinal) {
     for (auto& ev : e.ev_fork) GOCTR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     GOCTR_HIP(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
   }
-  e.active = e.stream;
   e.device = device_ordinal;
   e.inited = true;
   return 0;
@@ -236,5 +244,9 @@ int goctr_prof_get(int id, double* ms, int64_t* n) {
   return 0;
 }
 const char* goctr_prof_name(int id) { return id >= 0 && id < GOCTR_K_COUNT ? kNames[id] : "?"; }
+const char* goctr_prof_kernel(int id) {
+  const char* k = id >= 0 && id < GOCTR_K_COUNT ? engine().prof_kernel[id] : nullptr;
+  return k ? k : "";
+}
 
 }  // extern "C"

@@ -1378,7 +1378,12 @@ int goctr_mlp_create(const goctr_mlp_cfg* cfg, goctr_mlp** out) {
   return 0;
 }
 
-void goctr_mlp_destroy(goctr_mlp* p) { delete p; }
+void goctr_mlp_destroy(goctr_mlp* p) {
+  if (!p) return;
+  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
+  if (engine().inited) (void)hipStreamSynchronize(engine().stream);   // queued (asynchronous) steps still use its buffers and graphs
+  delete p;
+}
 size_t goctr_mlp_nparams(const goctr_mlp* p) { return p ? (size_t)p->nparams : 0; }
 
 int goctr_mlp_set_params(goctr_mlp* p, const double* theta, size_t n) {
@@ -1484,6 +1489,8 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
     if (p->fused_ok() && p->zpart.ensure((size_t)cdiv(p->up[1], 32) * p->cfg.batch, false)) return -1;
     if (!p->step_graph || p->step_graph_rows != p->rows || p->step_graph_perm != (p->perm.n > 1) ||
         p->step_graph_x != p->Xr.p || p->step_graph_y != p->Yr.p || p->step_graph_p != p->perm.p || p->step_graph_w != p->W0img.p) {
+      // (goctr_mlp_train_steps is asynchronous: replays of the old execs may still be queued -- never destroy one in flight)
+      if (p->step_graph || p->multi_graph[0] || p->multi_graph[1]) GOCTR_HIP(hipStreamSynchronize(e.stream));
       if (p->step_graph) { (void)hipGraphExecDestroy(p->step_graph); p->step_graph = nullptr; }
       for (auto& mg : p->multi_graph) { if (mg) (void)hipGraphExecDestroy(mg); mg = nullptr; }
       hipGraph_t g = nullptr;

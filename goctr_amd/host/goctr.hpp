@@ -180,9 +180,14 @@ inline std::vector<float> BatchPredict(model::CtrNet& net, RecSys& rs, const std
 // rcmd.go:248-275
 inline std::vector<ItemScore> Rank(model::CtrNet& net, RecSys& rs, int userId, const std::vector<int>& itemIds, int64_t now,
                                    int predBatch = 4096) {
-  std::vector<Sample> keys(itemIds.size());
-  for (size_t i = 0; i < itemIds.size(); ++i) keys[i] = Sample{userId, itemIds[i], 0.f, now};
-  auto y = BatchPredict(net, rs, keys, predBatch);
+  // one user, one timestamp: goctr_rank takes them as scalars (no per-key arrays are built or copied)
+  const int64_t n = (int64_t)itemIds.size();
+  std::vector<float> y((size_t)n);
+  std::vector<uint8_t> failed((size_t)n);
+  static_assert(sizeof(int) == sizeof(int32_t), "item ids are int32");
+  check(goctr_rank(net.Vm(), rs.handle(), userId, reinterpret_cast<const int32_t*>(itemIds.data()), n, now, predBatch, y.data(),
+                   failed.data(), nullptr));
+  if (n && failed[(size_t)n - 1]) throw std::runtime_error("get sample vector error: last key has no features");   // rcmd.go:258-260
   std::vector<ItemScore> out(itemIds.size());
   for (size_t i = 0; i < itemIds.size(); ++i) out[i] = ItemScore{itemIds[i], y[i]};
   return out;

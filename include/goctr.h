@@ -9,9 +9,16 @@
  *   - no callback into the host language, no host pointer retained after a call returns;
  *   - host buffers are row-major, float32 for DIN / YouTube (gorgonia tensor.Float32,
  *     model/model.go:14), float64 for the sklearn-port MLP and item2vec (as in the reference);
- *   - any host thread may call any entry point on any handle: the engine owns ONE submission stream, so calls are
- *     serialised engine-wide by an internal lock (concurrent PredictAbstract.Predict from gin handler goroutines,
- *     recommend/api.go:106-131, is safe; the calls queue behind each other);
+ *   - any host thread may call any entry point on any handle.  Calls that queue work on the engine's main stream
+ *     (training, uploads, dataset builds) are serialised engine-wide by an internal lock.  The SERVING entry points --
+ *     goctr_batch_predict, goctr_rank, goctr_predict_dense: what concurrent gin handler goroutines reach through
+ *     Rank -> BatchPredict -> PredictAbstract.Predict, recommend/api.go:106-131 -- run CONCURRENTLY: each call takes a
+ *     serving slot (own HIP stream, pinned staging buffers, forward workspace; GOCTR_SERVE_SLOTS of them, default 4)
+ *     under a shared lock of the model, so calls on one model or on different models overlap on the GPU while a
+ *     training call on that model waits for them (and they for it).  Small goctr_rank / goctr_batch_predict calls
+ *     (<= GOCTR_SERVE_COALESCE rows, default 1024) that arrive while another one is in flight on the same
+ *     (recsys, model) pair are coalesced into one launch sequence (a micro-batcher); scores do not depend on
+ *     whether or with what a call was coalesced (rows are scored independently, same kernel, same bits);
  *   - there is NO CPU fallback: without a HIP device every compute entry point fails loudly.
  */
 #ifndef GOCTR_H
@@ -224,6 +231,9 @@ int goctr_prof_reset(void);
 /* total milliseconds and launch count per kernel family since the last reset */
 int goctr_prof_get(int kernel_id, double* total_ms, int64_t* launches);
 const char* goctr_prof_name(int kernel_id);
+/* symbol (name + template arguments, e.g. "ctr_chain_x3_kernel<9,false>") of the kernel the family's last profiled launch
+ * ran; "" when none.  bench.py refuses rocprofv3 counters committed for another kernel than the one it just timed. */
+const char* goctr_prof_kernel(int kernel_id);
 
 /* ---------------------------------------------------------------- sklearn-port MLP (f64) --- */
 /* replaces nn.NewMLPClassifier + Fit + Predict (nn/neural_network/multilayer_perceptron.go:81-125,

@@ -111,11 +111,20 @@ def one_step_checks(oracle, kind, U, T, D, Cc, V, B, seed, drop):
     om2, dm2 = models(oracle, kind, U, T, D, Cc, np.random.default_rng(seed + 1), 0.15)
     cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=2 if drop else 0, p0=0.005, p1=0.005, seed=77)
     c_id = gm.train_steps(dm2, ds, cfg, 1, emb=tab, want_costs=True)
+    # the oracle's gradient of this very step, before it updates: the entries whose (L2-regularised) gradient lies inside the
+    # float32 noise of zero -- noise = the oracle's own distance from the float64 truth, measured above per tensor
+    _, g_step, _ = om2.loss_grad(X, Y, B=B, drop=dict(mode=2, p0=0.005, p1=0.005, seed=77, step=0) if drop else None)
+    noise = {on: float(np.max(np.abs(np.asarray(rg[on], np.float64).ravel() - np.asarray(g64[on], np.float64).ravel()))) for _, on in pairs}
+    near_zero = {on: np.abs(g_step[on].ravel() + float(cfg.l2) * getattr(om2, on).ravel()) <= 8 * noise[on] for _, on in pairs}
     ref_costs = om2.train(X, Y, batch=B, epochs=1, drop_mode=2 if drop else 0, p0=0.005, p1=0.005, seed=77)
     assert abs(c_id[0] - ref_costs[0]) <= LOSS_TOL
     for dn, on in pairs:
         d = np.abs(dm2.get_weights(dn).ravel() - getattr(om2, on).ravel())
-        assert np.quantile(d, 0.999) <= 1e-5 and np.max(d) <= 2.1e-2, (dn, float(np.quantile(d, 0.999)), float(np.max(d)))
+        out = d > 1e-5
+        # Adam's first update is lr * sign(g): only an entry whose gradient is float32-indistinguishable from zero may differ,
+        # and then by at most 2 lr.  Every other entry is held to 1e-5; the outliers are counted, not waved through.
+        assert int(np.sum(out & ~near_zero[on])) == 0, (dn, int(np.sum(out & ~near_zero[on])), float(d[out & ~near_zero[on]].max()))
+        assert float(out.mean()) <= 2e-3 and np.max(d) <= 2.1e-2, (dn, float(out.mean()), float(np.max(d)))
     # and the next predict sees the updated weights
     assert np.max(np.abs(gm.predict_dataset(dm2, ds, 4096, emb=tab) - om2.predict(X, 4096))) <= 5e-5
 

@@ -126,3 +126,120 @@ def test_train_from_keys_then_rank(oracle):
     keys = [gr.Sample(uids[0], i, 0.0, 600) for i in iids[:20]]
     ref_s, _ = oracle_scores(oracle, rs, om, keys, model.PredBatchSize)
     assert np.max(np.abs(np.array([x.Score for x in s], np.float32) - ref_s)) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Serving as the reference calls it (recommend/api.go:106-131): many handler goroutines, each one Rank call with a short
+# candidate list.  goctr_rank / goctr_batch_predict run on serving slots (own stream, pinned staging) under a shared lock
+# of the model, and small calls that arrive while a pass is in flight are coalesced into one pass.  None of that may
+# change a score: every concurrent answer must be bit-equal to the single-threaded answer of the same request.
+
+def _rank_raw(net, rs, user_idx, item_idx, now):
+    import ctypes as C
+    from goctr_amd import capi
+    items = np.ascontiguousarray(item_idx, np.int32)
+    y = np.empty(items.size, np.float32)
+    failed = np.zeros(items.size, np.uint8)
+    nf = C.c_int64(0)
+    capi.check(capi.load().goctr_rank(net._h, rs._h, C.c_int32(int(user_idx)), capi.ptr(items, C.c_int32), C.c_int64(items.size),
+                                      C.c_int64(now), C.c_int(4096), capi.ptr(y, C.c_float), capi.ptr(failed, C.c_uint8), C.byref(nf)))
+    return y, failed, nf.value
+
+
+@pytest.mark.parametrize("coalesce", ["1024", "0"])
+def test_concurrent_rank_calls_are_bit_equal_to_sequential(oracle, coalesce, monkeypatch):
+    import threading
+    monkeypatch.setenv("GOCTR_SERVE_COALESCE", coalesce)
+    rng = np.random.default_rng(51)
+    rs, om, net, uids, iids, extra = build(oracle, rng, 0, n_users=64, n_items=2000, T=50, U=52, Cc=53)
+    n_items_tab = rs.item_table.shape[0]
+    reqs = []
+    for q in range(48):
+        n = int(rng.choice([1, 7, 32, 100, 256, 700]))
+        items = rng.integers(0, n_items_tab, size=n).astype(np.int32)
+        if q % 5 == 0 and n > 3:
+            items[n // 2] = n_items_tab + 17                         # a key without features in the middle: zero row + flag
+        reqs.append((int(rng.integers(0, len(uids))), items, int(rng.integers(1, 1100))))
+    want = [_rank_raw(net, rs, *r) for r in reqs]
+    errs, got = [], {}
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                for q in range(t % 4, len(reqs), 4):                   # (threads t and t + 4 race on identical requests)
+                    got[(t, rep, q)] = _rank_raw(net, rs, *reqs[q])
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert len(got) == 8 * 6 * 12
+    for (t, rep, q), (y, failed, nf) in got.items():
+        assert np.array_equal(y, want[q][0]) and np.array_equal(failed, want[q][1]) and nf == want[q][2], (t, rep, q)
+    assert any(w[2] > 0 for w in want)
+
+
+def test_serving_while_training_the_same_model(oracle):
+    """a training call on a model waits for the serving passes in flight and they for it (shared / exclusive model lock,
+    and the slot streams wait for the main stream's last weight write): scores returned after training equal a fresh call's,
+    and training lands on the bits of an undisturbed run"""
+    import threading
+    from goctr_amd import capi, model as gm
+    rng = np.random.default_rng(61)
+    rs, om, net, uids, iids, extra = build(oracle, rng, 0, n_users=64, n_items=2000, T=50, U=52, Cc=53)
+    twin = gm.DinNet(52, 50, 16, 16, 53)
+    for n in ("mlp0", "mlp1", "mlp2", "att0"):
+        twin.set_weights(n, net.get_weights(n))
+    U, T, D, Cc, V, rows, B = 52, 50, 16, 53, rs.emb.get_rows().shape[0], 4096, 512
+    ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
+    it = rng.integers(0, V, size=rows).astype(np.int32)
+    uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+    Y = (uf[:, 0] > 0.5).astype(np.float32)
+    ds = gm.Dataset.ids(ub, it, uf, cf, Y)
+    cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=2, p0=0.005, p1=0.005, seed=9)
+    want_costs = np.concatenate([gm.train_steps(twin, ds, cfg, 8, first_batch=8 * r, emb=rs.emb, want_costs=True) for r in range(5)])
+    items = rng.integers(0, rs.item_table.shape[0], size=200).astype(np.int32)
+    stop, errs, n_calls = threading.Event(), [], [0]
+
+    def server():
+        try:
+            while not stop.is_set():
+                y, _, _ = _rank_raw(net, rs, 5, items, 700)
+                assert np.all(np.isfinite(y))
+                n_calls[0] += 1
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=server) for _ in range(3)]
+    for t in th:
+        t.start()
+    costs = np.concatenate([gm.train_steps(net, ds, cfg, 8, first_batch=8 * r, emb=rs.emb, want_costs=True) for r in range(5)])
+    stop.set()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert n_calls[0] > 0
+    assert np.array_equal(costs, want_costs)
+    assert np.array_equal(net.get_weights("mlp0"), twin.get_weights("mlp0"))
+    y_after, _, _ = _rank_raw(net, rs, 5, items, 700)
+    y_twin, _, _ = _rank_raw(twin, rs, 5, items, 700)
+    assert np.array_equal(y_after, y_twin)
+
+
+def test_rank_bench_binary_runs_and_is_bit_equal():
+    """goctr_amd/host/rank_bench (std::thread callers above the C-ABI, what bench.py's rank_* fields come from): exits 0 only
+    if every concurrent answer was bit-equal to the single-threaded one"""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "goctr_amd", "host", "rank_bench")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe, "--threads", "1,4", "--n", "16,300", "--seconds", "0.15"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["bit_equal_to_single_threaded"] is True and len(d["results"]) == 8
+    assert all(e["calls"] > 0 and e["mismatched_calls"] == 0 for e in d["results"])
