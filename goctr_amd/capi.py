@@ -12,7 +12,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgoctr_hip.so")
+# GOCTR_LIB: load another build of the same C-ABI (tests/test_bench_dryrun.py drives bench.py --gpus 8 against a stub that
+# exports every symbol of include/goctr.h and computes nothing -- launcher / rendezvous / JSON plumbing on a GPU-less box)
+LIB_PATH = os.environ.get("GOCTR_LIB") or os.path.join(_HERE, "libgoctr_hip.so")
 
 
 class GoctrError(RuntimeError):
@@ -60,7 +62,7 @@ SYMBOLS = [
     "goctr_mlp_nparams", "goctr_mlp_set_params", "goctr_mlp_get_params", "goctr_mlp_loss_grad", "goctr_mlp_fit",
     "goctr_mlp_upload", "goctr_mlp_train_steps", "goctr_mlp_predict", "goctr_w2v_cfg_default", "goctr_w2v_create",
     "goctr_w2v_destroy", "goctr_w2v_set_param", "goctr_w2v_set_aux", "goctr_w2v_get_param", "goctr_w2v_get_aux",
-    "goctr_w2v_get_paths", "goctr_w2v_train", "goctr_w2v_upload_doc", "goctr_w2v_train_resident",
+    "goctr_w2v_get_paths", "goctr_huffman_build", "goctr_w2v_train", "goctr_w2v_upload_doc", "goctr_w2v_train_resident",
     "goctr_w2v_export_f32", "goctr_searcher_create", "goctr_searcher_destroy", "goctr_searcher_search",
     "goctr_ubcache_create", "goctr_ubcache_destroy", "goctr_ubcache_get", "goctr_dataset_create_keys", "goctr_dataset_get_ids",
     "goctr_recsys_create", "goctr_recsys_destroy", "goctr_batch_predict", "goctr_rank",

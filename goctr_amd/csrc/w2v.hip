@@ -25,6 +25,8 @@
 #include <memory>
 #include <numeric>
 
+#include <chrono>
+
 #include "common.h"
 #include "corpus.h"
 
@@ -730,6 +732,24 @@ int goctr_w2v_get_paths(goctr_w2v* w, int64_t* path_off, int32_t* nodes, uint8_t
   const int64_t n = std::min<int64_t>(cap, (int64_t)w->h_nodes.size());
   if (nodes) memcpy(nodes, w->h_nodes.data(), sizeof(int32_t) * (size_t)n);
   if (codes) memcpy(codes, w->h_codes.data(), (size_t)n);
+  return 0;
+}
+
+int goctr_huffman_build(const int64_t* counts, int64_t V, int max_depth, int64_t* path_off, int32_t* nodes, uint8_t* codes,
+                        int64_t cap, int64_t* total, double* build_ms) {
+  GOCTR_CHECK(counts && V > 0 && path_off && max_depth > 0, "goctr_huffman_build: bad arguments");
+  GOCTR_CHECK(V <= 0x3fffffff, "goctr_huffman_build: V = %lld exceeds the 2^30 words the int32 node ids can number", (long long)V);
+  std::vector<long long> off;
+  std::vector<int> nd;
+  std::vector<unsigned char> cd;
+  const auto t0 = std::chrono::steady_clock::now();
+  build_huffman(counts, V, max_depth, off, nd, cd);
+  if (build_ms) *build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (size_t i = 0; i < off.size(); ++i) path_off[i] = off[i];
+  if (total) *total = (int64_t)nd.size();
+  const int64_t n = std::min<int64_t>(cap, (int64_t)nd.size());
+  if (nodes && n > 0) memcpy(nodes, nd.data(), sizeof(int32_t) * (size_t)n);
+  if (codes && n > 0) memcpy(codes, cd.data(), (size_t)n);
   return 0;
 }
 

@@ -228,3 +228,21 @@ def TrainEmbedding(inputCh, window: int, dim: int, iter: int, **kw) -> Word2Vec:
     mod = Word2Vec(window=window, dim=dim, iter=iter, optimizer="hs", **kw)
     mod.Train(inputCh)
     return mod
+
+
+def huffman_paths(counts, max_depth=100, want_ms=False):
+    """dictionary/huffman.go:23-57 + node.go:39-42 on the host side of the library (goctr_huffman_build; needs no device):
+    (path_off [V+1], inner-node ids, codes) of the root-to-leaf paths, the reference's tie-breaking."""
+    L = capi.load()
+    counts = np.ascontiguousarray(counts, np.int64)
+    V = counts.size
+    off = np.zeros(V + 1, np.int64)
+    total, ms = C.c_int64(0), C.c_double(0)
+    capi.check(L.goctr_huffman_build(capi.ptr(counts, C.c_int64), C.c_int64(V), C.c_int(max_depth), capi.ptr(off, C.c_int64), None, None,
+                                     C.c_int64(0), C.byref(total), None))
+    nodes = np.zeros(max(total.value, 1), np.int32)
+    codes = np.zeros(max(total.value, 1), np.uint8)
+    capi.check(L.goctr_huffman_build(capi.ptr(counts, C.c_int64), C.c_int64(V), C.c_int(max_depth), capi.ptr(off, C.c_int64),
+                                     capi.ptr(nodes, C.c_int32), capi.ptr(codes, C.c_uint8), C.c_int64(total.value), C.byref(total), C.byref(ms)))
+    res = (off, nodes[:total.value], codes[:total.value])
+    return res + (ms.value,) if want_ms else res

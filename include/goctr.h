@@ -304,6 +304,12 @@ int goctr_w2v_get_param(goctr_w2v* w, double* param);
 int goctr_w2v_get_aux(goctr_w2v* w, double* aux);
 int goctr_w2v_get_paths(goctr_w2v* w, int64_t* path_off /*[V+1]*/, int32_t* nodes, uint8_t* codes, int64_t cap,
                         int64_t* total);
+/* The Huffman tree alone (dictionary/huffman.go:23-57, node/node.go:39-42 GetPath): root-to-leaf inner-node ids and codes of
+ * every word as a CSR, with the reference's tie-breaking (leaves stable-sorted by count, a merged node in front of every
+ * node of equal value), built on the HOST in O(V log V) -- no device needed, so also callable without goctr_init.  Call
+ * with nodes == codes == NULL to get *total, then again with cap >= *total.  *build_ms (may be NULL): wall time of the build. */
+int goctr_huffman_build(const int64_t* counts, int64_t V, int max_depth, int64_t* path_off /*[V+1]*/, int32_t* nodes,
+                        uint8_t* codes, int64_t cap, int64_t* total, double* build_ms);
 /* one iteration over doc (word2vec.go:151-175): keep_mask = injected sub-sampling trials
  * (subsample.go:45-52) or NULL; corpus_len = unfiltered corpus length (Q17).  lr in/out. */
 int goctr_w2v_train(goctr_w2v* w, const int32_t* doc, int64_t n_words, int64_t corpus_len,
