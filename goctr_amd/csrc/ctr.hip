@@ -152,6 +152,14 @@ struct goctr_model {
   DevBuf<long long> emb_accum;
   DevBuf<int> emb_slot_id;
   long long emb_Vw = 0;           // rows of one owner's bucket in the (owner-major) mark / rank index space
+  // per-batch sparse plan of the id-major update (emb_train.h, "Round 3"): built once per (dataset, batch, vocabulary, world)
+  struct EmbPlan {
+    bool valid = false; uint64_t ds = 0; long long V = 0; int B = 0, W = 0, T = 0;
+    DevBuf<int> pair, pslot, pid, slot_id; DevBuf<unsigned int> slot_off; DevBuf<long long> pair_off, slot_base;
+    long long nb = 0, max_pairs = 0, max_slots = 0, total_pairs = 0, total_slots = 0;
+    EmbPlanView view() const { return EmbPlanView{pair.p, pslot.p, pid.p, pair_off.p, slot_id.p, slot_off.p, slot_base.p}; }
+  } plan;
+  DevBuf<float4> emb_coef; DevBuf<float> emb_gsum;
   // bucketed exchange (data parallel): bucket bounds / counts, received pairs, the owner's reduction, the gathered deltas
   DevBuf<int> ex_off, ex_cnt, ex_allcnt, ex_rids, ex_red_ids, ex_nred, ex_allnred, ex_gids;
   DevBuf<long long> ex_rrows, ex_red;
@@ -823,6 +831,133 @@ int launch_emb_exchange(goctr_model* m, const EmbTrainArgs& a) {
   return 0;
 }
 
+// Shapes the id-major plan path covers (emb_train.h "Round 3"); everything else keeps emb_grad_kernel's atomics.
+bool emb_plan_ok(const goctr_model* m, int B) {
+  const goctr_ctr_cfg& c = m->cfg;
+  const bool lay = c.kind != GOCTR_DIN || c.D == 4 || c.D == 8 || c.D == 16 || c.D == 32 || c.D == 64;
+  return lay && c.D <= 64 && c.T < (1 << EMB_PAIR_TBITS) && B < (1 << (31 - EMB_PAIR_TBITS)) && env_int("GOCTR_EMB_PLAN", 1) != 0;
+}
+
+// Build (or reuse) the sparse plan of dataset d at batch size B: per batch the distinct ids in ascending owner-major order
+// and the (sample, slot) pairs sorted by id.  One-time work per dataset, outside every capture: a count per id, two prefix
+// sums over the vocabulary and a fill per batch, with one small read-back per batch to advance the bases.
+int ensure_emb_plan(goctr_model* m, const goctr_dataset* d, const RowSource& src, int B) {
+  Engine& e = engine();
+  const goctr_ctr_cfg& c = m->cfg;
+  const int W = e.comm_active() ? e.world : 1;
+  auto& P = m->plan;
+  if (P.valid && P.ds == d->uid && P.V == src.V && P.B == B && P.W == W && P.T == c.T) return 0;
+  P.valid = false;
+  hipStream_t s = e.stream;
+  GOCTR_HIP(hipStreamSynchronize(s));
+  m->graph.destroy();                                  // captured launches bake the plan's pointers in
+  const long long Vw = m->emb_Vw, Vp = Vw * W;
+  const long long nb = cdiv(d->rows, B), per = c.T + 1, cap = d->rows * per;
+  DevBuf<int> tpair, tpslot, tpid, tsid;
+  DevBuf<unsigned int> tsoff;
+  DevBuf<unsigned long long> tot;                      // [0] slots, [1] pairs of the batch being built
+  if (tpair.alloc((size_t)cap, false) || tpslot.alloc((size_t)cap, false) || tpid.alloc((size_t)cap, false) ||
+      tsid.alloc((size_t)cap, false) || tsoff.alloc((size_t)(cap + nb), false) || tot.alloc(2)) return -1;
+  std::vector<long long> pair_off((size_t)nb + 1, 0), slot_base((size_t)nb + 1, 0);
+  long long max_pairs = 0, max_slots = 0;
+  unsigned int* cnt = m->emb_mark.p;                   // all zero between steps; the fill counts it back to zero
+  for (long long k = 0; k < nb; ++k) {
+    EmbPlanBuildArgs a{src, B, c.T, src.V, W, Vw, k};
+    const dim3 g((unsigned)cdiv((long long)B * per, 256));
+    unsigned int* soff = tsoff.p + slot_base[k] + k;
+    hipLaunchKernelGGL(emb_plan_count_kernel, g, dim3(256), 0, s, a, cnt);
+    GOCTR_HIP(hipGetLastError());
+    if (exclusive_scan_sink(cnt, Vp, m->emb_tiles, tot.p, EmbNonZeroMap{}, EmbPlanSlotSink{m->emb_rank.p, tsid.p + slot_base[k], W, Vw})) return -1;
+    if (exclusive_scan_sink(cnt, Vp, m->emb_tiles, tot.p + 1, ScanIdentity{}, EmbPlanOffSink{m->emb_rank.p, soff})) return -1;
+    hipLaunchKernelGGL(emb_plan_tail_kernel, dim3(1), dim3(1), 0, s, tot.p, tot.p + 1, soff);
+    hipLaunchKernelGGL(emb_plan_fill_kernel, g, dim3(256), 0, s, a, cnt, m->emb_rank.p, soff, tpair.p + pair_off[k], tpslot.p + pair_off[k],
+                       tpid.p + pair_off[k]);
+    GOCTR_HIP(hipGetLastError());
+    unsigned long long h[2];
+    if (tot.download(h, 2)) return -1;
+    pair_off[k + 1] = pair_off[k] + (long long)h[1];
+    slot_base[k + 1] = slot_base[k] + (long long)h[0];
+    max_pairs = std::max(max_pairs, (long long)h[1]);
+    max_slots = std::max(max_slots, (long long)h[0]);
+  }
+  const size_t np = (size_t)std::max<long long>(pair_off[nb], 1), ns = (size_t)std::max<long long>(slot_base[nb], 1);
+  if (P.pair.alloc(np, false) || P.pslot.alloc(np, false) || P.pid.alloc(np, false) || P.slot_id.alloc(ns, false) ||
+      P.slot_off.alloc(ns + (size_t)nb, false) || P.pair_off.alloc((size_t)nb + 1, false) || P.slot_base.alloc((size_t)nb + 1, false)) return -1;
+  GOCTR_HIP(hipMemcpyAsync(P.pair.p, tpair.p, np * 4, hipMemcpyDeviceToDevice, s));
+  GOCTR_HIP(hipMemcpyAsync(P.pslot.p, tpslot.p, np * 4, hipMemcpyDeviceToDevice, s));
+  GOCTR_HIP(hipMemcpyAsync(P.pid.p, tpid.p, np * 4, hipMemcpyDeviceToDevice, s));
+  GOCTR_HIP(hipMemcpyAsync(P.slot_id.p, tsid.p, ns * 4, hipMemcpyDeviceToDevice, s));
+  GOCTR_HIP(hipMemcpyAsync(P.slot_off.p, tsoff.p, (ns + (size_t)nb) * 4, hipMemcpyDeviceToDevice, s));
+  if (P.pair_off.upload(pair_off.data(), pair_off.size()) || P.slot_base.upload(slot_base.data(), slot_base.size())) return -1;   // (synchronises)
+  if (c.kind == GOCTR_DIN && (m->emb_coef.ensure((size_t)B * c.T, false) || m->emb_gsum.ensure((size_t)B * c.D, false))) return -1;
+  P.ds = d->uid; P.V = src.V; P.B = B; P.W = W; P.T = c.T; P.nb = nb; P.max_pairs = max_pairs; P.max_slots = max_slots;
+  P.total_pairs = pair_off[nb]; P.total_slots = slot_base[nb];
+  P.valid = true;
+  return 0;
+}
+
+template <int GS>
+int launch_emb_slot_gs(int mode, bool direct, dim3 grid, hipStream_t s, const EmbSlotArgs& a) {
+#define GOCTR_SLOT(M) do { if (direct) hipLaunchKernelGGL((emb_slot_kernel<GS, M, true>), grid, dim3(EMB_SLOT_THREADS), 0, s, a); \
+                           else hipLaunchKernelGGL((emb_slot_kernel<GS, M, false>), grid, dim3(EMB_SLOT_THREADS), 0, s, a); } while (0)
+  if (mode == 0) GOCTR_SLOT(0); else GOCTR_SLOT(1);
+#undef GOCTR_SLOT
+  GOCTR_HIP(hipGetLastError());
+  if (direct) {
+    const long long wgp = (long long)(EMB_SLOT_THREADS / GS) * EMB_SEG;
+    const long long borders = std::max<long long>(cdiv(a.B * (long long)(a.T + 1), wgp), 1);      // (upper bound over the batches)
+    hipLaunchKernelGGL((emb_span_apply_kernel<GS>), dim3((unsigned)cdiv(borders, 256 / GS)), dim3(256), 0, s, a);
+    GOCTR_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int launch_emb_exchange(goctr_model* m, const EmbTrainArgs& a);
+
+// the id-major update of one step over the plan (after the dpv GEMM)
+int launch_emb_plan_step(goctr_model* m, const RowSource& src, int B, const StepState* st, int Np) {
+  const goctr_ctr_cfg& c = m->cfg;
+  Engine& e = engine();
+  hipStream_t s = e.stream;
+  const int mode = c.kind != GOCTR_DIN ? 0 : (c.att == GOCTR_ATT_COSINE ? 1 : 2);
+  const bool direct = !e.comm_active();
+  EmbSlotArgs a{};
+  a.plan = m->plan.view(); a.st = st; a.B = B; a.T = c.T; a.D = c.D; a.dpv = m->dpv.p; a.ldp = Np;
+  a.coef = m->emb_coef.p; a.gsum = m->emb_gsum.p; a.h0 = m->h0.p; a.Ip = m->Ip; a.U = c.U;
+  a.emb = const_cast<float*>(src.emb); a.accum = m->emb_accum.p; a.lr = m->emb_lr;
+  {
+    ProfScope ps(GOCTR_K_EMB_GRAD);
+    if (ps.on) {
+      static char sym[48];
+      snprintf(sym, sizeof sym, "emb_slot_kernel<%d,%d,%s>", c.D <= 16 ? 16 : c.D <= 32 ? 32 : 64, mode ? 1 : 0, direct ? "true" : "false");
+      prof_note_kernel(GOCTR_K_EMB_GRAD, sym);
+    }
+    if (mode != 0) {
+      EmbCoefArgs ca{src, st, B, c.T, c.D, m->dpv.p, Np, m->gate_p(m->stp), m->W.p + m->offa, m->emb_coef.p, m->emb_gsum.p};
+      const dim3 g((unsigned)cdiv(B, 4));
+      const int lpr = c.D / 4;
+#define GOCTR_COEF(L) do { if (mode == 1) hipLaunchKernelGGL((emb_coef_kernel<L, 1>), g, dim3(256), 0, s, ca); \
+                           else hipLaunchKernelGGL((emb_coef_kernel<L, 2>), g, dim3(256), 0, s, ca); } while (0)
+      if (lpr == 1) GOCTR_COEF(1); else if (lpr == 2) GOCTR_COEF(2); else if (lpr == 4) GOCTR_COEF(4); else if (lpr == 8) GOCTR_COEF(8); else GOCTR_COEF(16);
+#undef GOCTR_COEF
+      GOCTR_HIP(hipGetLastError());
+    }
+    const int gs = c.D <= 16 ? 16 : c.D <= 32 ? 32 : 64;
+    const dim3 grid((unsigned)std::max<long long>(cdiv(m->plan.max_pairs, (long long)(EMB_SLOT_THREADS / gs) * EMB_SEG), 1));
+    if (gs == 16 ? launch_emb_slot_gs<16>(mode, direct, grid, s, a) : gs == 32 ? launch_emb_slot_gs<32>(mode, direct, grid, s, a)
+                                                                              : launch_emb_slot_gs<64>(mode, direct, grid, s, a)) return -1;
+  }
+  if (direct) return 0;
+  // data parallel: the exchange reads the batch's slot -> id list and count from fixed buffers
+  const int cus = e.compute_units > 0 ? e.compute_units : 256;
+  hipLaunchKernelGGL(emb_plan_select_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(cdiv(m->plan.max_slots, 256), 1), 4 * cus)), dim3(256), 0, s,
+                     m->plan.view(), st, m->emb_slot_id.p, m->emb_total.p);
+  GOCTR_HIP(hipGetLastError());
+  EmbTrainArgs ea{};
+  ea.D = c.D; ea.lr = m->emb_lr; ea.emb = const_cast<float*>(src.emb);
+  return launch_emb_exchange(m, ea);
+}
+
 // Sparse embedding update of one step (emb_train.h).  Runs after every reader of the table in this step (attn_fwd,
 // attn_bwd's re-gather) and before the step state advances.
 int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepState* st) {
@@ -843,6 +978,18 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   a.mark = m->emb_mark.p; a.rank = m->emb_rank.p; a.accum = m->emb_accum.p; a.lr = m->emb_lr; a.dbg = env_int("GOCTR_EMB_DBG", 0);
   a.W = W; a.Vw = m->emb_Vw;
   hipStream_t s = e.stream;
+  if (m->plan.valid) {
+    // the id-major path: no marks, no scans, no accumulators to apply -- the dpv GEMM, then the plan kernels
+    {
+      ProfScope ps(GOCTR_K_EMB_TRAIN);
+      hipLaunchKernelGGL(w0pv_transpose_kernel, dim3((unsigned)cdiv((long long)m->H1p * Np, 256)), dim3(256), 0, s, m->W.p, m->H1p,
+                         c.U, 2 * c.D, Np, m->W0pvT.p);
+      GOCTR_HIP(hipGetLastError());
+    }
+    EpiStore sp{m->dpv.p, Np};
+    if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
+    return launch_emb_plan_step(m, src, B, st, Np);
+  }
   {
   ProfScope ps(GOCTR_K_EMB_TRAIN);
   // ids with a single occurrence are applied in place (emb_train.h); only without a communicator (another rank may touch
@@ -1254,6 +1401,8 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
   if (m->emb_lr > 0.f) {
     GOCTR_CHECK(src.id_mode, "embedding training needs an id-mode dataset (the dense TrainSample rows carry no ids)");
     if (ensure_emb_workspace(m, src.V, B)) return -1;
+    if (emb_plan_ok(m, B)) { if (ensure_emb_plan(m, d, src, B)) return -1; }
+    else m->plan.valid = false;
   }
   // the bias corrections of the state the call starts from (ctr_kernels.h: StepState::corr1/2); later states get theirs from
   // the loss block of the step before them
@@ -2133,13 +2282,19 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
     memcpy(hit + o, g.items, sizeof(int32_t) * (size_t)g.n);
     o += g.n;
   }
-  GOCTR_HIP(hipMemcpyAsync(s->d_in.p, s->h_in, (size_t)N * 16, hipMemcpyHostToDevice, s->stream));
+  // Small passes read the keys and write the scores straight through the pinned staging buffers (device-visible host
+  // memory: 16 B in and 5 B out per row over PCIe from inside the kernels) -- no copy commands on the stream at all, a pass
+  // is three launches and one wait.  Larger passes keep the two DMA copies (GOCTR_SERVE_ZEROCOPY=rows, default 4096; 0 = never).
+  const bool zc = N <= (int64_t)env_int("GOCTR_SERVE_ZEROCOPY", 4096);
+  if (!zc) GOCTR_HIP(hipMemcpyAsync(s->d_in.p, s->h_in, (size_t)N * 16, hipMemcpyHostToDevice, s->stream));
   if (serve_wait_weights(m, s)) return -1;
-  const long long* dts = reinterpret_cast<const long long*>(s->d_in.p);
-  const int32_t* dus = reinterpret_cast<const int32_t*>(s->d_in.p + 8 * N);
-  const int32_t* dit = reinterpret_cast<const int32_t*>(s->d_in.p + 12 * N);
-  float* dscore = reinterpret_cast<float*>(s->d_out.p);
-  unsigned char* dfail = reinterpret_cast<unsigned char*>(s->d_out.p + 4 * Br);
+  const char* in_base = zc ? s->h_in : s->d_in.p;
+  char* out_base = zc ? s->h_out : s->d_out.p;
+  const long long* dts = reinterpret_cast<const long long*>(in_base);
+  const int32_t* dus = reinterpret_cast<const int32_t*>(in_base + 8 * N);
+  const int32_t* dit = reinterpret_cast<const int32_t*>(in_base + 12 * N);
+  float* dscore = reinterpret_cast<float*>(out_base);
+  unsigned char* dfail = reinterpret_cast<unsigned char*>(out_base + 4 * Br);
   const goctr_ubcache* c = r->ub;
   StreamScope on_slot(s->stream);
   hipLaunchKernelGGL(assemble_keys_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, s->stream,
@@ -2160,7 +2315,7 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   for (int k = 0; k < nseg; ++k) want_failed = want_failed || segs[k]->failed || segs[k]->n_failed >= 0;
   // scores and flags are adjacent: one copy back (the gap between them is < 128 bytes)
   const size_t out_bytes = want_failed ? 4 * Br + (size_t)N : 4 * (size_t)N;
-  GOCTR_HIP(hipMemcpyAsync(s->h_out, s->d_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));
+  if (!zc) GOCTR_HIP(hipMemcpyAsync(s->h_out, s->d_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));
   GOCTR_HIP(hipStreamSynchronize(s->stream));
   const float* hs = reinterpret_cast<const float*>(s->h_out);
   const unsigned char* hf = reinterpret_cast<const unsigned char*>(s->h_out + 4 * Br);

@@ -333,6 +333,385 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
   }
 }
 
+// =====================================================================================================================
+// Round 3: the update WITHOUT contended atomics -- a per-batch sparse PLAN + an id-major accumulation.
+//
+// model.Train walks the resident rows in the same fixed batches epoch after epoch (model/model.go:96-211: no shuffle), so
+// which (sample, slot) pairs of a batch touch which embedding row never changes.  That structure is computed ONCE per
+// (dataset, batch size, vocabulary, world) and kept in HBM (12 B per pair -- 160 MB for bench.py's 262 144 rows, of 288 GB):
+//     slots of batch k   = the distinct ids it touches, in ascending (owner-major) id order      slot_id, slot_off
+//     pairs of batch k   = its (sample b, slot t) pairs sorted by slot                            pair = b << 12 | t, pslot, pid
+// (emb_plan_* kernels below: a count per id, two prefix sums over the vocabulary, a fill -- the only atomics left, and
+// they run once per dataset.)  A step then needs neither emb_mark, nor the rank scans, nor the LDS cache, nor emb_apply:
+//   emb_coef   (DIN; one wavefront per sample, the attention kernels' layout) per pair the three scalars of
+//                  dx_t = alpha dp + beta v + gamma x_t        (alpha = g / T;  cosine: beta = h, gamma = -h s |v| / |x|;
+//                                                                euclid: beta = q / r, gamma = -q / r)
+//              and per sample the item-row gradient gsum = dvh + sum_t (delta_t x_t) + (sum_t eps_t) v
+//   emb_slot   id-major: a lane group walks EMB_SEG consecutive pairs of the sorted list, adds dx (2^-44 fixed point, so the
+//              sum does not depend on the order the plan listed the pairs in) and, where a slot's run ends inside its
+//              segment, writes E[id] -= lr * sum itself: ONE writer per row, no atomic, no second pass.  Runs that cross
+//              segment borders are merged through LDS inside the 1024-thread workgroup (2048 pairs); only a run that
+//              crosses a WORKGROUP border -- the Zipf head: an id with 30 000 occurrences in the batch is 15 of them --
+//              goes through a 64-bit atomic add, and emb_span_apply finishes those rows.
+// Same math as emb_grad_kernel and the same 2^-44 integer sums (bit-reproducible from run to run, and the exchange stays an
+// integer sum); the per-pair expression is associated differently (alpha dp + beta v + gamma x), so the two paths agree to
+// float32 rounding, not bit for bit.  emb_grad_kernel stays for embedding widths the attention layout does not cover (DIN
+// with D not in {4, 8, 16, 32, 64}) and as the A/B reference (GOCTR_EMB_PLAN=0).
+
+struct EmbPlanView {
+  const int* pair;               // [pairs of all batches]  b << 12 | t   (t == T: the candidate item)
+  const int* pslot;              // slot of the pair inside its batch
+  const int* pid;                // embedding row of the pair
+  const long long* pair_off;     // [nb + 1]
+  const int* slot_id;            // [slots of all batches]
+  const unsigned int* slot_off;  // per batch n_slots + 1 entries (relative to the batch's pairs): batch k's start at slot_base[k] + k
+  const long long* slot_base;    // [nb + 1]
+};
+constexpr int EMB_PAIR_TBITS = 12;                 // t < 4096, b < 2^19
+constexpr int EMB_SEG = 32;                        // pairs per lane group
+constexpr int EMB_SLOT_THREADS = 1024;
+
+// ---- plan build (once per dataset): count -> scans (scan.h) -> fill
+struct EmbPlanBuildArgs {
+  RowSource src; int B, T; long long V; int W; long long Vw; long long batch;
+};
+__device__ __forceinline__ long long emb_pidx_w(int id, int W, long long Vw) {
+  if (W == 1) return id;
+  const int q = id / W;
+  return (long long)(id - q * W) * Vw + q;
+}
+__device__ __forceinline__ int emb_plan_pair_id(const EmbPlanBuildArgs& a, long long p, int* code) {
+  const int per = a.T + 1;
+  if (p >= (long long)a.B * per) return -1;
+  const int b = (int)(p / per), t = (int)(p % per);
+  const long long gr = a.batch * (long long)a.B + b;
+  if (gr >= a.src.rows) return -1;
+  const int id = t < a.T ? a.src.ub_ids[gr * a.T + t] : a.src.item_ids[gr];
+  *code = (b << EMB_PAIR_TBITS) | t;
+  return (id >= 0 && id < a.V) ? id : -1;
+}
+__global__ void emb_plan_count_kernel(EmbPlanBuildArgs a, unsigned int* cnt) {
+  int code;
+  const int id = emb_plan_pair_id(a, (long long)blockIdx.x * 256 + threadIdx.x, &code);
+  if (id >= 0) atomicAdd(cnt + emb_pidx_w(id, a.W, a.Vw), 1u);
+}
+struct EmbNonZeroMap {
+  __device__ __forceinline__ unsigned int operator()(unsigned int v) const { return v ? 1u : 0u; }
+};
+// scan 1 (of "touched" flags): slot number of every touched id, slot -> id
+struct EmbPlanSlotSink {
+  unsigned int* rank; int* slot_id; int W; long long Vw;
+  __device__ __forceinline__ void operator()(long long i, unsigned int c, unsigned int r) const {
+    if (c) { rank[i] = r; slot_id[r] = (int)(W == 1 ? i : (i % Vw) * W + i / Vw); }
+  }
+};
+// scan 2 (of the counts): first pair of every slot
+struct EmbPlanOffSink {
+  const unsigned int* rank; unsigned int* slot_off;
+  __device__ __forceinline__ void operator()(long long i, unsigned int c, unsigned int off) const {
+    if (c) slot_off[rank[i]] = off;
+  }
+};
+__global__ void emb_plan_tail_kernel(const unsigned long long* n_slots, const unsigned long long* n_pairs, unsigned int* slot_off) {
+  slot_off[*n_slots] = (unsigned int)*n_pairs;
+}
+// the counts run back to zero here: the array is clean for the next batch
+__global__ void emb_plan_fill_kernel(EmbPlanBuildArgs a, unsigned int* cnt, const unsigned int* rank, const unsigned int* slot_off,
+                                     int* pair, int* pslot, int* pid) {
+  int code;
+  const int id = emb_plan_pair_id(a, (long long)blockIdx.x * 256 + threadIdx.x, &code);
+  if (id < 0) return;
+  const long long pi = emb_pidx_w(id, a.W, a.Vw);
+  const unsigned int s = rank[pi];
+  const unsigned int pos = slot_off[s] + atomicSub(cnt + pi, 1u) - 1u;
+  pair[pos] = code; pslot[pos] = (int)s; pid[pos] = id;
+}
+
+// ---- per step, DIN: the per-pair coefficients (sample-major; the layout of attn_bwd_kernel)
+struct EmbCoefArgs {
+  RowSource src; const StepState* st;
+  int B, T, D;
+  const float* dpv; int ldp;          // [B, ldp]: 0..D-1 d cost / d pooled, D..2D-1 d cost / d item segment of h0
+  const float* gate; const float* att0;
+  float4* coef;                       // [B, T]  (alpha, beta, gamma, -)
+  float* gsum;                        // [B, D]  gradient of the candidate item's row
+};
+// MODE 1 = cosine, 2 = euclid.  VEC = 4, LPR = D / 4 lanes per row.
+template <int LPR, int MODE>
+__global__ __launch_bounds__(256) void emb_coef_kernel(EmbCoefArgs a) {
+  constexpr int VEC = 4, RPP = 64 / LPR, NPB = LPR < 4 ? LPR : 4, SLOTS = NPB * RPP;
+  constexpr bool cosine = MODE == 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= a.B) return;
+  const RowSource& s = a.src;
+  const int dl = lane % LPR, rl = lane / LPR, d0 = dl * VEC;
+  const int D = a.D, T = a.T;
+  const long long gr = a.st->batch_idx * (long long)a.B + b;
+  const bool valid = gr < s.rows;
+  float dpt[VEC], vv[VEC], dvh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { dpt[e] = a.dpv[(size_t)b * a.ldp + d0 + e]; dvh[e] = a.dpv[(size_t)b * a.ldp + D + d0 + e]; }
+  const int item = valid ? s.item_ids[gr] : -1;
+  const bool item_ok = item >= 0 && item < s.V;
+  load_row_nn<VEC>(s.emb + (long long)(item_ok ? item : s.V) * D, d0, D, true, vv);
+  float syy = 0.f;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) syy += vv[e] * vv[e];
+  const float nv = sqrtf(group_sum<LPR>(syy));
+  const float inv_nv = nv > 0.f ? 1.0f / nv : 0.f;
+  const float invT = 1.0f / (float)T;
+  float dsum[VEC] = {0.f, 0.f, 0.f, 0.f};
+  float esum = 0.f;
+  for (int tb = 0; tb < T; tb += SLOTS) {
+    int myid = -1;
+    if (valid && lane < SLOTS && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
+    float gl = 0.f, al = 0.f;
+    if (lane < SLOTS && tb + lane < T) { gl = a.gate[(size_t)b * T + tb + lane]; al = a.att0[tb + lane]; }
+    float x[NPB][VEC];
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+      const int t = tb + p * RPP + rl;
+      const int id = __shfl(myid, p * RPP + rl, 64);
+      load_row_nn<VEC>(s.emb + (long long)((t < T && id >= 0 && id < s.V) ? id : s.V) * D, d0, D, true, x[p]);
+    }
+    const int src = (lane % RPP) * LPR, pw = lane / RPP;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;      // of slot tb + lane: dp . x, |x|^2 (euclid: |x - v|^2), x . v
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+      float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        u0 += dpt[e] * x[p][e];
+        if (cosine) { u1 += x[p][e] * x[p][e]; u2 += x[p][e] * vv[e]; }
+        else { const float df = x[p][e] - vv[e]; u1 += df * df; }
+      }
+      u0 = group_sum<LPR>(u0); u1 = group_sum<LPR>(u1);
+      if (cosine) u2 = group_sum<LPR>(u2);
+      const float v0 = __shfl(u0, src, 64), v1 = __shfl(u1, src, 64), v2 = cosine ? __shfl(u2, src, 64) : 0.f;
+      if (pw == p) { s0 = v0; s1 = v1; s2 = v2; }
+    }
+    // the slot's coefficients, once, in its own lane (the expressions of emb_grad_kernel)
+    const bool live = lane < SLOTS && tb + lane < T && myid >= 0 && myid < s.V;
+    float alpha = 0.f, beta = 0.f, gamma = 0.f, delta = 0.f, eps = 0.f;
+    if (live) {
+      alpha = gl * invT;
+      const float q = s0 * invT * gl * (1.0f - gl) * al;
+      if (cosine) {
+        const float inx = s1 > 0.f ? __frsqrt_rn(s1) : 0.f, nx = s1 * inx;
+        const float iden = __frcp_rn(nx * nv + 1e-8f);
+        const float h = 0.5f * q * iden, sc = s2 * iden;
+        beta = h; gamma = -(h * (sc * nv * inx));
+        delta = h; eps = -(h * (sc * nx * inv_nv));
+      } else {
+        const float ir = s1 > 0.f ? __frsqrt_rn(s1) : 0.f;
+        beta = q * ir; gamma = -(q * ir);
+        delta = q * ir; eps = -(q * ir);
+      }
+    }
+    if (lane < SLOTS && tb + lane < T) a.coef[(size_t)b * T + tb + lane] = make_float4(alpha, beta, gamma, 0.f);
+    esum += eps;
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+      const float d = __shfl(delta, p * RPP + rl, 64);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dsum[e] += d * x[p][e];
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) esum += __shfl_xor(esum, o, 64);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const float dv = cross_row_sum<LPR>(dsum[e]) + esum * vv[e];
+    if (rl == 0) a.gsum[(size_t)b * D + d0 + e] = dv + dvh[e];
+  }
+}
+
+// ---- per step: id-major accumulation over the plan
+struct EmbSlotArgs {
+  EmbPlanView plan; const StepState* st;
+  int B, T, D;
+  const float* dpv; int ldp;
+  const float4* coef; const float* gsum;       // DIN (MODE != 0)
+  const float* h0; int Ip, U;                  // v = h0[b, U + D ..] (the candidate row attn_fwd gathered)
+  float* emb; long long* accum; float lr;
+};
+
+// MODE: 0 mean pooling (dx = dp / T), otherwise DIN (dx = alpha dp + beta v + gamma x).  DIRECT: single GPU -- finished rows are
+// written to the table; false: every slot's sum goes to accum (the send buffer of the data-parallel exchange).
+template <int GS, int MODE, bool DIRECT>
+__global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs a) {
+  constexpr int NG = 64 / GS, GPB = EMB_SLOT_THREADS / GS;
+  __shared__ long long entL[GPB][GS], entR[GPB][GS];
+  __shared__ int slotL[GPB], slotR[GPB], bothL[GPB], idL[GPB], idR[GPB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l = lane % GS, grp = lane / GS, gib = wave * NG + grp;
+  const int D = a.D, T = a.T;
+  const bool act = l < D;
+  const long long k = a.st->batch_idx;
+  const long long pbase = a.plan.pair_off[k], npairs = a.plan.pair_off[k + 1] - pbase;
+  const long long wg_begin = (long long)blockIdx.x * GPB * EMB_SEG;
+  if (wg_begin >= npairs) return;
+  const long long wg_end = wg_begin + GPB * EMB_SEG < npairs ? wg_begin + GPB * EMB_SEG : npairs;
+  const long long sb = a.plan.slot_base[k];
+  const unsigned int* slot_off = a.plan.slot_off + sb + k;
+  const int* pair = a.plan.pair + pbase;
+  const int* pslot = a.plan.pslot + pbase;
+  const int* pid = a.plan.pid + pbase;
+  const long long beg = wg_begin + (long long)gib * EMB_SEG;
+  const long long end = beg + EMB_SEG < wg_end ? beg + EMB_SEG : wg_end;
+  const float invT = 1.0f / (float)T;
+  if (l == 0) { slotL[gib] = -1; slotR[gib] = -1; bothL[gib] = 0; }
+
+  auto finish = [&](int id, long long q) {          // a slot whose whole run was summed here: the only writer of its row
+    if (!act) return;
+    if (DIRECT) {
+      if (q) a.emb[(long long)id * D + l] -= a.lr * (float)((double)q * EMB_FIX_INV);
+    }
+  };
+  if (beg < end) {
+    const int prev_slot = beg > 0 ? pslot[beg - 1] : -1;
+    const int next_slot = end < npairs ? pslot[end] : -1;
+    // the segment's pairs: lane j of the group fetches pair j (and j + GS, ...): coalesced, handed round by shuffle
+    constexpr int NL = EMB_SEG / GS > 0 ? EMB_SEG / GS : 1;
+    int c_[NL], s_[NL], i_[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const long long i = beg + u * GS + l;
+      const bool in = (GS >= EMB_SEG ? l < EMB_SEG : true) && i < end;
+      c_[u] = in ? pair[i] : 0; s_[u] = in ? pslot[i] : -1; i_[u] = in ? pid[i] : 0;
+    }
+    int cur = -1, cur_id = 0;
+    bool cur_ol = false;
+    long long acc = 0;
+    auto close = [&](bool open_right) {
+      if (cur < 0) return;
+      if (!cur_ol && !open_right) {
+        if (DIRECT) finish(cur_id, acc);
+        else if (act) a.accum[(long long)cur * D + l] = acc;
+      } else if (cur_ol) {
+        if (act) entL[gib][l] = acc;
+        if (l == 0) { slotL[gib] = cur; bothL[gib] = open_right ? 1 : 0; idL[gib] = cur_id; }
+      } else {
+        if (act) entR[gib][l] = acc;
+        if (l == 0) { slotR[gib] = cur; idR[gib] = cur_id; }
+      }
+    };
+    constexpr int UNR = 4;
+    constexpr int PER = GS < EMB_SEG ? GS : EMB_SEG;          // pairs one register set (c_[ub], s_[ub], i_[ub]) holds
+#pragma unroll
+    for (int ub = 0; ub < NL; ++ub) {
+      for (int jj = 0; jj < PER; jj += UNR) {
+        if (beg + ub * PER + jj >= end) break;
+        int code[UNR], sl[UNR], id[UNR];
+        float dp[UNR], vv[UNR], xx[UNR];
+        float4 cf[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int srcl = grp * GS + jj + u;
+          code[u] = __shfl(c_[ub], srcl, 64);
+          sl[u] = __shfl(s_[ub], srcl, 64);
+          id[u] = __shfl(i_[ub], srcl, 64);
+          if (beg + ub * PER + jj + u >= end) sl[u] = -1;
+          const int b = code[u] >> EMB_PAIR_TBITS, t = code[u] & ((1 << EMB_PAIR_TBITS) - 1);
+          const bool on = sl[u] >= 0 && act;
+          if (MODE == 0) {
+            dp[u] = on ? a.dpv[(size_t)b * a.ldp + (t < T ? 0 : D) + l] : 0.f;
+          } else {
+            cf[u] = (sl[u] >= 0 && t < T) ? a.coef[(size_t)b * T + t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            dp[u] = on ? (t < T ? a.dpv[(size_t)b * a.ldp + l] : a.gsum[(size_t)b * D + l]) : 0.f;
+            vv[u] = (on && t < T) ? a.h0[(size_t)b * a.Ip + a.U + D + l] : 0.f;
+            xx[u] = (on && t < T) ? a.emb[(long long)id[u] * D + l] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (sl[u] < 0) continue;                              // (group-uniform)
+          if (sl[u] != cur) {
+            close(false);
+            cur = sl[u]; cur_id = id[u]; acc = 0;
+            cur_ol = (ub * PER + jj + u == 0) && cur == prev_slot;
+          }
+          const int t = code[u] & ((1 << EMB_PAIR_TBITS) - 1);
+          float dx;
+          if (MODE == 0) dx = t < T ? invT * dp[u] : dp[u];
+          else dx = t < T ? cf[u].x * dp[u] + cf[u].y * vv[u] + cf[u].z * xx[u] : dp[u];
+          acc += emb_fix(dx);
+        }
+      }
+    }
+    close(cur >= 0 && cur == next_slot);
+  }
+  __syncthreads();
+  // runs that cross segment borders inside this workgroup: the entry that opens a chain sums it
+  //   R(g) [closed left, open right] -> L(g+1) [open left] -> while that one is also open right: L(g+2) ...
+  //   L(0) opens the chain that arrives from the previous workgroup
+  const int ngroups = (int)((wg_end - wg_begin + EMB_SEG - 1) / EMB_SEG);
+  if (gib < ngroups) {
+    for (int which = 0; which < 2; ++which) {
+      // which 0: this group's R entry; which 1: group 0's L entry (arrives from the previous workgroup)
+      if (which == 1 && gib != 0) break;
+      const int s0 = which == 0 ? slotR[gib] : slotL[0];
+      if (s0 < 0) continue;
+      long long tot = which == 0 ? entR[gib][act ? l : 0] : entL[0][act ? l : 0];
+      const int id0 = which == 0 ? idR[gib] : idL[0];
+      bool closed = which == 1 && !bothL[0];
+      bool from_prev = which == 1;
+      int j = gib + 1;
+      if (!(which == 1 && !bothL[0])) {
+        for (; j < ngroups; ++j) {
+          if (slotL[j] != s0) break;                          // (cannot happen for a consistent plan; ends the chain)
+          tot += entL[j][act ? l : 0];
+          if (!bothL[j]) { closed = true; break; }
+        }
+      }
+      const bool whole = closed && !from_prev;                // the run began and ended inside this workgroup
+      if (!act) continue;
+      if (whole) {
+        if (DIRECT) { if (tot) a.emb[(long long)id0 * D + l] -= a.lr * (float)((double)tot * EMB_FIX_INV); }
+        else a.accum[(long long)s0 * D + l] = tot;
+      } else if (tot) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)s0 * D + l), (unsigned long long)tot);
+      }
+    }
+  }
+  (void)slot_off;
+}
+
+// rows whose run crosses a workgroup border of emb_slot_kernel (DIRECT): their sums sit in accum; the FIRST border inside a
+// run applies it and clears the accumulator.  One lane group per border.
+template <int GS>
+__global__ __launch_bounds__(256) void emb_span_apply_kernel(EmbSlotArgs a) {
+  constexpr int GPB = EMB_SLOT_THREADS / GS;
+  const long long WGP = (long long)GPB * EMB_SEG;
+  const int l = threadIdx.x % GS;
+  const long long w = (long long)blockIdx.x * (256 / GS) + threadIdx.x / GS + 1;      // border index, >= 1
+  const long long k = a.st->batch_idx;
+  const long long pbase = a.plan.pair_off[k], npairs = a.plan.pair_off[k + 1] - pbase;
+  const long long pos = w * WGP;
+  if (pos >= npairs) return;
+  const int* pslot = a.plan.pslot + pbase;
+  const int s = pslot[pos];
+  if (pslot[pos - 1] != s) return;
+  const long long sb = a.plan.slot_base[k];
+  const unsigned int start = a.plan.slot_off[sb + k + s];
+  if ((long long)(start / WGP) + 1 != w) return;              // an earlier border of the same run does it
+  if (l >= a.D) return;
+  const int id = a.plan.slot_id[sb + s];
+  const long long q = a.accum[(long long)s * a.D + l];
+  a.accum[(long long)s * a.D + l] = 0;
+  if (q) a.emb[(long long)id * a.D + l] -= a.lr * (float)((double)q * EMB_FIX_INV);
+}
+
+// data parallel: the exchange (ctr.hip: launch_emb_exchange) wants the batch's slot -> id list and slot count in fixed buffers
+__global__ void emb_plan_select_kernel(EmbPlanView plan, const StepState* st, int* slot_id_out, unsigned long long* n_slots_out) {
+  const long long k = st->batch_idx;
+  const long long sb = plan.slot_base[k], n = plan.slot_base[k + 1] - sb;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) slot_id_out[i] = plan.slot_id[sb + i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_slots_out = (unsigned long long)n;
+}
+
 // Sink of the rank scan (scan.h): rank of every id, slot -> id list of the touched ones (ascending ids), and the marks
 // are cleared for the next step in the same pass.
 struct EmbMultiMap {

@@ -97,13 +97,73 @@ def test_single_occurrence_ids_in_place_equals_accumulate_path(tmp_path):
     res = []
     for singles in ("1", "0"):
         out = str(tmp_path / f"s{singles}.npy")
-        env = dict(os.environ, GOCTR_EMB_SINGLES=singles)
+        env = dict(os.environ, GOCTR_EMB_SINGLES=singles, GOCTR_EMB_PLAN="0")      # (the atomics path: what widths outside the plan path use)
         r = subprocess.run([sys.executable, "-c", SINGLES_SCRIPT % dict(root=root, out=out)], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(np.load(out))
     assert np.isfinite(res[0]).all()
     assert np.array_equal(res[0], res[1])
+
+
+def test_plan_path_equals_atomics_path_and_is_reproducible(tmp_path):
+    """the id-major plan path (round 3: no contended atomics) against emb_grad_kernel's LDS-cache + atomics path on the same five
+    steps (a hot head, a long tail of singles, wrap-around over three batches): same math, 2^-44 integer sums on both sides,
+    the per-pair expression associated differently => float32 rounding apart; and the plan path twice => the same bits"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for tag, plan in (("p1", "1"), ("p2", "1"), ("a", "0")):
+        out = str(tmp_path / f"{tag}.npy")
+        r = subprocess.run([sys.executable, "-c", SINGLES_SCRIPT % dict(root=root, out=out)], env=dict(os.environ, GOCTR_EMB_PLAN=plan),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(out))
+    assert np.isfinite(res[0]).all()
+    assert np.array_equal(res[0], res[1])                               # bit-reproducible (new process, new plan build)
+    assert not np.array_equal(res[0][:40000 * 16], np.zeros(40000 * 16, np.float32))
+    assert np.max(np.abs(res[0] - res[2])) <= 2e-6 * max(1.0, float(np.max(np.abs(res[2]))))
+
+
+@pytest.mark.parametrize("kind,att,D", [("youtube", 0, 16), ("din", 0, 16), ("din", 1, 16), ("youtube", 0, 64), ("din", 0, 64)])
+def test_hot_ids_whose_runs_cross_segments_and_workgroups(oracle, kind, att, D):
+    """one id carries most of the batch's pairs (a run of > 10 000 pairs: it crosses hundreds of 32-pair segments and several
+    2048-pair workgroups of emb_slot_kernel -- LDS merge, atomics on the workgroup borders, emb_span_apply), a second one a
+    few hundred, the rest are singles"""
+    from goctr_amd import capi, model as gm
+    U, Cc, V, B, T = 8, 6, 5000, 1024, 20
+    rows = B
+    om, m, E, ub, items, uf, cf, y = _setup(oracle, kind, att, U, T, D, Cc, V, rows, seed=5 + D)
+    rng = np.random.default_rng(9)
+    hot = rng.random((rows, T))
+    ub[hot < 0.6] = 7
+    ub[(hot >= 0.6) & (hot < 0.63)] = 4999
+    items[::3] = 7
+    lr = 0.5
+    loss, dE = om.emb_loss_grad(E.astype(np.float64), ub, items, uf, cf, y, B=B)
+    tab = gm.EmbeddingTable(E)
+    ds = gm.Dataset.ids(ub, items, uf, cf, y)
+    m.set_embedding_training(lr)
+    costs = gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0), 1, emb=tab, want_costs=True)
+    capi.sync()
+    got = tab.get_rows()
+    upd = np.abs(lr * dE).max()
+    assert np.abs(got - (E.astype(np.float64) - lr * dE)).max() <= 1e-4 * upd + 1e-7
+    assert abs(float(costs[0]) - loss) < 1e-5 * max(1.0, abs(loss))
+    touched = np.zeros(V, bool)
+    touched[ub[(ub >= 0) & (ub < V)]] = True
+    touched[items[items >= 0]] = True
+    assert np.array_equal(got[~touched], E[~touched])
+    # second step on the same batch: the accumulators the borders used were left clean
+    E1 = got.copy()
+    loss2, dE2 = om.emb_loss_grad(E1.astype(np.float64), ub, items, uf, cf, y, B=B)
+    # (the dense weights moved too: only check finiteness and untouched rows here)
+    gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0), 1, first_batch=0, emb=tab)
+    capi.sync()
+    got2 = tab.get_rows()
+    assert np.isfinite(got2).all() and np.array_equal(got2[~touched], E[~touched])
+    assert np.abs(got2 - E1).max() <= 4 * upd                           # a sane second update, not a doubled accumulator
+    del loss2, dE2
 
 
 def test_one_step_matches_oracle_large_vocabulary(oracle):
