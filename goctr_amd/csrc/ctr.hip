@@ -47,6 +47,7 @@ struct StepGraph {
   // One captured step per ping-pong parity of the step state (a step reads slot p and writes slot p^1).
   // b[] only when a communicator splits the step (all-reduce between reduce and Adam).
   hipGraphExec_t a[2] = {nullptr, nullptr}, b[2] = {nullptr, nullptr};
+  hipGraphExec_t mid[2] = {nullptr, nullptr};   // data parallel + trainable embeddings: owner side of the sparse exchange + slab reduce
   // multi[p]: multi_steps (even) consecutive steps starting at parity p in ONE graph (single GPU): the boundary between
   // two graph launches costs about two kernel-to-kernel edges; every per-step scalar is device state, so nothing else changes
   // (built together with a[]: a first call in a timed region must not pay for a capture)
@@ -65,15 +66,16 @@ struct StepGraph {
     // exec in flight is not something HIP documents as safe.  The capture that follows a destroy is host-heavy anyway.
     bool any = false;
     for (int k = 0; k < 2; ++k) {
-      any = any || a[k] || b[k];
+      any = any || a[k] || b[k] || mid[k];
       for (int z = 0; z < kNMulti; ++z) any = any || multi[z][k];
     }
     if (any && engine().inited) (void)hipStreamSynchronize(engine().stream);
     for (int k = 0; k < 2; ++k) {
       if (a[k]) (void)hipGraphExecDestroy(a[k]);
       if (b[k]) (void)hipGraphExecDestroy(b[k]);
+      if (mid[k]) (void)hipGraphExecDestroy(mid[k]);
       for (int z = 0; z < kNMulti; ++z) { if (multi[z][k]) (void)hipGraphExecDestroy(multi[z][k]); multi[z][k] = nullptr; }
-      a[k] = b[k] = nullptr;
+      a[k] = b[k] = mid[k] = nullptr;
     }
     multi_on = false;
   }
@@ -147,6 +149,7 @@ struct goctr_model {
   float emb_lr = 0.f;
   long long emb_V = 0; int emb_B = 0, emb_world = 0; bool emb_comm = false;
   DevBuf<float> dpv, W0pvT;
+  bool w0pv_live = false;         // W0pvT holds the current W0[U:U+2D,:]^T and the Adam kernels keep it current
   DevBuf<unsigned int> emb_mark, emb_rank, emb_tiles;
   DevBuf<unsigned long long> emb_total;
   DevBuf<long long> emb_accum;
@@ -160,6 +163,10 @@ struct goctr_model {
     EmbPlanView view() const { return EmbPlanView{pair.p, pslot.p, pid.p, pair_off.p, slot_id.p, slot_off.p, slot_base.p}; }
   } plan;
   DevBuf<float4> emb_coef; DevBuf<float> emb_gsum;
+  // fixed-size exchange (emb_train.h, end): exact bounds from the plan, no host read-back between the collectives
+  bool ex_fixed = false; int ex_S = 0, ex_R = 0;
+  DevBuf<int> ex_bucket_off, ex_send_ids, ex_recv_ids; DevBuf<long long> ex_send_rows, ex_recv_rows;
+  ReduceArgs pend_ra{};            // launch_backward(stage 1) -> (stage 2)
   // bucketed exchange (data parallel): bucket bounds / counts, received pairs, the owner's reduction, the gathered deltas
   DevBuf<int> ex_off, ex_cnt, ex_allcnt, ex_rids, ex_red_ids, ex_nred, ex_allnred, ex_gids;
   DevBuf<long long> ex_rrows, ex_red;
@@ -741,6 +748,7 @@ int ensure_emb_workspace(goctr_model* m, long long V, int B) {
   }
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
   m->emb_V = V; m->emb_B = B; m->emb_world = engine().world; m->emb_comm = engine().comm_active(); m->emb_Vw = Vw;
+  m->w0pv_live = false; m->plan.valid = false;      // (W0pvT was reallocated; the plan's index space may have changed)
   m->graph.destroy();
   return 0;
 }
@@ -890,6 +898,37 @@ int ensure_emb_plan(goctr_model* m, const goctr_dataset* d, const RowSource& src
   GOCTR_HIP(hipMemcpyAsync(P.slot_off.p, tsoff.p, (ns + (size_t)nb) * 4, hipMemcpyDeviceToDevice, s));
   if (P.pair_off.upload(pair_off.data(), pair_off.size()) || P.slot_base.upload(slot_base.data(), slot_base.size())) return -1;   // (synchronises)
   if (c.kind == GOCTR_DIN && (m->emb_coef.ensure((size_t)B * c.T, false) || m->emb_gsum.ensure((size_t)B * c.D, false))) return -1;
+  m->ex_fixed = false;
+  if (e.comm_active() && env_int("GOCTR_EMB_FIXED_EXCHANGE", 1) != 0) {
+    // bucket bounds of every batch, the largest bucket over batches, owners AND ranks (one small all-gather, here, once)
+    GOCTR_CHECK(W <= 1023, "world %d too large for the bucket kernel", W);
+    if (m->ex_bucket_off.alloc((size_t)nb * (W + 1), false)) return -1;
+    hipLaunchKernelGGL(emb_plan_buckets_kernel, dim3((unsigned)nb), dim3((unsigned)round_up(W + 1, 64)), 0, s, P.view(), nb, W, m->ex_bucket_off.p);
+    GOCTR_HIP(hipGetLastError());
+    std::vector<int> boff((size_t)nb * (W + 1));
+    if (m->ex_bucket_off.download(boff.data(), boff.size())) return -1;
+    int smax = 1;
+    for (long long k = 0; k < nb; ++k)
+      for (int o = 0; o < W; ++o) smax = std::max(smax, boff[(size_t)k * (W + 1) + o + 1] - boff[(size_t)k * (W + 1) + o]);
+    DevBuf<int> one, all;
+    if (one.alloc(1, false) || all.alloc((size_t)W, false) || one.upload(&smax, 1)) return -1;
+    if (comm_allgather_i32(one.p, all.p, 1)) return -1;
+    std::vector<int> hs((size_t)W);
+    if (all.download(hs.data(), (size_t)W)) return -1;
+    for (int v : hs) smax = std::max(smax, v);
+    const int S = round_up(smax, 4);
+    const long long R = std::min<long long>(Vw, (long long)W * S);
+    m->ex_S = S; m->ex_R = (int)R;
+    const size_t ws = (size_t)W * S, wr = (size_t)W * (size_t)R;
+    if (m->ex_send_ids.alloc(ws, false) || m->ex_recv_ids.alloc(ws, false) || m->ex_send_rows.alloc(ws * c.D, false) ||
+        m->ex_recv_rows.alloc(ws * c.D, false) || m->ex_red.alloc(std::max<size_t>((size_t)R * c.D, 1)) ||     // (zeroed; kept zero by emb_delta)
+        m->ex_red_ids.alloc(std::max<size_t>((size_t)R, 1), false) || m->ex_delta.alloc(std::max<size_t>((size_t)R * c.D, 1), false) ||
+        m->ex_gids.alloc(std::max<size_t>(wr, 1), false) || m->ex_gdelta.alloc(std::max<size_t>(wr * c.D, 1), false)) return -1;
+    GOCTR_HIP(hipStreamSynchronize(s));
+    m->ex_fixed = true;
+    // bytes this rank sends per step: W padded buckets of (id, fixed-point row) + its padded (id, delta) list to every rank
+    m->ex_bytes_last = (double)W * S * (4 + 8.0 * c.D) + (double)W * (double)R * (4 + 4.0 * c.D);
+  }
   P.ds = d->uid; P.V = src.V; P.B = B; P.W = W; P.T = c.T; P.nb = nb; P.max_pairs = max_pairs; P.max_slots = max_slots;
   P.total_pairs = pair_off[nb]; P.total_slots = slot_base[nb];
   P.valid = true;
@@ -948,8 +987,17 @@ int launch_emb_plan_step(goctr_model* m, const RowSource& src, int B, const Step
                                                                               : launch_emb_slot_gs<64>(mode, direct, grid, s, a)) return -1;
   }
   if (direct) return 0;
-  // data parallel: the exchange reads the batch's slot -> id list and count from fixed buffers
   const int cus = e.compute_units > 0 ? e.compute_units : 256;
+  if (m->ex_fixed) {
+    // fixed-size buckets: pack the send buffers; the collectives and the owner's side follow from the step driver
+    // (emb_exchange_* below), with no host read-back anywhere
+    const long long n = (long long)e.world * m->ex_S * c.D;
+    hipLaunchKernelGGL(emb_pack_send_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(cdiv(n, 256), 1), 8 * cus)), dim3(256), 0, s,
+                       m->plan.view(), st, m->ex_bucket_off.p, e.world, m->ex_S, c.D, m->emb_accum.p, m->ex_send_ids.p, m->ex_send_rows.p);
+    GOCTR_HIP(hipGetLastError());
+    return 0;
+  }
+  // data parallel without fixed bounds: the exchange reads the batch's slot -> id list and count from fixed buffers
   hipLaunchKernelGGL(emb_plan_select_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(cdiv(m->plan.max_slots, 256), 1), 4 * cus)), dim3(256), 0, s,
                      m->plan.view(), st, m->emb_slot_id.p, m->emb_total.p);
   GOCTR_HIP(hipGetLastError());
@@ -979,13 +1027,9 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   a.W = W; a.Vw = m->emb_Vw;
   hipStream_t s = e.stream;
   if (m->plan.valid) {
-    // the id-major path: no marks, no scans, no accumulators to apply -- the dpv GEMM, then the plan kernels
-    {
-      ProfScope ps(GOCTR_K_EMB_TRAIN);
-      hipLaunchKernelGGL(w0pv_transpose_kernel, dim3((unsigned)cdiv((long long)m->H1p * Np, 256)), dim3(256), 0, s, m->W.p, m->H1p,
-                         c.U, 2 * c.D, Np, m->W0pvT.p);
-      GOCTR_HIP(hipGetLastError());
-    }
+    // the id-major path: no marks, no scans, no accumulators to apply -- the dpv GEMM, then the plan kernels.
+    // (W0[U:U+2D,:]^T is transposed once per call sequence -- ensure_w0pv, outside the captured step -- and then kept
+    // current by the Adam kernels like the other operand copies: 4.2 us per step less)
     EpiStore sp{m->dpv.p, Np};
     if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
     return launch_emb_plan_step(m, src, B, st, Np);
@@ -1044,10 +1088,70 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
 }
 
 // backward part up to and including the slab reduce (optionally fused with Adam on a single GPU)
+// ---- the fixed-size exchange of a data-parallel step with trainable embeddings, piece by piece (emb_train.h, end):
+//   [graph 1: forward, backward, plan kernels, emb_pack_send]  ->  emb_exchange_a2a  ->  [graph 2: emb_exchange_owner, slab
+//   reduce]  ->  emb_exchange_gather + the dense all-reduce  ->  [graph 3: emb_exchange_apply, Adam]
+bool emb_split3(const goctr_model* m) { return engine().comm_active() && m->emb_lr > 0.f && m->plan.valid && m->ex_fixed; }
+// uniform all-to-all: S (id, row) entries to and from every rank
+int emb_exchange_a2a(goctr_model* m) {
+  Engine& e = engine();
+  const int W = e.world, D = m->cfg.D;
+  std::vector<size_t> off((size_t)W), cnt((size_t)W), offD((size_t)W), cntD((size_t)W);
+  for (int p = 0; p < W; ++p) { off[p] = (size_t)p * m->ex_S; cnt[p] = (size_t)m->ex_S; offD[p] = off[p] * D; cntD[p] = cnt[p] * D; }
+  ProfScope ps(GOCTR_K_ALLREDUCE);
+  if (comm_alltoallv(m->ex_send_ids.p, off.data(), cnt.data(), m->ex_recv_ids.p, off.data(), cnt.data(), 4)) return -1;
+  return comm_alltoallv(m->ex_send_rows.p, offD.data(), cntD.data(), m->ex_recv_rows.p, offD.data(), cntD.data(), 8);
+}
+// owner: unique ids of my bucket among the W * S received entries -> dense slots, exact integer sums, deltas, padded id list
+int emb_exchange_owner(goctr_model* m) {
+  Engine& e = engine();
+  const int W = e.world, r = e.rank, D = m->cfg.D;
+  hipStream_t s = e.stream;
+  const long long nrecv = (long long)W * m->ex_S;
+  const int cus = e.compute_units > 0 ? e.compute_units : 256;
+  ProfScope ps(GOCTR_K_EMB_TRAIN);
+  hipLaunchKernelGGL(emb_recv_mark_kernel, dim3((unsigned)cdiv(nrecv, 256)), dim3(256), 0, s, m->ex_recv_ids.p, nrecv, W, m->emb_Vw, m->emb_mark.p);
+  GOCTR_HIP(hipGetLastError());
+  if (exclusive_scan_sink(m->emb_mark.p + (size_t)r * m->emb_Vw, m->emb_Vw, m->emb_tiles, m->ex_red_total.p, EmbMultiMap{},
+                          EmbRankSink{m->emb_mark.p, m->emb_rank.p, m->ex_red_ids.p, W, m->emb_Vw, (long long)r * m->emb_Vw})) return -1;
+  hipLaunchKernelGGL(emb_recv_accumulate_kernel, dim3((unsigned)cdiv(nrecv * D, 256)), dim3(256), 0, s, m->ex_recv_ids.p, m->ex_recv_rows.p,
+                     nrecv, D, W, m->emb_Vw, m->emb_rank.p, m->ex_red.p);
+  hipLaunchKernelGGL(emb_delta_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(cdiv((long long)m->ex_R * D, 256), 1), 16 * cus)), dim3(256), 0, s,
+                     m->ex_red.p, m->ex_red_total.p, D, m->emb_lr, m->ex_delta.p);
+  hipLaunchKernelGGL(emb_pad_ids_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(cdiv((long long)m->ex_R, 256), 1), 4 * cus)), dim3(256), 0, s,
+                     m->ex_red_ids.p, m->ex_red_total.p, m->ex_R);
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+// every owner's R (id, delta) entries to every rank
+int emb_exchange_gather(goctr_model* m) {
+  const int D = m->cfg.D;
+  ProfScope ps(GOCTR_K_ALLREDUCE);
+  if (comm_allgather_i32(m->ex_red_ids.p, m->ex_gids.p, (size_t)m->ex_R)) return -1;
+  return comm_allgather_i32(reinterpret_cast<const int*>(m->ex_delta.p), reinterpret_cast<int*>(m->ex_gdelta.p), (size_t)m->ex_R * D);
+}
+// every replica applies every delta (ids are unique across the owners' lists; -1 = padding)
+int emb_exchange_apply(goctr_model* m, const RowSource& src) {
+  Engine& e = engine();
+  const int D = m->cfg.D;
+  const long long ng = (long long)e.world * m->ex_R;
+  const int cus = e.compute_units > 0 ? e.compute_units : 256;
+  ProfScope ps(GOCTR_K_EMB_TRAIN);
+  hipLaunchKernelGGL(emb_apply_gathered_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(cdiv(ng * D, 256), 1), 16 * cus)), dim3(256), 0, e.stream,
+                     const_cast<float*>(src.emb), m->ex_gids.p, m->ex_gdelta.p, ng, D);
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_reduce_part(goctr_model* m, const RowSource& src, int B, const StepOpts& o, bool advance, bool fuse_update, const ReduceArgs& ra);
+// stage 0: the whole backward; 1: everything before the slab reduce (the sparse embedding update ends with its send buffers
+// packed); 2: the slab reduce alone -- the two halves of a data-parallel step with trainable embeddings, whose all-to-all
+// runs between them (split3 below)
 int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts& o, bool advance,
-                    bool fuse_update = false) {
+                    bool fuse_update = false, int stage = 0) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
+  if (stage == 2) return launch_reduce_part(m, src, B, o, advance, fuse_update, m->pend_ra);
   const StepState* st = m->st_cur();
   const uint32_t row_off = (uint32_t)(e.rank * B);
   const bool drop = o.drop_mode != 0;
@@ -1194,6 +1298,13 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     ra.nseg = 4;
   }
   ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st_cur(); ra.st_out = m->st_next(); ra.advance = advance ? 1 : 0;
+  if (stage == 1) { m->pend_ra = ra; return 0; }
+  return launch_reduce_part(m, src, B, o, advance, fuse_update, ra);
+}
+
+int launch_reduce_part(goctr_model* m, const RowSource& src, int B, const StepOpts& o, bool advance, bool fuse_update, const ReduceArgs& ra) {
+  const goctr_ctr_cfg& c = m->cfg;
+  Engine& e = engine();
   if (fuse_update) {
     ReduceAdamArgs p{};
     p.r = ra; p.ad = make_adam_args(m, B, *o.tc);
@@ -1226,6 +1337,8 @@ AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc) {
   a.W1T = m->W1T.p; a.W2T = m->W2T.p; a.W0sT = m->W0sT.p;
   a.W0i = m->img(0); a.W1i = m->img(1); a.W1Ti = m->img(2); a.W0sTi = m->img(3);
   a.x3 = m->x3_images();
+  // (kept in step with W0 once embedding training has built it: launch_emb_train transposes it once, Adam keeps it current)
+  a.W0pvT = (m->emb_lr > 0.f && m->w0pv_live) ? m->W0pvT.p : nullptr; a.Npv = round_up(2 * m->cfg.D, 16);
   a.lr = tc.lr; a.l2 = tc.l2; a.beta1 = tc.beta1; a.beta2 = tc.beta2; a.eps = tc.eps;
   a.div_by_batch = tc.adam_div_by_batch; a.l2_first = tc.adam_l2_before_batch_div;
   a.bglobal = B * e.world; a.st = m->st_cur(); a.costs = m->costs.p;
@@ -1250,6 +1363,12 @@ int allreduce_grads(goctr_model* m) {
 int train_step_eager(goctr_model* m, const RowSource& src, int B, const StepOpts& o) {
   if (launch_forward(m, src, B, o)) return -1;
   const bool fuse = !engine().comm_active() && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
+  if (emb_split3(m)) {
+    if (launch_backward(m, src, B, o, true, false, 1) || emb_exchange_a2a(m) || emb_exchange_owner(m) ||
+        launch_backward(m, src, B, o, true, false, 2) || emb_exchange_gather(m) || allreduce_grads(m) ||
+        emb_exchange_apply(m, src)) return -1;
+    return launch_adam(m, B, *o.tc);
+  }
   if (launch_backward(m, src, B, o, true, fuse)) return -1;
   if (fuse) return 0;
   if (allreduce_grads(m)) return -1;
@@ -1272,18 +1391,29 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   for (int par = 0; par < 2; ++par) {
     m->stp = par;                      // the captured launches bake this parity's state pointers in
     hipGraph_t g = nullptr;
+    const bool split3 = emb_split3(m);
     GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-    int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse);
+    int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse, split3 ? 1 : 0);
     if (!rc && !e.comm_active() && !fuse) rc = launch_adam(m, B, *o.tc);
     hipError_t ce = hipStreamEndCapture(e.stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); m->stp = stp_now; return -1; }
     GOCTR_HIP(ce);
     GOCTR_HIP(hipGraphInstantiate(&m->graph.a[par], g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
+    if (split3) {
+      hipGraph_t gm = nullptr;
+      GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+      rc = emb_exchange_owner(m) || launch_backward(m, src, B, o, true, false, 2);
+      ce = hipStreamEndCapture(e.stream, &gm);
+      if (rc) { if (gm) (void)hipGraphDestroy(gm); m->stp = stp_now; return -1; }
+      GOCTR_HIP(ce);
+      GOCTR_HIP(hipGraphInstantiate(&m->graph.mid[par], gm, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(gm);
+    }
     if (e.comm_active()) {
       hipGraph_t g2 = nullptr;
       GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-      rc = launch_adam(m, B, *o.tc);     // m->stp was flipped by launch_backward: Adam reads the new slot
+      rc = (split3 && emb_exchange_apply(m, src)) || launch_adam(m, B, *o.tc);     // m->stp was flipped by launch_backward: Adam reads the new slot
       ce = hipStreamEndCapture(e.stream, &g2);
       if (rc) { if (g2) (void)hipGraphDestroy(g2); m->stp = stp_now; return -1; }
       GOCTR_HIP(ce);
@@ -1386,6 +1516,19 @@ int mark_weights_written(goctr_model* m) {
   return 0;
 }
 
+// W0[U:U+2D,:]^T for the dpv GEMM of the plan path: built here (outside any capture), then maintained by the Adam kernels
+int ensure_w0pv(goctr_model* m) {
+  if (m->w0pv_live) return 0;
+  const goctr_ctr_cfg& c = m->cfg;
+  const int Np = round_up(2 * c.D, 16);
+  hipLaunchKernelGGL(w0pv_transpose_kernel, dim3((unsigned)cdiv((long long)m->H1p * Np, 256)), dim3(256), 0, engine().stream, m->W.p, m->H1p,
+                     c.U, 2 * c.D, Np, m->W0pvT.p);
+  GOCTR_HIP(hipGetLastError());
+  m->w0pv_live = true;
+  m->graph.destroy();            // the captured Adam launches did not carry the pointer
+  return 0;
+}
+
 // queue n_steps training steps (graph replay unless profiling / disabled)
 int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* tc, int n_steps);
 int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* tc, int n_steps) {
@@ -1401,15 +1544,16 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
   if (m->emb_lr > 0.f) {
     GOCTR_CHECK(src.id_mode, "embedding training needs an id-mode dataset (the dense TrainSample rows carry no ids)");
     if (ensure_emb_workspace(m, src.V, B)) return -1;
-    if (emb_plan_ok(m, B)) { if (ensure_emb_plan(m, d, src, B)) return -1; }
-    else m->plan.valid = false;
+    if (emb_plan_ok(m, B)) { if (ensure_emb_plan(m, d, src, B) || ensure_w0pv(m)) return -1; }
+    else { m->plan.valid = false; m->w0pv_live = false; }
   }
   // the bias corrections of the state the call starts from (ctr_kernels.h: StepState::corr1/2); later states get theirs from
   // the loss block of the step before them
   hipLaunchKernelGGL(step_state_corr_kernel, dim3(1), dim3(1), 0, e.stream, m->st_cur(), o.tc->beta1, o.tc->beta2);
   GOCTR_HIP(hipGetLastError());
-  // (with a communicator the sparse embedding exchange sizes a collective from a device counter: eager steps)
-  const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0 && !(e.comm_active() && m->emb_lr > 0.f);
+  // (with a communicator and NO plan the sparse embedding exchange sizes its collectives from device counters read back by
+  // the host: eager steps.  With the plan's fixed-size buckets the step is three captured graphs around the collectives.)
+  const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0 && !(e.comm_active() && m->emb_lr > 0.f && !emb_split3(m));
   if (use_graph) {
     o.pipelined = pipeline_ok(m, src);
     if (!graph_matches(m->graph, d, emb, B, o) && build_graph(m, d, emb, src, B, o)) return -1;
@@ -1431,6 +1575,11 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
     for (; s < n_steps; ++s) {
       const int par = m->stp;
       GOCTR_HIP(hipGraphLaunch(m->graph.a[par], e.stream));
+      if (m->graph.mid[par]) {          // data parallel + trainable embeddings: all-to-all, owner side + slab reduce, all-gather
+        if (emb_exchange_a2a(m)) return -1;
+        GOCTR_HIP(hipGraphLaunch(m->graph.mid[par], e.stream));
+        if (emb_exchange_gather(m)) return -1;
+      }
       m->stp ^= 1;
       if (e.comm_active()) {
         if (allreduce_grads(m)) return -1;
@@ -1595,6 +1744,7 @@ int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, si
   GOCTR_CHECK(m && host, "goctr_model_set_weights: null argument");
   std::unique_lock<std::shared_mutex> lk(m->mu);
   if (upload_padded_weights(m, tensor_id, host, n)) return -1;
+  if (tensor_id == GOCTR_W0) m->w0pv_live = false;
   if ((tensor_id == GOCTR_W0 || tensor_id == GOCTR_W1) && rebuild_x3_images(m)) return -1;
   return mark_weights_written(m);
 }
@@ -1679,6 +1829,7 @@ int goctr_model_set_embedding_training(goctr_model* m, double lr) {
   std::unique_lock<std::shared_mutex> lk(m->mu);
   GOCTR_CHECK(lr == 0 || m->cfg.D <= 64, "embedding training supports D <= 64 (got %d)", m->cfg.D);
   m->emb_lr = (float)lr;
+  m->w0pv_live = false;            // (the Adam kernels only keep W0pvT current while embedding training is on)
   m->graph.destroy();
   return 0;
 }
@@ -1825,12 +1976,26 @@ __global__ __launch_bounds__(256) void assemble_keys_kernel(const long long* __r
   long long first = 0, cnt = 0;
   const long long b = (uok && off) ? off[u] : 0, len = (uok && off) ? off[u + 1] - b : 0;   // off == NULL: no behaviour cache
   if (len > 0) {
-    long long mts = ts ? ts[r] : 0;
-    if (mts == 0) mts = seq_ts[b];                       // cache.go:72-74
-    long long lo = 0, hi = len;                          // first i with seq_ts[b + i] <= mts (descending order)
-    while (lo < hi) {
-      const long long mid = (lo + hi) >> 1;
-      if (seq_ts[b + mid] <= mts) hi = mid; else lo = mid + 1;
+    const long long mts = ts ? ts[r] : 0;
+    // first i with seq_ts[b + i] <= mts (descending order); mts == 0 means "from the newest" (cache.go:72-74: maxTs = Ts[0])
+    long long lo = 0;
+    if (mts != 0) {
+      if (len <= 256) {
+        // short histories (the common case): 64 entries per coalesced load and one ballot instead of a chain of ~7 dependent
+        // loads -- the serving pass of a Rank call is latency, not work
+        lo = len;
+        for (long long base = 0; base < len; base += 64) {
+          const long long i = base + lane;
+          const unsigned long long le = __ballot(i < len && seq_ts[b + i] <= mts);
+          if (le) { lo = base + (long long)__builtin_ctzll(le); break; }
+        }
+      } else {
+        long long hi = len;
+        while (lo < hi) {
+          const long long mid = (lo + hi) >> 1;
+          if (seq_ts[b + mid] <= mts) hi = mid; else lo = mid + 1;
+        }
+      }
     }
     first = lo;
     cnt = len - first < T ? len - first : T;

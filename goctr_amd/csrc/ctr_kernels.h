@@ -592,6 +592,7 @@ struct AdamArgs {
   int Ip, H1p, H2p, Dp, U, D;
   float* W1T; float* W2T; float* W0sT;  // transposed copies used by the backward-data GEMMs
   float* W0i; float* W1i; float* W1Ti; float* W0sTi;  // LDS images [K/4][N][4] read by the chain kernel
+  float* W0pvT; int Npv;     // trainable embeddings (emb_train.h): W0[U : U+2D, :]^T as [H1p, Npv], the B operand of dpv = dz0 . W0pv^T (null: not kept)
   CxImages x3;               // bf16-plane fragment images of the 6-product-split chain kernel (img0 == null: not kept)
   double lr, l2, beta1, beta2, eps;
   int div_by_batch, l2_first;
@@ -647,6 +648,7 @@ __device__ __forceinline__ void adam_apply_pre(const AdamArgs& a, int idx, float
       a.W0sT[(size_t)c * a.Dp + (r - a.U)] = w;
       a.W0sTi[img_index(c, r - a.U, a.Dp)] = w;
     }
+    if (a.W0pvT && r >= a.U && r < a.U + 2 * a.D) a.W0pvT[(size_t)c * a.Npv + (r - a.U)] = w;
   } else if (idx < a.off2) {
     const int k = idx - a.off1;
     const int r = k / a.H2p, c = k - r * a.H2p;

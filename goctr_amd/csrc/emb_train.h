@@ -564,10 +564,13 @@ __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs 
   const float invT = 1.0f / (float)T;
   if (l == 0) { slotL[gib] = -1; slotR[gib] = -1; bothL[gib] = 0; }
 
-  auto finish = [&](int id, long long q) {          // a slot whose whole run was summed here: the only writer of its row
+  // a slot whose whole run was summed here: this lane group is the only writer of its row.  x = the row's value, loaded
+  // together with the run's first pair (a load issued HERE would put one memory latency between every two runs: at cfg4
+  // nearly every pair is a run of its own and the kernel took 100 us that way)
+  auto finish = [&](int id, float x, long long q) {
     if (!act) return;
     if (DIRECT) {
-      if (q) a.emb[(long long)id * D + l] -= a.lr * (float)((double)q * EMB_FIX_INV);
+      if (q) a.emb[(long long)id * D + l] = x - a.lr * (float)((double)q * EMB_FIX_INV);
     }
   };
   if (beg < end) {
@@ -583,12 +586,13 @@ __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs 
       c_[u] = in ? pair[i] : 0; s_[u] = in ? pslot[i] : -1; i_[u] = in ? pid[i] : 0;
     }
     int cur = -1, cur_id = 0;
+    float cur_x = 0.f;
     bool cur_ol = false;
     long long acc = 0;
     auto close = [&](bool open_right) {
       if (cur < 0) return;
       if (!cur_ol && !open_right) {
-        if (DIRECT) finish(cur_id, acc);
+        if (DIRECT) finish(cur_id, cur_x, acc);
         else if (act) a.accum[(long long)cur * D + l] = acc;
       } else if (cur_ol) {
         if (act) entL[gib][l] = acc;
@@ -616,13 +620,13 @@ __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs 
           if (beg + ub * PER + jj + u >= end) sl[u] = -1;
           const int b = code[u] >> EMB_PAIR_TBITS, t = code[u] & ((1 << EMB_PAIR_TBITS) - 1);
           const bool on = sl[u] >= 0 && act;
+          xx[u] = (on && (MODE != 0 || DIRECT)) ? a.emb[(long long)id[u] * D + l] : 0.f;
           if (MODE == 0) {
             dp[u] = on ? a.dpv[(size_t)b * a.ldp + (t < T ? 0 : D) + l] : 0.f;
           } else {
             cf[u] = (sl[u] >= 0 && t < T) ? a.coef[(size_t)b * T + t] : make_float4(0.f, 0.f, 0.f, 0.f);
             dp[u] = on ? (t < T ? a.dpv[(size_t)b * a.ldp + l] : a.gsum[(size_t)b * D + l]) : 0.f;
             vv[u] = (on && t < T) ? a.h0[(size_t)b * a.Ip + a.U + D + l] : 0.f;
-            xx[u] = (on && t < T) ? a.emb[(long long)id[u] * D + l] : 0.f;
           }
         }
 #pragma unroll
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs 
           if (sl[u] < 0) continue;                              // (group-uniform)
           if (sl[u] != cur) {
             close(false);
-            cur = sl[u]; cur_id = id[u]; acc = 0;
+            cur = sl[u]; cur_id = id[u]; cur_x = xx[u]; acc = 0;
             cur_ol = (ub * PER + jj + u == 0) && cur == prev_slot;
           }
           const int t = code[u] & ((1 << EMB_PAIR_TBITS) - 1);
@@ -759,6 +763,7 @@ __global__ void emb_recv_mark_kernel(const int* rids, long long n, int W, long l
   const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
   if (k >= n) return;
   const int id = rids[k];
+  if (id < 0) return;                                          // (padding of a fixed-size bucket)
   mark[(long long)(id % W) * Vw + id / W] = EMB_MULTI;
 }
 
@@ -769,6 +774,7 @@ __global__ void emb_recv_accumulate_kernel(const int* rids, const long long* row
   if (i >= n * D) return;
   const long long k = i / D;
   const int l = (int)(i - k * D), id = rids[k];
+  if (id < 0) return;
   const long long q = rows[i];
   if (q) atomicAdd(reinterpret_cast<unsigned long long*>(red + (long long)rank[(long long)(id % W) * Vw + id / W] * D + l), (unsigned long long)q);
 }
@@ -789,7 +795,8 @@ __global__ void emb_count_to_i32_kernel(const unsigned long long* n, int* out) {
 __global__ void emb_apply_gathered_kernel(float* emb, const int* ids, const float* delta, long long n, int D) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n * D; i += (long long)gridDim.x * 256) {
     const float d = delta[i];
-    if (d != 0.f) emb[(long long)ids[i / D] * D + i % D] -= d;
+    const int id = ids[i / D];
+    if (id >= 0 && d != 0.f) emb[(long long)id * D + i % D] -= d;
   }
 }
 
@@ -802,6 +809,54 @@ __global__ void emb_apply_kernel(EmbTrainArgs a, const int* slot_id, const unsig
     a.accum[i] = 0;
     a.emb[(long long)slot_id[i / a.D] * a.D + i % a.D] -= a.lr * (float)((double)q * EMB_FIX_INV);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The exchange with FIXED-SIZE buckets (round 3): with a plan every batch's bucket sizes are known when the plan is built,
+// so the bound S = the largest bucket any rank sends for any batch is exact (no overflow possible) and the owner-side bound
+// is R = min(Vw, W S).  Buckets travel padded to S (ids -1, rows 0), the owners' (id, delta) lists padded to R: every
+// transfer has a size the host knows in advance -- no counts all-gather, no read-back, nothing between the collectives
+// but captured kernels.  Counts travel in-band (the -1 padding).
+
+// bucket bounds of every batch of the plan (once, at plan build): off[k][o] = first slot of batch k whose owner is >= o
+__global__ void emb_plan_buckets_kernel(EmbPlanView plan, long long nb, int W, int* off) {
+  const long long k = blockIdx.x;
+  const int o = threadIdx.x;
+  if (k >= nb || o > W) return;
+  const long long sb = plan.slot_base[k], n = plan.slot_base[k + 1] - sb;
+  long long lo = 0, hi = n;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (plan.slot_id[sb + mid] % W >= o) hi = mid; else lo = mid + 1;
+  }
+  off[k * (W + 1) + o] = (int)lo;
+}
+
+// send buffers of the running batch: for owner o, S (id, row) entries -- its bucket, then padding; the accumulators are
+// cleared behind (the next step's border atomics add into zeros)
+__global__ void emb_pack_send_kernel(EmbPlanView plan, const StepState* st, const int* bucket_off, int W, int S, int D, long long* accum,
+                                     int* send_ids, long long* send_rows) {
+  const long long k = st->batch_idx;
+  const long long sb = plan.slot_base[k];
+  const int* off = bucket_off + k * (W + 1);
+  const long long n = (long long)W * S * D;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long e = i / D;
+    const int l = (int)(i - e * D), o = (int)(e / S), j = (int)(e - (long long)o * S);
+    const int slot = off[o] + j;
+    const bool live = slot < off[o + 1];
+    long long q = 0;
+    if (live) { q = accum[(long long)slot * D + l]; accum[(long long)slot * D + l] = 0; }
+    send_rows[i] = q;
+    if (l == 0) send_ids[e] = live ? plan.slot_id[sb + slot] : -1;
+  }
+}
+
+// owner side, after emb_delta: the id list padded to R entries for the fixed-size all-gather
+__global__ void emb_pad_ids_kernel(int* red_ids, const unsigned long long* n_red, int R) {
+  const long long n = (long long)*n_red;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < R; i += (long long)gridDim.x * 256)
+    if (i >= n) red_ids[i] = -1;
 }
 
 }  // namespace goctr

@@ -197,7 +197,7 @@ def _emb_model(pyoracle, Ue, Te, De, Ce):
     return m
 
 
-def _emb_worker(rank, world, port, out):
+def _emb_worker(rank, world, port, out, fixed=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -225,6 +225,58 @@ def _emb_worker(rank, world, port, out):
     off = np.searchsorted(slot_id % W, np.arange(W + 1), side="left")             # emb_bucket_bounds_kernel
     cnt = np.diff(off).astype(np.int32)
     assert np.all(np.diff(slot_id % W) >= 0) and all(np.all(np.diff(slot_id[off[o]:off[o + 1]]) > 0) for o in range(W))
+    if fixed:
+        # Round 3, the graph-capturable form (csrc/emb_train.h, end; ctr.hip emb_exchange_*): every bucket padded to S = the
+        # largest bucket of any rank (ids -1, rows 0), the owners' lists to R = min(Vw, W S): uniform transfers whose sizes
+        # the host knows beforehand; the counts travel in-band as the padding
+        smax = torch.tensor([int(cnt.max()) if cnt.size else 0], dtype=torch.int32)
+        dist.all_reduce(smax, op=dist.ReduceOp.MAX)                                  # (on the device: once, when the plan is built)
+        S = max(4, -(-int(smax.item()) // 4) * 4)
+        R = min(Vw, W * S)
+        sid = np.full((W, S), -1, np.int32); srow = np.zeros((W, S, De), np.int64)
+        for o in range(W):                                                           # emb_pack_send_kernel
+            k = off[o + 1] - off[o]
+            sid[o, :k] = slot_id[off[o]:off[o + 1]]; srow[o, :k] = accum[off[o]:off[o + 1]]
+        rid = np.full((W, S), -1, np.int32); rrow = np.zeros((W, S, De), np.int64)
+        reqs, bufs = [], []
+        for p in range(W):                                                           # uniform all-to-all: S entries per peer
+            if p == r:
+                rid[r] = sid[r]; rrow[r] = srow[r]
+                continue
+            ti, tr = torch.from_numpy(sid[p].copy()), torch.from_numpy(srow[p].copy())
+            ri, rr = torch.zeros(S, dtype=torch.int32), torch.zeros((S, De), dtype=torch.int64)
+            bufs.append((p, ri, rr))
+            reqs += [dist.isend(ti, p, tag=1), dist.isend(tr, p, tag=2), dist.irecv(ri, p, tag=1), dist.irecv(rr, p, tag=2)]
+        for q in reqs:
+            q.wait()
+        for p, ri, rr in bufs:
+            rid[p] = ri.numpy(); rrow[p] = rr.numpy()
+        rids = rid.ravel().astype(np.int64); rrows = rrow.reshape(-1, De)
+        live = rids >= 0                                                             # the owner kernels skip the padding
+        assert np.all(rids[live] % W == r)
+        red_ids = np.unique(rids[live])
+        assert red_ids.size <= R
+        red = np.zeros((red_ids.size, De), np.int64)
+        np.add.at(red, np.searchsorted(red_ids, rids[live]), rrows[live])
+        lr = np.float32(0.05)
+        delta = (lr * (red.astype(np.float64) * 2.0 ** -44).astype(np.float32)).astype(np.float32)
+        gid = np.full(R, -1, np.int32); gdl = np.zeros((R, De), np.float32)          # emb_pad_ids_kernel
+        gid[:red_ids.size] = red_ids; gdl[:red_ids.size] = delta
+        all_ids = [torch.zeros(R, dtype=torch.int32) for _ in range(W)]
+        all_dl = [torch.zeros((R, De), dtype=torch.float32) for _ in range(W)]
+        dist.all_gather(all_ids, torch.from_numpy(gid))                              # fixed-size all-gathers
+        dist.all_gather(all_dl, torch.from_numpy(gdl))
+        g_ids = np.concatenate([t.numpy() for t in all_ids]); g_delta = np.concatenate([t.numpy() for t in all_dl])
+        keep = g_ids >= 0                                                            # emb_apply_gathered_kernel skips -1
+        assert np.unique(g_ids[keep]).size == int(keep.sum())
+        E32 = E.astype(np.float32)
+        new = E32.copy()
+        new[g_ids[keep]] = E32[g_ids[keep]] - g_delta[keep]
+        sent = float(W * S * (4 + 8 * De) + W * R * (4 + 4 * De))
+        out.put((rank, new, float(lr), sent))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     #  2. counts all-gather, then all-to-all-v of (ids, rows) to the owners
     allcnt = [torch.zeros(W, dtype=torch.int32) for _ in range(W)]
     dist.all_gather(allcnt, torch.from_numpy(cnt))
@@ -273,15 +325,16 @@ def _emb_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("fixed", [False, True])
 @pytest.mark.parametrize("world", [2, 4])
-def test_embedding_sparse_exchange_bucketed(oracle, world):
+def test_embedding_sparse_exchange_bucketed(oracle, world, fixed):
     """owner = id % world, all-to-all of the deduplicated (id, fixed-point row) pairs, exact
     owner-side sums, all-gather of (id, delta): every replica ends up with the SAME bits, equal to one SGD step on the
     full batch's oracle gradient up to the 2^-44 rounding of each rank's contribution"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_emb_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_emb_worker, args=(r, world, port, q, fixed)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
