@@ -953,7 +953,34 @@ int launch_emb_slot_gs(int mode, bool direct, dim3 grid, hipStream_t s, const Em
 
 int launch_emb_exchange(goctr_model* m, const EmbTrainArgs& a);
 
-// the id-major update of one step over the plan (after the dpv GEMM)
+bool emb_plan_active(const goctr_model* m) { return m->emb_lr > 0.f && m->plan.valid; }
+
+// First half of the plan path, in attn_bwd's place in the backward: dpv = dz0 . W0[U:U+2D,:]^T and (DIN) the per-pair
+// coefficients -- the kernel gathers every behaviour row and forms dp . x_t like attn_bwd_kernel, so it writes attn_bwd's
+// output (the per-sample terms of the att0 gradient, consumed by the weight-gradient launch) as well: one launch instead of two.
+int launch_emb_plan_early(goctr_model* m, const RowSource& src, int B, const StepState* st) {
+  const goctr_ctr_cfg& c = m->cfg;
+  hipStream_t s = engine().stream;
+  const int Np = round_up(2 * c.D, 16);
+  EpiStore sp{m->dpv.p, Np};
+  if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
+  if (c.kind != GOCTR_DIN) return 0;
+  const int mode = c.att == GOCTR_ATT_COSINE ? 1 : 2;
+  ProfScope ps(GOCTR_K_ATTN_BWD);
+  if (ps.on) { static char sym[40]; snprintf(sym, sizeof sym, "emb_coef_kernel<%d,%d>", c.D / 4, mode); prof_note_kernel(GOCTR_K_ATTN_BWD, sym); }
+  EmbCoefArgs ca{src, st, B, c.T, c.D, m->dpv.p, Np, m->gate_p(m->stp), m->W.p + m->offa, m->emb_coef.p, m->emb_gsum.p,
+                 m->wgt_p(m->stp), m->attp.p, m->Tp};
+  const dim3 g((unsigned)cdiv(B, 4));
+  const int lpr = c.D / 4;
+#define GOCTR_COEF(L) do { if (mode == 1) hipLaunchKernelGGL((emb_coef_kernel<L, 1>), g, dim3(256), 0, s, ca); \
+                           else hipLaunchKernelGGL((emb_coef_kernel<L, 2>), g, dim3(256), 0, s, ca); } while (0)
+  if (lpr == 1) GOCTR_COEF(1); else if (lpr == 2) GOCTR_COEF(2); else if (lpr == 4) GOCTR_COEF(4); else if (lpr == 8) GOCTR_COEF(8); else GOCTR_COEF(16);
+#undef GOCTR_COEF
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+// Second half (where the table may be written: after every reader of this step): the id-major accumulation over the plan
 int launch_emb_plan_step(goctr_model* m, const RowSource& src, int B, const StepState* st, int Np) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
@@ -970,16 +997,6 @@ int launch_emb_plan_step(goctr_model* m, const RowSource& src, int B, const Step
       static char sym[48];
       snprintf(sym, sizeof sym, "emb_slot_kernel<%d,%d,%s>", c.D <= 16 ? 16 : c.D <= 32 ? 32 : 64, mode ? 1 : 0, direct ? "true" : "false");
       prof_note_kernel(GOCTR_K_EMB_GRAD, sym);
-    }
-    if (mode != 0) {
-      EmbCoefArgs ca{src, st, B, c.T, c.D, m->dpv.p, Np, m->gate_p(m->stp), m->W.p + m->offa, m->emb_coef.p, m->emb_gsum.p};
-      const dim3 g((unsigned)cdiv(B, 4));
-      const int lpr = c.D / 4;
-#define GOCTR_COEF(L) do { if (mode == 1) hipLaunchKernelGGL((emb_coef_kernel<L, 1>), g, dim3(256), 0, s, ca); \
-                           else hipLaunchKernelGGL((emb_coef_kernel<L, 2>), g, dim3(256), 0, s, ca); } while (0)
-      if (lpr == 1) GOCTR_COEF(1); else if (lpr == 2) GOCTR_COEF(2); else if (lpr == 4) GOCTR_COEF(4); else if (lpr == 8) GOCTR_COEF(8); else GOCTR_COEF(16);
-#undef GOCTR_COEF
-      GOCTR_HIP(hipGetLastError());
     }
     const int gs = c.D <= 16 ? 16 : c.D <= 32 ? 32 : 64;
     const dim3 grid((unsigned)std::max<long long>(cdiv(m->plan.max_pairs, (long long)(EMB_SLOT_THREADS / gs) * EMB_SEG), 1));
@@ -1030,8 +1047,7 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
     // the id-major path: no marks, no scans, no accumulators to apply -- the dpv GEMM, then the plan kernels.
     // (W0[U:U+2D,:]^T is transposed once per call sequence -- ensure_w0pv, outside the captured step -- and then kept
     // current by the Adam kernels like the other operand copies: 4.2 us per step less)
-    EpiStore sp{m->dpv.p, Np};
-    if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
+    // (the dpv GEMM and the coefficient kernel already ran in attn_bwd's place: launch_emb_plan_early)
     return launch_emb_plan_step(m, src, B, st, Np);
   }
   {
@@ -1176,10 +1192,16 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
       EpiStore sp{m->dp.p, m->Dp};
       if (launch_nn(GOCTR_K_BWD_DP, m->dz0.p, m->H1p, m->W0sT.p, m->Dp, B, m->H1p, m->Dp, sp)) return -1;
     }
-    AttnBwdArgs ab{};
-    ab.src = src; ab.st = st; ab.B = B; ab.T = c.T; ab.D = c.D; ab.Dp = m->Dp; ab.Tp = m->Tp;
-    ab.dp = m->dp.p; ab.gate = m->gate_p(m->stp); ab.wgt = m->wgt_p(m->stp); ab.partial = m->attp.p;
-    if (launch_attn_bwd(ab, (int)cdiv(B, ATTN_BWD_WAVES))) return -1;
+    if (emb_plan_active(m) && src.id_mode) {
+      if (launch_emb_plan_early(m, src, B, st)) return -1;      // (does attn_bwd's job too)
+    } else {
+      AttnBwdArgs ab{};
+      ab.src = src; ab.st = st; ab.B = B; ab.T = c.T; ab.D = c.D; ab.Dp = m->Dp; ab.Tp = m->Tp;
+      ab.dp = m->dp.p; ab.gate = m->gate_p(m->stp); ab.wgt = m->wgt_p(m->stp); ab.partial = m->attp.p;
+      if (launch_attn_bwd(ab, (int)cdiv(B, ATTN_BWD_WAVES))) return -1;
+    }
+  } else if (emb_plan_active(m) && src.id_mode) {
+    if (launch_emb_plan_early(m, src, B, st)) return -1;
   }
 
   // weight gradients: all GEMMs in one launch; dW1 and dW2 are posed transposed, datt0 is a ones-column

@@ -369,7 +369,7 @@ struct EmbPlanView {
 };
 constexpr int EMB_PAIR_TBITS = 12;                 // t < 4096, b < 2^19
 constexpr int EMB_SEG = 32;                        // pairs per lane group
-constexpr int EMB_SLOT_THREADS = 1024;
+constexpr int EMB_SLOT_THREADS = 256;              // 16 lane groups at D = 16: 512 pairs per workgroup, several workgroups per CU
 
 // ---- plan build (once per dataset): count -> scans (scan.h) -> fill
 struct EmbPlanBuildArgs {
@@ -435,6 +435,9 @@ struct EmbCoefArgs {
   const float* gate; const float* att0;
   float4* coef;                       // [B, T]  (alpha, beta, gamma, -)
   float* gsum;                        // [B, D]  gradient of the candidate item's row
+  // attn_bwd_kernel's job rides along (the rows are gathered and dp . x is formed here anyway): the per-sample terms of the
+  // att0 gradient, dgs [B, Tp] = (dp . x_t / T) g (1 - g) w_t  (null: not wanted)
+  const float* wgt; float* partial; int Tp;
 };
 // MODE 1 = cosine, 2 = euclid.  VEC = 4, LPR = D / 4 lanes per row.
 template <int LPR, int MODE>
@@ -464,6 +467,8 @@ __global__ __launch_bounds__(256) void emb_coef_kernel(EmbCoefArgs a) {
   const float invT = 1.0f / (float)T;
   float dsum[VEC] = {0.f, 0.f, 0.f, 0.f};
   float esum = 0.f;
+  if (a.partial)
+    for (int t = T + lane; t < a.Tp; t += 64) a.partial[(size_t)b * a.Tp + t] = 0.f;
   for (int tb = 0; tb < T; tb += SLOTS) {
     int myid = -1;
     if (valid && lane < SLOTS && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
@@ -510,7 +515,10 @@ __global__ __launch_bounds__(256) void emb_coef_kernel(EmbCoefArgs a) {
         delta = q * ir; eps = -(q * ir);
       }
     }
-    if (lane < SLOTS && tb + lane < T) a.coef[(size_t)b * T + tb + lane] = make_float4(alpha, beta, gamma, 0.f);
+    if (lane < SLOTS && tb + lane < T) {
+      a.coef[(size_t)b * T + tb + lane] = make_float4(alpha, beta, gamma, 0.f);
+      if (a.partial) a.partial[(size_t)b * a.Tp + tb + lane] = (s0 * invT) * (gl * (1.0f - gl)) * a.wgt[(size_t)b * T + tb + lane];
+    }
     esum += eps;
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {

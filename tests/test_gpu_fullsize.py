@@ -270,3 +270,39 @@ def test_cfg5_item2vec_full_size_hogwild_vs_oracle(oracle):
     # (a topic holds V / topics = 166 items: two equally good racy runs rank them differently, so the lists overlap
     #  far less than they are pure -- but far more than two random lists of the vocabulary, 10 / V = 0.001)
     assert overlap >= 50 * 10.0 / V
+
+
+def test_item2vec_stress_point_v1e6_d64_hogwild_vs_oracle(oracle):
+    """cfg5's stress point: vocabulary 10^6, 64-d vectors -- 512 MB of float64 parameters + as many node
+    vectors, Huffman paths of ~22 nodes -- where the LDS-cached hot rows are a much smaller share of the traffic than at
+    V = 10 681 / D = 16.  10^6 words (the oracle's 16-thread Hogwild on the box's CPU quota is what bounds the size): same
+    statistical gate as above -- HS loss per path node within 3 % of the oracle's run from the same initial vectors"""
+    from goctr_amd import embedding as ge
+    rng = np.random.default_rng(106)
+    V, dim, n, streams, slices = 1_000_000, 64, 1_000_000, 32768, 16
+    doc, topics = _session_corpus(rng, V, n, topics=64, mean_len=70)
+    counts = np.bincount(doc, minlength=V) + 1
+    p0 = ((rng.random((V, dim), dtype=np.float32) - 0.5) / dim).astype(np.float64)
+    m = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=False, streams=streams, slices=slices)
+    m.create(counts, p0.copy())
+    m.train_pass(doc, n, None, lr=0.025)
+    gp, ga = m.get_param(), m.get_aux()
+    assert np.all(np.isfinite(gp)) and np.all(np.isfinite(ga))
+    oracle.set_threads(slices)
+    cfg = oracle.w2v_cfg(dim=dim, optimizer="hs")
+    paths = oracle.huffman_paths(counts)
+    assert _same_paths(m.get_paths(), paths)                     # the 10^6-word tree: product builder == oracle builder
+    op, oa = p0.copy(), np.zeros((V - 1, dim))
+    oracle.w2v_train_hogwild(cfg, doc, slices, None, op, oa, paths, oracle.sigmoid_table(), 0.025, n)
+    pos = rng.integers(1, n - 1, size=3000)
+    pairs = list(zip(doc[pos].tolist(), doc[pos + 1].tolist()))
+    l0 = _hs_loss(p0, np.zeros((V - 1, dim)), paths, pairs)
+    lg, lo = _hs_loss(gp, ga, paths, pairs), _hs_loss(op, oa, paths, pairs)
+    print(f"V=1e6 D=64: HS loss per node: init {l0:.4f}  device {lg:.4f}  oracle(16 threads) {lo:.4f}")
+    assert abs(l0 - np.log(2.0)) < 1e-9
+    assert lo < 0.97 * l0 and lg < 0.97 * l0
+    assert abs(lg - lo) <= 0.03 * lo
+
+
+def _same_paths(a, b):
+    return all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b))
