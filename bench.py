@@ -648,9 +648,16 @@ def main():
             wl = "youtube" if c["KIND"] == "youtube" else "din"
             if args.train_emb > 0:
                 wl += "emb"                      # profiles/r02_{dinemb,youtubeemb}_*: the same command with --train-emb
-                # algorithmic bytes of the sparse row update per launch: every (sample, slot) pair reads its row and the
-                # sample's dpv / gate terms and adds a D-wide int64 row; priced like the gather, on memory-side bytes
-                work["emb_grad"] = ("hbm", c["B"] * (c["T"] + 1) * (c["D"] * 4 + c["D"] * 8 + 4))
+                # algorithmic bytes of the id-major sparse row update per launch (emb_slot_kernel, batch 0's counts): every
+                # valid (sample, slot) pair reads its 12-byte plan entry and the sample's dp row (DIN: + the coefficient, the
+                # candidate row v and the slot's row x), every distinct id's row is read and written once; priced like the
+                # gather, on memory-side bytes
+                ids0 = np.concatenate([ub[:c["B"]].ravel(), it[:c["B"]]])
+                ids0 = ids0[(ids0 >= 0) & (ids0 < c["V"])]
+                pairs0, distinct0 = int(ids0.size), int(np.unique(ids0).size)
+                per_pair = 12 + 4 * c["D"] + ((16 + 8 * c["D"]) if c["KIND"] == "din" else 0)
+                work["emb_grad"] = ("hbm", pairs0 * per_pair + distinct0 * 8 * c["D"])
+                out["emb_batch0"] = {"valid_pairs": pairs0, "distinct_ids": distinct0}
             syms = capi.prof_kernels()           # the kernel symbol each family's launches actually ran (goctr_prof_kernel)
             dom = max((k for k in table if k in work), key=lambda k: prof[k][0])
             kind, w = work[dom]
