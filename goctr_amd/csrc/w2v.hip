@@ -739,6 +739,14 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
   } else {
     int streams = w->cfg.streams > 0 ? w->cfg.streams : 8192;
     if ((int64_t)streams > w->n_words) streams = (int)w->n_words;
+    // Every stream is a Hogwild worker and the hot rows of the workgroups' LDS copies are AVERAGED at the merges: a worker
+    // that walks only a few dozen positions contributes a few dozen updates' worth of learning to them however many workers
+    // there are (V = 10^6, D = 64, 10^6 words on 32 768 streams: HS loss 0.665 against the oracle's 0.624).  So the
+    // parallelism is capped by the corpus: at least 256 positions per stream (bench.py's 10^7 words / 32 768 streams = 305).
+    if (env_int_w2v("GOCTR_W2V_MIN_POS", 256) > 0) {
+      const int64_t cap = std::max<int64_t>(1, w->n_words / env_int_w2v("GOCTR_W2V_MIN_POS", 256));
+      if ((int64_t)streams > cap) streams = (int)cap;
+    }
     // slices = the reference's goroutines (window-clipping units); 0: one slice per stream (every piece clips its own windows)
     int slices = w->cfg.slices > 0 ? std::min(w->cfg.slices, streams) : streams;
     const int per = streams / slices;                 // workers per slice (the last slice takes the remainder)

@@ -35,6 +35,7 @@ def symbol(name):
     if n.endswith(".kd"):
         n = n[:-3]
     n = re.sub(r"^void\s+", "", n)
+    n = n.replace("(anonymous namespace)::", "")
     # cut the argument list: the last top-level '(' of the name
     depth, cut = 0, None
     for i, ch in enumerate(n):
@@ -49,7 +50,7 @@ def symbol(name):
         n = n[:cut]
     if "goctr" not in name and not n.endswith("_kernel") and "_kernel<" not in n:
         return None
-    n = n.replace("(anonymous namespace)::", "").replace("goctr::", "")
+    n = n.replace("goctr::", "")
     return n.replace(" ", "")
 
 
