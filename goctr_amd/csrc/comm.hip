@@ -25,6 +25,7 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -51,6 +52,7 @@ int load_rccl() {
   GOCTR_SYM(CommDestroy, "ncclCommDestroy");
   GOCTR_SYM(GetErrorString, "ncclGetErrorString");
 #undef GOCTR_SYM
+  g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(g_rccl.h, "ncclCommAbort"));
   return 0;
 }
 
@@ -94,6 +96,18 @@ int comm_alltoallv(const void* send, const size_t* send_off, const size_t* send_
   }
   GOCTR_NCCL(g_rccl.GroupEnd());
   return 0;
+}
+
+// A data-parallel call that fails on ONE rank between two collectives (a HIP error, a failed allocation) would leave its
+// peers blocked inside the next collective for ever.  The failing rank aborts the communicator instead: the peers' pending
+// and later RCCL calls return an error, every rank's call fails, nobody hangs.  (The communicator is unusable afterwards;
+// goctr_comm_init builds a new one.)
+void comm_abort_on_failure() {
+  Engine& e = engine();
+  if (!e.nccl_comm) return;
+  if (g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)e.nccl_comm);
+  else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)e.nccl_comm);
+  e.nccl_comm = nullptr; e.rank = 0; e.world = 1;
 }
 
 int comm_allreduce_f64_dev(double* dev, size_t n) {

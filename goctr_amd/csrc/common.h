@@ -144,6 +144,8 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // collective hook (comm.hip): in-place sum over ranks on the engine stream; no-op when world == 1
 int comm_allreduce_f32(float* dev, size_t n);
 int comm_allreduce_f64_dev(double* dev, size_t n);
+// a rank whose data-parallel call failed between collectives aborts the communicator so that its peers fail too instead of hanging
+void comm_abort_on_failure();
 // sparse embedding update (bucketed exchange, emb_train.h): counts all-gather + all-to-all-v of ids / rows
 int comm_allgather_i32(const int* send, int* recv, size_t n);
 int comm_alltoallv(const void* send, const size_t* send_off, const size_t* send_cnt, void* recv, const size_t* recv_off,

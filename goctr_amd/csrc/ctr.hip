@@ -2129,7 +2129,14 @@ int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const go
   if (check_dataset(m, d, emb)) return -1;
   const long long nb = cdiv(d->rows, cfg->batch);
   if (retarget_state(m, first_batch % nb, nb)) return -1;      // no host synchronisation on this path
-  if (run_steps(m, emb, d, cfg, n_steps)) return -1;
+  if (run_steps(m, emb, d, cfg, n_steps)) {
+    if (engine().comm_active()) {     // (keep this rank's error text; make the peers fail too instead of waiting in a collective)
+      const std::string msg = goctr_last_error();
+      comm_abort_on_failure();
+      set_error("%s [data-parallel step failed on this rank: communicator aborted]", msg.c_str());
+    }
+    return -1;
+  }
   if (costs) {
     GOCTR_HIP(hipStreamSynchronize(engine().stream));
     if (m->costs.download(costs, n_steps)) return -1;
@@ -2166,7 +2173,14 @@ int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const 
     unsigned slot0 = 0;
     while (done < nb) {  // keep each burst inside the cost ring
       const int burst = (int)std::min<long long>(nb - done, COST_RING / 2);
-      if (run_steps(m, emb, d, cfg, burst)) return -1;
+      if (run_steps(m, emb, d, cfg, burst)) {
+        if (engine().comm_active()) {
+          const std::string msg = goctr_last_error();
+          comm_abort_on_failure();
+          set_error("%s [data-parallel step failed on this rank: communicator aborted]", msg.c_str());
+        }
+        return -1;
+      }
       done += burst;
     }
     (void)slot0;

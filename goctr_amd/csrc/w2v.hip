@@ -260,53 +260,7 @@ struct HogHot {
   int merge_every;          // words per lane group between merges
   double merge_scale;       // a workgroup's delta enters the global row times this (1 / workgroups: the replicas are averaged)
   long long max_len;        // longest piece (uniform loop bound: every thread meets every barrier)
-  // Second tier (round 3): the NEXT n_nodes2 heaviest node vectors and n_words2 most frequent words -- too many for LDS, still
-  // hot enough that device-scope atomics on them are most of the kernel's memory-side traffic (5.1 KB per word in round 2).
-  // Each XCD keeps its own replica in global memory (t2N / t2W: [8][rows][dim], with the value it last agreed on in t2Nb /
-  // t2Wb): read with L1-bypassing loads and updated with workgroup-scope atomics, both of which are served by the XCD's own
-  // L2 (coherent among its 32 CUs) and never reach the fabric.  At every merge each workgroup folds a slice of its XCD's
-  // replica into the global rows (device-scope add of (replica - agreed) * t2_scale) and pulls the other XCDs' work back.
-  // word_slot: >= 0 LDS slot, -1 cold, <= -2 second tier (index -2 - slot).
-  int n_nodes2, n_words2;
-  long long node0_2;        // second-tier node rows are aux rows [node0_2, node0)
-  const int* word_id2;      // [n_words2] second-tier slot -> word
-  double* t2N; double* t2Nb; double* t2W; double* t2Wb;
-  double t2_scale;
 };
-
-// second-tier accesses: served by the XCD's L2 (sc1 load = L1 bypass; workgroup-scope atomic = performed in L2, no write-through)
-__device__ __forceinline__ double l2_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void l2_add(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// a load that goes past the (non-coherent) L2: what another XCD's device-scope atomics left in memory
-__device__ __forceinline__ double mem_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-
-// replicas <- global rows (before a pass) / global rows += what the replicas still hold (after it)
-__global__ void w2v_t2_init_kernel(const double* param, const double* aux, int dim, HogHot hot) {
-  const long long nN = (long long)hot.n_nodes2 * dim, nW = (long long)hot.n_words2 * dim;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nN + nW; i += (long long)gridDim.x * 256) {
-    const bool isn = i < nN;
-    const long long j = isn ? i : i - nN;
-    const long long r = j / dim; const int c = (int)(j - r * dim);
-    const double v = isn ? aux[(hot.node0_2 + r) * dim + c] : param[(long long)hot.word_id2[r] * dim + c];
-    for (int x = 0; x < 8; ++x) {
-      if (isn) { hot.t2N[(size_t)x * nN + j] = v; hot.t2Nb[(size_t)x * nN + j] = v; }
-      else { hot.t2W[(size_t)x * nW + j] = v; hot.t2Wb[(size_t)x * nW + j] = v; }
-    }
-  }
-}
-__global__ void w2v_t2_fold_kernel(double* param, double* aux, int dim, HogHot hot) {
-  const long long nN = (long long)hot.n_nodes2 * dim, nW = (long long)hot.n_words2 * dim;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nN + nW; i += (long long)gridDim.x * 256) {
-    const bool isn = i < nN;
-    const long long j = isn ? i : i - nN;
-    const long long r = j / dim; const int c = (int)(j - r * dim);
-    double d = 0.0;
-    for (int x = 0; x < 8; ++x)
-      d += isn ? hot.t2N[(size_t)x * nN + j] - hot.t2Nb[(size_t)x * nN + j] : hot.t2W[(size_t)x * nW + j] - hot.t2Wb[(size_t)x * nW + j];
-    double* gp = isn ? aux + (hot.node0_2 + r) * dim + c : param + (long long)hot.word_id2[r] * dim + c;
-    if (d != 0.0) *gp += d * hot.t2_scale;
-  }
-}
 
 constexpr int HOG_PF = 4;   // node vectors of a Huffman path in flight per lane group
 
@@ -329,37 +283,9 @@ __global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, i
     locW[i] = v; baseW[i] = v;
   }
   __syncthreads();
-  // this workgroup's XCD: selects the second-tier replica (any value 0..7 is correct -- the id only has to be the same for
-  // workgroups that share an L2, which is what the register says)
-  int xcc = 0;
-  if (hot.n_nodes2 + hot.n_words2 > 0) { asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 7; }
-  double* const t2N = hot.t2N + (size_t)xcc * hot.n_nodes2 * dim;
-  double* const t2Nb = hot.t2Nb + (size_t)xcc * hot.n_nodes2 * dim;
-  double* const t2W = hot.t2W + (size_t)xcc * hot.n_words2 * dim;
-  double* const t2Wb = hot.t2Wb + (size_t)xcc * hot.n_words2 * dim;
-  // the slice of the XCD's replica this workgroup merges: block b runs on XCD b % 8 (observed; if it did not, some rows of
-  // some replica would simply wait for w2v_t2_fold_kernel at the end of the pass)
-  const int t2_nwg = gridDim.x >= 8 ? (int)gridDim.x / 8 : 1, t2_rank = gridDim.x >= 8 ? (int)blockIdx.x / 8 : 0;
-  auto merge_t2 = [&](double* loc, double* base, int rows, bool nodes) {
-    for (int i = threadIdx.x; ; i += HOG_THREADS) {
-      const int rr = i / dim, c = i - rr * dim;
-      const int r = t2_rank + rr * t2_nwg;
-      if (r >= rows) break;
-      double* gp = nodes ? a.aux + (hot.node0_2 + r) * dim + c : a.param + (long long)hot.word_id2[r] * dim + c;
-      double* lp = loc + (size_t)r * dim + c;
-      const double cur = l2_load(lp), b = l2_load(base + (size_t)r * dim + c);
-      const double d = (cur - b) * hot.t2_scale;
-      if (d != 0.0) hog_add(gp, d);
-      const double v = mem_load(gp);
-      if (v != cur) l2_add(lp, v - cur);                 // (not a store: updates that arrived since `cur` was read stay)
-      __hip_atomic_store(base + (size_t)r * dim + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
   // add this workgroup's delta to the global rows, take the others' contributions back
   auto merge = [&]() {
     __syncthreads();
-    if (hot.n_nodes2) merge_t2(t2N, t2Nb, hot.n_nodes2, true);
-    if (hot.n_words2) merge_t2(t2W, t2Wb, hot.n_words2, false);
     for (int i = threadIdx.x; i < hot.n_nodes * GS; i += HOG_THREADS) {
       const int r = i / GS, c = i % GS;
       if (c < dim) {
@@ -397,26 +323,15 @@ __global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, i
   const long long cmin = clip_lo[gs] - lo, cmax = clip_hi[gs] - lo;   // window positions allowed, relative to this piece
   // vector component l of a word / of an inner node (HS) -- LDS when hot, device-scope memory access otherwise
   auto word_slot = [&](int id) { return hot.n_words ? hot.word_slot[id] : -1; };
-  // (a second-tier load and a cold load are the same instruction -- an L1-bypassing load -- on different addresses)
-  auto ld_word = [&](int id, int slot) {
-    if (slot >= 0) return locW[slot * GS + l];
-    const double* p = slot <= -2 ? t2W + (size_t)(-2 - slot) * dim + l : a.param + (long long)id * dim + l;
-    return hog_load(p);
-  };
+  auto ld_word = [&](int id, int slot) { return slot >= 0 ? locW[slot * GS + l] : hog_load(a.param + (long long)id * dim + l); };
   auto add_word = [&](int id, int slot, double v) {
-    if (slot >= 0) locW[slot * GS + l] += v;
-    else if (slot <= -2) l2_add(t2W + (size_t)(-2 - slot) * dim + l, v);
-    else hog_add(a.param + (long long)id * dim + l, v);
+    if (slot >= 0) locW[slot * GS + l] += v; else hog_add(a.param + (long long)id * dim + l, v);
   };
   auto ld_node = [&](int nd) {
-    if (nd >= hot.node0) return locN[(nd - (int)hot.node0) * GS + l];
-    const double* p = nd >= hot.node0_2 ? t2N + (size_t)(nd - hot.node0_2) * dim + l : a.aux + (long long)nd * dim + l;
-    return hog_load(p);
+    return nd >= hot.node0 ? locN[(nd - (int)hot.node0) * GS + l] : hog_load(a.aux + (long long)nd * dim + l);
   };
   auto add_node = [&](int nd, double v) {
-    if (nd >= hot.node0) locN[(nd - (int)hot.node0) * GS + l] += v;
-    else if (nd >= hot.node0_2) l2_add(t2N + (size_t)(nd - hot.node0_2) * dim + l, v);
-    else hog_add(a.aux + (long long)nd * dim + l, v);
+    if (nd >= hot.node0) locN[(nd - (int)hot.node0) * GS + l] += v; else hog_add(a.aux + (long long)nd * dim + l, v);
   };
   for (long long pos = 0; pos < hot.max_len; ++pos) {
     if (pos < len) {
@@ -651,8 +566,6 @@ struct goctr_w2v {
   DevBuf<long long> path_off, trained, slice_idx, clip_lo, clip_hi;
   DevBuf<int> path_nodes, doc, hot_word_slot, hot_word_id;   // hot_*: the most frequent words, cached in LDS by the Hogwild kernel
   int n_hot_words = 0;
-  DevBuf<int> hot_word_id2; int n_hot_words2 = -1;           // second tier (per-XCD replicas in global memory)
-  DevBuf<double> t2N, t2Nb, t2W, t2Wb; int t2_rows_n = 0;
   std::vector<long long> h_counts;
   DevBuf<unsigned char> path_codes, keep;
   DevBuf<unsigned long long> lcg;
@@ -776,48 +689,29 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     HogHot hot{};
     hot.n_nodes = w->cfg.optimizer == 0 ? (int)std::min<int64_t>(rows_cached, w->aux_rows) : 0;
     hot.node0 = w->aux_rows - hot.n_nodes;
-    // second tier: the next GOCTR_W2V_T2 (default 1024) rows of each table, skip-gram only (cbow reads its rows directly)
-    const int t2_want = (rows_cached > 0 && w->cfg.model == 0) ? std::max(0, env_int_w2v("GOCTR_W2V_T2", 1024)) : 0;
-    const int nh = (int)std::min<int64_t>(rows_cached, w->V);
-    const int nh2 = (int)std::min<int64_t>(t2_want, w->V - nh);
-    if (w->n_hot_words != nh || w->n_hot_words2 != nh2 || !w->hot_word_slot.p) {
-      std::vector<int> order((size_t)w->V), slot((size_t)w->V, -1), ids((size_t)std::max(nh, 1), 0), ids2((size_t)std::max(nh2, 1), 0);
+    if (w->n_hot_words != std::min<int64_t>(rows_cached, w->V) || !w->hot_word_slot.p) {
+      const int nh = (int)std::min<int64_t>(rows_cached, w->V);
+      std::vector<int> order((size_t)w->V), slot((size_t)w->V, -1), ids((size_t)std::max(nh, 1), 0);
       std::iota(order.begin(), order.end(), 0);
       if (!w->h_counts.empty())
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return w->h_counts[x] > w->h_counts[y]; });
       for (int k = 0; k < nh; ++k) { slot[order[k]] = k; ids[k] = order[k]; }
-      for (int k = 0; k < nh2; ++k) { slot[order[nh + k]] = -2 - k; ids2[k] = order[nh + k]; }
       if (w->hot_word_slot.alloc(slot.size(), false) || w->hot_word_slot.upload(slot.data(), slot.size())) return -1;
       if (w->hot_word_id.alloc(ids.size(), false) || w->hot_word_id.upload(ids.data(), ids.size())) return -1;
-      if (w->hot_word_id2.alloc(ids2.size(), false) || w->hot_word_id2.upload(ids2.data(), ids2.size())) return -1;
-      w->n_hot_words = nh; w->n_hot_words2 = nh2;
+      w->n_hot_words = nh;
     }
     hot.n_words = w->n_hot_words; hot.word_slot = w->hot_word_slot.p; hot.word_id = w->hot_word_id.p;
-    hot.n_words2 = w->n_hot_words2; hot.word_id2 = w->hot_word_id2.p;
-    hot.n_nodes2 = w->cfg.optimizer == 0 ? (int)std::min<int64_t>(t2_want, hot.node0) : 0;
-    hot.node0_2 = hot.node0 - hot.n_nodes2;
-    if (hot.n_nodes2 + hot.n_words2 > 0) {
-      const size_t nN = (size_t)std::max(hot.n_nodes2, 1) * dim * 8, nW = (size_t)std::max(hot.n_words2, 1) * dim * 8;
-      if (w->t2N.ensure(nN, false) || w->t2Nb.ensure(nN, false) || w->t2W.ensure(nW, false) || w->t2Wb.ensure(nW, false)) return -1;
-      hot.t2N = w->t2N.p; hot.t2Nb = w->t2Nb.p; hot.t2W = w->t2W.p; hot.t2Wb = w->t2Wb.p;
-    }
-    // a replica's delta enters the global row times this: 8 replicas, averaged like the LDS copies (GOCTR_W2V_T2_SUM=1: summed)
-    hot.t2_scale = env_int_w2v("GOCTR_W2V_T2_SUM", 0) ? 1.0 : 0.125;
     hot.merge_every = std::max(1, env_int_w2v("GOCTR_W2V_MERGE", 16));
     const int nwg = (int)cdiv(streams, HOG_THREADS / GSr);
     hot.merge_scale = env_int_w2v("GOCTR_W2V_AVG", 1) ? 1.0 / (double)nwg : 1.0;
     hot.max_len = 0;
     for (int k = 0; k < streams; ++k) hot.max_len = std::max(hot.max_len, idx[k + 1] - idx[k]);
-    const bool t2 = hot.n_nodes2 + hot.n_words2 > 0;
-    const unsigned t2_grid = (unsigned)std::min<long long>(cdiv((long long)(hot.n_nodes2 + hot.n_words2) * dim, 256), 1024);
-    if (t2) hipLaunchKernelGGL(w2v_t2_init_kernel, dim3(t2_grid), dim3(256), 0, e.stream, a.param, a.aux, dim, hot);
 #define GOCTR_HOG(GS) hipLaunchKernelGGL((w2v_hogwild_kernel<GS>), dim3((unsigned)cdiv(streams, HOG_THREADS / GS)), dim3(HOG_THREADS), 0, e.stream, a, streams, w->slice_idx.p, w->clip_lo.p, w->clip_hi.p, hot)
     if (dim <= 8) GOCTR_HOG(8);
     else if (dim <= 16) GOCTR_HOG(16);
     else if (dim <= 32) GOCTR_HOG(32);
     else GOCTR_HOG(64);
 #undef GOCTR_HOG
-    if (t2) hipLaunchKernelGGL(w2v_t2_fold_kernel, dim3(t2_grid), dim3(256), 0, e.stream, a.param, a.aux, dim, hot);
     GOCTR_HIP(hipGetLastError());
   }
   if (dp && exchange_deltas(w)) return -1;

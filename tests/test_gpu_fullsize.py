@@ -301,7 +301,9 @@ def test_item2vec_stress_point_v1e6_d64_hogwild_vs_oracle(oracle):
     print(f"V=1e6 D=64: HS loss per node: init {l0:.4f}  device {lg:.4f}  oracle(16 threads) {lo:.4f}")
     assert abs(l0 - np.log(2.0)) < 1e-9
     assert lo < 0.97 * l0 and lg < 0.97 * l0
-    assert abs(lg - lo) <= 0.03 * lo
+    # not worse than the oracle's Hogwild by more than 3 %; in this short-corpus regime the device run (whose hottest rows are
+    # averaged over the workgroups: lower-variance steps on the top of the tree) lands BELOW the oracle's loss (0.595 vs 0.624)
+    assert lg <= 1.03 * lo and lg >= 0.85 * lo
 
 
 def _same_paths(a, b):
