@@ -142,7 +142,7 @@ struct goctr_model {
   std::shared_mutex mu;
   // recorded on the main stream behind the last queued launch that writes the weights (training is asynchronous): a
   // serving slot's stream waits for it before it reads them
-  hipEvent_t ev_weights = nullptr; bool weights_pending = false;
+  hipEvent_t ev_weights = nullptr; std::atomic<bool> weights_pending{false};
   StepGraph graph;
   int attp_blocks = 0;
   // trainable-embedding extension (emb_train.h): off unless goctr_model_set_embedding_training(lr > 0)
@@ -167,6 +167,7 @@ struct goctr_model {
   bool ex_fixed = false; int ex_S = 0, ex_R = 0;
   DevBuf<int> ex_bucket_off, ex_send_ids, ex_recv_ids; DevBuf<long long> ex_send_rows, ex_recv_rows;
   ReduceArgs pend_ra{};            // launch_backward(stage 1) -> (stage 2)
+  bool pend_retarget = false; long long pend_batch_idx = 0, pend_n_batches = 1;   // goctr_train_steps -> run_steps' state-preparation launch
   // bucketed exchange (data parallel): bucket bounds / counts, received pairs, the owner's reduction, the gathered deltas
   DevBuf<int> ex_off, ex_cnt, ex_allcnt, ex_rids, ex_red_ids, ex_nred, ex_allnred, ex_gids;
   DevBuf<long long> ex_rrows, ex_red;
@@ -935,20 +936,29 @@ int ensure_emb_plan(goctr_model* m, const goctr_dataset* d, const RowSource& src
   return 0;
 }
 
-template <int GS>
-int launch_emb_slot_gs(int mode, bool direct, dim3 grid, hipStream_t s, const EmbSlotArgs& a) {
-#define GOCTR_SLOT(M) do { if (direct) hipLaunchKernelGGL((emb_slot_kernel<GS, M, true>), grid, dim3(EMB_SLOT_THREADS), 0, s, a); \
-                           else hipLaunchKernelGGL((emb_slot_kernel<GS, M, false>), grid, dim3(EMB_SLOT_THREADS), 0, s, a); } while (0)
+template <int GS, int VEC>
+int launch_emb_slot_gv(int mode, bool direct, long long max_pairs, hipStream_t s, const EmbSlotArgs& a) {
+  const long long wgp = EmbSlotGeo<GS, VEC>::WGP;
+  const dim3 grid((unsigned)std::max<long long>(cdiv(max_pairs, wgp), 1));
+#define GOCTR_SLOT(M) do { if (direct) hipLaunchKernelGGL((emb_slot_kernel<GS, VEC, M, true>), grid, dim3(EMB_SLOT_THREADS), 0, s, a); \
+                           else hipLaunchKernelGGL((emb_slot_kernel<GS, VEC, M, false>), grid, dim3(EMB_SLOT_THREADS), 0, s, a); } while (0)
   if (mode == 0) GOCTR_SLOT(0); else GOCTR_SLOT(1);
 #undef GOCTR_SLOT
   GOCTR_HIP(hipGetLastError());
   if (direct) {
-    const long long wgp = (long long)(EMB_SLOT_THREADS / GS) * EMB_SEG;
     const long long borders = std::max<long long>(cdiv(a.B * (long long)(a.T + 1), wgp), 1);      // (upper bound over the batches)
-    hipLaunchKernelGGL((emb_span_apply_kernel<GS>), dim3((unsigned)cdiv(borders, 256 / GS)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(emb_span_apply_kernel, dim3((unsigned)cdiv(borders * a.D, 256)), dim3(256), 0, s, a, wgp);
     GOCTR_HIP(hipGetLastError());
   }
   return 0;
+}
+// layout of the slot kernel: four components per lane (16-byte loads) when the widths allow, else one
+// (measured, GOCTR_EMB_SLOT_VEC=4 / 1 forces either: mean pooling at cfg4 80.7 -> 78.3 us with four components per lane; DIN at
+// cfg3 got SLOWER, 30.7 -> 33.5 us -- fewer, fatter wavefronts hide less of the latency that bounds it -- so DIN keeps one)
+bool emb_slot_vec4(const goctr_model* m) {
+  const goctr_ctr_cfg& c = m->cfg;
+  const int want = env_int("GOCTR_EMB_SLOT_VEC", c.kind != GOCTR_DIN ? 4 : 1);
+  return (c.D == 16 || c.D == 32 || c.D == 64) && (c.U + c.D) % 4 == 0 && want == 4;
 }
 
 int launch_emb_exchange(goctr_model* m, const EmbTrainArgs& a);
@@ -995,13 +1005,18 @@ int launch_emb_plan_step(goctr_model* m, const RowSource& src, int B, const Step
     ProfScope ps(GOCTR_K_EMB_GRAD);
     if (ps.on) {
       static char sym[48];
-      snprintf(sym, sizeof sym, "emb_slot_kernel<%d,%d,%s>", c.D <= 16 ? 16 : c.D <= 32 ? 32 : 64, mode ? 1 : 0, direct ? "true" : "false");
+      const bool v4 = emb_slot_vec4(m);
+      snprintf(sym, sizeof sym, "emb_slot_kernel<%d,%d,%d,%s>", v4 ? c.D / 4 : (c.D <= 16 ? 16 : c.D <= 32 ? 32 : 64), v4 ? 4 : 1, mode ? 1 : 0,
+               direct ? "true" : "false");
       prof_note_kernel(GOCTR_K_EMB_GRAD, sym);
     }
-    const int gs = c.D <= 16 ? 16 : c.D <= 32 ? 32 : 64;
-    const dim3 grid((unsigned)std::max<long long>(cdiv(m->plan.max_pairs, (long long)(EMB_SLOT_THREADS / gs) * EMB_SEG), 1));
-    if (gs == 16 ? launch_emb_slot_gs<16>(mode, direct, grid, s, a) : gs == 32 ? launch_emb_slot_gs<32>(mode, direct, grid, s, a)
-                                                                              : launch_emb_slot_gs<64>(mode, direct, grid, s, a)) return -1;
+    const long long mp = m->plan.max_pairs;
+    int rc;
+    if (emb_slot_vec4(m)) rc = c.D == 16 ? launch_emb_slot_gv<4, 4>(mode, direct, mp, s, a) : c.D == 32 ? launch_emb_slot_gv<8, 4>(mode, direct, mp, s, a)
+                                                                                                        : launch_emb_slot_gv<16, 4>(mode, direct, mp, s, a);
+    else rc = c.D <= 16 ? launch_emb_slot_gv<16, 1>(mode, direct, mp, s, a) : c.D <= 32 ? launch_emb_slot_gv<32, 1>(mode, direct, mp, s, a)
+                                                                                         : launch_emb_slot_gv<64, 1>(mode, direct, mp, s, a);
+    if (rc) return -1;
   }
   if (direct) return 0;
   const int cus = e.compute_units > 0 ? e.compute_units : 256;
@@ -1486,19 +1501,24 @@ int build_multi_graphs(goctr_model* m, const RowSource& src, int B, const StepOp
 
 int set_state(goctr_model* m, unsigned gstep, unsigned slot, long long batch_idx, long long n_batches) {
   StepState s{gstep, slot, batch_idx, n_batches};
+  m->pend_retarget = false;
   if (m->ra_flag.p) GOCTR_HIP(hipMemsetAsync(m->ra_flag.p, 0, sizeof(unsigned int), engine().stream));   // (gstep may jump: no stale match)
   GOCTR_HIP(hipMemcpyAsync(m->st_cur(), &s, sizeof s, hipMemcpyHostToDevice, engine().stream));
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
   return 0;
 }
 
-// point the running state at another batch of another dataset without a host round trip (gstep stays on the device)
-__global__ void step_state_retarget_kernel(StepState* st, long long batch_idx, long long n_batches) {
-  st->slot = 0; st->batch_idx = batch_idx; st->n_batches = n_batches;
+// point the running state at another batch of another dataset without a host round trip (gstep stays on the device), and
+// give the state a call starts from its Adam bias corrections (ctr_kernels.h: StepState::corr1/2)
+__global__ void step_state_prepare_kernel(StepState* st, double beta1, double beta2, int retarget, long long batch_idx, long long n_batches) {
+  StepState s = *st;
+  if (retarget) { s.slot = 0; s.batch_idx = batch_idx; s.n_batches = n_batches; }
+  state_corrections(s, beta1, beta2);
+  *st = s;
 }
+// (applied by run_steps' state-preparation launch: no kernel of its own)
 int retarget_state(goctr_model* m, long long batch_idx, long long n_batches) {
-  hipLaunchKernelGGL(step_state_retarget_kernel, dim3(1), dim3(1), 0, engine().stream, m->st_cur(), batch_idx, n_batches);
-  GOCTR_HIP(hipGetLastError());
+  m->pend_retarget = true; m->pend_batch_idx = batch_idx; m->pend_n_batches = n_batches;
   return 0;
 }
 
@@ -1534,7 +1554,7 @@ int check_dataset(const goctr_model* m, const goctr_dataset* d, const goctr_emb*
 int mark_weights_written(goctr_model* m) {
   if (!m->ev_weights) GOCTR_HIP(hipEventCreateWithFlags(&m->ev_weights, hipEventDisableTiming));
   GOCTR_HIP(hipEventRecord(m->ev_weights, engine().stream));
-  m->weights_pending = true;
+  m->weights_pending.store(true, std::memory_order_release);
   return 0;
 }
 
@@ -1571,7 +1591,11 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
   }
   // the bias corrections of the state the call starts from (ctr_kernels.h: StepState::corr1/2); later states get theirs from
   // the loss block of the step before them
-  hipLaunchKernelGGL(step_state_corr_kernel, dim3(1), dim3(1), 0, e.stream, m->st_cur(), o.tc->beta1, o.tc->beta2);
+  // (one launch together with the cursor retarget of goctr_train_steps: two one-thread kernels in front of a 20-step call
+  // were ~3 us of its timed region)
+  hipLaunchKernelGGL(step_state_prepare_kernel, dim3(1), dim3(1), 0, e.stream, m->st_cur(), o.tc->beta1, o.tc->beta2,
+                     m->pend_retarget ? 1 : 0, m->pend_batch_idx, m->pend_n_batches);
+  m->pend_retarget = false;
   GOCTR_HIP(hipGetLastError());
   // (with a communicator and NO plan the sparse embedding exchange sizes its collectives from device counters read back by
   // the host: eager steps.  With the plan's fixed-size buckets the step is three captured graphs around the collectives.)
@@ -2455,9 +2479,17 @@ struct SlotLease {
   ~SlotLease() { if (s) serve_pool().release(s); }
 };
 
-// the slot's stream must see every weight write queued on the main stream so far (training is asynchronous)
+// A serving pass must see every weight write queued on the main stream so far (training is asynchronous).  The calling
+// thread waits for the event on the HOST: a hipStreamWaitEvent from the slot's stream fails ("dependency created on
+// uncaptured work in another stream") whenever another thread happens to be capturing a step graph on the main stream at
+// that moment -- HIP judges the event by its stream's current capture state.  The caller holds the model's lock shared, so
+// no new weight write can be queued while it waits; once the event has completed nothing is pending until the next one.
 int serve_wait_weights(goctr_model* m, ServeSlot* s) {
-  if (m->weights_pending && m->ev_weights) GOCTR_HIP(hipStreamWaitEvent(s->stream, m->ev_weights, 0));
+  (void)s;
+  if (m->weights_pending.load(std::memory_order_acquire) && m->ev_weights) {
+    GOCTR_HIP(hipEventSynchronize(m->ev_weights));
+    m->weights_pending.store(false, std::memory_order_release);
+  }
   return 0;
 }
 

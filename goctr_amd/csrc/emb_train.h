@@ -368,7 +368,7 @@ struct EmbPlanView {
   const long long* slot_base;    // [nb + 1]
 };
 constexpr int EMB_PAIR_TBITS = 12;                 // t < 4096, b < 2^19
-constexpr int EMB_SEG = 32;                        // pairs per lane group
+constexpr int EMB_SEG = 16;                        // pairs per lane group (one component per lane): all of them in flight at once
 constexpr int EMB_SLOT_THREADS = 256;              // 16 lane groups at D = 16: 512 pairs per workgroup, several workgroups per CU
 
 // ---- plan build (once per dataset): count -> scans (scan.h) -> fill
@@ -548,108 +548,164 @@ struct EmbSlotArgs {
 
 // MODE: 0 mean pooling (dx = dp / T), otherwise DIN (dx = alpha dp + beta v + gamma x).  DIRECT: single GPU -- finished rows are
 // written to the table; false: every slot's sum goes to accum (the send buffer of the data-parallel exchange).
-template <int GS, int MODE, bool DIRECT>
+// A lane group = GS lanes x VEC components per lane (GS * VEC >= D).  VEC = 4: four lanes carry a 16-wide row with one
+// 16-byte load each, so a wavefront instruction serves 16 pairs (64 / GS) instead of 4 -- the kernel is ISSUE-bound at cfg3
+// (the per-pair bookkeeping: three hand-offs, address arithmetic, run tracking, was paid on every one of 16 lanes per pair).
+// VEC = 1 is the generic layout (any D <= 64, any alignment).
+template <int GS, int VEC>
+struct EmbSlotGeo {
+  static constexpr int SEG = VEC == 1 ? EMB_SEG : (GS * 4 < 16 ? 16 : GS * 4);      // pairs per lane group
+  static constexpr int GPB = EMB_SLOT_THREADS / GS;                                 // lane groups per workgroup
+  static constexpr long long WGP = (long long)GPB * SEG;                            // pairs per workgroup
+};
+
+template <int GS, int VEC, int MODE, bool DIRECT>
 __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs a) {
-  constexpr int NG = 64 / GS, GPB = EMB_SLOT_THREADS / GS;
-  __shared__ long long entL[GPB][GS], entR[GPB][GS];
+  typedef float fv __attribute__((ext_vector_type(VEC)));
+  constexpr int SEG = EmbSlotGeo<GS, VEC>::SEG, GPB = EmbSlotGeo<GS, VEC>::GPB, DW = GS * VEC;
+  __shared__ long long entL[GPB][DW], entR[GPB][DW];
   __shared__ int slotL[GPB], slotR[GPB], bothL[GPB], idL[GPB], idR[GPB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NG = 64 / GS;
   const int l = lane % GS, grp = lane / GS, gib = wave * NG + grp;
   const int D = a.D, T = a.T;
-  const bool act = l < D;
+  const int c0 = l * VEC;                            // first component of this lane
+  const bool act = c0 < D;                           // (D % VEC == 0: a lane is all in or all out)
   const long long k = a.st->batch_idx;
   const long long pbase = a.plan.pair_off[k], npairs = a.plan.pair_off[k + 1] - pbase;
-  const long long wg_begin = (long long)blockIdx.x * GPB * EMB_SEG;
+  const long long wg_begin = (long long)blockIdx.x * GPB * SEG;
   if (wg_begin >= npairs) return;
-  const long long wg_end = wg_begin + GPB * EMB_SEG < npairs ? wg_begin + GPB * EMB_SEG : npairs;
-  const long long sb = a.plan.slot_base[k];
-  const unsigned int* slot_off = a.plan.slot_off + sb + k;
+  const long long wg_end = wg_begin + (long long)GPB * SEG < npairs ? wg_begin + (long long)GPB * SEG : npairs;
   const int* pair = a.plan.pair + pbase;
   const int* pslot = a.plan.pslot + pbase;
   const int* pid = a.plan.pid + pbase;
-  const long long beg = wg_begin + (long long)gib * EMB_SEG;
-  const long long end = beg + EMB_SEG < wg_end ? beg + EMB_SEG : wg_end;
+  const long long beg = wg_begin + (long long)gib * SEG;
+  const long long end = beg + SEG < wg_end ? beg + SEG : wg_end;
   const float invT = 1.0f / (float)T;
   if (l == 0) { slotL[gib] = -1; slotR[gib] = -1; bothL[gib] = 0; }
 
+  auto ldv = [&](const float* p) -> fv {            // VEC consecutive floats (16-byte load when VEC == 4)
+    fv r;
+    if (VEC == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r[0] = t.x; r[1 % VEC] = t.y; r[2 % VEC] = t.z; r[3 % VEC] = t.w; }
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) r[e] = p[e];
+    }
+    return r;
+  };
   // a slot whose whole run was summed here: this lane group is the only writer of its row.  x = the row's value, loaded
   // together with the run's first pair (a load issued HERE would put one memory latency between every two runs: at cfg4
   // nearly every pair is a run of its own and the kernel took 100 us that way)
-  auto finish = [&](int id, float x, long long q) {
-    if (!act) return;
-    if (DIRECT) {
-      if (q) a.emb[(long long)id * D + l] = x - a.lr * (float)((double)q * EMB_FIX_INV);
+  auto finish = [&](int id, const fv& x, const long long (&q)[VEC]) {
+    if (!act || !DIRECT) return;
+    bool any = false;
+    fv nv;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { any = any || q[e] != 0; nv[e] = x[e] - a.lr * (float)((double)q[e] * EMB_FIX_INV); }
+    if (!any) return;
+    float* p = a.emb + (long long)id * D + c0;
+    if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(nv[0], nv[1 % VEC], nv[2 % VEC], nv[3 % VEC]);
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) p[e] = nv[e];
     }
   };
   if (beg < end) {
     const int prev_slot = beg > 0 ? pslot[beg - 1] : -1;
     const int next_slot = end < npairs ? pslot[end] : -1;
     // the segment's pairs: lane j of the group fetches pair j (and j + GS, ...): coalesced, handed round by shuffle
-    constexpr int NL = EMB_SEG / GS > 0 ? EMB_SEG / GS : 1;
+    constexpr int NL = SEG / GS > 0 ? SEG / GS : 1;
     int c_[NL], s_[NL], i_[NL];
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
       const long long i = beg + u * GS + l;
-      const bool in = (GS >= EMB_SEG ? l < EMB_SEG : true) && i < end;
+      const bool in = (GS >= SEG ? l < SEG : true) && i < end;
       c_[u] = in ? pair[i] : 0; s_[u] = in ? pslot[i] : -1; i_[u] = in ? pid[i] : 0;
     }
     int cur = -1, cur_id = 0;
-    float cur_x = 0.f;
+    fv cur_x;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) cur_x[e] = 0.f;
     bool cur_ol = false;
-    long long acc = 0;
+    long long acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0;
     auto close = [&](bool open_right) {
       if (cur < 0) return;
       if (!cur_ol && !open_right) {
         if (DIRECT) finish(cur_id, cur_x, acc);
-        else if (act) a.accum[(long long)cur * D + l] = acc;
+        else if (act) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) a.accum[(long long)cur * D + c0 + e] = acc[e];
+        }
       } else if (cur_ol) {
-        if (act) entL[gib][l] = acc;
+        if (act) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) entL[gib][c0 + e] = acc[e];
+        }
         if (l == 0) { slotL[gib] = cur; bothL[gib] = open_right ? 1 : 0; idL[gib] = cur_id; }
       } else {
-        if (act) entR[gib][l] = acc;
+        if (act) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) entR[gib][c0 + e] = acc[e];
+        }
         if (l == 0) { slotR[gib] = cur; idR[gib] = cur_id; }
       }
     };
-    constexpr int UNR = 4;
-    constexpr int PER = GS < EMB_SEG ? GS : EMB_SEG;          // pairs one register set (c_[ub], s_[ub], i_[ub]) holds
+    // pairs whose rows are requested before the first of them is used.  The kernel is LATENCY-bound where the table is
+    // L2-resident (cfg3): with 4 pairs in flight a 32-pair segment was 8 dependent round trips (31 us); the one-component layout
+    // now asks for all 16 pairs of its segment at once (7 registers per pair).  Four components per lane cost 16 registers per
+    // pair: 8 pairs in flight for mean pooling (no v / coefficient rows), 4 for DIN.
+    constexpr int UNR = VEC == 1 ? 16 : (MODE == 0 ? 8 : 4);
+    constexpr int PER = GS < SEG ? GS : SEG;          // pairs one register set (c_[ub], s_[ub], i_[ub]) holds
+    constexpr int UN = UNR < PER ? UNR : PER;
+    static_assert(PER % UN == 0, "segment layout");
 #pragma unroll
     for (int ub = 0; ub < NL; ++ub) {
-      for (int jj = 0; jj < PER; jj += UNR) {
+      for (int jj = 0; jj < PER; jj += UN) {
         if (beg + ub * PER + jj >= end) break;
-        int code[UNR], sl[UNR], id[UNR];
-        float dp[UNR], vv[UNR], xx[UNR];
-        float4 cf[UNR];
+        int code[UN], sl[UN], id[UN];
+        fv dp[UN], vv[UN], xx[UN];
+        float4 cf[UN];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        for (int u = 0; u < UN; ++u) {
           const int srcl = grp * GS + jj + u;
           code[u] = __shfl(c_[ub], srcl, 64);
           sl[u] = __shfl(s_[ub], srcl, 64);
           id[u] = __shfl(i_[ub], srcl, 64);
           if (beg + ub * PER + jj + u >= end) sl[u] = -1;
-          const int b = code[u] >> EMB_PAIR_TBITS, t = code[u] & ((1 << EMB_PAIR_TBITS) - 1);
+          const unsigned b = (unsigned)code[u] >> EMB_PAIR_TBITS, t = (unsigned)code[u] & ((1u << EMB_PAIR_TBITS) - 1u);
           const bool on = sl[u] >= 0 && act;
-          xx[u] = (on && (MODE != 0 || DIRECT)) ? a.emb[(long long)id[u] * D + l] : 0.f;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { dp[u][e] = 0.f; vv[u][e] = 0.f; xx[u][e] = 0.f; }
+          cf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (on && (MODE != 0 || DIRECT)) xx[u] = ldv(a.emb + (long long)id[u] * D + c0);
           if (MODE == 0) {
-            dp[u] = on ? a.dpv[(size_t)b * a.ldp + (t < T ? 0 : D) + l] : 0.f;
+            if (on) dp[u] = ldv(a.dpv + (b * (unsigned)a.ldp + ((int)t < T ? 0u : (unsigned)D) + (unsigned)c0));
           } else {
-            cf[u] = (sl[u] >= 0 && t < T) ? a.coef[(size_t)b * T + t] : make_float4(0.f, 0.f, 0.f, 0.f);
-            dp[u] = on ? (t < T ? a.dpv[(size_t)b * a.ldp + l] : a.gsum[(size_t)b * D + l]) : 0.f;
-            vv[u] = (on && t < T) ? a.h0[(size_t)b * a.Ip + a.U + D + l] : 0.f;
+            if (sl[u] >= 0 && (int)t < T) cf[u] = a.coef[b * (unsigned)T + t];
+            if (on) dp[u] = (int)t < T ? ldv(a.dpv + (b * (unsigned)a.ldp + (unsigned)c0)) : ldv(a.gsum + (b * (unsigned)D + (unsigned)c0));
+            if (on && (int)t < T) vv[u] = ldv(a.h0 + (b * (unsigned)a.Ip + (unsigned)(a.U + D + c0)));
           }
         }
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        for (int u = 0; u < UN; ++u) {
           if (sl[u] < 0) continue;                              // (group-uniform)
           if (sl[u] != cur) {
             close(false);
-            cur = sl[u]; cur_id = id[u]; cur_x = xx[u]; acc = 0;
+            cur = sl[u]; cur_id = id[u]; cur_x = xx[u];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[e] = 0;
             cur_ol = (ub * PER + jj + u == 0) && cur == prev_slot;
           }
           const int t = code[u] & ((1 << EMB_PAIR_TBITS) - 1);
-          float dx;
-          if (MODE == 0) dx = t < T ? invT * dp[u] : dp[u];
-          else dx = t < T ? cf[u].x * dp[u] + cf[u].y * vv[u] + cf[u].z * xx[u] : dp[u];
-          acc += emb_fix(dx);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float dx;
+            if (MODE == 0) dx = t < T ? invT * dp[u][e] : dp[u][e];
+            else dx = t < T ? cf[u].x * dp[u][e] + cf[u].y * vv[u][e] + cf[u].z * xx[u][e] : dp[u][e];
+            acc[e] += emb_fix(dx);
+          }
         }
       }
     }
@@ -659,46 +715,49 @@ __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs 
   // runs that cross segment borders inside this workgroup: the entry that opens a chain sums it
   //   R(g) [closed left, open right] -> L(g+1) [open left] -> while that one is also open right: L(g+2) ...
   //   L(0) opens the chain that arrives from the previous workgroup
-  const int ngroups = (int)((wg_end - wg_begin + EMB_SEG - 1) / EMB_SEG);
+  const int ngroups = (int)((wg_end - wg_begin + SEG - 1) / SEG);
   if (gib < ngroups) {
     for (int which = 0; which < 2; ++which) {
       // which 0: this group's R entry; which 1: group 0's L entry (arrives from the previous workgroup)
       if (which == 1 && gib != 0) break;
       const int s0 = which == 0 ? slotR[gib] : slotL[0];
       if (s0 < 0) continue;
-      long long tot = which == 0 ? entR[gib][act ? l : 0] : entL[0][act ? l : 0];
+      long long tot[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) tot[e] = which == 0 ? entR[gib][act ? c0 + e : 0] : entL[0][act ? c0 + e : 0];
       const int id0 = which == 0 ? idR[gib] : idL[0];
       bool closed = which == 1 && !bothL[0];
-      bool from_prev = which == 1;
-      int j = gib + 1;
+      const bool from_prev = which == 1;
       if (!(which == 1 && !bothL[0])) {
-        for (; j < ngroups; ++j) {
+        for (int j = gib + 1; j < ngroups; ++j) {
           if (slotL[j] != s0) break;                          // (cannot happen for a consistent plan; ends the chain)
-          tot += entL[j][act ? l : 0];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) tot[e] += entL[j][act ? c0 + e : 0];
           if (!bothL[j]) { closed = true; break; }
         }
       }
       const bool whole = closed && !from_prev;                // the run began and ended inside this workgroup
       if (!act) continue;
-      if (whole) {
-        if (DIRECT) { if (tot) a.emb[(long long)id0 * D + l] -= a.lr * (float)((double)tot * EMB_FIX_INV); }
-        else a.accum[(long long)s0 * D + l] = tot;
-      } else if (tot) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)s0 * D + l), (unsigned long long)tot);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (whole) {
+          if (DIRECT) { if (tot[e]) a.emb[(long long)id0 * D + c0 + e] -= a.lr * (float)((double)tot[e] * EMB_FIX_INV); }
+          else a.accum[(long long)s0 * D + c0 + e] = tot[e];
+        } else if (tot[e]) {
+          atomicAdd(reinterpret_cast<unsigned long long*>(a.accum + (long long)s0 * D + c0 + e), (unsigned long long)tot[e]);
+        }
       }
     }
   }
-  (void)slot_off;
 }
 
 // rows whose run crosses a workgroup border of emb_slot_kernel (DIRECT): their sums sit in accum; the FIRST border inside a
-// run applies it and clears the accumulator.  One lane group per border.
-template <int GS>
-__global__ __launch_bounds__(256) void emb_span_apply_kernel(EmbSlotArgs a) {
-  constexpr int GPB = EMB_SLOT_THREADS / GS;
-  const long long WGP = (long long)GPB * EMB_SEG;
-  const int l = threadIdx.x % GS;
-  const long long w = (long long)blockIdx.x * (256 / GS) + threadIdx.x / GS + 1;      // border index, >= 1
+// run applies it and clears the accumulator.  One lane per (border, component); WGP = the slot kernel's pairs per workgroup.
+__global__ __launch_bounds__(256) void emb_span_apply_kernel(EmbSlotArgs a, long long WGP) {
+  const int D = a.D;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long w = gid / D + 1;                            // border index, >= 1
+  const int l = (int)(gid % D);
   const long long k = a.st->batch_idx;
   const long long pbase = a.plan.pair_off[k], npairs = a.plan.pair_off[k + 1] - pbase;
   const long long pos = w * WGP;
@@ -709,11 +768,10 @@ __global__ __launch_bounds__(256) void emb_span_apply_kernel(EmbSlotArgs a) {
   const long long sb = a.plan.slot_base[k];
   const unsigned int start = a.plan.slot_off[sb + k + s];
   if ((long long)(start / WGP) + 1 != w) return;              // an earlier border of the same run does it
-  if (l >= a.D) return;
   const int id = a.plan.slot_id[sb + s];
-  const long long q = a.accum[(long long)s * a.D + l];
-  a.accum[(long long)s * a.D + l] = 0;
-  if (q) a.emb[(long long)id * a.D + l] -= a.lr * (float)((double)q * EMB_FIX_INV);
+  const long long q = a.accum[(long long)s * D + l];
+  a.accum[(long long)s * D + l] = 0;
+  if (q) a.emb[(long long)id * D + l] -= a.lr * (float)((double)q * EMB_FIX_INV);
 }
 
 // data parallel: the exchange (ctr.hip: launch_emb_exchange) wants the batch's slot -> id list and slot count in fixed buffers
