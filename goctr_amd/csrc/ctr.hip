@@ -162,7 +162,7 @@ struct goctr_model {
     long long nb = 0, max_pairs = 0, max_slots = 0, total_pairs = 0, total_slots = 0;
     EmbPlanView view() const { return EmbPlanView{pair.p, pslot.p, pid.p, pair_off.p, slot_id.p, slot_off.p, slot_base.p}; }
   } plan;
-  DevBuf<float4> emb_coef; DevBuf<float> emb_gsum;
+  DevBuf<float> emb_dx, emb_gsum;  // emb_coef's per-pair row gradients [B, T, D] and item-row gradients [B, D]
   // fixed-size exchange (emb_train.h, end): exact bounds from the plan, no host read-back between the collectives
   bool ex_fixed = false; int ex_S = 0, ex_R = 0;
   DevBuf<int> ex_bucket_off, ex_send_ids, ex_recv_ids; DevBuf<long long> ex_send_rows, ex_recv_rows;
@@ -898,7 +898,7 @@ int ensure_emb_plan(goctr_model* m, const goctr_dataset* d, const RowSource& src
   GOCTR_HIP(hipMemcpyAsync(P.slot_id.p, tsid.p, ns * 4, hipMemcpyDeviceToDevice, s));
   GOCTR_HIP(hipMemcpyAsync(P.slot_off.p, tsoff.p, (ns + (size_t)nb) * 4, hipMemcpyDeviceToDevice, s));
   if (P.pair_off.upload(pair_off.data(), pair_off.size()) || P.slot_base.upload(slot_base.data(), slot_base.size())) return -1;   // (synchronises)
-  if (c.kind == GOCTR_DIN && (m->emb_coef.ensure((size_t)B * c.T, false) || m->emb_gsum.ensure((size_t)B * c.D, false))) return -1;
+  if (c.kind == GOCTR_DIN && (m->emb_dx.ensure((size_t)B * c.T * c.D, false) || m->emb_gsum.ensure((size_t)B * c.D, false))) return -1;
   m->ex_fixed = false;
   if (e.comm_active() && env_int("GOCTR_EMB_FIXED_EXCHANGE", 1) != 0) {
     // bucket bounds of every batch, the largest bucket over batches, owners AND ranks (one small all-gather, here, once)
@@ -958,7 +958,7 @@ int launch_emb_slot_gv(int mode, bool direct, long long max_pairs, hipStream_t s
 bool emb_slot_vec4(const goctr_model* m) {
   const goctr_ctr_cfg& c = m->cfg;
   const int want = env_int("GOCTR_EMB_SLOT_VEC", c.kind != GOCTR_DIN ? 4 : 1);
-  return (c.D == 16 || c.D == 32 || c.D == 64) && (c.U + c.D) % 4 == 0 && want == 4;
+  return (c.D == 16 || c.D == 32 || c.D == 64) && want == 4;
 }
 
 int launch_emb_exchange(goctr_model* m, const EmbTrainArgs& a);
@@ -978,7 +978,7 @@ int launch_emb_plan_early(goctr_model* m, const RowSource& src, int B, const Ste
   const int mode = c.att == GOCTR_ATT_COSINE ? 1 : 2;
   ProfScope ps(GOCTR_K_ATTN_BWD);
   if (ps.on) { static char sym[40]; snprintf(sym, sizeof sym, "emb_coef_kernel<%d,%d>", c.D / 4, mode); prof_note_kernel(GOCTR_K_ATTN_BWD, sym); }
-  EmbCoefArgs ca{src, st, B, c.T, c.D, m->dpv.p, Np, m->gate_p(m->stp), m->W.p + m->offa, m->emb_coef.p, m->emb_gsum.p,
+  EmbCoefArgs ca{src, st, B, c.T, c.D, m->dpv.p, Np, m->gate_p(m->stp), m->W.p + m->offa, m->emb_dx.p, m->emb_gsum.p,
                  m->wgt_p(m->stp), m->attp.p, m->Tp};
   const dim3 g((unsigned)cdiv(B, 4));
   const int lpr = c.D / 4;
@@ -999,7 +999,7 @@ int launch_emb_plan_step(goctr_model* m, const RowSource& src, int B, const Step
   const bool direct = !e.comm_active();
   EmbSlotArgs a{};
   a.plan = m->plan.view(); a.st = st; a.B = B; a.T = c.T; a.D = c.D; a.dpv = m->dpv.p; a.ldp = Np;
-  a.coef = m->emb_coef.p; a.gsum = m->emb_gsum.p; a.h0 = m->h0.p; a.Ip = m->Ip; a.U = c.U;
+  a.dx = m->emb_dx.p; a.gsum = m->emb_gsum.p;
   a.emb = const_cast<float*>(src.emb); a.accum = m->emb_accum.p; a.lr = m->emb_lr;
   {
     ProfScope ps(GOCTR_K_EMB_GRAD);

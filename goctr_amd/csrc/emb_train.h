@@ -433,7 +433,7 @@ struct EmbCoefArgs {
   int B, T, D;
   const float* dpv; int ldp;          // [B, ldp]: 0..D-1 d cost / d pooled, D..2D-1 d cost / d item segment of h0
   const float* gate; const float* att0;
-  float4* coef;                       // [B, T]  (alpha, beta, gamma, -)
+  float* dx;                          // [B, T, D]  the row gradient of every (sample, slot) pair: alpha dp + beta v + gamma x_t
   float* gsum;                        // [B, D]  gradient of the candidate item's row
   // attn_bwd_kernel's job rides along (the rows are gathered and dp . x is formed here anyway): the per-sample terms of the
   // att0 gradient, dgs [B, Tp] = (dp . x_t / T) g (1 - g) w_t  (null: not wanted)
@@ -515,16 +515,26 @@ __global__ __launch_bounds__(256) void emb_coef_kernel(EmbCoefArgs a) {
         delta = q * ir; eps = -(q * ir);
       }
     }
-    if (lane < SLOTS && tb + lane < T) {
-      a.coef[(size_t)b * T + tb + lane] = make_float4(alpha, beta, gamma, 0.f);
-      if (a.partial) a.partial[(size_t)b * a.Tp + tb + lane] = (s0 * invT) * (gl * (1.0f - gl)) * a.wgt[(size_t)b * T + tb + lane];
-    }
+    if (a.partial && lane < SLOTS && tb + lane < T)
+      a.partial[(size_t)b * a.Tp + tb + lane] = (s0 * invT) * (gl * (1.0f - gl)) * a.wgt[(size_t)b * T + tb + lane];
     esum += eps;
+    // The pair's whole row gradient leaves here, where dp, v and x_t are in registers: 64 contiguous bytes per pair, a pass
+    // of 16 rows = 1 KiB per store instruction.  (The first version left three scalars per pair and emb_slot re-fetched dp, v
+    // and x for every pair: 73 MB of 64-byte requests past the L2s, 31 us, SQ_WAIT_ANY 68 % -- the id-major side sees the
+    // samples in random order.)
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
-      const float d = __shfl(delta, p * RPP + rl, 64);
+      const int sl = p * RPP + rl, t = tb + sl;
+      const float d = __shfl(delta, sl, 64);
+      const float pa = __shfl(alpha, sl, 64), pb = __shfl(beta, sl, 64), pg = __shfl(gamma, sl, 64);
+      typedef float v4 __attribute__((ext_vector_type(4)));
+      v4 o;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) dsum[e] += d * x[p][e];
+      for (int e = 0; e < VEC; ++e) {
+        dsum[e] += d * x[p][e];
+        o[e] = pa * dpt[e] + pb * vv[e] + pg * x[p][e];
+      }
+      if (t < T) *reinterpret_cast<v4*>(a.dx + ((size_t)b * T + t) * D + d0) = o;
     }
   }
 #pragma unroll
@@ -541,8 +551,7 @@ struct EmbSlotArgs {
   EmbPlanView plan; const StepState* st;
   int B, T, D;
   const float* dpv; int ldp;
-  const float4* coef; const float* gsum;       // DIN (MODE != 0)
-  const float* h0; int Ip, U;                  // v = h0[b, U + D ..] (the candidate row attn_fwd gathered)
+  const float* dx; const float* gsum;          // DIN (MODE != 0): per-pair row gradients [B, T, D] and the item rows' [B, D] (emb_coef)
   float* emb; long long* accum; float lr;
 };
 
@@ -622,7 +631,7 @@ __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs 
       const bool in = (GS >= SEG ? l < SEG : true) && i < end;
       c_[u] = in ? pair[i] : 0; s_[u] = in ? pslot[i] : -1; i_[u] = in ? pid[i] : 0;
     }
-    int cur = -1, cur_id = 0;
+    int cur = -1, cur_id = 0, cur_prev = -2;          // cur_prev: slot of the last pair of the previous block of loads
     fv cur_x;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) cur_x[e] = 0.f;
@@ -652,11 +661,9 @@ __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs 
         if (l == 0) { slotR[gib] = cur; idR[gib] = cur_id; }
       }
     };
-    // pairs whose rows are requested before the first of them is used.  The kernel is LATENCY-bound where the table is
-    // L2-resident (cfg3): with 4 pairs in flight a 32-pair segment was 8 dependent round trips (31 us); the one-component layout
-    // now asks for all 16 pairs of its segment at once (7 registers per pair).  Four components per lane cost 16 registers per
-    // pair: 8 pairs in flight for mean pooling (no v / coefficient rows), 4 for DIN.
-    constexpr int UNR = VEC == 1 ? 16 : (MODE == 0 ? 8 : 4);
+    // pairs whose rows are requested before the first of them is used (8 and 16 in flight were measured: no gain at cfg3, a
+    // loss at cfg4 -- 78 -> 92 us with four components per lane, and the one-component layout spilled)
+    constexpr int UNR = 4;
     constexpr int PER = GS < SEG ? GS : SEG;          // pairs one register set (c_[ub], s_[ub], i_[ub]) holds
     constexpr int UN = UNR < PER ? UNR : PER;
     static_assert(PER % UN == 0, "segment layout");
@@ -665,8 +672,7 @@ __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs 
       for (int jj = 0; jj < PER; jj += UN) {
         if (beg + ub * PER + jj >= end) break;
         int code[UN], sl[UN], id[UN];
-        fv dp[UN], vv[UN], xx[UN];
-        float4 cf[UN];
+        fv dp[UN], xx[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
           const int srcl = grp * GS + jj + u;
@@ -677,17 +683,16 @@ __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs 
           const unsigned b = (unsigned)code[u] >> EMB_PAIR_TBITS, t = (unsigned)code[u] & ((1u << EMB_PAIR_TBITS) - 1u);
           const bool on = sl[u] >= 0 && act;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) { dp[u][e] = 0.f; vv[u][e] = 0.f; xx[u][e] = 0.f; }
-          cf[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (on && (MODE != 0 || DIRECT)) xx[u] = ldv(a.emb + (long long)id[u] * D + c0);
-          if (MODE == 0) {
-            if (on) dp[u] = ldv(a.dpv + (b * (unsigned)a.ldp + ((int)t < T ? 0u : (unsigned)D) + (unsigned)c0));
-          } else {
-            if (sl[u] >= 0 && (int)t < T) cf[u] = a.coef[b * (unsigned)T + t];
-            if (on) dp[u] = (int)t < T ? ldv(a.dpv + (b * (unsigned)a.ldp + (unsigned)c0)) : ldv(a.gsum + (b * (unsigned)D + (unsigned)c0));
-            if (on && (int)t < T) vv[u] = ldv(a.h0 + (b * (unsigned)a.Ip + (unsigned)(a.U + D + c0)));
+          for (int e = 0; e < VEC; ++e) { dp[u][e] = 0.f; xx[u][e] = 0.f; }
+          // the row itself is only needed where a run starts (it is applied at the run's end)
+          const int before = u > 0 ? sl[u - 1] : (jj == 0 && ub == 0 ? -2 : cur_prev);
+          if (on && DIRECT && sl[u] != before) xx[u] = ldv(a.emb + (long long)id[u] * D + c0);
+          if (on) {
+            if (MODE == 0) dp[u] = ldv(a.dpv + (b * (unsigned)a.ldp + ((int)t < T ? 0u : (unsigned)D) + (unsigned)c0));
+            else dp[u] = (int)t < T ? ldv(a.dx + ((size_t)(b * (unsigned)T + t) * (unsigned)D + (unsigned)c0)) : ldv(a.gsum + (b * (unsigned)D + (unsigned)c0));
           }
         }
+        cur_prev = sl[UN - 1] >= 0 ? sl[UN - 1] : cur_prev;
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
           if (sl[u] < 0) continue;                              // (group-uniform)
@@ -701,9 +706,7 @@ __global__ __launch_bounds__(EMB_SLOT_THREADS) void emb_slot_kernel(EmbSlotArgs 
           const int t = code[u] & ((1 << EMB_PAIR_TBITS) - 1);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
-            float dx;
-            if (MODE == 0) dx = t < T ? invT * dp[u][e] : dp[u][e];
-            else dx = t < T ? cf[u].x * dp[u][e] + cf[u].y * vv[u][e] + cf[u].z * xx[u][e] : dp[u][e];
+            const float dx = (MODE == 0 && t < T) ? invT * dp[u][e] : dp[u][e];
             acc[e] += emb_fix(dx);
           }
         }
