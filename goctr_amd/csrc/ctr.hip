@@ -348,6 +348,13 @@ int launch_nn(int kid, const float* A, int lda, const float* Bm, int ldb, int M,
   const size_t lds = gemm_nn_lds_bytes<float>(KPH, ncols_alloc);
   hipStream_t st = engine().active;
   ProfScope ps(kid);
+  // B fits one LDS phase and there are many more row tiles than CUs: the persistent variant parks B once per workgroup
+  if (KPH >= Kp && ntw == 4 && (int)grid.x >= 2 * engine().compute_units && env_int("GOCTR_NN_ROWS", 1) != 0) {
+    const dim3 g2((unsigned)engine().compute_units, grid.y);
+    hipLaunchKernelGGL((gemm_nn_rows_kernel<float, Epi, 4>), g2, dim3(256), lds, st, A, lda, Bm, ldb, M, Kp, Np, WN, epi);
+    GOCTR_HIP(hipGetLastError());
+    return 0;
+  }
 #define GOCTR_NN(N) hipLaunchKernelGGL((gemm_nn_kernel<float, Epi, N>), grid, dim3(256), lds, st, A, lda, Bm, ldb, M, Kp, Np, WN, KPH, epi)
   switch (ntw) {
     case 1: GOCTR_NN(1); break;
@@ -400,7 +407,8 @@ int init_kernel_attrs() {
   static bool done = false;
   if (done) return 0;
 #define GOCTR_NN_ATTR(E) (allow_big_lds(gemm_nn_kernel<float, E, 1>) || allow_big_lds(gemm_nn_kernel<float, E, 3>) || \
-                          allow_big_lds(gemm_nn_kernel<float, E, 4>) || allow_big_lds(gemm_nn_kernel<float, E, 7>))
+                          allow_big_lds(gemm_nn_kernel<float, E, 4>) || allow_big_lds(gemm_nn_kernel<float, E, 7>) || \
+                          allow_big_lds(gemm_nn_rows_kernel<float, E, 4>))
   if (GOCTR_NN_ATTR(EpiSigDrop) || GOCTR_NN_ATTR(EpiOut) || GOCTR_NN_ATTR(EpiDSig) || GOCTR_NN_ATTR(EpiStore) ||
       allow_big_lds(ctr_chain_kernel<7, 5, 0>) || allow_big_lds(ctr_chain_kernel<7, 5, 1>) ||
       allow_big_lds(ctr_chain_kernel<7, 5, 2>) || allow_big_lds(ctr_fwd16_kernel<4, 5>) || allow_big_lds(emb_grad_kernel<16, 0, true>) || allow_big_lds(emb_grad_kernel<16, 1, true>) || allow_big_lds(emb_grad_kernel<16, 2, true>) || allow_big_lds(emb_grad_kernel<32, 0, true>) ||

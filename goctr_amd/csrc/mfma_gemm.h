@@ -77,6 +77,95 @@ inline int gemm_nn_phase_rows(int Kp, int ncols_blk) {
 template <typename T>
 inline size_t gemm_nn_lds_bytes(int kph, int ncols_alloc) { return (size_t)kph * (ncols_alloc + 4) * sizeof(T); }
 
+// The same product for a B operand that fits one LDS phase (Kp <= KPH), PERSISTENT over row tiles: a workgroup parks B once
+// and then walks row tiles blockIdx.x, + gridDim.x, ...; the A fragments of the NEXT tile are requested before the current
+// tile's MFMAs (one workgroup per CU -- B takes most of the LDS -- so no other wavefront would hide that latency).
+// gemm_nn_kernel parks B once per 16*WM rows: at M = 16384, Kp = 208, Np = 128 (the dpv product of the trainable-embedding
+// path at cfg4) that was 512 fills of 106 KB, each in front of 208 MFMAs per wavefront: 29 us, MFMA-busy 19 %.
+template <typename T, class Epi, int NTW>
+__global__ __launch_bounds__(256, 1) void gemm_nn_rows_kernel(const T* __restrict__ A, int lda, const T* __restrict__ Bm, int ldb, int M,
+                                                              int Kp, int Np, int WN, Epi epi) {
+  constexpr int ntw = NTW;
+  using MF = Mfma<T>;
+  using acc_t = typename MF::acc_t;
+  using vec_t = typename MF::vec_t;
+  constexpr int VEC = MF::VEC;
+  constexpr int PHCH = NnPhase<T>::CH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
+  T* Bs = reinterpret_cast<T*>(goctr_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int WM = 4 / WN;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int i = lane & 15, q = lane >> 4;
+  const int NTall = Np >> 4;
+  const int nblk0 = blockIdx.y * (WN * ntw);
+  int nt_blk = NTall - nblk0;
+  if (nt_blk > WN * ntw) nt_blk = WN * ntw;
+  const int ncols_blk = nt_blk * 16;
+  const int Ns = WN * ntw * 16 + 4;
+  int ntiles = nt_blk - wn * ntw;
+  ntiles = ntiles < 0 ? 0 : (ntiles > ntw ? ntw : ntiles);
+  const int nch = Kp >> 4;
+  // park B once
+  {
+    const int vpr = ncols_blk / VEC, total_v = Kp * vpr;
+    const T* bsrc = Bm + nblk0 * 16;
+    for (int idx = tid; idx < total_v; idx += 256) {
+      const int r = idx / vpr, cv = idx - r * vpr;
+      *reinterpret_cast<vec_t*>(Bs + r * Ns + cv * VEC) = *reinterpret_cast<const vec_t*>(bsrc + (size_t)r * ldb + cv * VEC);
+    }
+  }
+  const int nrt = (M + 16 * WM - 1) / (16 * WM);
+  auto load_a = [&](int rt, T (&dst)[PHCH][4]) {
+    int arow = rt * (16 * WM) + wm * 16 + i;
+    if (arow > M - 1) arow = M - 1;
+    const T* ap = A + (size_t)arow * lda + 4 * q;
+#pragma unroll
+    for (int c = 0; c < PHCH; ++c)
+      if (c < nch) MF::load4(ap + c * 16, dst[c]);
+  };
+  T av[PHCH][4], an[PHCH][4];
+  int rt = blockIdx.x;
+  if (rt < nrt) load_a(rt, av);
+  __syncthreads();
+  for (; rt < nrt; rt += gridDim.x) {
+    const int nxt = rt + gridDim.x;
+    if (nxt < nrt) load_a(nxt, an);
+    acc_t acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = acc_t{0, 0, 0, 0};
+    const T* brow = Bs + (4 * q) * Ns + wn * ntw * 16 + i;
+#pragma unroll
+    for (int c = 0; c < PHCH; ++c) {
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = MF::mma(av[c][j], brow[t * 16], acc[t]);
+          brow += Ns;
+        }
+        brow += 12 * Ns;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const int row0 = rt * (16 * WM) + wm * 16, nt0 = nblk0 + wn * ntw;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      if (t < ntiles) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = row0 + MF::crow(lane, r);
+          if (row < M) epi(row, (nt0 + t) * 16 + i, acc[t][r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < PHCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[c][j] = an[c][j];
+  }
+}
+
 // C = epi(A . B).  grid = (ceil(M / (16*WM)), n-blocks), block = 256, WM = 4 / WN; a column block is
 // WN*ntw tiles, wave (wm,wn) owns rows [16*wm,+16) x tiles [wn*ntw, +ntw).
 // epi(row, col, value) is called once per output element of rows < M.

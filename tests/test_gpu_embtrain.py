@@ -166,6 +166,36 @@ def test_hot_ids_whose_runs_cross_segments_and_workgroups(oracle, kind, att, D):
     del loss2, dE2
 
 
+@pytest.mark.parametrize("kind", ["youtube", "din"])
+def test_one_step_matches_oracle_at_cfg4_batch_size(oracle, kind):
+    """batch 16 384, T = 50 -- the launch geometry of BASELINE configs[3]'s slice: the persistent-row variant of the dpv GEMM
+    (gemm_nn_rows_kernel: M / 32 >= 2 x CUs), a plan of ~8 x 10^5 pairs, the four-components-per-lane slot kernel (mean
+    pooling, D = 64) / emb_coef's per-pair rows (DIN, D = 16), Zipf ids"""
+    from goctr_amd import capi, model as gm
+    U, Cc, V, B, T = 52, 53, 50_000, 16384, 50
+    D = 64 if kind == "youtube" else 16
+    om, m, E, ub, items, uf, cf, y = _setup(oracle, kind, 0, U, T, D, Cc, V, B, seed=91)
+    rng = np.random.default_rng(92)
+    ub[:] = ((rng.zipf(1.05, size=ub.shape) - 1) % V).astype(np.int32)
+    ub[rng.random(ub.shape) < 0.2] = -1
+    lr = 0.5
+    loss, dE = om.emb_loss_grad(E.astype(np.float64), ub, items, uf, cf, y, B=B)
+    tab = gm.EmbeddingTable(E)
+    ds = gm.Dataset.ids(ub, items, uf, cf, y)
+    m.set_embedding_training(lr)
+    costs = gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0), 1, emb=tab, want_costs=True)
+    capi.sync()
+    got = tab.get_rows()
+    upd = np.abs(lr * dE).max()
+    assert upd > 1e-6
+    assert np.abs(got - (E.astype(np.float64) - lr * dE)).max() <= 1e-4 * upd + 1e-7
+    assert abs(float(costs[0]) - loss) < 1e-5 * max(1.0, abs(loss))
+    touched = np.zeros(V, bool)
+    touched[ub[(ub >= 0) & (ub < V)]] = True
+    touched[items[items >= 0]] = True
+    assert np.array_equal(got[~touched], E[~touched])
+
+
 def test_one_step_matches_oracle_large_vocabulary(oracle):
     """same check as test_one_step_matches_oracle with V >> B (T+1): the in-place path for single ids is on"""
     from goctr_amd import capi, model as gm
