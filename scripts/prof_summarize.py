@@ -69,7 +69,9 @@ def trace_table(path):
     for r in csv.DictReader(open(path)):
         s = symbol(r["Kernel_Name"])
         if s:
-            by[(s, int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            # (the counter CSVs report the TOTAL grid; the trace reports it per dimension)
+            grid = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+            by[(s, grid, int(r["Workgroup_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return by
 
 
