@@ -704,6 +704,30 @@ def main():
             out["kernels"] = table
     rdv.barrier()
 
+    if world > 1:
+        # Data-parallel replicas must stay BIT-identical (same all-reduced gradient, same Adam; with --train-emb the same
+        # integer row sums from the owners): every rank checksums its weights (and the first 65 536 rows of its table -- the
+        # Zipf-hot ids are the low ones) and rank 0 compares.  This is the only place a W > 1 run of the device code is ever
+        # checked: the GPU test boxes have one GPU.
+        import ctypes as C
+        import zlib
+        capi.sync()
+        crc = 0
+        for tid, shape in ((0, (c["U"] + 2 * c["D"] + c["C"], c["H1"])), (1, (c["H1"], c["H2"])), (2, (c["H2"], 1))) + \
+                (((3, (1, c["T"])),) if c["KIND"] == "din" else ()):
+            w = np.zeros(shape, np.float32)
+            capi.check(L.goctr_model_get_weights(m._h, C.c_int(tid), capi.ptr(w, C.c_float), C.c_size_t(w.size)))
+            crc = zlib.crc32(w.tobytes(), crc)
+        if args.train_emb > 0:
+            nrow = min(c["V"], 65536)
+            rows = np.zeros((nrow, c["D"]), np.float32)
+            capi.check(L.goctr_emb_get_rows(tab._h, C.c_int64(0), C.c_int64(nrow), capi.ptr(rows, C.c_float)))
+            crc = zlib.crc32(rows.tobytes(), crc)
+        crcs = rdv.allgather(int(crc))
+        out["replicas_bit_identical"] = len(set(crcs)) == 1
+        if rank == 0 and not out["replicas_bit_identical"]:
+            print(f"bench.py: the {world} data-parallel replicas DIVERGED (weight / table checksums {crcs})", file=sys.stderr)
+
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
@@ -712,6 +736,8 @@ def main():
     if world > 1:
         L.goctr_comm_destroy()
     rdv.close()
+    if world > 1 and not out.get("replicas_bit_identical", True):
+        sys.exit(3)
 
 
 if __name__ == "__main__":
