@@ -150,6 +150,7 @@ struct goctr_model {
   long long emb_V = 0; int emb_B = 0, emb_world = 0; bool emb_comm = false;
   DevBuf<float> dpv, W0pvT;
   bool w0pv_live = false;         // W0pvT holds the current W0[U:U+2D,:]^T and the Adam kernels keep it current
+  bool dpv_from_chain = false;    // the step's chain launch wrote dpv itself (launch_chain_x3): no dpv GEMM in this step
   DevBuf<unsigned int> emb_mark, emb_rank, emb_tiles;
   DevBuf<unsigned long long> emb_total;
   DevBuf<long long> emb_accum;
@@ -559,6 +560,8 @@ void launch_chain_x3_n(const ChainX3Args& a, dim3 grid, hipStream_t s, bool fwd)
   else hipLaunchKernelGGL((ctr_chain_x3_kernel<NCH0, false>), grid, dim3(512), chain_x3_lds_bytes<NCH0>(), s, a);
 }
 
+bool emb_plan_active(const goctr_model* m) { return m->emb_lr > 0.f && m->plan.valid; }
+
 int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st, const FwdBufs& fb) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
@@ -573,6 +576,11 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   a.d1 = DropCfg{drop && o.p1 > 0 ? 2 : 0, o.p1, nullptr, c.H2, o.seed, 1u, row_off};
   a.st = st; a.Y = src.Y; a.rows = src.rows; a.inv_bglobal = 1.0f / (float)(B * e.world);
   a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;   // (forward only: none of these is touched)
+  // trainable embeddings, DIN, 2 D <= 32: the 32-wide dp product of this kernel also yields d cost / d candidate-item segment
+  // (IMG3 holds W0[U : U+2D]^T) -- it writes dpv = [dp | dvh] itself and the step needs no GEMM launch for it (6.9 us at cfg3)
+  m->dpv_from_chain = o.train && emb_plan_active(m) && src.id_mode && c.kind == GOCTR_DIN && 2 * c.D <= 32 &&
+                      env_int("GOCTR_EMB_DPV_CHAIN", 1) != 0;
+  if (m->dpv_from_chain) { a.dp = m->dpv.p; a.Dp = round_up(2 * c.D, 16); }
   a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
   static DevBuf<unsigned long long> dbgbuf;
   const bool dbg = o.train && env_int("GOCTR_CHAIN_DBG", 0) != 0;
@@ -711,6 +719,7 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
     const AttnArgs aa = make_attn_args(m, src, B, st, fb);
     if (launch_attn_fwd(aa)) return -1;
   }
+  if (o.train) m->dpv_from_chain = false;                      // (launch_chain_x3 sets it when it writes dpv itself)
   if (chain_ok(m)) return launch_chain(m, src, B, o, st, fb);  // layers + (when training) backward-data, fused
 
   const int bglobal = B * e.world;
@@ -971,7 +980,6 @@ bool emb_slot_vec4(const goctr_model* m) {
 
 int launch_emb_exchange(goctr_model* m, const EmbTrainArgs& a);
 
-bool emb_plan_active(const goctr_model* m) { return m->emb_lr > 0.f && m->plan.valid; }
 
 // First half of the plan path, in attn_bwd's place in the backward: dpv = dz0 . W0[U:U+2D,:]^T and (DIN) the per-pair
 // coefficients -- the kernel gathers every behaviour row and forms dp . x_t like attn_bwd_kernel, so it writes attn_bwd's
@@ -980,8 +988,10 @@ int launch_emb_plan_early(goctr_model* m, const RowSource& src, int B, const Ste
   const goctr_ctr_cfg& c = m->cfg;
   hipStream_t s = engine().stream;
   const int Np = round_up(2 * c.D, 16);
-  EpiStore sp{m->dpv.p, Np};
-  if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
+  if (!m->dpv_from_chain) {
+    EpiStore sp{m->dpv.p, Np};
+    if (launch_nn(GOCTR_K_EMB_TRAIN, m->dz0.p, m->H1p, m->W0pvT.p, Np, B, m->H1p, Np, sp)) return -1;
+  }
   if (c.kind != GOCTR_DIN) return 0;
   const int mode = c.att == GOCTR_ATT_COSINE ? 1 : 2;
   ProfScope ps(GOCTR_K_ATTN_BWD);

@@ -7,7 +7,7 @@
 //   IMG0  W0   for F0:  [H1 tile t][k chunk c][plane][lane = 32 kg + m][8]   = W0[16c + 8kg + s][32t + m]
 //   IMG1  W1   for F1:  [H1 chunk cc][H2 tile u][plane][lane = 32 kg + m][8] = W1[perm(cc, kg, s)][32u + m]
 //   IMG2  W1^T for B0:  [H1 tile t][H2 chunk c][plane][lane = 32 kg + m][8]  = W1[32t + m][16c + 8kg + s]
-//   IMG3  W0[U:U+D]^T for dp: [H1 chunk cc][plane][lane = 32 kg + d][8]      = W0[U + d][perm(cc, kg, s)]
+//   IMG3  W0[U:U+D]^T for dp: [H1 chunk cc][plane][lane = 32 kg + d][8]      = W0[U + d][perm(cc, kg, s)]   (d < 2 D when 2 D <= 32)
 // perm(cc, kg, s) = the H1 feature a lane holds at accumulator position of the 32x32 MFMA result:
 //   32 (cc / 2) + 8 (2 (cc % 2) + s / 4) + 4 kg + s % 4.
 #pragma once
@@ -77,7 +77,11 @@ __device__ __forceinline__ void cx_scatter_weight(const CxImages& im, float w, i
     cx_split1(w, pl[0], pl[1], pl[2]);
 #pragma unroll
     for (int p = 0; p < 3; ++p) im.img0[cx_img0_index(k, f1, im.nch0, p)] = pl[p];
-    if (k >= U && k < U + D && D <= 32) {
+    // rows U .. U+D-1 give dp (d cost / d pooled); when 2 D <= 32 the 32-wide product has room for rows U+D .. U+2D-1 as well:
+    // d cost / d candidate-item segment, which the trainable-embedding path needs (emb_train.h: dpv = [dp | dvh]) and used
+    // to get from a GEMM launch of its own.  The frozen path stores only the first Dp columns.
+    const int Dx = 2 * D <= 32 ? 2 * D : D;
+    if (k >= U && k < U + Dx && D <= 32) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) im.img3[cx_img3_index(f1, k - U, p)] = pl[p];
     }
