@@ -437,8 +437,27 @@ int launch_attn_fwd(const AttnArgs& a) {
     int L = 1;
     while (L < groups) L *= 2;
     if (!vec4 && L < 8) L = 8;
-    snprintf(sym, sizeof sym, "attn_fwd_kernel<%d,%d,%d>", vec4 ? 4 : 1, std::min(L, 64), (fast && groups <= 16) ? fast : 0);
+    if (a.src.k_users) snprintf(sym, sizeof sym, "attn_fwd_keys_kernel<%d,%d>", std::min(L, 64), fast);
+    else snprintf(sym, sizeof sym, "attn_fwd_kernel<%d,%d,%d>", vec4 ? 4 : 1, std::min(L, 64), (fast && groups <= 16) ? fast : 0);
     prof_note_kernel(GOCTR_K_ATTN_FWD, sym);
+  }
+  if (a.src.k_users) {
+    // serving pass in key mode (serve_keys_pass): only the compile-time shapes have a key variant -- the caller checked
+    if (!(fast && groups <= 16)) { set_error("attn_fwd: key mode needs an id-mode fast shape"); return -1; }
+#define GOCTR_ATTN_KEYS(L)                                                                         \
+  do {                                                                                             \
+    if (fast == 1) hipLaunchKernelGGL((attn_fwd_keys_kernel<L, 1>), grid, blk, 0, st, a);          \
+    else if (fast == 2) hipLaunchKernelGGL((attn_fwd_keys_kernel<L, 2>), grid, blk, 0, st, a);     \
+    else hipLaunchKernelGGL((attn_fwd_keys_kernel<L, 3>), grid, blk, 0, st, a);                    \
+  } while (0)
+    if (groups == 1) GOCTR_ATTN_KEYS(1);
+    else if (groups == 2) GOCTR_ATTN_KEYS(2);
+    else if (groups == 4) GOCTR_ATTN_KEYS(4);
+    else if (groups == 8) GOCTR_ATTN_KEYS(8);
+    else GOCTR_ATTN_KEYS(16);
+#undef GOCTR_ATTN_KEYS
+    GOCTR_HIP(hipGetLastError());
+    return 0;
   }
 #define GOCTR_ATTN_FWD(V, L) hipLaunchKernelGGL((attn_fwd_kernel<V, L, 0>), grid, blk, 0, st, a)
 #define GOCTR_ATTN_FWD_FAST(L)                                                                     \
@@ -2553,15 +2572,27 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   unsigned char* dfail = reinterpret_cast<unsigned char*>(out_base + 4 * Br);
   const goctr_ubcache* c = r->ub;
   StreamScope on_slot(s->stream);
-  hipLaunchKernelGGL(assemble_keys_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, s->stream,
-                     c ? c->off.p : (const long long*)nullptr, c ? c->items.p : (const int32_t*)nullptr,
-                     c ? c->ts.p : (const long long*)nullptr, (long long)r->n_users, r->user_table.p, r->U, r->item_table.p,
-                     (long long)r->n_items, r->C, dus, dit, dts, (long long)N, T, s->ub_ids.p, s->ufeat.p, s->cfeat.p,
-                     s->item_ids.p, dfail);
-  GOCTR_HIP(hipGetLastError());
   RowSource src{};
   src.rows = N; src.id_mode = 1; src.emb = r->emb->rows.p; src.V = r->emb->V;
-  src.ub_ids = s->ub_ids.p; src.item_ids = s->item_ids.p; src.ufeat = s->ufeat.p; src.cfeat = s->cfeat.p;
+  // Embedding widths with a compile-time attention variant (D = 4 .. 64, a power of two) look the keys up INSIDE attn_fwd
+  // (attn_fwd_keys_kernel): a pass is two launches, and the assembled rows (behaviour ids, feature rows) never exist in
+  // HBM.  Other widths, or GOCTR_SERVE_FUSE=0, assemble first.
+  const int D = m->cfg.D;
+  static const bool fuse_on = env_int("GOCTR_SERVE_FUSE", 1) != 0;
+  const bool fuse = fuse_on && D % 4 == 0 && D <= 64 && ((D / 4) & (D / 4 - 1)) == 0;
+  if (fuse) {
+    src.k_users = dus; src.k_items = dit; src.k_ts = dts; src.k_failed = dfail;
+    src.ub_off = c ? c->off.p : nullptr; src.ub_items = c ? c->items.p : nullptr; src.ub_ts = c ? c->ts.p : nullptr;
+    src.user_table = r->user_table.p; src.item_table = r->item_table.p; src.n_users = r->n_users; src.n_items = r->n_items;
+  } else {
+    hipLaunchKernelGGL(assemble_keys_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, s->stream,
+                       c ? c->off.p : (const long long*)nullptr, c ? c->items.p : (const int32_t*)nullptr,
+                       c ? c->ts.p : (const long long*)nullptr, (long long)r->n_users, r->user_table.p, r->U, r->item_table.p,
+                       (long long)r->n_items, r->C, dus, dit, dts, (long long)N, T, s->ub_ids.p, s->ufeat.p, s->cfeat.p,
+                       s->item_ids.p, dfail);
+    GOCTR_HIP(hipGetLastError());
+    src.ub_ids = s->ub_ids.p; src.item_ids = s->item_ids.p; src.ufeat = s->ufeat.p; src.cfeat = s->cfeat.p;
+  }
   FwdBufs fb = s->ws.bufs();
   fb.yhat = dscore;
   StepOpts op;

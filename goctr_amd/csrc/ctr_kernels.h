@@ -79,6 +79,13 @@ struct RowSource {
   const float* Y;          // may be null (predict)
   long long rows;
   int id_mode;
+  // key mode (serving passes, attn_fwd_kernel<..., KEYS = true>): the sample IS a (user, item, timestamp) key; behaviour ids,
+  // side-feature rows and the candidate id are looked up where attn_fwd needs them -- recommend/rcmd.go:462-536
+  // GetSampleVector + feature/ubcache/cache.go:71-94 TimeSeq.Filter inside the attention kernel, no assembled rows in HBM
+  const int32_t* k_users; const int32_t* k_items; const long long* k_ts;
+  const long long* ub_off; const int32_t* ub_items; const long long* ub_ts;     // behaviour cache CSR (ub_off null: none)
+  const float* user_table; const float* item_table; long long n_users, n_items;
+  unsigned char* k_failed;                                                        // [rows] 1 = key without features (scored as the zero row)
 };
 
 struct DropCfg {
@@ -170,7 +177,7 @@ __device__ __forceinline__ void load_row_nn(const float* row, int d0, int D, boo
 // the block that owns att0 publishes `expect` in *flag (device scope) once its stores are out (null: plain attn_fwd)
 struct RaCtx { const unsigned int* flag; unsigned int expect; const float* att0; };
 
-template <int VEC, int LPR, int FAST>
+template <int VEC, int LPR, int FAST, bool KEYS = false>
 __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long long batch_idx, const float* att0w,
                                               const RaCtx* ra = nullptr) {
   const bool idm = FAST ? true : (bool)a.src.id_mode;
@@ -189,19 +196,62 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
   const int d0 = dl * VEC;
   const int D = a.D, T = a.T;
 
+  // key mode: the sample's key -> its user / item feature rows and the window of its behaviour sequence
+  const float* kurow = nullptr; const float* kirow = nullptr;     // feature rows (null: all-zero)
+  int kitem = -1;                                                  // candidate id (-1: failed key => zero row)
+  long long kb = 0, kcnt = 0;                                      // behaviour ids = ub_items[kb .. kb + kcnt)
+  if (KEYS && valid) {
+    // the key's three fields up front (they may sit in pinned HOST memory: one PCIe round trip, not three)
+    const int u = s.k_users[gr];
+    const int it = s.k_items[gr];
+    const long long mts = s.k_ts ? s.k_ts[gr] : 0;
+    const bool ok = u >= 0 && u < s.n_users && it >= 0 && it < s.n_items;     // rcmd.go:291-307: else the ALL-zero row
+    if (lane == 0 && s.k_failed) s.k_failed[gr] = ok ? 0 : 1;
+    if (ok) {
+      kurow = s.user_table + (long long)u * a.U; kirow = s.item_table + (long long)it * a.C; kitem = it;
+      const long long b0 = s.ub_off ? s.ub_off[u] : 0, len = s.ub_off ? s.ub_off[u + 1] - b0 : 0;
+      if (len > 0) {
+        // TimeSeq.Filter (cache.go:71-94): first i with ts[i] <= maxTs in the newest-first sequence; maxTs == 0: from the newest
+        long long lo = 0;
+        if (mts != 0) {
+          if (len <= 256) {
+            lo = len;
+            for (long long base = 0; base < len; base += 64) {
+              const long long i = base + lane;
+              const unsigned long long le = __ballot(i < len && s.ub_ts[b0 + i] <= mts);
+              if (le) { lo = base + (long long)__builtin_ctzll(le); break; }
+            }
+          } else {
+            long long hi = len;
+            while (lo < hi) {
+              const long long mid = (lo + hi) >> 1;
+              if (s.ub_ts[b0 + mid] <= mts) hi = mid; else lo = mid + 1;
+            }
+          }
+        }
+        kb = b0 + lo;
+        kcnt = len - lo < T ? len - lo : T;
+      }
+    }
+  }
   // user / context side features: issue the loads first so they overlap the gather chain
   float uside[2], cside[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int ju = lane + 64 * k;
-    uside[k] = (valid && ju < a.U) ? (idm ? s.ufeat[gr * a.U + ju] : s.X[gr * (long long)s.xcols + s.r_u + ju]) : 0.f;
-    cside[k] = (valid && ju < a.C) ? (idm ? s.cfeat[gr * a.C + ju] : s.X[gr * (long long)s.xcols + s.r_c + ju]) : 0.f;
+    if (KEYS) {
+      uside[k] = (kurow && ju < a.U) ? kurow[ju] : 0.f;
+      cside[k] = (kirow && ju < a.C) ? kirow[ju] : 0.f;
+    } else {
+      uside[k] = (valid && ju < a.U) ? (idm ? s.ufeat[gr * a.U + ju] : s.X[gr * (long long)s.xcols + s.r_u + ju]) : 0.f;
+      cside[k] = (valid && ju < a.C) ? (idm ? s.cfeat[gr * a.C + ju] : s.X[gr * (long long)s.xcols + s.r_c + ju]) : 0.f;
+    }
   }
   // candidate item embedding v
   const bool full = FAST ? true : D == LPR * VEC;   // every lane owns VEC in-range embedding columns (wave-uniform)
   float vv[VEC];
   if (idm) {
-    const int it = valid ? s.item_ids[gr] : -1;
+    const int it = KEYS ? kitem : (valid ? s.item_ids[gr] : -1);
     load_row_nn<VEC>(s.emb + (long long)((it >= 0 && it < s.V) ? it : s.V) * D, d0, D, full, vv);
   } else {
     load_row<VEC>(valid ? s.X + gr * (long long)s.xcols + s.r_v : nullptr, d0, D, vv);
@@ -221,7 +271,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
   constexpr int SLOTS = NPB * RPP;
   for (int tb0 = 0; tb0 < T; tb0 += 64) {
   int ids64 = -1;
-  if (idm && valid && tb0 + lane < T) ids64 = s.ub_ids[gr * T + tb0 + lane];
+  if (KEYS) { if (tb0 + lane < kcnt) ids64 = s.ub_items[kb + tb0 + lane]; }
+  else if (idm && valid && tb0 + lane < T) ids64 = s.ub_ids[gr * T + tb0 + lane];
   auto load_block = [&](int tbx, float (&xx)[NPB][VEC]) {
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
@@ -343,14 +394,19 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
     if (j < a.C) hrow[a.U + 2 * D + j] = cside[k];
   }
   for (int j = lane + 128; j < a.U; j += 64)   // (side blocks wider than 128 columns)
-    hrow[j] = valid ? (idm ? s.ufeat[gr * a.U + j] : s.X[gr * (long long)s.xcols + s.r_u + j]) : 0.f;
+    hrow[j] = KEYS ? (kurow ? kurow[j] : 0.f) : (valid ? (idm ? s.ufeat[gr * a.U + j] : s.X[gr * (long long)s.xcols + s.r_u + j]) : 0.f);
   for (int j = lane + 128; j < a.C; j += 64)
-    hrow[a.U + 2 * D + j] = valid ? (idm ? s.cfeat[gr * a.C + j] : s.X[gr * (long long)s.xcols + s.r_c + j]) : 0.f;
+    hrow[a.U + 2 * D + j] = KEYS ? (kirow ? kirow[j] : 0.f) : (valid ? (idm ? s.cfeat[gr * a.C + j] : s.X[gr * (long long)s.xcols + s.r_c + j]) : 0.f);
 }
 
 template <int VEC, int LPR, int FAST>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x, a.st->batch_idx, a.att0);
+}
+// serving passes: the rows come from (user, item, timestamp) keys (RowSource key mode) -- key assembly and attention in one launch
+template <int LPR, int FAST>
+__global__ __launch_bounds__(256) void attn_fwd_keys_kernel(AttnArgs a) {
+  attn_fwd_body<4, LPR, FAST, true>(a, (int)blockIdx.x, 0, a.att0);
 }
 
 // ---------------------------------------------------------------- attention backward (att0 grad)
