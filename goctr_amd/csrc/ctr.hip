@@ -150,6 +150,7 @@ struct goctr_model {
   long long emb_V = 0; int emb_B = 0, emb_world = 0; bool emb_comm = false;
   DevBuf<float> dpv, W0pvT;
   bool w0pv_live = false;         // W0pvT holds the current W0[U:U+2D,:]^T and the Adam kernels keep it current
+  bool attn_bwd_in_chain = false;  // launch_chain_x3 -> launch_backward: this step's chain launch wrote the att0 terms
   bool dpv_from_chain = false;    // the step's chain launch wrote dpv itself (launch_chain_x3): no dpv GEMM in this step
   DevBuf<unsigned int> emb_mark, emb_rank, emb_tiles;
   DevBuf<unsigned long long> emb_total;
@@ -600,6 +601,14 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   m->dpv_from_chain = o.train && emb_plan_active(m) && src.id_mode && c.kind == GOCTR_DIN && 2 * c.D <= 32 &&
                       env_int("GOCTR_EMB_DPV_CHAIN", 1) != 0;
   if (m->dpv_from_chain) { a.dp = m->dpv.p; a.Dp = round_up(2 * c.D, 16); }
+  // frozen embeddings, DIN, D = 16, T <= 64: the att0 gradient's per-sample terms come out of this kernel's tail
+  // (ChainX3Args::ab_*), launch_backward skips attn_bwd (GOCTR_CHAIN_ATTN_BWD=0: the separate kernel)
+  m->attn_bwd_in_chain = o.train && c.kind == GOCTR_DIN && src.id_mode && !emb_plan_active(m) && c.D == 16 && c.T <= 64 &&
+                         env_int("GOCTR_CHAIN_ATTN_BWD", 1) != 0;
+  if (m->attn_bwd_in_chain) {
+    a.ab_ids = src.ub_ids; a.ab_emb = src.emb; a.ab_V = src.V; a.ab_gate = fb.gate; a.ab_wgt = fb.wgt; a.ab_out = m->attp.p;
+    a.ab_T = c.T; a.ab_Tp = m->Tp;
+  }
   a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
   static DevBuf<unsigned long long> dbgbuf;
   const bool dbg = o.train && env_int("GOCTR_CHAIN_DBG", 0) != 0;
@@ -738,7 +747,7 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
     const AttnArgs aa = make_attn_args(m, src, B, st, fb);
     if (launch_attn_fwd(aa)) return -1;
   }
-  if (o.train) m->dpv_from_chain = false;                      // (launch_chain_x3 sets it when it writes dpv itself)
+  if (o.train) { m->dpv_from_chain = false; m->attn_bwd_in_chain = false; }   // (launch_chain_x3 sets them when it does the work itself)
   if (chain_ok(m)) return launch_chain(m, src, B, o, st, fb);  // layers + (when training) backward-data, fused
 
   const int bglobal = B * e.world;
@@ -1246,6 +1255,8 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     }
     if (emb_plan_active(m) && src.id_mode) {
       if (launch_emb_plan_early(m, src, B, st)) return -1;      // (does attn_bwd's job too)
+    } else if (fused && m->attn_bwd_in_chain) {
+      // (the chain kernel's tail wrote the terms, launch_chain_x3)
     } else {
       AttnBwdArgs ab{};
       ab.src = src; ab.st = st; ab.B = B; ab.T = c.T; ab.D = c.D; ab.Dp = m->Dp; ab.Tp = m->Tp;

@@ -51,6 +51,12 @@ struct ChainX3Args {
   const float* Y; long long rows; float inv_bglobal;
   float* A0; float* A1; float* dz0; float* dz1; float* dz2; float* dp; float* yhat; float* lossrow;
   unsigned long long* dbg;
+  // Attention backward inside this kernel (DIN, frozen embeddings, id mode, D == 16, T <= 64; ab_ids == null: the separate
+  // attn_bwd_kernel does it).  The per-sample terms of the att0 gradient need dp -- which this kernel ends with -- and the
+  // behaviour rows again; ids, gates and rows are requested while B0 / the dp product run, so the launch that used to
+  // follow (6.0 us at cfg3: 410 k row gathers behind a kernel boundary) becomes ~50 instructions per sample at the tail.
+  const int32_t* ab_ids; const float* ab_emb; long long ab_V; const float* ab_gate; const float* ab_wgt; float* ab_out;
+  int ab_T, ab_Tp;
 };
 
 constexpr int CX_NSTAMP = 16;
@@ -120,6 +126,45 @@ struct CxDrop {
   __device__ __forceinline__ float factor(int slot) const { return (bits >> slot) & 1u ? kv : 0.0f; }
 };
 
+
+// Attention backward inside the chain kernel (see ChainX3Args::ab_*): wavefront w finishes samples 4 w .. 4 w + 3 of the
+// tile, one at a time in attn_bwd_kernel<4, 4, .>'s lane layout (lane = 4 rl + dl: slot 16 p + rl, embedding columns
+// 4 dl .. 4 dl + 3).  cx_ab_ids: the slot ids, gates and similarity weights of its four samples, slot = lane;
+// cx_ab_gather: the behaviour rows of the four samples, 16 x 16 bytes per lane in flight under the products that follow.
+template <class Args>
+__device__ __forceinline__ void cx_ab_ids(const Args& a, int w, int lane, int (&abid)[4], float (&abg)[4], float (&abw)[4]) {
+  const long long b0 = a.st->batch_idx * (long long)a.B;
+  const int lc = lane < a.ab_T ? lane : a.ab_T - 1;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    // unconditional loads from clamped addresses, selects afterwards: a predicated load is a branch, and branches up here
+    // split the scheduling region the first operand loads are issued from
+    const int b = blockIdx.x * 32 + 4 * w + s;
+    const int bc = b < a.B ? b : a.B - 1;
+    const long long gr = b0 + bc < a.rows ? b0 + bc : a.rows - 1;
+    const int id = a.ab_ids[gr * a.ab_T + lc];
+    const float g = a.ab_gate[(size_t)bc * a.ab_T + lc], wv = a.ab_wgt[(size_t)bc * a.ab_T + lc];
+    const bool in = b < a.B && lane < a.ab_T;
+    // missing / out-of-range ids, slots past T and rows past the dataset's end read the all-zero row V (like attn_bwd_kernel)
+    abid[s] = (in && b0 + b < a.rows && id >= 0 && id < a.ab_V) ? id : (int)a.ab_V;
+    abg[s] = in ? g : 0.f;
+    abw[s] = in ? wv : 0.f;
+  }
+}
+template <class Args>
+__device__ __forceinline__ void cx_ab_gather(const Args& a, const int (&abid)[4], int lane, float (&abx)[4][4][4]) {
+  const int rl = lane >> 2, dl = lane & 3;
+  const float* const base = a.ab_emb + 4 * dl;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int id = __shfl(abid[s], 16 * p + rl, 64);
+      const float4 t4 = *reinterpret_cast<const float4*>(base + (size_t)(unsigned)id * 16);
+      abx[s][p][0] = t4.x; abx[s][p][1] = t4.y; abx[s][p][2] = t4.z; abx[s][p][3] = t4.w;
+    }
+}
+
 // FWD: forward only (predict at launch sizes that give every CU a 32-row tile: the products and epilogues up to the output
 // unit, no activations or deltas stored, no backward operands requested)
 template <int NCH0, bool FWD = false>
@@ -181,6 +226,8 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     const long long gr = a.st->batch_idx * (long long)a.B + row;
     y = (a.Y && vrow && gr < a.rows) ? a.Y[gr] : 0.f;
   }
+  const bool ab = !FWD && din && a.ab_ids != nullptr;
+  int abid[4] = {-1, -1, -1, -1}; float abg[4] = {0.f, 0.f, 0.f, 0.f}, abw[4] = {0.f, 0.f, 0.f, 0.f};
   // layer-1 columns this wavefront finishes after the exchange: group (u = w / 4, g = w % 4) and, for wavefronts 0..3,
   // (u = 2, g = w):  f = 32 u + 8 g + 4 h + r
   const int fA = 32 * (w >> 2) + 8 * (w & 3) + 4 * h, fB = 64 + 8 * (w & 3) + 4 * h;
@@ -400,6 +447,9 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) ra3[j][p] = *(g3 + (size_t)((2 * tt + j) * 3 + p) * 64);
   }
+  // (measured: requesting the ids at the kernel's start and the rows before B0 is no faster -- 48.9 vs 49.1 us per step --
+  // and costs 28 more registers: the tail's price is the 128 KB gather burst per CU, not its latency)
+  if (ab) cx_ab_ids(a, w, lane, abid, abg, abw);
   __syncthreads();                                            // (4) dz1 image complete
   stamp(6);
 
@@ -416,6 +466,8 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra2[c][p]);
     CX_MMA6(ahb, acb, af, bf);
   }
+  float abx[4][4][4];
+  if (ab) cx_ab_gather(a, abid, lane, abx);
   stamp(7);
   float dzv[16];
 #pragma unroll
@@ -468,6 +520,37 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
       for (int ws = 0; ws < CX_NT0; ++ws) z += *reinterpret_cast<const cx_f4*>(xch + ((size_t)(ws * 4 + w) * 64 + lane) * 4);
       if (vrow) *reinterpret_cast<cx_f4*>(a.dp + (size_t)row * a.Dp + d0) = z;
+      if (ab && d0 < 16) {
+        // dp / T once per element here (attn_bwd_kernel's first step), not once per consumer lane
+        const float Tf = (float)a.ab_T;
+        *reinterpret_cast<cx_f4*>(reinterpret_cast<float*>(h0img) + n * 16 + d0) = cx_f4{z[0] / Tf, z[1] / Tf, z[2] / Tf, z[3] / Tf};   // (h0 image: free since F0)
+      }
+    }
+  }
+  if (ab) {
+    __syncthreads();                                          // (6) the tile's dp rows visible
+    const float* dpl = reinterpret_cast<const float*>(h0img);
+    const int dl = lane & 3, T = a.ab_T;
+    const int src = (lane & 15) * 4, pw = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int b = blockIdx.x * 32 + 4 * w + s;
+      if (b >= a.B) break;
+      // same arithmetic, in the same order, as attn_bwd_kernel (ctr_kernels.h): the terms are bit-identical
+      const cx_f4 dpt = *reinterpret_cast<const cx_f4*>(dpl + (4 * w + s) * 16 + 4 * dl);
+      float term = 0.f;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        float dg = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dg += dpt[e] * abx[s][p][e];
+        dg = group_sum<4>(dg);
+        const float dgs = __shfl(dg, src, 64);
+        if (pw == p) term = dgs;
+      }
+      float* out = a.ab_out + (size_t)b * a.ab_Tp;
+      if (lane < T) out[lane] = term * (abg[s] * (1.0f - abg[s])) * abw[s];
+      for (int t = T + lane; t < a.ab_Tp; t += 64) out[t] = 0.f;
     }
   }
   stamp(9);

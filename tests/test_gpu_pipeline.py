@@ -83,7 +83,7 @@ def test_cfg4_youtube_6_pipelined_graph_steps_vs_oracle(oracle):
     _free_running_steps_vs_oracle(oracle, 1, 52, 50, 64, 53, 10_000_000, 16384, 6, 301, 0.003)
 
 
-@pytest.mark.parametrize("knob", ["GOCTR_PIPELINE", "GOCTR_GRAPH_STEPS", "GOCTR_NO_GRAPH"])
+@pytest.mark.parametrize("knob", ["GOCTR_PIPELINE", "GOCTR_GRAPH_STEPS", "GOCTR_NO_GRAPH", "GOCTR_CHAIN_ATTN_BWD"])
 def test_id_mode_pipelined_graphs_equal_unpipelined_and_eager(knob):
     """id mode, B = 8192 (377 reduce blocks beside 2048 attention workgroups in the merged launch), dropout on, 39 steps =
     16 + 16 + 4 + 2 + 1: the default path and the path with the knob flipped must land on the same bits"""
@@ -94,7 +94,9 @@ def test_id_mode_pipelined_graphs_equal_unpipelined_and_eager(knob):
     tab = gm.EmbeddingTable(emb)
     ds = gm.Dataset.ids(ub, it, uf, cf, Y)
     res = []
-    flipped = {"GOCTR_PIPELINE": "0", "GOCTR_GRAPH_STEPS": "0", "GOCTR_NO_GRAPH": "1"}[knob]
+    # (GOCTR_CHAIN_ATTN_BWD=0: the att0 gradient's per-sample terms from the separate attn_bwd_kernel instead of the chain
+    # kernel's tail -- same arithmetic in the same order)
+    flipped = {"GOCTR_PIPELINE": "0", "GOCTR_GRAPH_STEPS": "0", "GOCTR_NO_GRAPH": "1", "GOCTR_CHAIN_ATTN_BWD": "0"}[knob]
     for val in (None, flipped):
         if val is not None:
             os.environ[knob] = val
