@@ -73,10 +73,19 @@ def init_weights(m, seed, scale=1.0):
     m.set_weights("mlp2", (rng.standard_normal((CFG["H2"], 1)) * scale).astype(np.float32))
 
 
-def kernel_work():
+def attn_bwd_in_chain(train_emb=False):
+    """DIN with frozen embeddings, D = 16, T <= 64: the chain launch ends with the att0 gradient's per-sample terms (what
+    attn_bwd_kernel did in a launch of its own; csrc/ctr_chain_x3.h ChainX3Args::ab_*, GOCTR_CHAIN_ATTN_BWD=0 switches back)"""
+    c = CFG
+    return (c["KIND"] == "din" and not train_emb and c["D"] == 16 and c["T"] <= 64
+            and os.environ.get("GOCTR_CHAIN_ATTN_BWD", "1") != "0")
+
+
+def kernel_work(train_emb=False):
     """algorithmic work per launch of each kernel family for cfg3 (DESIGN.md 'Kernels')"""
     c = CFG
     B, I, H1, H2, T, D = c["B"], c["U"] + 2 * c["D"] + c["C"], c["H1"], c["H2"], c["T"], c["D"]
+    ab_flops = 2.0 * B * T * D if attn_bwd_in_chain(train_emb) else 0.0
     gather_bytes = B * ((T + 1) * D * 4 + (T + 1) * 4)   # SURVEY 8(d): 3 264 B rows + 204 B ids per sample
     return {
         "attn_fwd": ("hbm", gather_bytes), "attn_bwd": ("hbm", gather_bytes),
@@ -87,18 +96,25 @@ def kernel_work():
         # "chain" = layers 0..2 forward + BCE + dz1 + dz0 + dp per 32-row tile
         "dW0": ("mfma", 2.0 * B * (I * H1 + H1 * H2 + H2 + T)),
         "dW1": ("mfma", 2.0 * B * H1 * H2), "dW2": ("mfma", 2.0 * B * H2),
-        "chain": ("mfma", 2.0 * B * (I * H1 + H1 * H2 + H2 + H2 + H2 * H1 + H1 * D)),
+        # (+ the T x D dot products of the attention backward where the chain launch ends with them)
+        "chain": ("mfma", 2.0 * B * (I * H1 + H1 * H2 + H2 + H2 + H2 * H1 + H1 * D) + ab_flops),
     }
 
 
-def chain_algorithmic_bytes():
+def chain_algorithmic_bytes(train_emb=False):
     """HBM bytes the fused chain launch must move per training launch: h0 in; A0, A1, dz0, dz1, dz2, (DIN: dp,) yhat, loss
-    terms out -- padded widths, as stored (3 020 B per row at cfg3)."""
+    terms out -- padded widths, as stored (3 020 B per row at cfg3).  Where the launch ends with the
+    attention backward: + the behaviour ids, gates and similarity weights in, the per-sample att0 terms out, and every
+    distinct table row once (the rows themselves are gathered B x T times, from L2 at cfg3's 1.7 MB table)."""
     c = CFG
     I = c["U"] + 2 * c["D"] + c["C"]
     Ip, H1p, H2p = -(-I // 16) * 16, 208, 80
     Dp = -(-c["D"] // 16) * 16 if c["KIND"] == "din" else 0
-    return 4 * c["B"] * (Ip + Dp + 2 * H1p + 2 * H2p + 16 + 3)
+    n = 4 * c["B"] * (Ip + Dp + 2 * H1p + 2 * H2p + 16 + 3)
+    if attn_bwd_in_chain(train_emb):
+        Tp = -(-c["T"] // 16) * 16
+        n += 4 * c["B"] * (3 * c["T"] + Tp) + 4 * c["D"] * min(c["B"] * c["T"], c["V"])
+    return n
 
 
 def roofline_obj(kind, work, avg_ms):
@@ -643,7 +659,7 @@ def main():
         if rank == 0:
             prof = capi.prof_get()
             capi.prof_enable(False)
-            work = kernel_work()
+            work = kernel_work(args.train_emb > 0)
             table = {k: {"avg_us": round(ms / n * 1e3, 2), "launches": n} for k, (ms, n) in prof.items() if n}
             wl = "youtube" if c["KIND"] == "youtube" else "din"
             if args.train_emb > 0:
@@ -667,7 +683,7 @@ def main():
             # launch shape of the timed launch (threads), where this harness knows it: the entry of the committed summary
             # must be the same symbol AND the same grid
             grid = {"chain": -(-c["B"] // 32) * 512, "attn_fwd": -(-c["B"] // 4) * 256}.get(dom)
-            alg = chain_algorithmic_bytes() if dom == "chain" else (w if kind == "hbm" else None)
+            alg = chain_algorithmic_bytes(args.train_emb > 0) if dom == "chain" else (w if kind == "hbm" else None)
             rl = with_traffic(rl, wl, "train", syms.get(dom), grid, dom_ms, alg)
             if dom == "emb_grad":
                 rl["algorithmic_GBs"] = rl["achieved"]
@@ -675,7 +691,11 @@ def main():
                     rl["achieved"] = rl.pop("hbm_side_GBs")
                     rl["frac"] = round(rl["achieved"] / HBM_PEAK_GBS, 4)
                 rl["note"] = "sparse scatter-add of the embedding-row gradients (DESIGN 4.10); priced on memory-side bytes"
-            rl["algorithmic_bytes"] = chain_algorithmic_bytes() if dom == "chain" else None
+            rl["algorithmic_bytes"] = chain_algorithmic_bytes(args.train_emb > 0) if dom == "chain" else None
+            if dom == "chain" and attn_bwd_in_chain(args.train_emb > 0):
+                rl["note"] = ("this launch also does the attention backward (round 2: a launch of its own, 6.0 us): 8192 x 50 row gathers and "
+                              "dot products at its tail add ~3.8 us to it and no MFMA work, so its fraction of the MFMA peak reads lower "
+                              "than the same products alone (0.37-0.39) while the step got 2.3 us shorter")
             rl["duration_basis"] = ("hipEvent pair around every launch of an eager re-run of the K steps (includes the launch gap: "
                                     "reads ~2-3 us above rocprofv3's kernel duration)")
             if rl.get("avg_us_rocprofv3") and kind == "mfma":      # the same work over rocprofv3's own average duration of that kernel (committed summary)

@@ -2589,8 +2589,7 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   // (attn_fwd_keys_kernel): a pass is two launches, and the assembled rows (behaviour ids, feature rows) never exist in
   // HBM.  Other widths, or GOCTR_SERVE_FUSE=0, assemble first.
   const int D = m->cfg.D;
-  static const bool fuse_on = env_int("GOCTR_SERVE_FUSE", 1) != 0;
-  const bool fuse = fuse_on && D % 4 == 0 && D <= 64 && ((D / 4) & (D / 4 - 1)) == 0;
+  const bool fuse = env_int("GOCTR_SERVE_FUSE", 1) != 0 && D % 4 == 0 && D <= 64 && ((D / 4) & (D / 4 - 1)) == 0;
   if (fuse) {
     src.k_users = dus; src.k_items = dit; src.k_ts = dts; src.k_failed = dfail;
     src.ub_off = c ? c->off.p : nullptr; src.ub_items = c ? c->items.p : nullptr; src.ub_ts = c ? c->ts.p : nullptr;

@@ -343,6 +343,45 @@ def test_id_mode_shape_sweep(oracle, kind, att, U, T, D, Cc):
         assert np.max(np.abs(dm.get_weights(name) - w)) <= 2e-4 * max(1.0, np.max(np.abs(w)))
 
 
+@pytest.mark.parametrize("att", [0, 1])
+@pytest.mark.parametrize("T,B,rows", [(50, 100, 350), (64, 64, 200), (7, 33, 99), (1, 32, 64)])
+def test_attention_backward_in_the_chain_kernel(oracle, att, T, B, rows):
+    """DIN, D = 16, frozen embeddings, id mode: the att0 gradient's per-sample terms come out of ctr_chain_x3_kernel's tail
+    (ChainX3Args::ab_*).  Batches that are not a multiple of the 32-row tile, a ragged last batch (rows past the dataset's
+    end), T = 64 (every slot lane busy) and T = 1, missing ids: att0 after 2 epochs against the oracle, and bit for bit
+    against the separate attn_bwd_kernel (GOCTR_CHAIN_ATTN_BWD=0)"""
+    from goctr_amd import capi, model as gm
+    U, D, Cc, V = 52, 16, 53, 300
+    rng = np.random.default_rng(1000 + 10 * T + att)
+    emb = (rng.standard_normal((V, D)) * 0.5).astype(np.float32)
+    ub = rng.integers(0, V, size=(rows, T)).astype(np.int32)
+    ub[rng.random((rows, T)) < 0.25] = -1
+    ub[0, :] = -1
+    it = rng.integers(0, V, size=rows).astype(np.int32)
+    uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+    Y = (rng.random(rows) < 0.5).astype(np.float32)
+    X = oracle.assemble_rows(emb, ub, it, uf, cf)
+    res = []
+    for knob in (None, "0"):
+        if knob is not None:
+            os.environ["GOCTR_CHAIN_ATTN_BWD"] = knob
+        try:
+            om, dm, si = pair(oracle, 0, U, T, D, Cc, np.random.default_rng(77), att=att, scale=0.15)
+            tab = gm.EmbeddingTable(emb)
+            ds = gm.Dataset.ids(ub, it, uf, cf, Y)
+            cfg = capi.default_train_cfg(batch=B, epochs=2, early_stop=0, dropout_mode=2, p0=0.01, p1=0.01, seed=9)
+            costs = gm.train_dataset(dm, ds, cfg, emb=tab)
+            res.append((costs, dm.get_weights("att0"), dm.get_weights("mlp0"), dm.get_weights("mlp1")))
+        finally:
+            os.environ.pop("GOCTR_CHAIN_ATTN_BWD", None)
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    ref = om.train(X, Y, batch=B, epochs=2, drop_mode=2, p0=0.01, p1=0.01, seed=9)
+    assert np.max(np.abs(res[0][0] - ref)) <= 5e-5
+    assert np.max(np.abs(res[0][1].ravel() - om.att0.ravel())) <= 2e-4
+    assert np.max(np.abs(res[0][2] - om.W0)) <= 2e-4 * max(1.0, np.max(np.abs(om.W0)))
+
+
 def test_graph_is_rebuilt_for_a_new_dataset_at_a_reused_address(oracle):
     """the cached step graph bakes in the dataset's device pointers and row count: it must be keyed on the dataset's
     generation, not on the host address of its handle (malloc readily returns a freed handle's address).  Train on

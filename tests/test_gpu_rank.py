@@ -8,7 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def build(oracle, rng, kind, n_users=40, n_items=300, n_emb_only=20, T=10, D=16, U=7, Cc=9):
+def build(oracle, rng, kind, n_users=40, n_items=300, n_emb_only=20, T=10, D=16, U=7, Cc=9, max_hist=30):
     from goctr_amd import model as gm, recommend as gr, ubcache
     # ids are arbitrary ints like in the reference (not dense): users 1000+3k, items 7+5k
     uids = [1000 + 3 * k for k in range(n_users)]
@@ -19,7 +19,7 @@ def build(oracle, rng, kind, n_users=40, n_items=300, n_emb_only=20, T=10, D=16,
     iemb = {i: (rng.standard_normal(D) * 0.3).astype(np.float32) for i in iids[: n_items - 15] + extra}   # 15 items lack one
     ubc = ubcache.NewUserBehaviorCache()
     for u in uids:
-        n = int(rng.integers(0, 30))
+        n = int(rng.integers(0, max_hist))
         ts = np.sort(rng.integers(1, 1000, size=n))[::-1]
         its = rng.choice(iids + extra + [999_999], size=n)           # incl. an item unknown to every table
         ubc.Set(u, ubcache.TimeSeq(ts.tolist(), [int(x) for x in its]))
@@ -74,6 +74,30 @@ def test_batch_predict_matches_oracle(oracle, kind):
     # failing keys score exactly like an all-zero row
     zero = om.predict(np.zeros((1, om.xcols), np.float32), 1)[0]
     assert np.all(np.abs(y[failed.astype(bool), 0] - zero) <= 1e-5)
+
+
+@pytest.mark.parametrize("kind,D,T,max_hist", [(0, 16, 10, 30), (0, 8, 70, 400), (1, 64, 20, 400), (0, 4, 5, 30), (0, 12, 10, 30)])
+def test_key_lookup_inside_the_attention_kernel_equals_assembled_rows(oracle, monkeypatch, kind, D, T, max_hist):
+    """serving passes look the keys up inside attn_fwd (attn_fwd_keys_kernel; embedding widths 4 .. 64, powers of two) or
+    assemble the rows first (assemble_keys_kernel: other widths, GOCTR_SERVE_FUSE=0): same scores bit for bit, both against
+    the oracle; histories longer than 256 entries take the bisection instead of the ballot search, T > 64 two id blocks"""
+    from goctr_amd import recommend as gr
+    rng = np.random.default_rng(500 + D + T)
+    rs, om, net, uids, iids, extra = build(oracle, rng, kind, T=T, D=D, max_hist=max_hist)
+    n = 700
+    keys = [gr.Sample(int(rng.choice(uids)), int(rng.choice(iids)), 0.0, int(rng.integers(0, 1100))) for _ in range(n)]
+    keys[3] = gr.Sample(4242, keys[3].ItemId, 0.0, 50)
+    keys[10] = gr.Sample(keys[10].UserId, extra[0], 0.0, 50)
+    keys[11] = gr.Sample(keys[11].UserId, keys[11].ItemId, 0.0, 0)
+    model = gr.Predictor(rs, net, predBatchSize=256)
+    ys = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("GOCTR_SERVE_FUSE", fuse)
+        ys.append(gr.BatchPredict(model, keys)[:, 0].copy())
+    assert np.array_equal(ys[0], ys[1])
+    ref, failed = oracle_scores(oracle, rs, om, keys, 256)
+    assert failed.sum() == 2
+    assert np.max(np.abs(ys[0] - ref)) <= 1e-5
 
 
 def test_rank_and_error_behaviour(oracle):
