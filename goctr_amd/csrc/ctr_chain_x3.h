@@ -129,10 +129,10 @@ struct CxDrop {
 
 // Attention backward inside the chain kernel (see ChainX3Args::ab_*): wavefront w finishes samples 4 w .. 4 w + 3 of the
 // tile, one at a time in attn_bwd_kernel<4, 4, .>'s lane layout (lane = 4 rl + dl: slot 16 p + rl, embedding columns
-// 4 dl .. 4 dl + 3).  cx_ab_ids: the slot ids, gates and similarity weights of its four samples, slot = lane;
-// cx_ab_gather: the behaviour rows of the four samples, 16 x 16 bytes per lane in flight under the products that follow.
+// 4 dl .. 4 dl + 3).  cx_ab_ids / cx_ab_gw: the slot ids / gates and similarity weights of its four samples, slot = lane;
+// cx_ab_gather_one: one pass (16 behaviour rows) of one sample, 16 bytes per lane in flight under the products that follow.
 template <class Args>
-__device__ __forceinline__ void cx_ab_ids(const Args& a, int w, int lane, int (&abid)[4], float (&abg)[4], float (&abw)[4]) {
+__device__ __forceinline__ void cx_ab_ids(const Args& a, int w, int lane, int (&abid)[4]) {
   const long long b0 = a.st->batch_idx * (long long)a.B;
   const int lc = lane < a.ab_T ? lane : a.ab_T - 1;
 #pragma unroll
@@ -143,26 +143,36 @@ __device__ __forceinline__ void cx_ab_ids(const Args& a, int w, int lane, int (&
     const int bc = b < a.B ? b : a.B - 1;
     const long long gr = b0 + bc < a.rows ? b0 + bc : a.rows - 1;
     const int id = a.ab_ids[gr * a.ab_T + lc];
+    // missing / out-of-range ids, slots past T and rows past the dataset's end read the all-zero row V (like attn_bwd_kernel)
+    abid[s] = (b < a.B && lane < a.ab_T && b0 + b < a.rows && id >= 0 && id < a.ab_V) ? id : (int)a.ab_V;
+  }
+}
+// (gates and similarity weights are only needed at the very end: requested late, 8 registers less through the products)
+template <class Args>
+__device__ __forceinline__ void cx_ab_gw(const Args& a, int w, int lane, float (&abg)[4], float (&abw)[4]) {
+  const int lc = lane < a.ab_T ? lane : a.ab_T - 1;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int b = blockIdx.x * 32 + 4 * w + s;
+    const int bc = b < a.B ? b : a.B - 1;
     const float g = a.ab_gate[(size_t)bc * a.ab_T + lc], wv = a.ab_wgt[(size_t)bc * a.ab_T + lc];
     const bool in = b < a.B && lane < a.ab_T;
-    // missing / out-of-range ids, slots past T and rows past the dataset's end read the all-zero row V (like attn_bwd_kernel)
-    abid[s] = (in && b0 + b < a.rows && id >= 0 && id < a.ab_V) ? id : (int)a.ab_V;
     abg[s] = in ? g : 0.f;
     abw[s] = in ? wv : 0.f;
   }
 }
+// Samples whose rows are requested inside F0's chunk loop, one or two gathers per chunk (the others: behind B0).  A gather
+// instruction occupies the CU's texture-address path for ~40 cycles (16 separate 64-byte rows), and the 128 of them a
+// tile needs stall their issuers when they come as one burst; under F0's MFMAs they are free, but each early sample holds
+// 16 registers through the products.  Measured per step (cfg3, same box, three runs each): none early 50.5 us, 2 early 50.4,
+// 3 early 49.8 (255 registers, none spilled); 4 early spills 40 registers and is 1 us slower than none.
+constexpr int CX_AB_EARLY = 3;
 template <class Args>
-__device__ __forceinline__ void cx_ab_gather(const Args& a, const int (&abid)[4], int lane, float (&abx)[4][4][4]) {
+__device__ __forceinline__ void cx_ab_gather_one(const Args& a, const int (&abid)[4], int lane, int s, int p, float (&abx)[4][4][4]) {
   const int rl = lane >> 2, dl = lane & 3;
-  const float* const base = a.ab_emb + 4 * dl;
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int id = __shfl(abid[s], 16 * p + rl, 64);
-      const float4 t4 = *reinterpret_cast<const float4*>(base + (size_t)(unsigned)id * 16);
-      abx[s][p][0] = t4.x; abx[s][p][1] = t4.y; abx[s][p][2] = t4.z; abx[s][p][3] = t4.w;
-    }
+  const int id = __shfl(abid[s], 16 * p + rl, 64);
+  const float4 t4 = *reinterpret_cast<const float4*>(a.ab_emb + 4 * dl + (size_t)(unsigned)id * 16);
+  abx[s][p][0] = t4.x; abx[s][p][1] = t4.y; abx[s][p][2] = t4.z; abx[s][p][3] = t4.w;
 }
 
 // FWD: forward only (predict at launch sizes that give every CU a 32-row tile: the products and epilogues up to the output
@@ -228,6 +238,8 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   }
   const bool ab = !FWD && din && a.ab_ids != nullptr;
   int abid[4] = {-1, -1, -1, -1}; float abg[4] = {0.f, 0.f, 0.f, 0.f}, abw[4] = {0.f, 0.f, 0.f, 0.f};
+  float abx[4][4][4];
+  if (ab) cx_ab_ids(a, w, lane, abid);
   // layer-1 columns this wavefront finishes after the exchange: group (u = w / 4, g = w % 4) and, for wavefronts 0..3,
   // (u = 2, g = w):  f = 32 u + 8 g + 4 h + r
   const int fA = 32 * (w >> 2) + 8 * (w & 3) + 4 * h, fB = 64 + 8 * (w & 3) + 4 * h;
@@ -294,6 +306,13 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     if (!(CX_EXP & 1) && c + CX_PF0 < NCH0) load0(c + CX_PF0, c % CX_PF0);
     else if (c + CX_PF0 - NCH0 < 2 * CX_NU) load1_piece(c + CX_PF0 - NCH0);
     CX_MMA6(ah0, ac0, af, bf);
+    if (ab) {
+      // a row gather or so per chunk, from the second chunk on (the ids are a dependent load behind the step state)
+      constexpr int NE = 4 * CX_AB_EARLY;
+      constexpr int C0 = NCH0 > 4 ? 1 : 0, PER = (NE + (NCH0 - C0) - 1) / (NCH0 - C0);
+#pragma unroll
+      for (int k = (c - C0) * PER; c >= C0 && k < (c - C0 + 1) * PER && k < NE; ++k) cx_ab_gather_one(a, abid, lane, k >> 2, k & 3, abx);
+    }
     if (!(CX_EXP & 2)) {
 #pragma unroll
       for (int e = c * QDRAW; e < (c + 1) * QDRAW && e < 24; ++e) draw_job(e);
@@ -447,9 +466,6 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) ra3[j][p] = *(g3 + (size_t)((2 * tt + j) * 3 + p) * 64);
   }
-  // (measured: requesting the ids at the kernel's start and the rows before B0 is no faster -- 48.9 vs 49.1 us per step --
-  // and costs 28 more registers: the tail's price is the 128 KB gather burst per CU, not its latency)
-  if (ab) cx_ab_ids(a, w, lane, abid, abg, abw);
   __syncthreads();                                            // (4) dz1 image complete
   stamp(6);
 
@@ -466,8 +482,11 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra2[c][p]);
     CX_MMA6(ahb, acb, af, bf);
   }
-  float abx[4][4][4];
-  if (ab) cx_ab_gather(a, abid, lane, abx);
+  if (ab) cx_ab_gw(a, w, lane, abg, abw);
+  if (ab) {      // the behaviour rows of the remaining samples, in flight under the epilogue and the dp product
+#pragma unroll
+    for (int k = 4 * CX_AB_EARLY; k < 16; ++k) cx_ab_gather_one(a, abid, lane, k >> 2, k & 3, abx);
+  }
   stamp(7);
   float dzv[16];
 #pragma unroll
@@ -532,13 +551,14 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     const float* dpl = reinterpret_cast<const float*>(h0img);
     const int dl = lane & 3, T = a.ab_T;
     const int src = (lane & 15) * 4, pw = lane >> 4;
+    // (the 16 (sample, pass) chains are independent and stay in one basic block: no early exit for rows past B, their
+    // stores are predicated instead)
+    float term[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int b = blockIdx.x * 32 + 4 * w + s;
-      if (b >= a.B) break;
       // same arithmetic, in the same order, as attn_bwd_kernel (ctr_kernels.h): the terms are bit-identical
       const cx_f4 dpt = *reinterpret_cast<const cx_f4*>(dpl + (4 * w + s) * 16 + 4 * dl);
-      float term = 0.f;
+      term[s] = 0.f;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         float dg = 0.f;
@@ -546,11 +566,17 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
         for (int e = 0; e < 4; ++e) dg += dpt[e] * abx[s][p][e];
         dg = group_sum<4>(dg);
         const float dgs = __shfl(dg, src, 64);
-        if (pw == p) term = dgs;
+        if (pw == p) term[s] = dgs;
       }
-      float* out = a.ab_out + (size_t)b * a.ab_Tp;
-      if (lane < T) out[lane] = term * (abg[s] * (1.0f - abg[s])) * abw[s];
-      for (int t = T + lane; t < a.ab_Tp; t += 64) out[t] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int b = blockIdx.x * 32 + 4 * w + s;
+      if (b < a.B) {
+        float* out = a.ab_out + (size_t)b * a.ab_Tp;
+        if (lane < T) out[lane] = term[s] * (abg[s] * (1.0f - abg[s])) * abw[s];
+        for (int t = T + lane; t < a.ab_Tp; t += 64) out[t] = 0.f;
+      }
     }
   }
   stamp(9);
