@@ -87,11 +87,12 @@ template <bool HOG> __device__ __forceinline__ void w2v_upd(double* p, double ol
 // One optimizer call (optimizer.go:52-91 / :107-129) for the lane that owns component l of the vectors:
 // ctx = that component of the input vector, tmp accumulates the component of the input's update.
 // `sum` is the inner-product reduction (sequential for the deterministic mode, butterfly for Hogwild).
-template <bool HOG, class Sum>
+// OPT: -1 = a.optimizer decides at run time; 0 / 1 = hierarchical softmax / negative sampling fixed at compile time
+template <bool HOG, int OPT = -1, class Sum>
 __device__ __forceinline__ void w2v_optim(const W2vDev& a, const double* tab, int id, double lr, double ctx, double& tmp,
                                           unsigned long long& next, bool act, int l, Sum sum) {
   const int dim = a.dim;
-  if (a.optimizer == 0) {
+  if (OPT < 0 ? a.optimizer == 0 : OPT == 0) {
     for (long long i = a.path_off[id]; i < a.path_off[id + 1]; ++i) {
       double* pvp = a.aux + (long long)a.path_nodes[i] * dim + l;
       const double pv = act ? w2v_ld<HOG>(pvp) : 0.0;
@@ -126,7 +127,7 @@ __device__ __forceinline__ void w2v_optim(const W2vDev& a, const double* tab, in
 // cbow.trainOne (model.go:96-148): aggregate the window's vectors, one optimizer call on the aggregate, add its
 // update to every window vector.  The window shrink is drawn twice (once in the aggregate pass, once in the update
 // pass — `dowith` calls NextRandom each time), so the two passes may cover different windows.
-template <bool HOG, class Sum>
+template <bool HOG, int OPT = -1, class Sum>
 __device__ __forceinline__ void w2v_cbow_one(const W2vDev& a, const double* tab, const int* doc, long long cmin, long long cmax,
                                              long long pos, double lr, unsigned long long& next, bool act, int l, Sum sum) {
   const int dim = a.dim, win = a.window;
@@ -138,7 +139,7 @@ __device__ __forceinline__ void w2v_cbow_one(const W2vDev& a, const double* tab,
     if (c < cmin || c >= cmax) continue;
     if (act) agg += w2v_ld<HOG>(a.param + (long long)doc[c] * dim + l);
   }
-  w2v_optim<HOG>(a, tab, doc[pos], lr, agg, tmp, next, act, l, sum);
+  w2v_optim<HOG, OPT>(a, tab, doc[pos], lr, agg, tmp, next, act, l, sum);
   del = lcg_next(next, win);
   for (int w = del; w < win * 2 + 1 - del; ++w) {
     if (w == win) continue;
@@ -262,10 +263,19 @@ struct HogHot {
   long long max_len;        // longest piece (uniform loop bound: every thread meets every barrier)
 };
 
-constexpr int HOG_PF = 4;   // node vectors of a Huffman path in flight per lane group
+#ifndef HOG_PF_N
+#define HOG_PF_N 4
+#endif
+constexpr int HOG_PF = HOG_PF_N;   // node vectors of a Huffman path in flight per lane group
+#ifndef HOG_WAVES_PER_SIMD
+#define HOG_WAVES_PER_SIMD 8
+#endif
 
-template <int GS>
-__global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, int streams, const long long* slice_idx, const long long* clip_lo,
+// MODEL (0 skip-gram, 1 cbow) and OPT (0 hierarchical softmax, 1 negative sampling) are compile-time: one kernel holding all
+// four combinations needs 103 registers, and the 64 that let two 1024-thread workgroups share a CU (8 wavefronts per SIMD
+// instead of 4 -- the walk is a chain of dependent loads, more lane groups in flight is what it wants) are then 38 spilled
+template <int GS, int MODEL, int OPT>
+__global__ __launch_bounds__(HOG_THREADS, HOG_WAVES_PER_SIMD) void w2v_hogwild_kernel(W2vDev a, int streams, const long long* slice_idx, const long long* clip_lo,
                                                                   const long long* clip_hi, HogHot hot) {
   __shared__ double tab[1000];
   __shared__ double locN[HOG_HOT_DOUBLES], baseN[HOG_HOT_DOUBLES], locW[HOG_HOT_DOUBLES], baseW[HOG_HOT_DOUBLES];
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, i
   unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * (unsigned long long)(g + 1);  // per-stream LCG
   const double lr0 = *a.lr;
   double lr = lr0;
-  long long cnt = 0;
+  long long est = 0, at = 0;
   const int* doc = a.doc + lo;
   const long long len = hi - lo;
   const long long cmin = clip_lo[gs] - lo, cmax = clip_hi[gs] - lo;   // window positions allowed, relative to this piece
@@ -336,14 +346,15 @@ __global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, i
   for (long long pos = 0; pos < hot.max_len; ++pos) {
     if (pos < len) {
       const int id = doc[pos];
-      if (a.model == 1) {
+      if (MODEL == 1) {
         if (!a.keep || a.keep[lo + pos])
-          w2v_cbow_one<true>(a, tab, doc, cmin, cmax, pos, lr, next, act, l, [&](double v) { return group_sum64<GS>(v); });
+          w2v_cbow_one<true, OPT>(a, tab, doc, cmin, cmax, pos, lr, next, act, l, [&](double v) { return group_sum64<GS>(v); });
       } else if (!a.keep || a.keep[lo + pos]) {
         const int del = lcg_next(next, win);
         // every pair of this position walks the SAME Huffman path (the centre word's): its first GS nodes are fetched once
-        const long long hp0 = a.optimizer == 0 ? a.path_off[id] : 0, hp1 = a.optimizer == 0 ? a.path_off[id + 1] : 0;
-        const int hn0 = (int)(hp1 - hp0 < GS ? hp1 - hp0 : GS);
+        // (32-bit path offsets: the host refuses trees with 2^31 path entries or more)
+        const int hp0 = OPT == 0 ? (int)a.path_off[id] : 0, hp1 = OPT == 0 ? (int)a.path_off[id + 1] : 0;
+        const int hn0 = hp1 - hp0 < GS ? hp1 - hp0 : GS;
         const int h_nd0 = l < hn0 ? a.path_nodes[hp0 + l] : 0;
         const int h_code0 = l < hn0 ? (int)a.path_codes[hp0 + l] : 0;
         // ... and the context vector of the NEXT pair is requested before the current pair's walk starts
@@ -369,15 +380,15 @@ __global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, i
             next_ctx(w_n + 1, w2, cid2, cslot2, v2);
             w_n = w2; cid_n = cid2; cslot_n = cslot2; ctx_n = v2;
           }
-          if (a.optimizer == 0) {
+          if (OPT == 0) {
             // The path is known up front: its node ids and codes arrive with ONE coalesced load per GS nodes (lane k of the
             // group holds node k, handed round by shuffle), and the node vectors are requested HOG_PF nodes ahead -- a
             // device-scope load of a cold node takes microseconds, and with one node in flight the walk ran at one such
             // latency per node.  (The nodes of a path are distinct, so reading ahead skips no update of this walk.)
-            const long long p0 = hp0, p1 = hp1;
+            const int p0 = hp0, p1 = hp1;
             const int gbase = (int)(threadIdx.x & 63) & ~(GS - 1);
-            for (long long c0 = p0; c0 < p1; c0 += GS) {
-              const int n = (int)(p1 - c0 < GS ? p1 - c0 : GS);
+            for (int c0 = p0; c0 < p1; c0 += GS) {
+              const int n = p1 - c0 < GS ? p1 - c0 : GS;
               const int my_nd = c0 == p0 ? h_nd0 : (l < n ? a.path_nodes[c0 + l] : 0);
               const int my_code = c0 == p0 ? h_code0 : (l < n ? (int)a.path_codes[c0 + l] : 0);
               double pf[HOG_PF];
@@ -430,11 +441,12 @@ __global__ __launch_bounds__(HOG_THREADS, 2) void w2v_hogwild_kernel(W2vDev a, i
           if (w_n < win * 2 + 1 - del && cid_n == cid && act) ctx_n = ld_word(cid_n, cslot_n);   // same word again: re-read
         }
       }
-      ++cnt;
-      // observer estimate: all streams advance at the same rate => global count ~= cnt * streams
-      const long long est = cnt * (long long)streams, prev = (cnt - 1) * (long long)streams;
-      if (est / a.update_lr_batch != prev / a.update_lr_batch) {
-        const long long at = est / a.update_lr_batch * a.update_lr_batch;
+      // observer estimate: all streams advance at the same rate => global count ~= positions so far * streams; the rate is
+      // re-derived whenever that estimate passes a multiple `at` of update_lr_batch (word2vec.go:223-233).  Kept as a
+      // running multiple: two 64-bit divisions per position were ~300 instructions and a dozen registers of this loop.
+      est += streams;
+      if (est >= at + a.update_lr_batch) {
+        do at += a.update_lr_batch; while (est >= at + a.update_lr_batch);
         if (lr < a.min_lr) lr = a.min_lr;
         else lr = a.init_lr * (1.0 - (double)at / (double)a.corpus_len);
       }
@@ -706,12 +718,18 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     hot.merge_scale = env_int_w2v("GOCTR_W2V_AVG", 1) ? 1.0 / (double)nwg : 1.0;
     hot.max_len = 0;
     for (int k = 0; k < streams; ++k) hot.max_len = std::max(hot.max_len, idx[k + 1] - idx[k]);
-#define GOCTR_HOG(GS) hipLaunchKernelGGL((w2v_hogwild_kernel<GS>), dim3((unsigned)cdiv(streams, HOG_THREADS / GS)), dim3(HOG_THREADS), 0, e.stream, a, streams, w->slice_idx.p, w->clip_lo.p, w->clip_hi.p, hot)
+#define GOCTR_HOG_MO(GS, M, O) hipLaunchKernelGGL((w2v_hogwild_kernel<GS, M, O>), dim3((unsigned)cdiv(streams, HOG_THREADS / GS)), dim3(HOG_THREADS), 0, e.stream, a, streams, w->slice_idx.p, w->clip_lo.p, w->clip_hi.p, hot)
+#define GOCTR_HOG(GS)                                                   \
+  do {                                                                  \
+    if (a.model == 1) { if (a.optimizer == 0) GOCTR_HOG_MO(GS, 1, 0); else GOCTR_HOG_MO(GS, 1, 1); } \
+    else { if (a.optimizer == 0) GOCTR_HOG_MO(GS, 0, 0); else GOCTR_HOG_MO(GS, 0, 1); }              \
+  } while (0)
     if (dim <= 8) GOCTR_HOG(8);
     else if (dim <= 16) GOCTR_HOG(16);
     else if (dim <= 32) GOCTR_HOG(32);
     else GOCTR_HOG(64);
 #undef GOCTR_HOG
+#undef GOCTR_HOG_MO
     GOCTR_HIP(hipGetLastError());
   }
   if (dp && exchange_deltas(w)) return -1;
@@ -740,6 +758,7 @@ int goctr_w2v_create(const goctr_w2v_cfg* cfg, int64_t V, const int64_t* counts,
   std::unique_ptr<goctr_w2v> w(new goctr_w2v);
   w->cfg = *cfg; w->V = V;
   build_huffman(counts, V, cfg->max_depth, w->h_off, w->h_nodes, w->h_codes);
+  GOCTR_CHECK(w->h_nodes.size() < ((size_t)1 << 31), "goctr_w2v: Huffman paths with 2^31 entries or more (the Hogwild walk indexes them with 32 bits)");
   w->h_counts.assign(counts, counts + V);
   w->aux_rows = cfg->optimizer == 0 ? std::max<int64_t>(V - 1, 1) : V;
   if (w->param.alloc((size_t)V * cfg->dim) || w->aux.alloc((size_t)w->aux_rows * cfg->dim)) return -1;
