@@ -247,6 +247,11 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
       cside[k] = (valid && ju < a.C) ? (idm ? s.cfeat[gr * a.C + ju] : s.X[gr * (long long)s.xcols + s.r_c + ju]) : 0.f;
     }
   }
+  // the first 64 behaviour ids: requested BEFORE the candidate row is fetched and squared (both depend on nothing but the
+  // sample's index; behind them the wave's chain was state -> item id -> item row -> ids -> rows, one latency longer)
+  int ids64_first = -1;
+  if (KEYS) { if (lane < kcnt) ids64_first = s.ub_items[kb + lane]; }
+  else if (idm && valid && lane < T) ids64_first = s.ub_ids[gr * T + lane];
   // candidate item embedding v
   const bool full = FAST ? true : D == LPR * VEC;   // every lane owns VEC in-range embedding columns (wave-uniform)
   float vv[VEC];
@@ -270,9 +275,12 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
   // was a chain of four (ids, rows) round trips before, now it is ids + rows + three overlapped row fetches.
   constexpr int SLOTS = NPB * RPP;
   for (int tb0 = 0; tb0 < T; tb0 += 64) {
-  int ids64 = -1;
-  if (KEYS) { if (tb0 + lane < kcnt) ids64 = s.ub_items[kb + tb0 + lane]; }
-  else if (idm && valid && tb0 + lane < T) ids64 = s.ub_ids[gr * T + tb0 + lane];
+  int ids64 = ids64_first;
+  if (tb0 > 0) {
+    ids64 = -1;
+    if (KEYS) { if (tb0 + lane < kcnt) ids64 = s.ub_items[kb + tb0 + lane]; }
+    else if (idm && valid && tb0 + lane < T) ids64 = s.ub_ids[gr * T + tb0 + lane];
+  }
   auto load_block = [&](int tbx, float (&xx)[NPB][VEC]) {
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {

@@ -456,6 +456,9 @@ __global__ __launch_bounds__(256) void emb_coef_kernel(EmbCoefArgs a) {
   float dpt[VEC], vv[VEC], dvh[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { dpt[e] = a.dpv[(size_t)b * a.ldp + d0 + e]; dvh[e] = a.dpv[(size_t)b * a.ldp + D + d0 + e]; }
+  // (the first block's slot ids before the candidate row: both hang on the sample's index alone -- one latency less in the chain)
+  int myid_first = -1;
+  if (valid && lane < SLOTS && lane < T) myid_first = s.ub_ids[gr * T + lane];
   const int item = valid ? s.item_ids[gr] : -1;
   const bool item_ok = item >= 0 && item < s.V;
   load_row_nn<VEC>(s.emb + (long long)(item_ok ? item : s.V) * D, d0, D, true, vv);
@@ -470,8 +473,11 @@ __global__ __launch_bounds__(256) void emb_coef_kernel(EmbCoefArgs a) {
   if (a.partial)
     for (int t = T + lane; t < a.Tp; t += 64) a.partial[(size_t)b * a.Tp + t] = 0.f;
   for (int tb = 0; tb < T; tb += SLOTS) {
-    int myid = -1;
-    if (valid && lane < SLOTS && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
+    int myid = myid_first;
+    if (tb > 0) {
+      myid = -1;
+      if (valid && lane < SLOTS && tb + lane < T) myid = s.ub_ids[gr * T + tb + lane];
+    }
     float gl = 0.f, al = 0.f;
     if (lane < SLOTS && tb + lane < T) { gl = a.gate[(size_t)b * T + tb + lane]; al = a.att0[tb + lane]; }
     float x[NPB][VEC];
