@@ -630,7 +630,8 @@ def main():
                                 "(GOCTR_CHAIN_X3=0 / GOCTR_TN_F32=1 / GOCTR_PREDICT_X3=0 select the f32 MFMA bodies)"),
                    "global_batch": c["B"] * world, "parallelism": f"dp{world}", "resident_rows_per_gpu": args.rows},
         "recommend_qps": round(qps, 1) if qps else None, "recommend_batch": c["PRED_B"],
-        "recommend_note": "PredBatchSize 4096 at the API; the engine scores 4 consecutive batches per launch, on the forward-only bf16-split chain (rows are scored "
+        "recommend_note": f"PredBatchSize {c['PRED_B']} at the API; the engine scores {os.environ.get('GOCTR_PRED_GROUP', '8')} consecutive batches per launch "
+                          "(at most 32768 rows), on the forward-only bf16-split chain, one persistent workgroup per CU over the launch's row tiles (rows are scored "
                           "independently; scores equal one-batch launches to float32 rounding; GOCTR_PRED_GROUP=1 for one batch per launch)",
         "rccl_world": rccl_world, "per_rank_ms_per_step": per_rank_ms,
     }

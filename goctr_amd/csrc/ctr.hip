@@ -418,8 +418,7 @@ int init_kernel_attrs() {
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
       allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(gemm_tn_multi_x3w_kernel<9, 5>) || allow_big_lds(gemm_tn_multi_x3w_kernel<8, 5>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
-      allow_big_lds(ctr_chain_x3_kernel<15>) || allow_big_lds(ctr_chain_x3_kernel<2, true>) || allow_big_lds(ctr_chain_x3_kernel<9, true>) ||
-      allow_big_lds(ctr_chain_x3_kernel<15, true>)) return -1;
+      allow_big_lds(ctr_chain_x3_kernel<15>) || chain_x3_fwd_attributes()) return -1;
   done = true;
   return 0;
 }
@@ -576,7 +575,7 @@ int rebuild_x3_images(goctr_model* m) {
 
 template <int NCH0>
 void launch_chain_x3_n(const ChainX3Args& a, dim3 grid, hipStream_t s, bool fwd) {
-  if (fwd) hipLaunchKernelGGL((ctr_chain_x3_kernel<NCH0, true>), grid, dim3(512), chain_x3_lds_bytes<NCH0>(), s, a);
+  if (fwd) launch_chain_x3_fwd(NCH0, a, grid, s);       // (ctr_fwd.hip: its own translation unit, see there)
   else hipLaunchKernelGGL((ctr_chain_x3_kernel<NCH0, false>), grid, dim3(512), chain_x3_lds_bytes<NCH0>(), s, a);
 }
 
@@ -611,11 +610,14 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   }
   a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
   static DevBuf<unsigned long long> dbgbuf;
-  const bool dbg = o.train && env_int("GOCTR_CHAIN_DBG", 0) != 0;
+  const bool dbg = env_int("GOCTR_CHAIN_DBG", 0) != 0 && (hipStream_t)e.active == e.stream;   // (not from a serving slot)
   if (dbg && !dbgbuf.p && dbgbuf.alloc(8 * CX_NSTAMP)) return -1;
   a.dbg = dbg ? dbgbuf.p : nullptr;
   ProfScope ps(GOCTR_K_CHAIN);
-  const dim3 grid((unsigned)cdiv(B, 32));
+  // (forward only: one persistent workgroup per CU walks the row tiles, GOCTR_FWD_PERSIST=0: one workgroup per tile)
+  const int ntiles = (int)cdiv(B, 32);
+  const bool persist = !o.train && e.compute_units > 0 && env_int("GOCTR_FWD_PERSIST", 1) != 0;
+  const dim3 grid((unsigned)(persist ? std::min(ntiles, e.compute_units) : ntiles));
   static const char* const kSym[3][2] = {{"ctr_chain_x3_kernel<2,false>", "ctr_chain_x3_kernel<2,true>"},
                                          {"ctr_chain_x3_kernel<9,false>", "ctr_chain_x3_kernel<9,true>"},
                                          {"ctr_chain_x3_kernel<15,false>", "ctr_chain_x3_kernel<15,true>"}};
@@ -629,6 +631,11 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   if (dbg) {
     unsigned long long h[CX_NSTAMP];
     if (dbgbuf.download(h, CX_NSTAMP)) return -1;
+    if (!o.train)
+      fprintf(stderr, "chain_x3 forward-only phases (s_memtime ticks): h0 split+barrier %lld | F0 %lld | epi0 %lld | F1 %lld | xchg barrier %lld | epi1+z2 %lld | total %lld\n",
+              (long long)(h[1] - h[0]), (long long)(h[2] - h[1]), (long long)(h[3] - h[2]), (long long)(h[4] - h[3]), (long long)(h[5] - h[4]),
+              (long long)(h[6] - h[5]), (long long)(h[6] - h[0]));
+    else
     fprintf(stderr, "chain_x3 phases (s_memtime ticks): h0 split+barrier %lld | F0(+epi tile0) %lld | F1(+epi tile1) %lld | xchg barrier %lld | epi1+z2+dz1 %lld | B0(+epi) %lld | dp %lld + xchg %lld | total %lld\n",
             (long long)(h[1] - h[0]), (long long)(h[2] - h[1]), (long long)(h[4] - h[2]), (long long)(h[5] - h[4]), (long long)(h[6] - h[5]),
             (long long)(h[7] - h[6]), (long long)(h[8] - h[7]), (long long)(h[9] > h[8] ? h[9] - h[8] : 0),
@@ -2345,8 +2352,10 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
   // float32 rounding, not bit for bit: 16 384 rows take the 32-row-tile forward kernel, 4096 rows the 16-row-tile one
   // (322 instead of 418 M rows/s if the latter scored the groups too), and the two add the partial products of layer 1 in
   // different orders (tests/test_gpu_ctr.py bounds the difference; both are inside the 1e-5 parity bar vs the oracle).
-  // Measured at DIN cfg3, PredBatchSize 4096: 250 / 351 / 416 / 444 M rows/s at G = 1 / 2 / 4 / 8 (GOCTR_PRED_GROUP).
-  int G = std::max(1, env_int("GOCTR_PRED_GROUP", 4));
+  // Measured at DIN cfg3, PredBatchSize 4096: 250 / 351 / 416 / 444 M rows/s at G = 1 / 2 / 4 / 8 (GOCTR_PRED_GROUP) with one
+  // workgroup per 32-row tile; since the forward-only kernel walks its tiles as one persistent workgroup per CU (round 3,
+  // ctr_chain_x3.h: a tile's start hides behind its predecessor's tail) 516 / 573 M at G = 4 / 8 -- default 8.
+  int G = std::max(1, env_int("GOCTR_PRED_GROUP", 8));
   while (G > 1 && (long long)batch * G > 32768) G /= 2;     // (a launch of 32 768 rows fills the chip; the workspace grows with G)
   // forward-only workspace of its own (h0, gates, yhat): the training workspace -- sized for the training batch, with its
   // slab buffers and captured step graphs -- is left alone
@@ -2367,10 +2376,13 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
     std::vector<int> grp((size_t)cnt, 1);
     for (int64_t k = 0; k < cnt;) {
       const long long b = (first_batch + k0 + k) % nb;
-      // a group: G whole batches that start at a multiple of G and do not run past the call or the dataset's last batch
-      const bool group = G > 1 && b % G == 0 && k + G <= cnt && b + G <= nb;
-      const int g = group ? G : 1;
-      hs[k] = StepState{0u, 0u, group ? b / G : b, nb};
+      // a group: g whole batches that start at a multiple of g and do not run past the call or the dataset's last batch;
+      // g = G, or the largest G / 2^j that still fits (the tail of a dataset keeps to the large-launch kernel as long as
+      // two batches are left)
+      int g = 1;
+      for (int c = G; c > 1; c /= 2)
+        if (b % c == 0 && k + c <= cnt && b + c <= nb) { g = c; break; }
+      hs[k] = StepState{0u, 0u, b / g, nb};
       grp[k] = g;
       for (int j = 1; j < g; ++j) { hs[k + j] = hs[k]; grp[k + j] = 0; }
       k += g;

@@ -177,6 +177,9 @@ __device__ __forceinline__ void cx_ab_gather_one(const Args& a, const int (&abid
 
 // FWD: forward only (predict at launch sizes that give every CU a 32-row tile: the products and epilogues up to the output
 // unit, no activations or deltas stored, no backward operands requested)
+#ifndef CX_FWD_NFP
+#define CX_FWD_NFP 4      // W0 chunks of the next tile requested a trip ahead by a forward-only launch (of the ring's 6)
+#endif
 template <int NCH0, bool FWD = false>
 __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cx_smem[];
@@ -187,10 +190,14 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 31, h = lane >> 5;
-  const int row = blockIdx.x * 32 + n;
-  const bool vrow = row < a.B;
-  const int rowc = vrow ? row : a.B - 1;
+  int n = lane & 31, h = lane >> 5;             // (not const: laundered per trip of the forward-only tile loop, see there)
+  // FWD launches are persistent over row tiles (tile, tile + gridDim.x, ...: see the loop below); a training launch has one
+  // tile per workgroup
+  int tile = blockIdx.x;
+  const int ntiles = (a.B + 31) >> 5;
+  int row = tile * 32 + n;
+  bool vrow = row < a.B;
+  int rowc = vrow ? row : a.B - 1;
   const int H1p = a.H1p, H2p = a.H2p, Ip = a.Ip;
   const bool own = w < CX_NT0;                 // wavefront 7 has no H1 tile: it multiplies tile 6 again, keep bits 0
   const int tt = own ? w : CX_NT0 - 1;
@@ -206,8 +213,8 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   // chunk c is split by wavefront c % 8: lane (n, h) owns h0[row n][16c + 8h .. + 8]
   constexpr int NHQ = (NCH0 + 7) / 8;
   cx_f4 hv[NHQ][2];
-  {
-    const float* hp = a.h0 + (size_t)rowc * Ip + 8 * h;
+  auto load_hv = [&](int rc) {
+    const float* hp = a.h0 + (size_t)rc * Ip + 8 * h;
 #pragma unroll
     for (int cq = 0; cq < NHQ; ++cq) {
       const int c = cq * 8 + w < NCH0 ? cq * 8 + w : NCH0 - 1;
@@ -215,14 +222,19 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
       hv[cq][0] = *reinterpret_cast<const cx_f4*>(hp + c * 16);
       hv[cq][1] = *reinterpret_cast<const cx_f4*>(hp + c * 16 + 4);
     }
-  }
+  };
+  load_hv(rowc);
   // ---------------------------------------------------------------- A-operand streams (global -> registers)
-  const cx_u4* const g0 = reinterpret_cast<const cx_u4*>(a.img0) + lane;        // + (((t*NCH0 + c)*3 + p) * 64)
-  const cx_u4* const g1 = reinterpret_cast<const cx_u4*>(a.img1) + lane;        // + (((cc*NU + u)*3 + p) * 64)
-  const cx_u4* const g2 = reinterpret_cast<const cx_u4*>(a.img2) + lane;        // + (((t*NCH2 + c)*3 + p) * 64)
-  const cx_u4* const g3 = reinterpret_cast<const cx_u4*>(a.img3) + lane;        // + ((cc*3 + p) * 64)
+  // (not const: the forward-only tile loop re-derives them per trip from a laundered lane index -- otherwise the ~60
+  // loop-invariant 64-bit fragment addresses are hoisted out of the loop and spilled, 138 registers' worth)
+  int lane_v = lane;
+  const cx_u4* g0 = reinterpret_cast<const cx_u4*>(a.img0) + lane_v;        // + (((t*NCH0 + c)*3 + p) * 64)
+  const cx_u4* g1 = reinterpret_cast<const cx_u4*>(a.img1) + lane_v;        // + (((cc*NU + u)*3 + p) * 64)
+  const cx_u4* g2 = reinterpret_cast<const cx_u4*>(a.img2) + lane_v;        // + (((t*NCH2 + c)*3 + p) * 64)
+  const cx_u4* g3 = reinterpret_cast<const cx_u4*>(a.img3) + lane_v;        // + ((cc*3 + p) * 64)
 
-  constexpr int CX_PF0 = NCH0 < 6 ? NCH0 : 6;
+  // (ring depth: the forward-only tile loop carries the ring across its exchange / output-unit phases and has 12 registers less to spare)
+  constexpr int CX_PF0 = NCH0 < 6 ? NCH0 : (FWD ? 5 : 6);
   cx_u4 ra0[CX_PF0][3];
   auto load0 = [&](int c, int slot) {
 #pragma unroll
@@ -244,6 +256,25 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   // (u = 2, g = w):  f = 32 u + 8 g + 4 h + r
   const int fA = 32 * (w >> 2) + 8 * (w & 3) + 4 * h, fB = 64 + 8 * (w & 3) + 4 * h;
   const bool hasB = w < 4;
+  // (forward only: the output unit's weight columns of this wavefront, the same for every tile)
+  cx_f4 w2pre[2] = {cx_f4{0.f, 0.f, 0.f, 0.f}, cx_f4{0.f, 0.f, 0.f, 0.f}};
+  if (FWD) {
+    if (fA < H2p) w2pre[0] = *reinterpret_cast<const cx_f4*>(a.w2 + fA);
+    if (hasB && fB < H2p) w2pre[1] = *reinterpret_cast<const cx_f4*>(a.w2 + fB);
+  }
+  // Forward-only launches loop over their row tiles here.  A tile's start -- its h0 rows and the first six W0 chunks arriving,
+  // 5.2 k of a tile's 18.3 k cycles (s_memtime of workgroup 0, GOCTR_CHAIN_DBG=1) -- is requested while the previous tile's
+  // exchange and output unit run (below, behind F1), so only a launch's first tile per CU pays it.  (Training: one trip.)
+  for (;;) {
+  if (FWD) {
+    asm volatile("" : "+v"(lane_v), "+v"(n), "+v"(h));
+    g0 = reinterpret_cast<const cx_u4*>(a.img0) + lane_v; g1 = reinterpret_cast<const cx_u4*>(a.img1) + lane_v;
+    g2 = reinterpret_cast<const cx_u4*>(a.img2) + lane_v; g3 = reinterpret_cast<const cx_u4*>(a.img3) + lane_v;
+  }
+  if (FWD && tile != (int)blockIdx.x) {     // (a later trip: the ring slots its predecessor could not spare registers for)
+#pragma unroll
+    for (int c = CX_FWD_NFP; c < CX_PF0; ++c) load0(c, c);
+  }
   CxDrop dr0, dr1;
   dr0.init(a.d0, a.st, row, 32 * tt + 4 * h);
   dr1.init(a.d1, a.st, row, 0);
@@ -274,6 +305,17 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   // keep bits ride under the MFMAs (they depend on nothing computed here): 16 of layer 0 (slot i: column
   // 32 tt + 8 (i / 4) + 4 h + i % 4), then 8 of layer 1 (slots 0..3: fA + r, slots 4..7: fB + r)
   auto draw_job = [&](int e) {
+    if (FWD) {                       // no dropout at inference: the bits only mark the real columns, nothing is hashed
+      if (e < 16) {
+        const int cc = 8 * (e >> 2) + (e & 3);
+        dr0.bits |= (own && 32 * tt + 4 * h + cc < a.H1) ? (1u << e) : 0u;
+      } else if (e < 24) {
+        const bool second = e >= 20;
+        const int f = (second ? fB : fA) + (e & 3);
+        dr1.bits |= (f < a.H2 && (!second || hasB)) ? (1u << (e - 16)) : 0u;
+      }
+      return;
+    }
     if (e < 16) {
       const int cc = 8 * (e >> 2) + (e & 3);
       dr0.draw(cc, e, own && 32 * tt + 4 * h + cc < a.H1);
@@ -384,6 +426,19 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
             cx_f4{ah1[u][4 * g] + ac1[u][4 * g], ah1[u][4 * g + 1] + ac1[u][4 * g + 1], ah1[u][4 * g + 2] + ac1[u][4 * g + 2],
                   ah1[u][4 * g + 3] + ac1[u][4 * g + 3]};
   }
+  int next_tile = tile;
+  if (FWD) {
+    // the next tile's rows and first weight chunks (workgroup-uniform branch): hv and the ring are free since F0, the layer-1
+    // accumulators have just left for LDS.  In program order BEHIND every other load of this trip (the output unit's weights
+    // are fetched before the loop): a wait for an earlier load never waits for these
+    next_tile = tile + (int)gridDim.x;
+    if (next_tile < ntiles) {
+      const int nrow = next_tile * 32 + n;
+      load_hv(nrow < a.B ? nrow : a.B - 1);
+#pragma unroll
+      for (int c = 0; c < CX_FWD_NFP && c < CX_PF0; ++c) load0(c, c);
+    }
+  }
   __syncthreads();                                            // (2) partial Z1 visible
   stamp(5);
   // this wavefront finishes group A = (u = w / 4, g = w % 4) and, wavefronts 0..3, group B = (u = 2, g = w)
@@ -401,7 +456,8 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
         z += *reinterpret_cast<const cx_f4*>(xch + ((size_t)((ws * CX_NU + u) * 4 + g) * 64 + lane) * 4);
     }
     cx_f4 wv = cx_f4{0.f, 0.f, 0.f, 0.f};
-    if (act) wv = *reinterpret_cast<const cx_f4*>(a.w2 + f0);
+    if (FWD) wv = w2pre[k];
+    else if (act) wv = *reinterpret_cast<const cx_f4*>(a.w2 + f0);
     float a1v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -424,7 +480,15 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   const bool writer = w == 0 && h == 0 && vrow;
   if (FWD) {
     if (writer) a.yhat[row] = yh;
-    return;
+    stamp(6);
+    if (a.dbg && blockIdx.x == 0 && lane == 0 && tile == (int)blockIdx.x) {
+#pragma unroll
+      for (int k = 0; k < CX_NSTAMP; ++k) a.dbg[w * CX_NSTAMP + k] = ts[k];
+    }
+    if (next_tile >= ntiles) return;
+    tile = next_tile;
+    row = tile * 32 + n; vrow = row < a.B; rowc = vrow ? row : a.B - 1;
+    continue;
   }
   const float one_eps = (float)(1.0 + 1e-8);
   const float dy = -((y / yh) - ((1.0f - y) / (one_eps - yh))) * a.inv_bglobal;
@@ -584,6 +648,12 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
     for (int k = 0; k < CX_NSTAMP; ++k) a.dbg[w * CX_NSTAMP + k] = ts[k];
   }
+  break;
+  }   // (tile loop)
 }
+
+// (defined in ctr_fwd.hip)
+int chain_x3_fwd_attributes();
+void launch_chain_x3_fwd(int nch0, const ChainX3Args& a, dim3 grid, hipStream_t s);
 
 }  // namespace goctr

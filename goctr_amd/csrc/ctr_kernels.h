@@ -611,6 +611,7 @@ __device__ __forceinline__ void loss_sum_block(const float* lossrow, int B, floa
 // Every group of 4 consecutive gradient entries is summed by 8 adjacent lanes (lane p takes a
 // contiguous 1/8 of the slabs, 16-byte loads, all independent => deep memory-level parallelism),
 // partial sums are combined by xor-shuffles: a fixed association order => bitwise reproducible.
+#ifndef GOCTR_NO_PLAIN_KERNELS   // (a second translation unit includes this header for its templates only: ctr_fwd.hip)
 __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
   if (blockIdx.x == gridDim.x - 1) {  // last block: deterministic loss sum
     __shared__ float red[256];
@@ -647,6 +648,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
   }
   if (p == 0 && e0 < a.nflat) *reinterpret_cast<float4*>(a.G + e0) = acc;
 }
+#endif
 
 // ---------------------------------------------------------------- Adam (gorgonia AdamSolver.Step)
 struct AdamArgs {
@@ -729,6 +731,7 @@ __device__ __forceinline__ void adam_apply_pre(const AdamArgs& a, int idx, float
 
 // (split path: the reduce kernel has already advanced the state.  This step's bias corrections are the new state's pcorr;
 // one extra block computes the new state's own -- the next step's -- off everybody's critical path)
+#ifndef GOCTR_NO_PLAIN_KERNELS   // (a second translation unit includes this header for its templates only: ctr_fwd.hip)
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   if (blockIdx.x == gridDim.x - 1) {
     if (threadIdx.x == 0) {
@@ -750,6 +753,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   a.G[idx] = 0.f;
   adam_apply(a, idx, g, corr[0], corr[1]);
 }
+#endif
 
 // Single-GPU fast path: slab reduce + Adam + BCE sum + step advance in ONE launch.
 struct ReduceAdamArgs {
@@ -856,15 +860,19 @@ __device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int bl
 
 // the bias corrections of the state a call starts from (set_state / a restored checkpoint / a retargeted cursor leave them
 // to this launch; inside a call every step's loss block writes the next state's)
+#ifndef GOCTR_NO_PLAIN_KERNELS   // (a second translation unit includes this header for its templates only: ctr_fwd.hip)
 __global__ void step_state_corr_kernel(StepState* st, double beta1, double beta2) {
   StepState s = *st;
   state_corrections(s, beta1, beta2);
   st->corr1 = s.corr1; st->corr2 = s.corr2;
 }
+#endif
 
+#ifndef GOCTR_NO_PLAIN_KERNELS   // (a second translation unit includes this header for its templates only: ctr_fwd.hip)
 __global__ __launch_bounds__(256) void reduce_adam_kernel(ReduceAdamArgs p) {
   reduce_adam_body(p, (int)blockIdx.x, (int)gridDim.x);
 }
+#endif
 
 // ---------------------------------------------------------------- the step's last launch merged with the NEXT step's first
 // reduce_adam (blocks [0, nred)) beside attn_fwd of the following batch (the other blocks).  The two do not depend on each
@@ -893,6 +901,7 @@ struct GatherArgs {
   long long rows; float* X; int xcols;
 };
 // rcmd.go:497-533: one wavefront per row; pure copies => bit-exact
+#ifndef GOCTR_NO_PLAIN_KERNELS   // (a second translation unit includes this header for its templates only: ctr_fwd.hip)
 __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long r = (long long)blockIdx.x * 4 + wave;
@@ -907,5 +916,6 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(GatherArgs a) {
   }
   for (int j = lane; j < a.C; j += 64) row[a.U + TD + a.D + j] = a.cfeat[r * a.C + j];
 }
+#endif
 
 }  // namespace goctr

@@ -99,12 +99,14 @@ __device__ __forceinline__ void cx_scatter_weight(const CxImages& im, float w, i
 
 // (re)build every image from the flat float32 weights: after a host upload of weights (the images start zeroed, and the
 // padded weight entries are zero, so only real entries need writing -- but writing all keeps it simple)
+#ifndef GOCTR_NO_PLAIN_KERNELS   // (a second translation unit includes this header for its templates only: ctr_fwd.hip)
 __global__ __launch_bounds__(256) void x3_build_images_kernel(const float* __restrict__ W, int off1, int off2, int H1p, int H2p,
                                                               int U, int D, CxImages im) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= off2) return;
   cx_scatter_weight(im, W[idx], idx, off1, off2, H1p, H2p, U, D);
 }
+#endif
 
 
 }  // namespace goctr

@@ -119,11 +119,13 @@ def test_id_mode_pipelined_graphs_equal_unpipelined_and_eager(knob):
 
 @pytest.mark.parametrize("att", [0, 1])
 def test_din_predict_of_16384_row_launches_vs_oracle(oracle, att):
-    """recommend_qps's kernel: predict launches that give every CU a 32-row tile run ctr_chain_x3_kernel<9,true>.  4 batches
-    of 4096 form one 16 384-row launch; 5 x 4096 + 777 rows also exercise the ungrouped tail (ctr_fwd16_kernel)"""
+    """recommend_qps's kernel: predict launches that give every CU a 32-row tile run ctr_chain_x3_kernel<9,true>, one
+    persistent workgroup per CU over the launch's row tiles.  8 batches of 4096 form one 32 768-row launch (4 tiles per
+    workgroup), the next 4 a 16 384-row one, then a 2-batch launch (8192 rows: one tile each); the last, short batch runs
+    ctr_fwd16_kernel"""
     from goctr_amd import model as gm
     U, T, D, Cc, V = 52, 50, 16, 53, 26744
-    rows = 4096 * 5 + 777
+    rows = 4096 * 14 + 777
     rng = np.random.default_rng(320 + att)
     emb, ub, it, uf, cf, _ = synth(rng, rows, U, T, D, Cc, V)
     om = oracle.CtrModel(0, U, T, D, Cc, att=att)
@@ -140,5 +142,34 @@ def test_din_predict_of_16384_row_launches_vs_oracle(oracle, att):
     X = oracle.assemble_rows(emb, ub, it, uf, cf)
     ry = om.predict(X, 4096)
     assert y.shape == (rows,)
-    assert np.max(np.abs(y[:16384] - ry[:16384])) <= LOGIT_TOL          # the grouped 16 384-row launch
+    assert np.max(np.abs(y[:32768] - ry[:32768])) <= LOGIT_TOL          # the 32 768-row launch
     assert np.max(np.abs(y - ry)) <= LOGIT_TOL
+
+
+@pytest.mark.parametrize("PB,rows", [(1100, 8 * 1100), (4096, 8 * 4096), (1037, 8 * 1037 - 5)])
+def test_persistent_forward_kernel_equals_one_workgroup_per_tile(PB, rows):
+    """the forward-only chain as one persistent workgroup per CU (each walks tiles blockIdx.x, + gridDim.x, ...; the next tile's
+    rows and first weight chunks are requested a trip ahead) against one workgroup per tile (GOCTR_FWD_PERSIST=0): the same
+    bits.  275 tiles on 256 CUs (19 workgroups take a second trip), 1024 tiles (4 trips each), and a launch whose last tile
+    is partly past the dataset's end"""
+    from goctr_amd import model as gm
+    U, T, D, Cc, V = 52, 50, 16, 53, 5000
+    rng = np.random.default_rng(rows)
+    emb, ub, it, uf, cf, _ = synth(rng, rows, U, T, D, Cc, V)
+    dm = gm.DinNet(U, T, D, D, Cc)
+    r = np.random.default_rng(5)
+    dm.set_weights("mlp0", (r.standard_normal((U + 2 * D + Cc, 200)) * 0.15).astype(np.float32))
+    dm.set_weights("mlp1", (r.standard_normal((200, 80)) * 0.15).astype(np.float32))
+    dm.set_weights("mlp2", (r.standard_normal((80, 1)) * 0.15).astype(np.float32))
+    tab = gm.EmbeddingTable(emb)
+    ds = gm.Dataset.ids(ub, it, uf, cf, None)
+    ys = []
+    for knob in (None, "0"):
+        if knob is not None:
+            os.environ["GOCTR_FWD_PERSIST"] = knob
+        try:
+            ys.append(gm.predict_dataset(dm, ds, PB, emb=tab))
+        finally:
+            os.environ.pop("GOCTR_FWD_PERSIST", None)
+    assert ys[0].shape == (rows,) and np.all((ys[0] > 0) & (ys[0] < 1))
+    assert np.array_equal(ys[0], ys[1])
