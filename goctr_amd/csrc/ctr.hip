@@ -21,6 +21,7 @@
 #include "emb_train.h"
 #include "scan.h"
 #include "ctr_kernels.h"
+#include "ctr_serve.h"
 #include "mfma_gemm.h"
 
 using namespace goctr;
@@ -332,6 +333,12 @@ int allow_big_lds(K kernel) {
   return 0;
 }
 
+int serve16_attributes() {
+#define GOCTR_S16(L, H) (allow_big_lds(ctr_serve16_kernel<L, 1, H>) || allow_big_lds(ctr_serve16_kernel<L, 2, H>) || allow_big_lds(ctr_serve16_kernel<L, 3, H>))
+  return (GOCTR_S16(2, 10) || GOCTR_S16(2, 15) || GOCTR_S16(4, 10) || GOCTR_S16(4, 15) || GOCTR_S16(16, 10) || GOCTR_S16(16, 15)) ? -1 : 0;
+#undef GOCTR_S16
+}
+
 template <class Epi>
 int launch_nn(int kid, const float* A, int lda, const float* Bm, int ldb, int M, int Kp, int Np, Epi epi) {
   const int NT = Np / 16;
@@ -418,7 +425,8 @@ int init_kernel_attrs() {
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
       allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(gemm_tn_multi_x3w_kernel<9, 5>) || allow_big_lds(gemm_tn_multi_x3w_kernel<8, 5>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
-      allow_big_lds(ctr_chain_x3_kernel<15>) || chain_x3_fwd_attributes()) return -1;
+      allow_big_lds(ctr_chain_x3_kernel<15>) || chain_x3_fwd_attributes() ||
+      serve16_attributes()) return -1;
   done = true;
   return 0;
 }
@@ -644,8 +652,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   return 0;
 }
 
-int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st, const FwdBufs& fb) {
-  if (chain_x3_ok(m, o, B)) return launch_chain_x3(m, src, B, o, st, fb);
+ChainArgs make_chain_args(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st, const FwdBufs& fb) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
   const uint32_t row_off = (uint32_t)(e.rank * B);
@@ -661,6 +668,49 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
   a.buf_floats = chain_buf_floats(m->Ip, m->H1p, m->H2p);
   a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;   // (forward only: none of these is touched)
   a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
+  return a;
+}
+
+AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb);
+int attn_fast_mode(const goctr_model* m, const RowSource& src, int* groups);
+// A small serving pass in key mode as ONE launch (ctr_serve.h): the shapes with a compile-time attention variant at 8, 16
+// or 64 embedding columns, launches the 16-row forward kernel would take (too few rows for a 32-row tile per CU)
+bool serve16_ok(const goctr_model* m, const RowSource& src, int B) {
+  int groups = 0;
+  const int fast = attn_fast_mode(m, src, &groups);
+  StepOpts o; o.train = false;
+  return src.k_users && fast != 0 && (groups == 2 || groups == 4 || groups == 16) && chain_ok(m) && !chain_x3_ok(m, o, B) &&
+         cdiv(B, 32) < engine().compute_units && env_int("GOCTR_NO_FWD16", 0) == 0 && env_int("GOCTR_SERVE_ONE_LAUNCH", 1) != 0;
+}
+int launch_serve16(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb) {
+  int groups = 0;
+  const int fast = attn_fast_mode(m, src, &groups);
+  StepOpts o; o.train = false;
+  const ChainArgs a = make_chain_args(m, src, B, o, st, fb);
+  const AttnArgs aa = make_attn_args(m, src, B, st, fb);
+  const size_t lds = chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p);
+  const dim3 grid((unsigned)cdiv(B, 16)), blk(1024);
+  hipStream_t s = engine().active;
+#define GOCTR_SERVE16_H(L, H)                                                                          \
+  do {                                                                                                 \
+    if (fast == 1) hipLaunchKernelGGL((ctr_serve16_kernel<L, 1, H>), grid, blk, lds, s, aa, a);        \
+    else if (fast == 2) hipLaunchKernelGGL((ctr_serve16_kernel<L, 2, H>), grid, blk, lds, s, aa, a);   \
+    else hipLaunchKernelGGL((ctr_serve16_kernel<L, 3, H>), grid, blk, lds, s, aa, a);                  \
+  } while (0)
+#define GOCTR_SERVE16(L) do { if (m->Ip <= 160) GOCTR_SERVE16_H(L, 10); else GOCTR_SERVE16_H(L, 15); } while (0)
+  if (groups == 2) GOCTR_SERVE16(2);
+  else if (groups == 4) GOCTR_SERVE16(4);
+  else GOCTR_SERVE16(16);
+#undef GOCTR_SERVE16_H
+#undef GOCTR_SERVE16
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st, const FwdBufs& fb) {
+  if (chain_x3_ok(m, o, B)) return launch_chain_x3(m, src, B, o, st, fb);
+  Engine& e = engine();
+  ChainArgs a = make_chain_args(m, src, B, o, st, fb);
   static DevBuf<unsigned long long> dbgbuf;
   const bool dbg = o.train && env_int("GOCTR_CHAIN_DBG", 0) != 0;
   if (dbg && !dbgbuf.p && dbgbuf.alloc(CHAIN_NSTAMP)) return -1;
@@ -2619,6 +2669,9 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   fb.yhat = dscore;
   StepOpts op;
   op.train = false;
+  if (fuse && serve16_ok(m, src, (int)N)) {          // key lookup + attention + forward chain: one launch
+    if (launch_serve16(m, src, (int)N, s->st.p, fb)) return -1;
+  } else
   if (launch_forward(m, src, (int)N, op, s->st.p, &fb)) return -1;
   bool want_failed = false;
   for (int k = 0; k < nseg; ++k) want_failed = want_failed || segs[k]->failed || segs[k]->n_failed >= 0;

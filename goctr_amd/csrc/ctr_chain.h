@@ -452,8 +452,10 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_kernel(ChainArgs a) {
 // compute wavefronts (4 + 3 + 3 + 3): each wavefront issues 144 + 80 MFMAs instead of 252 + 140.  The four partial
 // Z1 are exchanged through LDS and added in wavefront order by every wavefront.  Same operands, staging and loader
 // wavefronts as ctr_chain_kernel; no dropout at inference (the reference's predict graph has p = 0, quirk Q1).
-template <int NT0Q, int NT1>
-__global__ __launch_bounds__(512, 1) void ctr_fwd16_kernel(ChainArgs a) {
+// (staged0: the loader wavefronts have already REQUESTED the first W0 block -- ctr_serve16_kernel, ctr_serve.h)
+// HV: h0 fragments a lane keeps in registers (Ip <= 16 HV; 10 for Ip <= 160 leaves room under a 128-register bound)
+template <int NT0Q, int NT1, int HV = CHAIN_HV>
+__device__ __forceinline__ void ctr_fwd16_body(const ChainArgs& a, bool staged0) {
   typedef chain_f4 f4;
   extern __shared__ __attribute__((aligned(16))) float chain_smem[];
   float* const bufP = chain_smem;
@@ -467,8 +469,10 @@ __global__ __launch_bounds__(512, 1) void ctr_fwd16_kernel(ChainArgs a) {
   if (wave >= 4) {                         // loader wavefronts: the barrier sequence mirrors the compute wavefronts'
     ChainStager stg;
     const int lw = wave - 4;
-    stg.begin(a.W0i, bufP, kph0 * H1p, lw);
-    stg.drain(lane);
+    if (!staged0) {
+      stg.begin(a.W0i, bufP, kph0 * H1p, lw);
+      stg.drain(lane);
+    }
     __syncthreads();
     int lpar = 0;
     for (int k0 = 0; k0 < Ip; k0 += CHAIN_KPH0) {
@@ -492,9 +496,9 @@ __global__ __launch_bounds__(512, 1) void ctr_fwd16_kernel(ChainArgs a) {
   const int t0 = wave * base + (wave < extra ? wave : extra);
   const int ntl = base + (wave < extra ? 1 : 0);
   const float* hp = a.h0 + (size_t)rowc * Ip + 4 * q;
-  f4 hall[CHAIN_HV];
+  f4 hall[HV];
 #pragma unroll
-  for (int c = 0; c < CHAIN_HV; ++c)
+  for (int c = 0; c < HV; ++c)
     if (c * 16 < Ip) hall[c] = *reinterpret_cast<const f4*>(hp + c * 16);
   f4 w2v[NT1];
 #pragma unroll
@@ -505,14 +509,14 @@ __global__ __launch_bounds__(512, 1) void ctr_fwd16_kernel(ChainArgs a) {
   int par = 0;
   __syncthreads();
 #pragma unroll
-  for (int ph = 0; ph < CHAIN_HV * 16 / CHAIN_KPH0; ++ph) {
+  for (int ph = 0; ph < HV * 16 / CHAIN_KPH0; ++ph) {
     const int k0 = ph * CHAIN_KPH0;
     if (k0 < Ip) {
       const int kph = Ip - k0 < CHAIN_KPH0 ? Ip - k0 : CHAIN_KPH0;
       float* cur = par ? bufQ : bufP;
       const float* wp = cur + ((size_t)q * H1p + t0 * 16 + i) * 4;    // (a wavefront with one tile less multiplies a throw-away one)
       chain_mma_phase<NT0Q, CHAIN_KPH0 / 16>(acc0, wp, 16 * H1p, kph >> 4,
-                                             [&](int c) { return hall[ph * (CHAIN_KPH0 / 16) + c < CHAIN_HV ? ph * (CHAIN_KPH0 / 16) + c : CHAIN_HV - 1]; });
+                                             [&](int c) { return hall[ph * (CHAIN_KPH0 / 16) + c < HV ? ph * (CHAIN_KPH0 / 16) + c : HV - 1]; });
       par ^= 1;
       __syncthreads();
     }
@@ -563,6 +567,10 @@ __global__ __launch_bounds__(512, 1) void ctr_fwd16_kernel(ChainArgs a) {
   float z2 = part + __shfl_xor(part, 16, 64);
   z2 += __shfl_xor(z2, 32, 64);
   if (wave == 0 && q == 0 && vrow) a.yhat[row] = sigm_out(z2);
+}
+template <int NT0Q, int NT1>
+__global__ __launch_bounds__(512, 1) void ctr_fwd16_kernel(ChainArgs a) {
+  ctr_fwd16_body<NT0Q, NT1>(a, false);
 }
 
 }  // namespace goctr

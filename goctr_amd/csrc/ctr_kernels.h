@@ -177,9 +177,12 @@ __device__ __forceinline__ void load_row_nn(const float* row, int d0, int D, boo
 // the block that owns att0 publishes `expect` in *flag (device scope) once its stores are out (null: plain attn_fwd)
 struct RaCtx { const unsigned int* flag; unsigned int expect; const float* att0; };
 
+// sample: the launch's row this wavefront takes, or -1 = workgroup `blk`'s row of its wavefront index (4 per workgroup)
+// key: (KEYS) the sample's key if its workgroup has already fetched it (ctr_serve16_kernel), else null = read it here
+struct AttnKey { int user, item; long long ts; };
 template <int VEC, int LPR, int FAST, bool KEYS = false>
 __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long long batch_idx, const float* att0w,
-                                              const RaCtx* ra = nullptr) {
+                                              const RaCtx* ra = nullptr, int sample = -1, const AttnKey* key = nullptr) {
   const bool idm = FAST ? true : (bool)a.src.id_mode;
   const bool din = FAST ? FAST >= 2 : a.kind == GOCTR_DIN;
   const bool cosine = FAST ? FAST == 2 : a.att == GOCTR_ATT_COSINE;
@@ -187,7 +190,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
   constexpr int NPB = LPR < 4 ? LPR : 4;  // passes per block; NPB*RPP <= 64
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the sample's base addresses live in SGPRs
-  const int b = blk * 4 + wave;
+  const int b = sample >= 0 ? sample : blk * 4 + wave;
   if (b >= a.B) return;
   const RowSource& s = a.src;
   const long long gr = batch_idx * (long long)a.B + b;
@@ -202,9 +205,9 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
   long long kb = 0, kcnt = 0;                                      // behaviour ids = ub_items[kb .. kb + kcnt)
   if (KEYS && valid) {
     // the key's three fields up front (they may sit in pinned HOST memory: one PCIe round trip, not three)
-    const int u = s.k_users[gr];
-    const int it = s.k_items[gr];
-    const long long mts = s.k_ts ? s.k_ts[gr] : 0;
+    const int u = key ? key->user : s.k_users[gr];
+    const int it = key ? key->item : s.k_items[gr];
+    const long long mts = key ? key->ts : (s.k_ts ? s.k_ts[gr] : 0);
     const bool ok = u >= 0 && u < s.n_users && it >= 0 && it < s.n_items;     // rcmd.go:291-307: else the ALL-zero row
     if (lane == 0 && s.k_failed) s.k_failed[gr] = ok ? 0 : 1;
     if (ok) {

@@ -78,8 +78,9 @@ def test_batch_predict_matches_oracle(oracle, kind):
 
 @pytest.mark.parametrize("kind,D,T,max_hist", [(0, 16, 10, 30), (0, 8, 70, 400), (1, 64, 20, 400), (0, 4, 5, 30), (0, 12, 10, 30)])
 def test_key_lookup_inside_the_attention_kernel_equals_assembled_rows(oracle, monkeypatch, kind, D, T, max_hist):
-    """serving passes look the keys up inside attn_fwd (attn_fwd_keys_kernel; embedding widths 4 .. 64, powers of two) or
-    assemble the rows first (assemble_keys_kernel: other widths, GOCTR_SERVE_FUSE=0): same scores bit for bit, both against
+    """serving passes run as one launch (ctr_serve16_kernel: key lookup + attention + forward chain; D = 8, 16, 64), look the
+    keys up inside attn_fwd (attn_fwd_keys_kernel; embedding widths 4 .. 64, powers of two; GOCTR_SERVE_ONE_LAUNCH=0) or
+    assemble the rows first (assemble_keys_kernel: other widths, GOCTR_SERVE_FUSE=0): same scores bit for bit, all against
     the oracle; histories longer than 256 entries take the bisection instead of the ballot search, T > 64 two id blocks"""
     from goctr_amd import recommend as gr
     rng = np.random.default_rng(500 + D + T)
@@ -91,10 +92,12 @@ def test_key_lookup_inside_the_attention_kernel_equals_assembled_rows(oracle, mo
     keys[11] = gr.Sample(keys[11].UserId, keys[11].ItemId, 0.0, 0)
     model = gr.Predictor(rs, net, predBatchSize=256)
     ys = []
-    for fuse in ("1", "0"):
+    # one launch per pass (ctr_serve16_kernel: D = 8, 16, 64) / key lookup inside attn_fwd + the forward chain / assembled rows first
+    for fuse, one in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("GOCTR_SERVE_FUSE", fuse)
+        monkeypatch.setenv("GOCTR_SERVE_ONE_LAUNCH", one)
         ys.append(gr.BatchPredict(model, keys)[:, 0].copy())
-    assert np.array_equal(ys[0], ys[1])
+    assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])
     ref, failed = oracle_scores(oracle, rs, om, keys, 256)
     assert failed.sum() == 2
     assert np.max(np.abs(ys[0] - ref)) <= 1e-5
