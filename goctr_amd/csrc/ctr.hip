@@ -1541,6 +1541,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
     if (rc) { if (g) (void)hipGraphDestroy(g); m->stp = stp_now; return -1; }
     GOCTR_HIP(ce);
     GOCTR_HIP(hipGraphInstantiate(&m->graph.a[par], g, nullptr, nullptr, 0));
+    (void)hipGraphUpload(m->graph.a[par], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
     (void)hipGraphDestroy(g);
     if (split3) {
       hipGraph_t gm = nullptr;
@@ -1550,6 +1551,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
       if (rc) { if (gm) (void)hipGraphDestroy(gm); m->stp = stp_now; return -1; }
       GOCTR_HIP(ce);
       GOCTR_HIP(hipGraphInstantiate(&m->graph.mid[par], gm, nullptr, nullptr, 0));
+      (void)hipGraphUpload(m->graph.mid[par], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
       (void)hipGraphDestroy(gm);
     }
     if (e.comm_active()) {
@@ -1560,6 +1562,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
       if (rc) { if (g2) (void)hipGraphDestroy(g2); m->stp = stp_now; return -1; }
       GOCTR_HIP(ce);
       GOCTR_HIP(hipGraphInstantiate(&m->graph.b[par], g2, nullptr, nullptr, 0));
+      (void)hipGraphUpload(m->graph.b[par], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
       (void)hipGraphDestroy(g2);
     }
   }
@@ -1598,6 +1601,7 @@ int build_multi_graphs(goctr_model* m, const RowSource& src, int B, const StepOp
       if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
       GOCTR_HIP(ce);
       GOCTR_HIP(hipGraphInstantiate(&sg.multi[z][par], g, nullptr, nullptr, 0));
+      (void)hipGraphUpload(sg.multi[z][par], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
       (void)hipGraphDestroy(g);
     }
   sg.multi_on = true;

@@ -1500,6 +1500,7 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
       if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
       GOCTR_HIP(ce);
       GOCTR_HIP(hipGraphInstantiate(&p->step_graph, g, nullptr, nullptr, 0));
+      (void)hipGraphUpload(p->step_graph, e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
       (void)hipGraphDestroy(g);
       p->step_graph_rows = p->rows; p->step_graph_perm = p->perm.n > 1;
       p->step_graph_x = p->Xr.p; p->step_graph_y = p->Yr.p; p->step_graph_p = p->perm.p; p->step_graph_w = p->W0img.p;
@@ -1520,6 +1521,7 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
           if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
           GOCTR_HIP(ce);
           GOCTR_HIP(hipGraphInstantiate(&p->multi_graph[z], g, nullptr, nullptr, 0));
+          (void)hipGraphUpload(p->multi_graph[z], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
           (void)hipGraphDestroy(g);
         }
       }
