@@ -28,6 +28,7 @@ using namespace goctr;
 
 struct goctr_emb {
   const uint64_t uid = next_uid();   // what a captured step graph is keyed on (never reused, unlike the host address)
+  uint64_t version = 0;              // bumped whenever rows change (goctr_emb_set_rows, embedding training): H0Carry is keyed on it
   int64_t V = 0; int D = 0;
   DevBuf<float> rows;
 };
@@ -151,6 +152,13 @@ struct goctr_model {
   long long emb_V = 0; int emb_B = 0, emb_world = 0; bool emb_comm = false;
   DevBuf<float> dpv, W0pvT;
   bool w0pv_live = false;         // W0pvT holds the current W0[U:U+2D,:]^T and the Adam kernels keep it current
+  // The last launch of a pipelined step computes the NEXT batch's h0 / gates (reduce_attn_kernel); the last step of a
+  // goctr_train_steps call computes them for the batch the next call usually starts at.  That call skips its own first attn_fwd
+  // (8.5 us + a launch of a call's ~32 us fixed cost) if NOTHING could have touched what those rows were computed from:
+  // `gen` counts every entry that locks the model exclusively (weights, state, workspace -- and this model's own calls), the
+  // table's version its row updates; dataset and table are identified by their never-reused uids.
+  uint64_t gen = 0;
+  struct H0Carry { bool valid = false; uint64_t gen = 0, ds_uid = 0, emb_uid = 0, emb_version = 0; int B = 0, stp = 0; long long batch = -1; } carry;
   bool attn_bwd_in_chain = false;  // launch_chain_x3 -> launch_backward: this step's chain launch wrote the att0 terms
   bool dpv_from_chain = false;    // the step's chain launch wrote dpv itself (launch_chain_x3): no dpv GEMM in this step
   DevBuf<unsigned int> emb_mark, emb_rank, emb_tiles;
@@ -1704,6 +1712,8 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
   // were ~3 us of its timed region)
   hipLaunchKernelGGL(step_state_prepare_kernel, dim3(1), dim3(1), 0, e.stream, m->st_cur(), o.tc->beta1, o.tc->beta2,
                      m->pend_retarget ? 1 : 0, m->pend_batch_idx, m->pend_n_batches);
+  const bool have_start = m->pend_retarget;                    // the host knows the batch the call starts at
+  const long long start_batch = m->pend_batch_idx, start_nb = m->pend_n_batches;
   m->pend_retarget = false;
   GOCTR_HIP(hipGetLastError());
   // (with a communicator and NO plan the sparse embedding exchange sizes its collectives from device counters read back by
@@ -1712,12 +1722,21 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
   if (use_graph) {
     o.pipelined = pipeline_ok(m, src);
     if (!graph_matches(m->graph, d, emb, B, o) && build_graph(m, d, emb, src, B, o)) return -1;
+    const bool retargeted = have_start;
     if (o.pipelined && n_steps > 0) {
-      // the first step's h0: nobody computed it yet (every later step gets it from its predecessor's last launch; the
-      // last step computes one nobody uses -- a call costs one attn_fwd more than its steps need)
-      const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
-      if (launch_attn_fwd(aa)) return -1;
+      // the first step's h0: every later step gets it from its predecessor's last launch, and so does the first one when the
+      // previous call ended exactly where this one starts and nothing happened in between (goctr_model::H0Carry)
+      const goctr_model::H0Carry& cy = m->carry;
+      const bool carried = cy.valid && retargeted && cy.gen + 1 == m->gen && cy.ds_uid == d->uid && emb && cy.emb_uid == emb->uid &&
+                           cy.emb_version == emb->version && cy.B == B && cy.stp == m->stp && cy.batch == start_batch &&
+                           env_int("GOCTR_H0_CARRY", 1) != 0;
+      if (!carried) {
+        const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
+        if (launch_attn_fwd(aa)) return -1;
+      }
     }
+    m->carry.valid = false;
+    if (m->emb_lr > 0.f && emb && n_steps > 0) ++emb->version;       // (rows are about to change: other models' carried h0 die)
     int s = 0;
     if (!e.comm_active() && env_int("GOCTR_GRAPH_STEPS", 1) != 0) {
       if (!m->graph.multi_on && build_multi_graphs(m, src, B, o)) return -1;
@@ -1741,7 +1760,11 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
         GOCTR_HIP(hipGraphLaunch(m->graph.b[par], e.stream));
       }
     }
+    if (o.pipelined && n_steps > 0 && retargeted && emb && start_nb > 0) {
+      m->carry = goctr_model::H0Carry{true, m->gen, d->uid, emb->uid, emb->version, B, m->stp, (start_batch + n_steps) % start_nb};
+    }
   } else {
+    if (m->emb_lr > 0.f && emb && n_steps > 0) ++emb->version;
     for (int s = 0; s < n_steps; ++s)
       if (train_step_eager(m, src, B, o)) return -1;
   }
@@ -1897,7 +1920,7 @@ void goctr_model_destroy(goctr_model* m) {
 int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, size_t n) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && host, "goctr_model_set_weights: null argument");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   if (upload_padded_weights(m, tensor_id, host, n)) return -1;
   if (tensor_id == GOCTR_W0) m->w0pv_live = false;
   if ((tensor_id == GOCTR_W0 || tensor_id == GOCTR_W1) && rebuild_x3_images(m)) return -1;
@@ -1907,7 +1930,7 @@ int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, si
 int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && host, "goctr_model_get_weights: null argument");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return download_padded(m, m->W.p, tensor_id, host, n);
 }
 
@@ -1949,14 +1972,14 @@ int upload_padded_flat(goctr_model* m, float* flat_dev, int tensor_id, const flo
 int goctr_model_get_moments(goctr_model* m, int tensor_id, int which, float* host, size_t n) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && host && (which == 0 || which == 1), "goctr_model_get_moments: bad argument");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return download_padded(m, which ? m->Vo.p : m->Mo.p, tensor_id, host, n);
 }
 
 int goctr_model_set_moments(goctr_model* m, int tensor_id, int which, const float* host, size_t n) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && host && (which == 0 || which == 1), "goctr_model_set_moments: bad argument");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return upload_padded_flat(m, which ? m->Vo.p : m->Mo.p, tensor_id, host, n);
 }
 
@@ -1964,7 +1987,7 @@ int goctr_model_set_moments(goctr_model* m, int tensor_id, int which, const floa
 int goctr_model_get_step(goctr_model* m, uint32_t* step) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && step, "goctr_model_get_step: null argument");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   StepState s;
   if (get_state(m, &s)) return -1;
   *step = s.gstep;
@@ -1974,14 +1997,14 @@ int goctr_model_get_step(goctr_model* m, uint32_t* step) {
 int goctr_model_set_step(goctr_model* m, uint32_t step) {
   GOCTR_ENTER();
   GOCTR_CHECK(m, "goctr_model_set_step: null argument");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return set_state(m, step, 0, 0, 1);
 }
 
 int goctr_model_set_embedding_training(goctr_model* m, double lr) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && lr >= 0 && lr == lr, "goctr_model_set_embedding_training: bad arguments");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   GOCTR_CHECK(lr == 0 || m->cfg.D <= 64, "embedding training supports D <= 64 (got %d)", m->cfg.D);
   m->emb_lr = (float)lr;
   m->w0pv_live = false;            // (the Adam kernels only keep W0pvT current while embedding training is on)
@@ -1992,7 +2015,7 @@ int goctr_model_set_embedding_training(goctr_model* m, double lr) {
 int goctr_model_sparse_exchange_bytes(goctr_model* m, double* bytes) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && bytes, "goctr_model_sparse_exchange_bytes: null argument");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   *bytes = engine().comm_active() ? m->ex_bytes_last : 0.0;
   return 0;
 }
@@ -2005,7 +2028,7 @@ int goctr_emb_get_rows(goctr_emb* e, int64_t first, int64_t n, float* host_rows)
 
 int goctr_model_reset_optimizer(goctr_model* m) {
   GOCTR_ENTER();
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
   GOCTR_HIP(hipMemsetAsync(m->Vo.p, 0, sizeof(float) * m->nflat, engine().stream));
   return set_state(m, 0, 0, 0, 1);
@@ -2025,6 +2048,7 @@ int goctr_emb_create(int64_t V, int D, const float* host_rows, goctr_emb** out) 
 int goctr_emb_set_rows(goctr_emb* e, int64_t first, int64_t n, const float* host_rows) {
   GOCTR_ENTER();
   GOCTR_CHECK(e && host_rows && first >= 0 && n >= 0 && first + n <= e->V, "goctr_emb_set_rows: range out of bounds");
+  ++e->version;
   return n ? e->rows.upload(host_rows, (size_t)n * e->D, (size_t)first * e->D) : 0;
 }
 void goctr_emb_destroy(goctr_emb* e) {
@@ -2262,7 +2286,7 @@ int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const go
   GOCTR_CHECK(d->has_y, "goctr_train_steps: dataset has no labels");
   GOCTR_CHECK(cfg->dropout_mode == 0 || cfg->dropout_mode == 2, "multi-step training supports dropout_mode 0 or 2");
   GOCTR_CHECK(n_steps <= COST_RING, "n_steps > %d per call", COST_RING);
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   if (check_dataset(m, d, emb)) return -1;
   const long long nb = cdiv(d->rows, cfg->batch);
   if (retarget_state(m, first_batch % nb, nb)) return -1;      // no host synchronisation on this path
@@ -2287,7 +2311,7 @@ int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const 
   GOCTR_CHECK(m && d && cfg && cfg->batch > 0 && cfg->epochs >= 0, "goctr_train_dataset: bad arguments");
   GOCTR_CHECK(d->has_y, "goctr_train_dataset: dataset has no labels");
   GOCTR_CHECK(cfg->dropout_mode == 0 || cfg->dropout_mode == 2, "multi-step training supports dropout_mode 0 or 2");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   if (check_dataset(m, d, emb)) return -1;
   // a fresh solver per model.Train call (model.go:88)
   GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
@@ -2343,7 +2367,7 @@ int goctr_train_dense(goctr_model* m, const float* X, const float* Y, int64_t ro
   int rc = goctr_train_dataset(m, nullptr, d, cfg, epoch_costs, epochs_run);
   if (!rc) rc = goctr_sync();
   {
-    std::unique_lock<std::shared_mutex> lk(m->mu);
+    std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
     m->graph.destroy();  // (keyed on the dataset's generation id, so it could never be replayed again anyway)
   }
   goctr_dataset_destroy(d);
@@ -2358,7 +2382,7 @@ int goctr_loss_grad_dense(goctr_model* m, const float* X, const float* Y, int va
   goctr_dataset* d = nullptr;
   if (goctr_dataset_create_dense(X, Y, valid, xcols, ranges, &d)) return -1;
   std::unique_ptr<goctr_dataset> guard(d);
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   if (check_dataset(m, d, nullptr)) return -1;
   if (ensure_workspace(m, B)) return -1;
   StepOpts o = opts_from(cfg);
@@ -2467,7 +2491,7 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
 int goctr_predict_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, float* y_out) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && d && y_out && batch > 0, "goctr_predict_dataset: bad arguments");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return predict_batches(m, emb, d, batch, 0, cdiv(d->rows, batch), y_out);
 }
 
@@ -2475,7 +2499,7 @@ int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int ba
                         int n_batches) {
   GOCTR_ENTER();
   GOCTR_CHECK(m && d && batch > 0 && n_batches >= 0, "goctr_predict_steps: bad arguments");
-  std::unique_lock<std::shared_mutex> lk(m->mu);
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return predict_batches(m, emb, d, batch, first_batch, n_batches, nullptr);
 }
 

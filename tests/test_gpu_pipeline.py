@@ -173,3 +173,50 @@ def test_persistent_forward_kernel_equals_one_workgroup_per_tile(PB, rows):
             os.environ.pop("GOCTR_FWD_PERSIST", None)
     assert ys[0].shape == (rows,) and np.all((ys[0] > 0) & (ys[0] < 1))
     assert np.array_equal(ys[0], ys[1])
+
+
+@pytest.mark.parametrize("between", ["nothing", "set_att0", "set_rows", "predict", "jump", "other_steps"])
+def test_h0_carried_from_the_previous_call_only_when_nothing_touched_it(between):
+    """the last launch of a goctr_train_steps call has computed the next batch's h0 / gates; the next call skips its first
+    attn_fwd when it starts at exactly that batch and no entry point that could touch weights, table, dataset or workspace ran
+    in between (goctr_model::H0Carry).  10 + 10 steps with something in between, carry on (default) against GOCTR_H0_CARRY=0:
+    the same bits -- for `nothing` the carry is used, for every other case it must have been dropped"""
+    from goctr_amd import capi, model as gm
+    import ctypes as C
+    U, T, D, Cc, V, B = 52, 50, 16, 53, 5000, 512
+    rng = np.random.default_rng(77)
+    emb, ub, it, uf, cf, Y = synth(rng, 24 * B, U, T, D, Cc, V)
+    res = []
+    for knob in (None, "0"):
+        if knob is not None:
+            os.environ["GOCTR_H0_CARRY"] = knob
+        try:
+            tab = gm.EmbeddingTable(emb)
+            ds = gm.Dataset.ids(ub, it, uf, cf, Y)
+            m = gm.DinNet(U, T, D, D, Cc)
+            r = np.random.default_rng(78)
+            m.set_weights("mlp0", (r.standard_normal((U + 2 * D + Cc, 200)) * 0.15).astype(np.float32))
+            m.set_weights("mlp1", (r.standard_normal((200, 80)) * 0.15).astype(np.float32))
+            m.set_weights("mlp2", (r.standard_normal((80, 1)) * 0.15).astype(np.float32))
+            m.set_weights("att0", (1 + 0.3 * r.standard_normal(T)).astype(np.float32))
+            cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=2, p0=0.01, p1=0.01, seed=3)
+            c1 = gm.train_steps(m, ds, cfg, 10, first_batch=0, emb=tab, want_costs=True)
+            nxt = 10
+            if between == "set_att0":
+                m.set_weights("att0", (1 + 0.3 * np.random.default_rng(5).standard_normal(T)).astype(np.float32))
+            elif between == "set_rows":
+                new = (np.random.default_rng(6).standard_normal((64, D)) * 0.3).astype(np.float32)
+                capi.check(capi.load().goctr_emb_set_rows(tab._h, C.c_int64(0), C.c_int64(64), capi.ptr(new, C.c_float)))
+            elif between == "predict":
+                gm.predict_dataset(m, ds, 512, emb=tab)
+            elif between == "jump":
+                nxt = 3
+            elif between == "other_steps":
+                gm.train_steps(m, ds, cfg, 2, first_batch=20, emb=tab)
+            c2 = gm.train_steps(m, ds, cfg, 10, first_batch=nxt, emb=tab, want_costs=True)
+            res.append((c1, c2, m.get_weights("mlp0"), m.get_weights("att0")))
+        finally:
+            os.environ.pop("GOCTR_H0_CARRY", None)
+    assert np.all(np.isfinite(res[0][1]))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
