@@ -695,7 +695,8 @@ int launch_serve16(goctr_model* m, const RowSource& src, int B, const StepState*
   const int fast = attn_fast_mode(m, src, &groups);
   StepOpts o; o.train = false;
   const ChainArgs a = make_chain_args(m, src, B, o, st, fb);
-  const AttnArgs aa = make_attn_args(m, src, B, st, fb);
+  AttnArgs aa = make_attn_args(m, src, B, st, fb);
+  aa.gate = nullptr; aa.wgt = nullptr;                  // (only the training step's backward reads gates and weights)
   const size_t lds = chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p);
   const dim3 grid((unsigned)cdiv(B, 16)), blk(1024);
   hipStream_t s = engine().active;
@@ -809,7 +810,8 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
   const StepState* st = st_override ? st_override : m->st_cur();
   const FwdBufs fb = fbp ? *fbp : train_bufs(m, m->stp);
   if (!o.pipelined) {
-    const AttnArgs aa = make_attn_args(m, src, B, st, fb);
+    AttnArgs aa = make_attn_args(m, src, B, st, fb);
+    if (!o.train) { aa.gate = nullptr; aa.wgt = nullptr; }     // (only the backward reads them: 13 MB less per 32 768-row launch)
     if (launch_attn_fwd(aa)) return -1;
   }
   if (o.train) { m->dpv_from_chain = false; m->attn_bwd_in_chain = false; }   // (launch_chain_x3 sets them when it does the work itself)

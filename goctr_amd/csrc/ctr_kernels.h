@@ -360,7 +360,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
       }
       g_l = sigm_hidden(w_l * aw);
     }
-    if (lane < NPB * RPP && tb + lane < T) {
+    if (a.gate && lane < NPB * RPP && tb + lane < T) {      // (forward-only passes hand no gate / weight buffers: nobody reads them)
       a.gate[(size_t)b * T + tb + lane] = g_l;
       a.wgt[(size_t)b * T + tb + lane] = w_l;
     }
