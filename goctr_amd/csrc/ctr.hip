@@ -158,7 +158,8 @@ struct goctr_model {
   // `gen` counts every entry that locks the model exclusively (weights, state, workspace -- and this model's own calls), the
   // table's version its row updates; dataset and table are identified by their never-reused uids.
   uint64_t gen = 0;
-  struct H0Carry { bool valid = false; uint64_t gen = 0, ds_uid = 0, emb_uid = 0, emb_version = 0; int B = 0, stp = 0; long long batch = -1; } carry;
+  struct H0Carry { bool valid = false; uint64_t gen = 0, ds_uid = 0, emb_uid = 0, emb_version = 0; int B = 0, stp = 0; long long batch = -1;
+                   double beta1 = 0, beta2 = 0; /* (the bias corrections the last loss block left were made with these) */ } carry;
   bool attn_bwd_in_chain = false;  // launch_chain_x3 -> launch_backward: this step's chain launch wrote the att0 terms
   bool dpv_from_chain = false;    // the step's chain launch wrote dpv itself (launch_chain_x3): no dpv GEMM in this step
   DevBuf<unsigned int> emb_mark, emb_rank, emb_tiles;
@@ -178,6 +179,7 @@ struct goctr_model {
   bool ex_fixed = false; int ex_S = 0, ex_R = 0;
   DevBuf<int> ex_bucket_off, ex_send_ids, ex_recv_ids; DevBuf<long long> ex_send_rows, ex_recv_rows;
   ReduceArgs pend_ra{};            // launch_backward(stage 1) -> (stage 2)
+  bool pend_no_costs = false;      // goctr_train_steps: the caller does not read this call's costs
   bool pend_retarget = false; long long pend_batch_idx = 0, pend_n_batches = 1;   // goctr_train_steps -> run_steps' state-preparation launch
   // bucketed exchange (data parallel): bucket bounds / counts, received pairs, the owner's reduction, the gathered deltas
   DevBuf<int> ex_off, ex_cnt, ex_allcnt, ex_rids, ex_red_ids, ex_nred, ex_allnred, ex_gids;
@@ -1708,34 +1710,36 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
     if (emb_plan_ok(m, B)) { if (ensure_emb_plan(m, d, src, B) || ensure_w0pv(m)) return -1; }
     else { m->plan.valid = false; m->w0pv_live = false; }
   }
-  // the bias corrections of the state the call starts from (ctr_kernels.h: StepState::corr1/2); later states get theirs from
-  // the loss block of the step before them
-  // (one launch together with the cursor retarget of goctr_train_steps: two one-thread kernels in front of a 20-step call
-  // were ~3 us of its timed region)
-  hipLaunchKernelGGL(step_state_prepare_kernel, dim3(1), dim3(1), 0, e.stream, m->st_cur(), o.tc->beta1, o.tc->beta2,
-                     m->pend_retarget ? 1 : 0, m->pend_batch_idx, m->pend_n_batches);
   const bool have_start = m->pend_retarget;                    // the host knows the batch the call starts at
   const long long start_batch = m->pend_batch_idx, start_nb = m->pend_n_batches;
-  m->pend_retarget = false;
-  GOCTR_HIP(hipGetLastError());
   // (with a communicator and NO plan the sparse embedding exchange sizes its collectives from device counters read back by
   // the host: eager steps.  With the plan's fixed-size buckets the step is three captured graphs around the collectives.)
   const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0 && !(e.comm_active() && m->emb_lr > 0.f && !emb_split3(m));
+  if (use_graph) o.pipelined = pipeline_ok(m, src);
+  // The previous call ended exactly where this one starts and nothing happened in between (goctr_model::H0Carry): its last
+  // launch computed this call's first h0 / gates, and its last loss block left the state this call starts from -- cursor,
+  // Adam's bias corrections and all.
+  const goctr_model::H0Carry& cy = m->carry;
+  const bool retargeted = have_start;
+  const bool carried = use_graph && o.pipelined && n_steps > 0 && cy.valid && retargeted && cy.gen + 1 == m->gen && cy.ds_uid == d->uid &&
+                       emb && cy.emb_uid == emb->uid && cy.emb_version == emb->version && cy.B == B && cy.stp == m->stp &&
+                       cy.batch == start_batch && cy.beta1 == (double)o.tc->beta1 && cy.beta2 == (double)o.tc->beta2 &&
+                       env_int("GOCTR_H0_CARRY", 1) != 0;
+  // The state-preparation launch: the cursor retarget of goctr_train_steps + the bias corrections of the state the call starts
+  // from (ctr_kernels.h: StepState::corr1/2; later states get theirs from the loss block of the step before them).  A carried
+  // start needs neither -- only the cost ring would not restart at slot 0, which matters to a caller that reads the costs.
+  if (!(carried && m->pend_no_costs)) {
+    hipLaunchKernelGGL(step_state_prepare_kernel, dim3(1), dim3(1), 0, e.stream, m->st_cur(), o.tc->beta1, o.tc->beta2,
+                       m->pend_retarget ? 1 : 0, m->pend_batch_idx, m->pend_n_batches);
+    GOCTR_HIP(hipGetLastError());
+  }
+  m->pend_retarget = false;
   if (use_graph) {
-    o.pipelined = pipeline_ok(m, src);
     if (!graph_matches(m->graph, d, emb, B, o) && build_graph(m, d, emb, src, B, o)) return -1;
-    const bool retargeted = have_start;
-    if (o.pipelined && n_steps > 0) {
-      // the first step's h0: every later step gets it from its predecessor's last launch, and so does the first one when the
-      // previous call ended exactly where this one starts and nothing happened in between (goctr_model::H0Carry)
-      const goctr_model::H0Carry& cy = m->carry;
-      const bool carried = cy.valid && retargeted && cy.gen + 1 == m->gen && cy.ds_uid == d->uid && emb && cy.emb_uid == emb->uid &&
-                           cy.emb_version == emb->version && cy.B == B && cy.stp == m->stp && cy.batch == start_batch &&
-                           env_int("GOCTR_H0_CARRY", 1) != 0;
-      if (!carried) {
-        const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
-        if (launch_attn_fwd(aa)) return -1;
-      }
+    if (o.pipelined && n_steps > 0 && !carried) {
+      // the first step's h0 (every later step gets it from its predecessor's last launch)
+      const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
+      if (launch_attn_fwd(aa)) return -1;
     }
     m->carry.valid = false;
     if (m->emb_lr > 0.f && emb && n_steps > 0) ++emb->version;       // (rows are about to change: other models' carried h0 die)
@@ -1763,7 +1767,8 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
       }
     }
     if (o.pipelined && n_steps > 0 && retargeted && emb && start_nb > 0) {
-      m->carry = goctr_model::H0Carry{true, m->gen, d->uid, emb->uid, emb->version, B, m->stp, (start_batch + n_steps) % start_nb};
+      m->carry = goctr_model::H0Carry{true, m->gen, d->uid, emb->uid, emb->version, B, m->stp, (start_batch + n_steps) % start_nb,
+                                      (double)o.tc->beta1, (double)o.tc->beta2};
     }
   } else {
     if (m->emb_lr > 0.f && emb && n_steps > 0) ++emb->version;
@@ -2292,7 +2297,10 @@ int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const go
   if (check_dataset(m, d, emb)) return -1;
   const long long nb = cdiv(d->rows, cfg->batch);
   if (retarget_state(m, first_batch % nb, nb)) return -1;      // no host synchronisation on this path
-  if (run_steps(m, emb, d, cfg, n_steps)) {
+  m->pend_no_costs = costs == nullptr;
+  const int rs = run_steps(m, emb, d, cfg, n_steps);
+  m->pend_no_costs = false;
+  if (rs) {
     if (engine().comm_active()) {     // (keep this rank's error text; make the peers fail too instead of waiting in a collective)
       const std::string msg = goctr_last_error();
       comm_abort_on_failure();

@@ -220,3 +220,40 @@ def test_h0_carried_from_the_previous_call_only_when_nothing_touched_it(between)
     assert np.all(np.isfinite(res[0][1]))
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("change_betas", [False, True])
+def test_carried_start_without_costs_needs_no_state_preparation(change_betas):
+    """a carried start whose caller reads no costs also skips the state-preparation launch (the previous call's last loss
+    block left cursor and Adam bias corrections): three calls of 7 steps each, continuing, against GOCTR_H0_CARRY=0 -- and with
+    other Adam betas in the second call, which must bring the preparation back (the corrections depend on them)"""
+    from goctr_amd import capi, model as gm
+    U, T, D, Cc, V, B = 52, 50, 16, 53, 5000, 512
+    rng = np.random.default_rng(81)
+    emb, ub, it, uf, cf, Y = synth(rng, 24 * B, U, T, D, Cc, V)
+    res = []
+    for knob in (None, "0"):
+        if knob is not None:
+            os.environ["GOCTR_H0_CARRY"] = knob
+        try:
+            tab = gm.EmbeddingTable(emb)
+            ds = gm.Dataset.ids(ub, it, uf, cf, Y)
+            m = gm.DinNet(U, T, D, D, Cc)
+            r = np.random.default_rng(82)
+            m.set_weights("mlp0", (r.standard_normal((U + 2 * D + Cc, 200)) * 0.15).astype(np.float32))
+            m.set_weights("mlp1", (r.standard_normal((200, 80)) * 0.15).astype(np.float32))
+            m.set_weights("mlp2", (r.standard_normal((80, 1)) * 0.15).astype(np.float32))
+            m.set_weights("att0", (1 + 0.3 * r.standard_normal(T)).astype(np.float32))
+            cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=2, p0=0.01, p1=0.01, seed=3)
+            gm.train_steps(m, ds, cfg, 7, first_batch=0, emb=tab)
+            cfg2 = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=2, p0=0.01, p1=0.01, seed=3)
+            if change_betas:
+                cfg2.beta1, cfg2.beta2 = 0.8, 0.99
+            gm.train_steps(m, ds, cfg2, 7, first_batch=7, emb=tab)
+            last = gm.train_steps(m, ds, cfg2, 7, first_batch=14, emb=tab, want_costs=True)
+            res.append((last, m.get_weights("mlp0"), m.get_weights("mlp1"), m.get_weights("att0")))
+        finally:
+            os.environ.pop("GOCTR_H0_CARRY", None)
+    assert np.all(np.isfinite(res[0][0]))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
