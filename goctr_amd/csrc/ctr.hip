@@ -448,7 +448,9 @@ int launch_attn_fwd(const AttnArgs& a) {
   const bool vec4 = a.src.id_mode && a.D % 4 == 0;
   const int groups = vec4 ? a.D / 4 : a.D;  // lanes needed per row
   // compile-time mode for the shapes that matter (id mode, every lane owns 4 in-range columns)
-  const int fast = !(vec4 && groups * 4 == a.D && (groups & (groups - 1)) == 0) ? 0
+  // (the compile-time modes address table rows with 32-bit byte offsets: tables below 4 GB)
+  const bool small_table = (unsigned long long)(a.src.V + 1) * (unsigned long long)a.D * 4ull < (1ull << 32);
+  const int fast = !(vec4 && small_table && groups * 4 == a.D && (groups & (groups - 1)) == 0) ? 0
                    : a.kind != GOCTR_DIN ? 1 : (a.att == GOCTR_ATT_COSINE ? 2 : 3);
   if (ps.on) {   // the symbol the dispatch below selects (goctr_prof_kernel)
     static char sym[48];
@@ -772,7 +774,8 @@ int attn_fast_mode(const goctr_model* m, const RowSource& src, int* groups) {
   const bool vec4 = src.id_mode && c.D % 4 == 0;
   const int g = vec4 ? c.D / 4 : c.D;
   if (groups) *groups = g;
-  return !(vec4 && g * 4 == c.D && (g & (g - 1)) == 0) ? 0 : c.kind != GOCTR_DIN ? 1 : (c.att == GOCTR_ATT_COSINE ? 2 : 3);
+  const bool small_table = (unsigned long long)(src.V + 1) * (unsigned long long)c.D * 4ull < (1ull << 32);   // (32-bit row offsets in those kernels)
+  return !(vec4 && small_table && g * 4 == c.D && (g & (g - 1)) == 0) ? 0 : c.kind != GOCTR_DIN ? 1 : (c.att == GOCTR_ATT_COSINE ? 2 : 3);
 }
 // can the steps of a graph be pipelined (reduce_attn_kernel)?  Single GPU, fused update, the fused chain, D = 16 or 64 rows
 bool pipeline_ok(const goctr_model* m, const RowSource& src) {
@@ -2688,8 +2691,8 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   // Embedding widths with a compile-time attention variant (D = 4 .. 64, a power of two) look the keys up INSIDE attn_fwd
   // (attn_fwd_keys_kernel): a pass is two launches, and the assembled rows (behaviour ids, feature rows) never exist in
   // HBM.  Other widths, or GOCTR_SERVE_FUSE=0, assemble first.
-  const int D = m->cfg.D;
-  const bool fuse = env_int("GOCTR_SERVE_FUSE", 1) != 0 && D % 4 == 0 && D <= 64 && ((D / 4) & (D / 4 - 1)) == 0;
+  int fgroups = 0;
+  const bool fuse = env_int("GOCTR_SERVE_FUSE", 1) != 0 && attn_fast_mode(m, src, &fgroups) != 0 && fgroups <= 16;   // (D = 4 .. 64, table < 4 GB)
   if (fuse) {
     src.k_users = dus; src.k_items = dit; src.k_ts = dts; src.k_failed = dfail;
     src.ub_off = c ? c->off.p : nullptr; src.ub_items = c ? c->items.p : nullptr; src.ub_ts = c ? c->ts.p : nullptr;

@@ -161,6 +161,16 @@ __device__ __forceinline__ void load_row_nn(const float* row, int d0, int D, boo
   }
 }
 
+// a table row in the compile-time modes (FAST != 0): uniform base + a 32-bit byte offset per lane -- one multiply-add instead
+// of a 64-bit multiply and add per gathered row (17 per sample).  The host only selects those modes for tables below 4 GB
+// (ctr.hip attn_fast_mode); larger ones take the run-time-mode kernel with its 64-bit addresses.
+template <int VEC>
+__device__ __forceinline__ void load_row_off32(const float* base, int row, int D, int d0, float x[VEC]) {
+  const unsigned off = ((unsigned)row * (unsigned)D + (unsigned)d0) * 4u;
+  const float4 t4 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off);
+  x[0] = t4.x; x[1 % VEC] = t4.y; x[2 % VEC] = t4.z; x[3 % VEC] = t4.w;
+}
+
 // One wavefront per sample.  A wavefront covers RPP = 64/LPR behaviour rows per pass, LPR lanes per
 // row, VEC consecutive embedding lanes per lane (VEC=4 => one 16-byte load per lane, a 64-byte row
 // of a D=16 table is fetched by 4 adjacent lanes: fully coalesced 64 B segments).  The ids of up to
@@ -260,7 +270,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
   float vv[VEC];
   if (idm) {
     const int it = KEYS ? kitem : (valid ? s.item_ids[gr] : -1);
-    load_row_nn<VEC>(s.emb + (long long)((it >= 0 && it < s.V) ? it : s.V) * D, d0, D, full, vv);
+    if (FAST) load_row_off32<VEC>(s.emb, (it >= 0 && it < s.V) ? it : (int)s.V, D, d0, vv);
+    else load_row_nn<VEC>(s.emb + (long long)((it >= 0 && it < s.V) ? it : s.V) * D, d0, D, full, vv);
   } else {
     load_row<VEC>(valid ? s.X + gr * (long long)s.xcols + s.r_v : nullptr, d0, D, vv);
   }
@@ -290,7 +301,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
       const int t = tbx + p * RPP + rl;
       if (idm) {
         const int id = __shfl(ids64, (tbx - tb0) + p * RPP + rl, 64);
-        load_row_nn<VEC>(s.emb + (long long)((t < T && id >= 0 && id < s.V) ? id : s.V) * D, d0, D, full, xx[p]);
+        if (FAST) load_row_off32<VEC>(s.emb, (t < T && id >= 0 && id < s.V) ? id : (int)s.V, D, d0, xx[p]);
+        else load_row_nn<VEC>(s.emb + (long long)((t < T && id >= 0 && id < s.V) ? id : s.V) * D, d0, D, full, xx[p]);
       } else {
         load_row<VEC>((valid && t < T) ? s.X + gr * (long long)s.xcols + s.r_ub + t * D : nullptr, d0, D, xx[p]);
       }
