@@ -783,7 +783,14 @@ bool pipeline_ok(const goctr_model* m, const RowSource& src) {
   const int fast = attn_fast_mode(m, src, &groups);
   // (DIN: one reduce block must own the whole att0 segment -- it publishes the flag the attention workgroups wait for)
   const bool one_block = m->cfg.kind != GOCTR_DIN || (m->offa * 2) / 256 == ((m->offa + m->Tp) * 2 - 1) / 256;
-  return fast != 0 && (groups == 4 || groups == 16) && one_block && chain_ok(m) && !engine().comm_active() &&
+  if (engine().comm_active()) {
+    // data parallel (dense all-reduce only): the part behind the collective -- Adam -- shares its launch with the next step's
+    // attention (adam_attn_kernel); one 256-parameter Adam block must own the att0 segment
+    const bool one_adam_block = m->cfg.kind != GOCTR_DIN || m->offa / 256 == (m->offa + m->Tp - 1) / 256;
+    return fast != 0 && (groups == 4 || groups == 16) && one_adam_block && chain_ok(m) && m->emb_lr <= 0.f &&
+           env_int("GOCTR_PIPELINE", 1) != 0 && env_int("GOCTR_PIPELINE_DP", 1) != 0;
+  }
+  return fast != 0 && (groups == 4 || groups == 16) && one_block && chain_ok(m) &&
          env_int("GOCTR_FUSED_UPDATE", 1) != 0 && env_int("GOCTR_PIPELINE", 1) != 0;
 }
 
@@ -1510,6 +1517,32 @@ int launch_adam(goctr_model* m, int B, const goctr_train_cfg& tc) {
   return 0;
 }
 
+// the Adam launch of a step whose reduce and update are separate launches (data parallel: the all-reduce sits between them);
+// pipelined: merged with the NEXT step's attention (adam_attn_kernel) -- state and parity are already the new step's
+int launch_adam_step(goctr_model* m, const RowSource& src, int B, const StepOpts& o) {
+  if (!(o.pipelined && engine().comm_active())) return launch_adam(m, B, *o.tc);
+  int groups = 0;
+  const int fast = attn_fast_mode(m, src, &groups);
+  const AdamArgs ad = make_adam_args(m, B, *o.tc);
+  const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
+  const int nadam = (int)cdiv(m->nflat, 256) + 1;
+  const int ra_block = m->cfg.kind == GOCTR_DIN ? m->offa / 256 : -1;
+  const dim3 grid((unsigned)(nadam + cdiv(B, 4))), blk(256);
+  hipStream_t st = engine().active;
+  ProfScope ps(GOCTR_K_ADAM);
+#define GOCTR_AA(L)                                                                                                       \
+  do {                                                                                                                    \
+    if (fast == 1) hipLaunchKernelGGL((adam_attn_kernel<4, L, 1>), grid, blk, 0, st, ad, m->ra_flag.p, ra_block, aa, nadam);       \
+    else if (fast == 2) hipLaunchKernelGGL((adam_attn_kernel<4, L, 2>), grid, blk, 0, st, ad, m->ra_flag.p, ra_block, aa, nadam);  \
+    else hipLaunchKernelGGL((adam_attn_kernel<4, L, 3>), grid, blk, 0, st, ad, m->ra_flag.p, ra_block, aa, nadam);                 \
+  } while (0)
+  if (groups == 4) GOCTR_AA(4);
+  else GOCTR_AA(16);
+#undef GOCTR_AA
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
 int allreduce_grads(goctr_model* m) {
   if (!engine().comm_active()) return 0;
   ProfScope ps(GOCTR_K_ALLREDUCE);
@@ -1572,7 +1605,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
     if (e.comm_active()) {
       hipGraph_t g2 = nullptr;
       GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-      rc = (split3 && emb_exchange_apply(m, src)) || launch_adam(m, B, *o.tc);     // m->stp was flipped by launch_backward: Adam reads the new slot
+      rc = (split3 && emb_exchange_apply(m, src)) || launch_adam_step(m, src, B, o);     // m->stp was flipped by launch_backward: Adam reads the new slot
       ce = hipStreamEndCapture(e.stream, &g2);
       if (rc) { if (g2) (void)hipGraphDestroy(g2); m->stp = stp_now; return -1; }
       GOCTR_HIP(ce);

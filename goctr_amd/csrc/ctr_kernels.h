@@ -909,6 +909,52 @@ __global__ __launch_bounds__(256) void reduce_attn_kernel(ReduceAdamArgs p, Attn
   attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x - nred, nb, a.att0, FAST >= 2 ? &ctx : nullptr);
 }
 
+// The data-parallel step's counterpart of reduce_attn_kernel: the step is [.. reduce] -> all-reduce -> [Adam], and what can share
+// a launch with the next step's attention is the part BEHIND the collective.  Blocks [0, nadam) are adam_kernel's (the reduce
+// has already advanced the state: `ad.st` is the NEW state, whose cursor is the batch the attention part gathers), the att0
+// block trades places with block 0 and publishes the new state's gstep once its weights are out, exactly like the reduce
+// block of reduce_attn_kernel.  Same arithmetic as adam_kernel + attn_fwd_kernel: tests/test_gpu_comm.py holds the
+// data-parallel path (one-rank communicator) to the single-GPU path's bits.
+template <int VEC, int LPR, int FAST>
+__global__ __launch_bounds__(256) void adam_attn_kernel(AdamArgs ad, unsigned int* ra_flag, int ra_block, AttnArgs a, int nadam) {
+  const int bi = (int)blockIdx.x;
+  if (bi < nadam) {
+    const int blk = ra_block < 0 ? bi : (bi == 0 ? ra_block : (bi == ra_block ? 0 : bi));
+    if (blk == nadam - 1) {                      // (adam_kernel's extra block: the new state's own bias corrections)
+      if (threadIdx.x == 0) {
+        StepState* w = const_cast<StepState*>(ad.st);
+        StepState t = *w;
+        state_corrections(t, ad.beta1, ad.beta2);
+        w->corr1 = t.corr1; w->corr2 = t.corr2;
+      }
+      return;
+    }
+    const int idx = blk * 256 + threadIdx.x;
+    const float c1 = ad.st->pcorr1, c2 = ad.st->pcorr2;
+    if (idx == 0) {
+      const float sum = ad.G[ad.nflat];
+      ad.costs[(ad.st->slot - 1u) % COST_RING] = -(sum / (float)ad.bglobal);  // cost.go:15 Neg(Mean(...))
+    }
+    if (idx < ad.nflat) {
+      const float g = ad.G[idx];
+      ad.G[idx] = 0.f;
+      adam_apply(ad, idx, g, c1, c2);
+    }
+    if (blk == ra_block) {                       // (see reduce_adam_body: write-through repeats of the own stores, then the flag)
+      if (idx < ad.nflat) {
+        const float wn = ad.W[idx];
+        __hip_atomic_store(ad.W + idx, wn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      if (threadIdx.x == 0) __hip_atomic_store(ra_flag, ad.st->gstep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  const RaCtx ctx{ra_flag, ad.st->gstep, a.att0};
+  attn_fwd_body<VEC, LPR, FAST>(a, bi - nadam, ad.st->batch_idx, a.att0, FAST >= 2 ? &ctx : nullptr);
+}
+
 // ---------------------------------------------------------------- standalone gather (bit-exact)
 struct GatherArgs {
   const float* emb; long long V; int D, T, U, C;
