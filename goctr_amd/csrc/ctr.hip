@@ -50,6 +50,9 @@ struct StepGraph {
   // b[] only when a communicator splits the step (all-reduce between reduce and Adam).
   hipGraphExec_t a[2] = {nullptr, nullptr}, b[2] = {nullptr, nullptr};
   hipGraphExec_t mid[2] = {nullptr, nullptr};   // data parallel + trainable embeddings: owner side of the sparse exchange + slab reduce
+  // ba[p]: b[p] and the NEXT step's a[p ^ 1] as one graph (dense all-reduce only): a step inside a call is then all-reduce +
+  // ONE graph launch instead of two -- every boundary between host-issued items costs the GPU ~4 us
+  hipGraphExec_t ba[2] = {nullptr, nullptr};
   // multi[p]: multi_steps (even) consecutive steps starting at parity p in ONE graph (single GPU): the boundary between
   // two graph launches costs about two kernel-to-kernel edges; every per-step scalar is device state, so nothing else changes
   // (built together with a[]: a first call in a timed region must not pay for a capture)
@@ -68,7 +71,7 @@ struct StepGraph {
     // exec in flight is not something HIP documents as safe.  The capture that follows a destroy is host-heavy anyway.
     bool any = false;
     for (int k = 0; k < 2; ++k) {
-      any = any || a[k] || b[k] || mid[k];
+      any = any || a[k] || b[k] || mid[k] || ba[k];
       for (int z = 0; z < kNMulti; ++z) any = any || multi[z][k];
     }
     if (any && engine().inited) (void)hipStreamSynchronize(engine().stream);
@@ -76,8 +79,9 @@ struct StepGraph {
       if (a[k]) (void)hipGraphExecDestroy(a[k]);
       if (b[k]) (void)hipGraphExecDestroy(b[k]);
       if (mid[k]) (void)hipGraphExecDestroy(mid[k]);
+      if (ba[k]) (void)hipGraphExecDestroy(ba[k]);
       for (int z = 0; z < kNMulti; ++z) { if (multi[z][k]) (void)hipGraphExecDestroy(multi[z][k]); multi[z][k] = nullptr; }
-      a[k] = b[k] = mid[k] = nullptr;
+      a[k] = b[k] = mid[k] = ba[k] = nullptr;
     }
     multi_on = false;
   }
@@ -1612,6 +1616,18 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
       GOCTR_HIP(hipGraphInstantiate(&m->graph.b[par], g2, nullptr, nullptr, 0));
       (void)hipGraphUpload(m->graph.b[par], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
       (void)hipGraphDestroy(g2);
+      if (!split3 && env_int("GOCTR_DP_JOIN_GRAPHS", 1) != 0) {
+        // b[par] + the next step's a (parity par ^ 1, where m->stp stands now): launch_backward flips m->stp back to par
+        hipGraph_t g3 = nullptr;
+        GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+        rc = launch_adam_step(m, src, B, o) || launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, false, 0);
+        ce = hipStreamEndCapture(e.stream, &g3);
+        if (rc) { if (g3) (void)hipGraphDestroy(g3); m->stp = stp_now; return -1; }
+        GOCTR_HIP(ce);
+        GOCTR_HIP(hipGraphInstantiate(&m->graph.ba[par], g3, nullptr, nullptr, 0));
+        (void)hipGraphUpload(m->graph.ba[par], e.stream);
+        (void)hipGraphDestroy(g3);
+      }
     }
   }
   m->stp = stp_now;
@@ -1786,6 +1802,17 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
       for (int z = 0; z < StepGraph::kNMulti; ++z) {   // even step counts: the parity is the same after each launch
         const int sz = m->graph.kMulti[z];
         for (; sz >= 2 && s + sz <= n_steps; s += sz) GOCTR_HIP(hipGraphLaunch(m->graph.multi[z][m->stp], e.stream));
+      }
+    }
+    if (e.comm_active() && m->graph.ba[0] && m->graph.ba[1] && s < n_steps) {
+      // dense data parallel: a(0) | all-reduce | [b(0) a(1)] | all-reduce | ... | [b(n-2) a(n-1)] | all-reduce | b(n-1)
+      int par = m->stp;
+      GOCTR_HIP(hipGraphLaunch(m->graph.a[par], e.stream));
+      for (; s < n_steps; ++s) {
+        m->stp ^= 1;
+        if (allreduce_grads(m)) return -1;
+        if (s + 1 < n_steps) { GOCTR_HIP(hipGraphLaunch(m->graph.ba[par], e.stream)); par ^= 1; }
+        else GOCTR_HIP(hipGraphLaunch(m->graph.b[par], e.stream));
       }
     }
     for (; s < n_steps; ++s) {
