@@ -24,40 +24,44 @@ if %(comm)d:
     capi.check(L.goctr_comm_unique_id(idbuf))
     capi.check(L.goctr_comm_init(C.c_int(0), C.c_int(1), idbuf))
 rng = np.random.default_rng(5)
-rows, U, T, D, Cc, V = 4096, 52, 50, 16, 53, 500
+rows, U, T, D, Cc, V = 4096, 52, 50, %(D)d, 53, 500
 emb = (rng.standard_normal((V, D)) * 0.25).astype(np.float32)
 ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
 it = rng.integers(0, V, size=rows).astype(np.int32)
 uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
 y = (rng.random(rows) < 0.5).astype(np.float32)
 tab = gm.EmbeddingTable(emb); ds = gm.Dataset.ids(ub, it, uf, cf, y)
-m = gm.DinNet(U, T, D, D, Cc).init_gaussian(np.random.default_rng(1))
+m = (gm.YoutubeDnn if %(youtube)d else gm.DinNet)(U, T, D, D, Cc).init_gaussian(np.random.default_rng(1))
 cfg = capi.default_train_cfg(batch=1024, epochs=1, dropout_mode=0)
 gm.train_steps(m, ds, cfg, 7, emb=tab)          # odd count: both graph parities are replayed
+gm.train_steps(m, ds, cfg, 4, first_batch=3, emb=tab)   # a second call that continues where the first ended (7 %% 4 batches)
 capi.sync()
-out = np.concatenate([m.get_weights(n).ravel() for n in ("mlp0", "mlp1", "mlp2", "att0")])
+out = np.concatenate([m.get_weights(n).ravel() for n in (("mlp0", "mlp1", "mlp2") if %(youtube)d else ("mlp0", "mlp1", "mlp2", "att0"))])
 np.save(%(out)r, out)
 if %(comm)d:
     capi.check(L.goctr_comm_destroy())
 '''
 
 
-def run(tmp_path, comm, graph):
-    out = str(tmp_path / f"w_{comm}_{graph}.npy")
+def run(tmp_path, comm, graph, youtube=False):
+    out = str(tmp_path / f"w_{comm}_{graph}_{youtube}.npy")
     env = dict(os.environ)
     env["GOCTR_FORCE_COMM"] = "1" if comm else "0"
     if not graph:
         env["GOCTR_NO_GRAPH"] = "1"
-    r = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT, comm=int(comm), out=out)], env=env,
+    r = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT, comm=int(comm), out=out, youtube=int(youtube),
+                                                            D=64 if youtube else 16)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(out)
 
 
-@pytest.mark.parametrize("graph", [True, False])
-def test_one_rank_communicator_equals_fused_path(tmp_path, graph):
-    ref = run(tmp_path, comm=False, graph=graph)
-    got = run(tmp_path, comm=True, graph=graph)
+@pytest.mark.parametrize("graph,youtube", [(True, False), (False, False), (True, True)])
+def test_one_rank_communicator_equals_fused_path(tmp_path, graph, youtube):
+    """(graph: the data-parallel step is pipelined -- adam_attn_kernel, b(n) + a(n + 1) as one graph -- and the second call is a
+    carried start; DIN with its att0 hand-over and YouTube-DNN, whose attention does not depend on the weights)"""
+    ref = run(tmp_path, comm=False, graph=graph, youtube=youtube)
+    got = run(tmp_path, comm=True, graph=graph, youtube=youtube)
     assert np.isfinite(ref).all() and np.abs(ref).max() > 0
     assert np.array_equal(ref, got)
 
