@@ -2733,7 +2733,7 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   }
   // Small passes read the keys and write the scores straight through the pinned staging buffers (device-visible host
   // memory: 16 B in and 5 B out per row over PCIe from inside the kernels) -- no copy commands on the stream at all, a pass
-  // is three launches and one wait.  Larger passes keep the two DMA copies (GOCTR_SERVE_ZEROCOPY=rows, default 4096; 0 = never).
+  // is one launch (ctr_serve16_kernel) and one wait.  Larger passes keep the two DMA copies (GOCTR_SERVE_ZEROCOPY=rows, default 4096; 0 = never).
   const bool zc = N <= (int64_t)env_int("GOCTR_SERVE_ZEROCOPY", 4096);
   if (!zc) GOCTR_HIP(hipMemcpyAsync(s->d_in.p, s->h_in, (size_t)N * 16, hipMemcpyHostToDevice, s->stream));
   if (serve_wait_weights(m, s)) return -1;
@@ -2749,8 +2749,8 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   RowSource src{};
   src.rows = N; src.id_mode = 1; src.emb = r->emb->rows.p; src.V = r->emb->V;
   // Embedding widths with a compile-time attention variant (D = 4 .. 64, a power of two) look the keys up INSIDE attn_fwd
-  // (attn_fwd_keys_kernel): a pass is two launches, and the assembled rows (behaviour ids, feature rows) never exist in
-  // HBM.  Other widths, or GOCTR_SERVE_FUSE=0, assemble first.
+  // (attn_fwd_keys_kernel, or the whole pass as ctr_serve16_kernel): the assembled rows (behaviour ids, feature rows) never
+  // exist in HBM.  Other widths, tables of 4 GB and more, or GOCTR_SERVE_FUSE=0, assemble first.
   int fgroups = 0;
   const bool fuse = env_int("GOCTR_SERVE_FUSE", 1) != 0 && attn_fast_mode(m, src, &fgroups) != 0 && fgroups <= 16;   // (D = 4 .. 64, table < 4 GB)
   if (fuse) {
