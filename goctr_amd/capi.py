@@ -30,7 +30,7 @@ class TrainCfg(C.Structure):
     _fields_ = [("batch", C.c_int), ("epochs", C.c_int), ("early_stop", C.c_int), ("lr", C.c_double),
                 ("l2", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("adam_div_by_batch", C.c_int), ("adam_l2_before_batch_div", C.c_int), ("dropout_mode", C.c_int),
-                ("p0", C.c_float), ("p1", C.c_float), ("seed", C.c_uint32)]
+                ("p0", C.c_float), ("p1", C.c_float), ("seed", C.c_uint32), ("devices", C.c_int)]
 
 
 class MlpCfg(C.Structure):
@@ -50,9 +50,9 @@ class W2vCfg(C.Structure):
 
 # every symbol include/goctr.h declares (tests/test_capi_symbols.py checks the list against the header)
 SYMBOLS = [
-    "goctr_init", "goctr_device_count", "goctr_sync", "goctr_last_error", "goctr_version", "goctr_device_info",
+    "goctr_init", "goctr_init_devices", "goctr_engine_count", "goctr_engine_select", "goctr_comm_group_enable", "goctr_device_count", "goctr_sync", "goctr_last_error", "goctr_version", "goctr_device_info",
     "goctr_comm_unique_id", "goctr_comm_init", "goctr_comm_world", "goctr_comm_allreduce_f64", "goctr_comm_destroy",
-    "goctr_model_create", "goctr_model_destroy", "goctr_model_set_weights", "goctr_model_get_weights",
+    "goctr_model_replica", "goctr_emb_replica", "goctr_model_create", "goctr_model_destroy", "goctr_model_set_weights", "goctr_model_get_weights",
     "goctr_model_reset_optimizer", "goctr_model_get_moments", "goctr_model_set_moments", "goctr_model_get_step",
     "goctr_model_set_step", "goctr_model_set_embedding_training", "goctr_model_sparse_exchange_bytes", "goctr_emb_get_rows", "goctr_train_cfg_default", "goctr_train_dense", "goctr_predict_dense",
     "goctr_loss_grad_dense", "goctr_emb_create", "goctr_emb_set_rows", "goctr_emb_destroy", "goctr_gather_rows",
@@ -121,10 +121,39 @@ def init(device: int | None = None):
     global _inited
     L = load()
     if device is None:
+        if _inited:                 # (already bound -- possibly by init_devices)
+            return L
         device = int(os.environ.get("LOCAL_RANK", "0"))
     check(L.goctr_init(C.c_int(device)))
     _inited = True
     return L
+
+
+def init_devices(device_ids):
+    """goctr_init_devices: ONE process drives len(device_ids) ranks (engine k on HIP device device_ids[k]); a repeated device
+    id gives several logical ranks on that device joined by the loop-back communicator.  Training calls with
+    ``cfg.devices = len(device_ids)`` then run data-parallel inside one call."""
+    global _inited
+    L = load()
+    ids = (C.c_int * len(device_ids))(*[int(x) for x in device_ids])
+    check(L.goctr_init_devices(C.c_int(len(device_ids)), ids))
+    _inited = True
+    return L
+
+
+def engine_count() -> int:
+    n = C.c_int(0)
+    check(load().goctr_engine_count(C.byref(n)))
+    return n.value
+
+
+def engine_select(k: int):
+    """bind the calling thread to engine k for the handles it creates (tools / tests)"""
+    check(load().goctr_engine_select(C.c_int(k)))
+
+
+def comm_group_enable(on: bool = True):
+    check(load().goctr_comm_group_enable(C.c_int(1 if on else 0)))
 
 
 def device_count() -> int:

@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -34,9 +36,28 @@ void set_error(const char* fmt, ...);
     }                                     \
   } while (0)
 
+struct LoopGroup;   // loop-back communicator shared by the engines of one goctr_init_devices group (comm.hip)
+
+// One ENGINE = one logical rank: a HIP device binding with its own streams, device arena, lock, profiler and communicator
+// slot.  A process holds one engine (goctr_init: one process per GPU, the launcher path) or several (goctr_init_devices:
+// one process drives n ranks from n host threads -- distinct devices over RCCL, or several logical ranks on ONE device over
+// the loop-back communicator).  Every handle (goctr_model, goctr_emb, ...) remembers the engine it was created on; an entry
+// point that takes a handle runs on the handle's engine whatever thread calls it (EngineScope below).
 struct Engine {
+  int index = 0;                  // position in the process' engine list (= the rank goctr_init_devices gave it)
   bool inited = false;
   int device = -1;
+  std::recursive_mutex mu;        // GOCTR_ENTER: calls that queue work on this engine's main stream are serialised
+  // device arena (engine.hip): ONE large hipMalloc per engine, first-fit free list
+  struct Arena {
+    char* base = nullptr;
+    size_t size = 0;
+    std::map<size_t, size_t> free_blocks;   // offset -> length
+    std::map<size_t, size_t> used;          // offset -> length
+    std::mutex mu;
+  } arena;
+  bool kernel_attrs_done = false, mlp_attrs_done = false;   // hipFuncSetAttribute is per device: once per engine
+  void* serve_pool = nullptr;     // ctr.hip: this engine's serving slots (streams + pinned staging live on its device)
   int compute_units = 0;
   hipStream_t stream = nullptr;   // the engine's main stream
   hipStream_t side = nullptr;     // forked inside captured step graphs for independent kernels
@@ -50,9 +71,17 @@ struct Engine {
   // data-parallel communicator (comm.hip)
   int rank = 0, world = 1;
   void* nccl_comm = nullptr;
+  LoopGroup* loop = nullptr;      // loop-back communicator (several logical ranks of one process, comm.hip)
   // true when the step must take the split path (reduce -> all-reduce -> Adam): world > 1, or a one-rank
   // communicator forced with GOCTR_FORCE_COMM=1 (exercises the RCCL path on a single-GPU box)
-  bool comm_active() const { return nccl_comm != nullptr; }
+  // A goctr_init_devices group's communicator takes part only in calls that run on ALL its ranks (the single-call multi-device
+  // entries switch it on for their duration, goctr_comm_group_enable for explicit per-rank threads): a plain call on one engine
+  // of the group is a single-device call.  goctr_comm_init's communicator (one process per GPU) is always on.
+  bool comm_enabled = true;
+  bool comm_active() const { return (nccl_comm != nullptr || loop != nullptr) && comm_enabled; }
+  // rank / world of the CALL in flight: a group engine running a single-device call is rank 0 of 1
+  int eff_rank() const { return comm_active() ? rank : 0; }
+  int eff_world() const { return comm_active() ? world : 1; }
   // profiling
   bool prof = false;
   double prof_ms[GOCTR_K_COUNT] = {0};
@@ -62,19 +91,43 @@ struct Engine {
   std::vector<Pending> pending;
   std::vector<hipEvent_t> event_pool;
 };
+// the engine the CALLING THREAD is bound to: the one an EngineScope switched to, else the thread's selection
+// (goctr_engine_select), else the process' first engine
 Engine& engine();
-int require_engine();  // 0 if goctr_init succeeded, else sets the error and returns -1
+Engine* engine_at(int k);     // k-th engine of the process, or nullptr
+int engine_count();           // engines created so far (>= 1)
+Engine* engine_create();      // appends an (un-initialised) engine; engine.hip
+int engine_bind(Engine& e, int device_ordinal);   // hipSetDevice + streams + events (what goctr_init does for engine 0)
+int require_engine();  // 0 if the calling thread's engine is bound to a device, else sets the error and returns -1
 
-// Every C-ABI entry point that queues work on the engine's MAIN stream (training, uploads, dataset builds, the captured
-// step graphs) starts with GOCTR_ENTER(): those calls are serialised engine-wide, whatever handles they use.  Recursive:
-// entry points call each other (goctr_train_dense -> goctr_dataset_create_dense -> ...).
+// Binds the calling thread to `e` (null: keep the thread's current engine) for the scope: engine() returns it and the
+// thread's HIP device is e's device (hipSetDevice is per host thread).
+struct EngineScope {
+  Engine* prev;
+  explicit EngineScope(Engine* e);
+  ~EngineScope();
+};
+template <class H> inline Engine* handle_engine(const H* h) { return h ? h->eng : nullptr; }
+// run fn(rank) for rank = 0 .. n-1, each on a host thread bound to engine rank (rank 0 on the calling thread); returns -1
+// and the first failing rank's error text if any rank failed.  The ranks may block on each other (collectives).
+int run_on_engines(int n, const std::function<int(int)>& fn);
+
+// Every C-ABI entry point that queues work on an engine's MAIN stream (training, uploads, dataset builds, the captured
+// step graphs) starts with GOCTR_ENTER() / GOCTR_ENTER_H(handle): those calls are serialised per engine, whatever handles
+// they use.  Recursive: entry points call each other (goctr_train_dense -> goctr_dataset_create_dense -> ...).
 // The serving entry points (goctr_batch_predict / goctr_rank / goctr_predict_dense: what concurrent gin handler goroutines
-// call, recommend/api.go:106-131) do NOT take it: each runs on a serving slot with its own stream, staging buffers and
+// call, recommend/api.go:106-131) do NOT take the lock: each runs on a serving slot with its own stream, staging buffers and
 // forward workspace (ctr.hip: ServeSlot) under a shared lock of the model.
-std::recursive_mutex& engine_mutex();
-#define GOCTR_ENTER()                              \
-  if (::goctr::require_engine()) return -1;        \
-  std::lock_guard<std::recursive_mutex> _goctr_engine_lock(::goctr::engine_mutex())
+#define GOCTR_ENTER_ON(eng_ptr)                                   \
+  ::goctr::EngineScope _goctr_engine_scope(eng_ptr);              \
+  if (::goctr::require_engine()) return -1;                       \
+  std::lock_guard<std::recursive_mutex> _goctr_engine_lock(::goctr::engine().mu)
+#define GOCTR_ENTER() GOCTR_ENTER_ON(nullptr)
+// entry points that take a handle run on the handle's engine
+#define GOCTR_ENTER_H(h) GOCTR_ENTER_ON(::goctr::handle_engine(h))
+// two handles of one call must live on the same engine
+#define GOCTR_SAME_ENGINE(a, b) \
+  GOCTR_CHECK(!(a) || !(b) || (a)->eng == (b)->eng, "%s: the handles were created on different engines (devices)", __func__)
 
 // generation ids for handles whose device pointers get baked into captured graphs (a freed handle's host address may be
 // handed out again by malloc; its uid never is)
@@ -101,24 +154,26 @@ inline void prof_note_kernel(int id, const char* symbol) { engine().prof_kernel[
 // Device memory comes from ONE large hipMalloc'd arena (first-fit free list) so that every buffer of
 // the engine sits in the same 2 MiB-fragment mapping (few TLB entries) instead of dozens of small
 // separately-mapped allocations.  Requests that do not fit fall back to a plain hipMalloc.
-void* arena_alloc(size_t bytes);
-void arena_free(void* p);
+void* arena_alloc(size_t bytes);              // from the calling thread's engine
+void arena_free(Engine* owner, void* p);      // back to the engine it came from (any thread)
 
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  Engine* owner = nullptr;     // the engine whose arena p came from
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) arena_free(p);
+    if (p) arena_free(owner, p);
     p = nullptr; n = 0;
   }
   int alloc(size_t count, bool zero = true) {
     release();
     if (count == 0) count = 1;
+    owner = &engine();
     p = static_cast<T*>(arena_alloc(count * sizeof(T)));
     if (!p) return -1;
     n = count;
@@ -141,7 +196,9 @@ struct DevBuf {
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// collective hook (comm.hip): in-place sum over ranks on the engine stream; no-op when world == 1
+// collective hooks (comm.hip), on the calling thread's engine: RCCL (one process per GPU, or one process with one engine
+// per distinct device) or the loop-back communicator (several logical ranks of one process; any device list).
+// in-place sum over ranks on the engine stream; no-op when world == 1
 int comm_allreduce_f32(float* dev, size_t n);
 int comm_allreduce_f64_dev(double* dev, size_t n);
 // a rank whose data-parallel call failed between collectives aborts the communicator so that its peers fail too instead of hanging
@@ -150,5 +207,15 @@ void comm_abort_on_failure();
 int comm_allgather_i32(const int* send, int* recv, size_t n);
 int comm_alltoallv(const void* send, const size_t* send_off, const size_t* send_cnt, void* recv, const size_t* recv_off,
                    const size_t* recv_cnt, int bytes_per_elem);
+// root's buffer to every rank (replica set-up of the single-call multi-device entry)
+int comm_broadcast(void* dev, size_t bytes, int root);
+// waits for the engine stream like hipStreamSynchronize, but behind RCCL collectives it polls the communicator's asynchronous
+// error state and a timeout: a peer that failed or died makes this rank's call fail instead of hanging
+int comm_watch_stream();
+// a goctr_init_devices group before a new multi-rank call: clears the loop-back barrier's abort flag (every rank of the
+// previous call has returned -- run_on_engines serialises the calls); fails if an RCCL group communicator was aborted
+int comm_group_reset();
+// true when a captured graph may hold this engine's collectives (RCCL: yes; loop-back: host barriers, never)
+bool comm_capturable();
 
 }  // namespace goctr

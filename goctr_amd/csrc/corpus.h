@@ -7,6 +7,7 @@
 #include "common.h"
 
 struct goctr_corpus {
+  goctr::Engine* const eng = &goctr::engine();   // the engine (device, streams, arena) the handle was created on
   int64_t capacity = 0;
   int64_t n_words = 0;      // Corpus.Len() = maxLen: every word read, filtered or not
   int64_t V = 0;            // Dictionary.Len()

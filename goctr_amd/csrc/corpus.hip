@@ -121,7 +121,7 @@ int goctr_corpus_create(int64_t capacity_words, goctr_corpus** out) {
 void goctr_corpus_destroy(goctr_corpus* c) { delete c; }
 
 int goctr_corpus_append(goctr_corpus* c, const int64_t* keys, int64_t n) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(c);
   GOCTR_CHECK(c && (keys || n == 0) && n >= 0, "goctr_corpus_append: bad arguments");
   std::lock_guard<std::mutex> lk(c->mu);
   GOCTR_CHECK(c->n_words + n <= c->capacity, "goctr_corpus_append: %lld + %lld words exceed the capacity %lld",
@@ -134,7 +134,7 @@ int goctr_corpus_append(goctr_corpus* c, const int64_t* keys, int64_t n) {
 }
 
 int goctr_corpus_build(goctr_corpus* c, int64_t min_count, int64_t max_count) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(c);
   GOCTR_CHECK(c, "goctr_corpus_build: null corpus");
   std::lock_guard<std::mutex> lk(c->mu);
   GOCTR_CHECK(c->n_words > 0, "goctr_corpus_build: empty corpus");
@@ -188,7 +188,7 @@ int goctr_corpus_info(goctr_corpus* c, int64_t* n_words, int64_t* V, int64_t* n_
 }
 
 int goctr_corpus_get_dictionary(goctr_corpus* c, int64_t* id2key, int64_t* cfs) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(c);
   GOCTR_CHECK(c, "goctr_corpus_get_dictionary: null corpus");
   std::lock_guard<std::mutex> lk(c->mu);
   GOCTR_CHECK(c->built, "goctr_corpus_get_dictionary: call goctr_corpus_build first");
@@ -198,7 +198,7 @@ int goctr_corpus_get_dictionary(goctr_corpus* c, int64_t* id2key, int64_t* cfs) 
 }
 
 int goctr_corpus_get_doc(goctr_corpus* c, int32_t* idoc, int32_t* indexed) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(c);
   GOCTR_CHECK(c, "goctr_corpus_get_doc: null corpus");
   std::lock_guard<std::mutex> lk(c->mu);
   GOCTR_CHECK(c->built, "goctr_corpus_get_doc: call goctr_corpus_build first");

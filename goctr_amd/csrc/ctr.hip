@@ -27,13 +27,18 @@
 using namespace goctr;
 
 struct goctr_emb {
+  goctr::Engine* const eng = &goctr::engine();   // the engine (device, streams, arena) the handle was created on
   const uint64_t uid = next_uid();   // what a captured step graph is keyed on (never reused, unlike the host address)
   uint64_t version = 0;              // bumped whenever rows change (goctr_emb_set_rows, embedding training): H0Carry is keyed on it
   int64_t V = 0; int D = 0;
   DevBuf<float> rows;
+  // single-call multi-device training (goctr_train_cfg::devices): this table's replicas on engines 1 .. n-1 (owned), and the
+  // version of THIS table they were last made equal to
+  std::vector<goctr_emb*> reps; uint64_t reps_version = ~0ull;
 };
 
 struct goctr_dataset {
+  goctr::Engine* const eng = &goctr::engine();   // the engine (device, streams, arena) the handle was created on
   const uint64_t uid = next_uid();
   bool id_mode = false;
   int64_t rows = 0;
@@ -43,6 +48,10 @@ struct goctr_dataset {
   // ids
   DevBuf<int32_t> ub_ids, item_ids; DevBuf<float> ufeat, cfeat; int U = 0, C = 0, T = 0;
   DevBuf<float> Y;
+  // single-call multi-device training: shards[r] (on engine r, owned) holds rank r's rows of every global batch of shard_B rows,
+  // batch-major, the short last batch zero-padded (model.go:357-371) -- local batch k of rank r = rows [r, r+1) * shard_B / n of
+  // global batch k
+  std::vector<goctr_dataset*> shards; int shard_B = 0;
 };
 
 struct StepGraph {
@@ -113,6 +122,7 @@ struct FwdWs {
 };
 
 struct goctr_model {
+  goctr::Engine* const eng = &goctr::engine();   // the engine (device, streams, arena) the handle was created on
   goctr_ctr_cfg cfg{};
   int I = 0, Ip = 0, H1p = 0, H2p = 0, Dp = 0, Tp = 0;
   int off1 = 0, off2 = 0, offa = 0, nflat = 0;
@@ -191,6 +201,9 @@ struct goctr_model {
   DevBuf<float> ex_delta, ex_gdelta;
   DevBuf<unsigned long long> ex_red_total;
   double ex_bytes_last = 0;       // bytes this rank SENT in the last step's exchange
+  // single-call multi-device training: replicas on engines 1 .. n-1 (owned; reps[0] unused) and this model's `gen` after the
+  // last call that left them bit-identical to it (anything else that locked the model since then forces a re-broadcast)
+  std::vector<goctr_model*> reps; uint64_t reps_gen = ~0ull;
 };
 
 namespace {
@@ -427,7 +440,7 @@ int launch_tn(int kid, const float* A, int lda, int KT, const float* Dm, int ldd
 
 // opt every GEMM instantiation into > 64 KiB of dynamic LDS up front (never inside a stream capture)
 int init_kernel_attrs() {
-  static bool done = false;
+  bool& done = engine().kernel_attrs_done;     // (function attributes are per device)
   if (done) return 0;
 #define GOCTR_NN_ATTR(E) (allow_big_lds(gemm_nn_kernel<float, E, 1>) || allow_big_lds(gemm_nn_kernel<float, E, 3>) || \
                           allow_big_lds(gemm_nn_kernel<float, E, 4>) || allow_big_lds(gemm_nn_kernel<float, E, 7>) || \
@@ -608,7 +621,7 @@ bool emb_plan_active(const goctr_model* m) { return m->emb_lr > 0.f && m->plan.v
 int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st, const FwdBufs& fb) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
-  const uint32_t row_off = (uint32_t)(e.rank * B);
+  const uint32_t row_off = (uint32_t)(e.eff_rank() * B);
   const bool drop = o.drop_mode == 2;
   const CxImages im = m->x3_images();
   ChainX3Args a{};
@@ -617,7 +630,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   a.H1 = c.H1; a.H2 = c.H2; a.H1p = m->H1p; a.H2p = m->H2p; a.Dp = m->Dp; a.B = B; a.kind = c.kind;
   a.d0 = DropCfg{drop && o.p0 > 0 ? 2 : 0, o.p0, nullptr, c.H1, o.seed, 0u, row_off};
   a.d1 = DropCfg{drop && o.p1 > 0 ? 2 : 0, o.p1, nullptr, c.H2, o.seed, 1u, row_off};
-  a.st = st; a.Y = src.Y; a.rows = src.rows; a.inv_bglobal = 1.0f / (float)(B * e.world);
+  a.st = st; a.Y = src.Y; a.rows = src.rows; a.inv_bglobal = 1.0f / (float)(B * e.eff_world());
   a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;   // (forward only: none of these is touched)
   // trainable embeddings, DIN, 2 D <= 32: the 32-wide dp product of this kernel also yields d cost / d candidate-item segment
   // (IMG3 holds W0[U : U+2D]^T) -- it writes dpv = [dp | dvh] itself and the step needs no GEMM launch for it (6.9 us at cfg3)
@@ -671,7 +684,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
 ChainArgs make_chain_args(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st, const FwdBufs& fb) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
-  const uint32_t row_off = (uint32_t)(e.rank * B);
+  const uint32_t row_off = (uint32_t)(e.eff_rank() * B);
   const bool drop = o.train && o.drop_mode != 0;
   ChainArgs a{};
   a.h0 = fb.h0; a.Ip = m->Ip;
@@ -680,7 +693,7 @@ ChainArgs make_chain_args(goctr_model* m, const RowSource& src, int B, const Ste
   a.train = o.train ? 1 : 0; a.kind = c.kind;
   a.d0 = DropCfg{drop && o.p0 > 0 ? o.drop_mode : 0, o.p0, m->mask0.p, c.H1, o.seed, 0u, row_off};
   a.d1 = DropCfg{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
-  a.st = st; a.Y = src.Y; a.rows = src.rows; a.inv_bglobal = 1.0f / (float)(B * e.world);
+  a.st = st; a.Y = src.Y; a.rows = src.rows; a.inv_bglobal = 1.0f / (float)(B * e.eff_world());
   a.buf_floats = chain_buf_floats(m->Ip, m->H1p, m->H2p);
   a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;   // (forward only: none of these is touched)
   a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
@@ -833,8 +846,8 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
   if (o.train) { m->dpv_from_chain = false; m->attn_bwd_in_chain = false; }   // (launch_chain_x3 sets them when it does the work itself)
   if (chain_ok(m)) return launch_chain(m, src, B, o, st, fb);  // layers + (when training) backward-data, fused
 
-  const int bglobal = B * e.world;
-  const uint32_t row_off = (uint32_t)(e.rank * B);
+  const int bglobal = B * e.eff_world();
+  const uint32_t row_off = (uint32_t)(e.eff_rank() * B);
   const bool drop = o.train && o.drop_mode != 0;
   DropCfg d0{drop && o.p0 > 0 ? o.drop_mode : 0, o.p0, m->mask0.p, c.H1, o.seed, 0u, row_off};
   DropCfg d1{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
@@ -858,11 +871,11 @@ AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc);
 // hipMemsetAsync issued during capture becomes a graph node and would re-zero hundreds of MB on every replay.
 int ensure_emb_workspace(goctr_model* m, long long V, int B) {
   // (the accumulators are sized for this rank's own ids; a communicator created after the first step changes the index space)
-  if (m->emb_lr <= 0.f || (m->emb_V == V && m->emb_B == B && m->emb_world == engine().world &&
+  if (m->emb_lr <= 0.f || (m->emb_V == V && m->emb_B == B && m->emb_world == engine().eff_world() &&
                            m->emb_comm == engine().comm_active())) return 0;
   const goctr_ctr_cfg& c = m->cfg;
   const int Np = round_up(2 * c.D, 16);
-  const int W = engine().comm_active() ? engine().world : 1;
+  const int W = engine().comm_active() ? engine().eff_world() : 1;
   const long long Vw = round_up((int)cdiv(V, W), 4);
   const long long Vp = Vw * W;                                        // owner-major index space (emb_train.h: emb_pidx)
   const long long cap = std::min<long long>(V, (long long)B * (c.T + 1));
@@ -876,7 +889,7 @@ int ensure_emb_workspace(goctr_model* m, long long V, int B) {
     // (the data buffers grow on demand: their sizes follow the ids the batches actually touch)
   }
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
-  m->emb_V = V; m->emb_B = B; m->emb_world = engine().world; m->emb_comm = engine().comm_active(); m->emb_Vw = Vw;
+  m->emb_V = V; m->emb_B = B; m->emb_world = engine().eff_world(); m->emb_comm = engine().comm_active(); m->emb_Vw = Vw;
   m->w0pv_live = false; m->plan.valid = false;      // (W0pvT was reallocated; the plan's index space may have changed)
   m->graph.destroy();
   return 0;
@@ -902,7 +915,7 @@ void launch_emb_grad(int mode, bool cache, dim3 gb, size_t lds, hipStream_t s, c
 // eagerly; the traffic is proportional to the ids the batches touch, not to the vocabulary.
 int launch_emb_exchange(goctr_model* m, const EmbTrainArgs& a) {
   Engine& e = engine();
-  const int W = e.world, r = e.rank, D = a.D;
+  const int W = e.eff_world(), r = e.eff_rank(), D = a.D;
   hipStream_t s = e.stream;
   hipLaunchKernelGGL(emb_bucket_bounds_kernel, dim3(1), dim3(64), 0, s, m->emb_slot_id.p, m->emb_total.p, W, m->ex_off.p, m->ex_cnt.p);
   GOCTR_HIP(hipGetLastError());
@@ -981,7 +994,7 @@ bool emb_plan_ok(const goctr_model* m, int B) {
 int ensure_emb_plan(goctr_model* m, const goctr_dataset* d, const RowSource& src, int B) {
   Engine& e = engine();
   const goctr_ctr_cfg& c = m->cfg;
-  const int W = e.comm_active() ? e.world : 1;
+  const int W = e.comm_active() ? e.eff_world() : 1;
   auto& P = m->plan;
   if (P.valid && P.ds == d->uid && P.V == src.V && P.B == B && P.W == W && P.T == c.T) return 0;
   P.valid = false;
@@ -1152,9 +1165,9 @@ int launch_emb_plan_step(goctr_model* m, const RowSource& src, int B, const Step
   if (m->ex_fixed) {
     // fixed-size buckets: pack the send buffers; the collectives and the owner's side follow from the step driver
     // (emb_exchange_* below), with no host read-back anywhere
-    const long long n = (long long)e.world * m->ex_S * c.D;
+    const long long n = (long long)e.eff_world() * m->ex_S * c.D;
     hipLaunchKernelGGL(emb_pack_send_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(cdiv(n, 256), 1), 8 * cus)), dim3(256), 0, s,
-                       m->plan.view(), st, m->ex_bucket_off.p, e.world, m->ex_S, c.D, m->emb_accum.p, m->ex_send_ids.p, m->ex_send_rows.p);
+                       m->plan.view(), st, m->ex_bucket_off.p, e.eff_world(), m->ex_S, c.D, m->emb_accum.p, m->ex_send_ids.p, m->ex_send_rows.p);
     GOCTR_HIP(hipGetLastError());
     return 0;
   }
@@ -1177,9 +1190,9 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   const int Np = round_up(2 * c.D, 16);
   const long long V = src.V;
   const long long cap = std::min<long long>(V, (long long)B * (c.T + 1));
-  GOCTR_CHECK(m->emb_V == V && m->emb_B == B && m->emb_world == e.world && m->emb_comm == e.comm_active(),
+  GOCTR_CHECK(m->emb_V == V && m->emb_B == B && m->emb_world == e.eff_world() && m->emb_comm == e.comm_active(),
               "embedding-training workspace not prepared (ensure_emb_workspace)");
-  const int W = e.comm_active() ? e.world : 1;
+  const int W = e.comm_active() ? e.eff_world() : 1;
   EmbTrainArgs a{};
   a.src = src; a.st = st; a.B = B; a.T = c.T; a.D = c.D; a.kind = c.kind; a.att = c.att;
   a.dpv = m->dpv.p; a.ldp = Np; a.gate = m->gate_p(m->stp); a.wgt = m->wgt_p(m->stp); a.att0 = m->W.p + m->offa;
@@ -1255,7 +1268,7 @@ bool emb_split3(const goctr_model* m) { return engine().comm_active() && m->emb_
 // uniform all-to-all: S (id, row) entries to and from every rank
 int emb_exchange_a2a(goctr_model* m) {
   Engine& e = engine();
-  const int W = e.world, D = m->cfg.D;
+  const int W = e.eff_world(), D = m->cfg.D;
   std::vector<size_t> off((size_t)W), cnt((size_t)W), offD((size_t)W), cntD((size_t)W);
   for (int p = 0; p < W; ++p) { off[p] = (size_t)p * m->ex_S; cnt[p] = (size_t)m->ex_S; offD[p] = off[p] * D; cntD[p] = cnt[p] * D; }
   ProfScope ps(GOCTR_K_ALLREDUCE);
@@ -1265,7 +1278,7 @@ int emb_exchange_a2a(goctr_model* m) {
 // owner: unique ids of my bucket among the W * S received entries -> dense slots, exact integer sums, deltas, padded id list
 int emb_exchange_owner(goctr_model* m) {
   Engine& e = engine();
-  const int W = e.world, r = e.rank, D = m->cfg.D;
+  const int W = e.eff_world(), r = e.eff_rank(), D = m->cfg.D;
   hipStream_t s = e.stream;
   const long long nrecv = (long long)W * m->ex_S;
   const int cus = e.compute_units > 0 ? e.compute_units : 256;
@@ -1294,7 +1307,7 @@ int emb_exchange_gather(goctr_model* m) {
 int emb_exchange_apply(goctr_model* m, const RowSource& src) {
   Engine& e = engine();
   const int D = m->cfg.D;
-  const long long ng = (long long)e.world * m->ex_R;
+  const long long ng = (long long)e.eff_world() * m->ex_R;
   const int cus = e.compute_units > 0 ? e.compute_units : 256;
   ProfScope ps(GOCTR_K_EMB_TRAIN);
   hipLaunchKernelGGL(emb_apply_gathered_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(cdiv(ng * D, 256), 1), 16 * cus)), dim3(256), 0, e.stream,
@@ -1313,7 +1326,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   Engine& e = engine();
   if (stage == 2) return launch_reduce_part(m, src, B, o, advance, fuse_update, m->pend_ra);
   const StepState* st = m->st_cur();
-  const uint32_t row_off = (uint32_t)(e.rank * B);
+  const uint32_t row_off = (uint32_t)(e.eff_rank() * B);
   const bool drop = o.drop_mode != 0;
   DropCfg d0{drop && o.p0 > 0 ? o.drop_mode : 0, o.p0, m->mask0.p, c.H1, o.seed, 0u, row_off};
   DropCfg d1{drop && o.p1 > 0 ? o.drop_mode : 0, o.p1, m->mask1.p, c.H2, o.seed, 1u, row_off};
@@ -1509,7 +1522,7 @@ AdamArgs make_adam_args(goctr_model* m, int B, const goctr_train_cfg& tc) {
   a.W0pvT = (m->emb_lr > 0.f && m->w0pv_live) ? m->W0pvT.p : nullptr; a.Npv = round_up(2 * m->cfg.D, 16);
   a.lr = tc.lr; a.l2 = tc.l2; a.beta1 = tc.beta1; a.beta2 = tc.beta2; a.eps = tc.eps;
   a.div_by_batch = tc.adam_div_by_batch; a.l2_first = tc.adam_l2_before_batch_div;
-  a.bglobal = B * e.world; a.st = m->st_cur(); a.costs = m->costs.p;
+  a.bglobal = B * e.eff_world(); a.st = m->st_cur(); a.costs = m->costs.p;
   return a;
 }
 
@@ -1573,7 +1586,7 @@ bool graph_matches(const StepGraph& g, const goctr_dataset* d, const goctr_emb* 
   return g.a[0] && g.a[1] && g.ds == d->uid && g.emb == (e ? e->uid : 0) && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
          g.seed == o.seed && g.lr == o.tc->lr && g.l2 == o.tc->l2 && g.b1 == o.tc->beta1 && g.b2 == o.tc->beta2 &&
          g.eps == o.tc->eps && g.flags == o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div &&
-         g.world == engine().world && g.comm == engine().comm_active() && g.pipelined == o.pipelined;
+         g.world == engine().eff_world() && g.comm == engine().comm_active() && g.pipelined == o.pipelined;
 }
 
 int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, const RowSource& src, int B,
@@ -1634,7 +1647,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   StepGraph& sg = m->graph;
   sg.ds = d->uid; sg.emb = emb ? emb->uid : 0; sg.B = B; sg.mode = o.drop_mode; sg.p0 = o.p0; sg.p1 = o.p1; sg.seed = o.seed;
   sg.lr = o.tc->lr; sg.l2 = o.tc->l2; sg.b1 = o.tc->beta1; sg.b2 = o.tc->beta2; sg.eps = o.tc->eps;
-  sg.flags = o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div; sg.world = e.world; sg.comm = e.comm_active();
+  sg.flags = o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div; sg.world = e.eff_world(); sg.comm = e.comm_active();
   sg.pipelined = o.pipelined;
   return 0;
 }
@@ -1980,7 +1993,10 @@ int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
 
 void goctr_model_destroy(goctr_model* m) {
   if (!m) return;
-  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
+  for (goctr_model* r : m->reps) goctr_model_destroy(r);        // (replicas of the multi-device entry, on their own engines)
+  m->reps.clear();
+  EngineScope on(m->eng);
+  std::lock_guard<std::recursive_mutex> lk(m->eng->mu);
   if (engine().inited) (void)hipDeviceSynchronize();
   m->graph.destroy();
   if (m->ev_weights) (void)hipEventDestroy(m->ev_weights);
@@ -1988,7 +2004,7 @@ void goctr_model_destroy(goctr_model* m) {
 }
 
 int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, size_t n) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && host, "goctr_model_set_weights: null argument");
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   if (upload_padded_weights(m, tensor_id, host, n)) return -1;
@@ -1998,7 +2014,7 @@ int goctr_model_set_weights(goctr_model* m, int tensor_id, const float* host, si
 }
 
 int goctr_model_get_weights(goctr_model* m, int tensor_id, float* host, size_t n) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && host, "goctr_model_get_weights: null argument");
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return download_padded(m, m->W.p, tensor_id, host, n);
@@ -2040,14 +2056,14 @@ int upload_padded_flat(goctr_model* m, float* flat_dev, int tensor_id, const flo
 }
 
 int goctr_model_get_moments(goctr_model* m, int tensor_id, int which, float* host, size_t n) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && host && (which == 0 || which == 1), "goctr_model_get_moments: bad argument");
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return download_padded(m, which ? m->Vo.p : m->Mo.p, tensor_id, host, n);
 }
 
 int goctr_model_set_moments(goctr_model* m, int tensor_id, int which, const float* host, size_t n) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && host && (which == 0 || which == 1), "goctr_model_set_moments: bad argument");
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return upload_padded_flat(m, which ? m->Vo.p : m->Mo.p, tensor_id, host, n);
@@ -2055,7 +2071,7 @@ int goctr_model_set_moments(goctr_model* m, int tensor_id, int which, const floa
 
 // Global step counter: Adam's iteration number and the dropout stream position.
 int goctr_model_get_step(goctr_model* m, uint32_t* step) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && step, "goctr_model_get_step: null argument");
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   StepState s;
@@ -2065,14 +2081,14 @@ int goctr_model_get_step(goctr_model* m, uint32_t* step) {
 }
 
 int goctr_model_set_step(goctr_model* m, uint32_t step) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m, "goctr_model_set_step: null argument");
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return set_state(m, step, 0, 0, 1);
 }
 
 int goctr_model_set_embedding_training(goctr_model* m, double lr) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && lr >= 0 && lr == lr, "goctr_model_set_embedding_training: bad arguments");
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   GOCTR_CHECK(lr == 0 || m->cfg.D <= 64, "embedding training supports D <= 64 (got %d)", m->cfg.D);
@@ -2083,21 +2099,21 @@ int goctr_model_set_embedding_training(goctr_model* m, double lr) {
 }
 
 int goctr_model_sparse_exchange_bytes(goctr_model* m, double* bytes) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && bytes, "goctr_model_sparse_exchange_bytes: null argument");
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
-  *bytes = engine().comm_active() ? m->ex_bytes_last : 0.0;
+  *bytes = m->emb_comm ? m->ex_bytes_last : 0.0;      // (emb_comm: the last step's sparse update ran with a communicator)
   return 0;
 }
 
 int goctr_emb_get_rows(goctr_emb* e, int64_t first, int64_t n, float* host_rows) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(e);
   GOCTR_CHECK(e && host_rows && first >= 0 && n >= 0 && first + n <= e->V, "goctr_emb_get_rows: range out of bounds");
   return n ? e->rows.download(host_rows, (size_t)n * e->D, (size_t)first * e->D) : 0;
 }
 
 int goctr_model_reset_optimizer(goctr_model* m) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
   GOCTR_HIP(hipMemsetAsync(m->Vo.p, 0, sizeof(float) * m->nflat, engine().stream));
@@ -2116,21 +2132,24 @@ int goctr_emb_create(int64_t V, int D, const float* host_rows, goctr_emb** out) 
   return 0;
 }
 int goctr_emb_set_rows(goctr_emb* e, int64_t first, int64_t n, const float* host_rows) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(e);
   GOCTR_CHECK(e && host_rows && first >= 0 && n >= 0 && first + n <= e->V, "goctr_emb_set_rows: range out of bounds");
   ++e->version;
   return n ? e->rows.upload(host_rows, (size_t)n * e->D, (size_t)first * e->D) : 0;
 }
 void goctr_emb_destroy(goctr_emb* e) {
   if (!e) return;
-  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
+  for (goctr_emb* r : e->reps) goctr_emb_destroy(r);
+  e->reps.clear();
+  EngineScope on(e->eng);
+  std::lock_guard<std::recursive_mutex> lk(e->eng->mu);
   if (engine().inited) (void)hipStreamSynchronize(engine().stream);
   delete e;
 }
 
 int goctr_gather_rows(goctr_emb* e, const int32_t* ub_ids, const int32_t* item_ids, const float* user_feat, int U,
                       const float* ctx_feat, int C, int T, int64_t rows, float* X_out) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(e);
   GOCTR_CHECK(e && X_out && rows >= 0, "goctr_gather_rows: bad arguments");
   if (rows == 0) return 0;
   const int xcols = U + T * e->D + e->D + C;
@@ -2176,7 +2195,10 @@ int goctr_dataset_create_ids(const int32_t* ub_ids, const int32_t* item_ids, con
 }
 void goctr_dataset_destroy(goctr_dataset* d) {
   if (!d) return;
-  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
+  for (goctr_dataset* s : d->shards) goctr_dataset_destroy(s);
+  d->shards.clear();
+  EngineScope on(d->eng);
+  std::lock_guard<std::recursive_mutex> lk(d->eng->mu);
   if (engine().inited) (void)hipStreamSynchronize(engine().stream);   // queued (asynchronous) steps may still read the rows
   delete d;
 }
@@ -2187,6 +2209,7 @@ void goctr_dataset_destroy(goctr_dataset* d) {
 // ubcache.UserBehaviorCache (feature/ubcache/cache.go) as a CSR in HBM + the per-sample gather of GetSampleVector
 // (recommend/rcmd.go:460-536) as one kernel: keys (user, item, timestamp) -> behaviour ids, user / item feature rows.
 struct goctr_ubcache {
+  goctr::Engine* const eng = &goctr::engine();   // the engine (device, streams, arena) the handle was created on
   int64_t n_users = 0, nnz = 0;
   DevBuf<long long> off, ts;
   DevBuf<int32_t> items;
@@ -2290,7 +2313,7 @@ int goctr_ubcache_create(int64_t n_users, const int64_t* off, const int32_t* ite
 void goctr_ubcache_destroy(goctr_ubcache* c) { delete c; }
 
 int goctr_ubcache_get(goctr_ubcache* c, const int32_t* users, const int64_t* max_ts, int64_t rows, int T, int32_t* out_ids) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(c);
   GOCTR_CHECK(c && users && out_ids && rows > 0 && T > 0, "goctr_ubcache_get: bad arguments");
   DevBuf<int32_t> du, dout; DevBuf<long long> dts;
   std::vector<long long> t(rows, 0);
@@ -2308,7 +2331,7 @@ int goctr_ubcache_get(goctr_ubcache* c, const int32_t* users, const int64_t* max
 int goctr_dataset_create_keys(goctr_ubcache* c, const float* user_table, int64_t n_users, int U, const float* item_table,
                               int64_t n_items, int C, const int32_t* users, const int32_t* items, const int64_t* ts,
                               const float* Y, int64_t rows, int T, goctr_dataset** out) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(c);
   GOCTR_CHECK(c && users && items && rows > 0 && T > 0 && out && n_items >= 0 && U >= 0 && C >= 0,
               "goctr_dataset_create_keys: bad arguments");
   GOCTR_CHECK(n_users == c->n_users, "goctr_dataset_create_keys: user table has %lld rows, the behaviour cache %lld users",
@@ -2336,7 +2359,7 @@ int goctr_dataset_create_keys(goctr_ubcache* c, const float* user_table, int64_t
 
 // read back the assembled keys of an id-mode dataset (tests, debugging)
 int goctr_dataset_get_ids(goctr_dataset* d, int32_t* ub_ids, float* user_feat, float* ctx_feat) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(d);
   GOCTR_CHECK(d && d->id_mode, "goctr_dataset_get_ids: not an id-mode dataset");
   if (ub_ids && d->ub_ids.download(ub_ids, (size_t)d->rows * d->T)) return -1;
   if (user_feat && d->U && d->ufeat.download(user_feat, (size_t)d->rows * d->U)) return -1;
@@ -2346,18 +2369,199 @@ int goctr_dataset_get_ids(goctr_dataset* d, int32_t* ub_ids, float* user_feat, f
 
 }  // extern "C"
 
+
+// ------------------------------------------------------------------ single-call multi-device training (goctr_train_cfg::devices)
+// recommend.Train -> Fitter.Fit -> model.Train is ONE call from ONE Go process (recommend/rcmd.go:196-246, model/model.go:27-213).
+// After goctr_init_devices(n, ids) a training call with cfg->devices = n runs that call data-parallel over the n engines: the
+// model / table / dataset handles the caller holds live on engine 0; replicas of the model (weights, Adam moments, step
+// state, operand images) and of the embedding table on engines 1 .. n-1 are made by broadcast, the dataset is cut into
+// per-rank shards (rank r owns rows [r, r+1) * B/n of every global batch of B rows), and n host threads -- one per engine --
+// each run the ordinary per-rank data-parallel step loop (the one a one-process-per-GPU run executes) on their replica with
+// the group's communicator switched on.  Replicas and shards are cached on the handles: a second call only re-broadcasts
+// what changed in between (set_weights, set_rows, ...).
+namespace {
+
+// out[r][b * Bl + i][c] = in[(b * B + r * Bl + i)][c], `fill` where that row does not exist (4-byte elements)
+__global__ __launch_bounds__(256) void shard_rows_kernel(const uint32_t* __restrict__ in, long long rows, int w, int B, int Bl, int W,
+                                                         long long nb, uint32_t fill, uint32_t* __restrict__ out) {
+  const long long per = nb * Bl * (long long)w, total = per * W;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long r = idx / per, rem = idx - r * per;
+    const long long lr = rem / w; const int c = (int)(rem - lr * w);
+    const long long b = lr / Bl; const int i = (int)(lr - b * Bl);
+    const long long g = b * B + r * Bl + i;
+    out[idx] = g < rows ? in[g * w + c] : fill;
+  }
+}
+
+struct ShardPack {            // root-side staging of one array of the dataset: [W][nb * Bl][w]
+  DevBuf<uint32_t> buf; size_t per = 0;
+};
+
+int pack_array(ShardPack& p, const void* in, long long rows, int w, int B, int W, long long nb, uint32_t fill) {
+  const int Bl = B / W;
+  p.per = (size_t)nb * Bl * w;
+  if (!w || !in) { p.per = 0; return 0; }
+  if (p.buf.alloc(p.per * W, false)) return -1;
+  const long long total = (long long)p.per * W;
+  const int cus = engine().compute_units > 0 ? engine().compute_units : 256;
+  hipLaunchKernelGGL(shard_rows_kernel, dim3((unsigned)std::min<long long>(std::max<long long>(cdiv(total, 256), 1), 32 * cus)), dim3(256), 0,
+                     engine().stream, static_cast<const uint32_t*>(in), rows, w, B, Bl, W, nb, fill, p.buf.p);
+  GOCTR_HIP(hipGetLastError());
+  return 0;
+}
+
+// collective: rank 0's pack -> every rank's `dst` (its per-rank slice)
+int scatter_array(const ShardPack* root_pack, size_t per, void* dst) {
+  Engine& e = engine();
+  if (!per) return 0;
+  const int W = e.world;
+  std::vector<size_t> so((size_t)W, 0), sc((size_t)W, 0), ro((size_t)W, 0), rc((size_t)W, 0);
+  if (e.rank == 0) for (int p = 0; p < W; ++p) { so[p] = (size_t)p * per; sc[p] = per; }
+  rc[0] = per;
+  return comm_alltoallv(e.rank == 0 ? (const void*)root_pack->buf.p : (const void*)dst, so.data(), sc.data(), dst, ro.data(), rc.data(), 4);
+}
+
+// collective: rank 0's model state -> this rank's replica
+int model_broadcast(goctr_model* mk, int stp_root, float emb_lr_root) {
+  Engine& e = engine();
+  auto bc = [&](void* p, size_t bytes) -> int { return (p && bytes) ? comm_broadcast(p, bytes, 0) : 0; };
+  if (bc(mk->W.p, sizeof(float) * mk->nflat) || bc(mk->Mo.p, sizeof(float) * mk->nflat) || bc(mk->Vo.p, sizeof(float) * mk->nflat) ||
+      bc(mk->W1T.p, sizeof(float) * mk->W1T.n) || bc(mk->W2T.p, sizeof(float) * mk->W2T.n) || bc(mk->W0sT.p, sizeof(float) * mk->W0sT.n) ||
+      bc(mk->Wimg.p, sizeof(float) * mk->Wimg.n) || bc(mk->Wx3.p, mk->x3_nch0 ? sizeof(unsigned short) * mk->Wx3.n : 0) ||
+      bc(mk->st.p, sizeof(StepState) * 2)) return -1;
+  if (e.rank != 0) {
+    mk->stp = stp_root;
+    if (mk->emb_lr != emb_lr_root) { mk->emb_lr = emb_lr_root; mk->graph.destroy(); }
+    mk->w0pv_live = false;              // (rebuilt from the broadcast W0 by ensure_w0pv)
+    mk->carry.valid = false;
+    if (mk->ra_flag.p) GOCTR_HIP(hipMemsetAsync(mk->ra_flag.p, 0, sizeof(unsigned int), e.stream));
+  }
+  return 0;
+}
+
+struct CommCallScope {       // the group's communicator takes part in this call only
+  Engine& e; bool prev;
+  explicit CommCallScope(Engine& en) : e(en), prev(en.comm_enabled) { e.comm_enabled = true; }
+  ~CommCallScope() { e.comm_enabled = prev; }
+};
+
+// per_rank(model, table, shard, local cfg, rank) is the ordinary per-rank call
+template <class Fn>
+int train_multi(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg, Fn per_rank) {
+  const int N = cfg->devices, B = cfg->batch;
+  Engine* e0 = engine_at(0);
+  GOCTR_CHECK(N == engine_count() && e0 && e0->world == N && (e0->loop || e0->nccl_comm),
+              "cfg.devices = %d, but goctr_init_devices set up %d engine(s)", N, (e0 && (e0->loop || e0->nccl_comm)) ? e0->world : 1);
+  GOCTR_CHECK(m->eng == e0 && (!emb || emb->eng == e0) && d->eng == e0, "multi-device training: the handles must live on engine 0");
+  GOCTR_CHECK(B % N == 0, "multi-device training: batch %d is not a multiple of devices %d", B, N);
+  if (comm_group_reset()) return -1;
+  const int Bl = B / N;
+  const long long nb = cdiv(d->rows, B);
+  // ---- handles on the other engines (no collectives yet)
+  bool new_model = false, new_emb = false;
+  if ((int)m->reps.size() != N) { for (auto* r : m->reps) goctr_model_destroy(r); m->reps.assign((size_t)N, nullptr); }
+  if (emb && (int)emb->reps.size() != N) { for (auto* r : emb->reps) goctr_emb_destroy(r); emb->reps.assign((size_t)N, nullptr); }
+  const bool need_shard = (int)d->shards.size() != N || d->shard_B != B;
+  if (need_shard) { for (auto* s : d->shards) goctr_dataset_destroy(s); d->shards.assign((size_t)N, nullptr); d->shard_B = 0; }
+  for (int k = 0; k < N; ++k) {
+    Engine* ek = engine_at(k);
+    EngineScope on(ek);
+    std::lock_guard<std::recursive_mutex> lk(ek->mu);
+    if (k > 0 && !m->reps[k]) { if (goctr_model_create(&m->cfg, &m->reps[k])) return -1; new_model = true; }
+    if (k > 0 && emb && !emb->reps[k]) { if (goctr_emb_create(emb->V, emb->D, nullptr, &emb->reps[k])) return -1; new_emb = true; }
+    if (need_shard) {
+      std::unique_ptr<goctr_dataset> s(new goctr_dataset);
+      s->id_mode = d->id_mode; s->rows = nb * Bl; s->has_y = d->has_y;
+      s->xcols = d->xcols; memcpy(s->ranges, d->ranges, sizeof s->ranges); s->U = d->U; s->C = d->C; s->T = d->T;
+      const size_t R = (size_t)s->rows;
+      if (d->id_mode) {
+        if (s->ub_ids.alloc(R * d->T, false) || s->item_ids.alloc(R, false) || s->ufeat.alloc(R * d->U, false) || s->cfeat.alloc(R * d->C, false)) return -1;
+      } else if (s->X.alloc(R * d->xcols, false)) return -1;
+      if (d->has_y && s->Y.alloc(R, false)) return -1;
+      GOCTR_HIP(hipStreamSynchronize(ek->stream));
+      d->shards[k] = s.release();
+    }
+  }
+  const bool model_sync = new_model || m->reps_gen + 1 != m->gen;
+  const bool emb_sync = emb && (new_emb || emb->reps_version != emb->version);
+  // ---- root-side staging of the shards
+  ShardPack pX, pY, pub, pit, puf, pcf;
+  if (need_shard) {
+    if (d->id_mode) {
+      if (pack_array(pub, d->ub_ids.p, d->rows, d->T, B, N, nb, 0xFFFFFFFFu) || pack_array(pit, d->item_ids.p, d->rows, 1, B, N, nb, 0xFFFFFFFFu) ||
+          pack_array(puf, d->ufeat.p, d->rows, d->U, B, N, nb, 0u) || pack_array(pcf, d->cfeat.p, d->rows, d->C, B, N, nb, 0u)) return -1;
+    } else if (pack_array(pX, d->X.p, d->rows, d->xcols, B, N, nb, 0u)) return -1;
+    if (d->has_y && pack_array(pY, d->Y.p, d->rows, 1, B, N, nb, 0u)) return -1;
+  }
+  goctr_train_cfg lcfg = *cfg;
+  lcfg.batch = Bl; lcfg.devices = 1;
+  const int stp_root = m->stp; const float emb_lr_root = m->emb_lr;
+  const int rc = run_on_engines(N, [&](int k) -> int {
+    Engine& e = engine();
+    std::lock_guard<std::recursive_mutex> elk(e.mu);
+    CommCallScope comm_on(e);
+    goctr_model* mk = k == 0 ? m : m->reps[k];
+    goctr_emb* ek = !emb ? nullptr : (k == 0 ? emb : emb->reps[k]);
+    goctr_dataset* dk = d->shards[k];
+    std::unique_lock<std::shared_mutex> lk(mk->mu, std::defer_lock);
+    if (k > 0) { lk.lock(); ++mk->gen; }          // (rank 0: the caller holds its model's lock)
+    int r = 0;
+    if (model_sync) r = model_broadcast(mk, stp_root, emb_lr_root);
+    if (!r && emb_sync) { r = comm_broadcast(ek->rows.p, sizeof(float) * (size_t)(emb->V + 1) * emb->D, 0); if (k > 0) ++ek->version; }
+    if (!r && need_shard) {
+      if (d->id_mode) r = scatter_array(&pub, pub.per, dk->ub_ids.p) || scatter_array(&pit, pit.per, dk->item_ids.p) ||
+                          scatter_array(&puf, puf.per, dk->ufeat.p) || scatter_array(&pcf, pcf.per, dk->cfeat.p);
+      else r = scatter_array(&pX, pX.per, dk->X.p);
+      if (!r && d->has_y) r = scatter_array(&pY, pY.per, dk->Y.p);
+      if (!r && k == 0) r = hipStreamSynchronize(e.stream) == hipSuccess ? 0 : -1;     // (the staging buffers are released after the call)
+    }
+    if (!r) r = per_rank(mk, ek, dk, &lcfg, k);
+    if (r) {
+      const std::string msg = goctr_last_error();
+      comm_abort_on_failure();
+      set_error("%s", msg.c_str());
+    }
+    return r;
+  });
+  if (rc) { m->reps_gen = ~0ull; if (emb) emb->reps_version = ~0ull; return -1; }
+  if (need_shard) d->shard_B = B;
+  m->reps_gen = m->gen;
+  if (emb) emb->reps_version = emb->version;
+  return 0;
+}
+
+}  // namespace
+
+static int train_steps_locked(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg, int64_t first_batch, int n_steps,
+                              float* costs);
+static int train_dataset_locked(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg, float* epoch_costs,
+                                int* epochs_run);
+
 extern "C" {
 
 // ------------------------------------------------------------------ training
 int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,
                       int64_t first_batch, int n_steps, float* costs) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && d && cfg && cfg->batch > 0 && n_steps >= 0, "goctr_train_steps: bad arguments");
   GOCTR_CHECK(d->has_y, "goctr_train_steps: dataset has no labels");
   GOCTR_CHECK(cfg->dropout_mode == 0 || cfg->dropout_mode == 2, "multi-step training supports dropout_mode 0 or 2");
   GOCTR_CHECK(n_steps <= COST_RING, "n_steps > %d per call", COST_RING);
+  GOCTR_SAME_ENGINE(m, d); GOCTR_SAME_ENGINE(m, emb);
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   if (check_dataset(m, d, emb)) return -1;
+  if (cfg->devices > 1)
+    return train_multi(m, emb, d, cfg, [&](goctr_model* mk, goctr_emb* ek, goctr_dataset* dk, const goctr_train_cfg* lc, int rank) {
+      return train_steps_locked(mk, ek, dk, lc, first_batch, n_steps, rank == 0 ? costs : nullptr);
+    });
+  return train_steps_locked(m, emb, d, cfg, first_batch, n_steps, costs);
+}
+
+}  // extern "C"
+
+static int train_steps_locked(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg, int64_t first_batch, int n_steps,
+                              float* costs) {
   const long long nb = cdiv(d->rows, cfg->batch);
   if (retarget_state(m, first_batch % nb, nb)) return -1;      // no host synchronisation on this path
   m->pend_no_costs = costs == nullptr;
@@ -2372,20 +2576,51 @@ int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const go
     return -1;
   }
   if (costs) {
-    GOCTR_HIP(hipStreamSynchronize(engine().stream));
+    if (comm_watch_stream()) return -1;
     if (m->costs.download(costs, n_steps)) return -1;
   }
   return 0;
 }
 
+extern "C" {
+
+int goctr_model_replica(goctr_model* m, int rank, goctr_model** out) {
+  GOCTR_ENTER_H(m);
+  GOCTR_CHECK(m && out && rank >= 0, "goctr_model_replica: bad arguments");
+  std::unique_lock<std::shared_mutex> lk(m->mu);
+  *out = rank == 0 ? m : (rank < (int)m->reps.size() ? m->reps[rank] : nullptr);
+  return 0;
+}
+int goctr_emb_replica(goctr_emb* e, int rank, goctr_emb** out) {
+  GOCTR_ENTER_H(e);
+  GOCTR_CHECK(e && out && rank >= 0, "goctr_emb_replica: bad arguments");
+  *out = rank == 0 ? e : (rank < (int)e->reps.size() ? e->reps[rank] : nullptr);
+  return 0;
+}
+
 int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,
                         float* epoch_costs, int* epochs_run) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && d && cfg && cfg->batch > 0 && cfg->epochs >= 0, "goctr_train_dataset: bad arguments");
   GOCTR_CHECK(d->has_y, "goctr_train_dataset: dataset has no labels");
   GOCTR_CHECK(cfg->dropout_mode == 0 || cfg->dropout_mode == 2, "multi-step training supports dropout_mode 0 or 2");
+  GOCTR_SAME_ENGINE(m, d); GOCTR_SAME_ENGINE(m, emb);
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   if (check_dataset(m, d, emb)) return -1;
+  if (cfg->devices > 1)
+    return train_multi(m, emb, d, cfg, [&](goctr_model* mk, goctr_emb* ek, goctr_dataset* dk, const goctr_train_cfg* lc, int rank) {
+      int ran = 0;
+      const int r = train_dataset_locked(mk, ek, dk, lc, rank == 0 ? epoch_costs : nullptr, &ran);
+      if (rank == 0 && epochs_run) *epochs_run = ran;
+      return r;
+    });
+  return train_dataset_locked(m, emb, d, cfg, epoch_costs, epochs_run);
+}
+
+}  // extern "C"
+
+static int train_dataset_locked(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg, float* epoch_costs,
+                                int* epochs_run) {
   // a fresh solver per model.Train call (model.go:88)
   GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
   GOCTR_HIP(hipMemsetAsync(m->Vo.p, 0, sizeof(float) * m->nflat, engine().stream));
@@ -2394,7 +2629,7 @@ int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const 
     // every rank issues one all-reduce per batch: unequal shard sizes would leave the shorter ranks' peers hanging
     double v[2] = {(double)nb, (double)nb * (double)nb};
     if (goctr_comm_allreduce_f64(v, 2)) return -1;
-    const double w = (double)engine().world;
+    const double w = (double)engine().eff_world();
     GOCTR_CHECK(v[0] == w * (double)nb && v[1] == w * (double)nb * (double)nb,
                 "goctr_train_dataset: the ranks' shards have different batch counts (this rank: %lld batches of %d); "
                 "shard the rows so that every rank steps the same number of times", nb, cfg->batch);
@@ -2430,9 +2665,11 @@ int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const 
   return 0;
 }
 
+extern "C" {
+
 int goctr_train_dense(goctr_model* m, const float* X, const float* Y, int64_t rows, int xcols, const int ranges[8],
                       const goctr_train_cfg* cfg, float* epoch_costs, int* epochs_run) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   goctr_dataset* d = nullptr;
   GOCTR_CHECK(m && cfg, "goctr_train_dense: null argument");
   GOCTR_CHECK(Y != nullptr, "goctr_train_dense: labels required");
@@ -2450,7 +2687,7 @@ int goctr_train_dense(goctr_model* m, const float* X, const float* Y, int64_t ro
 int goctr_loss_grad_dense(goctr_model* m, const float* X, const float* Y, int valid, int B, int xcols,
                           const int ranges[8], const goctr_train_cfg* cfg, uint32_t step, const float* m0,
                           const float* m1, float* cost, float* gW0, float* gW1, float* gW2, float* gatt0, float* y_out) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && X && Y && cfg && valid > 0 && valid <= B, "goctr_loss_grad_dense: bad arguments");
   goctr_dataset* d = nullptr;
   if (goctr_dataset_create_dense(X, Y, valid, xcols, ranges, &d)) return -1;
@@ -2486,7 +2723,7 @@ int goctr_loss_grad_dense(goctr_model* m, const float* X, const float* Y, int va
   if (cost) {
     float s = 0.f;
     if (m->G.download(&s, 1, m->nflat)) return -1;
-    *cost = -(s / (float)(B * engine().world));
+    *cost = -(s / (float)(B * engine().eff_world()));
   }
   if (y_out && m->yhat.download(y_out, B)) return -1;
   restore.armed = false;
@@ -2562,7 +2799,7 @@ static int predict_batches(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int
 }
 
 int goctr_predict_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, float* y_out) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && d && y_out && batch > 0, "goctr_predict_dataset: bad arguments");
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return predict_batches(m, emb, d, batch, 0, cdiv(d->rows, batch), y_out);
@@ -2570,7 +2807,7 @@ int goctr_predict_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int 
 
 int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int batch, int64_t first_batch,
                         int n_batches) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && d && batch > 0 && n_batches >= 0, "goctr_predict_steps: bad arguments");
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   return predict_batches(m, emb, d, batch, first_batch, n_batches, nullptr);
@@ -2599,6 +2836,7 @@ int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int ba
 // its own result is ready.  Rows are scored independently and passes of < 8192 rows all run the same forward kernel
 // (ctr_fwd16_kernel), so a request's scores are bit-identical whether or not, and with whatever, it was coalesced.
 struct goctr_recsys {
+  goctr::Engine* const eng = &goctr::engine();   // the engine (device, streams, arena) the handle was created on
   goctr_ubcache* ub = nullptr;    // not owned
   goctr_emb* emb = nullptr;       // not owned
   int64_t n_users = 0, n_items = 0; int U = 0, C = 0;
@@ -2688,11 +2926,18 @@ struct ServePool {
   // (goctr_*_destroy of something a slot may have buffers sized for: nothing to do -- slots hold no handle pointers)
 };
 // (never destroyed: a static destructor would release streams and pinned buffers after the HIP runtime has shut down)
-ServePool& serve_pool() { static ServePool* p = new ServePool; return *p; }
+ServePool& serve_pool() {
+  Engine& e = engine();                        // (slots hold streams and buffers of this engine's device)
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!e.serve_pool) e.serve_pool = new ServePool;
+  return *static_cast<ServePool*>(e.serve_pool);
+}
 struct SlotLease {
+  ServePool& pool;
   ServeSlot* s;
-  SlotLease() : s(serve_pool().acquire()) {}
-  ~SlotLease() { if (s) serve_pool().release(s); }
+  SlotLease() : pool(serve_pool()), s(pool.acquire()) {}
+  ~SlotLease() { if (s) pool.release(s); }
 };
 
 // A serving pass must see every weight write queued on the main stream so far (training is asynchronous).  The calling
@@ -2883,7 +3128,8 @@ extern "C" {
 
 int goctr_recsys_create(goctr_ubcache* c, goctr_emb* emb, const float* user_table, int64_t n_users, int U,
                         const float* item_table, int64_t n_items, int C, goctr_recsys** out) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(emb);
+  GOCTR_SAME_ENGINE(c, emb);
   GOCTR_CHECK(emb && out && n_users > 0 && n_items > 0 && U >= 0 && C >= 0, "goctr_recsys_create: bad arguments");
   GOCTR_CHECK((U == 0 || user_table) && (C == 0 || item_table), "goctr_recsys_create: feature table missing");
   GOCTR_CHECK(!c || c->n_users == n_users, "goctr_recsys_create: user table has %lld rows, the behaviour cache %lld users",
@@ -2898,15 +3144,18 @@ int goctr_recsys_create(goctr_ubcache* c, goctr_emb* emb, const float* user_tabl
 
 void goctr_recsys_destroy(goctr_recsys* r) {
   if (!r) return;
-  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
+  EngineScope on(r->eng);
+  std::lock_guard<std::recursive_mutex> lk(r->eng->mu);
   if (engine().inited) (void)hipDeviceSynchronize();      // (serving passes are synchronous: none is in flight once its caller returned)
   delete r;
 }
 
 int goctr_batch_predict(goctr_model* m, goctr_recsys* r, const int32_t* users, const int32_t* items, const int64_t* ts,
                         int64_t n, int batch, float* scores, uint8_t* failed, int64_t* n_failed) {
+  EngineScope on(handle_engine(m));
   if (require_engine()) return -1;
   GOCTR_CHECK(m && r && users && items && scores && n >= 0 && batch > 0, "goctr_batch_predict: bad arguments");
+  GOCTR_SAME_ENGINE(m, r);
   GOCTR_CHECK(r->emb->D == m->cfg.D && r->U == m->cfg.U && r->C == m->cfg.C, "goctr_batch_predict: recsys dims (U=%d,C=%d,D=%d) != model (U=%d,C=%d,D=%d)",
               r->U, r->C, r->emb->D, m->cfg.U, m->cfg.C, m->cfg.D);
   if (n_failed) *n_failed = 0;
@@ -2921,8 +3170,10 @@ int goctr_batch_predict(goctr_model* m, goctr_recsys* r, const int32_t* users, c
 
 int goctr_rank(goctr_model* m, goctr_recsys* r, int32_t user, const int32_t* items, int64_t n, int64_t ts, int batch,
                float* scores, uint8_t* failed, int64_t* n_failed) {
+  EngineScope on(handle_engine(m));
   if (require_engine()) return -1;
   GOCTR_CHECK(m && r && items && scores && n >= 0 && batch > 0, "goctr_rank: bad arguments");
+  GOCTR_SAME_ENGINE(m, r);
   GOCTR_CHECK(r->emb->D == m->cfg.D && r->U == m->cfg.U && r->C == m->cfg.C, "goctr_rank: recsys dims (U=%d,C=%d,D=%d) != model (U=%d,C=%d,D=%d)",
               r->U, r->C, r->emb->D, m->cfg.U, m->cfg.C, m->cfg.D);
   if (n_failed) *n_failed = 0;
@@ -2938,6 +3189,7 @@ int goctr_rank(goctr_model* m, goctr_recsys* r, int32_t user, const int32_t* ite
 // travel in passes of <= 64 MB.
 int goctr_predict_dense(goctr_model* m, const float* X, int64_t rows, int xcols, const int ranges[8], int batch,
                         float* y_out) {
+  EngineScope on(handle_engine(m));
   if (require_engine()) return -1;
   GOCTR_CHECK(m && X && y_out && ranges && rows >= 0 && batch > 0 && xcols > 0, "goctr_predict_dense: bad arguments");
   if (rows == 0) return 0;

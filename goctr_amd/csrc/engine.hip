@@ -2,9 +2,12 @@
 // per-kernel timers.  (No reference counterpart: go-ctr has no device runtime)
 #include "common.h"
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <map>
+#include <thread>
 
 namespace goctr {
 
@@ -19,10 +22,48 @@ void set_error(const char* fmt, ...) {
   g_err = buf;
 }
 
-Engine& engine() {
-  static Engine e;
+// ---------------------------------------------------------------- engines of the process
+// (never destroyed: a static destructor would release streams after the HIP runtime has shut down)
+namespace {
+constexpr int kMaxEngines = 64;
+std::atomic<Engine*> g_engines[kMaxEngines];
+std::atomic<int> g_nengines{0};
+std::mutex g_engines_mu;
+thread_local Engine* t_scope = nullptr;      // EngineScope
+thread_local Engine* t_selected = nullptr;   // goctr_engine_select / a rank worker's own engine
+}  // namespace
+
+Engine* engine_create() {
+  std::lock_guard<std::mutex> lk(g_engines_mu);
+  const int n = g_nengines.load();
+  if (n >= kMaxEngines) { set_error("more than %d engines", kMaxEngines); return nullptr; }
+  Engine* e = new Engine;
+  e->index = n;
+  g_engines[n].store(e);
+  g_nengines.store(n + 1);
   return e;
 }
+Engine* engine_at(int k) {
+  if (k == 0 && g_nengines.load() == 0) (void)engine_create();
+  return k >= 0 && k < g_nengines.load() ? g_engines[k].load() : nullptr;
+}
+int engine_count() { return std::max(1, g_nengines.load()); }
+
+Engine& engine() {
+  if (t_scope) return *t_scope;
+  if (t_selected) return *t_selected;
+  return *engine_at(0);
+}
+
+EngineScope::EngineScope(Engine* e) : prev(t_scope) {
+  if (e) t_scope = e;
+  Engine& cur = engine();
+  if (cur.inited) {     // hipSetDevice is per host thread: any thread may call any entry point on any handle
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != cur.device) (void)hipSetDevice(cur.device);
+  }
+}
+EngineScope::~EngineScope() { t_scope = prev; }
 
 // the calling thread's target stream (null = the engine's main stream)
 static thread_local hipStream_t t_active = nullptr;
@@ -32,11 +73,6 @@ Engine::ActiveStream& Engine::ActiveStream::operator=(hipStream_t s) {
   return *this;
 }
 
-std::recursive_mutex& engine_mutex() {
-  static std::recursive_mutex mu;
-  return mu;
-}
-
 uint64_t next_uid() {
   static std::atomic<uint64_t> n{1};
   return n.fetch_add(1);
@@ -44,10 +80,76 @@ uint64_t next_uid() {
 
 int require_engine() {
   if (!engine().inited) {
-    set_error("goctr: no HIP device bound -- call goctr_init() first (there is no CPU fallback)");
+    set_error("goctr: no HIP device bound -- call goctr_init() / goctr_init_devices() first (there is no CPU fallback)");
     return -1;
   }
   return 0;
+}
+
+// ---------------------------------------------------------------- rank workers (one persistent host thread per engine >= 1)
+namespace {
+struct Worker {
+  std::thread th;
+  std::mutex mu; std::condition_variable cv;
+  const std::function<int(int)>* job = nullptr;
+  bool done = false; int rc = 0; std::string err;
+};
+Worker* g_workers[kMaxEngines] = {nullptr};
+std::mutex g_run_mu;      // one multi-engine call at a time
+
+void worker_main(int k) {
+  Worker& w = *g_workers[k];
+  t_selected = engine_at(k);
+  for (;;) {
+    const std::function<int(int)>* job;
+    {
+      std::unique_lock<std::mutex> lk(w.mu);
+      w.cv.wait(lk, [&] { return w.job != nullptr; });
+      job = w.job;
+    }
+    int rc;
+    {
+      EngineScope on(engine_at(k));
+      rc = (*job)(k);
+    }
+    {
+      std::lock_guard<std::mutex> lk(w.mu);
+      w.rc = rc; w.err = rc ? g_err : std::string(); w.job = nullptr; w.done = true;
+    }
+    w.cv.notify_all();
+  }
+}
+}  // namespace
+
+int run_on_engines(int n, const std::function<int(int)>& fn) {
+  GOCTR_CHECK(n >= 1 && n <= engine_count(), "run_on_engines: %d ranks but %d engines (goctr_init_devices)", n, engine_count());
+  std::lock_guard<std::mutex> run_lk(g_run_mu);
+  for (int k = 1; k < n; ++k) {
+    if (!g_workers[k]) {
+      g_workers[k] = new Worker;
+      g_workers[k]->th = std::thread(worker_main, k);
+      g_workers[k]->th.detach();
+    }
+    Worker& w = *g_workers[k];
+    { std::lock_guard<std::mutex> lk(w.mu); w.done = false; w.job = &fn; }
+    w.cv.notify_all();
+  }
+  int rc0;
+  {
+    EngineScope on(engine_at(0));
+    rc0 = fn(0);
+  }
+  std::string first = rc0 ? ("rank 0: " + g_err) : std::string();
+  int rc = rc0;
+  for (int k = 1; k < n; ++k) {
+    Worker& w = *g_workers[k];
+    std::unique_lock<std::mutex> lk(w.mu);
+    w.cv.wait(lk, [&] { return w.done; });
+    if (w.rc && first.empty()) first = "rank " + std::to_string(k) + ": " + w.err;
+    if (w.rc) rc = -1;
+  }
+  if (rc) set_error("%s", first.c_str());
+  return rc ? -1 : 0;
 }
 
 static const char* kNames[GOCTR_K_COUNT] = {
@@ -86,21 +188,11 @@ void prof_flush() {
   e.pending.clear();
 }
 
-// ---------------------------------------------------------------- device arena
-namespace {
-struct Arena {
-  char* base = nullptr;
-  size_t size = 0;
-  std::map<size_t, size_t> free_blocks;   // offset -> length
-  std::map<size_t, size_t> used;          // offset -> length
-  std::mutex mu;
-};
-Arena g_arena;
-}  // namespace
-
+// ---------------------------------------------------------------- device arena (one per engine)
 void* arena_alloc(size_t bytes) {
-  std::lock_guard<std::mutex> lk(g_arena.mu);
-  Arena& a = g_arena;
+  Engine& e = engine();
+  Engine::Arena& a = e.arena;
+  std::lock_guard<std::mutex> lk(a.mu);
   const size_t need = (bytes + 255) / 256 * 256;
   if (!a.base) {
     const char* ev = getenv("GOCTR_ARENA_MB");
@@ -126,34 +218,72 @@ void* arena_alloc(size_t bytes) {
   }
   void* p = nullptr;
   if (hipMalloc(&p, need) != hipSuccess) {
+    (void)hipGetLastError();
     set_error("device allocation of %zu bytes failed", need);
     return nullptr;
   }
   return p;
 }
 
-void arena_free(void* p) {
+void arena_free(Engine* owner, void* p) {
   if (!p) return;
-  std::lock_guard<std::mutex> lk(g_arena.mu);
-  Arena& a = g_arena;
-  char* c = static_cast<char*>(p);
-  if (a.base && c >= a.base && c < a.base + a.size) {
-    size_t off = (size_t)(c - a.base);
-    auto u = a.used.find(off);
-    if (u == a.used.end()) return;
-    size_t len = u->second;
-    a.used.erase(u);
-    auto nxt = a.free_blocks.lower_bound(off);
-    if (nxt != a.free_blocks.end() && off + len == nxt->first) { len += nxt->second; nxt = a.free_blocks.erase(nxt); }
-    if (nxt != a.free_blocks.begin()) {
-      auto prv = std::prev(nxt);
-      if (prv->first + prv->second == off) { off = prv->first; len += prv->second; a.free_blocks.erase(prv); }
+  if (owner) {
+    Engine::Arena& a = owner->arena;
+    std::lock_guard<std::mutex> lk(a.mu);
+    char* c = static_cast<char*>(p);
+    if (a.base && c >= a.base && c < a.base + a.size) {
+      size_t off = (size_t)(c - a.base);
+      auto u = a.used.find(off);
+      if (u == a.used.end()) return;
+      size_t len = u->second;
+      a.used.erase(u);
+      auto nxt = a.free_blocks.lower_bound(off);
+      if (nxt != a.free_blocks.end() && off + len == nxt->first) { len += nxt->second; nxt = a.free_blocks.erase(nxt); }
+      if (nxt != a.free_blocks.begin()) {
+        auto prv = std::prev(nxt);
+        if (prv->first + prv->second == off) { off = prv->first; len += prv->second; a.free_blocks.erase(prv); }
+      }
+      a.free_blocks[off] = len;
+      return;
     }
-    a.free_blocks[off] = len;
-    return;
   }
   (void)hipFree(p);
 }
+
+int engine_bind(Engine& e, int device_ordinal) {
+  int n = 0;
+  goctr_device_count(&n);
+  GOCTR_CHECK(n > 0, "goctr_init: no HIP device visible (this engine has no CPU fallback)");
+  GOCTR_CHECK(device_ordinal >= 0 && device_ordinal < n, "goctr_init: device %d out of range (have %d)", device_ordinal, n);
+  if (e.inited && e.device == device_ordinal) return 0;
+  GOCTR_CHECK(!e.inited, "goctr_init: engine %d is already bound to device %d (asked for %d); one engine, one device", e.index,
+              e.device, device_ordinal);
+  GOCTR_HIP(hipSetDevice(device_ordinal));
+  {
+    // GOCTR_SYNC=spin|yield|block (experiments): how the host waits in goctr_sync / blocking copies
+    const char* sm = getenv("GOCTR_SYNC");
+    if (sm && *sm) {
+      const unsigned f = sm[0] == 's' ? hipDeviceScheduleSpin : (sm[0] == 'y' ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync);
+      (void)hipSetDeviceFlags(f);
+      (void)hipGetLastError();
+    }
+  }
+  hipDeviceProp_t prop;
+  GOCTR_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+  GOCTR_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+              "goctr_init: device is %s; this library is built for gfx950 (MI355X) only", prop.gcnArchName);
+  e.compute_units = prop.multiProcessorCount;
+  GOCTR_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
+  GOCTR_HIP(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
+  for (auto& ev : e.ev_fork) GOCTR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  GOCTR_HIP(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
+  e.device = device_ordinal;
+  e.inited = true;
+  return 0;
+}
+
+// comm.hip: builds the communicator of a goctr_init_devices group (RCCL over the distinct devices, else loop-back)
+int comm_group_init(int n);
 
 }  // namespace goctr
 
@@ -173,43 +303,63 @@ int goctr_device_count(int* n) {
 }
 
 int goctr_init(int device_ordinal) {
-  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
-  Engine& e = engine();
-  int n = 0;
-  goctr_device_count(&n);
-  GOCTR_CHECK(n > 0, "goctr_init: no HIP device visible (this engine has no CPU fallback)");
-  GOCTR_CHECK(device_ordinal >= 0 && device_ordinal < n, "goctr_init: device %d out of range (have %d)", device_ordinal, n);
-  if (e.inited && e.device == device_ordinal) return 0;
-  GOCTR_HIP(hipSetDevice(device_ordinal));
-  {
-    // GOCTR_SYNC=spin|yield|block (experiments): how the host waits in goctr_sync / blocking copies
-    const char* sm = getenv("GOCTR_SYNC");
-    if (sm && *sm) {
-      const unsigned f = sm[0] == 's' ? hipDeviceScheduleSpin : (sm[0] == 'y' ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync);
-      (void)hipSetDeviceFlags(f);
-      (void)hipGetLastError();
-    }
+  Engine& e = *engine_at(0);
+  std::lock_guard<std::recursive_mutex> lk(e.mu);
+  EngineScope on(&e);
+  return engine_bind(e, device_ordinal);
+}
+
+int goctr_init_devices(int n, const int* device_ids) {
+  GOCTR_CHECK(n >= 1 && n <= kMaxEngines && device_ids, "goctr_init_devices: bad arguments (1 <= n <= %d)", kMaxEngines);
+  int have = 0;
+  goctr_device_count(&have);
+  GOCTR_CHECK(have > 0, "goctr_init_devices: no HIP device visible (this engine has no CPU fallback)");
+  for (int k = 0; k < n; ++k)
+    GOCTR_CHECK(device_ids[k] >= 0 && device_ids[k] < have, "goctr_init_devices: device %d out of range (have %d)", device_ids[k], have);
+  static std::mutex mu;
+  std::lock_guard<std::mutex> once(mu);
+  const int existing = g_nengines.load();
+  if (existing > 1 || (existing == 1 && engine_at(0)->comm_active())) {
+    // idempotent for the same list; a different one would need every handle of the old engines gone
+    bool same = existing == n;
+    for (int k = 0; same && k < n; ++k) same = engine_at(k)->inited && engine_at(k)->device == device_ids[k];
+    GOCTR_CHECK(same, "goctr_init_devices: the process already runs %d engine(s); the device list cannot change", existing);
+    return 0;
   }
-  hipDeviceProp_t prop;
-  GOCTR_HIP(hipGetDeviceProperties(&prop, device_ordinal));
-  GOCTR_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
-              "goctr_init: device is %s; this library is built for gfx950 (MI355X) only", prop.gcnArchName);
-  e.compute_units = prop.multiProcessorCount;
-  if (!e.stream) {
-    GOCTR_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
-    GOCTR_HIP(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
-    for (auto& ev : e.ev_fork) GOCTR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    GOCTR_HIP(hipEventCreateWithFlags(&e.ev_join, hipEventDisableTiming));
+  for (int k = 0; k < n; ++k) {
+    Engine* e = k == 0 ? engine_at(0) : (engine_at(k) ? engine_at(k) : engine_create());
+    if (!e) return -1;
+    std::lock_guard<std::recursive_mutex> lk(e->mu);
+    EngineScope on(e);
+    if (engine_bind(*e, device_ids[k])) return -1;
+    e->rank = k; e->world = n;
   }
-  e.device = device_ordinal;
-  e.inited = true;
+  return comm_group_init(n);
+}
+
+int goctr_engine_count(int* n) {
+  GOCTR_CHECK(n, "goctr_engine_count: null argument");
+  *n = engine_count();
+  return 0;
+}
+
+int goctr_engine_select(int k) {
+  Engine* e = engine_at(k);
+  GOCTR_CHECK(e && e->inited, "goctr_engine_select: engine %d does not exist (goctr_init_devices made %d)", k, engine_count());
+  t_selected = e;
   return 0;
 }
 
 int goctr_sync(void) {
-  GOCTR_ENTER();
-  GOCTR_HIP(hipStreamSynchronize(engine().stream));
-  GOCTR_HIP(hipDeviceSynchronize());
+  if (require_engine()) return -1;
+  for (int k = 0; k < engine_count(); ++k) {     // every engine of the process
+    Engine* e = engine_at(k);
+    if (!e || !e->inited) continue;
+    EngineScope on(e);
+    std::lock_guard<std::recursive_mutex> lk(e->mu);
+    GOCTR_HIP(hipStreamSynchronize(e->stream));
+    GOCTR_HIP(hipDeviceSynchronize());
+  }
   return 0;
 }
 

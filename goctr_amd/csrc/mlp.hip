@@ -1035,7 +1035,7 @@ int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int
 }
 
 int init_attrs64() {
-  static bool done = false;
+  bool& done = engine().mlp_attrs_done;        // (function attributes are per device)
   if (done) return 0;
   if (allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 1>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 2>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 4>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 1>) ||
@@ -1048,6 +1048,7 @@ int init_attrs64() {
 }  // namespace
 
 struct goctr_mlp {
+  goctr::Engine* const eng = &goctr::engine();   // the engine (device, streams, arena) the handle was created on
   goctr_mlp_cfg cfg{};
   int nl = 0;                 // number of weight layers = n_layers - 1
   int units[8] = {0}, up[8] = {0};
@@ -1208,7 +1209,7 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   if (e.comm_active() && do_update) {
     // data-parallel step: rows sharded over the ranks (each rank's resident rows are its shard), local slab sums with the
     // GLOBAL batch size in the 1/n factors, ONE f64 all-reduce of [G | loss-term sum], then the identical update everywhere
-    a.world = e.world; a.n = n * e.world;
+    a.world = e.eff_world(); a.n = n * e.eff_world();
     a.mode = 3; a.do_update = 0;
     hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk + 1), dim3(256), 0, e.stream, a);
     GOCTR_HIP(hipGetLastError());
@@ -1380,14 +1381,15 @@ int goctr_mlp_create(const goctr_mlp_cfg* cfg, goctr_mlp** out) {
 
 void goctr_mlp_destroy(goctr_mlp* p) {
   if (!p) return;
-  std::lock_guard<std::recursive_mutex> lk(engine_mutex());
+  EngineScope on(p->eng);
+  std::lock_guard<std::recursive_mutex> lk(p->eng->mu);
   if (engine().inited) (void)hipStreamSynchronize(engine().stream);   // queued (asynchronous) steps still use its buffers and graphs
   delete p;
 }
 size_t goctr_mlp_nparams(const goctr_mlp* p) { return p ? (size_t)p->nparams : 0; }
 
 int goctr_mlp_set_params(goctr_mlp* p, const double* theta, size_t n) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(p);
   GOCTR_CHECK(p && theta && n == (size_t)p->nparams, "goctr_mlp_set_params: expected %lld values", p ? p->nparams : 0);
   std::lock_guard<std::mutex> lk(p->mu);
   std::vector<double> w((size_t)p->nflat, 0.0);
@@ -1434,14 +1436,14 @@ static int unpack(goctr_mlp* p, const DevBuf<double>& src, double* theta) {
 }
 
 int goctr_mlp_get_params(goctr_mlp* p, double* theta, size_t n) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(p);
   GOCTR_CHECK(p && theta && n == (size_t)p->nparams, "goctr_mlp_get_params: expected %lld values", p ? p->nparams : 0);
   std::lock_guard<std::mutex> lk(p->mu);
   return unpack(p, p->W, theta);
 }
 
 int goctr_mlp_loss_grad(goctr_mlp* p, const double* X, const double* Y, int n, double* loss, double* grads) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(p);
   GOCTR_CHECK(p && X && Y && n > 0, "goctr_mlp_loss_grad: bad arguments");
   std::lock_guard<std::mutex> lk(p->mu);
   if (ensure_ws(p, n)) return -1;
@@ -1463,7 +1465,7 @@ int goctr_mlp_loss_grad(goctr_mlp* p, const double* X, const double* Y, int n, d
 }
 
 int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(p);
   GOCTR_CHECK(p && X && Y && rows > 0, "goctr_mlp_upload: bad arguments");
   std::lock_guard<std::mutex> lk(p->mu);
   const int F = p->units[0], no = p->units[p->nl];
@@ -1475,7 +1477,7 @@ int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows)
 }
 
 int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(p);
   GOCTR_CHECK(p && p->rows > 0 && n_steps >= 0, "goctr_mlp_train_steps: upload rows first");
   std::lock_guard<std::mutex> lk(p->mu);
   const long long nb = p->rows / p->cfg.batch;
@@ -1538,7 +1540,7 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
 
 int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, const int32_t* perm, double* loss_curve,
                   int* iters_run) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(p);
   GOCTR_CHECK(p && X && Y && rows > 0, "goctr_mlp_fit: bad arguments");
   GOCTR_CHECK(rows % p->cfg.batch == 0, "goctr_mlp_fit: rows (%lld) must be a multiple of batch (%d) -- the reference "
               "leaves stale rows in a short last batch (basemlp64.go:800-802)", (long long)rows, p->cfg.batch);
@@ -1573,7 +1575,7 @@ int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, co
 }
 
 int goctr_mlp_predict(goctr_mlp* p, const float* X, int64_t rows, float* y_out) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(p);
   GOCTR_CHECK(p && X && y_out && rows >= 0, "goctr_mlp_predict: bad arguments");
   if (rows == 0) return 0;
   std::lock_guard<std::mutex> lk(p->mu);

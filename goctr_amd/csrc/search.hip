@@ -21,6 +21,7 @@
 using namespace goctr;
 
 struct goctr_searcher {
+  goctr::Engine* const eng = &goctr::engine();   // the engine (device, streams, arena) the handle was created on
   int64_t V = 0; int D = 0;
   DevBuf<double> items, norms, q, cand_sim, out_sim;
   DevBuf<long long> cand_idx, out_idx, ignore;
@@ -317,7 +318,7 @@ void goctr_searcher_destroy(goctr_searcher* s) { delete s; }
 
 int goctr_searcher_search(goctr_searcher* s, const double* queries, int Q, int k, const int64_t* ignore, int64_t* out_idx,
                           double* out_sim, int* out_count) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(s);
   GOCTR_CHECK(s && queries && out_idx && out_sim && out_count, "goctr_searcher_search: null argument");
   GOCTR_CHECK(Q > 0 && k > 0 && k <= KNN_MAX_K, "goctr_searcher_search: Q %d, k %d (k <= %d)", Q, k, KNN_MAX_K);
   std::lock_guard<std::mutex> lk(s->mu);

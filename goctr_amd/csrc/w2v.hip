@@ -571,6 +571,7 @@ void build_huffman(const int64_t* counts, int64_t V, int max_depth, std::vector<
 }  // namespace
 
 struct goctr_w2v {
+  goctr::Engine* const eng = &goctr::engine();   // the engine (device, streams, arena) the handle was created on
   goctr_w2v_cfg cfg{};
   int64_t V = 0;
   int64_t aux_rows = 0;
@@ -783,22 +784,22 @@ int goctr_w2v_create(const goctr_w2v_cfg* cfg, int64_t V, const int64_t* counts,
 void goctr_w2v_destroy(goctr_w2v* w) { delete w; }
 
 int goctr_w2v_set_param(goctr_w2v* w, const double* param) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && param, "goctr_w2v_set_param: null argument");
   return w->param.upload(param, (size_t)w->V * w->cfg.dim);
 }
 int goctr_w2v_set_aux(goctr_w2v* w, const double* aux) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && aux, "goctr_w2v_set_aux: null argument");
   return w->aux.upload(aux, (size_t)w->aux_rows * w->cfg.dim);
 }
 int goctr_w2v_get_param(goctr_w2v* w, double* param) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && param, "goctr_w2v_get_param: null argument");
   return w->param.download(param, (size_t)w->V * w->cfg.dim);
 }
 int goctr_w2v_get_aux(goctr_w2v* w, double* aux) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && aux, "goctr_w2v_get_aux: null argument");
   return w->aux.download(aux, (size_t)w->aux_rows * w->cfg.dim);
 }
@@ -832,7 +833,7 @@ int goctr_huffman_build(const int64_t* counts, int64_t V, int max_depth, int64_t
 }
 
 int goctr_w2v_upload_doc(goctr_w2v* w, const int32_t* doc, int64_t n_words, const uint8_t* keep_mask) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && doc && n_words > 0, "goctr_w2v_upload_doc: bad arguments");
   std::lock_guard<std::mutex> lk(w->mu);
   for (int64_t i = 0; i < n_words; ++i)
@@ -845,7 +846,7 @@ int goctr_w2v_upload_doc(goctr_w2v* w, const int32_t* doc, int64_t n_words, cons
 }
 
 int goctr_w2v_train_resident(goctr_w2v* w, int64_t corpus_len, double* lr) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && lr && corpus_len > 0, "goctr_w2v_train_resident: bad arguments");
   std::lock_guard<std::mutex> lk(w->mu);
   return run_pass(w, corpus_len, lr);
@@ -860,7 +861,7 @@ int goctr_w2v_train(goctr_w2v* w, const int32_t* doc, int64_t n_words, int64_t c
 // word2vec.Train's prelude over a device-resident corpus (word2vec.go:90-135): the model is sized by the corpus'
 // dictionary, the Huffman tree / NS table come from its cfs.
 int goctr_w2v_create_from_corpus(const goctr_w2v_cfg* cfg, goctr_corpus* c, goctr_w2v** out) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(c);
   GOCTR_CHECK(cfg && c && out, "goctr_w2v_create_from_corpus: null argument");
   std::vector<int64_t> cfs;
   {
@@ -874,7 +875,7 @@ int goctr_w2v_create_from_corpus(const goctr_w2v_cfg* cfg, goctr_corpus* c, goct
 
 // The training doc of one iteration = the corpus' IndexedDoc (device-to-device) + a fresh subsampling mask.
 int goctr_w2v_use_corpus(goctr_w2v* w, goctr_corpus* c, double subsample_threshold, uint64_t seed) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && c, "goctr_w2v_use_corpus: null argument");
   std::lock_guard<std::mutex> lk(w->mu);
   std::lock_guard<std::mutex> lk2(c->mu);
@@ -897,7 +898,7 @@ int goctr_w2v_use_corpus(goctr_w2v* w, goctr_corpus* c, double subsample_thresho
 }
 
 int goctr_w2v_get_keep_mask(goctr_w2v* w, uint8_t* keep, int64_t n) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && keep, "goctr_w2v_get_keep_mask: null argument");
   std::lock_guard<std::mutex> lk(w->mu);
   GOCTR_CHECK(w->has_keep && n == w->n_words, "goctr_w2v_get_keep_mask: no mask resident or %lld != %lld words", (long long)n, (long long)w->n_words);
@@ -905,7 +906,7 @@ int goctr_w2v_get_keep_mask(goctr_w2v* w, uint8_t* keep, int64_t n) {
 }
 
 int goctr_w2v_export_f32(goctr_w2v* w, float* out) {
-  GOCTR_ENTER();
+  GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && out, "goctr_w2v_export_f32: null argument");
   const long long n = (long long)w->V * w->cfg.dim;
   DevBuf<float> d;

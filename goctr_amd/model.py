@@ -109,6 +109,20 @@ class _CtrNet:
         capi.check(capi.load().goctr_model_sparse_exchange_bytes(self._h, C.byref(v)))
         return v.value
 
+    def replica(self, rank):
+        """the replica a multi-device training call (cfg.devices = n) keeps on engine `rank`, as a borrowed model object
+        (rank 0: this model); None before the first such call"""
+        h = C.c_void_p()
+        capi.check(capi.load().goctr_model_replica(self._h, C.c_int(rank), C.byref(h)))
+        if not h:
+            return None
+        if rank == 0:
+            return self
+        r = object.__new__(type(self))
+        r.__dict__.update(self.__dict__)
+        r._h, r._borrowed = h, True
+        return r
+
     def init_gaussian(self, rng):
         """G.Gaussian(0, 1) weights, att0 = 1 (din.go:181-191; dnn.go:125-127)."""
         for n in ("mlp0", "mlp1", "mlp2"):
@@ -133,9 +147,9 @@ class _CtrNet:
         return json.dumps(d).encode()
 
     def close(self):
-        if self._h:
+        if self._h and not getattr(self, "_borrowed", False):
             capi.load().goctr_model_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -194,18 +208,20 @@ def NewYoutubeDnnFromJson(data: bytes) -> YoutubeDnn:
 
 
 def Train(uProfileDim, uBehaviorSize, uBehaviorDim, iFeatureDim, cFeatureDim, numExamples, batchSize, epochs,
-          earlyStop, si: SampleInfo, inputs: np.ndarray, targets: np.ndarray, m: _CtrNet, dropout_seed=42):
+          earlyStop, si: SampleInfo, inputs: np.ndarray, targets: np.ndarray, m: _CtrNet, dropout_seed=42, devices=0):
     """model.go:27-213.  ``inputs`` [numExamples, XCols] float32, ``targets`` [numExamples(,1)].
     Returns the per-epoch costs (the Go version only logs them: model.go:205).
     Like the reference, training applies Dropout(m.d0) / Dropout(m.d1) whenever the model carries non-zero rates
     (NewDinNet: 0.005, din.go:204-205,307-312; NewYoutubeDnn: 0.003): a counter-hash mask stream on the device, seeded
     by ``dropout_seed``.  The reference draws its masks from Go's math/rand, which cannot be reproduced without Go, so
-    the mask BITS are unpinned; the distribution is the same.  ``dropout_seed=None`` is the explicit opt-out."""
+    the mask BITS are unpinned; the distribution is the same.  ``dropout_seed=None`` is the explicit opt-out.
+    ``devices=n`` (after ``capi.init_devices``): the same single call, data-parallel over n engines (batchSize stays the
+    global batch; no reference counterpart)."""
     X = capi.f32(inputs)
     Y = capi.f32(targets).ravel()
     if X.shape[0] != numExamples or Y.shape[0] != numExamples:
         raise ValueError("numExamples does not match inputs/targets")
-    cfg = capi.default_train_cfg(batch=batchSize, epochs=epochs, early_stop=earlyStop, dropout_mode=0)
+    cfg = capi.default_train_cfg(batch=batchSize, epochs=epochs, early_stop=earlyStop, dropout_mode=0, devices=devices)
     if dropout_seed is not None and (m.d0 > 0 or m.d1 > 0):
         cfg.dropout_mode, cfg.p0, cfg.p1, cfg.seed = 2, m.d0, m.d1, dropout_seed
     costs = np.zeros(max(epochs, 1), np.float32)
@@ -271,6 +287,18 @@ class EmbeddingTable:
         capi.check(capi.load().goctr_emb_create(C.c_int64(self.V), C.c_int(self.D), capi.ptr(rows, C.c_float),
                                                 C.byref(self._h)))
 
+    def replica(self, rank):
+        """this table's replica on engine `rank` (multi-device training), borrowed; None before the first such call"""
+        h = C.c_void_p()
+        capi.check(capi.load().goctr_emb_replica(self._h, C.c_int(rank), C.byref(h)))
+        if not h:
+            return None
+        if rank == 0:
+            return self
+        r = object.__new__(EmbeddingTable)
+        r.V, r.D, r._h, r._borrowed = self.V, self.D, h, True
+        return r
+
     def get_rows(self, first=0, n=None):
         n = self.V - first if n is None else n
         out = np.empty((n, self.D), np.float32)
@@ -290,9 +318,9 @@ class EmbeddingTable:
         return X
 
     def close(self):
-        if self._h:
+        if self._h and not getattr(self, "_borrowed", False):
             capi.load().goctr_emb_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:

@@ -39,6 +39,23 @@ typedef struct goctr_w2v goctr_w2v;         /* item2vec state (param, HS node ve
 /* ---------------------------------------------------------------- runtime ---------------- */
 /* Binds the calling process to one GPU (one process per GPU) and creates the engine's streams. */
 int goctr_init(int device_ordinal);
+/* ONE process drives n ranks (SURVEY 8(b)'s goctr_init(n_devices, device_ids)): engine k is bound to HIP device
+ * device_ids[k], with its own streams, device arena and lock.  Distinct devices get an RCCL communicator over xGMI
+ * (ncclCommInitAll); a device that appears more than once gets several LOGICAL ranks joined by the loop-back communicator
+ * (csrc/comm.hip: fixed-rank-order sums and device copies ordered by events and a host barrier -- RCCL rejects duplicate
+ * GPUs), which runs every W > 1 code path on a one-GPU box (GOCTR_COMM=loopback forces it for distinct devices too).
+ * Handles created afterwards live on engine 0 (or the engine goctr_engine_select chose for the calling thread); every
+ * entry point that takes a handle runs on the handle's engine, whatever thread calls it.  A training call whose
+ * goctr_train_cfg.devices = n then shards each global batch over the n ranks from n internal host threads -- the single Go
+ * process of recommend.Train (recommend/rcmd.go:196-246) needs no launcher.  Idempotent for the same list. */
+int goctr_init_devices(int n, const int* device_ids);
+int goctr_engine_count(int* n);
+/* Tools / tests: bind the CALLING THREAD to engine k for the handles it creates from now on (a Go caller would need
+ * runtime.LockOSThread; the single-call entries above need neither this nor the next function). */
+int goctr_engine_select(int k);
+/* Tools / tests: let the calling thread's engine take part in its group's collectives (per-rank calls from n host
+ * threads, one per engine); off by default so that a plain call on one engine of a group is a single-device call. */
+int goctr_comm_group_enable(int on);
 int goctr_device_count(int* n);
 /* blocks until all work queued by this library has finished (hipDeviceSynchronize) */
 int goctr_sync(void);
@@ -118,6 +135,13 @@ typedef struct {
                                       come from Go's math/rand, so mask bits are unpinned, the distribution is not) */
   float p0, p1;                    /* 0.005/0.005 DIN (din.go:204-205), 0.003/0.003 YouTube (dnn.go:136-137) */
   uint32_t seed;
+  int devices;                     /* 0 / 1: the model's own engine.  n > 1 (= the n of goctr_init_devices): data parallel
+                                      inside this ONE call -- `batch` stays the GLOBAL batch of model.Train (model.go:28), rank r
+                                      takes rows [r, r+1) * batch/n of every batch (batch % n == 0), the flat gradient buffer is
+                                      all-reduced once per step, every rank applies the same Adam update; with embedding training
+                                      the sparse row gradients take the bucketed exchange.  The result lands in the handles the
+                                      caller passed (rank 0); replicas on the other engines are kept for the next call.
+                                      No reference counterpart: go-ctr trains on one CPU process. */
 } goctr_train_cfg;
 void goctr_train_cfg_default(goctr_train_cfg* c); /* the reference's literals */
 
@@ -205,6 +229,12 @@ int goctr_batch_predict(goctr_model* m, goctr_recsys* r, const int32_t* users, c
 /* Rank (rcmd.go:248-275): one user, n candidate items, one timestamp (time.Now().Unix() there) */
 int goctr_rank(goctr_model* m, goctr_recsys* r, int32_t user, const int32_t* items, int64_t n, int64_t ts, int batch,
                float* scores, uint8_t* failed, int64_t* n_failed);
+
+/* The replica a multi-device training call (cfg.devices = n) keeps on engine `rank` (rank 0: the handle itself); NULL before
+ * the first such call.  Borrowed: owned by the handle it was asked from.  For checks that the replicas are bit-identical
+ * (tests, bench.py's replica checksum) -- every entry point works on it, on its own engine. */
+int goctr_model_replica(goctr_model* m, int rank, goctr_model** out);
+int goctr_emb_replica(goctr_emb* e, int rank, goctr_emb** out);
 
 /* model.Train's epoch loop over a resident dataset (emb == NULL for dense datasets). */
 int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg,

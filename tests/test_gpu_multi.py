@@ -1,0 +1,281 @@
+"""W > 1 on ONE GPU: goctr_init_devices(W, [0] * W) makes W logical ranks (engines with their own streams, arenas, model
+replicas and row shards) joined by the loop-back communicator (csrc/comm.hip: RCCL rejects two ranks on one GPU), so every
+piece of the multi-GPU device code -- the split step graphs around the dense all-reduce, adam_attn_kernel behind a real
+reduction, emb_pack_send, the owner's base = r * Vw scan, emb_apply_gathered, the padded p * S exchange layout, item2vec's
+delta exchange -- runs with W = 2, 4, 8 and is compared with the single-device run on the GLOBAL batch.
+
+The training calls are the single-call entries: ONE goctr_train_steps / goctr_train_dataset / goctr_train_dense with
+cfg.devices = W (what a single Go process' recommend.Train reaches, recommend/rcmd.go:196-246), except item2vec and the
+sklearn-port MLP, which run per-rank calls from W host threads (goctr_engine_select + goctr_comm_group_enable)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PRELUDE = r'''
+import sys, ctypes as C, threading, numpy as np
+sys.path.insert(0, %(root)r)
+from goctr_amd import capi, model as gm
+W = %(W)d
+capi.init_devices([0] * W)
+assert capi.engine_count() == W
+'''
+
+
+def run_script(body, tmp_path, tag, timeout=900, env=None, **kw):
+    out = str(tmp_path / f"{tag}.npz")
+    kw = dict(kw, root=ROOT, out=out)
+    script = (PRELUDE + body) % kw
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, "-c", script], env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:] + "\n" + r.stderr[-4000:])
+    return np.load(out)
+
+
+DENSE_DP = r'''
+rng = np.random.default_rng(5)
+youtube = %(youtube)d
+rows, U, T, D, Cc, V = 4000, 52, 50, (64 if youtube else 16), 53, 500      # 4000 rows: the 4th global batch is short (928 rows)
+emb = (rng.standard_normal((V, D)) * 0.25).astype(np.float32)
+ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
+it = rng.integers(0, V, size=rows).astype(np.int32)
+uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+y = (rng.random(rows) < 0.5).astype(np.float32)
+tab = gm.EmbeddingTable(emb); ds = gm.Dataset.ids(ub, it, uf, cf, y)
+cls = gm.YoutubeDnn if youtube else gm.DinNet
+names = ("mlp0", "mlp1", "mlp2") if youtube else ("mlp0", "mlp1", "mlp2", "att0")
+def flat(m): return np.concatenate([m.get_weights(n).ravel() for n in names])
+def mk():                      # 0.2 N(0,1): the reference's N(0,1) init saturates the output sigmoid to exactly 1.0f on some rows once dropout
+    m = cls(U, T, D, D, Cc)    # rescales the activations, and BCE's 0 * log(0) is NaN there (in the reference too)
+    r = np.random.default_rng(1)
+    for n in ("mlp0", "mlp1", "mlp2"): m.set_weights(n, (r.standard_normal(m._shape(n)) * 0.2).astype(np.float32))
+    return m
+mA, mB = mk(), mk()
+B = 1024
+cA = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=2, p0=0.01, p1=0.01, seed=7, devices=W)
+cB = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=2, p0=0.01, p1=0.01, seed=7, devices=1)
+costA = gm.train_steps(mA, ds, cA, 13, emb=tab, want_costs=True)           # odd count: both graph parities
+costA2 = gm.train_steps(mA, ds, cA, 7, first_batch=13 %% 4, emb=tab, want_costs=True)   # a second call continuing the first (cached replicas / shards)
+costB = gm.train_steps(mB, ds, cB, 13, emb=tab, want_costs=True)
+costB2 = gm.train_steps(mB, ds, cB, 7, first_batch=13 %% 4, emb=tab, want_costs=True)
+capi.sync()
+reps = np.stack([flat(mA.replica(k)) for k in range(W)])
+np.savez(%(out)r, reps=reps, single=flat(mB), costA=np.concatenate([costA, costA2]), costB=np.concatenate([costB, costB2]))
+'''
+
+
+@pytest.mark.parametrize("W", [2, 4, 8])
+@pytest.mark.parametrize("youtube", [0, 1])
+def test_dense_data_parallel_one_call(tmp_path, W, youtube):
+    """20 steps of the frozen-embedding step (hash dropout on), global batch 1024 over W logical ranks in ONE call: every
+    replica bit-identical; equal to the single-device run on the global batch up to the summation order of the gradient
+    (W partial sums instead of one: <= 1e-6 relative per step)"""
+    r = run_script(DENSE_DP, tmp_path, f"dense_{W}_{youtube}", W=W, youtube=youtube)
+    reps, single = r["reps"], r["single"]
+    assert np.isfinite(single).all() and np.abs(single).max() > 0
+    for k in range(1, W):
+        assert np.array_equal(reps[0], reps[k]), f"replica {k} differs from rank 0"
+    # costs: the mean BCE over the global batch
+    assert np.max(np.abs(r["costA"] - r["costB"])) <= 1e-5
+    # weights after 20 Adam steps (|w| ~ 1; the first step's update is lr * sign-like, so order-of-summation noise is amplified
+    # only where a gradient is below Adam's eps)
+    assert np.max(np.abs(reps[0] - single)) <= 2e-5 * max(1.0, float(np.abs(single).max()))
+    assert np.mean(np.abs(reps[0] - single)) <= 1e-6
+
+
+TRAIN_DATASET = r'''
+from goctr_amd.recommend import SampleInfo
+rng = np.random.default_rng(11)
+U, T, D, Cc = 5, 3, 7, 5                                # model_test.go:22-27 dims
+rows, B = 118 * 4, 40 * W                               # a short last batch (model_test.go:33-34: 118 @ 20)
+X = rng.random((rows, U + T * D + D + Cc), dtype=np.float32)
+Y = (rng.random(rows) < 0.5).astype(np.float32)
+si = SampleInfo.from_dims(U, T, D, Cc)
+def mk():
+    m = gm.DinNet(U, T, D, D, Cc)
+    r = np.random.default_rng(2)
+    for n in ("mlp0", "mlp1", "mlp2"): m.set_weights(n, (r.standard_normal(m._shape(n)) * 0.3).astype(np.float32))
+    return m
+mA, mB = mk(), mk()
+costsA = gm.Train(U, T, D, D, Cc, rows, B, 6, 3, si, X, Y, mA, dropout_seed=None, devices=W)
+costsB = gm.Train(U, T, D, D, Cc, rows, B, 6, 3, si, X, Y, mB, dropout_seed=None)
+names = ("mlp0", "mlp1", "mlp2", "att0")
+def flat(m): return np.concatenate([m.get_weights(n).ravel() for n in names])
+reps = np.stack([flat(mA.replica(k)) for k in range(W)])
+np.savez(%(out)r, reps=reps, single=flat(mB), costA=costsA, costB=costsB)
+'''
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_model_train_dense_rows_one_call(tmp_path, W):
+    """model.Train's own convention (dense TrainSample rows from the host, epochs, early stop on the last batch's cost) with
+    devices = W: same epoch count, costs within 1e-5 of the single-device call, replicas bit-identical"""
+    r = run_script(TRAIN_DATASET, tmp_path, f"train_{W}", W=W)
+    assert len(r["costA"]) == len(r["costB"]) and len(r["costA"]) >= 1
+    assert np.max(np.abs(r["costA"] - r["costB"])) <= 1e-5
+    for k in range(1, W):
+        assert np.array_equal(r["reps"][0], r["reps"][k])
+    assert np.max(np.abs(r["reps"][0] - r["single"])) <= 2e-5
+
+
+EMB_DP = r'''
+rng = np.random.default_rng(9)
+youtube, case = %(youtube)d, %(case)r
+rows, U, T, D, Cc, V = 2048, 52, 20, (64 if youtube else 16), 53, 3001
+p = 1.0 / np.arange(1, V + 1) ** 1.05; p /= p.sum()
+perm = np.arange(V)
+if case == "hot1":      # the hottest id is 1: its owner (1 %% W) is not rank 0
+    perm[[0, 1]] = perm[[1, 0]]
+ub = perm[rng.choice(V, size=(rows, T), p=p)].astype(np.int32)
+it = perm[rng.choice(V, size=rows, p=p)].astype(np.int32)
+if case == "empty":     # every id a multiple of W: the buckets of owners 1 .. W-1 are empty in every batch
+    ub = (ub // W) * W; it = (it // W) * W
+ub[rng.random((rows, T)) < 0.2] = -1
+emb = (rng.standard_normal((V, D)) * 0.25).astype(np.float32)
+uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+y = (rng.random(rows) < 0.5).astype(np.float32)
+ds = gm.Dataset.ids(ub, it, uf, cf, y)
+cls = gm.YoutubeDnn if youtube else gm.DinNet
+names = ("mlp0", "mlp1", "mlp2") if youtube else ("mlp0", "mlp1", "mlp2", "att0")
+def flat(m): return np.concatenate([m.get_weights(n).ravel() for n in names])
+def mk():
+    m = cls(U, T, D, D, Cc)
+    r = np.random.default_rng(3)
+    for n in ("mlp0", "mlp1", "mlp2"): m.set_weights(n, (r.standard_normal(m._shape(n)) * 0.05).astype(np.float32))
+    return m.set_embedding_training(0.05)
+B = 512
+res = {}
+for steps in (1, 6):
+    tabA, tabB = gm.EmbeddingTable(emb), gm.EmbeddingTable(emb)
+    mA, mB = mk(), mk()
+    cA = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0, devices=W)
+    cB = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0, devices=1)
+    gm.train_steps(mA, ds, cA, steps, emb=tabA)
+    gm.train_steps(mB, ds, cB, steps, emb=tabB)
+    capi.sync()
+    res[f"tabs{steps}"] = np.stack([tabA.replica(k).get_rows() for k in range(W)])
+    res[f"tab1_{steps}"] = tabB.get_rows()
+    res[f"reps{steps}"] = np.stack([flat(mA.replica(k)) for k in range(W)])
+    res[f"single{steps}"] = flat(mB)
+    res[f"bytes{steps}"] = np.array([mA.replica(k).sparse_exchange_bytes() for k in range(W)])
+res["emb0"] = emb
+np.savez(%(out)r, **res)
+'''
+
+
+@pytest.mark.parametrize("W,youtube,case", [(2, 0, "hot1"), (4, 0, "hot1"), (2, 1, "hot1"), (2, 0, "empty"), (4, 1, "empty"), (8, 0, "zipf")])
+def test_trainable_embeddings_fixed_size_exchange(tmp_path, W, youtube, case):
+    """--train-emb: owner = id mod W, fixed-size buckets, three captured graphs around the collectives, with W > 1 on the
+    device.  The sparse row gradients are 64-bit fixed-point sums of per-sample terms, so after ONE step the table equals the
+    single-device table bit for bit (the per-sample terms do not depend on how the batch is sharded); after 6 steps the dense
+    weights differ by summation order and the tables follow them.  Replicas: tables and weights bit-identical."""
+    r = run_script(EMB_DP, tmp_path, f"emb_{W}_{youtube}_{case}", W=W, youtube=youtube, case=case)
+    for steps in (1, 6):
+        tabs, reps = r[f"tabs{steps}"], r[f"reps{steps}"]
+        assert np.isfinite(tabs).all()
+        assert np.abs(tabs[0] - r["emb0"]).max() > 0, "the table did not move"
+        for k in range(1, W):
+            assert np.array_equal(tabs[0], tabs[k]), f"table replica {k} differs"
+            assert np.array_equal(reps[0], reps[k]), f"weight replica {k} differs"
+        assert (r[f"bytes{steps}"] > 0).all()
+    # one step: exact integer sums of identical per-sample terms (2^-44 is one unit of the fixed-point accumulator); what may
+    # differ is the float rounding of  E - lr * sum  (applied in place on one device, as a gathered float delta on W)
+    d1 = np.abs(r["tabs1"][0].astype(np.float64) - r["tab1_1"].astype(np.float64)).max()
+    assert d1 <= 6e-8, f"after one step the table differs from the single-device table by {d1}"
+    d6 = np.abs(r["tabs6"][0] - r["tab1_6"]).max()
+    assert d6 <= 2e-6, d6
+    assert np.abs(r["reps6"][0] - r["single6"]).max() <= 2e-5
+
+
+W2V_THREADS = r'''
+from goctr_amd import embedding as ge
+rng = np.random.default_rng(3)
+V, n, dim = 60, 4000, 16
+p = 1.0 / np.arange(1, V + 1); p /= p.sum()
+docs = [rng.choice(V, size=n, p=p).astype(np.int32) for _ in range(W)]
+counts = np.bincount(np.concatenate(docs), minlength=V) + 1
+p0 = (rng.random((V, dim)) - 0.5) / dim
+def one(doc):                      # a rank's pass on its own (single device): p_r
+    m = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=True)
+    m.create(counts, p0)
+    lr = m.train_pass(doc, n * W, None, lr=0.025)
+    return m.get_param(), m.get_aux(), lr
+solo = [one(d) for d in docs]
+out = [None] * W
+errs = []
+def rank(k):
+    try:
+        capi.engine_select(k)
+        capi.comm_group_enable(True)
+        m = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=True)
+        m.create(counts, p0)
+        lr = m.train_pass(docs[k], n * W, None, lr=0.025)
+        out[k] = (m.get_param(), m.get_aux(), lr)
+    except Exception as e:
+        errs.append(repr(e))
+ths = [threading.Thread(target=rank, args=(k,)) for k in range(W)]
+[t.start() for t in ths]; [t.join() for t in ths]
+assert not errs, errs
+np.savez(%(out)r, solo_p=np.stack([s[0] for s in solo]), solo_a=np.stack([s[1] for s in solo]), p0=p0,
+         dp_p=np.stack([o[0] for o in out]), dp_a=np.stack([o[1] for o in out]))
+'''
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_item2vec_delta_exchange(tmp_path, W):
+    """item2vec, W ranks from W host threads: snapshot, local deterministic pass on the rank's corpus shard, all-reduce of
+    the parameter deltas, p = p0 + sum_r (p_r - p0).  The local passes are bit-exact single-stream f64, so the expected
+    result is computable from W single-device passes."""
+    r = run_script(W2V_THREADS, tmp_path, f"w2v_{W}", W=W)
+    for k in range(1, W):
+        assert np.array_equal(r["dp_p"][0], r["dp_p"][k]) and np.array_equal(r["dp_a"][0], r["dp_a"][k])
+    exp_p = r["p0"] + sum(r["solo_p"][k] - r["p0"] for k in range(W))
+    exp_a = sum(r["solo_a"][k] for k in range(W))          # (the HS node vectors start at zero)
+    assert np.max(np.abs(r["dp_p"][0] - exp_p)) <= 1e-12
+    assert np.max(np.abs(r["dp_a"][0] - exp_a)) <= 1e-12
+    assert np.max(np.abs(r["dp_p"][0] - r["p0"])) > 1e-4
+
+
+ABORT = r'''
+rng = np.random.default_rng(5)
+rows, U, T, D, Cc, V = 1024, 52, 10, 16, 53, 100
+emb = (rng.standard_normal((V, D)) * 0.25).astype(np.float32)
+ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
+it = rng.integers(0, V, size=rows).astype(np.int32)
+uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+y = (rng.random(rows) < 0.5).astype(np.float32)
+# per-rank calls from W threads; rank 1 never makes its call: rank 0 must come back with an error, not hang
+out = {}
+def rank(k):
+    capi.engine_select(k)
+    capi.comm_group_enable(True)
+    tab = gm.EmbeddingTable(emb); ds = gm.Dataset.ids(ub, it, uf, cf, y)
+    m = gm.DinNet(U, T, D, D, Cc).init_gaussian(np.random.default_rng(1))
+    cfg = capi.default_train_cfg(batch=256, epochs=1, dropout_mode=0)
+    if k == 1:
+        out[k] = "skipped"
+        return
+    try:
+        gm.train_steps(m, ds, cfg, 3, emb=tab, want_costs=True)
+        out[k] = "returned"
+    except capi.GoctrError as e:
+        out[k] = "error: " + str(e)
+ths = [threading.Thread(target=rank, args=(k,)) for k in range(W)]
+[t.start() for t in ths]; [t.join() for t in ths]
+np.savez(%(out)r, msg=np.array([out[0]]))
+'''
+
+
+def test_missing_rank_fails_instead_of_hanging(tmp_path):
+    """a rank that never reaches the collective: the loop-back barrier's timeout aborts the group and the waiting rank's call
+    returns an error (the watchdog the advisor asked for, on the communicator these boxes can run)"""
+    r = run_script(ABORT, tmp_path, "abort", W=2, env={"GOCTR_LOOP_TIMEOUT_S": "3"}, timeout=300)
+    msg = str(r["msg"][0])
+    assert msg.startswith("error:") and "did not reach the collective" in msg, msg
