@@ -19,6 +19,7 @@
 #include "ctr_chain.h"
 #include "ctr_chain_x3.h"
 #include "emb_train.h"
+#include "emb_plan.h"
 #include "scan.h"
 #include "ctr_kernels.h"
 #include "ctr_serve.h"
@@ -35,6 +36,11 @@ struct goctr_emb {
   // single-call multi-device training (goctr_train_cfg::devices): this table's replicas on engines 1 .. n-1 (owned), and the
   // version of THIS table they were last made equal to
   std::vector<goctr_emb*> reps; uint64_t reps_version = ~0ull;
+  // Rows are READ by serving passes on their slots' streams (shared) and WRITTEN on the main stream by goctr_emb_set_rows and
+  // by embedding training of any model that was given this table (exclusive).  ev_rows is recorded behind the last queued
+  // write: training is asynchronous, a serving pass waits for the event before its launches read the rows.
+  std::shared_mutex mu;
+  hipEvent_t ev_rows = nullptr; std::atomic<bool> rows_pending{false};
 };
 
 struct goctr_dataset {
@@ -108,6 +114,7 @@ struct FwdWs {
   int ensure(int Bn, int Ipn, int Tn, int H1p, int H2p, bool modular, hipStream_t st) {
     if (Bn <= B && Ipn == Ip && Tn == T && h0.p && (!modular || P0.p)) return 0;
     GOCTR_HIP(hipStreamSynchronize(st));       // launches still reading the old buffers
+    B = 0;                                     // (a failure below must not leave the old size next to missing buffers)
     auto z = [&](DevBuf<float>& b, size_t n) -> int {
       if (b.alloc(n, false)) return -1;
       GOCTR_HIP(hipMemsetAsync(b.p, 0, n * sizeof(float), st));
@@ -988,6 +995,21 @@ bool emb_plan_ok(const goctr_model* m, int B) {
   return lay && c.D <= 64 && c.T < (1 << EMB_PAIR_TBITS) && B < (1 << (31 - EMB_PAIR_TBITS)) && env_int("GOCTR_EMB_PLAN", 1) != 0;
 }
 
+// The plan is resident for the whole dataset (12 B per pair + 8 B per slot): bounded by GOCTR_EMB_PLAN_MAX_MB (default 32 768,
+// of 288 GB); a dataset beyond it keeps the atomics path (emb_grad_kernel), with a note on stderr, instead of failing an
+// allocation deep inside the first step.
+bool emb_plan_fits(const goctr_model* m, const goctr_dataset* d, long long V, int B) {
+  const long long per = m->cfg.T + 1, nb = cdiv(d->rows, B);
+  const double bytes = 12.0 * (double)(nb * B * per) + 8.0 * (double)(nb * std::min<long long>((long long)B * per, V));
+  const double budget = (double)env_int("GOCTR_EMB_PLAN_MAX_MB", 32768) * 1048576.0;
+  if (bytes <= budget) return true;
+  static std::atomic<bool> said{false};
+  if (!said.exchange(true))
+    fprintf(stderr, "goctr: the sparse plan of this dataset would take %.1f GB (> GOCTR_EMB_PLAN_MAX_MB = %d): embedding training "
+            "uses the atomics path\n", bytes / 1073741824.0, env_int("GOCTR_EMB_PLAN_MAX_MB", 32768));
+  return false;
+}
+
 // Build (or reuse) the sparse plan of dataset d at batch size B: per batch the distinct ids in ascending owner-major order
 // and the (sample, slot) pairs sorted by id.  One-time work per dataset, outside every capture: a count per id, two prefix
 // sums over the vocabulary and a fill per batch, with one small read-back per batch to advance the bases.
@@ -1001,44 +1023,20 @@ int ensure_emb_plan(goctr_model* m, const goctr_dataset* d, const RowSource& src
   hipStream_t s = e.stream;
   GOCTR_HIP(hipStreamSynchronize(s));
   m->graph.destroy();                                  // captured launches bake the plan's pointers in
-  const long long Vw = m->emb_Vw, Vp = Vw * W;
-  const long long nb = cdiv(d->rows, B), per = c.T + 1, cap = d->rows * per;
-  DevBuf<int> tpair, tpslot, tpid, tsid;
-  DevBuf<unsigned int> tsoff;
-  DevBuf<unsigned long long> tot;                      // [0] slots, [1] pairs of the batch being built
-  if (tpair.alloc((size_t)cap, false) || tpslot.alloc((size_t)cap, false) || tpid.alloc((size_t)cap, false) ||
-      tsid.alloc((size_t)cap, false) || tsoff.alloc((size_t)(cap + nb), false) || tot.alloc(2)) return -1;
-  std::vector<long long> pair_off((size_t)nb + 1, 0), slot_base((size_t)nb + 1, 0);
-  long long max_pairs = 0, max_slots = 0;
-  unsigned int* cnt = m->emb_mark.p;                   // all zero between steps; the fill counts it back to zero
-  for (long long k = 0; k < nb; ++k) {
-    EmbPlanBuildArgs a{src, B, c.T, src.V, W, Vw, k};
-    const dim3 g((unsigned)cdiv((long long)B * per, 256));
-    unsigned int* soff = tsoff.p + slot_base[k] + k;
-    hipLaunchKernelGGL(emb_plan_count_kernel, g, dim3(256), 0, s, a, cnt);
-    GOCTR_HIP(hipGetLastError());
-    if (exclusive_scan_sink(cnt, Vp, m->emb_tiles, tot.p, EmbNonZeroMap{}, EmbPlanSlotSink{m->emb_rank.p, tsid.p + slot_base[k], W, Vw})) return -1;
-    if (exclusive_scan_sink(cnt, Vp, m->emb_tiles, tot.p + 1, ScanIdentity{}, EmbPlanOffSink{m->emb_rank.p, soff})) return -1;
-    hipLaunchKernelGGL(emb_plan_tail_kernel, dim3(1), dim3(1), 0, s, tot.p, tot.p + 1, soff);
-    hipLaunchKernelGGL(emb_plan_fill_kernel, g, dim3(256), 0, s, a, cnt, m->emb_rank.p, soff, tpair.p + pair_off[k], tpslot.p + pair_off[k],
-                       tpid.p + pair_off[k]);
-    GOCTR_HIP(hipGetLastError());
-    unsigned long long h[2];
-    if (tot.download(h, 2)) return -1;
-    pair_off[k + 1] = pair_off[k] + (long long)h[1];
-    slot_base[k + 1] = slot_base[k] + (long long)h[0];
-    max_pairs = std::max(max_pairs, (long long)h[1]);
-    max_slots = std::max(max_slots, (long long)h[0]);
+  const long long Vw = m->emb_Vw;
+  const long long nb = cdiv(d->rows, B), per = c.T + 1;
+  // (emb_plan.hip: a stable sort of each batch's keys by owner-major row + one flag / scan / fill pass; no atomics, no
+  // per-batch read-back, temporaries sized for one batch)
+  const size_t np_cap = (size_t)(nb * B * per), ns_cap = (size_t)(nb * std::min<long long>((long long)B * per, src.V));
+  if (P.pair.alloc(np_cap, false) || P.pslot.alloc(np_cap, false) || P.pid.alloc(np_cap, false) || P.slot_id.alloc(ns_cap, false) ||
+      P.slot_off.alloc(ns_cap + (size_t)nb, false) || P.pair_off.alloc((size_t)nb + 1, false) || P.slot_base.alloc((size_t)nb + 1, false)) return -1;
+  long long tot[4] = {0, 0, 0, 0};
+  {
+    ProfScope ps(GOCTR_K_EMB_PLAN);
+    if (emb_plan_build(EmbPlanSource{src.ub_ids, src.item_ids, src.rows, src.V}, B, c.T, W, Vw, nb,
+                       EmbPlanArrays{P.pair.p, P.pslot.p, P.pid.p, P.slot_id.p, P.slot_off.p, P.pair_off.p, P.slot_base.p}, tot)) return -1;
   }
-  const size_t np = (size_t)std::max<long long>(pair_off[nb], 1), ns = (size_t)std::max<long long>(slot_base[nb], 1);
-  if (P.pair.alloc(np, false) || P.pslot.alloc(np, false) || P.pid.alloc(np, false) || P.slot_id.alloc(ns, false) ||
-      P.slot_off.alloc(ns + (size_t)nb, false) || P.pair_off.alloc((size_t)nb + 1, false) || P.slot_base.alloc((size_t)nb + 1, false)) return -1;
-  GOCTR_HIP(hipMemcpyAsync(P.pair.p, tpair.p, np * 4, hipMemcpyDeviceToDevice, s));
-  GOCTR_HIP(hipMemcpyAsync(P.pslot.p, tpslot.p, np * 4, hipMemcpyDeviceToDevice, s));
-  GOCTR_HIP(hipMemcpyAsync(P.pid.p, tpid.p, np * 4, hipMemcpyDeviceToDevice, s));
-  GOCTR_HIP(hipMemcpyAsync(P.slot_id.p, tsid.p, ns * 4, hipMemcpyDeviceToDevice, s));
-  GOCTR_HIP(hipMemcpyAsync(P.slot_off.p, tsoff.p, (ns + (size_t)nb) * 4, hipMemcpyDeviceToDevice, s));
-  if (P.pair_off.upload(pair_off.data(), pair_off.size()) || P.slot_base.upload(slot_base.data(), slot_base.size())) return -1;   // (synchronises)
+  const long long max_pairs = tot[2], max_slots = tot[3];
   if (c.kind == GOCTR_DIN && (m->emb_dx.ensure((size_t)B * c.T * c.D, false) || m->emb_gsum.ensure((size_t)B * c.D, false))) return -1;
   m->ex_fixed = false;
   if (e.comm_active() && env_int("GOCTR_EMB_FIXED_EXCHANGE", 1) != 0) {
@@ -1072,7 +1070,7 @@ int ensure_emb_plan(goctr_model* m, const goctr_dataset* d, const RowSource& src
     m->ex_bytes_last = (double)W * S * (4 + 8.0 * c.D) + (double)W * (double)R * (4 + 4.0 * c.D);
   }
   P.ds = d->uid; P.V = src.V; P.B = B; P.W = W; P.T = c.T; P.nb = nb; P.max_pairs = max_pairs; P.max_slots = max_slots;
-  P.total_pairs = pair_off[nb]; P.total_slots = slot_base[nb];
+  P.total_pairs = tot[0]; P.total_slots = tot[1];
   P.valid = true;
   return 0;
 }
@@ -1595,6 +1593,10 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   m->graph.destroy();
   const bool fuse = !e.comm_active() && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
   const int stp_now = m->stp;
+  struct StpGuard {      // every exit path (the GOCTR_HIP returns included) restores the parity and drops a half-built graph set
+    goctr_model* m; int stp; bool ok = false;
+    ~StpGuard() { m->stp = stp; if (!ok) m->graph.destroy(); }
+  } stp_guard{m, stp_now};
   for (int par = 0; par < 2; ++par) {
     m->stp = par;                      // the captured launches bake this parity's state pointers in
     hipGraph_t g = nullptr;
@@ -1649,6 +1651,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   sg.lr = o.tc->lr; sg.l2 = o.tc->l2; sg.b1 = o.tc->beta1; sg.b2 = o.tc->beta2; sg.eps = o.tc->eps;
   sg.flags = o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div; sg.world = e.eff_world(); sg.comm = e.comm_active();
   sg.pipelined = o.pipelined;
+  stp_guard.ok = true;
   return 0;
 }
 
@@ -1744,6 +1747,14 @@ int mark_weights_written(goctr_model* m) {
   return 0;
 }
 
+// behind the last queued launch that writes the table's rows (embedding training): serve_wait_rows
+int emb_mark_written(goctr_emb* e) {
+  if (!e->ev_rows) GOCTR_HIP(hipEventCreateWithFlags(&e->ev_rows, hipEventDisableTiming));
+  GOCTR_HIP(hipEventRecord(e->ev_rows, engine().stream));
+  e->rows_pending.store(true, std::memory_order_release);
+  return 0;
+}
+
 // W0[U:U+2D,:]^T for the dpv GEMM of the plan path: built here (outside any capture), then maintained by the Adam kernels
 int ensure_w0pv(goctr_model* m) {
   if (m->w0pv_live) return 0;
@@ -1760,8 +1771,17 @@ int ensure_w0pv(goctr_model* m) {
 // queue n_steps training steps (graph replay unless profiling / disabled)
 int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* tc, int n_steps);
 int run_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* tc, int n_steps) {
-  if (run_steps_impl(m, emb, d, tc, n_steps)) return -1;
-  return n_steps > 0 ? mark_weights_written(m) : 0;
+  // A call that fails half way may already have queued launches that write the weights: the event is recorded on EVERY exit,
+  // so a serving slot that takes the model's lock afterwards still waits for whatever was queued.
+  const int rc = run_steps_impl(m, emb, d, tc, n_steps);
+  if (n_steps > 0) {
+    const std::string msg = rc ? goctr_last_error() : "";
+    const int mrc = mark_weights_written(m);
+    if (m->emb_lr > 0.f && emb) (void)emb_mark_written(emb);
+    if (rc) { set_error("%s", msg.c_str()); return -1; }
+    if (mrc) return -1;
+  }
+  return rc;
 }
 int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* tc, int n_steps) {
   Engine& e = engine();
@@ -1772,7 +1792,7 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
   if (m->emb_lr > 0.f) {
     GOCTR_CHECK(src.id_mode, "embedding training needs an id-mode dataset (the dense TrainSample rows carry no ids)");
     if (ensure_emb_workspace(m, src.V, B)) return -1;
-    if (emb_plan_ok(m, B)) { if (ensure_emb_plan(m, d, src, B) || ensure_w0pv(m)) return -1; }
+    if (emb_plan_ok(m, B) && emb_plan_fits(m, d, src.V, B)) { if (ensure_emb_plan(m, d, src, B) || ensure_w0pv(m)) return -1; }
     else { m->plan.valid = false; m->w0pv_live = false; }
   }
   const bool have_start = m->pend_retarget;                    // the host knows the batch the call starts at
@@ -2098,6 +2118,27 @@ int goctr_model_set_embedding_training(goctr_model* m, double lr) {
   return 0;
 }
 
+int goctr_model_get_emb_plan(goctr_model* m, int64_t* n_batches, int64_t* n_pairs, int64_t* n_slots, int32_t* pair, int32_t* pslot,
+                             int32_t* pid, int32_t* slot_id, uint32_t* slot_off, int64_t* pair_off, int64_t* slot_base) {
+  GOCTR_ENTER_H(m);
+  GOCTR_CHECK(m, "goctr_model_get_emb_plan: null argument");
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
+  const auto& P = m->plan;
+  GOCTR_CHECK(P.valid, "goctr_model_get_emb_plan: no plan resident (run an embedding-training step first)");
+  if (n_batches) *n_batches = P.nb;
+  if (n_pairs) *n_pairs = P.total_pairs;
+  if (n_slots) *n_slots = P.total_slots;
+  const size_t np = (size_t)P.total_pairs, ns = (size_t)P.total_slots, nb = (size_t)P.nb;
+  if (pair && np && P.pair.download(pair, np)) return -1;
+  if (pslot && np && P.pslot.download(pslot, np)) return -1;
+  if (pid && np && P.pid.download(pid, np)) return -1;
+  if (slot_id && ns && P.slot_id.download(slot_id, ns)) return -1;
+  if (slot_off && P.slot_off.download(slot_off, ns + nb)) return -1;
+  if (pair_off && P.pair_off.download(reinterpret_cast<long long*>(pair_off), nb + 1)) return -1;
+  if (slot_base && P.slot_base.download(reinterpret_cast<long long*>(slot_base), nb + 1)) return -1;
+  return 0;
+}
+
 int goctr_model_sparse_exchange_bytes(goctr_model* m, double* bytes) {
   GOCTR_ENTER_H(m);
   GOCTR_CHECK(m && bytes, "goctr_model_sparse_exchange_bytes: null argument");
@@ -2134,6 +2175,7 @@ int goctr_emb_create(int64_t V, int D, const float* host_rows, goctr_emb** out) 
 int goctr_emb_set_rows(goctr_emb* e, int64_t first, int64_t n, const float* host_rows) {
   GOCTR_ENTER_H(e);
   GOCTR_CHECK(e && host_rows && first >= 0 && n >= 0 && first + n <= e->V, "goctr_emb_set_rows: range out of bounds");
+  std::unique_lock<std::shared_mutex> lk(e->mu);       // (serving passes read the rows under the shared lock; the upload below is synchronous)
   ++e->version;
   return n ? e->rows.upload(host_rows, (size_t)n * e->D, (size_t)first * e->D) : 0;
 }
@@ -2144,6 +2186,7 @@ void goctr_emb_destroy(goctr_emb* e) {
   EngineScope on(e->eng);
   std::lock_guard<std::recursive_mutex> lk(e->eng->mu);
   if (engine().inited) (void)hipStreamSynchronize(engine().stream);
+  if (e->ev_rows) (void)hipEventDestroy(e->ev_rows);
   delete e;
 }
 
@@ -2562,6 +2605,8 @@ int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const go
 
 static int train_steps_locked(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg, int64_t first_batch, int n_steps,
                               float* costs) {
+  std::unique_lock<std::shared_mutex> rows_lk;          // embedding training writes the table: serving passes wait (lock order: model, table)
+  if (m->emb_lr > 0.f && emb) rows_lk = std::unique_lock<std::shared_mutex>(emb->mu);
   const long long nb = cdiv(d->rows, cfg->batch);
   if (retarget_state(m, first_batch % nb, nb)) return -1;      // no host synchronisation on this path
   m->pend_no_costs = costs == nullptr;
@@ -2621,6 +2666,8 @@ int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const 
 
 static int train_dataset_locked(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg, float* epoch_costs,
                                 int* epochs_run) {
+  std::unique_lock<std::shared_mutex> rows_lk;          // embedding training writes the table: serving passes wait (lock order: model, table)
+  if (m->emb_lr > 0.f && emb) rows_lk = std::unique_lock<std::shared_mutex>(emb->mu);
   // a fresh solver per model.Train call (model.go:88)
   GOCTR_HIP(hipMemsetAsync(m->Mo.p, 0, sizeof(float) * m->nflat, engine().stream));
   GOCTR_HIP(hipMemsetAsync(m->Vo.p, 0, sizeof(float) * m->nflat, engine().stream));
@@ -2890,6 +2937,7 @@ struct ServeSlot {
     GOCTR_HIP(hipStreamSynchronize(stream));
     const int64_t want = std::max<int64_t>(std::max<int64_t>(n, 256), std::min<int64_t>(2 * cap, SERVE_PASS_ROWS));
     const size_t Br = (size_t)round_up((int)want, 32);
+    cap = 0;                                   // (a failure below must not leave the old capacity next to missing buffers)
     if (h_in) { (void)hipHostFree(h_in); h_in = nullptr; }
     if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; }
     GOCTR_HIP(hipHostMalloc((void**)&h_in, (size_t)want * 16, hipHostMallocDefault));
@@ -2953,6 +3001,15 @@ int serve_wait_weights(goctr_model* m, ServeSlot* s) {
   }
   return 0;
 }
+// the same for the embedding rows a pass gathers (written by embedding training of ANY model that was given the table);
+// the caller holds the table's lock shared
+int serve_wait_rows(goctr_emb* e) {
+  if (e && e->rows_pending.load(std::memory_order_acquire) && e->ev_rows) {
+    GOCTR_HIP(hipEventSynchronize(e->ev_rows));
+    e->rows_pending.store(false, std::memory_order_release);
+  }
+  return 0;
+}
 
 // One pass: the keys of `segs` (N rows in all, N <= SERVE_PASS_ROWS) -> scores / failed flags of every segment.
 // Caller holds m->mu shared and owns the slot.
@@ -2981,7 +3038,7 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   // is one launch (ctr_serve16_kernel) and one wait.  Larger passes keep the two DMA copies (GOCTR_SERVE_ZEROCOPY=rows, default 4096; 0 = never).
   const bool zc = N <= (int64_t)env_int("GOCTR_SERVE_ZEROCOPY", 4096);
   if (!zc) GOCTR_HIP(hipMemcpyAsync(s->d_in.p, s->h_in, (size_t)N * 16, hipMemcpyHostToDevice, s->stream));
-  if (serve_wait_weights(m, s)) return -1;
+  if (serve_wait_weights(m, s) || serve_wait_rows(r->emb)) return -1;
   const char* in_base = zc ? s->h_in : s->d_in.p;
   char* out_base = zc ? s->h_out : s->d_out.p;
   const long long* dts = reinterpret_cast<const long long*>(in_base);
@@ -3116,6 +3173,7 @@ int serve_keys_coalesced(goctr_model* m, goctr_recsys* r, KeySeg& g) {
 
 int serve_keys(goctr_model* m, goctr_recsys* r, KeySeg& g, int64_t* n_failed) {
   std::shared_lock<std::shared_mutex> lm(m->mu);        // weights stay put while a slot reads them
+  std::shared_lock<std::shared_mutex> le(r->emb->mu);   // ... and so do the embedding rows (lock order: model, table)
   const int64_t coalesce = std::min<int64_t>(std::max(0, env_int("GOCTR_SERVE_COALESCE", 1024)), SERVE_COALESCE_ROWS);
   const int rc = g.n <= coalesce ? serve_keys_coalesced(m, r, g) : serve_keys_direct(m, r, g);
   if (!rc && n_failed) *n_failed = g.n_failed;

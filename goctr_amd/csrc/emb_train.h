@@ -341,8 +341,8 @@ __global__ __launch_bounds__(EMB_GRAD_THREADS) void emb_grad_kernel(EmbTrainArgs
 // (dataset, batch size, vocabulary, world) and kept in HBM (12 B per pair -- 160 MB for bench.py's 262 144 rows, of 288 GB):
 //     slots of batch k   = the distinct ids it touches, in ascending (owner-major) id order      slot_id, slot_off
 //     pairs of batch k   = its (sample b, slot t) pairs sorted by slot                            pair = b << 12 | t, pslot, pid
-// (emb_plan_* kernels below: a count per id, two prefix sums over the vocabulary, a fill -- the only atomics left, and
-// they run once per dataset.)  A step then needs neither emb_mark, nor the rank scans, nor the LDS cache, nor emb_apply:
+// (emb_plan.hip: per batch a stable radix sort of the keys by owner-major row, a head-flag pass, one prefix sum and a fill --
+// no atomics, byte-identical from build to build; once per dataset.)  A step then needs neither emb_mark, nor the rank scans, nor the LDS cache, nor emb_apply:
 //   emb_coef   (DIN; one wavefront per sample, the attention kernels' layout) per pair the three scalars of
 //                  dx_t = alpha dp + beta v + gamma x_t        (alpha = g / T;  cosine: beta = h, gamma = -h s |v| / |x|;
 //                                                                euclid: beta = q / r, gamma = -q / r)
@@ -371,61 +371,7 @@ constexpr int EMB_PAIR_TBITS = 12;                 // t < 4096, b < 2^19
 constexpr int EMB_SEG = 16;                        // pairs per lane group (one component per lane): all of them in flight at once
 constexpr int EMB_SLOT_THREADS = 256;              // 16 lane groups at D = 16: 512 pairs per workgroup, several workgroups per CU
 
-// ---- plan build (once per dataset): count -> scans (scan.h) -> fill
-struct EmbPlanBuildArgs {
-  RowSource src; int B, T; long long V; int W; long long Vw; long long batch;
-};
-__device__ __forceinline__ long long emb_pidx_w(int id, int W, long long Vw) {
-  if (W == 1) return id;
-  const int q = id / W;
-  return (long long)(id - q * W) * Vw + q;
-}
-__device__ __forceinline__ int emb_plan_pair_id(const EmbPlanBuildArgs& a, long long p, int* code) {
-  const int per = a.T + 1;
-  if (p >= (long long)a.B * per) return -1;
-  const int b = (int)(p / per), t = (int)(p % per);
-  const long long gr = a.batch * (long long)a.B + b;
-  if (gr >= a.src.rows) return -1;
-  const int id = t < a.T ? a.src.ub_ids[gr * a.T + t] : a.src.item_ids[gr];
-  *code = (b << EMB_PAIR_TBITS) | t;
-  return (id >= 0 && id < a.V) ? id : -1;
-}
-__global__ void emb_plan_count_kernel(EmbPlanBuildArgs a, unsigned int* cnt) {
-  int code;
-  const int id = emb_plan_pair_id(a, (long long)blockIdx.x * 256 + threadIdx.x, &code);
-  if (id >= 0) atomicAdd(cnt + emb_pidx_w(id, a.W, a.Vw), 1u);
-}
-struct EmbNonZeroMap {
-  __device__ __forceinline__ unsigned int operator()(unsigned int v) const { return v ? 1u : 0u; }
-};
-// scan 1 (of "touched" flags): slot number of every touched id, slot -> id
-struct EmbPlanSlotSink {
-  unsigned int* rank; int* slot_id; int W; long long Vw;
-  __device__ __forceinline__ void operator()(long long i, unsigned int c, unsigned int r) const {
-    if (c) { rank[i] = r; slot_id[r] = (int)(W == 1 ? i : (i % Vw) * W + i / Vw); }
-  }
-};
-// scan 2 (of the counts): first pair of every slot
-struct EmbPlanOffSink {
-  const unsigned int* rank; unsigned int* slot_off;
-  __device__ __forceinline__ void operator()(long long i, unsigned int c, unsigned int off) const {
-    if (c) slot_off[rank[i]] = off;
-  }
-};
-__global__ void emb_plan_tail_kernel(const unsigned long long* n_slots, const unsigned long long* n_pairs, unsigned int* slot_off) {
-  slot_off[*n_slots] = (unsigned int)*n_pairs;
-}
-// the counts run back to zero here: the array is clean for the next batch
-__global__ void emb_plan_fill_kernel(EmbPlanBuildArgs a, unsigned int* cnt, const unsigned int* rank, const unsigned int* slot_off,
-                                     int* pair, int* pslot, int* pid) {
-  int code;
-  const int id = emb_plan_pair_id(a, (long long)blockIdx.x * 256 + threadIdx.x, &code);
-  if (id < 0) return;
-  const long long pi = emb_pidx_w(id, a.W, a.Vw);
-  const unsigned int s = rank[pi];
-  const unsigned int pos = slot_off[s] + atomicSub(cnt + pi, 1u) - 1u;
-  pair[pos] = code; pslot[pos] = (int)s; pid[pos] = id;
-}
+// ---- plan build (once per dataset): emb_plan.hip (a stable sort of each batch's keys + one flag / scan / fill pass)
 
 // ---- per step, DIN: the per-pair coefficients (sample-major; the layout of attn_bwd_kernel)
 struct EmbCoefArgs {

@@ -154,7 +154,7 @@ int run_on_engines(int n, const std::function<int(int)>& fn) {
 
 static const char* kNames[GOCTR_K_COUNT] = {
     "attn_fwd", "gemm_fwd0", "gemm_fwd1", "gemm_out", "bwd_dz1", "bwd_dz0", "bwd_dp",
-    "attn_bwd", "dW0", "dW1", "dW2", "reduce", "allreduce", "adam", "chain", "emb_train", "emb_grad"};
+    "attn_bwd", "dW0", "dW1", "dW2", "reduce", "allreduce", "adam", "chain", "emb_train", "emb_grad", "emb_plan"};
 
 // (main-stream launches only: the event pool is not shared with the serving slots' threads)
 ProfScope::ProfScope(int kernel_id) : id(kernel_id), on(engine().prof && t_active == nullptr) {

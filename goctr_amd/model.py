@@ -103,6 +103,20 @@ class _CtrNet:
         capi.check(capi.load().goctr_model_set_embedding_training(self._h, C.c_double(lr)))
         return self
 
+    def emb_plan(self):
+        """the resident sparse plan of the last embedding-training call as a dict of numpy arrays (tests / tools)"""
+        L = capi.load()
+        nb, npair, nslot = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        capi.check(L.goctr_model_get_emb_plan(self._h, C.byref(nb), C.byref(npair), C.byref(nslot), None, None, None, None, None, None, None))
+        p = {"pair": np.empty(npair.value, np.int32), "pslot": np.empty(npair.value, np.int32), "pid": np.empty(npair.value, np.int32),
+             "slot_id": np.empty(nslot.value, np.int32), "slot_off": np.empty(nslot.value + nb.value, np.uint32),
+             "pair_off": np.empty(nb.value + 1, np.int64), "slot_base": np.empty(nb.value + 1, np.int64)}
+        capi.check(L.goctr_model_get_emb_plan(self._h, None, None, None, capi.ptr(p["pair"], C.c_int32), capi.ptr(p["pslot"], C.c_int32),
+                                              capi.ptr(p["pid"], C.c_int32), capi.ptr(p["slot_id"], C.c_int32),
+                                              capi.ptr(p["slot_off"], C.c_uint32), capi.ptr(p["pair_off"], C.c_int64),
+                                              capi.ptr(p["slot_base"], C.c_int64)))
+        return p
+
     def sparse_exchange_bytes(self):
         """bytes this rank sent in the last step's sparse-gradient exchange (0 without a communicator)"""
         v = C.c_double(0)

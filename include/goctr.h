@@ -111,6 +111,13 @@ int goctr_model_set_embedding_training(goctr_model* m, double lr);
 /* bytes this rank SENT in the last step's sparse-gradient exchange (ids + 64-bit fixed-point rows to their owners, then
  * the owners' (id, delta) lists to every rank; self included); 0 without a communicator */
 int goctr_model_sparse_exchange_bytes(goctr_model* m, double* bytes);
+/* The resident sparse plan the last embedding-training call built for its dataset (csrc/emb_plan.hip; tests / tools): per
+ * batch the (sample << 12 | slot) pairs sorted by embedding row -- stable, so two builds are byte-identical -- with their
+ * slot and row, the distinct rows in ascending owner-major order and the run starts.  Call with the array pointers NULL to
+ * get the sizes (*n_pairs, *n_slots, *n_batches), then with arrays of pair / pslot / pid [n_pairs], slot_id [n_slots],
+ * slot_off [n_slots + n_batches], pair_off / slot_base [n_batches + 1].  Fails when no plan is resident. */
+int goctr_model_get_emb_plan(goctr_model* m, int64_t* n_batches, int64_t* n_pairs, int64_t* n_slots, int32_t* pair, int32_t* pslot,
+                             int32_t* pid, int32_t* slot_id, uint32_t* slot_off, int64_t* pair_off, int64_t* slot_base);
 /* resets the Adam moments and the step counter (a fresh gorgonia AdamSolver, model.go:88) */
 int goctr_model_reset_optimizer(goctr_model* m);
 /* Optimizer state for checkpoint / resume ("dinModel JSON ... with optimizer state added for resume";
@@ -255,7 +262,8 @@ int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int ba
  * While enabled the step runs eagerly (no hipGraph) with an event pair around every launch. */
 enum { GOCTR_K_ATTN_FWD = 0, GOCTR_K_GEMM_FWD0, GOCTR_K_GEMM_FWD1, GOCTR_K_GEMM_OUT, GOCTR_K_BWD_DZ1,
        GOCTR_K_BWD_DZ0, GOCTR_K_BWD_DP, GOCTR_K_ATTN_BWD, GOCTR_K_DW0, GOCTR_K_DW1, GOCTR_K_DW2,
-       GOCTR_K_REDUCE, GOCTR_K_ALLREDUCE, GOCTR_K_ADAM, GOCTR_K_CHAIN, GOCTR_K_EMB_TRAIN, GOCTR_K_EMB_GRAD, GOCTR_K_COUNT };
+       GOCTR_K_REDUCE, GOCTR_K_ALLREDUCE, GOCTR_K_ADAM, GOCTR_K_CHAIN, GOCTR_K_EMB_TRAIN, GOCTR_K_EMB_GRAD, GOCTR_K_EMB_PLAN,
+       GOCTR_K_COUNT };
 int goctr_prof_enable(int on);
 int goctr_prof_reset(void);
 /* total milliseconds and launch count per kernel family since the last reset */

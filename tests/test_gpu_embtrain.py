@@ -288,3 +288,82 @@ def test_errors():
     ds = gm.Dataset.dense(X, np.zeros(32, np.float32), SampleInfo.from_dims(4, 3, 8, 4))
     with pytest.raises(capi.GoctrError):
         gm.train_steps(m, ds, capi.default_train_cfg(batch=32, epochs=1, dropout_mode=0), 1)        # dense rows carry no ids
+
+
+PLAN_SCRIPT = r'''
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from goctr_amd import capi, model as gm
+W = %(W)d
+if W > 1: capi.init_devices([0] * W)
+rng = np.random.default_rng(14)
+U, T, D, Cc, V, B, rows = 8, 50, 64, 6, %(V)d, %(B)d, %(rows)d
+p = 1.0 / np.arange(1, V + 1) ** 1.05; p /= p.sum()
+ub = rng.choice(V, size=(rows, T), p=p).astype(np.int32)
+ub[rng.random((rows, T)) < 0.2] = -1
+ub[3, 5] = V + 7                                                      # an id outside the table: no pair
+items = rng.choice(V, size=rows, p=p).astype(np.int32)
+E = (rng.standard_normal((V, D)) * 0.1).astype(np.float32)
+uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+y = (rng.random(rows) < 0.5).astype(np.float32)
+m = gm.YoutubeDnn(U, T, D, D, Cc)
+r = np.random.default_rng(1)
+for n in ("mlp0", "mlp1", "mlp2"):
+    m.set_weights(n, (r.standard_normal(m._shape(n)) * 0.05).astype(np.float32))
+m.set_embedding_training(0.05)
+tab = gm.EmbeddingTable(E); ds = gm.Dataset.ids(ub, items, uf, cf, y)
+gm.train_steps(m, ds, capi.default_train_cfg(batch=B, epochs=1, dropout_mode=0, devices=W), 1, emb=tab)
+capi.sync()
+plans = [m.replica(k).emb_plan() for k in range(W)]
+np.savez(%(out)r, ub=ub, items=items, **{f"{k}_{r}": v for r, pl in enumerate(plans) for k, v in pl.items()})
+'''
+
+
+def numpy_plan(ub, items, V, B, W, rank):
+    """the plan by definition: per batch of this rank's shard the pairs with a real row, STABLE-sorted by owner-major row index"""
+    rows, T = ub.shape
+    Bl = B // W
+    nb = -(-rows // B)
+    Vw = -(-(-(-V // W)) // 4) * 4
+    out = {k: [] for k in ("pair", "pslot", "pid", "slot_id", "slot_off")}
+    pair_off, slot_base = [0], [0]
+    for k in range(nb):
+        g = k * B + rank * Bl + np.arange(Bl)                          # this rank's rows of global batch k (pad rows: no pairs)
+        ids = np.full((Bl, T + 1), -1, np.int64)
+        ok = g < rows
+        ids[ok, :T] = ub[g[ok]]; ids[ok, T] = items[g[ok]]
+        code = (np.arange(Bl)[:, None] << 12) | np.arange(T + 1)[None, :]
+        ids, code = ids.ravel(), code.ravel()
+        real = (ids >= 0) & (ids < V)
+        ids, code = ids[real], code[real]
+        pidx = ids if W == 1 else (ids % W) * Vw + ids // W
+        order = np.argsort(pidx, kind="stable")
+        ids, code, pidx = ids[order], code[order], pidx[order]
+        head = np.ones(len(ids), bool); head[1:] = pidx[1:] != pidx[:-1]
+        out["pair"].append(code); out["pid"].append(ids); out["pslot"].append(np.cumsum(head) - 1)
+        out["slot_id"].append(ids[head]); out["slot_off"].append(np.concatenate([np.nonzero(head)[0], [len(ids)]]))
+        pair_off.append(pair_off[-1] + len(ids)); slot_base.append(slot_base[-1] + int(head.sum()))
+    res = {k: np.concatenate(v) for k, v in out.items()}
+    res["pair_off"], res["slot_base"] = np.array(pair_off), np.array(slot_base)
+    return res
+
+
+@pytest.mark.parametrize("W,V,B,rows", [(1, 3001, 512, 1500), (1, 1000003, 2048, 4096), (4, 50021, 1024, 2500)])
+def test_plan_build_is_the_stable_sort_by_row(tmp_path, W, V, B, rows):
+    """the plan (csrc/emb_plan.hip: radix sort + head flags + prefix sum + fill, no atomics) is EXACTLY the stable sort of each
+    batch's (sample, slot) pairs by owner-major row index -- byte for byte, a short last batch, pad slots, an id outside the
+    table, W = 1 and the per-rank plans of a W = 4 run (owner-major index space, each rank its own shard); two builds in two
+    processes: identical by construction (both equal the definition)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for trial in range(2):
+        out = str(tmp_path / f"plan{trial}.npz")
+        r = subprocess.run([sys.executable, "-c", PLAN_SCRIPT % dict(root=root, out=out, W=W, V=V, B=B, rows=rows)],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        z = np.load(out)
+        for rank in range(W):
+            ref = numpy_plan(z["ub"], z["items"], V, B, W, rank)
+            for k, v in ref.items():
+                got = z[f"{k}_{rank}"]
+                assert got.shape == v.shape and np.array_equal(got.astype(np.int64), v.astype(np.int64)), (trial, rank, k)

@@ -243,6 +243,49 @@ def test_item2vec_delta_exchange(tmp_path, W):
     assert np.max(np.abs(r["dp_p"][0] - r["p0"])) > 1e-4
 
 
+MLP_THREADS = r"""
+from goctr_amd import mlp as gmlp
+rng = np.random.default_rng(4)
+F, H, B, rows = 37, 20, 128, 1024
+X = rng.random((rows, F), dtype=np.float32)
+y = (X[:, 0] + X[:, 1] > 1.0).astype(np.float32)
+units = [F, H, 1]
+def make(batch):
+    clf = gmlp.MLPClassifier([H], "relu", "adam", 1e-4)
+    clf.BatchSize = batch
+    clf.create(units, batch, clf.init_params(units, np.random.default_rng(1)))
+    return clf
+single = make(B); single.upload(X, y); single.train_steps(11); capi.sync()
+Bl = B // W
+out = [None] * W; errs = []
+def rank(k):
+    try:
+        capi.engine_select(k)
+        capi.comm_group_enable(True)
+        idx = np.concatenate([np.arange(b * B + k * Bl, b * B + (k + 1) * Bl) for b in range(rows // B)])   # rank k's rows of every global batch
+        clf = make(Bl); clf.upload(X[idx], y[idx]); clf.train_steps(11); capi.sync()
+        out[k] = clf.get_params()
+    except Exception as e:
+        errs.append(repr(e))
+ths = [threading.Thread(target=rank, args=(k,)) for k in range(W)]
+[t.start() for t in ths]; [t.join() for t in ths]
+assert not errs, errs
+np.savez(%(out)r, single=single.get_params(), dp=np.stack(out))
+"""
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_sklearn_mlp_data_parallel(tmp_path, W):
+    """the sklearn-port MLP (f64): local slab sums with the GLOBAL batch in the 1/n factors, one f64 all-reduce of
+    [G | loss-term sum], the identical per-parameter Adam everywhere -- W ranks from W host threads vs the single-device
+    step on the global batch (f64 summation order only)"""
+    r = run_script(MLP_THREADS, tmp_path, f"mlp_{W}", W=W)
+    for k in range(1, W):
+        assert np.array_equal(r["dp"][0], r["dp"][k])
+    assert np.isfinite(r["single"]).all()
+    assert np.max(np.abs(r["dp"][0] - r["single"])) <= 1e-9 * max(1.0, float(np.abs(r["single"]).max()))
+
+
 ABORT = r'''
 rng = np.random.default_rng(5)
 rows, U, T, D, Cc, V = 1024, 52, 10, 16, 53, 100
