@@ -637,6 +637,13 @@ def main():
     }
     if args.train_emb > 0:
         out["sparse_exchange_bytes_per_step_per_rank"] = m.sparse_exchange_bytes()      # (0 without a communicator)
+        # the one-time sparse plan of the dataset (csrc/emb_plan.hip) is built before the timed region: charged here to a run of
+        # E epochs over the resident rows -- samples/s = E rows / (E batches x step + plan build)
+        pms, pnb = m.emb_plan_build_ms()
+        step_s = dt / args.steps
+        out["plan_build_ms"] = round(pms, 3)
+        out["plan_build_us_per_batch"] = round(pms * 1e3 / max(pnb, 1), 2)
+        out["samples_per_s_incl_plan"] = {f"epochs={E}": round(E * pnb * c["B"] * world / (E * pnb * step_s + pms * 1e-3), 1) for E in (1, 20, 200)}
     if args.train_emb > 0:
         out["config"]["workload"] += (f"; EXTENSION: embedding table trained too (SGD scatter-add, lr {args.train_emb}; "
                                       "the reference keeps it frozen; weights 0.05 N(0,1) so that the row gradients are non-zero)")

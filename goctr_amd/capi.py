@@ -54,7 +54,7 @@ SYMBOLS = [
     "goctr_comm_unique_id", "goctr_comm_init", "goctr_comm_world", "goctr_comm_allreduce_f64", "goctr_comm_destroy",
     "goctr_model_replica", "goctr_emb_replica", "goctr_model_create", "goctr_model_destroy", "goctr_model_set_weights", "goctr_model_get_weights",
     "goctr_model_reset_optimizer", "goctr_model_get_moments", "goctr_model_set_moments", "goctr_model_get_step",
-    "goctr_model_set_step", "goctr_model_get_emb_plan", "goctr_model_set_embedding_training", "goctr_model_sparse_exchange_bytes", "goctr_emb_get_rows", "goctr_train_cfg_default", "goctr_train_dense", "goctr_predict_dense",
+    "goctr_model_set_step", "goctr_model_get_emb_plan", "goctr_model_emb_plan_build_ms", "goctr_model_set_embedding_training", "goctr_model_sparse_exchange_bytes", "goctr_emb_get_rows", "goctr_train_cfg_default", "goctr_train_dense", "goctr_predict_dense",
     "goctr_loss_grad_dense", "goctr_emb_create", "goctr_emb_set_rows", "goctr_emb_destroy", "goctr_gather_rows",
     "goctr_dataset_create_dense", "goctr_dataset_create_ids", "goctr_dataset_destroy", "goctr_train_dataset",
     "goctr_train_steps", "goctr_predict_dataset", "goctr_predict_steps", "goctr_prof_enable", "goctr_prof_reset",

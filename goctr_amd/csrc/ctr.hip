@@ -7,6 +7,7 @@
 // all on one HIP stream; per-step varying values live in a device-side StepState so the sequence
 // can be captured once into a hipGraph and replayed.
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -193,6 +194,7 @@ struct goctr_model {
     bool valid = false; uint64_t ds = 0; long long V = 0; int B = 0, W = 0, T = 0;
     DevBuf<int> pair, pslot, pid, slot_id; DevBuf<unsigned int> slot_off; DevBuf<long long> pair_off, slot_base;
     long long nb = 0, max_pairs = 0, max_slots = 0, total_pairs = 0, total_slots = 0;
+    double build_ms = 0;         // host wall time of the build (goctr_model_emb_plan_build_ms)
     EmbPlanView view() const { return EmbPlanView{pair.p, pslot.p, pid.p, pair_off.p, slot_id.p, slot_off.p, slot_base.p}; }
   } plan;
   DevBuf<float> emb_dx, emb_gsum;  // emb_coef's per-pair row gradients [B, T, D] and item-row gradients [B, D]
@@ -1031,12 +1033,14 @@ int ensure_emb_plan(goctr_model* m, const goctr_dataset* d, const RowSource& src
   if (P.pair.alloc(np_cap, false) || P.pslot.alloc(np_cap, false) || P.pid.alloc(np_cap, false) || P.slot_id.alloc(ns_cap, false) ||
       P.slot_off.alloc(ns_cap + (size_t)nb, false) || P.pair_off.alloc((size_t)nb + 1, false) || P.slot_base.alloc((size_t)nb + 1, false)) return -1;
   long long tot[4] = {0, 0, 0, 0};
+  const auto t_build = std::chrono::steady_clock::now();
   {
     ProfScope ps(GOCTR_K_EMB_PLAN);
     if (emb_plan_build(EmbPlanSource{src.ub_ids, src.item_ids, src.rows, src.V}, B, c.T, W, Vw, nb,
                        EmbPlanArrays{P.pair.p, P.pslot.p, P.pid.p, P.slot_id.p, P.slot_off.p, P.pair_off.p, P.slot_base.p}, tot)) return -1;
   }
   const long long max_pairs = tot[2], max_slots = tot[3];
+  P.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
   if (c.kind == GOCTR_DIN && (m->emb_dx.ensure((size_t)B * c.T * c.D, false) || m->emb_gsum.ensure((size_t)B * c.D, false))) return -1;
   m->ex_fixed = false;
   if (e.comm_active() && env_int("GOCTR_EMB_FIXED_EXCHANGE", 1) != 0) {
@@ -2136,6 +2140,16 @@ int goctr_model_get_emb_plan(goctr_model* m, int64_t* n_batches, int64_t* n_pair
   if (slot_off && P.slot_off.download(slot_off, ns + nb)) return -1;
   if (pair_off && P.pair_off.download(reinterpret_cast<long long*>(pair_off), nb + 1)) return -1;
   if (slot_base && P.slot_base.download(reinterpret_cast<long long*>(slot_base), nb + 1)) return -1;
+  return 0;
+}
+
+int goctr_model_emb_plan_build_ms(goctr_model* m, double* ms, int64_t* n_batches) {
+  GOCTR_ENTER_H(m);
+  GOCTR_CHECK(m, "goctr_model_emb_plan_build_ms: null argument");
+  std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
+  GOCTR_CHECK(m->plan.valid, "goctr_model_emb_plan_build_ms: no plan resident (run an embedding-training step first)");
+  if (ms) *ms = m->plan.build_ms;
+  if (n_batches) *n_batches = m->plan.nb;
   return 0;
 }
 

@@ -117,6 +117,12 @@ class _CtrNet:
                                               capi.ptr(p["slot_base"], C.c_int64)))
         return p
 
+    def emb_plan_build_ms(self):
+        """(wall milliseconds, batches) of the resident plan's build"""
+        ms, nb = C.c_double(0), C.c_int64(0)
+        capi.check(capi.load().goctr_model_emb_plan_build_ms(self._h, C.byref(ms), C.byref(nb)))
+        return ms.value, nb.value
+
     def sparse_exchange_bytes(self):
         """bytes this rank sent in the last step's sparse-gradient exchange (0 without a communicator)"""
         v = C.c_double(0)

@@ -118,6 +118,9 @@ int goctr_model_sparse_exchange_bytes(goctr_model* m, double* bytes);
  * slot_off [n_slots + n_batches], pair_off / slot_base [n_batches + 1].  Fails when no plan is resident. */
 int goctr_model_get_emb_plan(goctr_model* m, int64_t* n_batches, int64_t* n_pairs, int64_t* n_slots, int32_t* pair, int32_t* pslot,
                              int32_t* pid, int32_t* slot_id, uint32_t* slot_off, int64_t* pair_off, int64_t* slot_base);
+/* wall time (host clock around the build, which ends with the one synchronisation it needs) and batch count of the resident
+ * plan's build: what bench.py's --train-emb lines charge to the first epoch */
+int goctr_model_emb_plan_build_ms(goctr_model* m, double* ms, int64_t* n_batches);
 /* resets the Adam moments and the step counter (a fresh gorgonia AdamSolver, model.go:88) */
 int goctr_model_reset_optimizer(goctr_model* m);
 /* Optimizer state for checkpoint / resume ("dinModel JSON ... with optimizer state added for resume";
