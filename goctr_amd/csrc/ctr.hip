@@ -11,6 +11,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
+#include <deque>
 #include <memory>
 #include <array>
 #include <map>
@@ -2888,7 +2889,7 @@ int goctr_predict_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, int ba
 // asynchronous on the slot's stream; no per-call allocation, no std::vector copies), the id-mode rows assembled from the
 // keys and a forward workspace.  It holds the model's lock SHARED (training holds it exclusive), and its stream waits for
 // the event the last weight-writing call recorded on the main stream -- training is asynchronous.  Slots: GOCTR_SERVE_SLOTS
-// (default 4), created on first use; further callers wait for a free one.
+// (default 8), created on first use; further callers wait for a free one, first come first served (ServePool).
 //
 // Micro-batching.  A Rank request is tens to hundreds of rows: three small launches and two copies whose cost is latency,
 // not work.  Requests of <= GOCTR_SERVE_COALESCE rows (default 1024) go through a combining queue per recsys: the first
@@ -2905,7 +2906,7 @@ struct goctr_recsys {
   // combining queue of small requests (micro-batcher)
   struct Req;
   std::mutex qmu; std::condition_variable qcv;
-  std::vector<Req*> queue; bool leader = false;
+  std::vector<Req*> queue; std::atomic<bool> leader{false};
 };
 
 namespace {
@@ -2964,26 +2965,53 @@ struct ServeSlot {
   }
 };
 
+// Slots are handed out FAIRLY: a released slot goes straight to the longest-waiting caller (FIFO hand-off, no barging).  With a
+// plain condition variable a caller in a closed loop re-took the slot it had just released before the woken waiter was
+// scheduled, and waiters starved: 8 callers on 4 slots had a p99 of 300 - 870 us and a worst case of 50 ms against a p50 of
+// 40 us (round 3's serving tail; profiles/r04_serve_tail.txt).  A waiter first spins on its hand-off word for about one pass
+// (~50 us) -- a futex wake-up costs as much as the pass it waits for -- and only then blocks.
 struct ServePool {
-  std::mutex mu; std::condition_variable cv;
+  std::mutex mu;
   std::vector<std::unique_ptr<ServeSlot>> all; std::vector<ServeSlot*> idle;
-  ServeSlot* acquire() {
-    std::unique_lock<std::mutex> lk(mu);
-    const size_t max_slots = (size_t)std::max(1, env_int("GOCTR_SERVE_SLOTS", 4));
-    for (;;) {
-      if (!idle.empty()) { ServeSlot* s = idle.back(); idle.pop_back(); return s; }
-      if (all.size() < max_slots) {
-        std::unique_ptr<ServeSlot> s(new ServeSlot);
-        if (s->init()) return nullptr;
-        all.push_back(std::move(s));
-        return all.back().get();
+  struct Waiter { std::atomic<ServeSlot*> got{nullptr}; std::condition_variable cv; bool blocked = false; };
+  std::deque<Waiter*> waiters;
+  // try_only: null instead of waiting when every slot is busy (the micro-batcher's "is a slot free right now?")
+  ServeSlot* acquire(bool try_only = false) {
+    Waiter w;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      const size_t max_slots = (size_t)std::max(1, env_int("GOCTR_SERVE_SLOTS", 8));
+      if (waiters.empty()) {
+        if (!idle.empty()) { ServeSlot* s = idle.back(); idle.pop_back(); return s; }
+        if (all.size() < max_slots) {
+          std::unique_ptr<ServeSlot> s(new ServeSlot);
+          if (s->init()) return nullptr;
+          all.push_back(std::move(s));
+          return all.back().get();
+        }
       }
-      cv.wait(lk);
+      if (try_only) return nullptr;
+      waiters.push_back(&w);
     }
+    for (int spin = 0; spin < 20000; ++spin) {            // ~50 us
+      if (ServeSlot* s = w.got.load(std::memory_order_acquire)) return s;
+      __builtin_ia32_pause();
+    }
+    std::unique_lock<std::mutex> lk(mu);
+    w.blocked = true;
+    w.cv.wait(lk, [&] { return w.got.load(std::memory_order_acquire) != nullptr; });
+    return w.got.load(std::memory_order_acquire);
   }
   void release(ServeSlot* s) {
-    { std::lock_guard<std::mutex> lk(mu); idle.push_back(s); }
-    cv.notify_one();
+    std::lock_guard<std::mutex> lk(mu);
+    if (waiters.empty()) { idle.push_back(s); return; }
+    Waiter* w = waiters.front();
+    waiters.pop_front();
+    // (w lives on the waiter's stack.  A SPINNING waiter returns the moment it sees `got`: nothing of w may be touched after
+    // the store.  A BLOCKED waiter cannot return before it re-takes `mu`, which we hold until after the notify.)
+    const bool blocked = w->blocked;
+    w->got.store(s, std::memory_order_release);
+    if (blocked) w->cv.notify_one();
   }
   // (goctr_*_destroy of something a slot may have buffers sized for: nothing to do -- slots hold no handle pointers)
 };
@@ -3031,8 +3059,11 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   int64_t N = 0;
   for (int k = 0; k < nseg; ++k) N += segs[k]->n;
   const int T = m->cfg.T;
-  if (s->ensure_keys(N, T, r->U, r->C)) return -1;
-  if (s->ws.ensure((int)N, m->Ip, T, m->H1p, m->H2p, !chain_ok(m), s->stream)) return -1;
+  // (sized for a full coalesced pass from the first call on: a slot that grew with every larger pass paid a pinned
+  // re-allocation + a stream synchronisation each time -- part of round 3's serving tail)
+  const int64_t cap_rows = std::max<int64_t>(N, SERVE_COALESCE_ROWS);
+  if (s->ensure_keys(cap_rows, T, r->U, r->C)) return -1;
+  if (s->ws.ensure((int)cap_rows, m->Ip, T, m->H1p, m->H2p, !chain_ok(m), s->stream)) return -1;
   const size_t Br = (size_t)round_up((int)N, 32);
   long long* hts = reinterpret_cast<long long*>(s->h_in);
   int32_t* hus = reinterpret_cast<int32_t*>(s->h_in + 8 * N);
@@ -3116,7 +3147,8 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
 }  // namespace
 
 struct goctr_recsys::Req {
-  goctr_model* m; KeySeg seg; int rc = 0; bool done = false; std::string err;
+  goctr_model* m; KeySeg seg; int rc = 0; std::atomic<bool> done{false}; std::string err;
+  Req(goctr_model* mm, const KeySeg& s) : m(mm), seg(s) {}
 };
 
 namespace {
@@ -3146,11 +3178,21 @@ int serve_keys_direct(goctr_model* m, goctr_recsys* r, KeySeg& g) {
 
 // the micro-batcher (see the section comment)
 int serve_keys_coalesced(goctr_model* m, goctr_recsys* r, KeySeg& g) {
-  goctr_recsys::Req me{m, g};
+  goctr_recsys::Req me(m, g);
   std::unique_lock<std::mutex> lk(r->qmu);
   r->queue.push_back(&me);
   while (!me.done) {
-    if (r->leader) { r->qcv.wait(lk); continue; }
+    if (r->leader.load(std::memory_order_acquire)) {
+      // a pass is in flight: it ends within tens of microseconds -- spin for about that long before paying a futex sleep + wake
+      lk.unlock();
+      for (int spin = 0; spin < 30000; ++spin) {
+        if (me.done.load(std::memory_order_acquire) || !r->leader.load(std::memory_order_acquire)) break;
+        __builtin_ia32_pause();
+      }
+      lk.lock();
+      if (!me.done.load(std::memory_order_acquire) && r->leader.load(std::memory_order_acquire)) r->qcv.wait(lk);
+      continue;
+    }
     // lead one pass: the longest prefix of the queue on one model that fits a pass (always contains the front)
     r->leader = true;
     std::vector<goctr_recsys::Req*> batch;
@@ -3175,8 +3217,8 @@ int serve_keys_coalesced(goctr_model* m, goctr_recsys* r, KeySeg& g) {
       if (rc) err = goctr_last_error();
     }
     lk.lock();
-    for (auto* q : batch) { q->rc = rc; q->err = err; q->done = true; }
-    r->leader = false;
+    for (auto* q : batch) { q->rc = rc; q->err = err; q->done.store(true, std::memory_order_release); }
+    r->leader.store(false, std::memory_order_release);
     r->qcv.notify_all();
   }
   lk.unlock();
@@ -3189,7 +3231,20 @@ int serve_keys(goctr_model* m, goctr_recsys* r, KeySeg& g, int64_t* n_failed) {
   std::shared_lock<std::shared_mutex> lm(m->mu);        // weights stay put while a slot reads them
   std::shared_lock<std::shared_mutex> le(r->emb->mu);   // ... and so do the embedding rows (lock order: model, table)
   const int64_t coalesce = std::min<int64_t>(std::max(0, env_int("GOCTR_SERVE_COALESCE", 1024)), SERVE_COALESCE_ROWS);
-  const int rc = g.n <= coalesce ? serve_keys_coalesced(m, r, g) : serve_keys_direct(m, r, g);
+  // Small requests: straight onto a slot when one is free RIGHT NOW (nothing to wait for, nothing to combine with: coalescing
+  // would only add the wait for the pass in flight -- it raised the 8-caller p50 at n = 256 from 38 to 63 us in round 3);
+  // when every slot is busy they join the combining queue, whose next leader scores everything that queued up in ONE pass.
+  int rc;
+  if (g.n <= coalesce) {
+    ServeSlot* free_slot = env_int("GOCTR_SERVE_ADAPTIVE", 1) != 0 ? serve_pool().acquire(true) : nullptr;
+    if (free_slot) {
+      KeySeg* one = &g;
+      const int64_t want_failed = g.n_failed;
+      rc = serve_keys_pass(m, r, free_slot, &one, 1);
+      serve_pool().release(free_slot);
+      if (want_failed < 0) g.n_failed = -1;
+    } else rc = serve_keys_coalesced(m, r, g);
+  } else rc = serve_keys_direct(m, r, g);
   if (!rc && n_failed) *n_failed = g.n_failed;
   return rc;
 }

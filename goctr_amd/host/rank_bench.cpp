@@ -117,9 +117,11 @@ int main(int argc, char** argv) {
           mean /= std::max<size_t>(k, 1);
           if (bad.load()) all_equal = false;
           std::printf("%s{\"n\": %d, \"threads\": %d, \"coalesce\": %s, \"calls\": %zu, \"rank_qps\": %.1f, \"rows_per_s\": %.1f, "
-                      "\"latency_us\": {\"mean\": %.1f, \"p50\": %.1f, \"p99\": %.1f, \"min\": %.1f}, \"mismatched_calls\": %d}",
+                      "\"latency_us\": {\"mean\": %.1f, \"p50\": %.1f, \"p90\": %.1f, \"p99\": %.1f, \"p999\": %.1f, \"max\": %.1f, \"min\": %.1f}, "
+                      "\"mismatched_calls\": %d}",
                       first ? "" : ", ", n, nt, mode == "0" ? "false" : "true", k, k / dt, k * (double)n / dt, mean,
-                      k ? all[k / 2] : 0.f, k ? all[std::min(k - 1, (size_t)(k * 0.99))] : 0.f, k ? all[0] : 0.f, bad.load());
+                      k ? all[k / 2] : 0.f, k ? all[std::min(k - 1, (size_t)(k * 0.90))] : 0.f, k ? all[std::min(k - 1, (size_t)(k * 0.99))] : 0.f,
+                      k ? all[std::min(k - 1, (size_t)(k * 0.999))] : 0.f, k ? all[k - 1] : 0.f, k ? all[0] : 0.f, bad.load());
           first = false;
         }
       }

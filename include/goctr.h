@@ -13,12 +13,12 @@
  *     (training, uploads, dataset builds) are serialised engine-wide by an internal lock.  The SERVING entry points --
  *     goctr_batch_predict, goctr_rank, goctr_predict_dense: what concurrent gin handler goroutines reach through
  *     Rank -> BatchPredict -> PredictAbstract.Predict, recommend/api.go:106-131 -- run CONCURRENTLY: each call takes a
- *     serving slot (own HIP stream, pinned staging buffers, forward workspace; GOCTR_SERVE_SLOTS of them, default 4)
- *     under a shared lock of the model, so calls on one model or on different models overlap on the GPU while a
- *     training call on that model waits for them (and they for it).  Small goctr_rank / goctr_batch_predict calls
- *     (<= GOCTR_SERVE_COALESCE rows, default 1024) that arrive while another one is in flight on the same
- *     (recsys, model) pair are coalesced into one launch sequence (a micro-batcher); scores do not depend on
- *     whether or with what a call was coalesced (rows are scored independently, same kernel, same bits);
+ *     serving slot (own HIP stream, pinned staging buffers, forward workspace; GOCTR_SERVE_SLOTS of them, default 8,
+ *     handed out first-come-first-served) under a shared lock of the model and of the embedding table, so calls on one
+ *     model or on different models overlap on the GPU while a training call on that model waits for them (and they for
+ *     it).  Small goctr_rank / goctr_batch_predict calls (<= GOCTR_SERVE_COALESCE rows, default 1024) that arrive while
+ *     EVERY slot is busy are coalesced into one launch sequence on the same (recsys, model) pair (a micro-batcher); scores
+ *     do not depend on whether or with what a call was coalesced (rows are scored independently, same kernel, same bits);
  *   - there is NO CPU fallback: without a HIP device every compute entry point fails loudly.
  */
 #ifndef GOCTR_H
