@@ -635,6 +635,12 @@ def main():
                           "independently; scores equal one-batch launches to float32 rounding; GOCTR_PRED_GROUP=1 for one batch per launch)",
         "rccl_world": rccl_world, "per_rank_ms_per_step": per_rank_ms,
     }
+    if world > 1:
+        mode = C.c_int(0)
+        capi.check(L.goctr_comm_capture_mode(C.byref(mode)))
+        out["dp_allreduce"] = ("a node of the multi-step graphs (captured RCCL collective, self-tested on this communicator)" if mode.value == 1
+                               else "between graph launches (capture off or failed its self-test)")
+        out["dp_mode"] = "one process per GPU (goctr_comm_init over the launcher's rendezvous); the single-process entry is goctr_init_devices + cfg.devices"
     if args.train_emb > 0:
         out["sparse_exchange_bytes_per_step_per_rank"] = m.sparse_exchange_bytes()      # (0 without a communicator)
         # the one-time sparse plan of the dataset (csrc/emb_plan.hip) is built before the timed region: charged here to a run of

@@ -51,7 +51,7 @@ class W2vCfg(C.Structure):
 # every symbol include/goctr.h declares (tests/test_capi_symbols.py checks the list against the header)
 SYMBOLS = [
     "goctr_init", "goctr_init_devices", "goctr_engine_count", "goctr_engine_select", "goctr_comm_group_enable", "goctr_device_count", "goctr_sync", "goctr_last_error", "goctr_version", "goctr_device_info",
-    "goctr_comm_unique_id", "goctr_comm_init", "goctr_comm_world", "goctr_comm_allreduce_f64", "goctr_comm_destroy",
+    "goctr_comm_unique_id", "goctr_comm_init", "goctr_comm_world", "goctr_comm_capture_mode", "goctr_comm_allreduce_f64", "goctr_comm_destroy",
     "goctr_model_replica", "goctr_emb_replica", "goctr_model_create", "goctr_model_destroy", "goctr_model_set_weights", "goctr_model_get_weights",
     "goctr_model_reset_optimizer", "goctr_model_get_moments", "goctr_model_set_moments", "goctr_model_get_step",
     "goctr_model_set_step", "goctr_model_get_emb_plan", "goctr_model_emb_plan_build_ms", "goctr_model_set_embedding_training", "goctr_model_sparse_exchange_bytes", "goctr_emb_get_rows", "goctr_train_cfg_default", "goctr_train_dense", "goctr_predict_dense",

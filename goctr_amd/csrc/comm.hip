@@ -261,6 +261,61 @@ int comm_broadcast(void* dev, size_t bytes, int root) {
   GOCTR_NCCL(g_rccl.Broadcast(dev, dev, bytes, ncclChar, root, (ncclComm_t)e.nccl_comm, e.stream));
   return 0;
 }
+namespace {
+__global__ void capture_test_fill_kernel(float* buf, int n, int rank, int round) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) buf[i] = (float)((i * 31 + rank * 7 + round) % 97) * 0.125f - 3.0f;
+}
+__global__ void capture_test_cmp_kernel(const float* a, const float* b, int n, float* mismatches) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && __float_as_uint(a[i]) != __float_as_uint(b[i])) atomicAdd(mismatches, 1.0f);
+}
+}  // namespace
+
+// Collective: every rank of the communicator calls it at the same point (the first data-parallel call that wants captured
+// collectives).  Two rounds of [fill | all-reduce] as a replayed graph against the same eagerly; the mismatch counts (and a
+// failed capture, counted as one) are summed over the ranks with an EAGER all-reduce, so all ranks reach the same verdict.
+// Waits go through comm_watch_stream: a replay that never completes fails the call on a timeout instead of hanging it.
+int comm_capture_selftest() {
+  Engine& e = engine();
+  if (e.capture_state != 0) return e.capture_state == 1 ? 1 : 0;
+  if (!comm_capturable()) { e.capture_state = -1; return 0; }
+  const int n = 4096;
+  DevBuf<float> cap, eag, bad;
+  if (cap.alloc(n, false) || eag.alloc(n, false) || bad.alloc(1)) { e.capture_state = -1; return 0; }
+  hipStream_t s = e.stream;
+  if (hipStreamSynchronize(s) != hipSuccess) { e.capture_state = -1; return 0; }
+  hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+  bool captured = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (captured) {
+    const ncclResult_t r = g_rccl.AllReduce(cap.p, cap.p, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s);
+    const hipError_t ce = hipStreamEndCapture(s, &g);
+    captured = r == ncclSuccess && ce == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess;
+  }
+  (void)hipGetLastError();
+  float local_bad = captured ? 0.f : 1.f;
+  int rc = 0;
+  for (int round = 0; round < 2 && !rc; ++round) {
+    hipLaunchKernelGGL(capture_test_fill_kernel, dim3(n / 256), dim3(256), 0, s, cap.p, n, e.rank, round);
+    hipLaunchKernelGGL(capture_test_fill_kernel, dim3(n / 256), dim3(256), 0, s, eag.p, n, e.rank, round);
+    if (captured && hipGraphLaunch(ge, s) != hipSuccess) { captured = false; local_bad = 1.f; (void)hipGetLastError(); }
+    if (g_rccl.AllReduce(eag.p, eag.p, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s) != ncclSuccess) rc = -1;
+    if (!rc && captured) hipLaunchKernelGGL(capture_test_cmp_kernel, dim3(n / 256), dim3(256), 0, s, cap.p, eag.p, n, bad.p);
+  }
+  if (!rc && local_bad != 0.f) rc = hipMemcpyAsync(bad.p, &local_bad, sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1;
+  if (!rc && g_rccl.AllReduce(bad.p, bad.p, 1, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s) != ncclSuccess) rc = -1;
+  float total_bad = 1.f;
+  if (!rc) rc = comm_watch_stream();
+  if (!rc) rc = bad.download(&total_bad, 1);
+  if (ge) (void)hipGraphExecDestroy(ge);
+  if (g) (void)hipGraphDestroy(g);
+  e.capture_state = (!rc && total_bad == 0.f) ? 1 : -1;
+  if (e.capture_state != 1 && e.rank == 0)
+    fprintf(stderr, "goctr: captured RCCL all-reduce failed its self-test (%s): the data-parallel step keeps the collective between graph launches\n",
+            rc ? "error" : "results differ from the eager collective");
+  return e.capture_state == 1 ? 1 : 0;
+}
+
 int comm_group_reset() {
   Engine& e = *engine_at(0);
   if (e.loop) {
@@ -407,6 +462,14 @@ int goctr_comm_group_enable(int on) {
   Engine& e = engine();
   GOCTR_CHECK(e.loop || e.nccl_comm, "goctr_comm_group_enable: this engine has no communicator (goctr_init_devices with n > 1)");
   e.comm_enabled = on != 0;
+  return 0;
+}
+
+int goctr_comm_capture_mode(int* mode) {
+  GOCTR_CHECK(mode, "goctr_comm_capture_mode: null argument");
+  const char* v = getenv("GOCTR_DP_CAPTURE_COMM");
+  const Engine& e = engine();
+  *mode = (v && *v == '0') || e.loop ? -1 : e.capture_state;
   return 0;
 }
 

@@ -78,6 +78,7 @@ struct Engine {
   // entries switch it on for their duration, goctr_comm_group_enable for explicit per-rank threads): a plain call on one engine
   // of the group is a single-device call.  goctr_comm_init's communicator (one process per GPU) is always on.
   bool comm_enabled = true;
+  int capture_state = 0;          // comm_capture_selftest: 0 not tested, 1 captured collectives work, -1 they do not
   bool comm_active() const { return (nccl_comm != nullptr || loop != nullptr) && comm_enabled; }
   // rank / world of the CALL in flight: a group engine running a single-device call is rank 0 of 1
   int eff_rank() const { return comm_active() ? rank : 0; }
@@ -215,6 +216,9 @@ int comm_watch_stream();
 // a goctr_init_devices group before a new multi-rank call: clears the loop-back barrier's abort flag (every rank of the
 // previous call has returned -- run_on_engines serialises the calls); fails if an RCCL group communicator was aborted
 int comm_group_reset();
+// 1: a captured all-reduce replays correctly on this engine's communicator (tested once per communicator, every rank takes part
+// and all agree), 0: not (or not capturable at all)
+int comm_capture_selftest();
 // true when a captured graph may hold this engine's collectives (RCCL: yes; loop-back: host barriers, never)
 bool comm_capturable();
 

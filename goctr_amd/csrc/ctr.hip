@@ -1660,12 +1660,25 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   return 0;
 }
 
-// kMulti[z] (even) consecutive steps starting at either parity as one graph each (no communicator: nothing splits the step)
+// Data parallel (dense all-reduce only): may the multi-step graphs hold the collective itself?  RCCL collectives can be
+// captured; whether THIS build of RCCL on THIS box replays them correctly is established once per communicator by
+// comm_capture_selftest (comm.hip: captured vs eager all-reduce, the verdict agreed on by all ranks), GOCTR_DP_CAPTURE_COMM=0
+// switches the mode off, =2 on without the test.  The loop-back communicator's host barriers can never be captured.
+bool dp_capture_ok(const goctr_model* m) {
+  const int mode = env_int("GOCTR_DP_CAPTURE_COMM", 1);
+  if (mode == 0 || !comm_capturable() || m->emb_lr > 0.f) return false;
+  return mode == 2 || comm_capture_selftest() == 1;
+}
+
+// kMulti[z] (even) consecutive steps starting at either parity as one graph each.  Without a communicator nothing splits the
+// step; with one (dp_capture_ok) the all-reduce is a node of the graph: reduce | ncclAllReduce | Adam (+ the next step's
+// attention when pipelined) -- a step inside a call costs no host-issued item at all instead of two
 int build_multi_graphs(goctr_model* m, const RowSource& src, int B, const StepOpts& o) {
   Engine& e = engine();
   StepGraph& sg = m->graph;
   const int stp_now = m->stp;
-  const bool fuse = env_int("GOCTR_FUSED_UPDATE", 1) != 0;
+  const bool dp = e.comm_active();
+  const bool fuse = !dp && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
   if (const char* v = getenv("GOCTR_GRAPH_SIZES")) {
     int x[3] = {0, 0, 0};
     if (sscanf(v, "%d,%d,%d", &x[0], &x[1], &x[2]) >= 1)
@@ -1679,7 +1692,8 @@ int build_multi_graphs(goctr_model* m, const RowSource& src, int B, const StepOp
       int rc = 0;
       for (int k = 0; k < sg.kMulti[z] && !rc; ++k) {   // launch_backward flips m->stp: the captured steps alternate
         rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse);
-        if (!rc && !fuse) rc = launch_adam(m, B, *o.tc);
+        if (!rc && dp) rc = allreduce_grads(m) || launch_adam_step(m, src, B, o);
+        else if (!rc && !fuse) rc = launch_adam(m, B, *o.tc);
       }
       const hipError_t ce = hipStreamEndCapture(e.stream, &g);
       m->stp = stp_now;
@@ -1834,7 +1848,7 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
     m->carry.valid = false;
     if (m->emb_lr > 0.f && emb && n_steps > 0) ++emb->version;       // (rows are about to change: other models' carried h0 die)
     int s = 0;
-    if (!e.comm_active() && env_int("GOCTR_GRAPH_STEPS", 1) != 0) {
+    if ((!e.comm_active() || dp_capture_ok(m)) && env_int("GOCTR_GRAPH_STEPS", 1) != 0) {
       if (!m->graph.multi_on && build_multi_graphs(m, src, B, o)) return -1;
       // (long graphs first: a short one in front was measured slower at 20 steps per call, 66 vs 63.5 us per step)
       for (int z = 0; z < StepGraph::kNMulti; ++z) {   // even step counts: the parity is the same after each launch

@@ -70,6 +70,10 @@ int goctr_device_info(char* name, size_t name_cap, int* compute_units, int64_t* 
 int goctr_comm_unique_id(uint8_t id[128]);
 int goctr_comm_init(int rank, int world, const uint8_t id[128]);
 int goctr_comm_world(int* rank, int* world);
+/* How the data-parallel step of the calling thread's engine issues its dense all-reduce: 1 = as a node of the multi-step
+ * graphs (the captured RCCL collective passed its self-test on this communicator), -1 = between graph launches (self-test
+ * failed, GOCTR_DP_CAPTURE_COMM=0, or a loop-back communicator), 0 = not decided yet (no data-parallel step has run). */
+int goctr_comm_capture_mode(int* mode);
 /* sum-all-reduce of a host double (used for timing / cost aggregation); world==1 => identity */
 int goctr_comm_allreduce_f64(double* v, int n);
 int goctr_comm_destroy(void);

@@ -39,14 +39,19 @@ capi.sync()
 out = np.concatenate([m.get_weights(n).ravel() for n in (("mlp0", "mlp1", "mlp2") if %(youtube)d else ("mlp0", "mlp1", "mlp2", "att0"))])
 np.save(%(out)r, out)
 if %(comm)d:
+    mode = C.c_int(0)
+    capi.check(L.goctr_comm_capture_mode(C.byref(mode)))
+    open(%(out)r + ".mode", "w").write(str(mode.value))
     capi.check(L.goctr_comm_destroy())
 '''
 
 
-def run(tmp_path, comm, graph, youtube=False):
-    out = str(tmp_path / f"w_{comm}_{graph}_{youtube}.npy")
+def run(tmp_path, comm, graph, youtube=False, capture=None):
+    out = str(tmp_path / f"w_{comm}_{graph}_{youtube}_{capture}.npy")
     env = dict(os.environ)
     env["GOCTR_FORCE_COMM"] = "1" if comm else "0"
+    if capture is not None:
+        env["GOCTR_DP_CAPTURE_COMM"] = str(capture)
     if not graph:
         env["GOCTR_NO_GRAPH"] = "1"
     r = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=ROOT, comm=int(comm), out=out, youtube=int(youtube),
@@ -61,9 +66,15 @@ def test_one_rank_communicator_equals_fused_path(tmp_path, graph, youtube):
     """(graph: the data-parallel step is pipelined -- adam_attn_kernel, b(n) + a(n + 1) as one graph -- and the second call is a
     carried start; DIN with its att0 hand-over and YouTube-DNN, whose attention does not depend on the weights)"""
     ref = run(tmp_path, comm=False, graph=graph, youtube=youtube)
-    got = run(tmp_path, comm=True, graph=graph, youtube=youtube)
+    got = run(tmp_path, comm=True, graph=graph, youtube=youtube, capture=0)        # the all-reduce between graph launches
     assert np.isfinite(ref).all() and np.abs(ref).max() > 0
     assert np.array_equal(ref, got)
+    if graph:
+        # the all-reduce as a node of the 4- / 2-step graphs (after the communicator's self-test: captured vs eager collective)
+        cap = run(tmp_path, comm=True, graph=True, youtube=youtube, capture=1)
+        mode = int(open(str(tmp_path / f"w_True_True_{youtube}_1.npy") + ".mode").read())
+        assert mode == 1, "the captured RCCL all-reduce did not pass its self-test on this box"
+        assert np.array_equal(ref, cap)
 
 
 W2V_SCRIPT = r'''
