@@ -636,6 +636,7 @@ def main():
         "rccl_world": rccl_world, "per_rank_ms_per_step": per_rank_ms,
     }
     if world > 1:
+        import ctypes as C
         mode = C.c_int(0)
         capi.check(L.goctr_comm_capture_mode(C.byref(mode)))
         out["dp_allreduce"] = ("a node of the multi-step graphs (captured RCCL collective, self-tested on this communicator)" if mode.value == 1
@@ -649,7 +650,7 @@ def main():
         step_s = dt / args.steps
         out["plan_build_ms"] = round(pms, 3)
         out["plan_build_us_per_batch"] = round(pms * 1e3 / max(pnb, 1), 2)
-        out["samples_per_s_incl_plan"] = {f"epochs={E}": round(E * pnb * c["B"] * world / (E * pnb * step_s + pms * 1e-3), 1) for E in (1, 20, 200)}
+        out["samples_per_s_incl_plan"] = {f"epochs={E}": round(E * pnb * c["B"] * world / max(E * pnb * step_s + pms * 1e-3, 1e-12), 1) for E in (1, 20, 200)}
     if args.train_emb > 0:
         out["config"]["workload"] += (f"; EXTENSION: embedding table trained too (SGD scatter-add, lr {args.train_emb}; "
                                       "the reference keeps it frozen; weights 0.05 N(0,1) so that the row gradients are non-zero)")
