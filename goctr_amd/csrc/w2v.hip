@@ -29,6 +29,7 @@
 #include <thread>
 
 #include "common.h"
+#include "huffman.h"
 #include "corpus.h"
 
 using namespace goctr;
@@ -568,6 +569,15 @@ void build_huffman(const int64_t* counts, int64_t V, int max_depth, std::vector<
   }
 }
 
+// vocabularies from GOCTR_HUFFMAN_DEVICE_MIN words on (default 50 000) are built with the device (huffman.hip); below that the
+// host builder is faster than the copies.  GOCTR_HUFFMAN_DEVICE=0 / 1 forces either.
+bool huffman_on_device(int64_t V) {
+  const char* f = getenv("GOCTR_HUFFMAN_DEVICE");
+  if (f && *f) return *f != '0';
+  const char* m = getenv("GOCTR_HUFFMAN_DEVICE_MIN");
+  return V >= (m && *m ? atoll(m) : 50000);
+}
+
 }  // namespace
 
 struct goctr_w2v {
@@ -583,6 +593,8 @@ struct goctr_w2v {
   DevBuf<unsigned char> path_codes, keep;
   DevBuf<unsigned long long> lcg;
   std::vector<long long> h_off; std::vector<int> h_nodes; std::vector<unsigned char> h_codes;
+  bool h_paths = false;          // the host copies above are filled (built on the host, or downloaded for goctr_w2v_get_paths)
+  long long path_total = 0;
   int64_t n_words = 0; bool has_keep = false;
   std::mutex mu;
 };
@@ -758,16 +770,23 @@ int goctr_w2v_create(const goctr_w2v_cfg* cfg, int64_t V, const int64_t* counts,
   GOCTR_CHECK(cfg->optimizer == 0 || cfg->optimizer == 1, "goctr_w2v: optimizer must be hs (0) or ns (1)");
   std::unique_ptr<goctr_w2v> w(new goctr_w2v);
   w->cfg = *cfg; w->V = V;
-  build_huffman(counts, V, cfg->max_depth, w->h_off, w->h_nodes, w->h_codes);
-  GOCTR_CHECK(w->h_nodes.size() < ((size_t)1 << 31), "goctr_w2v: Huffman paths with 2^31 entries or more (the Hogwild walk indexes them with 32 bits)");
   w->h_counts.assign(counts, counts + V);
   w->aux_rows = cfg->optimizer == 0 ? std::max<int64_t>(V - 1, 1) : V;
   if (w->param.alloc((size_t)V * cfg->dim) || w->aux.alloc((size_t)w->aux_rows * cfg->dim)) return -1;
-  if (w->path_off.alloc(w->h_off.size(), false) || w->path_off.upload(w->h_off.data(), w->h_off.size())) return -1;
-  if (w->path_nodes.alloc(std::max<size_t>(w->h_nodes.size(), 1)) ||
-      (!w->h_nodes.empty() && w->path_nodes.upload(w->h_nodes.data(), w->h_nodes.size()))) return -1;
-  if (w->path_codes.alloc(std::max<size_t>(w->h_codes.size(), 1)) ||
-      (!w->h_codes.empty() && w->path_codes.upload(w->h_codes.data(), w->h_codes.size()))) return -1;
+  if (huffman_on_device(V)) {
+    // large vocabularies: sort and path fill on the device, the merge on the host in sorted-rank space (huffman.hip); the
+    // paths are born in HBM and reach the host only if goctr_w2v_get_paths asks for them
+    if (huffman_build_device(w->h_counts.data(), V, cfg->max_depth, w->path_off, w->path_nodes, w->path_codes, &w->path_total, nullptr)) return -1;
+  } else {
+    build_huffman(counts, V, cfg->max_depth, w->h_off, w->h_nodes, w->h_codes);
+    GOCTR_CHECK(w->h_nodes.size() < ((size_t)1 << 31), "goctr_w2v: Huffman paths with 2^31 entries or more (the Hogwild walk indexes them with 32 bits)");
+    w->h_paths = true; w->path_total = (long long)w->h_nodes.size();
+    if (w->path_off.alloc(w->h_off.size(), false) || w->path_off.upload(w->h_off.data(), w->h_off.size())) return -1;
+    if (w->path_nodes.alloc(std::max<size_t>(w->h_nodes.size(), 1)) ||
+        (!w->h_nodes.empty() && w->path_nodes.upload(w->h_nodes.data(), w->h_nodes.size()))) return -1;
+    if (w->path_codes.alloc(std::max<size_t>(w->h_codes.size(), 1)) ||
+        (!w->h_codes.empty() && w->path_codes.upload(w->h_codes.data(), w->h_codes.size()))) return -1;
+  }
   std::vector<double> tab(1000);
   for (int i = 0; i < 1000; ++i) {  // sigmoid_table.go:28-38
     const double ev = std::exp(((double)i / 1000.0 * 2. - 1.) * 6.0);
@@ -805,7 +824,15 @@ int goctr_w2v_get_aux(goctr_w2v* w, double* aux) {
 }
 
 int goctr_w2v_get_paths(goctr_w2v* w, int64_t* path_off, int32_t* nodes, uint8_t* codes, int64_t cap, int64_t* total) {
-  GOCTR_CHECK(w, "goctr_w2v_get_paths: null handle");
+  GOCTR_ENTER_H(w);
+  GOCTR_CHECK(w, "goctr_w2v_get_paths: null argument");
+  std::lock_guard<std::mutex> lk(w->mu);
+  if (!w->h_paths) {       // built on the device: fetched on first request
+    w->h_off.resize((size_t)w->V + 1); w->h_nodes.resize((size_t)w->path_total); w->h_codes.resize((size_t)w->path_total);
+    if (w->path_off.download(w->h_off.data(), w->h_off.size())) return -1;
+    if (w->path_total && (w->path_nodes.download(w->h_nodes.data(), w->h_nodes.size()) || w->path_codes.download(w->h_codes.data(), w->h_codes.size()))) return -1;
+    w->h_paths = true;
+  }
   if (total) *total = (int64_t)w->h_nodes.size();
   if (path_off) for (size_t i = 0; i < w->h_off.size(); ++i) path_off[i] = w->h_off[i];
   const int64_t n = std::min<int64_t>(cap, (int64_t)w->h_nodes.size());
@@ -818,6 +845,26 @@ int goctr_huffman_build(const int64_t* counts, int64_t V, int max_depth, int64_t
                         int64_t cap, int64_t* total, double* build_ms) {
   GOCTR_CHECK(counts && V > 0 && path_off && max_depth > 0, "goctr_huffman_build: bad arguments");
   GOCTR_CHECK(V <= 0x3fffffff, "goctr_huffman_build: V = %lld exceeds the 2^30 words the int32 node ids can number", (long long)V);
+  if (engine().inited && huffman_on_device(V)) {
+    // with a device bound: the build of huffman.hip.  *build_ms = until the paths are resident in HBM (what goctr_w2v_create
+    // pays); copying them out to the caller's arrays (1.2 GB at V = 10^7) comes on top and is not part of the build
+    GOCTR_ENTER();
+    DevBuf<long long> off; DevBuf<int> nd; DevBuf<unsigned char> cd;
+    long long tot = 0; double parts[4] = {0, 0, 0, 0};
+    std::vector<long long> c64(counts, counts + V);
+    if (huffman_build_device(c64.data(), V, max_depth, off, nd, cd, &tot, parts)) return -1;
+    if (build_ms) *build_ms = parts[3];
+    if (getenv("GOCTR_HUFFMAN_PARTS")) fprintf(stderr, "huffman V=%lld: sort+d2h %.2f ms, host merge %.2f ms, device lengths+scan+fill %.2f ms, total %.2f ms\n",
+                                             (long long)V, parts[0], parts[1], parts[2], parts[3]);
+    std::vector<long long> ho((size_t)V + 1);
+    if (off.download(ho.data(), ho.size())) return -1;
+    for (size_t i = 0; i < ho.size(); ++i) path_off[i] = ho[i];
+    if (total) *total = tot;
+    const int64_t n = std::min<int64_t>(cap, tot);
+    if (nodes && n > 0 && nd.download(nodes, (size_t)n)) return -1;
+    if (codes && n > 0 && cd.download(codes, (size_t)n)) return -1;
+    return 0;
+  }
   std::vector<long long> off;
   std::vector<int> nd;
   std::vector<unsigned char> cd;
