@@ -735,6 +735,17 @@ def main():
                 else:
                     grl["basis"] = "algorithmic bytes (no rocprofv3 summary committed for this kernel symbol and grid)"
                 out["gather_roofline"] = grl
+            # the whole replayed step against its algorithmic bytes (committed summary: sum over the step's launches)
+            try:
+                import glob
+                pf = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{wl}_kernels.json")))
+                stt = json.load(open(pf[-1])).get("step_total") if pf else None
+                if stt and stt.get("traffic_ratio") and stt.get("batch") == c["B"]:
+                    out["step_traffic_ratio"] = stt["traffic_ratio"]
+                    out["step_traffic"] = {"memory_side_bytes": stt["sum_hbm_bytes"], "algorithmic_bytes": stt["algorithmic_bytes"],
+                                           "sum_kernel_us_rocprofv3": stt["sum_avg_us"], "kernels": stt["kernels"], "source": os.path.basename(pf[-1])}
+            except Exception:
+                pass
             out["kernel_symbols"] = {k: v for k, v in syms.items() if v and k in table}
             out["kernels"] = table
     rdv.barrier()

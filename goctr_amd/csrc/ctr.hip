@@ -1887,6 +1887,15 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
     }
   } else {
     if (m->emb_lr > 0.f && emb && n_steps > 0) ++emb->version;
+    m->carry.valid = false;
+    // GOCTR_EAGER_PIPELINE=1 (profiling: the rocprofv3 counter passes want ONE dispatch record per launch AND the kernels of
+    // the replayed step): the pipelined launch sequence -- chain, weight gradients, reduce_attn with the next step's attention --
+    // issued eagerly, launch by launch, instead of as a captured graph
+    if (!e.prof && !e.comm_active() && n_steps > 0 && env_int("GOCTR_EAGER_PIPELINE", 0) != 0 && pipeline_ok(m, src)) {
+      o.pipelined = true;
+      const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
+      if (launch_attn_fwd(aa)) return -1;
+    }
     for (int s = 0; s < n_steps; ++s)
       if (train_step_eager(m, src, B, o)) return -1;
   }

@@ -129,6 +129,35 @@ def summarize_phase(src, phase, legs):
     return out
 
 
+# the launches of ONE graph-replayed training step per workload (what bench.py's `value` times), and the step's algorithmic bytes
+# per sample (cfg3 whole step ~3 900 B; cfg4: rows 13 056 + ids 204 + side features 420 = 13 680 B)
+STEP_KERNELS = {"din": (("ctr_chain_x3_kernel<", ",false>"), ("gemm_tn_multi_x3w_kernel<", ""), ("reduce_attn_kernel<", "")),
+                "youtube": (("ctr_chain_x3_kernel<", ",false>"), ("gemm_tn_multi_x3w_kernel<", ""), ("reduce_attn_kernel<", ""))}
+STEP_ALG_BYTES_PER_SAMPLE = {"din": 3900, "youtube": 13680}
+STEP_BATCH = {"din": 8192, "youtube": 16384}
+
+
+def step_total(tab, workload):
+    """sum over the replayed step's launches: rocprofv3 duration and memory-side bytes, each kernel at its most-called shape"""
+    if workload not in STEP_KERNELS:
+        return None
+    ents = []
+    for pre, suf in STEP_KERNELS[workload]:
+        c = [e for e in tab.values() if e["kernel"].startswith(pre) and e["kernel"].endswith(suf) and e.get("avg_us")]
+        if not c:
+            return None
+        ents.append(max(c, key=lambda e: e.get("calls", 0)))
+    alg = STEP_ALG_BYTES_PER_SAMPLE[workload] * STEP_BATCH[workload]
+    out = {"kernels": [f"{e['kernel']}@{e['grid_threads']}" for e in ents], "sum_avg_us": round(sum(e["avg_us"] for e in ents), 3),
+           "algorithmic_bytes": alg, "batch": STEP_BATCH[workload]}
+    if all(e.get("hbm_bytes") is not None for e in ents):
+        out["sum_hbm_bytes"] = sum(e["hbm_bytes"] for e in ents)
+        out["traffic_ratio"] = round(out["sum_hbm_bytes"] / alg, 3)
+    else:
+        out["missing_counters"] = [e["kernel"] for e in ents if e.get("hbm_bytes") is None]
+    return out
+
+
 def main():
     tag = sys.argv[1]
     src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/p"
@@ -136,6 +165,8 @@ def main():
     phases = {}
     train_legs = {k: k for k in ("kt", "fetch", "write", "sq", "l2") if os.path.isdir(f"{src}/{k}")}
     phases["train"] = summarize_phase(src, "train", train_legs)
+    workload = tag.split("_", 1)[1] if "_" in tag else tag
+    stt = step_total(phases["train"], workload)
     pred_legs = {k: f"p{k}" for k in ("kt", "fetch", "write", "sq", "l2") if os.path.isdir(f"{src}/p{k}")}
     if pred_legs:
         phases["predict"] = summarize_phase(src, "predict", pred_legs)
@@ -158,6 +189,8 @@ def main():
                      "x 2 (gfx950 correction, MI355X_MICROARCH.md 'HBM'); write_bytes = WRITE_SIZE KiB x 1024; hbm_bytes = their sum. "
                      "Keys: '<kernel symbol>@<grid threads>' inside the phase the pass ran.",
            "commit": head, "phases": phases}
+    if stt:
+        doc["step_total"] = stt
     json.dump(doc, open(f"profiles/{tag}_kernels.json", "w"), indent=1)
     with open(f"profiles/{tag}_kernel_trace.txt", "w") as f:
         f.write(f"# rocprofv3 per phase / kernel symbol / launch shape (commit {head})\n")
@@ -168,6 +201,9 @@ def main():
                 f.write(f"{e['kernel'][:58]:58s} {e['grid_threads']:9d} {e.get('calls', 0):6d} {e.get('avg_us', 0):8.2f} {e.get('min_us', 0):8.2f} "
                         f"{(e.get('hbm_bytes') or 0) / 1e6:8.2f} {e.get('l2_hit_rate') if e.get('l2_hit_rate') is not None else '':>6} "
                         f"{(e.get('sq') or {}).get('mfma_busy_pct', ''):>6}\n")
+        if stt:
+            f.write(f"## replayed training step: {' + '.join(stt['kernels'])}\n   sum of kernel durations {stt['sum_avg_us']} us; memory-side "
+                    f"{stt.get('sum_hbm_bytes', 0) / 1e6:.1f} MB vs {stt['algorithmic_bytes'] / 1e6:.1f} MB algorithmic = {stt.get('traffic_ratio')} x\n")
     print(open(f"profiles/{tag}_kernel_trace.txt").read())
 
 

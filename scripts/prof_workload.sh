@@ -6,11 +6,12 @@
 # predict launches can never be mixed up -- at cfg4 they have the same grid.  Counters NEVER together with tracing, one
 # counter family per pass (MI355X_MICROARCH.md "rocprofv3 PMC slots"):
 #   kt     --kernel-trace --stats            per-kernel durations: graph replay as benchmarked + the eager instrumented re-run
-#   fetch  --pmc FETCH_SIZE                  memory-side read bytes      (eager steps: one dispatch record per launch)
+#   fetch  --pmc FETCH_SIZE                  memory-side read bytes      (eager steps, GOCTR_NO_GRAPH=1 GOCTR_EAGER_PIPELINE=1: one
+#                                            dispatch record per launch, the PIPELINED kernels of the replayed step -- reduce_attn included)
 #   write  --pmc WRITE_SIZE                  memory-side write bytes
 #   sq     --pmc SQ_*                        MFMA-busy, VALU / wave cycles
 #   l2     --pmc TCC_HIT_sum TCC_MISS_sum    L2 hit rate
-#   pkt / pfetch / pwrite                    the same three for the predict phase (PREDICT=1; din / youtube only)
+#   pkt / pfetch / pwrite / psq / pl2        the same for the predict phase (PREDICT=1; din / youtube only)
 # PASSES="kt fetch write" restricts the training passes (default: all five).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 NAME=$1; shift
@@ -24,16 +25,18 @@ SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI
 for P in $PASSES; do
   case $P in
     kt)    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python $R/bench.py --steps 200 --warmup 20 $COMMON --phase train "$@" > $OUT/kt_bench.json 2> $OUT/kt.err ;;
-    fetch) GOCTR_NO_GRAPH=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python $R/bench.py --steps 30 --warmup 5 $COMMON --no-roofline --phase train "$@" > $OUT/f.json 2> $OUT/f.err ;;
-    write) GOCTR_NO_GRAPH=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python $R/bench.py --steps 30 --warmup 5 $COMMON --no-roofline --phase train "$@" > $OUT/w.json 2> $OUT/w.err ;;
-    sq)    GOCTR_NO_GRAPH=1 rocprofv3 --pmc $SQ --output-format csv -d $OUT/sq -- python $R/bench.py --steps 30 --warmup 5 $COMMON --no-roofline --phase train "$@" > $OUT/s.json 2> $OUT/s.err ;;
-    l2)    GOCTR_NO_GRAPH=1 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python $R/bench.py --steps 30 --warmup 5 $COMMON --no-roofline --phase train "$@" > $OUT/l.json 2> $OUT/l.err ;;
+    fetch) GOCTR_NO_GRAPH=1 GOCTR_EAGER_PIPELINE=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python $R/bench.py --steps 30 --warmup 5 $COMMON --no-roofline --phase train "$@" > $OUT/f.json 2> $OUT/f.err ;;
+    write) GOCTR_NO_GRAPH=1 GOCTR_EAGER_PIPELINE=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python $R/bench.py --steps 30 --warmup 5 $COMMON --no-roofline --phase train "$@" > $OUT/w.json 2> $OUT/w.err ;;
+    sq)    GOCTR_NO_GRAPH=1 GOCTR_EAGER_PIPELINE=1 rocprofv3 --pmc $SQ --output-format csv -d $OUT/sq -- python $R/bench.py --steps 30 --warmup 5 $COMMON --no-roofline --phase train "$@" > $OUT/s.json 2> $OUT/s.err ;;
+    l2)    GOCTR_NO_GRAPH=1 GOCTR_EAGER_PIPELINE=1 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l2 -- python $R/bench.py --steps 30 --warmup 5 $COMMON --no-roofline --phase train "$@" > $OUT/l.json 2> $OUT/l.err ;;
   esac
 done
 if [ "${PREDICT:-0}" = "1" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pkt -- python $R/bench.py --steps 200 --warmup 20 $COMMON --no-roofline --phase predict "$@" > $OUT/pkt_bench.json 2> $OUT/pkt.err
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pfetch -- python $R/bench.py --steps 100 --warmup 5 $COMMON --no-roofline --phase predict "$@" > $OUT/pf.json 2> $OUT/pf.err
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pwrite -- python $R/bench.py --steps 100 --warmup 5 $COMMON --no-roofline --phase predict "$@" > $OUT/pw.json 2> $OUT/pw.err
+  rocprofv3 --pmc $SQ --output-format csv -d $OUT/psq -- python $R/bench.py --steps 100 --warmup 5 $COMMON --no-roofline --phase predict "$@" > $OUT/ps.json 2> $OUT/ps.err
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pl2 -- python $R/bench.py --steps 100 --warmup 5 $COMMON --no-roofline --phase predict "$@" > $OUT/pl.json 2> $OUT/pl.err
 fi
 # keep only what the summariser reads (the merge back is capped at 64 MiB)
 find $OUT -type f ! -name '*_kernel_stats.csv' ! -name '*_kernel_trace.csv' ! -name '*_counter_collection.csv' ! -name '*.json' ! -name '*.err' ! -name HEAD -delete
