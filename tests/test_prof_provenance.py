@@ -37,7 +37,8 @@ def test_kernel_symbols_keep_their_template_arguments():
 def test_pmc_entry_returns_only_the_exact_phase_symbol_and_grid():
     sys.path.insert(0, ROOT)
     import bench
-    doc = json.load(open(os.path.join(ROOT, "profiles", "r03_din_kernels.json")))
+    import glob
+    doc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_din_kernels.json")))[-1]))      # (the one bench.py reads: the newest)
     train = doc["phases"]["train"]
     key = next(k for k in train if k.startswith("ctr_chain_x3_kernel<9,false>@"))
     sym, grid = key.split("@")
@@ -48,3 +49,22 @@ def test_pmc_entry_returns_only_the_exact_phase_symbol_and_grid():
     assert not bench.pmc_entry("din", "train", sym, int(grid) * 2)
     assert not bench.pmc_entry("din", "predict", sym, int(grid))
     assert not bench.pmc_entry("din", "train", "no_such_kernel", None)
+
+
+def test_step_total_is_the_sum_of_the_replayed_steps_launches():
+    """the whole step's memory-side traffic is recomputable from ONE tracked file -- every launch of the
+    graph-replayed step (chain, weight gradients, reduce_attn: the last one has counters since the PMC passes run the pipelined
+    kernels eagerly) carries hbm_bytes, and step_total is their sum over the SURVEY 8(d) algorithmic bytes"""
+    import glob
+    for wl, per_sample, batch in (("din", 3900, 8192), ("youtube", 13680, 16384)):
+        doc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{wl}_kernels.json")))[-1]))
+        st = doc["step_total"]
+        ents = [doc["phases"]["train"][k] for k in st["kernels"]]
+        assert len(ents) == 3 and all(e.get("hbm_bytes") for e in ents) and any(e["kernel"].startswith("reduce_attn_kernel") for e in ents)
+        assert st["sum_hbm_bytes"] == sum(e["hbm_bytes"] for e in ents)
+        assert abs(st["sum_avg_us"] - sum(e["avg_us"] for e in ents)) < 1e-6
+        assert st["algorithmic_bytes"] == per_sample * batch
+        assert abs(st["traffic_ratio"] - st["sum_hbm_bytes"] / st["algorithmic_bytes"]) < 1e-3
+        # the predict phase has SQ counters and an L2 hit rate too
+        pred = [e for e in doc["phases"]["predict"].values() if e["kernel"].startswith("ctr_chain_x3_kernel") and e.get("calls", 0) > 10]
+        assert pred and pred[0].get("sq") and pred[0].get("l2_hit_rate") is not None
