@@ -305,7 +305,7 @@ int comm_capture_selftest() {
   if (!rc && local_bad != 0.f) rc = hipMemcpyAsync(bad.p, &local_bad, sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1;
   if (!rc && g_rccl.AllReduce(bad.p, bad.p, 1, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s) != ncclSuccess) rc = -1;
   float total_bad = 1.f;
-  if (!rc) rc = comm_watch_stream();
+  if (!rc) rc = comm_watch_stream(std::max(1, env_int_comm("GOCTR_CAPTURE_TEST_TIMEOUT_S", 30)));     // (a replay that never completes: fail fast)
   if (!rc) rc = bad.download(&total_bad, 1);
   if (ge) (void)hipGraphExecDestroy(ge);
   if (g) (void)hipGraphDestroy(g);
@@ -346,11 +346,11 @@ void comm_abort_on_failure() {
 // Host-side watchdog for a rank that waits for its stream behind RCCL collectives: polls the stream and the communicator's
 // asynchronous error state; on an error (a peer aborted or died) or after GOCTR_COMM_TIMEOUT_S (default 300) it aborts the
 // local communicator and fails the call instead of blocking in hipStreamSynchronize for ever.
-int comm_watch_stream() {
+int comm_watch_stream(int timeout_override_s) {
   Engine& e = engine();
   if (!e.nccl_comm || !g_rccl.CommGetAsyncError) { GOCTR_HIP(hipStreamSynchronize(e.stream)); return 0; }
   const auto t0 = std::chrono::steady_clock::now();
-  const int timeout_s = std::max(1, env_int_comm("GOCTR_COMM_TIMEOUT_S", 300));
+  const int timeout_s = timeout_override_s > 0 ? timeout_override_s : std::max(1, env_int_comm("GOCTR_COMM_TIMEOUT_S", 300));
   for (unsigned spin = 0;; ++spin) {
     const hipError_t q = hipStreamQuery(e.stream);
     if (q == hipSuccess) return 0;

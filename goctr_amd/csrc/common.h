@@ -212,7 +212,7 @@ int comm_alltoallv(const void* send, const size_t* send_off, const size_t* send_
 int comm_broadcast(void* dev, size_t bytes, int root);
 // waits for the engine stream like hipStreamSynchronize, but behind RCCL collectives it polls the communicator's asynchronous
 // error state and a timeout: a peer that failed or died makes this rank's call fail instead of hanging
-int comm_watch_stream();
+int comm_watch_stream(int timeout_override_s = 0);
 // a goctr_init_devices group before a new multi-rank call: clears the loop-back barrier's abort flag (every rank of the
 // previous call has returned -- run_on_engines serialises the calls); fails if an RCCL group communicator was aborted
 int comm_group_reset();

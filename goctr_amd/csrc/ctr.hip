@@ -2569,6 +2569,15 @@ struct CommCallScope {       // the group's communicator takes part in this call
   ~CommCallScope() { e.comm_enabled = prev; }
 };
 
+// Does this training call take the multi-device entry?  devices = n > 1; or devices = 1 on a ONE-engine group that
+// goctr_init_devices built a communicator for (GOCTR_FORCE_COMM=1): the same entry with one rank -- ncclCommInitAll, the
+// broadcast, the scatter and the split step with a one-rank RCCL communicator, which is all of mode 2 that a one-GPU box can run
+bool multi_call(const goctr_model* m, const goctr_train_cfg* cfg) {
+  if (cfg->devices > 1) return true;
+  const Engine* e = m->eng;
+  return cfg->devices == 1 && engine_count() == 1 && e->index == 0 && (e->nccl_comm || e->loop) && !e->comm_enabled;
+}
+
 // per_rank(model, table, shard, local cfg, rank) is the ordinary per-rank call
 template <class Fn>
 int train_multi(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_train_cfg* cfg, Fn per_rank) {
@@ -2674,7 +2683,7 @@ int goctr_train_steps(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const go
   GOCTR_SAME_ENGINE(m, d); GOCTR_SAME_ENGINE(m, emb);
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   if (check_dataset(m, d, emb)) return -1;
-  if (cfg->devices > 1)
+  if (multi_call(m, cfg))
     return train_multi(m, emb, d, cfg, [&](goctr_model* mk, goctr_emb* ek, goctr_dataset* dk, const goctr_train_cfg* lc, int rank) {
       return train_steps_locked(mk, ek, dk, lc, first_batch, n_steps, rank == 0 ? costs : nullptr);
     });
@@ -2732,7 +2741,7 @@ int goctr_train_dataset(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const 
   GOCTR_SAME_ENGINE(m, d); GOCTR_SAME_ENGINE(m, emb);
   std::unique_lock<std::shared_mutex> lk(m->mu); ++m->gen;
   if (check_dataset(m, d, emb)) return -1;
-  if (cfg->devices > 1)
+  if (multi_call(m, cfg))
     return train_multi(m, emb, d, cfg, [&](goctr_model* mk, goctr_emb* ek, goctr_dataset* dk, const goctr_train_cfg* lc, int rank) {
       int ran = 0;
       const int r = train_dataset_locked(mk, ek, dk, lc, rank == 0 ? epoch_costs : nullptr, &ran);

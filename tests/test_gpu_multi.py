@@ -322,3 +322,53 @@ def test_missing_rank_fails_instead_of_hanging(tmp_path):
     r = run_script(ABORT, tmp_path, "abort", W=2, env={"GOCTR_LOOP_TIMEOUT_S": "3"}, timeout=300)
     msg = str(r["msg"][0])
     assert msg.startswith("error:") and "did not reach the collective" in msg, msg
+
+
+RCCL_GROUP_ONE = r'''
+rng = np.random.default_rng(5)
+rows, U, T, D, Cc, V = 4000, 52, 50, 16, 53, 500
+emb = (rng.standard_normal((V, D)) * 0.25).astype(np.float32)
+ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
+it = rng.integers(0, V, size=rows).astype(np.int32)
+uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
+y = (rng.random(rows) < 0.5).astype(np.float32)
+names = ("mlp0", "mlp1", "mlp2", "att0")
+def flat(m): return np.concatenate([m.get_weights(n).ravel() for n in names])
+def mk():
+    m = gm.DinNet(U, T, D, D, Cc)
+    r = np.random.default_rng(1)
+    for n in ("mlp0", "mlp1", "mlp2"): m.set_weights(n, (r.standard_normal(m._shape(n)) * 0.2).astype(np.float32))
+    return m
+res = {}
+for emb_lr in (0.0, 0.05):
+    tabA, tabB = gm.EmbeddingTable(emb), gm.EmbeddingTable(emb)
+    ds = gm.Dataset.ids(ub, it, uf, cf, y)
+    mA, mB = mk(), mk()
+    if emb_lr: mA.set_embedding_training(emb_lr); mB.set_embedding_training(emb_lr)
+    cA = capi.default_train_cfg(batch=1024, epochs=1, dropout_mode=2, p0=0.01, p1=0.01, seed=7, devices=1)    # the multi-device entry, one rank
+    cB = capi.default_train_cfg(batch=1024, epochs=1, dropout_mode=2, p0=0.01, p1=0.01, seed=7, devices=0)    # the plain call
+    cA_ = gm.train_steps(mA, ds, cA, 9, emb=tabA, want_costs=True)
+    cB_ = gm.train_steps(mB, ds, cB, 9, emb=tabB, want_costs=True)
+    capi.sync()
+    res[f"wA{emb_lr}"], res[f"wB{emb_lr}"] = flat(mA), flat(mB)
+    res[f"tA{emb_lr}"], res[f"tB{emb_lr}"] = tabA.get_rows(), tabB.get_rows()
+    res[f"cA{emb_lr}"], res[f"cB{emb_lr}"] = cA_, cB_
+mode = C.c_int(0)
+capi.check(capi.load().goctr_comm_capture_mode(C.byref(mode)))
+res["mode"] = np.array([mode.value])
+np.savez(%(out)r, **res)
+'''
+
+
+def test_single_call_entry_over_an_rccl_group_of_one(tmp_path):
+    """mode 2 (goctr_init_devices over distinct devices: ncclCommInitAll, every rank a thread) as far as a one-GPU box can run
+    it: a group of ONE engine with GOCTR_FORCE_COMM=1 -- ncclCommInitAll, ncclBroadcast of the replica state, the shard scatter as
+    grouped ncclSend / ncclRecv, the split step graphs around ncclAllReduce (captured after the self-test), the fixed-size sparse
+    exchange -- must reproduce the plain single-device call bit for bit (one rank: every collective is the identity)"""
+    r = run_script(RCCL_GROUP_ONE, tmp_path, "rccl1", W=1, env={"GOCTR_FORCE_COMM": "1"})
+    for lr in ("0.0", "0.05"):
+        assert np.isfinite(r[f"wB{lr}"]).all()
+        assert np.array_equal(r[f"cA{lr}"], r[f"cB{lr}"])
+        assert np.array_equal(r[f"wA{lr}"], r[f"wB{lr}"])
+        assert np.array_equal(r[f"tA{lr}"], r[f"tB{lr}"])
+    assert np.abs(r["tA0.05"] - r["tA0.0"]).max() > 0
