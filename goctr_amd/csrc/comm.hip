@@ -272,8 +272,8 @@ __global__ void capture_test_cmp_kernel(const float* a, const float* b, int n, f
 }
 }  // namespace
 
-// Collective: every rank of the communicator calls it at the same point (the first data-parallel call that wants captured
-// collectives).  Two rounds of [fill | all-reduce] as a replayed graph against the same eagerly; the mismatch counts (and a
+// Collective: every rank of the communicator calls it at the same point (goctr_comm_init; the start of the first multi-device
+// call of a goctr_init_devices group).  Two rounds of [fill | all-reduce] as a replayed graph against the same eagerly; the mismatch counts (and a
 // failed capture, counted as one) are summed over the ranks with an EAGER all-reduce, so all ranks reach the same verdict.
 // Waits go through comm_watch_stream: a replay that never completes fails the call on a timeout instead of hanging it.
 int comm_capture_selftest() {
@@ -454,6 +454,9 @@ int goctr_comm_init(int rank, int world, const uint8_t id[128]) {
   ncclComm_t c = nullptr;
   GOCTR_NCCL(g_rccl.CommInitRank(&c, world, u, rank));
   e.nccl_comm = c;
+  e.capture_state = 0;
+  // may the data-parallel step graphs hold the all-reduce?  Decided HERE, where every rank is (comm_capture_selftest is a collective)
+  if (env_int_comm("GOCTR_DP_CAPTURE_COMM", 1) == 1) (void)comm_capture_selftest();
   return 0;
 }
 

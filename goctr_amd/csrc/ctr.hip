@@ -1702,7 +1702,9 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
 bool dp_capture_ok(const goctr_model* m) {
   const int mode = env_int("GOCTR_DP_CAPTURE_COMM", 1);
   if (mode == 0 || !comm_capturable() || m->emb_lr > 0.f) return false;
-  return mode == 2 || comm_capture_selftest() == 1;
+  // (the self-test is a collective: it runs where every rank is known to be -- goctr_comm_init, or the start of a multi-device
+  // call -- never lazily here, where a rank that happens to step eagerly would not take part)
+  return mode == 2 || engine().capture_state == 1;
 }
 
 // kMulti[z] (even) consecutive steps starting at either parity as one graph each.  Without a communicator nothing splits the
@@ -2633,6 +2635,7 @@ int train_multi(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_tr
     Engine& e = engine();
     std::lock_guard<std::recursive_mutex> elk(e.mu);
     CommCallScope comm_on(e);
+    if (comm_capturable() && env_int("GOCTR_DP_CAPTURE_COMM", 1) == 1) (void)comm_capture_selftest();   // (once per communicator; every rank is here)
     goctr_model* mk = k == 0 ? m : m->reps[k];
     goctr_emb* ek = !emb ? nullptr : (k == 0 ? emb : emb->reps[k]);
     goctr_dataset* dk = d->shards[k];
