@@ -23,6 +23,14 @@ namespace goctr {
 inline void check(int rc) {
   if (rc != 0) throw std::runtime_error(goctr_last_error());
 }
+// bind the process to GPU 0 unless something (goctr_init / goctr_init_devices) already bound it
+inline void ensure_init() {
+  char name[8];
+  if (goctr_device_info(name, sizeof name, nullptr, nullptr) != 0) check(goctr_init(0));
+}
+// one process, n ranks (SURVEY 8(b) goctr_init(n_devices, ids)): engine k on HIP device ids[k]; a repeated id = logical ranks on one device.
+// Training calls then take `devices = ids.size()` (model::Train below): recommend.Train reaches n GPUs unchanged.
+inline void InitDevices(const std::vector<int>& ids) { check(goctr_init_devices((int)ids.size(), ids.data())); }
 
 namespace recommend {
 // recommend/rcmd.go:19-28
@@ -68,7 +76,7 @@ class CtrNet {  // the device twin of model.Model (model.go:16-25)
   CtrNet(int kind, int U, int T, int D, int iD, int C, int att = GOCTR_ATT_COSINE) : U(U), T(T), D(D), C(C) {
     if (kind == GOCTR_DIN && D != iD)  // din.go:176-178
       throw std::invalid_argument("uBehaviorDim != iFeatureDim");
-    check(goctr_init(0));
+    ensure_init();
     goctr_ctr_cfg cfg{kind, att, U, T, D, C, mlp0_1, mlp1_2};
     check(goctr_model_create(&cfg, &h_));
   }
@@ -112,10 +120,11 @@ class CtrNet {  // the device twin of model.Model (model.go:16-25)
 inline std::vector<float> Train(int /*uProfileDim*/, int /*uBehaviorSize*/, int /*uBehaviorDim*/, int /*iFeatureDim*/,
                                 int /*cFeatureDim*/, int numExamples, int batchSize, int epochs, int earlyStop,
                                 const recommend::SampleInfo& si, const float* inputs, int xcols, const float* targets,
-                                CtrNet& m) {
+                                CtrNet& m, int devices = 0) {
   goctr_train_cfg cfg;
   goctr_train_cfg_default(&cfg);
   cfg.batch = batchSize; cfg.epochs = epochs; cfg.early_stop = earlyStop;
+  cfg.devices = devices;        // n of InitDevices: batchSize stays the GLOBAL batch, sharded over the n ranks inside this one call
   auto r = si.ranges();
   std::vector<float> costs((size_t)std::max(epochs, 1));
   int ran = 0;
@@ -147,7 +156,7 @@ class RecSys {
   RecSys(const std::vector<int64_t>& ub_off, const std::vector<int32_t>& ub_items, const std::vector<int64_t>& ub_ts,
          const std::vector<float>& user_table, int U, const std::vector<float>& item_table, int C,
          const std::vector<float>& item_emb, int D) {
-    check(goctr_init(0));
+    ensure_init();
     const int64_t n_users = (int64_t)ub_off.size() - 1, n_items = C ? (int64_t)item_table.size() / C : 0;
     check(goctr_ubcache_create(n_users, ub_off.data(), ub_items.data(), ub_ts.data(), &ub_));
     check(goctr_emb_create((int64_t)item_emb.size() / D, D, item_emb.data(), &emb_));
@@ -217,7 +226,7 @@ class MLPClassifier {
   std::vector<double> LossCurve;
   ~MLPClassifier() { goctr_mlp_destroy(h_); }
   void Fit(const float* X, const float* Y, int64_t rows, int xcols) {
-    check(goctr_init(0));
+    ensure_init();
     goctr_mlp_cfg cfg;
     goctr_mlp_cfg_default(&cfg);
     std::vector<int> units{xcols};
@@ -263,7 +272,7 @@ struct Model {
 };
 inline Model TrainEmbedding(const std::vector<int64_t>& counts, const std::vector<int32_t>& doc, int64_t corpus_len,
                             int window, int dim, int iter, uint64_t seed = 1) {
-  check(goctr_init(0));
+  ensure_init();
   goctr_w2v_cfg cfg;
   goctr_w2v_cfg_default(&cfg);
   cfg.dim = dim; cfg.window = window;
@@ -289,7 +298,7 @@ inline Model TrainEmbedding(const std::vector<int64_t>& counts, const std::vecto
 struct IdModel : Model { std::vector<int64_t> ids; };
 inline IdModel TrainEmbeddingIds(const std::vector<std::vector<int64_t>>& batches, int window, int dim, int iter,
                                  int64_t min_count = 5, int64_t max_count = -1, double subsample = 1e-3, uint64_t seed = 1) {
-  check(goctr_init(0));
+  ensure_init();
   int64_t cap = 0;
   for (const auto& b : batches) cap += (int64_t)b.size();
   goctr_corpus* c = nullptr;
@@ -334,7 +343,7 @@ class Searcher {
   Searcher(std::vector<std::string> words, const std::vector<double>& vectors, int dim) : words_(std::move(words)), dim_(dim) {
     if (words_.empty() || vectors.size() != words_.size() * (size_t)dim) throw std::runtime_error("embeddings do not validate");
     vec_ = vectors;
-    check(goctr_init(0));
+    ensure_init();
     check(goctr_searcher_create(vec_.data(), (int64_t)words_.size(), dim, &h_));
   }
   ~Searcher() { if (h_) goctr_searcher_destroy(h_); }

@@ -228,12 +228,13 @@ class Predictor:
         self.recSys, self.net, self.PredBatchSize = recSys, net, predBatchSize
 
 
-def Train(recSys: DeviceRecSys, samples, net, batchSize=200, epochs=200, earlyStop=20, dropout_seed=42, predBatchSize=4096):
+def Train(recSys: DeviceRecSys, samples, net, batchSize=200, epochs=200, earlyStop=20, dropout_seed=42, predBatchSize=4096, devices=0):
     """rcmd.go:187-246 for a DIN / YouTube net (``net`` = model.NewDinNet(...) / NewYoutubeDnn(...)): GetSample ->
-    model.Train -> Predictor.  Returns (Predictor, per-epoch costs)."""
+    model.Train -> Predictor.  Returns (Predictor, per-epoch costs).  ``devices=n`` (after ``capi.init_devices``): the same call
+    data-parallel over n engines, batchSize staying the global batch (no reference counterpart)."""
     from . import model as gm
     ds, _si, _kept = GetSample(recSys, samples)
-    cfg = capi.default_train_cfg(batch=batchSize, epochs=epochs, early_stop=earlyStop, dropout_mode=0)
+    cfg = capi.default_train_cfg(batch=batchSize, epochs=epochs, early_stop=earlyStop, dropout_mode=0, devices=devices)
     if dropout_seed is not None and (net.d0 > 0 or net.d1 > 0):
         cfg.dropout_mode, cfg.p0, cfg.p1, cfg.seed = 2, net.d0, net.d1, dropout_seed
     costs = gm.train_dataset(net, ds, cfg, emb=recSys.emb)
