@@ -372,3 +372,68 @@ def test_single_call_entry_over_an_rccl_group_of_one(tmp_path):
         assert np.array_equal(r[f"wA{lr}"], r[f"wB{lr}"])
         assert np.array_equal(r[f"tA{lr}"], r[f"tB{lr}"])
     assert np.abs(r["tA0.05"] - r["tA0.0"]).max() > 0
+
+
+HOUSEKEEPING = r'''
+rng = np.random.default_rng(8)
+U, T, D, Cc, V = 52, 10, 16, 53, 200
+def data(rows, seed):
+    r = np.random.default_rng(seed)
+    return (r.integers(-1, V, size=(rows, T)).astype(np.int32), r.integers(0, V, size=rows).astype(np.int32),
+            r.random((rows, U), dtype=np.float32), r.random((rows, Cc), dtype=np.float32), (r.random(rows) < 0.5).astype(np.float32))
+emb = (rng.standard_normal((V, D)) * 0.25).astype(np.float32)
+names = ("mlp0", "mlp1", "mlp2", "att0")
+def flat(m): return np.concatenate([m.get_weights(n).ravel() for n in names])
+def mk(seed=1):
+    m = gm.DinNet(U, T, D, D, Cc)
+    r = np.random.default_rng(seed)
+    for n in ("mlp0", "mlp1", "mlp2"): m.set_weights(n, (r.standard_normal(m._shape(n)) * 0.2).astype(np.float32))
+    return m
+tab = gm.EmbeddingTable(emb)
+ds1, ds2 = gm.Dataset.ids(*data(1000, 1)), gm.Dataset.ids(*data(777, 2))
+cW = capi.default_train_cfg(batch=64 * W, epochs=1, dropout_mode=0, devices=W)
+c1 = capi.default_train_cfg(batch=64 * W, epochs=1, dropout_mode=0, devices=1)
+log = {}
+# 1. a call that must fail on every rank before any collective (batch not a multiple of devices), then a good one: the group is usable again
+bad = capi.default_train_cfg(batch=64 * W + 1, epochs=1, dropout_mode=0, devices=W)
+mA, mB = mk(), mk()
+try:
+    gm.train_steps(mA, ds1, bad, 2, emb=tab); log["bad_batch"] = "no error"
+except capi.GoctrError as e:
+    log["bad_batch"] = str(e)
+gm.train_steps(mA, ds1, cW, 3, emb=tab); gm.train_steps(mB, ds1, c1, 3, emb=tab)
+# 2. weights changed between two multi-device calls: the replicas must be re-broadcast
+w = mA.get_weights("mlp1") * 0.5
+mA.set_weights("mlp1", w); mB.set_weights("mlp1", w)
+gm.train_steps(mA, ds1, cW, 3, first_batch=3, emb=tab); gm.train_steps(mB, ds1, c1, 3, first_batch=3, emb=tab)
+# 3. another dataset (new shards), a ragged one; then back to the first (shards rebuilt)
+gm.train_steps(mA, ds2, cW, 4, emb=tab); gm.train_steps(mB, ds2, c1, 4, emb=tab)
+gm.train_steps(mA, ds1, cW, 2, emb=tab); gm.train_steps(mB, ds1, c1, 2, emb=tab)
+# 4. a plain single-device call on the model that has replicas, then multi again (re-broadcast)
+gm.train_steps(mA, ds1, c1, 2, first_batch=2, emb=tab); gm.train_steps(mB, ds1, c1, 2, first_batch=2, emb=tab)
+gm.train_steps(mA, ds1, cW, 2, first_batch=4, emb=tab); gm.train_steps(mB, ds1, c1, 2, first_batch=4, emb=tab)
+capi.sync()
+reps = np.stack([flat(mA.replica(k)) for k in range(W)])
+# 5. the table changed through set_rows: the table replicas follow on the next call (frozen embeddings: only the forward reads them)
+e2 = emb.copy(); e2[:50] *= -1.0
+tab.set_rows(e2) if hasattr(tab, "set_rows") else capi.check(capi.load().goctr_emb_set_rows(tab._h, C.c_int64(0), C.c_int64(V), capi.ptr(capi.f32(e2), C.c_float)))
+gm.train_steps(mA, ds1, cW, 1, emb=tab)
+capi.sync()
+tabs = np.stack([tab.replica(k).get_rows() for k in range(W)])
+np.savez(%(out)r, reps=reps, single=flat(mB), tabs=tabs, e2=e2, msg=np.array([log["bad_batch"]]))
+'''
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_replica_and_shard_caches_follow_what_changed(tmp_path, W):
+    """the single-call entry caches replicas and shards on the handles: an argument error before any collective leaves the group
+    usable; set_weights between two calls, another dataset, a plain single-device call in between, set_rows on the table -- every
+    change is re-broadcast / re-sharded, the replicas stay bit-identical and track the single-device run"""
+    r = run_script(HOUSEKEEPING, tmp_path, f"house_{W}", W=W)
+    assert "not a multiple" in str(r["msg"][0])
+    for k in range(1, W):
+        assert np.array_equal(r["reps"][0], r["reps"][k])
+        assert np.array_equal(r["tabs"][k], r["e2"])
+    assert np.array_equal(r["tabs"][0], r["e2"])
+    assert np.isfinite(r["single"]).all()
+    assert np.max(np.abs(r["reps"][0] - r["single"])) <= 2e-5
