@@ -1768,6 +1768,9 @@ int retarget_state(goctr_model* m, long long batch_idx, long long n_batches) {
 }
 
 int get_state(goctr_model* m, StepState* s) {
+  // (data parallel: the steps queued so far hold collectives -- wait for them under the communicator's watchdog, so that a peer
+  // that failed makes this rank's call fail instead of blocking in the copy below)
+  if (engine().comm_active() && comm_watch_stream()) return -1;
   GOCTR_HIP(hipMemcpyAsync(s, m->st_cur(), sizeof *s, hipMemcpyDeviceToHost, engine().stream));
   GOCTR_HIP(hipStreamSynchronize(engine().stream));
   return 0;
