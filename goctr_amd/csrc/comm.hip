@@ -284,7 +284,11 @@ int comm_capture_selftest() {
   DevBuf<float> cap, eag, bad;
   if (cap.alloc(n, false) || eag.alloc(n, false) || bad.alloc(1)) { e.capture_state = -1; return 0; }
   hipStream_t s = e.stream;
-  if (hipStreamSynchronize(s) != hipSuccess) { e.capture_state = -1; return 0; }
+  // one EAGER collective first: a communicator sets up its connections (buffers, IPC handles, proxy threads) inside its first
+  // collective, and none of that may happen inside a stream capture
+  hipLaunchKernelGGL(capture_test_fill_kernel, dim3(n / 256), dim3(256), 0, s, eag.p, n, e.rank, 7);
+  if (g_rccl.AllReduce(eag.p, eag.p, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s) != ncclSuccess ||
+      comm_watch_stream(std::max(1, env_int_comm("GOCTR_CAPTURE_TEST_TIMEOUT_S", 30)))) { e.capture_state = -1; return 0; }
   hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
   bool captured = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
   if (captured) {
