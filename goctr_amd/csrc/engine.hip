@@ -319,7 +319,7 @@ int goctr_init_devices(int n, const int* device_ids) {
   static std::mutex mu;
   std::lock_guard<std::mutex> once(mu);
   const int existing = g_nengines.load();
-  if (existing > 1 || (existing == 1 && engine_at(0)->comm_active())) {
+  if (existing > 1 || (existing == 1 && (engine_at(0)->nccl_comm || engine_at(0)->loop))) {
     // idempotent for the same list; a different one would need every handle of the old engines gone
     bool same = existing == n;
     for (int k = 0; same && k < n; ++k) same = engine_at(k)->inited && engine_at(k)->device == device_ids[k];
