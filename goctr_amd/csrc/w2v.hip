@@ -252,13 +252,20 @@ __device__ __forceinline__ double group_sum64(double v) {
 // 0.565 vs the oracle's 0.559 (16 threads) at 10^7 words; cold rows -- few updates each, none to waste -- take the
 // exact path: device-scope load + atomic add straight to memory.
 constexpr int HOG_THREADS = 1024;
-constexpr int HOG_HOT_DOUBLES = 2048;     // doubles per cached table: 2 tables x (copy + base) x 16 KB + 8 KB sigmoid table = 72 KB
+// doubles per cached table.  Round 4: the hot copies' BASE values (what a copy held at its last merge: delta = copy - base) moved
+// from LDS to a workgroup-private strip of global memory -- they are touched only at the merges, 64 KB per workgroup read and
+// written once per 16 positions = 128 B per word of plain cached traffic -- so the same 72 KB of LDS (2 tables x 32 KB + the 8 KB
+// sigmoid table; two workgroups per CU) now hold TWICE the rows: 256 node vectors + 256 word vectors at dim 16.  With Zipfian
+// counts a Huffman path's nodes halve in weight per level, so 256 cached nodes cover one more level of every walk than 128
+// (cold read-modify-writes per pair 3.05 -> ~2.0 estimated at V = 10 681).
+constexpr int HOG_HOT_DOUBLES = 4096;
 
 struct HogHot {
   const int* word_slot;     // [V] slot of a hot word in the LDS cache or -1
   const int* word_id;       // [n_words_hot] slot -> word
   int n_nodes, n_words;     // rows cached of aux (the LAST n_nodes rows = the heaviest Huffman nodes) and of param
   long long node0;          // first cached aux row
+  double* base;             // [workgroups][2][HOG_HOT_DOUBLES] base values of the hot copies (global, private per workgroup)
   int merge_every;          // words per lane group between merges
   double merge_scale;       // a workgroup's delta enters the global row times this (1 / workgroups: the replicas are averaged)
   long long max_len;        // longest piece (uniform loop bound: every thread meets every barrier)
@@ -279,7 +286,9 @@ template <int GS, int MODEL, int OPT>
 __global__ __launch_bounds__(HOG_THREADS, HOG_WAVES_PER_SIMD) void w2v_hogwild_kernel(W2vDev a, int streams, const long long* slice_idx, const long long* clip_lo,
                                                                   const long long* clip_hi, HogHot hot) {
   __shared__ double tab[1000];
-  __shared__ double locN[HOG_HOT_DOUBLES], baseN[HOG_HOT_DOUBLES], locW[HOG_HOT_DOUBLES], baseW[HOG_HOT_DOUBLES];
+  __shared__ double locN[HOG_HOT_DOUBLES], locW[HOG_HOT_DOUBLES];
+  double* const baseN = hot.base + (size_t)blockIdx.x * 2 * HOG_HOT_DOUBLES;      // (only this workgroup reads or writes its strip)
+  double* const baseW = baseN + HOG_HOT_DOUBLES;
   const int dim = a.dim, win = a.window;
   for (int i = threadIdx.x; i < 1000; i += HOG_THREADS) tab[i] = a.sigtab[i];
   // fill the caches (row stride GS doubles)
@@ -586,6 +595,7 @@ struct goctr_w2v {
   int64_t V = 0;
   int64_t aux_rows = 0;
   DevBuf<double> param, aux, sigtab, lr, snap_param, snap_aux;   // snap_*: the pass's starting point (multi-GPU exchange)
+  DevBuf<double> hot_base;                                        // Hogwild kernel: the workgroups' base strips (HogHot::base)
   DevBuf<long long> path_off, trained, slice_idx, clip_lo, clip_hi;
   DevBuf<int> path_nodes, doc, hot_word_slot, hot_word_id;   // hot_*: the most frequent words, cached in LDS by the Hogwild kernel
   int n_hot_words = 0;
@@ -710,7 +720,14 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     const int GSr = dim <= 8 ? 8 : dim <= 16 ? 16 : dim <= 32 ? 32 : 64;
     // hot rows cached in LDS per workgroup: the heaviest Huffman nodes are the LAST merges (weights are non-decreasing
     // along the merge order), the hottest words the most frequent ones (ties: lower id first)
-    const int rows_cached = env_int_w2v("GOCTR_W2V_HOT", 1) ? HOG_HOT_DOUBLES / GSr : 0;
+    // GOCTR_W2V_HOT: 0 = no hot rows; 1 (default) = three quarters of what the LDS tables hold (192 rows at dim 16); n > 1 = at
+    // most n rows per table.  Measured at V = 10 681, 10^7 words (scripts/w2v_hot.sh, profiles/r04_w2v_hot_set.txt): 128 rows 189 M
+    // words/s, 5.8 KB/word memory-side, HS loss 0.5651 (oracle 0.557-0.560); 192 rows 231 M, loss 0.5686; 256 rows 232 M, 4.8 KB,
+    // loss 0.5716 -- hot rows are AVERAGED over the workgroups (see above), so every row that joins the hot set learns more slowly:
+    // the last quarter buys 0.6 % of speed for 0.5 % of loss, against a 3 % gate.
+    const int hot_knob = env_int_w2v("GOCTR_W2V_HOT", 1);
+    const int hot_cap = HOG_HOT_DOUBLES / GSr;
+    const int rows_cached = hot_knob == 0 ? 0 : (hot_knob == 1 ? hot_cap * 3 / 4 : std::min(hot_knob, hot_cap));
     HogHot hot{};
     hot.n_nodes = w->cfg.optimizer == 0 ? (int)std::min<int64_t>(rows_cached, w->aux_rows) : 0;
     hot.node0 = w->aux_rows - hot.n_nodes;
@@ -728,6 +745,8 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     hot.n_words = w->n_hot_words; hot.word_slot = w->hot_word_slot.p; hot.word_id = w->hot_word_id.p;
     hot.merge_every = std::max(1, env_int_w2v("GOCTR_W2V_MERGE", 16));
     const int nwg = (int)cdiv(streams, HOG_THREADS / GSr);
+    if (w->hot_base.ensure((size_t)nwg * 2 * HOG_HOT_DOUBLES, false)) return -1;
+    hot.base = w->hot_base.p;
     hot.merge_scale = env_int_w2v("GOCTR_W2V_AVG", 1) ? 1.0 / (double)nwg : 1.0;
     hot.max_len = 0;
     for (int k = 0; k < streams; ++k) hot.max_len = std::max(hot.max_len, idx[k + 1] - idx[k]);
