@@ -604,6 +604,9 @@ struct goctr_w2v {
   DevBuf<unsigned long long> lcg;
   std::vector<long long> h_off; std::vector<int> h_nodes; std::vector<unsigned char> h_codes;
   bool h_paths = false;          // the host copies above are filled (built on the host, or downloaded for goctr_w2v_get_paths)
+  // single-call multi-device passes (cfg.devices = n): replicas on engines 1 .. n-1 (owned), `gen` counts what changed this
+  // model's vectors from outside a multi-device pass, reps_gen = gen when the replicas were last known equal to it
+  std::vector<goctr_w2v*> reps; uint64_t gen = 1, reps_gen = 0;
   long long path_total = 0;
   int64_t n_words = 0; bool has_keep = false;
   std::mutex mu;
@@ -771,6 +774,85 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
 
 }  // namespace
 
+// ---- single-call multi-device passes (goctr_w2v_cfg::devices)
+static int w2v_upload_one(goctr_w2v* w, const int32_t* doc, int64_t n_words, const uint8_t* keep_mask) {
+  if (w->doc.alloc((size_t)n_words, false) || w->doc.upload(doc, (size_t)n_words)) return -1;
+  w->has_keep = keep_mask != nullptr;
+  if (keep_mask && (w->keep.alloc((size_t)n_words, false) || w->keep.upload(keep_mask, (size_t)n_words))) return -1;
+  w->n_words = n_words;
+  return 0;
+}
+// replicas on engines 1 .. n-1 (same cfg, same counts: the same tree) and the doc cut at the reference's slice boundaries;
+// fill(rank's handle, rank, first word, end word) puts the rank's shard in place (called with the rank's engine bound and locked)
+template <class Fill>
+static int w2v_multi_shards(goctr_w2v* w, int64_t n_words, Fill fill) {
+  const int N = w->cfg.devices;
+  Engine* e0 = engine_at(0);
+  GOCTR_CHECK(N == engine_count() && e0 && e0->world == N && (e0->loop || e0->nccl_comm),
+              "w2v cfg.devices = %d, but goctr_init_devices set up %d engine(s)", N, (e0 && (e0->loop || e0->nccl_comm)) ? e0->world : 1);
+  GOCTR_CHECK(w->eng == e0, "multi-device item2vec: the handle must live on engine 0");
+  GOCTR_CHECK(n_words >= N, "multi-device item2vec: %lld words for %d ranks", (long long)n_words, N);
+  if ((int)w->reps.size() != N) { for (auto* r : w->reps) goctr_w2v_destroy(r); w->reps.assign((size_t)N, nullptr); w->reps_gen = 0; }
+  // rank r takes slices [r, r + 1) * S / N of IndexPerThread's cut (modelutil.go:32-41) when the slices divide evenly, else an
+  // equal contiguous range; inside its shard every rank cuts its own S / N slices
+  const int S = w->cfg.slices;
+  std::vector<long long> cut((size_t)N + 1, 0);
+  cut[N] = n_words;
+  if (S >= N && S % N == 0) {
+    std::vector<long long> sidx((size_t)S + 1, 0);
+    sidx[S] = n_words;
+    for (int i = 1; i < S; ++i) sidx[i] = sidx[i - 1] + (long long)std::trunc((double)((n_words + i) / S));
+    for (int r = 1; r < N; ++r) cut[r] = sidx[(size_t)r * (S / N)];
+  } else {
+    for (int r = 1; r < N; ++r) cut[r] = n_words * r / N;
+  }
+  goctr_w2v_cfg rc = w->cfg;
+  rc.devices = 0; rc.slices = S > 0 ? std::max(1, S / N) : 0;
+  for (int k = N - 1; k >= 0; --k) {           // (rank 0 last: a device-resident source keeps its prefix)
+    Engine* ek = engine_at(k);
+    EngineScope on(ek);
+    std::lock_guard<std::recursive_mutex> elk(ek->mu);
+    if (k > 0 && !w->reps[k]) {
+      std::vector<int64_t> counts(w->h_counts.begin(), w->h_counts.end());
+      if (goctr_w2v_create(&rc, w->V, counts.data(), &w->reps[k])) return -1;
+      w->reps_gen = 0;
+    }
+    if (fill(k == 0 ? w : w->reps[k], k, cut[k], cut[k + 1])) return -1;
+  }
+  return 0;
+}
+static int w2v_multi_pass(goctr_w2v* w, int64_t corpus_len, double* lr) {
+  const int N = w->cfg.devices;
+  GOCTR_CHECK((int)w->reps.size() == N, "multi-device item2vec: upload the doc first (goctr_w2v_upload_doc / goctr_w2v_train)");
+  if (comm_group_reset()) return -1;
+  const bool sync = w->reps_gen != w->gen;
+  const double lr_in = *lr;
+  const int slices0 = w->cfg.slices;
+  w->cfg.slices = slices0 > 0 ? std::max(1, slices0 / N) : 0;       // (rank 0 cuts its shard like the replicas do)
+  std::vector<double> lrs((size_t)N, lr_in);
+  const int rc = run_on_engines(N, [&](int k) -> int {
+    Engine& e = engine();
+    std::lock_guard<std::recursive_mutex> elk(e.mu);
+    const bool prev = e.comm_enabled;
+    e.comm_enabled = true;
+    goctr_w2v* wk = k == 0 ? w : w->reps[k];
+    std::unique_lock<std::mutex> lk(wk->mu, std::defer_lock);
+    if (k > 0) lk.lock();
+    int r = 0;
+    if (sync) r = comm_broadcast(wk->param.p, sizeof(double) * (size_t)w->V * w->cfg.dim, 0) ||
+                  comm_broadcast(wk->aux.p, sizeof(double) * (size_t)w->aux_rows * w->cfg.dim, 0);
+    if (!r) r = run_pass(wk, corpus_len, &lrs[(size_t)k]);
+    if (r) { const std::string msg = goctr_last_error(); comm_abort_on_failure(); set_error("%s", msg.c_str()); }
+    e.comm_enabled = prev;
+    return r;
+  });
+  w->cfg.slices = slices0;
+  if (rc) { w->reps_gen = 0; return -1; }
+  w->reps_gen = w->gen;
+  *lr = lrs[0];
+  return 0;
+}
+
 extern "C" {
 
 void goctr_w2v_cfg_default(goctr_w2v_cfg* c) {
@@ -819,16 +901,22 @@ int goctr_w2v_create(const goctr_w2v_cfg* cfg, int64_t V, const int64_t* counts,
   return 0;
 }
 
-void goctr_w2v_destroy(goctr_w2v* w) { delete w; }
+void goctr_w2v_destroy(goctr_w2v* w) {
+  if (!w) return;
+  for (goctr_w2v* r : w->reps) goctr_w2v_destroy(r);
+  delete w;
+}
 
 int goctr_w2v_set_param(goctr_w2v* w, const double* param) {
   GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && param, "goctr_w2v_set_param: null argument");
+  ++w->gen;
   return w->param.upload(param, (size_t)w->V * w->cfg.dim);
 }
 int goctr_w2v_set_aux(goctr_w2v* w, const double* aux) {
   GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && aux, "goctr_w2v_set_aux: null argument");
+  ++w->gen;
   return w->aux.upload(aux, (size_t)w->aux_rows * w->cfg.dim);
 }
 int goctr_w2v_get_param(goctr_w2v* w, double* param) {
@@ -904,17 +992,18 @@ int goctr_w2v_upload_doc(goctr_w2v* w, const int32_t* doc, int64_t n_words, cons
   std::lock_guard<std::mutex> lk(w->mu);
   for (int64_t i = 0; i < n_words; ++i)
     GOCTR_CHECK(doc[i] >= 0 && doc[i] < w->V, "doc[%lld] = %d outside the dictionary (V = %lld)", (long long)i, doc[i], (long long)w->V);
-  if (w->doc.alloc((size_t)n_words, false) || w->doc.upload(doc, (size_t)n_words)) return -1;
-  w->has_keep = keep_mask != nullptr;
-  if (keep_mask && (w->keep.alloc((size_t)n_words, false) || w->keep.upload(keep_mask, (size_t)n_words))) return -1;
-  w->n_words = n_words;
-  return 0;
+  if (w->cfg.devices > 1)
+    return w2v_multi_shards(w, n_words, [&](goctr_w2v* wk, int, long long lo, long long hi) {
+      return w2v_upload_one(wk, doc + lo, hi - lo, keep_mask ? keep_mask + lo : nullptr);
+    });
+  return w2v_upload_one(w, doc, n_words, keep_mask);
 }
 
 int goctr_w2v_train_resident(goctr_w2v* w, int64_t corpus_len, double* lr) {
   GOCTR_ENTER_H(w);
   GOCTR_CHECK(w && lr && corpus_len > 0, "goctr_w2v_train_resident: bad arguments");
   std::lock_guard<std::mutex> lk(w->mu);
+  if (w->cfg.devices > 1) return w2v_multi_pass(w, corpus_len, lr);
   return run_pass(w, corpus_len, lr);
 }
 
@@ -960,6 +1049,24 @@ int goctr_w2v_use_corpus(goctr_w2v* w, goctr_corpus* c, double subsample_thresho
     GOCTR_HIP(hipGetLastError());
   }
   w->n_words = n;
+  if (w->cfg.devices > 1) {
+    // cfg.devices = n: the doc and its mask were made on engine 0; ranks 1 .. n-1 take their shards device to device, rank 0
+    // keeps the prefix of what it holds
+    GOCTR_HIP(hipStreamSynchronize(s));
+    const goctr_w2v* src = w;
+    const int dev0 = w->eng->device;
+    return w2v_multi_shards(w, n, [&](goctr_w2v* wk, int k, long long lo, long long hi) -> int {
+      wk->n_words = hi - lo;
+      wk->has_keep = src->has_keep;
+      if (k == 0) return 0;
+      Engine& ek = engine();
+      if (wk->doc.ensure((size_t)(hi - lo), false) || (src->has_keep && wk->keep.ensure((size_t)(hi - lo), false))) return -1;
+      GOCTR_HIP(hipMemcpyPeerAsync(wk->doc.p, ek.device, src->doc.p + lo, dev0, sizeof(int) * (size_t)(hi - lo), ek.stream));
+      if (src->has_keep) GOCTR_HIP(hipMemcpyPeerAsync(wk->keep.p, ek.device, src->keep.p + lo, dev0, (size_t)(hi - lo), ek.stream));
+      GOCTR_HIP(hipStreamSynchronize(ek.stream));
+      return 0;
+    });
+  }
   return 0;
 }
 

@@ -41,7 +41,7 @@ class Word2Vec:
 
     def __init__(self, window=5, dim=16, iter=1, optimizer="hs", min_count=5, max_count=-1, init_lr=0.025,
                  subsample_threshold=1e-3, deterministic=False, streams=8192, slices=16, update_lr_batch=100000, rng=None,
-                 model="skipgram"):
+                 model="skipgram", devices=0):
         # options.go:38-58 defaults; wordemb.go:10-18 fixes SkipGram + HS + DocInMemory
         self.window, self.dim, self.iter, self.optimizer = window, dim, iter, optimizer
         self.min_count, self.max_count, self.init_lr = min_count, max_count, init_lr
@@ -50,6 +50,7 @@ class Word2Vec:
         self.slices = slices          # the reference's goroutine count (window-clipping units); workers = streams
         self.update_lr_batch = update_lr_batch
         self.model = model                                                  # options.go ModelType: skipgram | cbow
+        self.devices = devices        # n of capi.init_devices: every pass runs data-parallel inside ONE call (goctr_w2v_cfg.devices)
         self.rng = rng or np.random.default_rng()
         self.dic = Dictionary()
         self.idoc = []
@@ -79,6 +80,7 @@ class Word2Vec:
         c.init_lr, c.min_lr = self.init_lr, self.init_lr * 1.0e-4           # options.go:42,49
         c.update_lr_batch = self.update_lr_batch
         c.deterministic, c.streams, c.slices = int(self.deterministic), self.streams, self.slices
+        c.devices = self.devices
         return c
 
     def create(self, counts, param0=None, aux0=None):

@@ -271,11 +271,11 @@ struct Model {
   std::vector<float> vectors;  // GenEmbeddingMap32 rows (word2vec.go:298-324)
 };
 inline Model TrainEmbedding(const std::vector<int64_t>& counts, const std::vector<int32_t>& doc, int64_t corpus_len,
-                            int window, int dim, int iter, uint64_t seed = 1) {
+                            int window, int dim, int iter, uint64_t seed = 1, int devices = 0) {
   ensure_init();
   goctr_w2v_cfg cfg;
   goctr_w2v_cfg_default(&cfg);
-  cfg.dim = dim; cfg.window = window;
+  cfg.dim = dim; cfg.window = window; cfg.devices = devices;   // devices = n of InitDevices: every pass data-parallel in one call
   goctr_w2v* h = nullptr;
   check(goctr_w2v_create(&cfg, (int64_t)counts.size(), counts.data(), &h));
   std::mt19937_64 g(seed);
@@ -297,7 +297,8 @@ inline Model TrainEmbedding(const std::vector<int64_t>& counts, const std::vecto
 // over the ItemSeqGenerator batches as int64 item ids; `ids` of the result is Dictionary.id2word.
 struct IdModel : Model { std::vector<int64_t> ids; };
 inline IdModel TrainEmbeddingIds(const std::vector<std::vector<int64_t>>& batches, int window, int dim, int iter,
-                                 int64_t min_count = 5, int64_t max_count = -1, double subsample = 1e-3, uint64_t seed = 1) {
+                                 int64_t min_count = 5, int64_t max_count = -1, double subsample = 1e-3, uint64_t seed = 1,
+                                 int devices = 0) {
   ensure_init();
   int64_t cap = 0;
   for (const auto& b : batches) cap += (int64_t)b.size();
@@ -309,7 +310,7 @@ inline IdModel TrainEmbeddingIds(const std::vector<std::vector<int64_t>>& batche
   check(goctr_corpus_info(c, &n_words, &V, nullptr));
   goctr_w2v_cfg cfg;
   goctr_w2v_cfg_default(&cfg);
-  cfg.dim = dim; cfg.window = window;
+  cfg.dim = dim; cfg.window = window; cfg.devices = devices;
   goctr_w2v* h = nullptr;
   check(goctr_w2v_create_from_corpus(&cfg, c, &h));
   std::mt19937_64 g(seed);

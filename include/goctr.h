@@ -336,6 +336,12 @@ typedef struct {
   int slices;            /* the reference's goroutines (runtime.NumCPU(), options.go:41; default 16): the doc is cut into
                             `slices` by IndexPerThread (modelutil.go:32-41) and windows are clipped at SLICE ends only
                             (quirk Q18); every slice is shared by streams / slices workers.  0 = one slice per worker */
+  int devices;           /* 0 / 1: the engine the handle is created on.  n > 1 (= the n of goctr_init_devices): ONE
+                            goctr_w2v_upload_doc / goctr_w2v_train(_resident) call runs the pass data-parallel -- the doc is cut into n
+                            contiguous shards at the reference's slice boundaries (rank r takes slices [r, r+1) * slices / n), replicas
+                            of param / aux on engines 1 .. n-1 are broadcast when they are out of date, every rank trains its shard and
+                            the parameter deltas are summed (p = p0 + sum_r (p_r - p0)) -- embedding.TrainEmbedding stays one call from
+                            one Go process.  No reference counterpart (SURVEY 2.3, 8(e) item2vec row). */
 } goctr_w2v_cfg;
 void goctr_w2v_cfg_default(goctr_w2v_cfg* c);
 /* counts [V] = dictionary cfs (dictionary.go:70-81); builds the Huffman tree on the host with the

@@ -5,8 +5,9 @@ reduction, emb_pack_send, the owner's base = r * Vw scan, emb_apply_gathered, th
 delta exchange -- runs with W = 2, 4, 8 and is compared with the single-device run on the GLOBAL batch.
 
 The training calls are the single-call entries: ONE goctr_train_steps / goctr_train_dataset / goctr_train_dense with
-cfg.devices = W (what a single Go process' recommend.Train reaches, recommend/rcmd.go:196-246), except item2vec and the
-sklearn-port MLP, which run per-rank calls from W host threads (goctr_engine_select + goctr_comm_group_enable)."""
+cfg.devices = W (what a single Go process' recommend.Train reaches, recommend/rcmd.go:196-246); item2vec has both the single
+call (goctr_w2v_cfg.devices) and per-rank calls from W host threads (goctr_engine_select + goctr_comm_group_enable), the
+sklearn-port MLP the per-rank calls only."""
 import os
 import subprocess
 import sys
@@ -226,6 +227,84 @@ assert not errs, errs
 np.savez(%(out)r, solo_p=np.stack([s[0] for s in solo]), solo_a=np.stack([s[1] for s in solo]), p0=p0,
          dp_p=np.stack([o[0] for o in out]), dp_a=np.stack([o[1] for o in out]))
 '''
+
+
+W2V_SINGLE_CALL = r'''
+from goctr_amd import embedding as ge
+rng = np.random.default_rng(3)
+V, n, dim = 60, 4000, 16
+p = 1.0 / np.arange(1, V + 1); p /= p.sum()
+docs = [rng.choice(V, size=n, p=p).astype(np.int32) for _ in range(W)]
+keeps = [(rng.random(n) < 0.8).astype(np.uint8) for _ in range(W)]
+counts = np.bincount(np.concatenate(docs), minlength=V) + 1
+p0 = (rng.random((V, dim)) - 0.5) / dim
+def threads():         # the per-rank calls of test_item2vec_delta_exchange, three passes on the same handles: the expected result
+    out = [[None] * W for _ in range(3)]; errs = []; bar = threading.Barrier(W)
+    def rank(k):
+        try:
+            capi.engine_select(k)
+            capi.comm_group_enable(True)
+            m = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=True)
+            m.create(counts, p0)
+            lr = m.train_pass(docs[k], n * W, keeps[k], lr=0.025)
+            out[0][k] = (m.get_param(), m.get_aux(), lr)
+            bar.wait()
+            lr = m.train_resident(n * W, lr=out[0][0][2])            # (the single call hands rank 0's rate to every rank)
+            out[1][k] = (m.get_param(), m.get_aux(), lr)
+            m.set_param(p0); m.set_aux(np.zeros_like(out[1][k][1]))
+            lr = m.train_resident(n * W, lr=0.025)                   # (the window-shrink generators carry on from pass 2)
+            out[2][k] = (m.get_param(), m.get_aux(), lr)
+            capi.comm_group_enable(False)
+        except Exception as e:
+            errs.append(repr(e)); bar.abort()
+    ths = [threading.Thread(target=rank, args=(k,)) for k in range(W)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert not errs, errs
+    return out
+exp1, exp2, exp3 = threads()
+capi.engine_select(0)
+m = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=True, devices=W)
+m.create(counts, p0)
+lr1 = m.train_pass(np.concatenate(docs), n * W, np.concatenate(keeps), lr=0.025)       # ONE call: shards, replicas, exchange
+g1 = (m.get_param(), m.get_aux())
+lr2 = m.train_resident(n * W)                                                            # second pass on the resident shards
+g2 = (m.get_param(), m.get_aux())
+# a set_param from outside puts the replicas out of date: the next pass must broadcast again
+m.set_param(p0); m.set_aux(np.zeros_like(g1[1]))
+lr3 = m.train_resident(n * W, lr=0.025)
+g3 = (m.get_param(), m.get_aux())
+# the device-resident corpus path (TrainEmbedding over item ids): dictionary, IndexedDoc and subsampling mask are made on engine 0,
+# the ranks take their shards device to device -- against the host-doc path fed with the same doc and mask
+ids = [rng.choice(V, size=3000, p=p).astype(np.int64) + 1000 for _ in range(4)]
+solo = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=True, min_count=1, rng=np.random.default_rng(9))
+solo.TrainIds(ids, 12000, seed=5)
+cdoc = solo.corpus.IndexedDoc(); ckeep = solo.keep_mask(cdoc.size)
+cps_cfs = np.asarray(solo.corpus.Dictionary()[1], np.int64)
+cp0 = (np.random.default_rng(9).random((solo.V, dim)) - 0.5) / dim
+h = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=True, devices=W)
+h.create(cps_cfs, cp0)
+h.train_pass(cdoc, solo.corpus.Len(), ckeep, lr=0.025)
+c = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=True, min_count=1, rng=np.random.default_rng(9), devices=W)
+c.TrainIds(ids, 12000, seed=5)
+np.savez(%(out)r, e1p=exp1[0][0], e1a=exp1[0][1], e2p=exp2[0][0], e2a=exp2[0][1], e3p=exp3[0][0], e3a=exp3[0][1], g1p=g1[0], g1a=g1[1], g2p=g2[0], g2a=g2[1],
+         g3p=g3[0], g3a=g3[1], lrs=np.array([exp1[0][2], exp2[0][2], lr1, lr2, lr3, exp3[0][2]]), p0=p0,
+         hp=h.get_param(), ha=h.get_aux(), cp=c.get_param(), ca=c.get_aux(), sp=solo.get_param())
+'''
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_item2vec_single_call(tmp_path, W):
+    """goctr_w2v_cfg.devices = W: ONE goctr_w2v_train call cuts the doc at the slice boundaries, builds the replicas, broadcasts,
+    trains every shard and sums the deltas -- bit-equal to the W per-rank calls from W threads (same kernels, same fixed-order
+    reduction), over two passes, and again after the caller overwrote the vectors."""
+    r = run_script(W2V_SINGLE_CALL, tmp_path, f"w2v1_{W}", W=W)
+    assert np.array_equal(r["g1p"], r["e1p"]) and np.array_equal(r["g1a"], r["e1a"])
+    assert np.array_equal(r["g2p"], r["e2p"]) and np.array_equal(r["g2a"], r["e2a"])
+    assert np.array_equal(r["g3p"], r["e3p"]) and np.array_equal(r["g3a"], r["e3a"])
+    assert r["lrs"][2] == r["lrs"][0] and r["lrs"][3] == r["lrs"][1] and r["lrs"][4] == r["lrs"][5]
+    assert np.max(np.abs(r["g1p"] - r["p0"])) > 1e-4 and not np.array_equal(r["g2p"], r["g1p"])
+    assert np.array_equal(r["cp"], r["hp"]) and np.array_equal(r["ca"], r["ha"])
+    assert not np.array_equal(r["cp"], r["sp"])
 
 
 @pytest.mark.parametrize("W", [2, 4])
