@@ -398,7 +398,9 @@ def bench_item2vec(args):
     """BASELINE configs[4] / SURVEY 8(d) cfg5: SkipGram + hierarchical softmax, window 5, D = 16 float64, V = 10 681,
     Zipf(1.0) 10^7-word corpus resident in HBM; a step = one pass over the corpus (Hogwild kernel: the doc is cut into 16
     slices like the reference cuts it over runtime.NumCPU() goroutines, options.go:41 -- windows are clipped at those
-    16 ends only -- and every slice is walked by 2048 lane groups, 32768 workers in all)."""
+    16 ends only -- and every slice is walked by 2048 lane groups, 32768 workers in all; skip-gram + HS runs the node-major kernel
+    w2v_hogwild_nm_kernel: the pairs of a position walk the centre word's path four at a time, a node is read and updated once
+    per chunk instead of once per pair)."""
     from goctr_amd import capi, embedding as ge
     capi.init(0)
     V, dim, n, streams = 10681, 16, 10_000_000, 32768
@@ -420,19 +422,22 @@ def bench_item2vec(args):
     capi.sync()
     dt = time.perf_counter() - t0
     wps = steps * n / dt
-    bytes_per_word = 19968.0                                  # 6 contexts x (12 nodes x 2 x 128 B + 2 x 128 B)
+    bytes_per_word = 19968.0                                  # 6 contexts x (12 nodes x 2 x 128 B + 2 x 128 B): the
+    #                                                           reference's pair-major row traffic, kept as the yard-stick (the
+    #                                                           node-major walk touches a node once per 4 pairs: ~ 7 KB per word)
     out = {"metric": "item2vec training words/sec (SkipGram + HS, float64)", "value": round(wps, 1), "unit": "words/s",
            "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "BASELINE configs[4]: SkipGram+HS, window 5, D=16, V=10681, Zipf(1.0), 10^7-word corpus "
                                   "resident in HBM, one pass per step, Hogwild: 16 slices (window clipping as in the reference) x "
-                                  "2048 workers, hot rows cached in LDS and averaged, cold rows device-scope atomics", "parallelism": "dp1"},
+                                  "2048 workers, node-major walk (4 pairs per node visit), hot rows cached in LDS and averaged, "
+                                  "cold rows device-scope atomics", "parallelism": "dp1"},
            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                        "kernel": "w2v_hogwild_kernel"}}
+                        "kernel": "w2v_hogwild_nm_kernel"}}
     # The updater is a read-modify-write walk over 2.7 MB of parameters: they live in L2 (hit rate in the PMC summary), so
     # the HBM roof is the wrong yard-stick.  Reported: the memory-side rate (PMC bytes / pass) against HBM, and the
     # algorithmic row traffic (19 968 B per word) against the L2 roof.
-    rl = with_traffic(out["roofline"], "item2vec", "train", "w2v_hogwild_kernel*", None, dt / steps * 1e3)
+    rl = with_traffic(out["roofline"], "item2vec", "train", "w2v_hogwild_nm_kernel*", None, dt / steps * 1e3)
     if rl.get("traffic"):
         rl["achieved"] = rl.pop("hbm_side_GBs")
         rl["frac"] = round(rl["achieved"] / HBM_PEAK_GBS, 4)

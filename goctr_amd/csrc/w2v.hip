@@ -226,10 +226,28 @@ __global__ __launch_bounds__(64) void w2v_deterministic_kernel(W2vDev a) {
   if (lane == 0) { *a.lcg = next; *a.lr = lr; *a.trained = cnt; }
 }
 
+// Sum over the GS lanes of a lane group, the same bits in every lane (the lanes branch on it).  Steps inside a 16-lane DPP
+// row are VALU moves with a lane pattern (two per double) -- round 4: they were ds_bpermute pairs (__shfl_xor), eight LDS-crossbar
+// round trips per inner product, which is what the Hogwild walk spent its time in once the node traffic was cut.  Pairings:
+// quad_perm xor 1 / xor 2, then within 8 lanes the mirror (i <-> 7 - i), within 16 the rotation by 8 (= xor 8); every step adds
+// the same two values in both partner lanes (commutative: identical bits), so the group agrees on the result.
+template <int CTRL>
+__device__ __forceinline__ double dpp_add64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
 template <int GS>
 __device__ __forceinline__ double group_sum64(double v) {
+  if (GS >= 16) v = dpp_add64<0x128>(v);             // row_ror:8   lane i + lane (i + 8) % 16
+  if (GS >= 8) {
+    if (GS >= 16) v = dpp_add64<0x124>(v);           // row_ror:4   -> all lanes = i (mod 4)
+    else v = dpp_add64<0x141>(v);                    // row_half_mirror (GS = 8): lane i + lane 7 - i
+  }
+  v = dpp_add64<0x4E>(v);                            // quad_perm [2,3,0,1]
+  v = dpp_add64<0xB1>(v);                            // quad_perm [1,0,3,2]
 #pragma unroll
-  for (int o = 1; o < GS; o <<= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 16; o < GS; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
@@ -259,13 +277,16 @@ constexpr int HOG_THREADS = 1024;
 // counts a Huffman path's nodes halve in weight per level, so 256 cached nodes cover one more level of every walk than 128
 // (cold read-modify-writes per pair 3.05 -> ~2.0 estimated at V = 10 681).
 constexpr int HOG_HOT_DOUBLES = 4096;
+// doubles per cached table of the kernel variant with WPS wavefronts per SIMD: at 4 (one 1024-thread workgroup per CU, 128
+// registers per lane) the workgroup has the CU's LDS to itself and caches twice the rows
+constexpr int hog_hot_doubles(int wps) { return wps <= 4 ? 2 * HOG_HOT_DOUBLES : HOG_HOT_DOUBLES; }
 
 struct HogHot {
   const int* word_slot;     // [V] slot of a hot word in the LDS cache or -1
   const int* word_id;       // [n_words_hot] slot -> word
   int n_nodes, n_words;     // rows cached of aux (the LAST n_nodes rows = the heaviest Huffman nodes) and of param
   long long node0;          // first cached aux row
-  double* base;             // [workgroups][2][HOG_HOT_DOUBLES] base values of the hot copies (global, private per workgroup)
+  double* base;             // [workgroups][2][hog_hot_doubles(WPS)] base values of the hot copies (global, private per workgroup)
   int merge_every;          // words per lane group between merges
   double merge_scale;       // a workgroup's delta enters the global row times this (1 / workgroups: the replicas are averaged)
   long long max_len;        // longest piece (uniform loop bound: every thread meets every barrier)
@@ -285,10 +306,11 @@ constexpr int HOG_PF = HOG_PF_N;   // node vectors of a Huffman path in flight p
 template <int GS, int MODEL, int OPT>
 __global__ __launch_bounds__(HOG_THREADS, HOG_WAVES_PER_SIMD) void w2v_hogwild_kernel(W2vDev a, int streams, const long long* slice_idx, const long long* clip_lo,
                                                                   const long long* clip_hi, HogHot hot) {
+  constexpr int HOT = HOG_HOT_DOUBLES;
   __shared__ double tab[1000];
-  __shared__ double locN[HOG_HOT_DOUBLES], locW[HOG_HOT_DOUBLES];
-  double* const baseN = hot.base + (size_t)blockIdx.x * 2 * HOG_HOT_DOUBLES;      // (only this workgroup reads or writes its strip)
-  double* const baseW = baseN + HOG_HOT_DOUBLES;
+  __shared__ double locN[HOT], locW[HOT];
+  double* const baseN = hot.base + (size_t)blockIdx.x * 2 * HOT;      // (only this workgroup reads or writes its strip)
+  double* const baseW = baseN + HOT;
   const int dim = a.dim, win = a.window;
   for (int i = threadIdx.x; i < 1000; i += HOG_THREADS) tab[i] = a.sigtab[i];
   // fill the caches (row stride GS doubles)
@@ -466,6 +488,205 @@ __global__ __launch_bounds__(HOG_THREADS, HOG_WAVES_PER_SIMD) void w2v_hogwild_k
   merge();
   if (g == 0 && l == 0) *a.trained = a.n_words;
   if (g == streams - 1 && l == 0) *a.lr = lr;  // the lr the last words saw
+}
+
+// ---- hogwild, skip-gram + hierarchical softmax, NODE-MAJOR (round 4).  Every pair of a position walks the SAME Huffman path
+// (the centre word's) with its own context vector; pair-major order -- the reference's, model.go:60-77, and the kernel above --
+// reads and updates every node of the path once per PAIR: 2 x (window - shrink) ~ 6 device-scope loads and atomic adds per cold
+// node and position.  Here the pairs of a position are walked JB at a time, node by node: a node vector is read ONCE per chunk,
+// pair j + 1 sees pair j's update in a register (exactly what it would have read back: within a stream the arithmetic is the
+// sequential one -- pair j at node i still sees the updates of pairs < j at node i, and its own context vector as it was when
+// its walk began), and the chunk's summed update leaves with ONE atomic add.  A context word that occurs twice in a window
+// starts a new chunk (its second walk must begin from the first's result).  Other streams' updates of a node arrive between
+// chunks instead of between pairs: Hogwild's race window, a few hundred nanoseconds either way.
+//
+// CPL components per lane: a lane group is GS lanes holding GS x CPL >= dim components (component c = l + k GS in lane l), so
+// a wavefront carries 64 / GS streams.  What is per PAIR AND NODE and the same in all lanes of a group -- the range test, the
+// sigmoid lookup, the gradient scalar -- is paid once per group: at dim 16, 8 lanes x 2 components halve that share per stream
+// and drop one reduction step, and 128 registers (WPS = 4: one workgroup per CU, which then also has the CU's LDS to itself)
+// hold the 2 JB context / update vectors without spilling.
+template <int GS, int CPL, int JB, int WPS, int PF>
+__global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev a, int streams, const long long* slice_idx, const long long* clip_lo,
+                                                                         const long long* clip_hi, HogHot hot) {
+  constexpr int HOT = hog_hot_doubles(WPS);
+  constexpr int RS = GS * CPL;                 // row stride of the LDS tables
+  __shared__ double tab[1000];
+  __shared__ double locN[HOT], locW[HOT];
+  double* const baseN = hot.base + (size_t)blockIdx.x * 2 * HOT;      // (only this workgroup reads or writes its strip)
+  double* const baseW = baseN + HOT;
+  const int dim = a.dim, win = a.window;
+  for (int i = threadIdx.x; i < 1000; i += HOG_THREADS) tab[i] = a.sigtab[i];
+  for (int i = threadIdx.x; i < hot.n_nodes * RS; i += HOG_THREADS) {
+    const int r = i / RS, c = i % RS;
+    const double v = c < dim ? hog_load(a.aux + (hot.node0 + r) * dim + c) : 0.0;
+    locN[i] = v; baseN[i] = v;
+  }
+  for (int i = threadIdx.x; i < hot.n_words * RS; i += HOG_THREADS) {
+    const int r = i / RS, c = i % RS;
+    const double v = c < dim ? hog_load(a.param + (long long)hot.word_id[r] * dim + c) : 0.0;
+    locW[i] = v; baseW[i] = v;
+  }
+  __syncthreads();
+  auto merge = [&]() {                         // (see w2v_hogwild_kernel)
+    __syncthreads();
+    for (int i = threadIdx.x; i < hot.n_nodes * RS; i += HOG_THREADS) {
+      const int r = i / RS, c = i % RS;
+      if (c < dim) {
+        double* gp = a.aux + (hot.node0 + r) * dim + c;
+        const double d = (locN[i] - baseN[i]) * hot.merge_scale;
+        if (d != 0.0) hog_add(gp, d);
+        const double v = hog_load(gp);
+        locN[i] = v; baseN[i] = v;
+      }
+    }
+    for (int i = threadIdx.x; i < hot.n_words * RS; i += HOG_THREADS) {
+      const int r = i / RS, c = i % RS;
+      if (c < dim) {
+        double* gp = a.param + (long long)hot.word_id[r] * dim + c;
+        const double d = (locW[i] - baseW[i]) * hot.merge_scale;
+        if (d != 0.0) hog_add(gp, d);
+        const double v = hog_load(gp);
+        locW[i] = v; baseW[i] = v;
+      }
+    }
+    __syncthreads();
+  };
+  constexpr int GPB = HOG_THREADS / GS;
+  const int g = blockIdx.x * GPB + threadIdx.x / GS;
+  const int l = threadIdx.x % GS;
+  const int gs = g < streams ? g : streams - 1;
+  const long long lo = slice_idx[gs];
+  const int len = g < streams ? (int)(slice_idx[gs + 1] - lo) : 0;            // (the host refuses pieces of 2^31 words or more)
+  bool actk[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) actk[k] = l + k * GS < dim && g < streams;
+  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * (unsigned long long)(g + 1);
+  double lr = *a.lr;
+  long long est = 0, at = 0;
+  const int* doc = a.doc + lo;
+  const unsigned char* keep = a.keep ? a.keep + lo : nullptr;
+  const long long cmin = clip_lo[gs] - lo, cmax = clip_hi[gs] - lo;
+  const int gbase = (int)(threadIdx.x & 63) & ~(GS - 1);
+  auto ld_word = [&](int id, double (&v)[CPL]) {
+    const int slot = hot.n_words ? hot.word_slot[id] : -1;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+      v[k] = !actk[k] ? 0.0 : (slot >= 0 ? locW[slot * RS + l + k * GS] : hog_load(a.param + (long long)id * dim + l + k * GS));
+  };
+  auto add_word = [&](int id, const double (&v)[CPL]) {
+    const int slot = hot.n_words ? hot.word_slot[id] : -1;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+      if (actk[k] && v[k] != 0.0) { if (slot >= 0) locW[slot * RS + l + k * GS] += v[k]; else hog_add(a.param + (long long)id * dim + l + k * GS, v[k]); }
+  };
+  auto ld_node = [&](int nd, bool on, double (&v)[CPL]) {
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+      v[k] = !(on && actk[k]) ? 0.0
+             : (nd >= hot.node0 ? locN[(nd - (int)hot.node0) * RS + l + k * GS] : hog_load(a.aux + (long long)nd * dim + l + k * GS));
+  };
+  auto add_node = [&](int nd, const double (&v)[CPL]) {
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+      if (actk[k] && v[k] != 0.0) { if (nd >= hot.node0) locN[(nd - (int)hot.node0) * RS + l + k * GS] += v[k]; else hog_add(a.aux + (long long)nd * dim + l + k * GS, v[k]); }
+  };
+  for (long long pos = 0; pos < hot.max_len; ++pos) {
+    if (pos < len) {
+      if (!keep || keep[pos]) {
+        const int id = doc[pos];
+        const int del = lcg_next(next, win);
+        // the path's node ids and codes arrive with ONE coalesced load per GS nodes (lane k holds node k, handed round by shuffle)
+        const int hp0 = (int)a.path_off[id], hp1 = (int)a.path_off[id + 1];
+        const int hn0 = hp1 - hp0 < GS ? hp1 - hp0 : GS;
+        const int h_nd0 = l < hn0 ? a.path_nodes[hp0 + l] : 0;
+        const int h_code0 = l < hn0 ? (int)a.path_codes[hp0 + l] : 0;
+        const int wend = win * 2 + 1 - del;
+        int w = del;
+        while (w < wend) {
+          int cid[JB]; double ctx[JB][CPL], tmp[JB][CPL];
+          int nj = 0;
+#pragma unroll
+          for (int j = 0; j < JB; ++j) {
+            cid[j] = -1;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) { ctx[j][k] = 0.0; tmp[j][k] = 0.0; }
+            if (nj == j) {                                       // (the chunk is still open)
+              int found = -1;
+              for (; w < wend; ++w) {
+                if (w == win) continue;
+                const long long c = pos - win + w;
+                if (c < cmin || c >= cmax) continue;
+                found = doc[c];
+                break;
+              }
+              bool dup = false;
+#pragma unroll
+              for (int k = 0; k < j; ++k) dup = dup || cid[k] == found;
+              if (found >= 0 && !dup) { cid[j] = found; ++w; nj = j + 1; ld_word(found, ctx[j]); }
+            }
+          }
+          if (nj == 0) break;                                     // (no context left)
+          unsigned alive = (1u << nj) - 1u;
+          for (int c0 = hp0; c0 < hp1 && alive; c0 += GS) {
+            const int n = hp1 - c0 < GS ? hp1 - c0 : GS;
+            const int my_nd = c0 == hp0 ? h_nd0 : (l < n ? a.path_nodes[c0 + l] : 0);
+            const int my_code = c0 == hp0 ? h_code0 : (l < n ? (int)a.path_codes[c0 + l] : 0);
+            double pf[PF][CPL];                                   // node vectors requested PF nodes ahead
+#pragma unroll
+            for (int k = 0; k < PF; ++k) ld_node(__shfl(my_nd, gbase + (k < n ? k : 0), 64), k < n, pf[k]);
+            for (int i = 0; i < n && alive; ++i) {
+              const int nd = __shfl(my_nd, gbase + i, 64);
+              const double one_minus_code = 1.0 - (double)__shfl(my_code, gbase + i, 64);
+              double pvl[CPL], acc[CPL];
+#pragma unroll
+              for (int k = 0; k < CPL; ++k) { pvl[k] = pf[0][k]; acc[k] = 0.0; }
+#pragma unroll
+              for (int q = 0; q + 1 < PF; ++q)
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) pf[q][k] = pf[q + 1][k];
+              {
+                const int ia = i + PF;
+                ld_node(__shfl(my_nd, gbase + (ia < n ? ia : 0), 64), ia < n, pf[PF - 1]);
+              }
+#pragma unroll
+              for (int j = 0; j < JB; ++j) {
+                if (alive & (1u << j)) {
+                  double dot = ctx[j][0] * pvl[0];
+#pragma unroll
+                  for (int k = 1; k < CPL; ++k) dot += ctx[j][k] * pvl[k];
+                  const double inner = group_sum64<GS>(dot);
+                  if (inner <= -6.0 || inner >= 6.0) alive &= ~(1u << j);        // (quirk Q13: this pair's walk ends here)
+                  else {
+                    const double gg = (one_minus_code - sig_lookup(tab, inner)) * lr;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) {
+                      tmp[j][k] += gg * pvl[k];
+                      pvl[k] += gg * ctx[j][k];                    // pv += g * ctx (optimizer.go:125): what pair j + 1 reads
+                      acc[k] += gg * ctx[j][k];
+                    }
+                  }
+                }
+              }
+              add_node(nd, acc);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < JB; ++j)
+            if (j < nj) add_word(cid[j], tmp[j]);                  // ctx += tmp (model.go:74-76)
+        }
+      }
+      est += streams;                                              // (observer estimate: see w2v_hogwild_kernel)
+      if (est >= at + a.update_lr_batch) {
+        do at += a.update_lr_batch; while (est >= at + a.update_lr_batch);
+        if (lr < a.min_lr) lr = a.min_lr;
+        else lr = a.init_lr * (1.0 - (double)at / (double)a.corpus_len);
+      }
+    }
+    if ((pos + 1) % hot.merge_every == 0) merge();
+  }
+  merge();
+  if (g == 0 && l == 0) *a.trained = a.n_words;
+  if (g == streams - 1 && l == 0) *a.lr = lr;
 }
 
 __global__ void w2v_narrow_kernel(const double* p, long long n, float* out) {
@@ -720,17 +941,32 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     if (w->clip_lo.alloc(clo.size(), false) || w->clip_lo.upload(clo.data(), clo.size())) return -1;
     if (w->clip_hi.alloc(chi.size(), false) || w->clip_hi.upload(chi.data(), chi.size())) return -1;
     const int dim = w->cfg.dim;
-    const int GSr = dim <= 8 ? 8 : dim <= 16 ? 16 : dim <= 32 ? 32 : 64;
+    const int dimr = dim <= 8 ? 8 : dim <= 16 ? 16 : dim <= 32 ? 32 : 64;     // components per lane group, padded
+    // kernel variant.  Skip-gram + HS runs the node-major kernel (w2v_hogwild_nm_kernel): JB pairs per chunk, CPL components per
+    // lane, WPS wavefronts per SIMD, PF nodes requested ahead; GOCTR_W2V_JB=0 (and CBOW / negative sampling) the pair-major one
+    const bool sg_hs = w->cfg.model == 0 && w->cfg.optimizer == 0;
+    // Measured at V = 10 681, dim 16, 10^7 words, 32 768 streams (scripts/w2v_jb.sh, profiles/r04_w2v_node_major.txt):
+    //   pair-major, ds_bpermute sums (round 3 .. 4 start)   235 M words/s   5.04 KB/word memory-side   HS loss 0.5684
+    //   pair-major, DPP sums                                263 M           4.68
+    //   JB 3, 16 lanes x 1, WPS 8, PF 2                     375 M           3.08                       0.5684
+    //   JB 4,  8 lanes x 2, WPS 4, PF 8, 384 hot rows       426 M           1.55                       0.5695
+    //   JB 4,  8 lanes x 2, WPS 4, PF 8, 256 hot rows       412 M                                      0.5654   <- default
+    const int jb = sg_hs ? env_int_w2v("GOCTR_W2V_JB", dimr >= 16 ? 4 : 3) : 0;
+    const int cpl = jb > 0 && dimr >= 16 ? env_int_w2v("GOCTR_W2V_CPL", 2) : 1;
+    const int wps = jb > 0 ? env_int_w2v("GOCTR_W2V_WPS", cpl > 1 ? 4 : 8) : 8;
+    const int pf = env_int_w2v("GOCTR_W2V_PF", cpl > 1 ? 8 : 2);
+    const int GSr = dimr / (cpl > 1 ? 2 : 1);                                  // lanes per group
+    const int HOT = jb > 0 ? hog_hot_doubles(wps) : HOG_HOT_DOUBLES;
     // hot rows cached in LDS per workgroup: the heaviest Huffman nodes are the LAST merges (weights are non-decreasing
     // along the merge order), the hottest words the most frequent ones (ties: lower id first)
-    // GOCTR_W2V_HOT: 0 = no hot rows; 1 (default) = three quarters of what the LDS tables hold (192 rows at dim 16); n > 1 = at
-    // most n rows per table.  Measured at V = 10 681, 10^7 words (scripts/w2v_hot.sh, profiles/r04_w2v_hot_set.txt): 128 rows 189 M
+    // GOCTR_W2V_HOT: 0 = no hot rows; 1 (default) = three quarters of what the LDS tables hold (192 rows at dim 16; WPS 4, whose
+    // tables are twice as large: half, 256 rows -- the table above); n > 1 = at most n rows per table.  Measured at V = 10 681, 10^7 words (scripts/w2v_hot.sh, profiles/r04_w2v_hot_set.txt): 128 rows 189 M
     // words/s, 5.8 KB/word memory-side, HS loss 0.5651 (oracle 0.557-0.560); 192 rows 231 M, loss 0.5686; 256 rows 232 M, 4.8 KB,
     // loss 0.5716 -- hot rows are AVERAGED over the workgroups (see above), so every row that joins the hot set learns more slowly:
     // the last quarter buys 0.6 % of speed for 0.5 % of loss, against a 3 % gate.
     const int hot_knob = env_int_w2v("GOCTR_W2V_HOT", 1);
-    const int hot_cap = HOG_HOT_DOUBLES / GSr;
-    const int rows_cached = hot_knob == 0 ? 0 : (hot_knob == 1 ? hot_cap * 3 / 4 : std::min(hot_knob, hot_cap));
+    const int hot_cap = HOT / dimr;
+    const int rows_cached = hot_knob == 0 ? 0 : (hot_knob == 1 ? (jb > 0 && wps <= 4 ? hot_cap / 2 : hot_cap * 3 / 4) : std::min(hot_knob, hot_cap));
     HogHot hot{};
     hot.n_nodes = w->cfg.optimizer == 0 ? (int)std::min<int64_t>(rows_cached, w->aux_rows) : 0;
     hot.node0 = w->aux_rows - hot.n_nodes;
@@ -748,23 +984,40 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     hot.n_words = w->n_hot_words; hot.word_slot = w->hot_word_slot.p; hot.word_id = w->hot_word_id.p;
     hot.merge_every = std::max(1, env_int_w2v("GOCTR_W2V_MERGE", 32));   // (round 4: 16 -> 32 with the larger hot set: 229 -> 235 M words/s, same loss; 64: no further gain)
     const int nwg = (int)cdiv(streams, HOG_THREADS / GSr);
-    if (w->hot_base.ensure((size_t)nwg * 2 * HOG_HOT_DOUBLES, false)) return -1;
+    if (w->hot_base.ensure((size_t)nwg * 2 * HOT, false)) return -1;
     hot.base = w->hot_base.p;
     hot.merge_scale = env_int_w2v("GOCTR_W2V_AVG", 1) ? 1.0 / (double)nwg : 1.0;
     hot.max_len = 0;
     for (int k = 0; k < streams; ++k) hot.max_len = std::max(hot.max_len, idx[k + 1] - idx[k]);
-#define GOCTR_HOG_MO(GS, M, O) hipLaunchKernelGGL((w2v_hogwild_kernel<GS, M, O>), dim3((unsigned)cdiv(streams, HOG_THREADS / GS)), dim3(HOG_THREADS), 0, e.stream, a, streams, w->slice_idx.p, w->clip_lo.p, w->clip_hi.p, hot)
+    GOCTR_CHECK(hot.max_len < (1LL << 31), "goctr_w2v: a stream's piece of %lld words (more streams, or a shorter doc)", hot.max_len);
+    const dim3 grid((unsigned)nwg), block(HOG_THREADS);
+#define GOCTR_HOG_ARGS 0, e.stream, a, streams, w->slice_idx.p, w->clip_lo.p, w->clip_hi.p, hot
+    bool launched = false;
+#define GOCTR_NM(GS, CPL, JB, WPS, PF)                                                                              \
+    if (!launched && GSr == GS && cpl == CPL && jb == JB && wps == WPS && pf == PF) {                                \
+      hipLaunchKernelGGL((w2v_hogwild_nm_kernel<GS, CPL, JB, WPS, PF>), grid, block, GOCTR_HOG_ARGS); launched = true; \
+    }
+    if (jb > 0) {
+      GOCTR_NM(8, 2, 4, 4, 8) GOCTR_NM(16, 2, 4, 4, 8) GOCTR_NM(32, 2, 4, 4, 8)      // dim <= 16 / 32 / 64: the default shapes
+      GOCTR_NM(8, 1, 3, 8, 2)                                                      // dim <= 8
+      GOCTR_NM(16, 1, 3, 8, 2) GOCTR_NM(8, 2, 4, 4, 4)                             // (A/B: one component per lane; shallower prefetch)
+      GOCTR_CHECK(launched, "goctr_w2v: no node-major kernel for lanes %d x %d components, JB %d, WPS %d, PF %d", GSr, cpl, jb, wps, pf);
+    }
+#undef GOCTR_NM
+#define GOCTR_HOG_MO(GS, M, O) hipLaunchKernelGGL((w2v_hogwild_kernel<GS, M, O>), grid, block, GOCTR_HOG_ARGS)
 #define GOCTR_HOG(GS)                                                   \
   do {                                                                  \
     if (a.model == 1) { if (a.optimizer == 0) GOCTR_HOG_MO(GS, 1, 0); else GOCTR_HOG_MO(GS, 1, 1); } \
     else { if (a.optimizer == 0) GOCTR_HOG_MO(GS, 0, 0); else GOCTR_HOG_MO(GS, 0, 1); }              \
   } while (0)
-    if (dim <= 8) GOCTR_HOG(8);
+    if (launched) {}
+    else if (dim <= 8) GOCTR_HOG(8);
     else if (dim <= 16) GOCTR_HOG(16);
     else if (dim <= 32) GOCTR_HOG(32);
     else GOCTR_HOG(64);
 #undef GOCTR_HOG
 #undef GOCTR_HOG_MO
+#undef GOCTR_HOG_ARGS
     GOCTR_HIP(hipGetLastError());
   }
   if (dp && exchange_deltas(w)) return -1;
