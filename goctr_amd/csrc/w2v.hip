@@ -356,7 +356,7 @@ __global__ __launch_bounds__(HOG_THREADS, HOG_WAVES_PER_SIMD) void w2v_hogwild_k
   const bool act = l < dim && g < streams;
   const int gs = g < streams ? g : streams - 1;
   const long long lo = slice_idx[gs], hi = g < streams ? slice_idx[gs + 1] : lo;  // idle groups run 0 words
-  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * (unsigned long long)(g + 1);  // per-stream LCG
+  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * (unsigned long long)g;  // per-stream LCG; stream 0 starts from the reference's seed (modelutil.go:21-24)
   const double lr0 = *a.lr;
   double lr = lr0;
   long long est = 0, at = 0;
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev
   bool actk[CPL];
 #pragma unroll
   for (int k = 0; k < CPL; ++k) actk[k] = l + k * GS < dim && g < streams;
-  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * (unsigned long long)(g + 1);
+  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * (unsigned long long)g;     // (stream 0: the reference's seed)
   double lr = *a.lr;
   long long est = 0, at = 0;
   const int* doc = a.doc + lo;

@@ -122,6 +122,37 @@ def test_deterministic_lr_schedule_and_second_iteration(oracle):
     assert np.array_equal(m.get_param(), rp) and np.array_equal(m.get_aux(), rn)
 
 
+@pytest.mark.parametrize("dim", [5, 8, 16, 20, 32, 64])
+def test_hogwild_one_stream_is_the_sequential_pass(dim):
+    """The node-major Hogwild kernel (JB pairs of a position per node visit, 1 or 2 components per lane, hot rows in LDS with
+    merges) claims the SEQUENTIAL arithmetic within a stream.  With one stream there is nothing to race with, stream 0 draws its
+    window shrinks from the reference's seed, and the observer estimate is the exact word count -- so a pass must reproduce
+    the deterministic kernel (bit-exact vs the oracle, tests above) up to float64 rounding: the inner product is a DPP tree
+    instead of the j = 0 .. dim - 1 loop, and a hot row's update goes through (copy - base)."""
+    from goctr_amd import embedding as ge
+    rng = np.random.default_rng(11)
+    V, n = 70, 6000
+    doc = corpus(rng, V, n)
+    doc[100:104] = 7                                  # (the same word on both sides of a centre: the chunk must split)
+    counts = np.bincount(doc, minlength=V) + 1
+    keep = (rng.random(n) < 0.85).astype(np.uint8)
+    p0 = (rng.random((V, dim)) - 0.5) / dim
+    def one_pass(det, p, a, lr):
+        m = ge.Word2Vec(dim=dim, deterministic=det, streams=1, update_lr_batch=500)
+        m.create(counts, p, a)                        # (a fresh handle per pass: both kernels start their LCG from the seed)
+        lr = m.train_pass(doc, 2 * n, keep, lr=lr)
+        return m.get_param(), m.get_aux(), lr
+    p, a, lr = p0, None, 0.025
+    for _ in range(2):
+        dp, da, dlr = one_pass(True, p, a, lr)
+        hp, ha, hlr = one_pass(False, p, a, lr)
+        assert dlr == hlr
+        assert np.max(np.abs(dp - p)) > 1e-3
+        assert np.max(np.abs(hp - dp)) <= 1e-10 * max(1.0, np.abs(dp).max()), np.max(np.abs(hp - dp))
+        assert np.max(np.abs(ha - da)) <= 1e-10 * max(1.0, np.abs(da).max()), np.max(np.abs(ha - da))
+        p, a, lr = dp, da, dlr
+
+
 def test_hogwild_learns_cooccurrence():
     """two disjoint 'session' vocabularies: after Hogwild training, within-group cosine >> across-group"""
     from goctr_amd import embedding as ge
