@@ -16,6 +16,32 @@
 //   knn_merge_kernel: one workgroup per query: k-way merge of the tile lists -> threshold; tiles holding members
 //                     of C are replayed in order (a flagged tile is re-scored in full)
 // HBM-bound scan (V*D*8 bytes per query); nothing here is GEMM-shaped and nothing is reshaped into one.
+//
+// Round 4: the SCAN path (default for D = 16 / 32 / 64, k < 64; GOCTR_KNN_SCAN=0 keeps the two kernels above).  The tile kernel
+// reads the item matrix once per QUERY (64 queries per call: 8.2 GB through the MALL for a 128 MB matrix) and pays k
+// workgroup-wide arg-max rounds and two float64 divisions per (item, query) to rank 2048 items of which, for almost every tile,
+// none ends up among the k neighbours.  The scan path is FILTER + EXACT REFINE:
+//   knn_scan_kernel    filter, float32: the items are kept a second time as NORMALISED float32 rows (v / |v|, made once), a call's
+//                      queries likewise; one workgroup per tile of 1024 items and block of 64 queries: a thread holds its 4 rows in
+//                      registers (each row is read once per call), a query's components arrive by scalar loads as SGPR operands of
+//                      v_pk_fma_f32; per (item, query) the approximate cosine a = sum q^_d v^_d, |a - sim| <= E = (D + 8) 2^-23
+//                      (rounding of the inputs + D fused multiply-adds, products bounded by Cauchy-Schwarz); the tile's maximum
+//   knn_bound_kernel   per query L = the k-th largest of 64 group maxima (tiles dealt round-robin; the (k + 1)-th when an item
+//                      is ignored): k distinct items have a >= L, so the k-th best similarity is >= L - E, every member of the
+//                      candidate set C has sim >= L - E and lies in a tile whose maximum is >= L - 2 E -> work list of such
+//                      (query, tile) pairs, a few dozen per query
+//   knn_collect_kernel the listed tiles are scored EXACTLY (float64, the reference's d-order and its two divisions); items with
+//                      sim >= L - E join the query's candidates
+//   knn_replay_kernel  per query: candidates sorted by item index, the reference's insertion replayed over them.  Items
+//                      outside C never stand above a member of C in the k-array, so replaying any superset of C in item order
+//                      leaves the same array as the full loop -- bit-exact results from an approximate filter.  More than 2048
+//                      candidates (fewer than k positive group maxima, or masses of equal similarities): the call falls back to
+//                      the tile kernels.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 
 using namespace goctr;
@@ -26,7 +52,18 @@ struct goctr_searcher {
   DevBuf<double> items, norms, q, cand_sim, out_sim;
   DevBuf<long long> cand_idx, out_idx, ignore;
   DevBuf<int> out_cnt, cand_cut;
+  // scan path: 1 / norm per item, the call's packed input (queries | ignore) and output (idx | sim | count), per-tile maxima,
+  // bounds, candidate lists; pinned staging for ONE upload and ONE download per call
+  DevBuf<double> c_sim;
+  DevBuf<float> items32, tmax, bound;        // normalised float32 rows; per (query, tile) maxima; per query (tile bound, sim bound)
+  DevBuf<long long> c_idx;
+  DevBuf<int> c_cnt, wl_cnt;
+  DevBuf<long long> wl;                      // (query, tile) pairs as int2
+  DevBuf<unsigned char> in_pack, out_pack;
+  void* h_in = nullptr; void* h_out = nullptr; size_t h_in_bytes = 0, h_out_bytes = 0;
+  bool lds_ok = false;
   std::mutex mu;
+  ~goctr_searcher() { if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out); }
 };
 
 namespace {
@@ -35,13 +72,18 @@ constexpr int KNN_TILE = 2048;     // items per workgroup
 constexpr int KNN_PER = KNN_TILE / 256;
 constexpr int KNN_MAX_K = 256;
 
-__global__ void knn_norm_kernel(const double* items, long long V, int D, double* norms) {
+__global__ void knn_norm_kernel(const double* items, long long V, int D, double* norms, float* items32) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= V) return;
   const double* v = items + (size_t)i * D;
   double n = 0;
   for (int d = 0; d < D; ++d) n += v[d] * v[d];
-  norms[i] = sqrt(n);
+  n = sqrt(n);
+  norms[i] = n;
+  if (items32) {                             // scan path: v / |v| in float32 (a zero-norm item scores 0, as searchutil.go:21-23 returns)
+    const double r = n != 0 ? 1.0 / n : 0.0;
+    for (int d = 0; d < D; ++d) items32[(size_t)i * D + d] = (float)(v[d] * r);
+  }
 }
 
 // (a, ia) ranks before (b, ib)?  similarity descending, index ascending; idx < 0 = nothing
@@ -292,7 +334,313 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const double* __restrict
   if (threadIdx.x == 0) out_cnt[q] = cnt < k ? k - 1 : k;
 }
 
+// ------------------------------------------------------------------------------------------------------------- scan path
+constexpr int KNN2_QB = 64;        // queries per workgroup (the rows are read once per block: once per call up to 64 queries)
+constexpr int KNN2_CAP = 2048;     // candidates per query the replay kernel takes
+constexpr int KNN2_WL_PER_Q = 256; // (tile, query) pairs the work list holds per query of the call
+
+template <int CTRL>
+__device__ __forceinline__ float knn_dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+
+// knn_scan_kernel<D, IPT>: a thread keeps IPT normalised float32 rows in registers (read ONCE) and walks the block's queries; a
+// query's components are wavefront-uniform and arrive by SCALAR loads (constant address space) straight into the SGPR operands of
+// the packed multiply-adds -- no LDS traffic and no vector registers for them.  (Measured on the way, V = 10^6, D = 16, 64 queries
+// per call, float64 filter: query fragments as broadcast LDS reads, one item per read: 152 us, LDS-issue-bound at 2.4 x its VALU
+// time; two items per read with 256 registers: 219 us; scalar loads but the rows re-read per query group from L2: 575 us; rows in
+// registers + scalar loads: 104 us, VALU-bound on 32 float64 multiplies and adds per pair -- which an APPROXIMATE filter does not
+// need: float32, 8 packed FMAs per pair.)
+template <int D, int IPT>
+__global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ items32, long long V,
+                                                       const float* __restrict__ q32 /* normalised, padded to whole blocks */, int Q,
+                                                       int nt, float* __restrict__ tmax, int* __restrict__ wl_cnt) {
+  static_assert(D % 16 == 0, "scalar-load batches of 16 floats");
+  constexpr int TILE = 256 * IPT;
+  __shared__ float red[16 * KNN2_QB];                  // [16 rows of 16 lanes][QB]
+  const int tile = blockIdx.x, q0 = blockIdx.y * KNN2_QB;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *wl_cnt = 0;      // (knn_bound_kernel, the next launch, appends)
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f2 rowv[IPT][D / 2];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const long long it = (long long)tile * TILE + j * 256 + threadIdx.x;
+    const bool in = it < V;
+    const float* v = items32 + (size_t)(in ? it : V - 1) * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const f4 x = *reinterpret_cast<const f4*>(v + d);
+      rowv[j][d / 2] = in ? f2{x[0], x[1]} : f2{0.f, 0.f};          // (items past the end score 0)
+      rowv[j][d / 2 + 1] = in ? f2{x[2], x[3]} : f2{0.f, 0.f};
+    }
+  }
+  const int row = threadIdx.x >> 4;
+  typedef const f2 __attribute__((address_space(4))) cf2;
+  cf2* qbase = (cf2*)(unsigned long long)(q32 + (size_t)q0 * D);
+  const int nq = Q - q0 < KNN2_QB ? Q - q0 : KNN2_QB;
+#pragma unroll 1
+  for (int q = 0; q < nq; ++q) {
+    f2 acc[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) acc[j] = f2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < D / 2; c += 8) {
+      f2 qf[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[e] = qbase[(size_t)q * (D / 2) + c + e];
+#pragma unroll
+      for (int j = 0; j < IPT; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j] = __builtin_elementwise_fma(qf[e], rowv[j][c + e], acc[j]);
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) { const float sc = acc[j][0] + acc[j][1]; m = sc > m ? sc : m; }
+    // the query's maximum over the workgroup: DPP inside a 16-lane row, then 16 rows through LDS (below)
+    m = fmaxf(m, knn_dpp_f32<0xB1>(m)); m = fmaxf(m, knn_dpp_f32<0x4E>(m)); m = fmaxf(m, knn_dpp_f32<0x141>(m)); m = fmaxf(m, knn_dpp_f32<0x140>(m));
+    if ((threadIdx.x & 15) == 0) red[row * KNN2_QB + q] = m;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nq) {
+    float m = 0.f;
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, red[r * KNN2_QB + threadIdx.x]);
+    tmax[(size_t)(q0 + threadIdx.x) * nt + tile] = m;
+  }
+}
+
+// L = the k-th largest of 64 group maxima (tile mod 64; the (k + 1)-th when an item is ignored: it may own one of them): the
+// maxima belong to distinct items, so k items have a >= L.  bound[q] = (L - 2 E, L - E): the tile bound and the similarity
+// bound (see the header); both <= 0 when fewer groups have a positive maximum (then every positive item is a candidate and the
+// call most likely falls back).  One pass over the tile maxima and k rounds inside ONE wavefront (the exact k-th largest tile
+// maximum took k workgroup-wide arg-max rounds: 27 us, for a bound a few candidates tighter).  Resets the query's candidate
+// count and appends the (query, tile) pairs whose maximum reaches the tile bound to the work list of knn_collect_kernel.
+__global__ __launch_bounds__(256) void knn_bound_kernel(const float* __restrict__ tmax, int nt, int k, float E,
+                                                        const long long* __restrict__ ignore, float* __restrict__ bound,
+                                                        int* __restrict__ c_cnt, int2* wl, int* wl_cnt, int wl_cap) {
+  __shared__ float gmax[4][64];
+  __shared__ float sh_bd;
+  const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* tm = tmax + (size_t)q * nt;
+  float m = 0.f;
+  for (int t = threadIdx.x; t < nt; t += 256) m = fmaxf(m, tm[t]);      // (t mod 64 == lane)
+  gmax[wave][lane] = m;
+  __syncthreads();
+  if (wave == 0) {
+    float g = fmaxf(fmaxf(gmax[0][lane], gmax[1][lane]), fmaxf(gmax[2][lane], gmax[3][lane]));
+    const int rounds = k + (ignore[q] >= 0 ? 1 : 0);
+    float kth = 0.f;
+    for (int r = 0; r < rounds; ++r) {
+      float bs = g; int bl = lane;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float so = __shfl_xor(bs, o, 64);
+        const int lo = __shfl_xor(bl, o, 64);
+        if (so > bs || (so == bs && lo < bl)) { bs = so; bl = lo; }
+      }
+      if (!(bs > 0.f)) { kth = 0.f; break; }           // (uniform)
+      kth = bs;
+      if (lane == bl) g = -1.f;
+    }
+    if (lane == 0) { sh_bd = kth - 2.f * E; bound[2 * q] = kth - 2.f * E; bound[2 * q + 1] = kth - E; c_cnt[q] = 0; }
+  }
+  __syncthreads();
+  const float bd = sh_bd;
+  for (int t = threadIdx.x; t < nt; t += 256) {
+    const float x = tm[t];
+    if (x > 0.f && x >= bd) {
+      const int pos = atomicAdd(wl_cnt, 1);
+      if (pos < wl_cap) wl[pos] = make_int2(q, t);
+    }
+  }
+}
+
+// one (query, tile) pair of the work list per workgroup and turn: the tile's items pass the float32 filter once more (its own
+// bits: a >= L - 2 E holds for every member of C), the few that do are scored EXACTLY (the reference's similarity) and join the
+// query's candidates when they reach the similarity bound
+__global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restrict__ items, const double* __restrict__ norms,
+                                                          const float* __restrict__ items32, long long V, int D,
+                                                          const double* __restrict__ queries, const float* __restrict__ q32,
+                                                          const long long* __restrict__ ignore, const float* __restrict__ bound,
+                                                          const int2* __restrict__ wl, const int* __restrict__ wl_cnt, int wl_cap,
+                                                          int tile_items, int* c_cnt, long long* c_idx, double* c_sim) {
+  extern __shared__ __attribute__((aligned(16))) double knn_cq[];       // [D] the query, [1] its norm, then [D] floats: normalised
+  float* cq32 = reinterpret_cast<float*>(knn_cq + D + 1);
+  const int n = *wl_cnt;
+  if (n > wl_cap) return;                               // (knn_replay_kernel reports the overflow)
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  for (int w = blockIdx.x; w < n; w += gridDim.x) {
+    const int q = wl[w].x, tile = wl[w].y;
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) { knn_cq[d] = queries[(size_t)q * D + d]; cq32[d] = q32[(size_t)q * D + d]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double qn = 0;
+      for (int d = 0; d < D; ++d) qn += knn_cq[d] * knn_cq[d];           // embutil.Norm (search.go:86-90)
+      knn_cq[D] = sqrt(qn);
+    }
+    __syncthreads();
+    const double qn = knn_cq[D];
+    const float tb = bound[2 * q];
+    const double bd = (double)bound[2 * q + 1];
+    const long long ig = ignore[q];
+    for (int j = 0; j < tile_items / 256; ++j) {
+      const long long it = (long long)tile * tile_items + j * 256 + threadIdx.x;
+      if (it >= V || it == ig) continue;
+      // the filter, in knn_scan_kernel's arithmetic (two accumulators, the same order of packed FMAs)
+      const float* v32 = items32 + (size_t)it * D;
+      f2 acc = f2{0.f, 0.f};
+      for (int d = 0; d < D; d += 4) {
+        const f4 x = *reinterpret_cast<const f4*>(v32 + d);
+        acc = __builtin_elementwise_fma(f2{cq32[d], cq32[d + 1]}, f2{x[0], x[1]}, acc);
+        acc = __builtin_elementwise_fma(f2{cq32[d + 2], cq32[d + 3]}, f2{x[2], x[3]}, acc);
+      }
+      if (!(acc[0] + acc[1] >= tb)) continue;
+      const double n2 = norms[it];
+      if (qn == 0 || n2 == 0) continue;
+      const double* v = items + (size_t)it * D;
+      double dot = 0;
+      for (int d = 0; d < D; d += 2) {                 // dot += q[d] * v[d], d ascending (searchutil.go:17-20)
+        const d2 x = *reinterpret_cast<const d2*>(v + d);
+        dot += knn_cq[d] * x[0];
+        dot += knn_cq[d + 1] * x[1];
+      }
+      const double sim = dot / qn / n2;                 // searchutil.go:24-25
+      if (!(sim > 0 && sim >= bd)) continue;
+      const int pos = atomicAdd(&c_cnt[q], 1);
+      if (pos < KNN2_CAP) { c_idx[(size_t)q * KNN2_CAP + pos] = it; c_sim[(size_t)q * KNN2_CAP + pos] = sim; }
+    }
+  }
+}
+
+// out_cnt[q] = -1: more candidates than the replay takes (the host falls back to the tile kernels)
+__global__ __launch_bounds__(256) void knn_replay_kernel(const int* __restrict__ c_cnt, const long long* __restrict__ c_idx,
+                                                         const double* __restrict__ c_sim, int k, const int* __restrict__ wl_cnt,
+                                                         int wl_cap, long long* out_idx, double* out_sim, int* out_cnt) {
+  extern __shared__ __attribute__((aligned(16))) double knn3_smem[];
+  double* s_sim = knn3_smem;                                             // [CAP] sorted by item index
+  long long* s_idx = reinterpret_cast<long long*>(s_sim + KNN2_CAP);     // [CAP]
+  double* nb_s = reinterpret_cast<double*>(s_idx + KNN2_CAP);            // [k]
+  long long* nb_i = reinterpret_cast<long long*>(nb_s + k);              // [k]
+  const int q = blockIdx.x;
+  const int n = c_cnt[q];
+  if (n > KNN2_CAP || *wl_cnt > wl_cap) { if (threadIdx.x == 0) out_cnt[q] = -1; return; }
+  const long long* ci = c_idx + (size_t)q * KNN2_CAP;
+  const double* cs = c_sim + (size_t)q * KNN2_CAP;
+  for (int r = threadIdx.x; r < k; r += 256) { nb_s[r] = 0.0; nb_i[r] = -1; }
+  for (int e = threadIdx.x; e < n; e += 256) {          // rank sort (an item appears once)
+    const long long me = ci[e];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += ci[j] < me;
+    s_idx[rank] = me; s_sim[rank] = cs[e];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double low = 0;
+    for (int r = 0; r < n; ++r) knn_insert(nb_s, nb_i, k, s_sim[r], s_idx[r], low);
+  }
+  __syncthreads();
+  int cnt = 0;
+  for (int r = 0; r < k; ++r) cnt += nb_i[r] >= 0;
+  for (int r = threadIdx.x; r < k; r += 256) { out_idx[(size_t)q * k + r] = nb_i[r]; out_sim[(size_t)q * k + r] = nb_s[r]; }
+  if (threadIdx.x == 0) out_cnt[q] = cnt < k ? k - 1 : k;     // search.go:126-131 (see knn_merge_kernel)
+}
+
 }  // namespace
+
+// items per workgroup of the scan kernel for this dimension (0: no scan kernel -- the tile kernels serve the call)
+// (D = 16: 8 rows per thread measured the same scan time, 41.7 vs 43.6 us, and a slower collect pass: the tiles are twice as large)
+static int knn_scan_ipt(int D) { return D == 16 ? 4 : D == 32 ? 4 : D == 64 ? 2 : 0; }
+static int knn_scan_tile(int D) { return 256 * knn_scan_ipt(D); }
+static bool knn_scan_usable(const goctr_searcher* s, int k) {
+  const char* v = getenv("GOCTR_KNN_SCAN");
+  if (v && *v == '0') return false;
+  const int tile = knn_scan_tile(s->D);
+  return tile > 0 && s->items32.p && k + 1 <= 64 && cdiv(s->V, tile) <= (1 << 20);
+}
+// 0 = done, -1 = error, 1 = fall back to the tile kernels
+static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int k, const int64_t* ignore, int64_t* out_idx,
+                           double* out_sim, int* out_count) {
+  Engine& e = engine();
+  const int D = s->D, tile_items = knn_scan_tile(D), nt = (int)cdiv(s->V, tile_items), nqb = (int)cdiv(Q, KNN2_QB);
+  const size_t lds_r = sizeof(double) * (2 * (size_t)KNN2_CAP + 2 * (size_t)k);
+  if (!s->lds_ok) {
+    GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_replay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(double) * (2 * (size_t)KNN2_CAP + 2 * (size_t)KNN_MAX_K))));
+    s->lds_ok = true;
+  }
+  // one upload: [Q x D queries | Q ignore | the queries normalised, float32, padded with zero rows to whole 64-query blocks],
+  // one download: [Q x k idx | Q x k sim | Q count]
+  const size_t in_q = sizeof(double) * (size_t)Q * D, in_ig = sizeof(long long) * (size_t)Q;
+  const size_t in_q32 = sizeof(float) * (size_t)nqb * KNN2_QB * D, in_bytes = in_q + in_ig + in_q32;
+  const size_t o_idx = sizeof(long long) * (size_t)Q * k, o_sim = sizeof(double) * (size_t)Q * k, out_bytes = o_idx + o_sim + sizeof(int) * (size_t)Q;
+  if (s->h_in_bytes < in_bytes) {
+    if (s->h_in) (void)hipHostFree(s->h_in);
+    s->h_in = nullptr; s->h_in_bytes = 0;
+    GOCTR_HIP(hipHostMalloc(&s->h_in, in_bytes * 2, hipHostMallocDefault));
+    s->h_in_bytes = in_bytes * 2;
+  }
+  if (s->h_out_bytes < out_bytes) {
+    if (s->h_out) (void)hipHostFree(s->h_out);
+    s->h_out = nullptr; s->h_out_bytes = 0;
+    GOCTR_HIP(hipHostMalloc(&s->h_out, out_bytes * 2, hipHostMallocDefault));
+    s->h_out_bytes = out_bytes * 2;
+  }
+  if (s->in_pack.ensure(in_bytes, false) || s->tmax.ensure((size_t)Q * nt, false) ||
+      s->bound.ensure(2 * (size_t)Q, false) || s->c_cnt.ensure((size_t)Q, false) || s->c_idx.ensure((size_t)Q * KNN2_CAP, false) ||
+      s->c_sim.ensure((size_t)Q * KNN2_CAP, false) || s->wl.ensure((size_t)Q * KNN2_WL_PER_Q, false) || s->wl_cnt.ensure(1, false)) return -1;
+  const int wl_cap = Q * KNN2_WL_PER_Q;
+  memcpy(s->h_in, queries, in_q);
+  long long* h_ig = reinterpret_cast<long long*>(static_cast<char*>(s->h_in) + in_q);
+  for (int i = 0; i < Q; ++i) h_ig[i] = ignore ? (long long)ignore[i] : -1;
+  float* h_q32 = reinterpret_cast<float*>(static_cast<char*>(s->h_in) + in_q + in_ig);
+  memset(h_q32, 0, in_q32);
+  for (int i = 0; i < Q; ++i) {
+    double qn = 0;
+    for (int d = 0; d < D; ++d) qn += queries[(size_t)i * D + d] * queries[(size_t)i * D + d];
+    qn = std::sqrt(qn);
+    if (qn != 0 && std::isfinite(qn))
+      for (int d = 0; d < D; ++d) h_q32[(size_t)i * D + d] = (float)(queries[(size_t)i * D + d] / qn);
+  }
+  GOCTR_HIP(hipMemcpyAsync(s->in_pack.p, s->h_in, in_bytes, hipMemcpyHostToDevice, e.stream));
+  const double* d_q = reinterpret_cast<const double*>(s->in_pack.p);
+  const long long* d_ig = reinterpret_cast<const long long*>(s->in_pack.p + in_q);
+  const float* d_q32 = reinterpret_cast<const float*>(s->in_pack.p + in_q + in_ig);
+  const float E = (float)(D + 8) * 1.1920929e-07f;      // (D + 8) 2^-23
+  char* d_out = nullptr;                              // the device's view of the pinned output buffer (zero-copy: 10 KB per call)
+  GOCTR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_out), s->h_out, 0));
+  long long* d_oi = reinterpret_cast<long long*>(d_out);
+  double* d_os = reinterpret_cast<double*>(d_out + o_idx);
+  int* d_oc = reinterpret_cast<int*>(d_out + o_idx + o_sim);
+#define GOCTR_KNN_SCAN(DD, IPT) hipLaunchKernelGGL((knn_scan_kernel<DD, IPT>), dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, \
+                                                  (long long)s->V, d_q32, Q, nt, s->tmax.p, s->wl_cnt.p)
+  if (D == 16) GOCTR_KNN_SCAN(16, 4);
+  else if (D == 32) GOCTR_KNN_SCAN(32, 4);
+  else GOCTR_KNN_SCAN(64, 2);
+#undef GOCTR_KNN_SCAN
+  GOCTR_HIP(hipGetLastError());
+  hipLaunchKernelGGL(knn_bound_kernel, dim3(Q), dim3(256), 0, e.stream, s->tmax.p, nt, k, E, d_ig, s->bound.p, s->c_cnt.p,
+                     reinterpret_cast<int2*>(s->wl.p), s->wl_cnt.p, wl_cap);
+  GOCTR_HIP(hipGetLastError());
+  const int ncol = std::min(wl_cap, 8 * (e.compute_units > 0 ? e.compute_units : 256));
+  hipLaunchKernelGGL(knn_collect_kernel, dim3(ncol), dim3(256), sizeof(double) * ((size_t)D + 1) + sizeof(float) * (size_t)D, e.stream,
+                     s->items.p, s->norms.p, s->items32.p, (long long)s->V, D, d_q, d_q32, d_ig, s->bound.p, reinterpret_cast<const int2*>(s->wl.p), s->wl_cnt.p, wl_cap,
+                     tile_items, s->c_cnt.p, s->c_idx.p, s->c_sim.p);
+  GOCTR_HIP(hipGetLastError());
+  hipLaunchKernelGGL(knn_replay_kernel, dim3(Q), dim3(256), lds_r, e.stream, s->c_cnt.p, s->c_idx.p, s->c_sim.p, k, s->wl_cnt.p, wl_cap,
+                     d_oi, d_os, d_oc);
+  GOCTR_HIP(hipGetLastError());
+  GOCTR_HIP(hipStreamSynchronize(e.stream));         // (the replay kernel wrote the pinned host buffer itself: no copy command)
+  const long long* h_oi = static_cast<const long long*>(s->h_out);
+  const double* h_os = reinterpret_cast<const double*>(static_cast<const char*>(s->h_out) + o_idx);
+  const int* h_oc = reinterpret_cast<const int*>(static_cast<const char*>(s->h_out) + o_idx + o_sim);
+  for (int i = 0; i < Q; ++i) if (h_oc[i] < 0) return 1;
+  for (size_t i = 0; i < (size_t)Q * k; ++i) { out_idx[i] = h_oi[i]; out_sim[i] = h_os[i]; }
+  for (int i = 0; i < Q; ++i) out_count[i] = h_oc[i];
+  return 0;
+}
 
 extern "C" {
 
@@ -303,12 +651,13 @@ int goctr_searcher_create(const double* items, int64_t V, int D, goctr_searcher*
   GOCTR_CHECK(cdiv(V, KNN_TILE) <= 8192, "goctr_searcher_create: more than %d items", 8192 * KNN_TILE);
   goctr_searcher* s = new goctr_searcher;
   s->V = V; s->D = D;
-  if (s->items.alloc((size_t)V * D, false) || s->items.upload(items, (size_t)V * D) || s->norms.alloc((size_t)V, false)) {
+  if (s->items.alloc((size_t)V * D, false) || s->items.upload(items, (size_t)V * D) || s->norms.alloc((size_t)V, false) ||
+      (knn_scan_ipt(D) > 0 && s->items32.alloc((size_t)V * D, false))) {
     delete s;
     return -1;
   }
   hipLaunchKernelGGL(knn_norm_kernel, dim3((unsigned)cdiv(V, 256)), dim3(256), 0, engine().stream, s->items.p, (long long)V, D,
-                     s->norms.p);
+                     s->norms.p, s->items32.p);
   if (hipGetLastError() != hipSuccess) { set_error("knn_norm_kernel launch failed"); delete s; return -1; }
   *out = s;
   return 0;
@@ -323,6 +672,10 @@ int goctr_searcher_search(goctr_searcher* s, const double* queries, int Q, int k
   GOCTR_CHECK(Q > 0 && k > 0 && k <= KNN_MAX_K, "goctr_searcher_search: Q %d, k %d (k <= %d)", Q, k, KNN_MAX_K);
   std::lock_guard<std::mutex> lk(s->mu);
   Engine& e = engine();
+  if (knn_scan_usable(s, k)) {
+    const int rc = knn_search_scan(s, queries, Q, k, ignore, out_idx, out_sim, out_count);
+    if (rc <= 0) return rc;                  // (1: a query had more candidates than the replay takes -- the tile kernels below)
+  }
   const int ntiles = (int)cdiv(s->V, KNN_TILE);
   if (s->q.ensure((size_t)Q * s->D, false) || s->q.upload(queries, (size_t)Q * s->D)) return -1;
   if (s->ignore.ensure((size_t)Q, false)) return -1;

@@ -48,6 +48,36 @@ def test_matches_oracle_bit_exact(oracle, V, D, k):
         assert np.array_equal(sim[q, :cnt[q]], rs)          # bit-exact float64
 
 
+@pytest.mark.parametrize("V,D,k,Q", [(30000, 16, 10, 70), (2500, 32, 40, 33), (1024, 8, 5, 1)])
+def test_scan_path_query_blocks(oracle, V, D, k, Q):
+    """the scan path (csrc/search.hip: tile maxima of a division-free score -> bound -> exact similarities of the few
+    candidates -> replay) over several 32-query blocks and tiles, with near-duplicate items whose similarities differ in the
+    last bits (the bound's 1e-12 margin must keep every member of the candidate set) and ignored items that own a tile's
+    maximum; the same call with GOCTR_KNN_SCAN=0 (the tile kernels) must give the same bits"""
+    from goctr_amd import search as gs
+    rng = np.random.default_rng(V + D + k + Q)
+    items = rng.standard_normal((V, D))
+    near = rng.integers(0, V, size=V // 20)
+    items[near] = items[rng.integers(0, V, size=near.size)] * (1.0 + rng.integers(-3, 4, size=(near.size, 1)) * 2.0 ** -52)
+    s = gs.Searcher([str(i) for i in range(V)], items)
+    queries = rng.standard_normal((Q, D))
+    own = rng.integers(0, V, size=Q)
+    queries[::3] = items[own[::3]]                          # a third of the queries are items: their own row is ignored
+    ignore = np.full(Q, -1, np.int64)
+    ignore[::3] = own[::3]
+    idx, sim, cnt = s.search_vectors(queries, k, ignore)
+    for q in range(Q):
+        ri, rs, _ = oracle.knn_search(items, queries[q], k, ignore=int(ignore[q]))
+        assert cnt[q] == ri.size
+        assert np.array_equal(idx[q, :cnt[q]], ri) and np.array_equal(sim[q, :cnt[q]], rs)
+    os.environ["GOCTR_KNN_SCAN"] = "0"
+    try:
+        idx0, sim0, cnt0 = s.search_vectors(queries, k, ignore)
+    finally:
+        del os.environ["GOCTR_KNN_SCAN"]
+    assert np.array_equal(idx0, idx) and np.array_equal(sim0, sim) and np.array_equal(cnt0, cnt)
+
+
 @pytest.mark.parametrize("V,k", [(5000, 3), (5000, 25), (9000, 256)])
 def test_heavy_ties_replay(oracle, V, k):
     """items drawn from a pool of a few distinct vectors: thousands of exactly equal similarities, tie groups cut by
