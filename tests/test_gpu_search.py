@@ -78,21 +78,40 @@ def test_scan_path_query_blocks(oracle, V, D, k, Q):
     assert np.array_equal(idx0, idx) and np.array_equal(sim0, sim) and np.array_equal(cnt0, cnt)
 
 
-@pytest.mark.parametrize("V,k", [(5000, 3), (5000, 25), (9000, 256)])
-def test_heavy_ties_replay(oracle, V, k):
+@pytest.mark.parametrize("V,k,D", [(5000, 3, 8), (5000, 25, 8), (9000, 256, 8), (9000, 25, 16), (40000, 10, 16)])
+def test_heavy_ties_replay(oracle, V, k, D):
     """items drawn from a pool of a few distinct vectors: thousands of exactly equal similarities, tie groups cut by
     the k-th place and by the per-tile lists -- the order inside a tie group depends on the arrival history
     (search.go:108-115 uses a strict > for displaced elements too) and must still match bit for bit"""
     from goctr_amd import search as gs
     rng = np.random.default_rng(V + k)
-    pool = rng.standard_normal((6, 8))
+    pool = rng.standard_normal((6, D))
     items = pool[rng.integers(0, 6, size=V)]
-    items[rng.random(V) < 0.02] = rng.standard_normal(8)            # a few singletons in between
-    s = gs.Searcher([str(i) for i in range(V)], items)
-    queries = rng.standard_normal((5, 8))
+    items[rng.random(V) < 0.02] = rng.standard_normal(D)            # a few singletons in between
+    s = gs.Searcher([str(i) for i in range(V)], items)              # (D = 16: the scan path's candidate lists overflow -> tile kernels)
+    queries = rng.standard_normal((5, D))
     queries[0] = pool[0]
     idx, sim, cnt = s.search_vectors(queries, k)
     for q in range(5):
+        ri, rs, _ = oracle.knn_search(items, queries[q], k)
+        assert cnt[q] == ri.size
+        assert np.array_equal(idx[q, :cnt[q]], ri) and np.array_equal(sim[q, :cnt[q]], rs)
+
+
+def test_scan_path_few_positive_items(oracle):
+    """fewer than k items with a positive similarity (and fewer than k positive group maxima): the bound is 0, every positive
+    item is a candidate, the returned slice is the reference's short one"""
+    from goctr_amd import search as gs
+    rng = np.random.default_rng(77)
+    V, D, k = 3000, 16, 10
+    base = rng.standard_normal(D)
+    items = -np.abs(rng.standard_normal((V, 1))) * base + 1e-3 * rng.standard_normal((V, D))   # almost all opposite to `base`
+    pos = rng.choice(V, size=6, replace=False)
+    items[pos] = base * rng.random((6, 1)) + 1e-3 * rng.standard_normal((6, D))
+    s = gs.Searcher([str(i) for i in range(V)], items)
+    queries = np.stack([base, -base, base * 1e-150, np.zeros(D)])
+    idx, sim, cnt = s.search_vectors(queries, k)
+    for q in range(4):
         ri, rs, _ = oracle.knn_search(items, queries[q], k)
         assert cnt[q] == ri.size
         assert np.array_equal(idx[q, :cnt[q]], ri) and np.array_equal(sim[q, :cnt[q]], rs)
