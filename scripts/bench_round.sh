@@ -17,4 +17,4 @@ try:
     d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f'.split('/')[-1], d['value'], d['unit'], 'ms/step', d.get('ms_per_step'), 'qps', d.get('recommend_qps'), 'roofline', (d.get('roofline') or {}).get('frac'), 'ratio', d.get('step_traffic_ratio'))
 except Exception as e: print('$f', 'ERR', e)
 "; done
-tail -3 $O/*.err | head -40
+for f in $O/*.err; do tail -2 $f; done | head -40
