@@ -307,6 +307,40 @@ def test_item2vec_single_call(tmp_path, W):
     assert not np.array_equal(r["cp"], r["sp"])
 
 
+W2V_HOGWILD_MULTI = r'''
+from goctr_amd import embedding as ge
+rng = np.random.default_rng(3)
+V, dim = 200, 16
+sessions = []
+for _ in range(8000):
+    g = rng.integers(0, 2)
+    sessions.append(rng.integers(g * 100, g * 100 + 100, size=50))
+doc = np.concatenate(sessions).astype(np.int32)
+counts = np.bincount(doc, minlength=V)
+capi.engine_select(0)
+m = ge.Word2Vec(dim=dim, deterministic=False, streams=512, rng=np.random.default_rng(4), devices=W)
+m.create(counts)
+p0 = m.get_param()
+for _ in range(3):
+    m.train_pass(doc, doc.size, None, lr=0.025)
+np.savez(%(out)r, p=m.get_param(), p0=p0)
+'''
+
+
+@pytest.mark.parametrize("W", [2, 4])
+def test_item2vec_single_call_hogwild(tmp_path, W):
+    """the Hogwild kernel under goctr_w2v_cfg.devices = W (every rank its own shard and hot-row copies, deltas summed after
+    the pass): two disjoint session vocabularies must come apart as they do on one device"""
+    r = run_script(W2V_HOGWILD_MULTI, tmp_path, f"w2vh_{W}", W=W)
+    P = r["p"]
+    assert np.all(np.isfinite(P)) and np.max(np.abs(P - r["p0"])) > 1e-3
+    Pn = P / np.linalg.norm(P, axis=1, keepdims=True)
+    S = Pn @ Pn.T
+    within = (S[:100, :100].sum() - 100) / (100 * 99)
+    across = S[:100, 100:].mean()
+    assert within > across + 0.2, (within, across)
+
+
 @pytest.mark.parametrize("W", [2, 4])
 def test_item2vec_delta_exchange(tmp_path, W):
     """item2vec, W ranks from W host threads: snapshot, local deterministic pass on the rank's corpus shard, all-reduce of
