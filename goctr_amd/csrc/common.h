@@ -10,6 +10,8 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <thread>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -193,6 +195,35 @@ struct DevBuf {
     return 0;
   }
 };
+
+// Capture `body`'s launches on stream s into an executable graph (uploaded, so that its first launch inside a timed call does not).
+// A device-wide wait from ANOTHER host thread invalidates an open capture, ThreadLocal mode notwithstanding (seen once in 14 runs
+// of tests/test_gpu_multi.py::test_missing_rank_fails_instead_of_hanging: a peer rank's thread dropping its handles --
+// goctr_model_destroy used hipDeviceSynchronize -- while this one captured its step graphs).  The library no longer makes such
+// calls, but the host program may: when hipStreamEndCapture reports hipErrorStreamCaptureInvalidated the capture is taken again
+// (the collision is transient); restore() puts back whatever host state body() changed.
+template <class Body, class Restore>
+inline int capture_graph(hipStream_t s, hipGraphExec_t* exec, Body body, Restore restore) {
+  for (int attempt = 0;; ++attempt) {
+    hipGraph_t g = nullptr;
+    GOCTR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = body();
+    const hipError_t ce = hipStreamEndCapture(s, &g);
+    if (ce == hipErrorStreamCaptureInvalidated && attempt < 4) {
+      (void)hipGetLastError();
+      if (g) (void)hipGraphDestroy(g);
+      restore();
+      std::this_thread::sleep_for(std::chrono::milliseconds(1 << attempt));
+      continue;
+    }
+    if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
+    GOCTR_HIP(ce);
+    GOCTR_HIP(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));
+    (void)hipGraphUpload(*exec, s);
+    (void)hipGraphDestroy(g);
+    return 0;
+  }
+}
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

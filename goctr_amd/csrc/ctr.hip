@@ -1639,49 +1639,30 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   } stp_guard{m, stp_now};
   for (int par = 0; par < 2; ++par) {
     m->stp = par;                      // the captured launches bake this parity's state pointers in
-    hipGraph_t g = nullptr;
     const bool split3 = emb_split3(m);
-    GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-    int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse, split3 ? 1 : 0);
-    if (!rc && !e.comm_active() && !fuse) rc = launch_adam(m, B, *o.tc);
-    hipError_t ce = hipStreamEndCapture(e.stream, &g);
-    if (rc) { if (g) (void)hipGraphDestroy(g); m->stp = stp_now; return -1; }
-    GOCTR_HIP(ce);
-    GOCTR_HIP(hipGraphInstantiate(&m->graph.a[par], g, nullptr, nullptr, 0));
-    (void)hipGraphUpload(m->graph.a[par], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
-    (void)hipGraphDestroy(g);
+    // (capture_graph retakes a capture another thread's runtime calls invalidated; `back` = the parity its body starts from)
+    int back = m->stp;
+    auto restore = [&] { m->stp = back; };
+    if (capture_graph(e.stream, &m->graph.a[par], [&] {
+          int rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse, split3 ? 1 : 0);
+          if (!rc && !e.comm_active() && !fuse) rc = launch_adam(m, B, *o.tc);
+          return rc;
+        }, restore)) return -1;
     if (split3) {
-      hipGraph_t gm = nullptr;
-      GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-      rc = emb_exchange_owner(m) || launch_backward(m, src, B, o, true, false, 2);
-      ce = hipStreamEndCapture(e.stream, &gm);
-      if (rc) { if (gm) (void)hipGraphDestroy(gm); m->stp = stp_now; return -1; }
-      GOCTR_HIP(ce);
-      GOCTR_HIP(hipGraphInstantiate(&m->graph.mid[par], gm, nullptr, nullptr, 0));
-      (void)hipGraphUpload(m->graph.mid[par], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
-      (void)hipGraphDestroy(gm);
+      back = m->stp;
+      if (capture_graph(e.stream, &m->graph.mid[par], [&] { return emb_exchange_owner(m) || launch_backward(m, src, B, o, true, false, 2); },
+                        restore)) return -1;
     }
     if (e.comm_active()) {
-      hipGraph_t g2 = nullptr;
-      GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-      rc = (split3 && emb_exchange_apply(m, src)) || launch_adam_step(m, src, B, o);     // m->stp was flipped by launch_backward: Adam reads the new slot
-      ce = hipStreamEndCapture(e.stream, &g2);
-      if (rc) { if (g2) (void)hipGraphDestroy(g2); m->stp = stp_now; return -1; }
-      GOCTR_HIP(ce);
-      GOCTR_HIP(hipGraphInstantiate(&m->graph.b[par], g2, nullptr, nullptr, 0));
-      (void)hipGraphUpload(m->graph.b[par], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
-      (void)hipGraphDestroy(g2);
+      back = m->stp;                   // (flipped by launch_backward: Adam reads the new slot)
+      if (capture_graph(e.stream, &m->graph.b[par], [&] { return (split3 && emb_exchange_apply(m, src)) || launch_adam_step(m, src, B, o); },
+                        restore)) return -1;
       if (!split3 && env_int("GOCTR_DP_JOIN_GRAPHS", 1) != 0) {
         // b[par] + the next step's a (parity par ^ 1, where m->stp stands now): launch_backward flips m->stp back to par
-        hipGraph_t g3 = nullptr;
-        GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-        rc = launch_adam_step(m, src, B, o) || launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, false, 0);
-        ce = hipStreamEndCapture(e.stream, &g3);
-        if (rc) { if (g3) (void)hipGraphDestroy(g3); m->stp = stp_now; return -1; }
-        GOCTR_HIP(ce);
-        GOCTR_HIP(hipGraphInstantiate(&m->graph.ba[par], g3, nullptr, nullptr, 0));
-        (void)hipGraphUpload(m->graph.ba[par], e.stream);
-        (void)hipGraphDestroy(g3);
+        back = m->stp;
+        if (capture_graph(e.stream, &m->graph.ba[par], [&] {
+              return launch_adam_step(m, src, B, o) || launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, false, 0);
+            }, restore)) return -1;
       }
     }
   }
@@ -1724,21 +1705,17 @@ int build_multi_graphs(goctr_model* m, const RowSource& src, int B, const StepOp
   for (int z = 0; z < StepGraph::kNMulti; ++z)
     for (int par = 0; par < 2 && sg.kMulti[z] >= 2; ++par) {
       m->stp = par;
-      hipGraph_t g = nullptr;
-      GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-      int rc = 0;
-      for (int k = 0; k < sg.kMulti[z] && !rc; ++k) {   // launch_backward flips m->stp: the captured steps alternate
-        rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse);
-        if (!rc && dp) rc = allreduce_grads(m) || launch_adam_step(m, src, B, o);
-        else if (!rc && !fuse) rc = launch_adam(m, B, *o.tc);
-      }
-      const hipError_t ce = hipStreamEndCapture(e.stream, &g);
+      const int rcg = capture_graph(e.stream, &sg.multi[z][par], [&] {
+        int rc = 0;
+        for (int k = 0; k < sg.kMulti[z] && !rc; ++k) {   // launch_backward flips m->stp: the captured steps alternate
+          rc = launch_forward(m, src, B, o) || launch_backward(m, src, B, o, true, fuse);
+          if (!rc && dp) rc = allreduce_grads(m) || launch_adam_step(m, src, B, o);
+          else if (!rc && !fuse) rc = launch_adam(m, B, *o.tc);
+        }
+        return rc;
+      }, [&] { m->stp = par; });
       m->stp = stp_now;
-      if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
-      GOCTR_HIP(ce);
-      GOCTR_HIP(hipGraphInstantiate(&sg.multi[z][par], g, nullptr, nullptr, 0));
-      (void)hipGraphUpload(sg.multi[z][par], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
-      (void)hipGraphDestroy(g);
+      if (rcg) return -1;
     }
   sg.multi_on = true;
   return 0;
@@ -2091,7 +2068,10 @@ void goctr_model_destroy(goctr_model* m) {
   m->reps.clear();
   EngineScope on(m->eng);
   std::lock_guard<std::recursive_mutex> lk(m->eng->mu);
-  if (engine().inited) (void)hipDeviceSynchronize();
+  // (the engine's own streams, not hipDeviceSynchronize: a device-wide wait invalidates the stream capture of any OTHER thread
+  // that is building its step graphs on this device -- a second logical rank, or a training goroutine beside a serving one;
+  // serving passes are synchronous, none of this model's is in flight once its caller returned)
+  if (engine().inited) { (void)hipStreamSynchronize(engine().stream); (void)hipStreamSynchronize(engine().side); }
   m->graph.destroy();
   if (m->ev_weights) (void)hipEventDestroy(m->ev_weights);
   delete m;
@@ -3353,7 +3333,8 @@ void goctr_recsys_destroy(goctr_recsys* r) {
   if (!r) return;
   EngineScope on(r->eng);
   std::lock_guard<std::recursive_mutex> lk(r->eng->mu);
-  if (engine().inited) (void)hipDeviceSynchronize();      // (serving passes are synchronous: none is in flight once its caller returned)
+  // (serving passes are synchronous: none is in flight once its caller returned; no device-wide wait -- see goctr_model_destroy)
+  if (engine().inited) { (void)hipStreamSynchronize(engine().stream); (void)hipStreamSynchronize(engine().side); }
   delete r;
 }
 

@@ -357,8 +357,10 @@ int goctr_sync(void) {
     if (!e || !e->inited) continue;
     EngineScope on(e);
     std::lock_guard<std::recursive_mutex> lk(e->mu);
+    // (the engine's streams, never hipDeviceSynchronize: a device-wide wait invalidates the stream capture of another thread that
+    // is building step graphs on the same device; serving slots' streams are idle between calls)
     GOCTR_HIP(hipStreamSynchronize(e->stream));
-    GOCTR_HIP(hipDeviceSynchronize());
+    GOCTR_HIP(hipStreamSynchronize(e->side));
   }
   return 0;
 }

@@ -1495,15 +1495,7 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
       if (p->step_graph || p->multi_graph[0] || p->multi_graph[1]) GOCTR_HIP(hipStreamSynchronize(e.stream));
       if (p->step_graph) { (void)hipGraphExecDestroy(p->step_graph); p->step_graph = nullptr; }
       for (auto& mg : p->multi_graph) { if (mg) (void)hipGraphExecDestroy(mg); mg = nullptr; }
-      hipGraph_t g = nullptr;
-      GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-      const int rc = train_step_resident(p, true, 0);
-      const hipError_t ce = hipStreamEndCapture(e.stream, &g);
-      if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
-      GOCTR_HIP(ce);
-      GOCTR_HIP(hipGraphInstantiate(&p->step_graph, g, nullptr, nullptr, 0));
-      (void)hipGraphUpload(p->step_graph, e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
-      (void)hipGraphDestroy(g);
+      if (capture_graph(e.stream, &p->step_graph, [&] { return train_step_resident(p, true, 0); }, [] {})) return -1;
       p->step_graph_rows = p->rows; p->step_graph_perm = p->perm.n > 1;
       p->step_graph_x = p->Xr.p; p->step_graph_y = p->Yr.p; p->step_graph_p = p->perm.p; p->step_graph_w = p->W0img.p;
     }
@@ -1515,16 +1507,11 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
     if (env_int_mlp("GOCTR_MLP_GRAPH_STEPS", 1) != 0) {
       for (int z = 0; z < 2; ++z) {
         if (!p->multi_graph[z]) {
-          hipGraph_t g = nullptr;
-          GOCTR_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-          int rc = 0;
-          for (int k = 0; k < kMulti[z] && !rc; ++k) rc = train_step_resident(p, true, 0);
-          const hipError_t ce = hipStreamEndCapture(e.stream, &g);
-          if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
-          GOCTR_HIP(ce);
-          GOCTR_HIP(hipGraphInstantiate(&p->multi_graph[z], g, nullptr, nullptr, 0));
-          (void)hipGraphUpload(p->multi_graph[z], e.stream);   // (else the exec's FIRST launch uploads it: tens of us inside a timed call)
-          (void)hipGraphDestroy(g);
+          if (capture_graph(e.stream, &p->multi_graph[z], [&] {
+                int rc = 0;
+                for (int k = 0; k < kMulti[z] && !rc; ++k) rc = train_step_resident(p, true, 0);
+                return rc;
+              }, [] {})) return -1;
         }
       }
       for (int z = 0; z < 2; ++z)
