@@ -209,7 +209,11 @@ inline int capture_graph(hipStream_t s, hipGraphExec_t* exec, Body body, Restore
     GOCTR_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = body();
     const hipError_t ce = hipStreamEndCapture(s, &g);
-    if (ce == hipErrorStreamCaptureInvalidated && attempt < 4) {
+    // (an invalidated capture shows up as hipErrorStreamCaptureInvalidated, as a launch error inside body(), as a null graph or as
+    // a graph that does not instantiate -- all seen)
+    hipError_t ie = hipSuccess;
+    if (ce == hipSuccess && g && !rc) ie = hipGraphInstantiate(exec, g, nullptr, nullptr, 0);
+    if ((ce != hipSuccess || !g || ie != hipSuccess) && attempt < 4) {
       (void)hipGetLastError();
       if (g) (void)hipGraphDestroy(g);
       restore();
@@ -218,7 +222,8 @@ inline int capture_graph(hipStream_t s, hipGraphExec_t* exec, Body body, Restore
     }
     if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
     GOCTR_HIP(ce);
-    GOCTR_HIP(hipGraphInstantiate(exec, g, nullptr, nullptr, 0));
+    GOCTR_CHECK(g, "stream capture produced no graph");
+    GOCTR_HIP(ie);
     (void)hipGraphUpload(*exec, s);
     (void)hipGraphDestroy(g);
     return 0;

@@ -2988,12 +2988,14 @@ struct ServeSlot {
   int64_t cap = 0; int T = 0, U = 0, C = 0;
   // pinned staging: in = [ts i64 x N | users i32 x N | items i32 x N], out = [scores f32 x Br | failed u8 x N]
   char* h_in = nullptr; char* h_out = nullptr;
+  std::vector<void*> retired;      // outgrown pinned buffers (see ensure_keys)
   DevBuf<char> d_in, d_out;
   DevBuf<int32_t> ub_ids, item_ids; DevBuf<float> ufeat, cfeat;
   FwdWs ws;
   DevBuf<StepState> st;            // one all-zero state: "batch 0 of 1"
   DevBuf<float> X; size_t capX = 0;   // dense rows (goctr_predict_dense)
   ~ServeSlot() {
+    for (void* p : retired) (void)hipHostFree(p);
     if (h_in) (void)hipHostFree(h_in);
     if (h_out) (void)hipHostFree(h_out);
     if (stream) (void)hipStreamDestroy(stream);
@@ -3013,8 +3015,10 @@ struct ServeSlot {
     const int64_t want = std::max<int64_t>(std::max<int64_t>(n, 256), std::min<int64_t>(2 * cap, SERVE_PASS_ROWS));
     const size_t Br = (size_t)round_up((int)want, 32);
     cap = 0;                                   // (a failure below must not leave the old capacity next to missing buffers)
-    if (h_in) { (void)hipHostFree(h_in); h_in = nullptr; }
-    if (h_out) { (void)hipHostFree(h_out); h_out = nullptr; }
+    // (outgrown pinned buffers are kept until the slot goes: hipHostFree waits for the whole device, which would invalidate the
+    // stream capture of a thread that is building step graphs meanwhile -- a handful of geometric growths per slot at most)
+    if (h_in) { retired.push_back(h_in); h_in = nullptr; }
+    if (h_out) { retired.push_back(h_out); h_out = nullptr; }
     GOCTR_HIP(hipHostMalloc((void**)&h_in, (size_t)want * 16, hipHostMallocDefault));
     GOCTR_HIP(hipHostMalloc((void**)&h_out, Br * 4 + (size_t)want, hipHostMallocDefault));
     if (d_in.alloc((size_t)want * 16, false) || d_out.alloc(Br * 4 + (size_t)want, false) ||

@@ -41,6 +41,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "common.h"
 
@@ -63,7 +64,8 @@ struct goctr_searcher {
   void* h_in = nullptr; void* h_out = nullptr; size_t h_in_bytes = 0, h_out_bytes = 0;
   bool lds_ok = false;
   std::mutex mu;
-  ~goctr_searcher() { if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out); }
+  std::vector<void*> retired;                // outgrown pinned buffers: freed with the handle (hipHostFree waits for the whole device)
+  ~goctr_searcher() { for (void* p : retired) (void)hipHostFree(p); if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out); }
 };
 
 namespace {
@@ -577,13 +579,13 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   const size_t in_q32 = sizeof(float) * (size_t)nqb * KNN2_QB * D, in_bytes = in_q + in_ig + in_q32;
   const size_t o_idx = sizeof(long long) * (size_t)Q * k, o_sim = sizeof(double) * (size_t)Q * k, out_bytes = o_idx + o_sim + sizeof(int) * (size_t)Q;
   if (s->h_in_bytes < in_bytes) {
-    if (s->h_in) (void)hipHostFree(s->h_in);
+    if (s->h_in) s->retired.push_back(s->h_in);
     s->h_in = nullptr; s->h_in_bytes = 0;
     GOCTR_HIP(hipHostMalloc(&s->h_in, in_bytes * 2, hipHostMallocDefault));
     s->h_in_bytes = in_bytes * 2;
   }
   if (s->h_out_bytes < out_bytes) {
-    if (s->h_out) (void)hipHostFree(s->h_out);
+    if (s->h_out) s->retired.push_back(s->h_out);
     s->h_out = nullptr; s->h_out_bytes = 0;
     GOCTR_HIP(hipHostMalloc(&s->h_out, out_bytes * 2, hipHostMallocDefault));
     s->h_out_bytes = out_bytes * 2;
