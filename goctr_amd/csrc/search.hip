@@ -381,27 +381,42 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
   typedef const f2 __attribute__((address_space(4))) cf2;
   cf2* qbase = (cf2*)(unsigned long long)(q32 + (size_t)q0 * D);
   const int nq = Q - q0 < KNN2_QB ? Q - q0 : KNN2_QB;
-#pragma unroll 1
-  for (int q = 0; q < nq; ++q) {
+  // one query: D / 2 packed FMAs per row, the rows' scores and 0 folded with v_max3, the workgroup's maximum by integer maxima
+  // over DPP lane patterns (the scores are >= 0 and never NaN there: their bit patterns order like the values -- one
+  // instruction per step, where a float maximum of a DPP move costs a move, two canonicalising maxima and the maximum)
+  auto one_query = [&](int q, const f2 (&qf)[D / 2]) {
     f2 acc[IPT];
 #pragma unroll
     for (int j = 0; j < IPT; ++j) acc[j] = f2{0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < D / 2; c += 8) {
-      f2 qf[8];
+    for (int e = 0; e < D / 2; ++e)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qf[e] = qbase[(size_t)q * (D / 2) + c + e];
-#pragma unroll
-      for (int j = 0; j < IPT; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[j] = __builtin_elementwise_fma(qf[e], rowv[j][c + e], acc[j]);
-    }
+      for (int j = 0; j < IPT; ++j) acc[j] = __builtin_elementwise_fma(qf[e], rowv[j][e], acc[j]);
     float m = 0.f;
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) { const float sc = acc[j][0] + acc[j][1]; m = sc > m ? sc : m; }
-    // the query's maximum over the workgroup: DPP inside a 16-lane row, then 16 rows through LDS (below)
-    m = fmaxf(m, knn_dpp_f32<0xB1>(m)); m = fmaxf(m, knn_dpp_f32<0x4E>(m)); m = fmaxf(m, knn_dpp_f32<0x141>(m)); m = fmaxf(m, knn_dpp_f32<0x140>(m));
-    if ((threadIdx.x & 15) == 0) red[row * KNN2_QB + q] = m;
+    for (int j = 0; j < IPT; ++j) m = __builtin_fmaxf(m, acc[j][0] + acc[j][1]);     // (a NaN score -- an item with an infinite norm -- is dropped)
+    int mi = __builtin_bit_cast(int, m);
+    mi = max(mi, __builtin_amdgcn_update_dpp(0, mi, 0xB1, 0xf, 0xf, false));
+    mi = max(mi, __builtin_amdgcn_update_dpp(0, mi, 0x4E, 0xf, 0xf, false));
+    mi = max(mi, __builtin_amdgcn_update_dpp(0, mi, 0x141, 0xf, 0xf, false));
+    mi = max(mi, __builtin_amdgcn_update_dpp(0, mi, 0x140, 0xf, 0xf, false));
+    if ((threadIdx.x & 15) == 0) red[row * KNN2_QB + q] = __builtin_bit_cast(float, mi);
+  };
+  // QG queries' components are requested together (scalar loads return out of order: the only wait is for ALL outstanding ones,
+  // so one load per query in front of its FMAs exposes one scalar-cache latency per query; a group exposes one per QG queries).
+  // The block's query rows are padded with zero rows to whole blocks, so a group may run past nq.
+  constexpr int QG = D == 16 ? 4 : 2;                 // (QG x D / 2 SGPR pairs)
+  auto load_query = [&](int q, f2 (&qf)[D / 2]) {
+#pragma unroll
+    for (int e = 0; e < D / 2; ++e) qf[e] = qbase[(size_t)q * (D / 2) + e];
+  };
+#pragma unroll 1
+  for (int q = 0; q < nq; q += QG) {
+    f2 qf[QG][D / 2];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) load_query(q + u, qf[u]);
+#pragma unroll
+    for (int u = 0; u < QG; ++u) one_query(q + u, qf[u]);
   }
   __syncthreads();
   if ((int)threadIdx.x < nq) {
