@@ -26,12 +26,11 @@
 //                      registers (each row is read once per call), a query's components arrive by scalar loads as SGPR operands of
 //                      v_pk_fma_f32; per (item, query) the approximate cosine a = sum q^_d v^_d, |a - sim| <= E = (D + 8) 2^-23
 //                      (rounding of the inputs + D fused multiply-adds, products bounded by Cauchy-Schwarz); the tile's maximum
-//   knn_bound_kernel   per query L = the k-th largest of 64 group maxima (tiles dealt round-robin; the (k + 1)-th when an item
-//                      is ignored): k distinct items have a >= L, so the k-th best similarity is >= L - E, every member of the
-//                      candidate set C has sim >= L - E and lies in a tile whose maximum is >= L - 2 E -> work list of such
-//                      (query, tile) pairs, a few dozen per query
-//   knn_collect_kernel the listed tiles are scored EXACTLY (float64, the reference's d-order and its two divisions); items with
-//                      sim >= L - E join the query's candidates
+//   knn_collect_kernel per query (8 workgroups each) L = the k-th largest of 64 group maxima (tiles dealt round-robin; the
+//                      (k + 1)-th when an item is ignored): k distinct items have a >= L, so the k-th best similarity is >= L - E,
+//                      every member of the candidate set C has sim >= L - E and lies in a tile whose maximum is >= L - 2 E -- those
+//                      tiles, a few dozen per query, pass the filter again and the survivors are scored EXACTLY (float64, the
+//                      reference's d-order and its two divisions); items with sim >= L - E join the query's candidates
 //   knn_replay_kernel  per query: candidates sorted by item index, the reference's insertion replayed over them.  Items
 //                      outside C never stand above a member of C in the k-array, so replaying any superset of C in item order
 //                      leaves the same array as the full loop -- bit-exact results from an approximate filter.  More than 2048
@@ -56,10 +55,9 @@ struct goctr_searcher {
   // scan path: 1 / norm per item, the call's packed input (queries | ignore) and output (idx | sim | count), per-tile maxima,
   // bounds, candidate lists; pinned staging for ONE upload and ONE download per call
   DevBuf<double> c_sim;
-  DevBuf<float> items32, tmax, bound;        // normalised float32 rows; per (query, tile) maxima; per query (tile bound, sim bound)
+  DevBuf<float> items32, tmax;               // normalised float32 rows; per (query, tile) maxima
   DevBuf<long long> c_idx;
-  DevBuf<int> c_cnt, wl_cnt;
-  DevBuf<long long> wl;                      // (query, tile) pairs as int2
+  DevBuf<int> c_cnt;
   DevBuf<unsigned char> in_pack, out_pack;
   void* h_in = nullptr; void* h_out = nullptr; size_t h_in_bytes = 0, h_out_bytes = 0;
   bool lds_ok = false;
@@ -339,7 +337,6 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const double* __restrict
 // ------------------------------------------------------------------------------------------------------------- scan path
 constexpr int KNN2_QB = 64;        // queries per workgroup (the rows are read once per block: once per call up to 64 queries)
 constexpr int KNN2_CAP = 2048;     // candidates per query the replay kernel takes
-constexpr int KNN2_WL_PER_Q = 256; // (tile, query) pairs the work list holds per query of the call
 
 template <int CTRL>
 __device__ __forceinline__ float knn_dpp_f32(float v) {
@@ -356,12 +353,12 @@ __device__ __forceinline__ float knn_dpp_f32(float v) {
 template <int D, int IPT>
 __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ items32, long long V,
                                                        const float* __restrict__ q32 /* normalised, padded to whole blocks */, int Q,
-                                                       int nt, float* __restrict__ tmax, int* __restrict__ wl_cnt) {
+                                                       int nt, float* __restrict__ tmax, int* __restrict__ c_cnt) {
   static_assert(D % 16 == 0, "scalar-load batches of 16 floats");
   constexpr int TILE = 256 * IPT;
   __shared__ float red[16 * KNN2_QB];                  // [16 rows of 16 lanes][QB]
   const int tile = blockIdx.x, q0 = blockIdx.y * KNN2_QB;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *wl_cnt = 0;      // (knn_bound_kernel, the next launch, appends)
+  if (blockIdx.x == 0 && threadIdx.x < KNN2_QB && q0 + (int)threadIdx.x < Q) c_cnt[q0 + threadIdx.x] = 0;   // (knn_collect_kernel, the next launch, appends)
   typedef float f2 __attribute__((ext_vector_type(2)));
   typedef float f4 __attribute__((ext_vector_type(4)));
   f2 rowv[IPT][D / 2];
@@ -426,29 +423,43 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
   }
 }
 
-// L = the k-th largest of 64 group maxima (tile mod 64; the (k + 1)-th when an item is ignored: it may own one of them): the
-// maxima belong to distinct items, so k items have a >= L.  bound[q] = (L - 2 E, L - E): the tile bound and the similarity
-// bound (see the header); both <= 0 when fewer groups have a positive maximum (then every positive item is a candidate and the
-// call most likely falls back).  One pass over the tile maxima and k rounds inside ONE wavefront (the exact k-th largest tile
-// maximum took k workgroup-wide arg-max rounds: 27 us, for a bound a few candidates tighter).  Resets the query's candidate
-// count and appends the (query, tile) pairs whose maximum reaches the tile bound to the work list of knn_collect_kernel.
-__global__ __launch_bounds__(256) void knn_bound_kernel(const float* __restrict__ tmax, int nt, int k, float E,
-                                                        const long long* __restrict__ ignore, float* __restrict__ bound,
-                                                        int* __restrict__ c_cnt, int2* wl, int* wl_cnt, int wl_cap) {
+// knn_collect_kernel, KNN2_G workgroups per query.  Every workgroup first derives the query's bounds itself (a launch of its own
+// for them cost 14 us of mostly launch and memory latency): L = the k-th largest of 64 group maxima (tile mod 64; the (k + 1)-th
+// when an item is ignored: it may own one of them) -- the maxima belong to distinct items, so k items have a >= L; tile bound
+// L - 2 E, similarity bound L - E (header); both <= 0 when fewer groups have a positive maximum (then every positive item is a
+// candidate and the call most likely falls back).  One pass over the query's tile maxima and k rounds inside ONE wavefront.
+// Then the tiles whose maximum reaches the tile bound are numbered in tile order (the same numbering in every workgroup of the
+// query) and dealt round-robin; a workgroup's tiles pass the float32 filter once more (its own bits: a >= L - 2 E holds for
+// every member of C), the few survivors are scored EXACTLY (the reference's similarity) and join the query's candidates when they
+// reach the similarity bound.
+constexpr int KNN2_G = 8;          // workgroups per query
+constexpr int KNN2_MY = 256;       // listed tiles one workgroup takes (more: the candidate count is poisoned -> fallback)
+__global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restrict__ items, const double* __restrict__ norms,
+                                                          const float* __restrict__ items32, long long V, int D,
+                                                          const double* __restrict__ queries, const float* __restrict__ q32,
+                                                          const long long* __restrict__ ignore, const float* __restrict__ tmax, int nt,
+                                                          int tile_items, int k, float E, int* c_cnt, long long* c_idx, double* c_sim) {
+  extern __shared__ __attribute__((aligned(16))) double knn_cq[];       // [D] the query, [1] its norm, then [D] floats: normalised
+  float* cq32 = reinterpret_cast<float*>(knn_cq + D + 1);
   __shared__ float gmax[4][64];
-  __shared__ float sh_bd;
-  const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float sh_tb, sh_sb;
+  __shared__ int wave_cnt[4];
+  __shared__ int my_tiles[KNN2_MY];
+  __shared__ int n_my;
+  const int g = blockIdx.x, q = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* tm = tmax + (size_t)q * nt;
+  for (int d = threadIdx.x; d < D; d += 256) { knn_cq[d] = queries[(size_t)q * D + d]; cq32[d] = q32[(size_t)q * D + d]; }
+  if (threadIdx.x == 0) n_my = 0;
   float m = 0.f;
   for (int t = threadIdx.x; t < nt; t += 256) m = fmaxf(m, tm[t]);      // (t mod 64 == lane)
   gmax[wave][lane] = m;
   __syncthreads();
   if (wave == 0) {
-    float g = fmaxf(fmaxf(gmax[0][lane], gmax[1][lane]), fmaxf(gmax[2][lane], gmax[3][lane]));
+    float gm = fmaxf(fmaxf(gmax[0][lane], gmax[1][lane]), fmaxf(gmax[2][lane], gmax[3][lane]));
     const int rounds = k + (ignore[q] >= 0 ? 1 : 0);
     float kth = 0.f;
     for (int r = 0; r < rounds; ++r) {
-      float bs = g; int bl = lane;
+      float bs = gm; int bl = lane;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         const float so = __shfl_xor(bs, o, 64);
@@ -457,56 +468,48 @@ __global__ __launch_bounds__(256) void knn_bound_kernel(const float* __restrict_
       }
       if (!(bs > 0.f)) { kth = 0.f; break; }           // (uniform)
       kth = bs;
-      if (lane == bl) g = -1.f;
+      if (lane == bl) gm = -1.f;
     }
-    if (lane == 0) { sh_bd = kth - 2.f * E; bound[2 * q] = kth - 2.f * E; bound[2 * q + 1] = kth - E; c_cnt[q] = 0; }
+    if (lane == 0) { sh_tb = kth - 2.f * E; sh_sb = kth - E; }
+  } else if (threadIdx.x == 64) {
+    double qn = 0;
+    for (int d = 0; d < D; ++d) qn += knn_cq[d] * knn_cq[d];           // embutil.Norm (search.go:86-90)
+    knn_cq[D] = sqrt(qn);
   }
   __syncthreads();
-  const float bd = sh_bd;
-  for (int t = threadIdx.x; t < nt; t += 256) {
-    const float x = tm[t];
-    if (x > 0.f && x >= bd) {
-      const int pos = atomicAdd(wl_cnt, 1);
-      if (pos < wl_cap) wl[pos] = make_int2(q, t);
+  const float tb = sh_tb;
+  // the listed tiles in tile order: rank = (listed tiles before this one); tile of rank r belongs to workgroup r mod G
+  int base = 0;
+  for (int t0 = 0; t0 < nt; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const bool on = t < nt && tm[t] > 0.f && tm[t] >= tb;
+    const unsigned long long bal = __ballot(on);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = base;
+    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+    const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
+    if (on && rank % KNN2_G == g) {
+      const int pos = atomicAdd(&n_my, 1);
+      if (pos < KNN2_MY) my_tiles[pos] = t;
     }
+    base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
   }
-}
-
-// one (query, tile) pair of the work list per workgroup and turn: the tile's items pass the float32 filter once more (its own
-// bits: a >= L - 2 E holds for every member of C), the few that do are scored EXACTLY (the reference's similarity) and join the
-// query's candidates when they reach the similarity bound
-__global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restrict__ items, const double* __restrict__ norms,
-                                                          const float* __restrict__ items32, long long V, int D,
-                                                          const double* __restrict__ queries, const float* __restrict__ q32,
-                                                          const long long* __restrict__ ignore, const float* __restrict__ bound,
-                                                          const int2* __restrict__ wl, const int* __restrict__ wl_cnt, int wl_cap,
-                                                          int tile_items, int* c_cnt, long long* c_idx, double* c_sim) {
-  extern __shared__ __attribute__((aligned(16))) double knn_cq[];       // [D] the query, [1] its norm, then [D] floats: normalised
-  float* cq32 = reinterpret_cast<float*>(knn_cq + D + 1);
-  const int n = *wl_cnt;
-  if (n > wl_cap) return;                               // (knn_replay_kernel reports the overflow)
+  const int nmy = n_my;
+  if (nmy > KNN2_MY) { if (threadIdx.x == 0) atomicAdd(&c_cnt[q], KNN2_CAP + 1); return; }     // (the replay kernel reports it)
+  const double qn = knn_cq[D];
+  const double bd = (double)sh_sb;
+  const long long ig = ignore[q];
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef float f2 __attribute__((ext_vector_type(2)));
   typedef float f4 __attribute__((ext_vector_type(4)));
-  for (int w = blockIdx.x; w < n; w += gridDim.x) {
-    const int q = wl[w].x, tile = wl[w].y;
-    __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256) { knn_cq[d] = queries[(size_t)q * D + d]; cq32[d] = q32[(size_t)q * D + d]; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double qn = 0;
-      for (int d = 0; d < D; ++d) qn += knn_cq[d] * knn_cq[d];           // embutil.Norm (search.go:86-90)
-      knn_cq[D] = sqrt(qn);
-    }
-    __syncthreads();
-    const double qn = knn_cq[D];
-    const float tb = bound[2 * q];
-    const double bd = (double)bound[2 * q + 1];
-    const long long ig = ignore[q];
+  for (int w = 0; w < nmy; ++w) {
+    const int tile = my_tiles[w];
     for (int j = 0; j < tile_items / 256; ++j) {
       const long long it = (long long)tile * tile_items + j * 256 + threadIdx.x;
       if (it >= V || it == ig) continue;
-      // the filter, in knn_scan_kernel's arithmetic (two accumulators, the same order of packed FMAs)
+      // the filter, in knn_scan_kernel's arithmetic (one packed accumulator, the same order of packed FMAs)
       const float* v32 = items32 + (size_t)it * D;
       f2 acc = f2{0.f, 0.f};
       for (int d = 0; d < D; d += 4) {
@@ -534,8 +537,8 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
 
 // out_cnt[q] = -1: more candidates than the replay takes (the host falls back to the tile kernels)
 __global__ __launch_bounds__(256) void knn_replay_kernel(const int* __restrict__ c_cnt, const long long* __restrict__ c_idx,
-                                                         const double* __restrict__ c_sim, int k, const int* __restrict__ wl_cnt,
-                                                         int wl_cap, long long* out_idx, double* out_sim, int* out_cnt) {
+                                                         const double* __restrict__ c_sim, int k, long long* out_idx, double* out_sim,
+                                                         int* out_cnt) {
   extern __shared__ __attribute__((aligned(16))) double knn3_smem[];
   double* s_sim = knn3_smem;                                             // [CAP] sorted by item index
   long long* s_idx = reinterpret_cast<long long*>(s_sim + KNN2_CAP);     // [CAP]
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(256) void knn_replay_kernel(const int* __restrict__
   long long* nb_i = reinterpret_cast<long long*>(nb_s + k);              // [k]
   const int q = blockIdx.x;
   const int n = c_cnt[q];
-  if (n > KNN2_CAP || *wl_cnt > wl_cap) { if (threadIdx.x == 0) out_cnt[q] = -1; return; }
+  if (n > KNN2_CAP) { if (threadIdx.x == 0) out_cnt[q] = -1; return; }
   const long long* ci = c_idx + (size_t)q * KNN2_CAP;
   const double* cs = c_sim + (size_t)q * KNN2_CAP;
   for (int r = threadIdx.x; r < k; r += 256) { nb_s[r] = 0.0; nb_i[r] = -1; }
@@ -606,9 +609,7 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
     s->h_out_bytes = out_bytes * 2;
   }
   if (s->in_pack.ensure(in_bytes, false) || s->tmax.ensure((size_t)Q * nt, false) ||
-      s->bound.ensure(2 * (size_t)Q, false) || s->c_cnt.ensure((size_t)Q, false) || s->c_idx.ensure((size_t)Q * KNN2_CAP, false) ||
-      s->c_sim.ensure((size_t)Q * KNN2_CAP, false) || s->wl.ensure((size_t)Q * KNN2_WL_PER_Q, false) || s->wl_cnt.ensure(1, false)) return -1;
-  const int wl_cap = Q * KNN2_WL_PER_Q;
+      s->c_cnt.ensure((size_t)Q, false) || s->c_idx.ensure((size_t)Q * KNN2_CAP, false) || s->c_sim.ensure((size_t)Q * KNN2_CAP, false)) return -1;
   memcpy(s->h_in, queries, in_q);
   long long* h_ig = reinterpret_cast<long long*>(static_cast<char*>(s->h_in) + in_q);
   for (int i = 0; i < Q; ++i) h_ig[i] = ignore ? (long long)ignore[i] : -1;
@@ -632,22 +633,17 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   double* d_os = reinterpret_cast<double*>(d_out + o_idx);
   int* d_oc = reinterpret_cast<int*>(d_out + o_idx + o_sim);
 #define GOCTR_KNN_SCAN(DD, IPT) hipLaunchKernelGGL((knn_scan_kernel<DD, IPT>), dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, \
-                                                  (long long)s->V, d_q32, Q, nt, s->tmax.p, s->wl_cnt.p)
+                                                  (long long)s->V, d_q32, Q, nt, s->tmax.p, s->c_cnt.p)
   if (D == 16) GOCTR_KNN_SCAN(16, 4);
   else if (D == 32) GOCTR_KNN_SCAN(32, 4);
   else GOCTR_KNN_SCAN(64, 2);
 #undef GOCTR_KNN_SCAN
   GOCTR_HIP(hipGetLastError());
-  hipLaunchKernelGGL(knn_bound_kernel, dim3(Q), dim3(256), 0, e.stream, s->tmax.p, nt, k, E, d_ig, s->bound.p, s->c_cnt.p,
-                     reinterpret_cast<int2*>(s->wl.p), s->wl_cnt.p, wl_cap);
+  hipLaunchKernelGGL(knn_collect_kernel, dim3(KNN2_G, Q), dim3(256), sizeof(double) * ((size_t)D + 1) + sizeof(float) * (size_t)D, e.stream,
+                     s->items.p, s->norms.p, s->items32.p, (long long)s->V, D, d_q, d_q32, d_ig, s->tmax.p, nt, tile_items, k, E, s->c_cnt.p,
+                     s->c_idx.p, s->c_sim.p);
   GOCTR_HIP(hipGetLastError());
-  const int ncol = std::min(wl_cap, 8 * (e.compute_units > 0 ? e.compute_units : 256));
-  hipLaunchKernelGGL(knn_collect_kernel, dim3(ncol), dim3(256), sizeof(double) * ((size_t)D + 1) + sizeof(float) * (size_t)D, e.stream,
-                     s->items.p, s->norms.p, s->items32.p, (long long)s->V, D, d_q, d_q32, d_ig, s->bound.p, reinterpret_cast<const int2*>(s->wl.p), s->wl_cnt.p, wl_cap,
-                     tile_items, s->c_cnt.p, s->c_idx.p, s->c_sim.p);
-  GOCTR_HIP(hipGetLastError());
-  hipLaunchKernelGGL(knn_replay_kernel, dim3(Q), dim3(256), lds_r, e.stream, s->c_cnt.p, s->c_idx.p, s->c_sim.p, k, s->wl_cnt.p, wl_cap,
-                     d_oi, d_os, d_oc);
+  hipLaunchKernelGGL(knn_replay_kernel, dim3(Q), dim3(256), lds_r, e.stream, s->c_cnt.p, s->c_idx.p, s->c_sim.p, k, d_oi, d_os, d_oc);
   GOCTR_HIP(hipGetLastError());
   GOCTR_HIP(hipStreamSynchronize(e.stream));         // (the replay kernel wrote the pinned host buffer itself: no copy command)
   const long long* h_oi = static_cast<const long long*>(s->h_out);
