@@ -57,7 +57,9 @@ int goctr_engine_select(int k);
  * threads, one per engine); off by default so that a plain call on one engine of a group is a single-device call. */
 int goctr_comm_group_enable(int on);
 int goctr_device_count(int* n);
-/* blocks until all work queued by this library has finished (hipDeviceSynchronize) */
+/* blocks until all work queued by this library has finished: waits on every engine's own streams -- deliberately not a
+ * device-wide wait, which would invalidate the stream capture of another host thread that is building its step graphs on
+ * the same device (a training goroutine beside this caller) */
 int goctr_sync(void);
 const char* goctr_last_error(void);
 const char* goctr_version(void);
