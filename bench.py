@@ -502,10 +502,10 @@ def bench_knn(args):
            "config": {"workload": "SURVEY 8(f)2: Searcher.Search, V=10^6, D=16 f64, k=10, 64 queries per call", "parallelism": "dp1"},
            "roofline": {"bound": "hbm", "achieved": round(scan, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(scan / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel": "knn_scan_kernel (algorithmic = the reference's loop: every query scans V*D*8 bytes; the scan path "
+                        "kernel": "knn_scan_mfma_kernel (algorithmic = the reference's loop: every query scans V*D*8 bytes; the scan path "
                                   "reads a normalised float32 copy of the items ONCE per 64-query call -- filter + exact refine, "
                                   "csrc/search.hip -- so frac > 1 of the HBM roof means the roof does not bind the call)"}}
-    rl = with_traffic(out["roofline"], "knn", "train", "knn_scan_kernel*", None, None)
+    rl = with_traffic(out["roofline"], "knn", "train", "knn_scan_*", None, None)      # (knn_scan_mfma_kernel<D> from 48 queries per call on)
     rl["algorithmic_bytes"] = int(Q * V * D * 8)
     rl["filter_bytes_per_call"] = int(V * D * 4)           # what the dominant kernel has to read: the float32 rows, once
     if rl.get("avg_us_rocprofv3"):

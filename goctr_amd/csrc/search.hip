@@ -423,6 +423,69 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
   }
 }
 
+// knn_scan_mfma_kernel<D>: the same filter on the matrix cores -- the block's scores are a [1024 items] x [64 queries] product over
+// D dimensions.  A wavefront takes 32 items at a time: v_mfma_f32_32x32x2_f32 with the items as rows (lane l supplies item l % 32,
+// dimension 2 j + l / 32 of step j) and the queries as columns, D / 2 steps per 32 x 32 tile and half of the query block; a lane
+// then holds 16 items' scores of ONE query, folds them into its running maximum, and the lanes / wavefronts of a workgroup are
+// combined once at the end.  The float32 MFMA's error (1.3e-7 of sum |a b| measured on this chip, DESIGN_HISTORY 4.1) is inside
+// the same bound E.  The normalised rows are padded with zero rows to whole tiles (goctr_searcher_create): no tail checks.
+template <int D>
+__global__ __launch_bounds__(256) void knn_scan_mfma_kernel(const float* __restrict__ items32, const float* __restrict__ q32 /* padded */,
+                                                            int Q, int nt, float* __restrict__ tmax, int* __restrict__ c_cnt) {
+  typedef float v16 __attribute__((ext_vector_type(16)));
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ float red[4][KNN2_QB];
+  const int tile = blockIdx.x, q0 = blockIdx.y * KNN2_QB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
+  if (blockIdx.x == 0 && threadIdx.x < KNN2_QB && q0 + (int)threadIdx.x < Q) c_cnt[q0 + threadIdx.x] = 0;   // (knn_collect_kernel counts)
+  // this lane's query components: query q0 + h 32 + col, dimensions 2 j + half
+  float qb[2][D / 2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float* qp = q32 + (size_t)(q0 + h * 32 + col) * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const f4 x = *reinterpret_cast<const f4*>(qp + d);
+      qb[h][d / 2] = half ? x[1] : x[0];
+      qb[h][d / 2 + 1] = half ? x[3] : x[2];
+    }
+  }
+  float mx[2] = {0.f, 0.f};
+  const size_t row0 = (size_t)tile * 1024 + (size_t)wave * 256;
+#pragma unroll 2
+  for (int t = 0; t < 8; ++t) {                        // 8 tiles of 32 items per wavefront
+    const float* v = items32 + (row0 + (size_t)t * 32 + col) * D;
+    float a[D / 2];
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const f4 x = *reinterpret_cast<const f4*>(v + d);
+      a[d / 2] = half ? x[1] : x[0];
+      a[d / 2 + 1] = half ? x[3] : x[2];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      v16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < D / 2; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], qb[h][j], c, 0, 0, 0);
+      float m = mx[h];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = __builtin_fmaxf(m, c[r]);         // (a NaN score -- an item with an infinite norm -- is dropped)
+      mx[h] = m;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float m = mx[h];
+    m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));     // the other 16 rows of the column
+    if (half == 0) red[wave][h * 32 + col] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < KNN2_QB && q0 + (int)threadIdx.x < Q) {
+    const float m = __builtin_fmaxf(__builtin_fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), __builtin_fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+    tmax[(size_t)(q0 + threadIdx.x) * nt + tile] = m;
+  }
+}
+
 // knn_collect_kernel, KNN2_G workgroups per query.  Every workgroup first derives the query's bounds itself (a launch of its own
 // for them cost 14 us of mostly launch and memory latency): L = the k-th largest of 64 group maxima (tile mod 64; the (k + 1)-th
 // when an item is ignored: it may own one of them) -- the maxima belong to distinct items, so k items have a >= L; tile bound
@@ -574,6 +637,14 @@ __global__ __launch_bounds__(256) void knn_replay_kernel(const int* __restrict__
 // (D = 16: 8 rows per thread measured the same scan time, 41.7 vs 43.6 us, and a slower collect pass: the tiles are twice as large)
 static int knn_scan_ipt(int D) { return D == 16 ? 4 : D == 32 ? 4 : D == 64 ? 2 : 0; }
 static int knn_scan_tile(int D) { return 256 * knn_scan_ipt(D); }
+static int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+// the matrix-core scan kernel: from 48 queries per call on -- its cost is per block of 64 query columns (26 us), the VALU kernel's
+// per query (13 us for one, 34 us for 64; measured cross-over between 40 and 64 queries per call, scripts/knn_latency.py: Q 32 70.0
+// vs 72.2 us, Q 40 80.1 vs 77.4 us, Q 64 80.6 vs 89.8 us).  GOCTR_KNN_MFMA=0 / 1 forces either
+static bool knn_scan_mfma(int D, int Q) {
+  const char* v = getenv("GOCTR_KNN_MFMA");
+  return (v && *v ? *v != '0' : Q >= 48) && knn_scan_tile(D) == 1024;
+}
 static bool knn_scan_usable(const goctr_searcher* s, int k) {
   const char* v = getenv("GOCTR_KNN_SCAN");
   if (v && *v == '0') return false;
@@ -634,7 +705,10 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   int* d_oc = reinterpret_cast<int*>(d_out + o_idx + o_sim);
 #define GOCTR_KNN_SCAN(DD, IPT) hipLaunchKernelGGL((knn_scan_kernel<DD, IPT>), dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, \
                                                   (long long)s->V, d_q32, Q, nt, s->tmax.p, s->c_cnt.p)
-  if (D == 16) GOCTR_KNN_SCAN(16, 4);
+  if (knn_scan_mfma(D, Q)) {
+    if (D == 16) hipLaunchKernelGGL(knn_scan_mfma_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, d_q32, Q, nt, s->tmax.p, s->c_cnt.p);
+    else hipLaunchKernelGGL(knn_scan_mfma_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, d_q32, Q, nt, s->tmax.p, s->c_cnt.p);
+  } else if (D == 16) GOCTR_KNN_SCAN(16, 4);
   else if (D == 32) GOCTR_KNN_SCAN(32, 4);
   else GOCTR_KNN_SCAN(64, 2);
 #undef GOCTR_KNN_SCAN
@@ -665,10 +739,12 @@ int goctr_searcher_create(const double* items, int64_t V, int D, goctr_searcher*
   goctr_searcher* s = new goctr_searcher;
   s->V = V; s->D = D;
   if (s->items.alloc((size_t)V * D, false) || s->items.upload(items, (size_t)V * D) || s->norms.alloc((size_t)V, false) ||
-      (knn_scan_ipt(D) > 0 && s->items32.alloc((size_t)V * D, false))) {
+      (knn_scan_ipt(D) > 0 && s->items32.alloc((size_t)round_up64(V, 2048) * D, false))) {
     delete s;
     return -1;
   }
+  if (s->items32.p)      // (zero rows up to a whole tile: the matrix-core scan kernel reads whole tiles)
+    (void)hipMemsetAsync(s->items32.p + (size_t)V * D, 0, sizeof(float) * (size_t)(round_up64(V, 2048) - V) * D, engine().stream);
   hipLaunchKernelGGL(knn_norm_kernel, dim3((unsigned)cdiv(V, 256)), dim3(256), 0, engine().stream, s->items.p, (long long)V, D,
                      s->norms.p, s->items32.p);
   if (hipGetLastError() != hipSuccess) { set_error("knn_norm_kernel launch failed"); delete s; return -1; }

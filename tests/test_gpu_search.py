@@ -70,12 +70,13 @@ def test_scan_path_query_blocks(oracle, V, D, k, Q):
         ri, rs, _ = oracle.knn_search(items, queries[q], k, ignore=int(ignore[q]))
         assert cnt[q] == ri.size
         assert np.array_equal(idx[q, :cnt[q]], ri) and np.array_equal(sim[q, :cnt[q]], rs)
-    os.environ["GOCTR_KNN_SCAN"] = "0"
-    try:
-        idx0, sim0, cnt0 = s.search_vectors(queries, k, ignore)
-    finally:
-        del os.environ["GOCTR_KNN_SCAN"]
-    assert np.array_equal(idx0, idx) and np.array_equal(sim0, sim) and np.array_equal(cnt0, cnt)
+    for var, val in (("GOCTR_KNN_SCAN", "0"), ("GOCTR_KNN_MFMA", "1"), ("GOCTR_KNN_MFMA", "0")):     # tile kernels; either scan kernel
+        os.environ[var] = val
+        try:
+            idx0, sim0, cnt0 = s.search_vectors(queries, k, ignore)
+        finally:
+            del os.environ[var]
+        assert np.array_equal(idx0, idx) and np.array_equal(sim0, sim) and np.array_equal(cnt0, cnt), (var, val)
 
 
 @pytest.mark.parametrize("V,k,D", [(5000, 3, 8), (5000, 25, 8), (9000, 256, 8), (9000, 25, 16), (40000, 10, 16)])
