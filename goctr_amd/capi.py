@@ -62,7 +62,7 @@ SYMBOLS = [
     "goctr_mlp_nparams", "goctr_mlp_set_params", "goctr_mlp_get_params", "goctr_mlp_loss_grad", "goctr_mlp_fit",
     "goctr_mlp_upload", "goctr_mlp_train_steps", "goctr_mlp_predict", "goctr_w2v_cfg_default", "goctr_w2v_create",
     "goctr_w2v_destroy", "goctr_w2v_set_param", "goctr_w2v_set_aux", "goctr_w2v_get_param", "goctr_w2v_get_aux",
-    "goctr_w2v_get_paths", "goctr_huffman_build", "goctr_w2v_train", "goctr_w2v_upload_doc", "goctr_w2v_train_resident",
+    "goctr_w2v_get_paths", "goctr_huffman_build", "goctr_w2v_train", "goctr_w2v_upload_doc", "goctr_w2v_shard_cuts", "goctr_w2v_train_resident",
     "goctr_w2v_export_f32", "goctr_searcher_create", "goctr_searcher_destroy", "goctr_searcher_search",
     "goctr_ubcache_create", "goctr_ubcache_destroy", "goctr_ubcache_get", "goctr_dataset_create_keys", "goctr_dataset_get_ids",
     "goctr_recsys_create", "goctr_recsys_destroy", "goctr_batch_predict", "goctr_rank",

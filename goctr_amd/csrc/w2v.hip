@@ -1028,6 +1028,19 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
 }  // namespace
 
 // ---- single-call multi-device passes (goctr_w2v_cfg::devices)
+// cut[r] .. cut[r + 1] = rank r's words: slices [r, r + 1) * S / N of IndexPerThread's cut (modelutil.go:32-41) when the slices
+// divide evenly, else an equal contiguous range
+static void w2v_shard_cuts(long long n_words, int S, int N, long long* cut) {
+  cut[0] = 0; cut[N] = n_words;
+  if (S >= N && S % N == 0) {
+    std::vector<long long> sidx((size_t)S + 1, 0);
+    sidx[S] = n_words;
+    for (int i = 1; i < S; ++i) sidx[i] = sidx[i - 1] + (long long)std::trunc((double)((n_words + i) / S));
+    for (int r = 1; r < N; ++r) cut[r] = sidx[(size_t)r * (S / N)];
+  } else {
+    for (int r = 1; r < N; ++r) cut[r] = n_words * r / N;
+  }
+}
 static int w2v_upload_one(goctr_w2v* w, const int32_t* doc, int64_t n_words, const uint8_t* keep_mask) {
   if (w->doc.alloc((size_t)n_words, false) || w->doc.upload(doc, (size_t)n_words)) return -1;
   w->has_keep = keep_mask != nullptr;
@@ -1050,15 +1063,7 @@ static int w2v_multi_shards(goctr_w2v* w, int64_t n_words, Fill fill) {
   // equal contiguous range; inside its shard every rank cuts its own S / N slices
   const int S = w->cfg.slices;
   std::vector<long long> cut((size_t)N + 1, 0);
-  cut[N] = n_words;
-  if (S >= N && S % N == 0) {
-    std::vector<long long> sidx((size_t)S + 1, 0);
-    sidx[S] = n_words;
-    for (int i = 1; i < S; ++i) sidx[i] = sidx[i - 1] + (long long)std::trunc((double)((n_words + i) / S));
-    for (int r = 1; r < N; ++r) cut[r] = sidx[(size_t)r * (S / N)];
-  } else {
-    for (int r = 1; r < N; ++r) cut[r] = n_words * r / N;
-  }
+  w2v_shard_cuts(n_words, S, N, cut.data());
   goctr_w2v_cfg rc = w->cfg;
   rc.devices = 0; rc.slices = S > 0 ? std::max(1, S / N) : 0;
   for (int k = N - 1; k >= 0; --k) {           // (rank 0 last: a device-resident source keeps its prefix)
@@ -1236,6 +1241,14 @@ int goctr_huffman_build(const int64_t* counts, int64_t V, int max_depth, int64_t
   const int64_t n = std::min<int64_t>(cap, (int64_t)nd.size());
   if (nodes && n > 0) memcpy(nodes, nd.data(), sizeof(int32_t) * (size_t)n);
   if (codes && n > 0) memcpy(codes, cd.data(), (size_t)n);
+  return 0;
+}
+
+int goctr_w2v_shard_cuts(int64_t n_words, int slices, int devices, int64_t* cuts) {
+  GOCTR_CHECK(cuts && devices >= 1 && n_words >= devices && slices >= 0, "goctr_w2v_shard_cuts: bad arguments");
+  std::vector<long long> c((size_t)devices + 1);
+  w2v_shard_cuts(n_words, slices, devices, c.data());
+  for (int r = 0; r <= devices; ++r) cuts[r] = c[(size_t)r];
   return 0;
 }
 

@@ -367,6 +367,9 @@ int goctr_huffman_build(const int64_t* counts, int64_t V, int max_depth, int64_t
  * (subsample.go:45-52) or NULL; corpus_len = unfiltered corpus length (Q17).  lr in/out. */
 int goctr_w2v_train(goctr_w2v* w, const int32_t* doc, int64_t n_words, int64_t corpus_len,
                     const uint8_t* keep_mask, double* lr);
+/* Host-only helper (no device needed): the word ranges a pass with goctr_w2v_cfg.devices = `devices` gives its ranks --
+ * cuts[r] .. cuts[r + 1], r < devices; `slices` as in goctr_w2v_cfg (the reference's IndexPerThread, modelutil.go:32-41). */
+int goctr_w2v_shard_cuts(int64_t n_words, int slices, int devices, int64_t* cuts);
 /* same over a doc already resident in HBM (bench unit): upload once, then train passes */
 int goctr_w2v_upload_doc(goctr_w2v* w, const int32_t* doc, int64_t n_words, const uint8_t* keep_mask);
 int goctr_w2v_train_resident(goctr_w2v* w, int64_t corpus_len, double* lr);
