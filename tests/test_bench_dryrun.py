@@ -87,6 +87,11 @@ def test_bench_gpus8_runs_end_to_end_against_the_stub(stub):
     assert abs(d["ms_per_step"] - max(per)) <= 0.02 * max(per) + 1e-3    # the line carries the max over ranks
     assert d["config"]["global_batch"] == 8 * 8192 and d["config"]["parallelism"] == "dp8"
     assert d["value"] == pytest.approx(8 * 8192 / (d["ms_per_step"] * 1e-3), rel=0.02)
+    # the headline is the MEDIAN of 9 back-to-back regions of exactly K steps; all of them are on the line
+    reg = d["timed_regions_ms"]
+    assert d["timed_regions"] == 9 and len(reg) == 9 and all(x > 0 for x in reg)
+    assert d["ms_per_step"] * d["steps"] == pytest.approx(sorted(reg)[4], rel=1e-3)
+    assert d["timed_region_min_ms"] == min(reg) and d["timed_region_max_ms"] == max(reg)
     assert "cpu_baseline" not in d                         # rank 0 at N = 1 only
     assert d["roofline"]["kernel"] in ("chain", "dW0", "attn_fwd", "attn_bwd", "reduce")
     assert d["replicas_bit_identical"] is True            # (every rank checksums its weights; the stub leaves them zero)
