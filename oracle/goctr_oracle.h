@@ -181,6 +181,11 @@ void orc_mlp_predict(const orc_mlp_cfg* cfg, const double* theta, const double* 
 /* backprop (basemlp64.go:340-406): loss + packed grads for one batch of n rows. */
 double orc_mlp_loss_grad(const orc_mlp_cfg* cfg, double* theta, const double* X, const double* Y,
                          int n, double* grads);
+/* the same on the caller's activation / delta blocks of B rows each (acts[1..L-1], deltas[0..L-2]; acts[0] unused) for a
+ * batch of ns <= B rows: ns < B is the reference's SHORT LAST BATCH (quirk Q11, basemlp64.go:790-812) -- rows [ns, B) of
+ * acts[1] and deltas[last] are what the previous call left there and take part in the bias / upper-layer gradients. */
+double orc_mlp_loss_grad_rows(const orc_mlp_cfg* cfg, double* theta, const double* X, const double* Y, int ns, int B,
+                              double* const* acts, double* const* deltas, double* grads);
 /* AdamOptimizer64.updateParams (basemlp64.go:1075-1091, per-parameter beta powers) /
  * SGDOptimizer64.updateParams (:1024-1039). */
 void orc_mlp_opt_init(orc_mlp_opt* o, int solver, size_t nparams);
@@ -188,7 +193,7 @@ void orc_mlp_opt_free(orc_mlp_opt* o);
 void orc_mlp_update(orc_mlp_opt* o, double* theta, const double* grads, size_t nparams);
 /* fitStochastic (basemlp64.go:729-857) with a GIVEN batch order: X,Y are used in the given row
  * order each epoch (shuffle is the caller's job: perm [max_iter][n] or NULL for identity),
- * n must be a multiple of batch (Q11 avoided).  loss_curve [max_iter]. tol/no-improve stopping
+ * a short last batch (n % batch != 0) is trained the reference's way (Q11, stale rows).  loss_curve [max_iter]. tol/no-improve stopping
  * (basemlp64.go:859-895) with constant learning-rate schedule.  returns iterations run. */
 int orc_mlp_fit(const orc_mlp_cfg* cfg, double* theta, orc_mlp_opt* opt,
                 const double* X, const double* Y, int64_t n, int batch, int max_iter,

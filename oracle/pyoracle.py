@@ -475,6 +475,36 @@ def mlp_loss_grad(cfg, theta, X, Y):
     return float(loss), g
 
 
+def mlp_blocks(cfg, B):
+    """the activation / delta blocks fit allocates once per call (basemlp64.go:529-545): B rows per layer, zero-filled"""
+    L = cfg.n_layers
+    acts = [None] + [np.zeros((B, cfg.units[i]), np.float64) for i in range(1, L)]
+    deltas = [np.zeros((B, cfg.units[i]), np.float64) for i in range(1, L)]
+    return acts, deltas
+
+
+def mlp_loss_grad_rows(cfg, theta, X, Y, B, acts, deltas):
+    """backprop on the caller's blocks for a batch of ns = len(X) <= B rows; ns < B is the reference's short last batch
+    (quirk Q11): rows [ns, B) of acts[1] / deltas[-1] are whatever the previous call left there"""
+    X = np.ascontiguousarray(X, np.float64)
+    Y = np.ascontiguousarray(Y, np.float64)
+    assert theta.dtype == np.float64 and theta.flags.c_contiguous
+    L = cfg.n_layers
+    pa = (C.POINTER(C.c_double) * 8)()
+    pd = (C.POINTER(C.c_double) * 8)()
+    for i in range(1, L):
+        assert acts[i].shape == (B, cfg.units[i]) and acts[i].flags.c_contiguous and acts[i].dtype == np.float64
+        assert deltas[i - 1].shape == (B, cfg.units[i]) and deltas[i - 1].flags.c_contiguous
+        pa[i] = _p(acts[i], C.c_double)
+        pd[i - 1] = _p(deltas[i - 1], C.c_double)
+    g = np.zeros_like(theta)
+    f = lib().orc_mlp_loss_grad_rows
+    f.restype = C.c_double
+    loss = f(C.byref(cfg), _p(theta, C.c_double), _p(X, C.c_double), _p(Y, C.c_double), C.c_int(X.shape[0]), C.c_int(B),
+             pa, pd, _p(g, C.c_double))
+    return float(loss), g
+
+
 class MlpOptimizer:
     def __init__(self, solver, nparams, lr_init=0.001):
         self.o = MlpOpt()
