@@ -45,7 +45,7 @@ class W2vCfg(C.Structure):
     _fields_ = [("dim", C.c_int), ("window", C.c_int), ("optimizer", C.c_int), ("model", C.c_int),
                 ("neg_samples", C.c_int), ("init_lr", C.c_double), ("min_lr", C.c_double),
                 ("update_lr_batch", C.c_int64), ("max_depth", C.c_int), ("deterministic", C.c_int),
-                ("streams", C.c_int), ("slices", C.c_int), ("devices", C.c_int)]
+                ("streams", C.c_int), ("slices", C.c_int), ("devices", C.c_int), ("exchange_every", C.c_int64)]
 
 
 # every symbol include/goctr.h declares (tests/test_capi_symbols.py checks the list against the header)

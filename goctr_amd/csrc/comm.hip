@@ -276,19 +276,36 @@ __global__ void capture_test_cmp_kernel(const float* a, const float* b, int n, f
 // call of a goctr_init_devices group).  Two rounds of [fill | all-reduce] as a replayed graph against the same eagerly; the mismatch counts (and a
 // failed capture, counted as one) are summed over the ranks with an EAGER all-reduce, so all ranks reach the same verdict.
 // Waits go through comm_watch_stream: a replay that never completes fails the call on a timeout instead of hanging it.
+// Returns 1 = captured collectives work, 0 = they do not (the communicator is healthy: the collective stays between graph
+// launches), -1 = the COMMUNICATOR was lost while probing (a wait timed out or RCCL reported an error, so comm_watch_stream
+// aborted it; or this rank could not take part at all) -- the error text is set and the caller must fail its call: a rank that
+// carried on without a communicator would train alone on its shard, silently.  Every path either takes part in
+// all of the probe's collectives or aborts the communicator, so that no rank is left inside a collective its peers skipped.
 int comm_capture_selftest() {
   Engine& e = engine();
   if (e.capture_state != 0) return e.capture_state == 1 ? 1 : 0;
   if (!comm_capturable()) { e.capture_state = -1; return 0; }
   const int n = 4096;
+  const int wait_s = std::max(1, env_int_comm("GOCTR_CAPTURE_TEST_TIMEOUT_S", 30));
+  auto lost = [&](const char* what) {
+    // (comm_watch_stream has already aborted on a timeout / asynchronous error; abort here for the synchronous failures, which
+    // would otherwise leave the peers waiting inside the next collective of the probe)
+    std::string why = goctr_last_error() ? goctr_last_error() : "";
+    comm_abort_on_failure();
+    e.capture_state = -1;
+    set_error("captured-collective self-test: %s%s%s -- the communicator was aborted; this rank cannot continue the job", what,
+              why.empty() ? "" : ": ", why.c_str());
+    return -1;
+  };
   DevBuf<float> cap, eag, bad;
-  if (cap.alloc(n, false) || eag.alloc(n, false) || bad.alloc(1)) { e.capture_state = -1; return 0; }
+  if (cap.alloc(n, false) || eag.alloc(n, false) || bad.alloc(1)) return lost("device allocation failed");
   hipStream_t s = e.stream;
   // one EAGER collective first: a communicator sets up its connections (buffers, IPC handles, proxy threads) inside its first
   // collective, and none of that may happen inside a stream capture
   hipLaunchKernelGGL(capture_test_fill_kernel, dim3(n / 256), dim3(256), 0, s, eag.p, n, e.rank, 7);
-  if (g_rccl.AllReduce(eag.p, eag.p, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s) != ncclSuccess ||
-      comm_watch_stream(std::max(1, env_int_comm("GOCTR_CAPTURE_TEST_TIMEOUT_S", 30)))) { e.capture_state = -1; return 0; }
+  if (g_rccl.AllReduce(eag.p, eag.p, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s) != ncclSuccess)
+    return lost("the first all-reduce could not be enqueued");
+  if (comm_watch_stream(wait_s)) return lost("the first all-reduce did not complete");
   hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
   bool captured = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
   if (captured) {
@@ -298,25 +315,28 @@ int comm_capture_selftest() {
   }
   (void)hipGetLastError();
   float local_bad = captured ? 0.f : 1.f;
-  int rc = 0;
-  for (int round = 0; round < 2 && !rc; ++round) {
+  const char* fail = nullptr;
+  for (int round = 0; round < 2 && !fail; ++round) {
     hipLaunchKernelGGL(capture_test_fill_kernel, dim3(n / 256), dim3(256), 0, s, cap.p, n, e.rank, round);
     hipLaunchKernelGGL(capture_test_fill_kernel, dim3(n / 256), dim3(256), 0, s, eag.p, n, e.rank, round);
     if (captured && hipGraphLaunch(ge, s) != hipSuccess) { captured = false; local_bad = 1.f; (void)hipGetLastError(); }
-    if (g_rccl.AllReduce(eag.p, eag.p, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s) != ncclSuccess) rc = -1;
-    if (!rc && captured) hipLaunchKernelGGL(capture_test_cmp_kernel, dim3(n / 256), dim3(256), 0, s, cap.p, eag.p, n, bad.p);
+    if (g_rccl.AllReduce(eag.p, eag.p, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s) != ncclSuccess) fail = "an eager all-reduce could not be enqueued";
+    if (!fail && captured) hipLaunchKernelGGL(capture_test_cmp_kernel, dim3(n / 256), dim3(256), 0, s, cap.p, eag.p, n, bad.p);
   }
-  if (!rc && local_bad != 0.f) rc = hipMemcpyAsync(bad.p, &local_bad, sizeof(float), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1;
-  if (!rc && g_rccl.AllReduce(bad.p, bad.p, 1, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s) != ncclSuccess) rc = -1;
+  if (!fail && local_bad != 0.f && hipMemcpyAsync(bad.p, &local_bad, sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) fail = "host-to-device copy failed";
+  if (!fail && g_rccl.AllReduce(bad.p, bad.p, 1, ncclFloat32, ncclSum, (ncclComm_t)e.nccl_comm, s) != ncclSuccess) fail = "the verdict all-reduce could not be enqueued";
   float total_bad = 1.f;
-  if (!rc) rc = comm_watch_stream(std::max(1, env_int_comm("GOCTR_CAPTURE_TEST_TIMEOUT_S", 30)));     // (a replay that never completes: fail fast)
-  if (!rc) rc = bad.download(&total_bad, 1);
+  // (a replay that never completes: the watchdog aborts the communicator -- the stream behind a hung collective cannot be
+  // used again, so this IS fatal for the rank, and said so)
+  if (!fail && comm_watch_stream(wait_s)) fail = "a replayed or eager collective of the probe did not complete";
+  if (!fail && bad.download(&total_bad, 1)) fail = "device-to-host copy failed";
   if (ge) (void)hipGraphExecDestroy(ge);
   if (g) (void)hipGraphDestroy(g);
-  e.capture_state = (!rc && total_bad == 0.f) ? 1 : -1;
+  if (fail) return lost(fail);
+  e.capture_state = total_bad == 0.f ? 1 : -1;
   if (e.capture_state != 1 && e.rank == 0)
-    fprintf(stderr, "goctr: captured RCCL all-reduce failed its self-test (%s): the data-parallel step keeps the collective between graph launches\n",
-            rc ? "error" : "results differ from the eager collective");
+    fprintf(stderr, "goctr: captured RCCL all-reduce failed its self-test (results differ from the eager collective, or the capture "
+                    "failed on a rank): the data-parallel step keeps the collective between graph launches\n");
   return e.capture_state == 1 ? 1 : 0;
 }
 
@@ -460,7 +480,8 @@ int goctr_comm_init(int rank, int world, const uint8_t id[128]) {
   e.nccl_comm = c;
   e.capture_state = 0;
   // may the data-parallel step graphs hold the all-reduce?  Decided HERE, where every rank is (comm_capture_selftest is a collective)
-  if (env_int_comm("GOCTR_DP_CAPTURE_COMM", 1) == 1) (void)comm_capture_selftest();
+  if (env_int_comm("GOCTR_DP_CAPTURE_COMM", 1) == 1 && comm_capture_selftest() < 0) return -1;   // (communicator lost: say so)
+  GOCTR_CHECK(e.nccl_comm, "goctr_comm_init: the communicator did not survive its first collectives");
   return 0;
 }
 

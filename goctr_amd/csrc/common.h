@@ -107,6 +107,7 @@ int require_engine();  // 0 if the calling thread's engine is bound to a device,
 // thread's HIP device is e's device (hipSetDevice is per host thread).
 struct EngineScope {
   Engine* prev;
+  int prev_device = -1;       // the thread's HIP device before the scope switched it (restored by the destructor)
   explicit EngineScope(Engine* e);
   ~EngineScope();
 };
@@ -221,9 +222,12 @@ inline int capture_graph(hipStream_t s, hipGraphExec_t* exec, Body body, Restore
       continue;
     }
     if (rc) { if (g) (void)hipGraphDestroy(g); return -1; }
-    GOCTR_HIP(ce);
+    if (ce != hipSuccess || ie != hipSuccess) {      // the last retry failed too: drop the graph before reporting
+      if (g) (void)hipGraphDestroy(g);
+      GOCTR_HIP(ce);
+      GOCTR_HIP(ie);
+    }
     GOCTR_CHECK(g, "stream capture produced no graph");
-    GOCTR_HIP(ie);
     (void)hipGraphUpload(*exec, s);
     (void)hipGraphDestroy(g);
     return 0;

@@ -2618,7 +2618,9 @@ int train_multi(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_tr
     Engine& e = engine();
     std::lock_guard<std::recursive_mutex> elk(e.mu);
     CommCallScope comm_on(e);
-    if (comm_capturable() && env_int("GOCTR_DP_CAPTURE_COMM", 1) == 1) (void)comm_capture_selftest();   // (once per communicator; every rank is here)
+    // (once per communicator; every rank is here.  < 0: the probe lost the communicator -- fail the call on this rank, the
+    // others see the abort in their next wait)
+    if (comm_capturable() && env_int("GOCTR_DP_CAPTURE_COMM", 1) == 1 && comm_capture_selftest() < 0) return -1;
     goctr_model* mk = k == 0 ? m : m->reps[k];
     goctr_emb* ek = !emb ? nullptr : (k == 0 ? emb : emb->reps[k]);
     goctr_dataset* dk = d->shards[k];

@@ -60,10 +60,19 @@ EngineScope::EngineScope(Engine* e) : prev(t_scope) {
   Engine& cur = engine();
   if (cur.inited) {     // hipSetDevice is per host thread: any thread may call any entry point on any handle
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev != cur.device) (void)hipSetDevice(cur.device);
+    if (hipGetDevice(&dev) != hipSuccess || dev != cur.device) {
+      if (dev >= 0) prev_device = dev;
+      (void)hipSetDevice(cur.device);
+    }
   }
 }
-EngineScope::~EngineScope() { t_scope = prev; }
+// the thread's HIP device goes back with the engine: after `for k: EngineScope on(engine k)` the thread would otherwise stay on
+// the last device while engine() is engine 0 again, and a first-touch arena / fallback hipMalloc for an engine-0 buffer would
+// land on the wrong GPU
+EngineScope::~EngineScope() {
+  t_scope = prev;
+  if (prev_device >= 0) (void)hipSetDevice(prev_device);
+}
 
 // the calling thread's target stream (null = the engine's main stream)
 static thread_local hipStream_t t_active = nullptr;
@@ -317,6 +326,7 @@ int goctr_init_devices(int n, const int* device_ids) {
   for (int k = 0; k < n; ++k)
     GOCTR_CHECK(device_ids[k] >= 0 && device_ids[k] < have, "goctr_init_devices: device %d out of range (have %d)", device_ids[k], have);
   static std::mutex mu;
+  static bool group_ready = false;   // engines bound AND the group's communicator built: only then is a repeat a no-op
   std::lock_guard<std::mutex> once(mu);
   const int existing = g_nengines.load();
   if (existing > 1 || (existing == 1 && (engine_at(0)->nccl_comm || engine_at(0)->loop))) {
@@ -324,6 +334,11 @@ int goctr_init_devices(int n, const int* device_ids) {
     bool same = existing == n;
     for (int k = 0; same && k < n; ++k) same = engine_at(k)->inited && engine_at(k)->device == device_ids[k];
     GOCTR_CHECK(same, "goctr_init_devices: the process already runs %d engine(s); the device list cannot change", existing);
+    if (group_ready) return 0;
+    // an earlier call bound the engines and then failed to build the communicator (RCCL would not load, peer access refused):
+    // try again instead of reporting success without one
+    if (comm_group_init(n)) return -1;
+    group_ready = true;
     return 0;
   }
   for (int k = 0; k < n; ++k) {
@@ -334,7 +349,9 @@ int goctr_init_devices(int n, const int* device_ids) {
     if (engine_bind(*e, device_ids[k])) return -1;
     e->rank = k; e->world = n;
   }
-  return comm_group_init(n);
+  if (comm_group_init(n)) return -1;
+  group_ready = true;
+  return 0;
 }
 
 int goctr_engine_count(int* n) {

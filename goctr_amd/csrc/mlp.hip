@@ -76,12 +76,19 @@ struct EpiMlpDAct {
 __global__ __launch_bounds__(256) void mlp_gather_kernel(const float* X, const float* Y, const int* perm,
                                                          const MlpState* st, long long start_fixed, int use_state,
                                                          int batch, int F, int up0, int no, int upL, double* A0,
-                                                         double* Yb, MlpState* st_step) {
+                                                         double* Yb, MlpState* st_step, int valid) {
   const int r = blockIdx.x;
   // first kernel of a step: freeze the step's state; the last kernel advances the master copy in place while every
   // other kernel of the step reads the frozen one (no inter-workgroup ordering needed)
   if (st_step && r == 0 && threadIdx.x == 0) *st_step = *st;
   const long long start = use_state ? st->batch_idx * (long long)batch : start_fixed;
+  if (r >= valid) {
+    // short last batch (quirk Q11): the reference's activations[0] has only `valid` rows.  Rows beyond them are [0 .. 0 | 1]
+    // here, so that the weight-gradient product over all `batch` rows adds nothing to the coefficient rows and the ones
+    // column collects the bias row over all of deltas[0]'s rows (matRowMean64 runs over deltas.Rows = batch)
+    for (int j = threadIdx.x; j < up0; j += 256) A0[(size_t)r * up0 + j] = j == F ? 1.0 : 0.0;
+    return;
+  }
   const long long src = perm ? perm[start + r] : start + r;
   for (int j = threadIdx.x; j < up0; j += 256)
     A0[(size_t)r * up0 + j] = j < F ? (double)X[src * F + j] : (j == F ? 1.0 : 0.0);
@@ -101,10 +108,14 @@ __global__ __launch_bounds__(256) void mlp_copy_f64_kernel(const double* X, cons
 
 // delta_last = h - y and the binary log-loss terms (basemlp64.go:180-195,373-381); one block per row group
 __global__ __launch_bounds__(256) void mlp_delta_last_kernel(const double* H, const double* Yb, int n, int no, int upL,
-                                                             double* delta, double* lossterm) {
+                                                             double* delta, double* lossterm, int valid) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= n * upL) return;
   const int c = idx % upL;
+  if (idx / upL >= valid) {        // short last batch (Q11): y has `valid` rows -- the other rows of deltas[last] keep the
+    lossterm[idx] = 0;             // previous batch's values (basemlp64.go:373-381 loops y.Rows) and carry no loss term
+    return;
+  }
   double d = 0, l = 0;
   if (c < no) {
     const double h = H[idx], y = Yb[idx];
@@ -131,6 +142,17 @@ __global__ __launch_bounds__(256) void mlp_bn_kernel(double* A, int n, int ld, i
   if (M > 0) for (int r = threadIdx.x; r < n; r += 256) A[(size_t)r * ld + o] /= M;
 }
 
+// short last batch (quirk Q11, basemlp64.go:790-802): rows [valid, n) of activations[1] were not overwritten by the first
+// product (its A operand has `valid` rows), but addIntercepts64 and the activation loop run over activations[1].Rows = n
+// rows: a stale row becomes act(stale + b_0).  brow = row units_0 of the augmented first weight block (the intercepts).
+__global__ __launch_bounds__(256) void mlp_stale_rows_kernel(double* A1, int ld, int ncols, int kind, const double* brow,
+                                                             int valid, int n) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int r = valid + idx / ncols, c = idx % ncols;
+  if (r >= n) return;
+  A1[(size_t)r * ld + c] = act_fwd(kind, A1[(size_t)r * ld + c] + brow[c]);
+}
+
 // element (k, n) of the first weight block inside its LDS image [n/32][k/4][(k%4)/2][32][k%2] (mlp_fwd_kernel):
 // the two doubles a lane feeds to 2 consecutive MFMAs are one 16-byte read and the 16 lanes of a q-group read 256
 // contiguous bytes (a [..][32][4] layout made every ds_read_b128 a 2-way bank conflict)
@@ -154,6 +176,9 @@ struct MlpReduceArgs {
   long long nparams;          // packed parameter count (reference n)
   double* W; double* G; double* Mo; double* Vo; double* Vel;
   double alpha; int n;        // rows in the batch
+  int n_bias, n_loss;         // short last batch (Q11): the intercept means and the log-loss mean divide by the BLOCKS' row
+                              // count (matRowMean64 over deltas.Rows, `sum / float64(h.Rows)`), the coefficient blocks and
+                              // the penalty by the batch's rows n; 0 = n
   // optimizer
   int solver; int do_update;
   double lr_init, beta1, beta2, eps, momentum; int nesterov;
@@ -209,7 +234,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) {
-      a.ring[a.st->slot % MLP_LOSS_RING] = lsum / (double)a.n + (0.5 * a.alpha) * red[0] / (double)a.n;
+      a.ring[a.st->slot % MLP_LOSS_RING] = lsum / (double)(a.n_loss ? a.n_loss : a.n) + (0.5 * a.alpha) * red[0] / (double)a.n;
       if (a.advance) {
         MlpState ns = *a.st;
         ns.slot += 1;
@@ -300,7 +325,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
       if (a.mode == 1) {
         g = a.G[idx];                                         // summed over the ranks by the all-reduce
       } else {
-        g = s * (1 / (double)a.n);                            // gemm alpha = 1/n (and mean for the bias row)
+        g = s * (1 / (double)(is_b && a.n_bias ? a.n_bias : a.n));   // gemm alpha = 1/n (and mean for the bias row)
         if (is_w) g += (a.alpha / (double)a.n) * w / (double)a.world;   // every rank adds its share of the penalty term
         a.G[idx] = g;
       }
@@ -1113,9 +1138,13 @@ int ensure_ws(goctr_mlp* p, int n) {
   return 0;
 }
 
-// forward over A[0] (already filled) for n rows; bn applied afterwards like the reference
-int forward(goctr_mlp* p, int n, bool train) {
-  if (p->fused_ok() && p->W0img.p && env_int_mlp("GOCTR_MLP_NO_FUSED", 0) == 0) {
+// forward over A[0] (already filled) for n rows; bn applied afterwards like the reference.  `generic`: the per-layer GEMMs
+// (every block materialised in the workspace).  valid < n: the reference's short last batch (Q11) -- the first product
+// covers `valid` rows, the other rows of A[1] are the previous step's, re-biased and re-activated; the layers above and
+// the max-abs normalisation run over all n rows (forward_rows in oracle/orc_sklmlp.c spells out the row counts).
+int forward(goctr_mlp* p, int n, bool train, bool generic = false, int valid = -1) {
+  if (valid < 0) valid = n;
+  if (!generic && valid == n && p->fused_ok() && p->W0img.p && env_int_mlp("GOCTR_MLP_NO_FUSED", 0) == 0) {
     const int up0 = p->up[0], up1 = p->up[1], upL = p->up[2];
     const int ng = (int)cdiv(up1, 32);
     if (p->zpart.ensure((size_t)ng * n, false)) return -1;
@@ -1142,8 +1171,16 @@ int forward(goctr_mlp* p, int n, bool train) {
   p->fused_fwd_done = false;
   for (int l = 0; l < p->nl; ++l) {
     const bool last = l == p->nl - 1;
-    EpiMlpAct e{p->A[l + 1].p, p->up[l + 1], p->units[l + 1], last ? GOCTR_ACT_LOGISTIC : p->cfg.activation};
-    if (launch_nn64(p->A[l].p, p->up[l], p->W.p + p->woff[l], p->up[l + 1], n, p->up[l], p->up[l + 1], e)) return -1;
+    const int kind = last ? GOCTR_ACT_LOGISTIC : p->cfg.activation;
+    EpiMlpAct e{p->A[l + 1].p, p->up[l + 1], p->units[l + 1], kind};
+    const int m = l == 0 ? valid : n;           // activations[l].Rows
+    if (launch_nn64(p->A[l].p, p->up[l], p->W.p + p->woff[l], p->up[l + 1], m, p->up[l], p->up[l + 1], e)) return -1;
+    if (m < n) {
+      hipLaunchKernelGGL(mlp_stale_rows_kernel, dim3((unsigned)cdiv((int64_t)(n - m) * p->units[1], 256)), dim3(256), 0,
+                         engine().stream, p->A[1].p, p->up[1], p->units[1], kind,
+                         p->W.p + p->woff[0] + (long long)p->units[0] * p->up[1], m, n);
+      GOCTR_HIP(hipGetLastError());
+    }
   }
   if (train && p->cfg.batch_normalize) {
     for (int l = 0; l < p->nl - 1; ++l) {
@@ -1155,8 +1192,11 @@ int forward(goctr_mlp* p, int n, bool train) {
   return 0;
 }
 
-// backprop + optional update for the n rows in A[0]/Yb
-int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
+// backprop + optional update for the n rows in A[0]/Yb.  valid < n: short last batch (Q11) -- every product runs over the
+// blocks' n rows (A[0]'s rows beyond `valid` are [0 | 1], mlp_gather_kernel), the coefficient blocks and the penalty divide
+// by `valid`, the intercept means and the loss mean by n.
+int backward(goctr_mlp* p, int n, bool do_update, bool advance, int valid = -1) {
+  if (valid < 0) valid = n;
   Engine& e = engine();
   const int L = p->nl;
   if (p->cfg.weight_decay > 0) {  // basemlp64.go:342-346 (applied before the forward pass by the caller order)
@@ -1166,7 +1206,7 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   p->chain_done = false;
   if (!p->fused_fwd_done && !chain)
   hipLaunchKernelGGL(mlp_delta_last_kernel, dim3((unsigned)cdiv((int64_t)n * upL, 256)), dim3(256), 0, e.stream,
-                     p->A[L].p, p->Yb.p, n, no, upL, p->D[L].p, p->lossterm.p);
+                     p->A[L].p, p->Yb.p, n, no, upL, p->D[L].p, p->lossterm.p, valid);
   GOCTR_HIP(hipGetLastError());
   const bool fused_bwd = chain || (p->fused_fwd_done && up1_le128(p));
   if (fused_bwd && !chain) {
@@ -1194,7 +1234,8 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   if (chain) { a.L[1].nslabs = (int)cdiv(n, 16); a.L[1].coop = env_int_mlp("GOCTR_MLP_COOP", 1); }
   a.nflat = p->nflat; a.nparams = p->nparams;
   a.W = p->W.p; a.G = p->G.p; a.Mo = p->Mo.p; a.Vo = p->Vo.p; a.Vel = p->Vel.p;
-  a.alpha = p->cfg.alpha; a.n = n; a.solver = p->cfg.solver; a.do_update = do_update ? 1 : 0;
+  a.alpha = p->cfg.alpha; a.n = valid; a.solver = p->cfg.solver; a.do_update = do_update ? 1 : 0;
+  if (valid < n) { a.n_bias = n; a.n_loss = n; }
   a.lr_init = p->cfg.lr_init; a.beta1 = p->cfg.beta1; a.beta2 = p->cfg.beta2; a.eps = p->cfg.eps;
   {
     auto skip = [](double beta) { return (beta > 0.0 && beta < 1.0) ? 55.0 * 0.6931471805599453 / -std::log(beta) : 1e300; };
@@ -1209,6 +1250,7 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance) {
   if (e.comm_active() && do_update) {
     // data-parallel step: rows sharded over the ranks (each rank's resident rows are its shard), local slab sums with the
     // GLOBAL batch size in the 1/n factors, ONE f64 all-reduce of [G | loss-term sum], then the identical update everywhere
+    GOCTR_CHECK(valid == n, "the data-parallel MLP step takes whole batches only");
     a.world = e.eff_world(); a.n = n * e.eff_world();
     a.mode = 3; a.do_update = 0;
     hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk + 1), dim3(256), 0, e.stream, a);
@@ -1280,11 +1322,17 @@ int get_mstate(goctr_mlp* p, MlpState* s) {
   return 0;
 }
 
-// one optimisation step over resident rows [state.batch_idx*batch, +batch) (or a fixed start)
-int train_step_resident(goctr_mlp* p, bool use_state, long long start) {
+// one optimisation step over resident rows [state.batch_idx*batch, +batch) (or a fixed start).
+// valid = B: a whole batch; `generic` runs it on the per-layer kernels, which leave every activation / delta block in the
+// workspace (the fused chain keeps A[1] in registers).  valid < B: the reference's SHORT LAST BATCH (quirk Q11,
+// basemlp64.go:790-812) -- it must follow a `generic` step, whose A[1] and D[L] rows [valid, B) it inherits exactly like
+// the reference's blocks inherit the previous batch's.
+int train_step_resident(goctr_mlp* p, bool use_state, long long start, bool generic = false, int valid = -1) {
   const int B = p->cfg.batch, L = p->nl;
+  if (valid < 0) valid = B;
+  if (valid < B) generic = true;
   if (weight_decay(p)) return -1;
-  if (p->chain_ok() && p->W0img.p && env_int_mlp("GOCTR_MLP_CHAIN", 1) != 0 && env_int_mlp("GOCTR_MLP_NO_FUSED", 0) == 0) {
+  if (!generic && p->chain_ok() && p->W0img.p && env_int_mlp("GOCTR_MLP_CHAIN", 1) != 0 && env_int_mlp("GOCTR_MLP_NO_FUSED", 0) == 0) {
     MlpChainArgs c{};
     c.X = p->Xr.p; c.Y = p->Yr.p; c.perm = p->perm.n > 1 ? p->perm.p : nullptr;
     c.st = p->st.p; c.st_step = p->st_step.p; c.start_fixed = start; c.use_state = use_state ? 1 : 0; c.batch = B;
@@ -1330,10 +1378,10 @@ int train_step_resident(goctr_mlp* p, bool use_state, long long start) {
   }
   hipLaunchKernelGGL(mlp_gather_kernel, dim3(B), dim3(256), 0, engine().stream, p->Xr.p, p->Yr.p,
                      p->perm.n > 1 ? p->perm.p : nullptr, p->st.p, start, use_state ? 1 : 0, B, p->units[0], p->up[0],
-                     p->units[L], p->up[L], p->A[0].p, p->Yb.p, p->st_step.p);
+                     p->units[L], p->up[L], p->A[0].p, p->Yb.p, p->st_step.p, valid);
   GOCTR_HIP(hipGetLastError());
-  if (forward(p, B, true)) return -1;
-  return backward(p, B, true, true);
+  if (forward(p, B, true, generic, valid)) return -1;
+  return backward(p, B, true, true, valid);
 }
 
 }  // namespace
@@ -1529,12 +1577,21 @@ int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, co
                   int* iters_run) {
   GOCTR_ENTER_H(p);
   GOCTR_CHECK(p && X && Y && rows > 0, "goctr_mlp_fit: bad arguments");
-  GOCTR_CHECK(rows % p->cfg.batch == 0, "goctr_mlp_fit: rows (%lld) must be a multiple of batch (%d) -- the reference "
-              "leaves stale rows in a short last batch (basemlp64.go:800-802)", (long long)rows, p->cfg.batch);
+  GOCTR_CHECK(rows >= p->cfg.batch, "goctr_mlp_fit: fewer rows (%lld) than one batch (%d) -- the reference clips BatchSize to the "
+              "sample count (basemlp64.go:517-520): create the handle with batch = rows", (long long)rows, p->cfg.batch);
   if (goctr_mlp_upload(p, X, Y, rows)) return -1;
   std::lock_guard<std::mutex> lk(p->mu);
-  const long long nb = rows / p->cfg.batch;
+  // fitStochastic's batch loop (basemlp64.go:790-793): whole batches, then ONE short batch of rows % batch samples when the
+  // sample count is not a multiple -- the reference's own flagship run has one (main.go:39-50: 79 948 rows at 200).  It is
+  // trained the reference's way (quirk Q11): the step before it runs on the per-layer kernels so that its hidden block and
+  // output deltas are in the workspace for the short step to inherit.
+  const int B = p->cfg.batch;
+  const long long nfull = rows / B;
+  const int tail = (int)(rows - nfull * B);
+  const long long nb = nfull + (tail ? 1 : 0);
   GOCTR_CHECK(nb <= MLP_LOSS_RING, "too many batches per epoch for the loss ring");
+  GOCTR_CHECK(!(tail && engine().comm_active()), "goctr_mlp_fit: a short last batch is not supported on a data-parallel "
+              "communicator (rows %lld, batch %d)", (long long)rows, B);
   if (perm && p->perm.alloc((size_t)rows, false)) return -1;
   MlpState s;
   if (get_mstate(p, &s)) return -1;
@@ -1544,13 +1601,14 @@ int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, co
   for (it = 0; it < p->cfg.max_iter; ++it) {
     if (perm && p->perm.upload(reinterpret_cast<const int*>(perm) + (int64_t)it * rows, (size_t)rows)) return -1;
     if (set_mstate(p, s.t + (long long)it * nb, 0, nb, 0)) return -1;
-    for (long long b = 0; b < nb; ++b)
-      if (train_step_resident(p, true, 0)) return -1;
+    for (long long b = 0; b < nfull; ++b)
+      if (train_step_resident(p, true, 0, tail && b == nfull - 1)) return -1;
+    if (tail && train_step_resident(p, true, 0, true, tail)) return -1;
     GOCTR_HIP(hipStreamSynchronize(engine().stream));
     if (p->ring.download(bl.data(), (size_t)nb)) return -1;
     double acc = 0;
-    for (long long b = 0; b < nb; ++b) acc += bl[b] * (double)p->cfg.batch;  // basemlp64.go:806
-    const double loss = acc / (double)rows;
+    for (long long b = 0; b < nb; ++b) acc += bl[b] * (double)(b < nfull ? B : tail);  // basemlp64.go:806
+    const double loss = acc / (double)rows;                                           // :812
     if (loss_curve) loss_curve[it] = loss;
     if (loss > best - p->cfg.tol) no_improve++; else no_improve = 0;  // updateNoImprovementCount :859-895
     if (loss < best) best = loss;
@@ -1576,7 +1634,7 @@ int goctr_mlp_predict(goctr_mlp* p, const float* X, int64_t rows, float* y_out) 
     if (dX.upload(X + s0 * F, (size_t)n * F)) return -1;
     hipLaunchKernelGGL(mlp_gather_kernel, dim3(n), dim3(256), 0, engine().stream, dX.p, (const float*)nullptr,
                        (const int*)nullptr, p->st.p, 0LL, 0, n, F, p->up[0], no, p->up[L], p->A[0].p, (double*)nullptr,
-                       (MlpState*)nullptr);
+                       (MlpState*)nullptr, n);
     GOCTR_HIP(hipGetLastError());
     if (forward(p, n, false)) return -1;
     hipLaunchKernelGGL(mlp_narrow_kernel, dim3((unsigned)cdiv((int64_t)n * no, 256)), dim3(256), 0, engine().stream,

@@ -541,6 +541,12 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   }
   __syncthreads();
   const float tb = sh_tb;
+  // kth - 2E <= 0 (fewer than `rounds` positive group maxima, or a k-th maximum inside the filter's error): the candidate set
+  // reaches down to every similarity > 0, and an item whose exact similarity lies in (0, E] can have a float32 score <= 0 in a
+  // tile whose maximum is <= 0 -- the list below (tm > 0) would never visit it while the reference returns it (search.go:104:
+  // score > low, low = 0).  Hand the query to the exact tile kernels instead (the replay kernel reports the overflow mark).
+  // (A zero query has no neighbours at all -- searchutil.go:21-23 -- and needs no second opinion.)
+  if (!(tb > 0.f)) { if (g == 0 && threadIdx.x == 0 && knn_cq[D] != 0) atomicAdd(&c_cnt[q], KNN2_CAP + 1); return; }
   // the listed tiles in tile order: rank = (listed tiles before this one); tile of rank r belongs to workgroup r mod G
   int base = 0;
   for (int t0 = 0; t0 < nt; t0 += 256) {

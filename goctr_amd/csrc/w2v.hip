@@ -49,6 +49,13 @@ struct W2vDev {
   double* lr;              // in/out (deterministic) / in (hogwild)
   unsigned long long* lcg; // shared LCG state (deterministic)
   long long* trained;      // observer counter
+  // hogwild launches: segment `seg` of `nseg` equal parts of every stream's piece (data-parallel passes exchange parameter
+  // deltas between segments; 0 of 1 = the whole pass), the ranks sharing the pass (the observer estimate counts THEIR words
+  // too: the reference's schedule runs on the global trained-word count, word2vec.go:223-233) and this rank's first stream
+  // number (stream seeds differ between ranks)
+  int seg, nseg;
+  long long est_scale;
+  long long seed_base;
 };
 
 __device__ __forceinline__ int lcg_next(unsigned long long& next, int value) {
@@ -355,11 +362,14 @@ __global__ __launch_bounds__(HOG_THREADS, HOG_WAVES_PER_SIMD) void w2v_hogwild_k
   const int l = threadIdx.x % GS;
   const bool act = l < dim && g < streams;
   const int gs = g < streams ? g : streams - 1;
-  const long long lo = slice_idx[gs], hi = g < streams ? slice_idx[gs + 1] : lo;  // idle groups run 0 words
-  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * (unsigned long long)g;  // per-stream LCG; stream 0 starts from the reference's seed (modelutil.go:21-24)
+  const long long lo0 = slice_idx[gs], len0 = g < streams ? slice_idx[gs + 1] - lo0 : 0;  // idle groups run 0 words
+  const long long pb = len0 * a.seg / a.nseg;                      // this launch's part of the piece (whole piece: 0 of 1)
+  const long long lo = lo0 + pb, hi = lo0 + len0 * (a.seg + 1) / a.nseg;
+  // per-stream LCG; stream 0 of rank 0 starts its first segment from the reference's seed (modelutil.go:21-24)
+  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * ((unsigned long long)(a.seed_base + g) + (unsigned long long)a.seg * 0x100000000ULL);
   const double lr0 = *a.lr;
   double lr = lr0;
-  long long est = 0, at = 0;
+  long long est = pb * streams * a.est_scale, at = est / a.update_lr_batch * a.update_lr_batch;
   const int* doc = a.doc + lo;
   const long long len = hi - lo;
   const long long cmin = clip_lo[gs] - lo, cmax = clip_hi[gs] - lo;   // window positions allowed, relative to this piece
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(HOG_THREADS, HOG_WAVES_PER_SIMD) void w2v_hogwild_k
       // observer estimate: all streams advance at the same rate => global count ~= positions so far * streams; the rate is
       // re-derived whenever that estimate passes a multiple `at` of update_lr_batch (word2vec.go:223-233).  Kept as a
       // running multiple: two 64-bit divisions per position were ~300 instructions and a dozen registers of this loop.
-      est += streams;
+      est += streams * a.est_scale;
       if (est >= at + a.update_lr_batch) {
         do at += a.update_lr_batch; while (est >= at + a.update_lr_batch);
         if (lr < a.min_lr) lr = a.min_lr;
@@ -555,14 +565,17 @@ __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev
   const int g = blockIdx.x * GPB + threadIdx.x / GS;
   const int l = threadIdx.x % GS;
   const int gs = g < streams ? g : streams - 1;
-  const long long lo = slice_idx[gs];
-  const int len = g < streams ? (int)(slice_idx[gs + 1] - lo) : 0;            // (the host refuses pieces of 2^31 words or more)
+  const long long lo0 = slice_idx[gs], len0 = g < streams ? slice_idx[gs + 1] - lo0 : 0;   // (the host refuses pieces of 2^31 words or more)
+  const long long pb = len0 * a.seg / a.nseg;                      // this launch's part of the piece (whole piece: 0 of 1)
+  const long long lo = lo0 + pb;
+  const int len = (int)(len0 * (a.seg + 1) / a.nseg - pb);
   bool actk[CPL];
 #pragma unroll
   for (int k = 0; k < CPL; ++k) actk[k] = l + k * GS < dim && g < streams;
-  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * (unsigned long long)g;     // (stream 0: the reference's seed)
+  // (stream 0 of rank 0, first segment: the reference's seed)
+  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * ((unsigned long long)(a.seed_base + g) + (unsigned long long)a.seg * 0x100000000ULL);
   double lr = *a.lr;
-  long long est = 0, at = 0;
+  long long est = pb * streams * a.est_scale, at = est / a.update_lr_batch * a.update_lr_batch;
   const int* doc = a.doc + lo;
   const unsigned char* keep = a.keep ? a.keep + lo : nullptr;
   const long long cmin = clip_lo[gs] - lo, cmax = clip_hi[gs] - lo;
@@ -675,7 +688,7 @@ __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev
             if (j < nj) add_word(cid[j], tmp[j]);                  // ctx += tmp (model.go:74-76)
         }
       }
-      est += streams;                                              // (observer estimate: see w2v_hogwild_kernel)
+      est += streams * a.est_scale;                                              // (observer estimate: see w2v_hogwild_kernel)
       if (est >= at + a.update_lr_batch) {
         do at += a.update_lr_batch; while (est >= at + a.update_lr_batch);
         if (lr < a.min_lr) lr = a.min_lr;
@@ -892,19 +905,32 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
   if (w->lr.upload(lr_io, 1)) return -1;
   long long zero = 0;
   if (w->trained.upload(&zero, 1)) return -1;  // a fresh observer per iteration (word2vec.go:159-160)
-  const bool dp = e.comm_active();             // one exchange of parameter deltas per pass
-  if (dp) {
+  // data-parallel pass: the ranks exchange parameter deltas (p = p0 + sum_r (p_r - p0)) -- the Hogwild kernels every
+  // `exchange_every` words per rank (default update_lr_batch = 10^5: SURVEY 8(e)), so that a rank sees the others' updates
+  // during the pass like the reference's goroutines see each other's through the shared matrices (word2vec.go:198-243); the
+  // deterministic single-stream kernel once per pass.  Every rank derives the same segment count from corpus_len.
+  const bool dp = e.comm_active();
+  int nseg = 1;
+  if (dp && !w->cfg.deterministic) {
+    const long long every = w->cfg.exchange_every == 0 ? w->cfg.update_lr_batch : w->cfg.exchange_every;
+    if (every > 0) nseg = (int)std::min<long long>(4096, std::max<long long>(1, cdiv(cdiv(corpus_len, e.eff_world()), every)));
+    nseg = std::max(1, env_int_w2v("GOCTR_W2V_SEGMENTS", nseg));
+  }
+  auto snapshot = [&]() -> int {
     const size_t np = (size_t)w->V * w->cfg.dim, na = (size_t)w->aux_rows * w->cfg.dim;
     if (w->snap_param.ensure(np, false) || (na && w->snap_aux.ensure(na, false))) return -1;
     GOCTR_HIP(hipMemcpyAsync(w->snap_param.p, w->param.p, np * sizeof(double), hipMemcpyDeviceToDevice, e.stream));
     if (na) GOCTR_HIP(hipMemcpyAsync(w->snap_aux.p, w->aux.p, na * sizeof(double), hipMemcpyDeviceToDevice, e.stream));
-  }
+    return 0;
+  };
+  if (dp && w->cfg.deterministic && snapshot()) return -1;
   W2vDev a{};
   a.dim = w->cfg.dim; a.window = w->cfg.window; a.optimizer = w->cfg.optimizer; a.neg = w->cfg.neg_samples; a.model = w->cfg.model;
   a.init_lr = w->cfg.init_lr; a.min_lr = w->cfg.min_lr; a.update_lr_batch = w->cfg.update_lr_batch; a.V = w->V;
   a.param = w->param.p; a.aux = w->aux.p; a.path_off = w->path_off.p; a.path_nodes = w->path_nodes.p;
   a.path_codes = w->path_codes.p; a.sigtab = w->sigtab.p; a.doc = w->doc.p; a.keep = w->has_keep ? w->keep.p : nullptr;
   a.n_words = w->n_words; a.corpus_len = corpus_len; a.lr = w->lr.p; a.lcg = w->lcg.p; a.trained = w->trained.p;
+  a.seg = 0; a.nseg = 1; a.est_scale = 1; a.seed_base = 0;
   if (w->cfg.deterministic) {
     hipLaunchKernelGGL(w2v_deterministic_kernel, dim3(1), dim3(64), 0, e.stream, a);
     GOCTR_HIP(hipGetLastError());
@@ -987,9 +1013,25 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     if (w->hot_base.ensure((size_t)nwg * 2 * HOT, false)) return -1;
     hot.base = w->hot_base.p;
     hot.merge_scale = env_int_w2v("GOCTR_W2V_AVG", 1) ? 1.0 / (double)nwg : 1.0;
-    hot.max_len = 0;
-    for (int k = 0; k < streams; ++k) hot.max_len = std::max(hot.max_len, idx[k + 1] - idx[k]);
-    GOCTR_CHECK(hot.max_len < (1LL << 31), "goctr_w2v: a stream's piece of %lld words (more streams, or a shorter doc)", hot.max_len);
+    {
+      long long longest = 0;
+      for (int k = 0; k < streams; ++k) longest = std::max(longest, idx[k + 1] - idx[k]);
+      GOCTR_CHECK(longest < (1LL << 31), "goctr_w2v: a stream's piece of %lld words (more streams, or a shorter doc)", longest);
+    }
+    if (dp) {
+      // the observer's estimate counts the other ranks' words too (a rank that counted only its own shard let the rate
+      // decay world times too slowly), and the ranks' streams draw their window shrinks from different seeds
+      a.est_scale = e.eff_world(); a.seed_base = (long long)e.rank * streams;
+    }
+    a.nseg = nseg;
+    for (int seg = 0; seg < nseg; ++seg) {
+    a.seg = seg;
+    hot.max_len = 0;          // the longest part any stream walks in this launch (all threads of a workgroup loop alike: merges)
+    for (int k = 0; k < streams; ++k) {
+      const long long len0 = idx[k + 1] - idx[k];
+      hot.max_len = std::max(hot.max_len, len0 * (seg + 1) / nseg - len0 * seg / nseg);
+    }
+    if (dp && snapshot()) return -1;
     const dim3 grid((unsigned)nwg), block(HOG_THREADS);
 #define GOCTR_HOG_ARGS 0, e.stream, a, streams, w->slice_idx.p, w->clip_lo.p, w->clip_hi.p, hot
     bool launched = false;
@@ -1019,8 +1061,10 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
 #undef GOCTR_HOG_MO
 #undef GOCTR_HOG_ARGS
     GOCTR_HIP(hipGetLastError());
+    if (dp && exchange_deltas(w)) return -1;
+    }   // segments
   }
-  if (dp && exchange_deltas(w)) return -1;
+  if (dp && w->cfg.deterministic && exchange_deltas(w)) return -1;
   GOCTR_HIP(hipStreamSynchronize(e.stream));
   return w->lr.download(lr_io, 1);
 }

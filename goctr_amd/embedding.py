@@ -41,7 +41,7 @@ class Word2Vec:
 
     def __init__(self, window=5, dim=16, iter=1, optimizer="hs", min_count=5, max_count=-1, init_lr=0.025,
                  subsample_threshold=1e-3, deterministic=False, streams=8192, slices=16, update_lr_batch=100000, rng=None,
-                 model="skipgram", devices=0):
+                 model="skipgram", devices=0, exchange_every=0):
         # options.go:38-58 defaults; wordemb.go:10-18 fixes SkipGram + HS + DocInMemory
         self.window, self.dim, self.iter, self.optimizer = window, dim, iter, optimizer
         self.min_count, self.max_count, self.init_lr = min_count, max_count, init_lr
@@ -51,6 +51,9 @@ class Word2Vec:
         self.update_lr_batch = update_lr_batch
         self.model = model                                                  # options.go ModelType: skipgram | cbow
         self.devices = devices        # n of capi.init_devices: every pass runs data-parallel inside ONE call (goctr_w2v_cfg.devices)
+        # data-parallel passes: words per rank between two all-reduces of the parameter deltas (0 = update_lr_batch, < 0 = once per
+        # pass; goctr_w2v_cfg.exchange_every)
+        self.exchange_every = exchange_every
         self.rng = rng or np.random.default_rng()
         self.dic = Dictionary()
         self.idoc = []
@@ -81,6 +84,7 @@ class Word2Vec:
         c.update_lr_batch = self.update_lr_batch
         c.deterministic, c.streams, c.slices = int(self.deterministic), self.streams, self.slices
         c.devices = self.devices
+        c.exchange_every = self.exchange_every
         return c
 
     def create(self, counts, param0=None, aux0=None):

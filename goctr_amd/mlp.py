@@ -113,16 +113,16 @@ class MLPClassifier:
 
     def Fit(self, X, Y, theta0=None, perm=None):
         """Base64.Fit (basemlp64.go:578-599) -> fit :484 -> fitStochastic :729.  X float32 rows (the adapter
-        widens them, mlp.go:46-53), Y in {0,1}.  rows are truncated to a multiple of the batch (the reference
-        leaves stale activations in a short last batch, quirk Q11)."""
+        widens them, mlp.go:46-53), Y in {0,1}.  Every row is trained: a sample count that is not a multiple of the batch
+        ends each epoch with one short batch, computed the reference's way (quirk Q11, basemlp64.go:790-812 -- its hidden
+        block and output deltas keep the previous batch's rows beyond the short batch; csrc/mlp.hip goctr_mlp_fit)."""
         self._validate()
         X = capi.f32(X)
         Y = capi.f32(Y).reshape(X.shape[0], -1)
         rng = self.RandomState or np.random.default_rng()
         units = [X.shape[1], *self.HiddenLayerSizes, Y.shape[1]]
         batch = min(self.BatchSize if self.BatchSize > 0 else 200, X.shape[0])     # basemlp64.go:516-527
-        rows = X.shape[0] // batch * batch
-        X, Y = X[:rows], Y[:rows]
+        rows = X.shape[0]
         theta = theta0 if theta0 is not None else self.init_params(units, rng)
         self.create(units, batch, theta)
         if perm is None and self.Shuffle:

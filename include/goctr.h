@@ -311,7 +311,11 @@ int goctr_mlp_get_params(goctr_mlp* p, double* theta, size_t n);
 int goctr_mlp_loss_grad(goctr_mlp* p, const double* X, const double* Y, int n, double* loss, double* grads);
 /* fitStochastic (basemlp64.go:729-857) from float32 rows like SimpleMlpFitWrap.Fit widens them
  * (mlp.go:46-59).  perm: [max_iter][rows] row order per epoch (the host owns the shuffle RNG) or
- * NULL = given order.  rows must be a multiple of batch.  loss_curve [max_iter]. */
+ * NULL = given order.  rows >= batch; when rows is not a multiple of the batch every epoch ends with ONE short batch, as in
+ * the reference (basemlp64.go:790-793; main.go:39-50 trains 79 948 rows at 200) and computed its way (quirk Q11, :800-802:
+ * the hidden block and the output deltas keep the previous batch's rows beyond the short batch; the intercept means and
+ * the loss mean divide by the batch size, the coefficient blocks by the short row count); the epoch loss is
+ * sum(batch loss x batch rows) / rows (:806,:812).  loss_curve [max_iter]. */
 int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, const int32_t* perm,
                   double* loss_curve, int* iters_run);
 /* exactly n_steps updates cycling over resident rows (async) -- bench unit */
@@ -344,6 +348,13 @@ typedef struct {
                             of param / aux on engines 1 .. n-1 are broadcast when they are out of date, every rank trains its shard and
                             the parameter deltas are summed (p = p0 + sum_r (p_r - p0)) -- embedding.TrainEmbedding stays one call from
                             one Go process.  No reference counterpart (SURVEY 2.3, 8(e) item2vec row). */
+  int64_t exchange_every; /* data-parallel passes (devices > 1, or one process per GPU after goctr_comm_init): words PER RANK between two
+                            all-reduces of the parameter deltas.  0 = update_lr_batch (10^5: SURVEY 8(e), the cadence of the reference's
+                            shared observer, word2vec.go:223-233, options.go:55) -- a pass is then ceil(corpus_len / ranks / 10^5)
+                            segments, every rank sees the others' updates between segments like the reference's goroutines see
+                            each other's through the shared matrices (word2vec.go:198-243); n > 0 = every n words; < 0 = once per
+                            pass (rounds 3-4).  Each exchange moves the whole param + aux matrices over xGMI: raise it for
+                            large vocabularies. */
 } goctr_w2v_cfg;
 void goctr_w2v_cfg_default(goctr_w2v_cfg* c);
 /* counts [V] = dictionary cfs (dictionary.go:70-81); builds the Huffman tree on the host with the

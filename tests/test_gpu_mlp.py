@@ -185,3 +185,74 @@ def test_reference_nn_forward_kat():
     ref = -(Y * np.log(p) + (1 - Y) * np.log(1 - p)).sum() + 0.5 * 1e-4 * sum(
         (np.asarray(l, np.float64) ** 2).sum() for l in k["weights_layer_neuron_input"][:2])
     assert loss == pytest.approx(ref, rel=1e-9)
+
+
+# ---- quirk Q11: the short last batch (basemlp64.go:790-812; oracle pinned by tests/test_oracle_mlp_q11.py) ----
+
+@pytest.mark.parametrize("units,act,solver,bn,n,batch", [
+    ([20, 12, 1], "relu", "adam", False, 600 + 148, 200),          # 3 whole batches + 148 rows
+    ([20, 12, 1], "relu", "sgd", False, 200 + 1, 200),             # a ONE-row short batch
+    ([281, 100, 1], "relu", "adam", False, 2 * 200 + 148, 200),    # the fused-chain shape (main.go:39-46) around the generic steps
+    ([40, 33, 17, 1], "tanh", "adam", False, 3 * 64 + 63, 64),     # two hidden layers: only the first keeps stale rows
+    ([40, 33, 17, 1], "logistic", "adam", False, 3 * 64 + 5, 64),
+    ([10, 7, 1], "relu", "adam", True, 2 * 50 + 17, 50),           # max-abs normalisation runs over the stale rows too
+    ([12, 9, 1], "identity", "adam", False, 96 + 31, 96),
+])
+def test_fit_trains_the_short_last_batch_like_the_reference(oracle, units, act, solver, bn, n, batch):
+    from goctr_amd import mlp as gmlp
+    rng = np.random.default_rng(21)
+    iters = 4
+    X, Y = make(rng, n, units[0])
+    clf = gmlp.MLPClassifier(units[1:-1], act, solver, 1e-3)
+    clf.BatchSize, clf.MaxIter, clf.Tol, clf.BatchNormalize = batch, iters, -1.0, bn
+    theta0 = clf.init_params(units, rng)
+    perm = np.stack([rng.permutation(n) for _ in range(iters)]).astype(np.int32)
+    clf.Fit(X, Y, theta0=theta0.copy(), perm=perm)
+    cfg = oracle.mlp_cfg(units, act, alpha=1e-3, batch_normalize=bn)
+    theta = theta0.copy()
+    opt = oracle.MlpOptimizer(solver, theta.size)
+    ref = oracle.mlp_fit(cfg, theta, opt, X.astype(np.float64), Y.astype(np.float64), batch, iters, tol=-1.0, perm=perm)
+    assert opt.o.t == iters * (n // batch + 1)                     # the short batch is an update of its own
+    assert clf.NIter == iters and close(clf.LossCurve, ref, rtol=1e-8)
+    assert close(clf.get_params(), theta, rtol=1e-7, atol=1e-10)
+    # and it is NOT what dropping the tail computes (round 1-4 behaviour): the parameters differ visibly
+    th2 = theta0.copy()
+    nt = n // batch * batch
+    keep = np.stack([p[np.isin(p, p[:nt])][:nt] for p in perm])   # any whole-batch-only schedule
+    oracle.mlp_fit(cfg, th2, oracle.MlpOptimizer(solver, th2.size), X.astype(np.float64), Y.astype(np.float64), batch, iters,
+                   tol=-1.0, perm=None)
+    assert np.max(np.abs(th2 - theta)) > 1e-6 and keep.shape == (iters, nt)
+
+
+def test_flagship_run_79948_rows_at_batch_200(oracle):
+    """the reference's own entry point (main.go:39-50; BASELINE configs[0]): [281, 100, 1] relu / adam, alpha 1e-5, 79 948 rows
+    (feature_test.go:24), BatchSize 200, MaxIter 20 -> 399 whole batches and one of 148 per epoch, a given shuffle.
+    Loss curve 1e-8 relative and parameters 1e-7 against the oracle."""
+    from goctr_amd import mlp as gmlp
+    rng = np.random.default_rng(22)
+    n, F, iters = 79948, 281, 20
+    X = rng.random((n, F)).astype(np.float32)
+    Y = ((X[:, :8].sum(1) + 0.3 * rng.standard_normal(n)) > 4).astype(np.float32).reshape(-1, 1)
+    units = [F, 100, 1]
+    clf = gmlp.MLPClassifier([100], "relu", "adam", 1e-5)
+    clf.BatchSize, clf.MaxIter, clf.Tol = 200, iters, -1.0
+    theta0 = clf.init_params(units, rng)
+    order, perms = np.arange(n), []
+    for _ in range(iters):                                         # cumulative in-place shuffles, like fitStochastic :786-788
+        order = order[rng.permutation(n)]
+        perms.append(order.copy())
+    perm = np.stack(perms).astype(np.int32)
+    clf.Fit(X, Y, theta0=theta0.copy(), perm=perm)
+    cfg = oracle.mlp_cfg(units, "relu", alpha=1e-5)
+    theta = theta0.copy()
+    opt = oracle.MlpOptimizer("adam", theta.size)
+    import os
+    oracle.set_threads(min(16, len(os.sched_getaffinity(0))))      # (row-parallel loops: no summation order depends on it)
+    try:
+        ref = oracle.mlp_fit(cfg, theta, opt, X.astype(np.float64), Y.astype(np.float64), 200, iters, tol=-1.0, perm=perm)
+    finally:
+        oracle.set_threads(1)
+    assert opt.o.t == iters * 400
+    assert len(clf.LossCurve) == iters and close(clf.LossCurve, ref, rtol=1e-8)
+    assert close(clf.get_params(), theta, rtol=1e-7, atol=1e-10)
+    assert ref[-1] < ref[0]

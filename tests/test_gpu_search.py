@@ -141,3 +141,37 @@ def test_large_scan_properties():
         assert cnt[j] == k and np.all(np.diff(sim[j]) <= 0)
         assert np.allclose(sim[j], top, rtol=1e-12, atol=0)
         assert np.allclose(scores[idx[j]], sim[j], rtol=1e-12)
+
+
+def test_bench_shape_matches_oracle_bit_exact(oracle):
+    """the shape bench.py --workload knn times (V = 10^6, D = 16, k = 10, the same seeded items): 64 queries per call ->
+    knn_scan_mfma_kernel<16> over 977 tiles -> knn_collect -> knn_replay.  Q = 47 is the last call size on the VALU scan
+    kernel, 48 the first on the MFMA one, 64 a full query block, 65 two blocks; each call also forced onto the other scan
+    kernel.  Indices, float64 similarities and counts equal the oracle's sequential loop for EVERY query."""
+    from goctr_amd import search as gs
+    rng = np.random.default_rng(42)
+    V, D, k = 1_000_000, 16, 10
+    items = rng.standard_normal((V, D))
+    s = gs.Searcher([""] * V, items)
+    acc = np.zeros(V)
+    for d in range(D):                                      # embutil.go:21-27 / orc_norm64: the d-ordered sum, then sqrt
+        acc += items[:, d] * items[:, d]
+    norms = np.sqrt(acc)
+    assert all(norms[i] == oracle.norm64(items[i]) for i in range(0, V, 9973))
+    allq = rng.standard_normal((65, D))
+    allq[5] = items[123456]                                 # a query that is an item; its own row ignored
+    ign = np.full(65, -1, np.int64)
+    ign[5] = 123456
+    want = [oracle.knn_search(items, allq[q], k, ignore=int(ign[q]), norms=norms) for q in range(65)]
+    for Q in (47, 48, 64, 65):
+        for mfma in (None, "0", "1"):
+            if mfma is not None:
+                os.environ["GOCTR_KNN_MFMA"] = mfma
+            try:
+                idx, sim, cnt = s.search_vectors(allq[:Q], k, ign[:Q])
+            finally:
+                os.environ.pop("GOCTR_KNN_MFMA", None)
+            for q in range(Q):
+                ri, rs, _ = want[q]
+                assert cnt[q] == ri.size == k, (Q, mfma, q)
+                assert np.array_equal(idx[q, :k], ri) and np.array_equal(sim[q, :k], rs), (Q, mfma, q)

@@ -153,6 +153,45 @@ def test_hogwild_one_stream_is_the_sequential_pass(dim):
         p, a, lr = dp, da, dlr
 
 
+@pytest.mark.parametrize("hot", ["1", "0", "16"])
+@pytest.mark.parametrize("dim", [16, 64])
+def test_hogwild_one_stream_cold_rows_are_the_sequential_pass(dim, hot):
+    """the same claim on the COLD-ROW branch of w2v_hogwild_nm_kernel (device-scope load + one atomic add per chunk): V = 3000
+    words is far more than the LDS tables hold (256 + 256 rows at dim 16, 64 + 64 at dim 64), so most words and most Huffman
+    nodes of a walk are cold; GOCTR_W2V_HOT=0 makes every row cold, =16 leaves a 16-row hot set.  A rare (cold) word sits on
+    both sides of a centre, so that a chunk must split on a cold context row, and a rare word is its own neighbour's centre
+    (VERDICT r4 item 4b).  Match: feature/embedding/model/word2vec/optimizer.go:107-129."""
+    import os
+    from goctr_amd import embedding as ge
+    rng = np.random.default_rng(12)
+    V, n = 3000, 12000
+    doc = corpus(rng, V, n, zipf=1.0)
+    rare = V - 7
+    doc[200:205] = [rare, 11, 5, 12, rare]            # a cold context word twice in one window
+    doc[300:303] = [rare, rare, rare]                 # ... and next to itself
+    counts = np.bincount(doc, minlength=V) + 1
+    keep = (rng.random(n) < 0.9).astype(np.uint8)
+    keep[195:310] = 1
+    p0 = (rng.random((V, dim)) - 0.5) / dim
+
+    def one_pass(det):
+        m = ge.Word2Vec(dim=dim, deterministic=det, streams=1, update_lr_batch=500)
+        m.create(counts, p0)
+        lr = m.train_pass(doc, n, keep, lr=0.025)
+        return m.get_param(), m.get_aux(), lr
+
+    dp, da, dlr = one_pass(True)
+    os.environ["GOCTR_W2V_HOT"] = hot
+    try:
+        hp, ha, hlr = one_pass(False)
+    finally:
+        del os.environ["GOCTR_W2V_HOT"]
+    assert dlr == hlr
+    assert np.max(np.abs(dp[rare] - p0[rare])) > 1e-6             # the cold rare word was trained
+    assert np.max(np.abs(hp - dp)) <= 1e-10 * max(1.0, np.abs(dp).max()), np.max(np.abs(hp - dp))
+    assert np.max(np.abs(ha - da)) <= 1e-10 * max(1.0, np.abs(da).max()), np.max(np.abs(ha - da))
+
+
 def test_hogwild_learns_cooccurrence():
     """two disjoint 'session' vocabularies: after Hogwild training, within-group cosine >> across-group"""
     from goctr_amd import embedding as ge
