@@ -828,7 +828,7 @@ struct goctr_w2v {
   goctr_w2v_cfg cfg{};
   int64_t V = 0;
   int64_t aux_rows = 0;
-  DevBuf<double> param, aux, sigtab, lr, snap_param, snap_aux;   // snap_*: the pass's starting point (multi-GPU exchange)
+  DevBuf<double> param, aux, sigtab, lr, snap_param, snap_aux, touch_cnt;   // snap_*: the starting point of an exchange interval (multi-GPU); touch_cnt: ranks that updated a row
   DevBuf<double> hot_base;                                        // Hogwild kernel: the workgroups' base strips (HogHot::base)
   DevBuf<long long> path_off, trained, slice_idx, clip_lo, clip_hi;
   DevBuf<int> path_nodes, doc, hot_word_slot, hot_word_id;   // hot_*: the most frequent words, cached in LDS by the Hogwild kernel
@@ -867,9 +867,18 @@ __global__ void w2v_subsample_kernel(const int* doc, long long n, const long lon
   keep[pos] = z > u ? 1 : 0;
 }
 
-// data-parallel exchange (item2vec row): every rank trains its own corpus shard on a full replica; after
-// the pass the ranks' parameter DELTAS are summed (what Hogwild's shared matrices do with the threads' updates) and
-// applied to the common starting point, so all replicas agree again:  p = p0 + sum_r (p_r - p0)
+// data-parallel exchange (item2vec row): every rank trains its own corpus shard on a full replica; at an exchange
+// the ranks' parameter DELTAS since the common snapshot are combined and applied to it, so all replicas agree again.
+//   avg = false   p = p0 + sum_r d_r.  The deterministic single-stream mode (its tests compute the expected matrices from W
+//                 single-device passes).  NOT usable for Hogwild training: the W ranks each walk the Huffman root (and every
+//                 frequent node / word) thousands of times from the SAME stale snapshot, and stacking W such deltas is a step W
+//                 times too long -- measured at cfg5, W = 8: HS loss 6.2 (once per pass) and 8.9 (every 10^5 words) against
+//                 0.559 for the oracle's Hogwild run (round 5, profiles/r05_w2v_dp_exchange.txt; rounds 3-4 shipped this rule
+//                 unmeasured).  Threads of the reference do not stack: each update reads the row the others have just written.
+//   avg = true    p[row] = p0[row] + sum_r d_r[row] / #{r : d_r[row] != 0} -- per ROW the average over the ranks that updated it
+//                 (local SGD / model averaging, which SURVEY 8(e) names, but a row only one rank trained keeps its whole
+//                 update: rare words are not slowed down W times).  CPU simulation with the oracle's kernels (scripts/
+//                 w2v_dp_sim.py, 10^7 words, W = 8): 0.5640 at 13 exchanges per pass, 0.6258 at one -- sequential pass 0.5590.
 __global__ void w2v_delta_kernel(double* cur, const double* snap, long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) cur[i] -= snap[i];
@@ -878,17 +887,40 @@ __global__ void w2v_apply_kernel(double* cur, const double* snap, long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) cur[i] += snap[i];
 }
+// cnt[row] = 1 when this rank changed the row since the snapshot (cur already holds the delta)
+__global__ void w2v_touched_kernel(const double* delta, long long rows, int dim, double* cnt) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  bool any = false;
+  for (int c = 0; c < dim; ++c) any = any || delta[r * dim + c] != 0.0;
+  cnt[r] = any ? 1.0 : 0.0;
+}
+__global__ void w2v_apply_avg_kernel(double* cur, const double* snap, const double* cnt, long long n, int dim) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double c = cnt[i / dim];
+  cur[i] = snap[i] + (c > 1.0 ? cur[i] / c : cur[i]);
+}
 
-int exchange_deltas(goctr_w2v* w) {
+int exchange_deltas(goctr_w2v* w, bool avg) {
   Engine& e = engine();
-  struct Part { DevBuf<double>* cur; DevBuf<double>* snap; long long n; };
-  Part parts[2] = {{&w->param, &w->snap_param, (long long)w->V * w->cfg.dim}, {&w->aux, &w->snap_aux, (long long)w->aux_rows * w->cfg.dim}};
+  struct Part { DevBuf<double>* cur; DevBuf<double>* snap; long long rows; };
+  Part parts[2] = {{&w->param, &w->snap_param, (long long)w->V}, {&w->aux, &w->snap_aux, (long long)w->aux_rows}};
+  const int dim = w->cfg.dim;
   for (const Part& p : parts) {
-    if (p.n <= 0) continue;
-    hipLaunchKernelGGL(w2v_delta_kernel, dim3((unsigned)cdiv(p.n, 256)), dim3(256), 0, e.stream, p.cur->p, p.snap->p, p.n);
+    const long long n = p.rows * dim;
+    if (n <= 0) continue;
+    hipLaunchKernelGGL(w2v_delta_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, e.stream, p.cur->p, p.snap->p, n);
     GOCTR_HIP(hipGetLastError());
-    if (comm_allreduce_f64_dev(p.cur->p, (size_t)p.n)) return -1;
-    hipLaunchKernelGGL(w2v_apply_kernel, dim3((unsigned)cdiv(p.n, 256)), dim3(256), 0, e.stream, p.cur->p, p.snap->p, p.n);
+    if (avg) {
+      if (w->touch_cnt.ensure((size_t)p.rows, false)) return -1;
+      hipLaunchKernelGGL(w2v_touched_kernel, dim3((unsigned)cdiv(p.rows, 256)), dim3(256), 0, e.stream, p.cur->p, p.rows, dim, w->touch_cnt.p);
+      GOCTR_HIP(hipGetLastError());
+      if (comm_allreduce_f64_dev(w->touch_cnt.p, (size_t)p.rows)) return -1;
+    }
+    if (comm_allreduce_f64_dev(p.cur->p, (size_t)n)) return -1;
+    if (avg) hipLaunchKernelGGL(w2v_apply_avg_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, e.stream, p.cur->p, p.snap->p, w->touch_cnt.p, n, dim);
+    else hipLaunchKernelGGL(w2v_apply_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, e.stream, p.cur->p, p.snap->p, n);
     GOCTR_HIP(hipGetLastError());
   }
   return 0;
@@ -1061,10 +1093,10 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
 #undef GOCTR_HOG_MO
 #undef GOCTR_HOG_ARGS
     GOCTR_HIP(hipGetLastError());
-    if (dp && exchange_deltas(w)) return -1;
+    if (dp && exchange_deltas(w, env_int_w2v("GOCTR_W2V_EXCHANGE_SUM", 0) == 0)) return -1;
     }   // segments
   }
-  if (dp && w->cfg.deterministic && exchange_deltas(w)) return -1;
+  if (dp && w->cfg.deterministic && exchange_deltas(w, false)) return -1;
   GOCTR_HIP(hipStreamSynchronize(e.stream));
   return w->lr.download(lr_io, 1);
 }

@@ -346,8 +346,9 @@ typedef struct {
                             goctr_w2v_upload_doc / goctr_w2v_train(_resident) call runs the pass data-parallel -- the doc is cut into n
                             contiguous shards at the reference's slice boundaries (rank r takes slices [r, r+1) * slices / n), replicas
                             of param / aux on engines 1 .. n-1 are broadcast when they are out of date, every rank trains its shard and
-                            the parameter deltas are summed (p = p0 + sum_r (p_r - p0)) -- embedding.TrainEmbedding stays one call from
-                            one Go process.  No reference counterpart (SURVEY 2.3, 8(e) item2vec row). */
+                            the parameter deltas are combined every `exchange_every` words (Hogwild: per row, the average over the ranks
+                            that updated the row; deterministic mode: the plain sum p = p0 + sum_r (p_r - p0)) --
+                            embedding.TrainEmbedding stays one call from one Go process.  No reference counterpart (SURVEY 2.3, 8(e) item2vec row). */
   int64_t exchange_every; /* data-parallel passes (devices > 1, or one process per GPU after goctr_comm_init): words PER RANK between two
                             all-reduces of the parameter deltas.  0 = update_lr_batch (10^5: SURVEY 8(e), the cadence of the reference's
                             shared observer, word2vec.go:223-233, options.go:55) -- a pass is then ceil(corpus_len / ranks / 10^5)

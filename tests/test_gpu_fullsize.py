@@ -333,10 +333,13 @@ np.savez(%(out)r, **res)
 def test_cfg5_item2vec_w8_exchange_cadence_vs_oracle(oracle, tmp_path):
     """BASELINE configs[4] across devices: the 10^7-word corpus on W = 8 logical ranks
     (loop-back communicator on one GPU: every W > 1 code path), ONE goctr_w2v_train call with cfg.devices = 8, `iter 1`.
-    Two cadences of the parameter-delta all-reduce: every update_lr_batch = 10^5 words per rank (the default: 13 segments per
-    pass, aligned with the reference's observer, word2vec.go:223-233 / options.go:55) and once per pass (rounds 3-4: eight
-    independently trained deltas stacked into p0).  Gate for both: HS loss per path node within 3 % of the oracle's 16-thread
-    Hogwild run from the same initial vectors.  Both numbers are printed and written to gpurun_out/."""
+    Two cadences of the parameter-delta exchange (per row: the average over the ranks that updated it, csrc/w2v.hip
+    exchange_deltas): every update_lr_batch = 10^5 words per rank (the default: 13 segments per pass, aligned with the
+    reference's observer, word2vec.go:223-233 / options.go:55) and once per pass.  Gate: HS loss per path node within 3 % of the
+    oracle's 16-thread Hogwild run from the same initial vectors -- REQUIRED of the default cadence, measured and reported for
+    once-per-pass (the oracle-kernel simulation scripts/w2v_dp_sim.py predicts 0.564 vs 0.626 against 0.559).  Round 5's first
+    run of this test found what rounds 3-4 shipped unmeasured: the plain SUM of the eight deltas diverges (loss 6.2 once per
+    pass, 8.9 at 13 exchanges; profiles/r05_w2v_dp_exchange.txt).  Both numbers are printed and written to gpurun_out/."""
     import json
     from test_gpu_multi import run_script
     rng = np.random.default_rng(105)
@@ -369,5 +372,5 @@ def test_cfg5_item2vec_w8_exchange_cadence_vs_oracle(oracle, tmp_path):
     assert np.all(np.isfinite(r["periodic_p"])) and np.all(np.isfinite(r["once_p"]))
     assert lo < 0.9 * l0 and lp < 0.9 * l0
     assert abs(lp - lo) <= 0.03 * lo, line                       # the default cadence holds the gate
-    # once per pass is reported, not required: eight stale deltas stacked on the Huffman root are what the judge asked to measure
+    # once per pass is reported, not required to hold the gate (eight replicas averaged after training apart for a whole pass)
     assert l1 < l0, line
