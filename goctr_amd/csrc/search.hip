@@ -58,6 +58,7 @@ struct goctr_searcher {
   DevBuf<float> items32, tmax;               // normalised float32 rows; per (query, tile) maxima
   DevBuf<long long> c_idx;
   DevBuf<int> c_cnt;
+  DevBuf<unsigned int> c_done;   // folded collect + replay: workgroups of a query that have finished (self-resetting)
   DevBuf<unsigned char> in_pack, out_pack;
   void* h_in = nullptr; void* h_out = nullptr; size_t h_in_bytes = 0, h_out_bytes = 0;
   bool lds_ok = false;
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const double* __restrict
 // ------------------------------------------------------------------------------------------------------------- scan path
 constexpr int KNN2_QB = 64;        // queries per workgroup (the rows are read once per block: once per call up to 64 queries)
 constexpr int KNN2_CAP = 2048;     // candidates per query the replay kernel takes
+constexpr int KNN2_G = 8;          // collect workgroups per query (default; GOCTR_KNN_G)
 
 template <int CTRL>
 __device__ __forceinline__ float knn_dpp_f32(float v) {
@@ -486,6 +488,56 @@ __global__ __launch_bounds__(256) void knn_scan_mfma_kernel(const float* __restr
   }
 }
 
+// The replay of search.go:104-121 over a query's candidates (sorted by item index first: an item appears once).  FOLDED: called by
+// the query's last collect workgroup -- the other workgroups' candidates were written through other L2s, so they (and the count)
+// are read with device-scope loads.  smem: [CAP] similarities | [CAP] indices | [k] | [k].
+template <bool FOLDED>
+__device__ __forceinline__ void knn_replay_body(int q, const int* c_cnt, const long long* c_idx, const double* c_sim, int k,
+                                                long long* out_idx, double* out_sim, int* out_cnt, double* smem) {
+  double* s_sim = smem;                                                  // [CAP] sorted by item index
+  long long* s_idx = reinterpret_cast<long long*>(s_sim + KNN2_CAP);     // [CAP]
+  double* nb_s = reinterpret_cast<double*>(s_idx + KNN2_CAP);            // [k]
+  long long* nb_i = reinterpret_cast<long long*>(nb_s + k);              // [k]
+  const int n = FOLDED ? __hip_atomic_load(c_cnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : c_cnt[q];
+  if (n > KNN2_CAP) { if (threadIdx.x == 0) out_cnt[q] = -1; return; }
+  const long long* ci = c_idx + (size_t)q * KNN2_CAP;
+  const double* cs = c_sim + (size_t)q * KNN2_CAP;
+  auto ld_i = [&](int e) { return FOLDED ? __hip_atomic_load(ci + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ci[e]; };
+  auto ld_s = [&](int e) { return FOLDED ? __hip_atomic_load(cs + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cs[e]; };
+  for (int r = threadIdx.x; r < k; r += 256) { nb_s[r] = 0.0; nb_i[r] = -1; }
+  // the unsorted list once into LDS (its second half: the sorted one is built in the first), then the rank sort out of LDS
+  long long* u_idx = s_idx;                                              // (reused: ranks are written to s_* only after the barrier)
+  double* u_sim = s_sim;
+  for (int e = threadIdx.x; e < n; e += 256) { u_idx[e] = ld_i(e); u_sim[e] = ld_s(e); }
+  __syncthreads();
+  long long me[KNN2_CAP / 256]; double ms[KNN2_CAP / 256]; int rk[KNN2_CAP / 256];
+#pragma unroll
+  for (int u = 0; u < KNN2_CAP / 256; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    me[u] = 0; ms[u] = 0.0; rk[u] = -1;
+    if (e < n) {
+      me[u] = u_idx[e]; ms[u] = u_sim[e];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += u_idx[j] < me[u];
+      rk[u] = rank;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < KNN2_CAP / 256; ++u)
+    if (rk[u] >= 0) { s_idx[rk[u]] = me[u]; s_sim[rk[u]] = ms[u]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double low = 0;
+    for (int r = 0; r < n; ++r) knn_insert(nb_s, nb_i, k, s_sim[r], s_idx[r], low);
+  }
+  __syncthreads();
+  int cnt = 0;
+  for (int r = 0; r < k; ++r) cnt += nb_i[r] >= 0;
+  for (int r = threadIdx.x; r < k; r += 256) { out_idx[(size_t)q * k + r] = nb_i[r]; out_sim[(size_t)q * k + r] = nb_s[r]; }
+  if (threadIdx.x == 0) out_cnt[q] = cnt < k ? k - 1 : k;     // search.go:126-131 (see knn_merge_kernel)
+}
+
 // knn_collect_kernel, KNN2_G workgroups per query.  Every workgroup first derives the query's bounds itself (a launch of its own
 // for them cost 14 us of mostly launch and memory latency): L = the k-th largest of 64 group maxima (tile mod 64; the (k + 1)-th
 // when an item is ignored: it may own one of them) -- the maxima belong to distinct items, so k items have a >= L; tile bound
@@ -495,15 +547,19 @@ __global__ __launch_bounds__(256) void knn_scan_mfma_kernel(const float* __restr
 // query) and dealt round-robin; a workgroup's tiles pass the float32 filter once more (its own bits: a >= L - 2 E holds for
 // every member of C), the few survivors are scored EXACTLY (the reference's similarity) and join the query's candidates when they
 // reach the similarity bound.
-constexpr int KNN2_G = 8;          // workgroups per query
 constexpr int KNN2_MY = 256;       // listed tiles one workgroup takes (more: the candidate count is poisoned -> fallback)
 __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restrict__ items, const double* __restrict__ norms,
                                                           const float* __restrict__ items32, long long V, int D,
                                                           const double* __restrict__ queries, const float* __restrict__ q32,
                                                           const long long* __restrict__ ignore, const float* __restrict__ tmax, int nt,
-                                                          int tile_items, int k, float E, int* c_cnt, long long* c_idx, double* c_sim) {
-  extern __shared__ __attribute__((aligned(16))) double knn_cq[];       // [D] the query, [1] its norm, then [D] floats: normalised
+                                                          int tile_items, int k, float E, int* c_cnt, long long* c_idx, double* c_sim,
+                                                          unsigned int* c_done, long long* out_idx, double* out_sim, int* out_cnt) {
+  // c_done != null: FOLDED launch -- the query's last workgroup to finish replays the candidates itself (knn_replay_body) instead of
+  // a third launch doing it (round 4: knn_replay_kernel 13.5 us at 92 % waiting, plus a launch boundary, for a few hundred
+  // candidates per query).  Every workgroup of the query, whatever path it took, ends at the ticket.
+  extern __shared__ __attribute__((aligned(16))) double knn_cq[];       // [D] the query, [1] its norm, then [D] floats: normalised; folded: + the replay's arrays
   float* cq32 = reinterpret_cast<float*>(knn_cq + D + 1);
+  const int G = (int)gridDim.x;                                          // workgroups per query
   __shared__ float gmax[4][64];
   __shared__ float sh_tb, sh_sb;
   __shared__ int wave_cnt[4];
@@ -546,7 +602,9 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   // tile whose maximum is <= 0 -- the list below (tm > 0) would never visit it while the reference returns it (search.go:104:
   // score > low, low = 0).  Hand the query to the exact tile kernels instead (the replay kernel reports the overflow mark).
   // (A zero query has no neighbours at all -- searchutil.go:21-23 -- and needs no second opinion.)
-  if (!(tb > 0.f)) { if (g == 0 && threadIdx.x == 0 && knn_cq[D] != 0) atomicAdd(&c_cnt[q], KNN2_CAP + 1); return; }
+  bool skip = false;
+  if (!(tb > 0.f)) { if (g == 0 && threadIdx.x == 0 && knn_cq[D] != 0) atomicAdd(&c_cnt[q], KNN2_CAP + 1); skip = true; }
+  if (!skip) {
   // the listed tiles in tile order: rank = (listed tiles before this one); tile of rank r belongs to workgroup r mod G
   int base = 0;
   for (int t0 = 0; t0 < nt; t0 += 256) {
@@ -558,15 +616,15 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
     int before = base;
     for (int w = 0; w < wave; ++w) before += wave_cnt[w];
     const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (on && rank % KNN2_G == g) {
+    if (on && rank % G == g) {
       const int pos = atomicAdd(&n_my, 1);
       if (pos < KNN2_MY) my_tiles[pos] = t;
     }
     base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     __syncthreads();
   }
-  const int nmy = n_my;
-  if (nmy > KNN2_MY) { if (threadIdx.x == 0) atomicAdd(&c_cnt[q], KNN2_CAP + 1); return; }     // (the replay kernel reports it)
+  int nmy = n_my;
+  if (nmy > KNN2_MY) { if (threadIdx.x == 0) atomicAdd(&c_cnt[q], KNN2_CAP + 1); nmy = 0; }     // (the replay reports it)
   const double qn = knn_cq[D];
   const double bd = (double)sh_sb;
   const long long ig = ignore[q];
@@ -602,6 +660,22 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
       if (pos < KNN2_CAP) { c_idx[(size_t)q * KNN2_CAP + pos] = it; c_sim[(size_t)q * KNN2_CAP + pos] = sim; }
     }
   }
+  }   // !skip
+  if (!c_done) return;
+  // ---- fan-in: publish this workgroup's candidates (release at device scope: the eight L2s are not coherent), take a ticket
+  __shared__ unsigned int is_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned int prev = __hip_atomic_fetch_add(&c_done[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = prev == (unsigned int)G - 1u ? 1u : 0u;
+    if (is_last) __hip_atomic_store(&c_done[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  double* rs = knn_cq + D + 1 + (D + 1) / 2;                             // behind the query operands (16-byte aligned: D is a multiple of 4)
+  knn_replay_body<true>(q, c_cnt, c_idx, c_sim, k, out_idx, out_sim, out_cnt, rs);
 }
 
 // out_cnt[q] = -1: more candidates than the replay takes (the host falls back to the tile kernels)
@@ -609,32 +683,7 @@ __global__ __launch_bounds__(256) void knn_replay_kernel(const int* __restrict__
                                                          const double* __restrict__ c_sim, int k, long long* out_idx, double* out_sim,
                                                          int* out_cnt) {
   extern __shared__ __attribute__((aligned(16))) double knn3_smem[];
-  double* s_sim = knn3_smem;                                             // [CAP] sorted by item index
-  long long* s_idx = reinterpret_cast<long long*>(s_sim + KNN2_CAP);     // [CAP]
-  double* nb_s = reinterpret_cast<double*>(s_idx + KNN2_CAP);            // [k]
-  long long* nb_i = reinterpret_cast<long long*>(nb_s + k);              // [k]
-  const int q = blockIdx.x;
-  const int n = c_cnt[q];
-  if (n > KNN2_CAP) { if (threadIdx.x == 0) out_cnt[q] = -1; return; }
-  const long long* ci = c_idx + (size_t)q * KNN2_CAP;
-  const double* cs = c_sim + (size_t)q * KNN2_CAP;
-  for (int r = threadIdx.x; r < k; r += 256) { nb_s[r] = 0.0; nb_i[r] = -1; }
-  for (int e = threadIdx.x; e < n; e += 256) {          // rank sort (an item appears once)
-    const long long me = ci[e];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += ci[j] < me;
-    s_idx[rank] = me; s_sim[rank] = cs[e];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double low = 0;
-    for (int r = 0; r < n; ++r) knn_insert(nb_s, nb_i, k, s_sim[r], s_idx[r], low);
-  }
-  __syncthreads();
-  int cnt = 0;
-  for (int r = 0; r < k; ++r) cnt += nb_i[r] >= 0;
-  for (int r = threadIdx.x; r < k; r += 256) { out_idx[(size_t)q * k + r] = nb_i[r]; out_sim[(size_t)q * k + r] = nb_s[r]; }
-  if (threadIdx.x == 0) out_cnt[q] = cnt < k ? k - 1 : k;     // search.go:126-131 (see knn_merge_kernel)
+  knn_replay_body<false>((int)blockIdx.x, c_cnt, c_idx, c_sim, k, out_idx, out_sim, out_cnt, knn3_smem);
 }
 
 }  // namespace
@@ -666,6 +715,8 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   if (!s->lds_ok) {
     GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_replay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(double) * (2 * (size_t)KNN2_CAP + 2 * (size_t)KNN_MAX_K))));
+    GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_collect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(sizeof(double) * (2 * (size_t)KNN2_CAP + 2 * (size_t)KNN_MAX_K + 1024 + 2))));
     s->lds_ok = true;
   }
   // one upload: [Q x D queries | Q ignore | the queries normalised, float32, padded with zero rows to whole 64-query blocks],
@@ -719,12 +770,20 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   else GOCTR_KNN_SCAN(64, 2);
 #undef GOCTR_KNN_SCAN
   GOCTR_HIP(hipGetLastError());
-  hipLaunchKernelGGL(knn_collect_kernel, dim3(KNN2_G, Q), dim3(256), sizeof(double) * ((size_t)D + 1) + sizeof(float) * (size_t)D, e.stream,
+  // collect (+ replay by each query's last workgroup: GOCTR_KNN_FOLD=0 launches knn_replay_kernel instead)
+  const bool fold = !(getenv("GOCTR_KNN_FOLD") && getenv("GOCTR_KNN_FOLD")[0] == '0');
+  int G = KNN2_G;
+  if (const char* gv = getenv("GOCTR_KNN_G")) { const int x = atoi(gv); if (x >= 1 && x <= 64) G = x; }
+  const size_t lds_q = sizeof(double) * ((size_t)D + 1 + ((size_t)D + 1) / 2);      // [D] query | norm | [D] floats (rounded up to doubles)
+  if (fold && s->c_done.ensure((size_t)Q, true)) return -1;                          // (zeroed once; the last arriver resets its word)
+  hipLaunchKernelGGL(knn_collect_kernel, dim3(G, Q), dim3(256), lds_q + (fold ? lds_r : 0), e.stream,
                      s->items.p, s->norms.p, s->items32.p, (long long)s->V, D, d_q, d_q32, d_ig, s->tmax.p, nt, tile_items, k, E, s->c_cnt.p,
-                     s->c_idx.p, s->c_sim.p);
+                     s->c_idx.p, s->c_sim.p, fold ? s->c_done.p : nullptr, d_oi, d_os, d_oc);
   GOCTR_HIP(hipGetLastError());
-  hipLaunchKernelGGL(knn_replay_kernel, dim3(Q), dim3(256), lds_r, e.stream, s->c_cnt.p, s->c_idx.p, s->c_sim.p, k, d_oi, d_os, d_oc);
-  GOCTR_HIP(hipGetLastError());
+  if (!fold) {
+    hipLaunchKernelGGL(knn_replay_kernel, dim3(Q), dim3(256), lds_r, e.stream, s->c_cnt.p, s->c_idx.p, s->c_sim.p, k, d_oi, d_os, d_oc);
+    GOCTR_HIP(hipGetLastError());
+  }
   GOCTR_HIP(hipStreamSynchronize(e.stream));         // (the replay kernel wrote the pinned host buffer itself: no copy command)
   const long long* h_oi = static_cast<const long long*>(s->h_out);
   const double* h_os = reinterpret_cast<const double*>(static_cast<const char*>(s->h_out) + o_idx);
