@@ -529,6 +529,10 @@ int launch_attn_fwd(const AttnArgs& a) {
     else if (fast == 2) hipLaunchKernelGGL((attn_fwd_kernel<4, L, 2>), grid, blk, 0, st, a);       \
     else hipLaunchKernelGGL((attn_fwd_kernel<4, L, 3>), grid, blk, 0, st, a);                      \
   } while (0)
+  if (fast == 1 && groups == 16 && a.next && env_int("GOCTR_ATTN_LEAN", 1) != 0) {
+    // forked pipeline, D = 64 rows: the register-capped variant fits beside a weight-gradient workgroup (attn_fwd_lean_kernel)
+    hipLaunchKernelGGL((attn_fwd_lean_kernel<4, 16, 1>), grid, blk, 0, st, a);
+  } else
   if (fast && groups <= 16) {
     if (groups == 1) GOCTR_ATTN_FWD_FAST(1);
     else if (groups == 2) GOCTR_ATTN_FWD_FAST(2);
@@ -939,11 +943,6 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
     AttnArgs aa = make_attn_args(m, src, B, st, fb);
     if (!o.train) { aa.gate = nullptr; aa.wgt = nullptr; }     // (only the backward reads them: 13 MB less per 32 768-row launch)
     if (launch_attn_fwd(aa)) return -1;
-  } else if (o.forked && o.train && c.kind != GOCTR_DIN) {
-    // mean pooling depends on no weight: the next batch's gather starts with the step, on the side stream
-    if (side_begin()) return -1;
-    const int rc = launch_attn_next(m, src, B);
-    if (side_end() || rc) return -1;
   }
   if (o.train) { m->dpv_from_chain = false; m->attn_bwd_in_chain = false; }   // (launch_chain_x3 sets them when it does the work itself)
   if (chain_ok(m)) return launch_chain(m, src, B, o, st, fb);  // layers + (when training) backward-data, fused
@@ -1458,6 +1457,15 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     if (launch_emb_plan_early(m, src, B, st)) return -1;
   }
 
+  if (o.pipelined && o.forked && c.kind != GOCTR_DIN) {
+    // Mean pooling depends on no weight, so the next batch's gather could leave at the step's start -- measured (round 5,
+    // profiles/r05_fork_ab.txt): 108.4 vs 90.6 us per cfg4 step, WORSE: a chain workgroup is 8 wavefronts x 252 registers, the
+    // whole register file of its CU, so nothing runs beside it and the gather's 4096 workgroups only delay its dispatch.  The
+    // weight-gradient workgroups (8 x 202 registers) leave room for one more wavefront per SIMD: the fork is here.
+    if (side_begin()) return -1;
+    const int rc = launch_attn_next(m, src, B);
+    if (side_end() || rc) return -1;
+  }
   const bool att0_early = att0_early_ok(m);
   if (att0_early && stage != 2) {
     // the per-sample terms of the att0 gradient are out (chain tail / attn_bwd): att0_step_kernel sums them (and, in a fused

@@ -429,6 +429,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   if (a.next) { bi += 1; if (bi >= a.st->n_batches) bi = 0; }     // advance_state()'s cursor (reduce_adam_body)
   attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x, bi, a.att0);
 }
+// The same body under a register cap (5 wavefronts per SIMD => at most 96 VGPRs; the D = 64 instance takes 114 uncapped): the
+// forked pipeline runs the next batch's gather BESIDE the weight-gradient launch, whose workgroups hold 2 x 208 of a SIMD's 512
+// registers -- one 96-register wavefront fits next to them, a 120-register one does not.
+template <int VEC, int LPR, int FAST>
+__global__ __launch_bounds__(256, 5) void attn_fwd_lean_kernel(AttnArgs a) {
+  long long bi = a.st->batch_idx;
+  if (a.next) { bi += 1; if (bi >= a.st->n_batches) bi = 0; }
+  attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x, bi, a.att0);
+}
 // serving passes: the rows come from (user, item, timestamp) keys (RowSource key mode) -- key assembly and attention in one launch
 template <int LPR, int FAST>
 __global__ __launch_bounds__(256) void attn_fwd_keys_kernel(AttnArgs a) {
@@ -889,7 +898,7 @@ __device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int bl
 //   blocks 0 .. n-1: block k sums rows [k R, (k + 1) R) (thread = column t x row phase: coalesced 256-byte rows, four phases met
 //   in LDS) -> partial[k][t]; a ticket elects the LAST block to finish, which adds the n partials in block order (fixed order:
 //   the result does not depend on which block is last) and makes the update.  Fan-in across the eight non-coherent L2s: the
-//   partials are published with a release fence before the ticket and read back with device-scope loads.
+//   partials are written with device-scope stores before the ticket and read back with device-scope loads.
 struct Att0StepArgs { const float* terms; int B, Tp; float* partial; unsigned int* ticket; AdamArgs ad; int update; };
 #ifndef GOCTR_NO_PLAIN_KERNELS
 __global__ __launch_bounds__(256) void att0_step_kernel(Att0StepArgs p) {
@@ -915,16 +924,19 @@ __global__ __launch_bounds__(256) void att0_step_kernel(Att0StepArgs p) {
     const float tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
     __hip_atomic_store(p.partial + (size_t)blockIdx.x * 64 + t, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();                                          // (the stores above are acknowledged: s_waitcnt before the barrier)
+  // No device-scope release / acquire FENCES here: a release fence writes back every dirty line of the XCD's L2 and an acquire
+  // invalidates it -- under the weight-gradient launch that runs beside this kernel (reduce_adam_body's att0 block makes the same
+  // point).  The partials are device-scope (write-through) stores, the barrier's s_waitcnt sees them acknowledged before the
+  // ticket is taken, and the last block reads them back with device-scope loads.
+  __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // (compiler-level: the ticket must not move above the barrier)
     const unsigned int prev = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = prev == (unsigned int)nb - 1u ? 1u : 0u;
     if (is_last) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next step
   }
   __syncthreads();
   if (!is_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (threadIdx.x < p.Tp) {
     float g = 0.f;
     for (int k = 0; k < nb; ++k) g += __hip_atomic_load(p.partial + (size_t)k * 64 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

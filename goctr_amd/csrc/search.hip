@@ -657,23 +657,27 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
       const double sim = dot / qn / n2;                 // searchutil.go:24-25
       if (!(sim > 0 && sim >= bd)) continue;
       const int pos = atomicAdd(&c_cnt[q], 1);
-      if (pos < KNN2_CAP) { c_idx[(size_t)q * KNN2_CAP + pos] = it; c_sim[(size_t)q * KNN2_CAP + pos] = sim; }
+      if (pos < KNN2_CAP) {
+        // (device-scope stores: the query's last workgroup -- possibly on another XCD -- reads them in this launch when folded)
+        __hip_atomic_store(c_idx + (size_t)q * KNN2_CAP + pos, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(c_sim + (size_t)q * KNN2_CAP + pos, sim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   }   // !skip
   if (!c_done) return;
-  // ---- fan-in: publish this workgroup's candidates (release at device scope: the eight L2s are not coherent), take a ticket
+  // ---- fan-in: the candidates went out as device-scope (write-through) stores and the barrier's s_waitcnt has seen them
+  // acknowledged -- no release FENCE (it would write back this XCD's whole L2, once per workgroup) -- take a ticket
   __shared__ unsigned int is_last;
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     const unsigned int prev = __hip_atomic_fetch_add(&c_done[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = prev == (unsigned int)G - 1u ? 1u : 0u;
     if (is_last) __hip_atomic_store(&c_done[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
   }
   __syncthreads();
   if (!is_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   double* rs = knn_cq + D + 1 + (D + 1) / 2;                             // behind the query operands (16-byte aligned: D is a multiple of 4)
   knn_replay_body<true>(q, c_cnt, c_idx, c_sim, k, out_idx, out_sim, out_cnt, rs);
 }
