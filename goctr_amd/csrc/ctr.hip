@@ -880,9 +880,14 @@ bool att0_early_ok(const goctr_model* m) {
   return m->cfg.kind == GOCTR_DIN && m->Tp <= 64 && m->emb_lr <= 0.f && env_int("GOCTR_ATT0_EARLY", 1) != 0;
 }
 // may a pipelined step fork the next batch's attention onto the side stream (StepOpts::forked)?
+// DIN only by default.  YouTube-DNN's gather depends on no weight and could fork anywhere, but it is the HBM-bound launch of the
+// step and nothing it can run beside gains from its company (round 5, profiles/r05_fork_ab.txt, cfg4): forked at the step's start
+// the chain workgroups (8 x 252 registers: a whole CU each) queue behind its 4096 workgroups, 108.4 vs 90.6 us per step; forked
+// beside the weight-gradient launch (register-capped to fit next to its workgroups) that launch -- itself waiting on memory
+// 53 % of its cycles -- takes 52.4 instead of 26.6 us, 106.5 vs 90.2 us per step.  GOCTR_FORK_YT=1 reproduces the second.
 bool fork_ok(const goctr_model* m, const RowSource& src) {
-  return src.id_mode && !engine().comm_active() && m->emb_lr <= 0.f && (m->cfg.kind != GOCTR_DIN || att0_early_ok(m)) &&
-         engine().side && env_int("GOCTR_FORK_ATTN", 1) != 0;
+  const bool kind_ok = m->cfg.kind == GOCTR_DIN ? att0_early_ok(m) : env_int("GOCTR_FORK_YT", 0) != 0;
+  return src.id_mode && !engine().comm_active() && m->emb_lr <= 0.f && kind_ok && engine().side && env_int("GOCTR_FORK_ATTN", 1) != 0;
 }
 // launches between side_begin() and side_end() go to the engine's side stream, ordered behind everything the main stream holds
 // at side_begin(); side_join() makes the main stream wait for them.  Events, so the same calls build the fork / join edges of a

@@ -937,9 +937,23 @@ __global__ __launch_bounds__(256) void att0_step_kernel(Att0StepArgs p) {
   }
   __syncthreads();
   if (!is_last) return;
+  // all nb x 64 partials into LDS first -- every thread has its 16 device-scope loads in flight at once (a loop `g += load(k)`
+  // in 64 threads is 64 dependent round trips to memory: 20-26 us measured, profiles/r05_fork_ab.txt) -- then the fixed-order sum
+  __shared__ float part[64 * 64];
+  {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = (int)threadIdx.x + 256 * u;
+      v[u] = i < nb * 64 ? __hip_atomic_load(p.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) part[(int)threadIdx.x + 256 * u] = v[u];
+  }
+  __syncthreads();
   if (threadIdx.x < p.Tp) {
     float g = 0.f;
-    for (int k = 0; k < nb; ++k) g += __hip_atomic_load(p.partial + (size_t)k * 64 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int k = 0; k < nb; ++k) g += part[k * 64 + (int)threadIdx.x];
     // fused single-GPU step: the update itself (the step's bias corrections: reduce_adam_body).  Otherwise (gradient entry,
     // data-parallel step: reduce | all-reduce | Adam) only the gradient, where reduce_kernel leaves the att0 segment alone.
     if (p.update) adam_apply(p.ad, p.ad.offa + (int)threadIdx.x, g, p.ad.st->corr1, p.ad.st->corr2);

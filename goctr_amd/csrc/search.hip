@@ -527,9 +527,40 @@ __device__ __forceinline__ void knn_replay_body(int q, const int* c_cnt, const l
   for (int u = 0; u < KNN2_CAP / 256; ++u)
     if (rk[u] >= 0) { s_idx[rk[u]] = me[u]; s_sim[rk[u]] = ms[u]; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double low = 0;
-    for (int r = 0; r < n; ++r) knn_insert(nb_s, nb_i, k, s_sim[r], s_idx[r], low);
+  // The insertion loop of search.go:104-121 over the sorted candidates, by ONE WAVEFRONT with the k-array in registers (lane i =
+  // neighbors[i]; the scan path has k < 64).  knn_insert by one thread walks the array in LDS -- k dependent LDS round trips per
+  // accepted candidate, ~13 us per query for a few dozen of them (round 4: knn_replay_kernel at 92 % waiting).  What one insertion
+  // does to a non-increasing array a[]: the item lands at p = the first position with score > a[p]; the element it displaces is
+  // carried down PAST the elements equal to it (the reference's strict `>` for displaced elements too) and lands behind its tie
+  // run, displacing the first element of the next run, and so on; the last carry is dropped.  So: position p takes the item,
+  // every later run START takes the FIRST element of the run before it, everything else stays (the tie rotation, quirk Q22).
+  if (threadIdx.x < 64) {
+    const int lane = (int)threadIdx.x;
+    double s = 0.0; long long id = -1; double low = 0.0;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+      const int m = n - r0 < 64 ? n - r0 : 64;
+      const double bs = lane < m ? s_sim[r0 + lane] : 0.0;
+      const long long bi = lane < m ? s_idx[r0 + lane] : -1;
+      for (int j = 0; j < m; ++j) {
+        const double ts = __shfl(bs, j, 64);
+        if (!(ts > low)) continue;                                  // (uniform) search.go:104
+        const long long ti = __shfl(bi, j, 64);
+        const unsigned long long gt = __ballot(lane < k && ts > s);
+        if (!gt) continue;
+        const int p = __builtin_ctzll(gt);
+        const double sprev = __shfl_up(s, 1, 64);
+        const bool start = lane < k && (lane == p || (lane > p && sprev != s));
+        const unsigned long long S = __ballot(start);
+        const unsigned long long below = lane > 0 ? S & ((1ull << lane) - 1ull) : 0ull;
+        const int src = below ? 63 - __builtin_clzll(below) : 0;
+        const double fs = __shfl(s, src, 64);
+        const long long fid = __shfl(id, src, 64);
+        if (lane == p) { s = ts; id = ti; }
+        else if (start) { s = fs; id = fid; }
+        low = __shfl(s, k - 1, 64);
+      }
+    }
+    if (lane < k) { nb_s[lane] = s; nb_i[lane] = id; }
   }
   __syncthreads();
   int cnt = 0;
@@ -631,12 +662,63 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef float f2 __attribute__((ext_vector_type(2)));
   typedef float f4 __attribute__((ext_vector_type(4)));
+  // survivors of the float32 filter are scored exactly and join the query's candidates
+  auto exact = [&](long long it) {
+    const double n2 = norms[it];
+    if (qn == 0 || n2 == 0) return;
+    const double* v = items + (size_t)it * D;
+    double dot = 0;
+    for (int d = 0; d < D; d += 2) {                 // dot += q[d] * v[d], d ascending (searchutil.go:17-20)
+      const d2 x = *reinterpret_cast<const d2*>(v + d);
+      dot += knn_cq[d] * x[0];
+      dot += knn_cq[d + 1] * x[1];
+    }
+    const double sim = dot / qn / n2;                 // searchutil.go:24-25
+    if (!(sim > 0 && sim >= bd)) return;
+    const int pos = atomicAdd(&c_cnt[q], 1);
+    if (pos < KNN2_CAP) {
+      // (device-scope stores: the query's last workgroup -- possibly on another XCD -- reads them in this launch when folded)
+      __hip_atomic_store(c_idx + (size_t)q * KNN2_CAP + pos, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(c_sim + (size_t)q * KNN2_CAP + pos, sim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  const int ipt = tile_items / 256;
+  if (D == 16) {
+    // four of the workgroup's (tile, row group) pairs at a time, all 16 row loads of a thread in flight before the first FMA:
+    // the loop was one memory round trip per row group (20 in a row for a typical query: knn_collect_kernel at 83 % waiting)
+    const int nwork = nmy * ipt;
+    for (int w0 = 0; w0 < nwork; w0 += 4) {
+      f4 x[4][4]; long long its[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int wi = w0 + u;
+        const bool on = wi < nwork;
+        const int tile = my_tiles[on ? wi / ipt : 0];
+        const long long it = (long long)tile * tile_items + (wi % ipt) * 256 + threadIdx.x;
+        its[u] = (on && it < V && it != ig) ? it : -1;
+        const float* v32 = items32 + (size_t)(its[u] >= 0 ? its[u] : 0) * 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) x[u][c] = *reinterpret_cast<const f4*>(v32 + 4 * c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (its[u] < 0) continue;
+        // the filter, in knn_scan_kernel's arithmetic (one packed accumulator, the same order of packed FMAs)
+        f2 acc = f2{0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc = __builtin_elementwise_fma(f2{cq32[4 * c], cq32[4 * c + 1]}, f2{x[u][c][0], x[u][c][1]}, acc);
+          acc = __builtin_elementwise_fma(f2{cq32[4 * c + 2], cq32[4 * c + 3]}, f2{x[u][c][2], x[u][c][3]}, acc);
+        }
+        if (acc[0] + acc[1] >= tb) exact(its[u]);
+      }
+    }
+  } else
   for (int w = 0; w < nmy; ++w) {
     const int tile = my_tiles[w];
-    for (int j = 0; j < tile_items / 256; ++j) {
+    for (int j = 0; j < ipt; ++j) {
       const long long it = (long long)tile * tile_items + j * 256 + threadIdx.x;
       if (it >= V || it == ig) continue;
-      // the filter, in knn_scan_kernel's arithmetic (one packed accumulator, the same order of packed FMAs)
       const float* v32 = items32 + (size_t)it * D;
       f2 acc = f2{0.f, 0.f};
       for (int d = 0; d < D; d += 4) {
@@ -644,24 +726,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
         acc = __builtin_elementwise_fma(f2{cq32[d], cq32[d + 1]}, f2{x[0], x[1]}, acc);
         acc = __builtin_elementwise_fma(f2{cq32[d + 2], cq32[d + 3]}, f2{x[2], x[3]}, acc);
       }
-      if (!(acc[0] + acc[1] >= tb)) continue;
-      const double n2 = norms[it];
-      if (qn == 0 || n2 == 0) continue;
-      const double* v = items + (size_t)it * D;
-      double dot = 0;
-      for (int d = 0; d < D; d += 2) {                 // dot += q[d] * v[d], d ascending (searchutil.go:17-20)
-        const d2 x = *reinterpret_cast<const d2*>(v + d);
-        dot += knn_cq[d] * x[0];
-        dot += knn_cq[d + 1] * x[1];
-      }
-      const double sim = dot / qn / n2;                 // searchutil.go:24-25
-      if (!(sim > 0 && sim >= bd)) continue;
-      const int pos = atomicAdd(&c_cnt[q], 1);
-      if (pos < KNN2_CAP) {
-        // (device-scope stores: the query's last workgroup -- possibly on another XCD -- reads them in this launch when folded)
-        __hip_atomic_store(c_idx + (size_t)q * KNN2_CAP + pos, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(c_sim + (size_t)q * KNN2_CAP + pos, sim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (acc[0] + acc[1] >= tb) exact(it);
     }
   }
   }   // !skip

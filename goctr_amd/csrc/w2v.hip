@@ -973,8 +973,13 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     // that walks only a few dozen positions contributes a few dozen updates' worth of learning to them however many workers
     // there are (V = 10^6, D = 64, 10^6 words on 32 768 streams: HS loss 0.665 against the oracle's 0.624).  So the
     // parallelism is capped by the corpus: at least 256 positions per stream (bench.py's 10^7 words / 32 768 streams = 305).
-    if (env_int_w2v("GOCTR_W2V_MIN_POS", 256) > 0) {
-      const int64_t cap = std::max<int64_t>(1, w->n_words / env_int_w2v("GOCTR_W2V_MIN_POS", 256));
+    // Data-parallel passes take 2048: every stream of every rank starts an exchange interval from the same stale snapshot, and
+    // what the ranks learn beside each other is AVERAGED at the exchange (exchange_deltas), so the learning of an interval is
+    // what ONE rank's streams make of it -- more, shorter streams per rank make less of it.  Measured at cfg5 on W = 8 ranks
+    // (profiles/r05_w2v_dp_gpu_sweep.txt; oracle 0.5587): 256 positions per stream 0.5962, 1024 0.5738, 4096 0.5679.
+    const int min_pos = env_int_w2v(dp ? "GOCTR_W2V_MIN_POS_DP" : "GOCTR_W2V_MIN_POS", dp ? 2048 : 256);
+    if (env_int_w2v("GOCTR_W2V_MIN_POS", 256) > 0 && min_pos > 0) {
+      const int64_t cap = std::max<int64_t>(1, w->n_words / min_pos);
       if ((int64_t)streams > cap) streams = (int)cap;
     }
     // slices = the reference's goroutines (window-clipping units); 0: one slice per stream (every piece clips its own windows)

@@ -18,11 +18,11 @@ p0 = (rng.random((V, dim)) - 0.5) / dim
 pos = rng.integers(1, n - 1, size=4000)
 pairs = list(zip(doc[pos].tolist(), doc[pos + 1].tolist()))
 paths = None
-cases = [("every 1e5, min_pos 256 (default)", 0, 256), ("every 2.5e4", 25000, 256), ("every 1e4", 10000, 256),
+cases = [("every 1e5, min_pos 2048 (default)", 0, 2048), ("every 1e5, min_pos 256", 0, 256), ("every 2.5e4", 25000, 256), ("every 1e4", 10000, 256),
          ("every 1e5, min_pos 1024", 0, 1024), ("every 1e5, min_pos 4096", 0, 4096), ("every 2.5e4, min_pos 1024", 25000, 1024),
          ("once per pass", -1, 256), ("once per pass, min_pos 4096", -1, 4096)]
 for name, every, min_pos in cases:
-    os.environ["GOCTR_W2V_MIN_POS"] = str(min_pos)
+    os.environ["GOCTR_W2V_MIN_POS_DP"] = str(min_pos)
     capi.engine_select(0)
     m = ge.Word2Vec(dim=dim, optimizer="hs", deterministic=False, streams=32768, slices=16, devices=W, exchange_every=every)
     m.create(counts, p0.copy())
