@@ -20,7 +20,6 @@
 #include "common.h"
 #include "ctr_chain.h"
 #include "ctr_chain_x3.h"
-#include "ctr_chain_x16.h"
 #include "emb_train.h"
 #include "emb_plan.h"
 #include "scan.h"
@@ -141,17 +140,11 @@ struct goctr_model {
   DevBuf<float> Wimg;   // LDS images of W0 | W1 | W1^T | W0[U:U+D,:]^T (ctr_chain.h), kept in sync by Adam
   // bf16-plane fragment images of the 6-product-split training chain (ctr_chain_x3.h), kept in sync by the Adam kernels
   DevBuf<unsigned short> Wx3; int x3_nch0 = 0;
-  // ... and of the 16-row training chain (ctr_chain_x16.h); x16_nk0 = 32-k chunks of Ip
-  DevBuf<unsigned short> Wx16; int x16_nk0 = 0;
   CxImages x3_images() {
-    CxImages im{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    CxImages im{nullptr, nullptr, nullptr, nullptr, 0};
     if (!x3_nch0) return im;
     im.nch0 = x3_nch0;
     im.img0 = Wx3.p; im.img1 = im.img0 + cx_img0_elems(x3_nch0); im.img2 = im.img1 + cx_img1_elems(); im.img3 = im.img2 + cx_img2_elems();
-    if (x16_nk0) {
-      im.nk0 = x16_nk0;
-      im.j0 = Wx16.p; im.j1 = im.j0 + c16_j0_elems(x16_nk0); im.j2 = im.j1 + c16_j1_elems(); im.j3 = im.j2 + c16_j2_elems();
-    }
     return im;
   }
   float* img(int which) { return Wimg.p + (which == 0 ? 0 : which == 1 ? off1 : which == 2 ? off1 + H1p * H2p : off1 + 2 * H1p * H2p); }
@@ -477,8 +470,7 @@ int init_kernel_attrs() {
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
       allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(gemm_tn_multi_x3w_kernel<9, 5>) || allow_big_lds(gemm_tn_multi_x3w_kernel<8, 5>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
-      allow_big_lds(ctr_chain_x3_kernel<15>) || allow_big_lds(ctr_chain_x16_kernel<1>) || allow_big_lds(ctr_chain_x16_kernel<5>) ||
-      allow_big_lds(ctr_chain_x16_kernel<8>) || chain_x3_fwd_attributes() ||
+      allow_big_lds(ctr_chain_x3_kernel<15>) || chain_x3_fwd_attributes() ||
       serve16_attributes()) return -1;
   done = true;
   return 0;
@@ -663,7 +655,6 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   ChainX3Args a{};
   a.h0 = fb.h0; a.Ip = m->Ip;
   a.img0 = im.img0; a.img1 = im.img1; a.img2 = im.img2; a.img3 = im.img3; a.w2 = m->W2T.p;
-  a.j0 = im.j0; a.j1 = im.j1; a.j2 = im.j2; a.j3 = im.j3;
   a.H1 = c.H1; a.H2 = c.H2; a.H1p = m->H1p; a.H2p = m->H2p; a.Dp = m->Dp; a.B = B; a.kind = c.kind;
   a.d0 = DropCfg{drop && o.p0 > 0 ? 2 : 0, o.p0, nullptr, c.H1, o.seed, 0u, row_off};
   a.d1 = DropCfg{drop && o.p1 > 0 ? 2 : 0, o.p1, nullptr, c.H2, o.seed, 1u, row_off};
@@ -695,32 +686,9 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   static const char* const kSym[3][2] = {{"ctr_chain_x3_kernel<2,false>", "ctr_chain_x3_kernel<2,true>"},
                                          {"ctr_chain_x3_kernel<9,false>", "ctr_chain_x3_kernel<9,true>"},
                                          {"ctr_chain_x3_kernel<15,false>", "ctr_chain_x3_kernel<15,true>"}};
-  // EXPERIMENT, off by default (GOCTR_CHAIN_X16=1: training launches that would give a CU at most ONE 32-row tile take the
-  // 16-row kernel, ctr_chain_x16.h: two workgroups per CU; =2: every training launch).  Measured at cfg3: 25.8 us against the
-  // 32-row kernel's 20.9 us -- a 16-row tile's dependent pipeline is as long as a 32-row tile's (37 k cycles either way) and two
-  // co-resident workgroups slow each other down instead of filling each other's gaps (profiles/r04_chain_x16_ab.txt).
-  const int x16_mode = env_int("GOCTR_CHAIN_X16", 0);
-  if (o.train && m->x16_nk0 && (x16_mode == 2 || (x16_mode == 1 && ntiles <= std::max(e.compute_units, 1)))) {
-    const dim3 g16((unsigned)cdiv(B, 16));
-    static const char* const kSym16[3] = {"ctr_chain_x16_kernel<1>", "ctr_chain_x16_kernel<5>", "ctr_chain_x16_kernel<8>"};
-    if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, kSym16[m->x16_nk0 == 1 ? 0 : m->x16_nk0 == 5 ? 1 : 2]);
-    switch (m->x16_nk0) {
-      case 1: hipLaunchKernelGGL((ctr_chain_x16_kernel<1>), g16, dim3(512), chain_x16_lds_bytes<1>(), (hipStream_t)e.active, a); break;
-      case 5: hipLaunchKernelGGL((ctr_chain_x16_kernel<5>), g16, dim3(512), chain_x16_lds_bytes<5>(), (hipStream_t)e.active, a); break;
-      default: hipLaunchKernelGGL((ctr_chain_x16_kernel<8>), g16, dim3(512), chain_x16_lds_bytes<8>(), (hipStream_t)e.active, a); break;
-    }
-    GOCTR_HIP(hipGetLastError());
-    if (dbg) {
-      unsigned long long h[CX_NSTAMP];
-      if (dbgbuf.download(h, CX_NSTAMP)) return -1;
-      fprintf(stderr, "chain_x16 phases (s_memtime ticks, wavefront 0 of tile 0): h0 split+barrier %lld | F0 %lld | epi0 %lld | F1 %lld | xchg barrier %lld | "
-              "out+dz1+barrier %lld | B0 %lld | epi+dp %lld | xchg+tail %lld | total %lld\n",
-              (long long)(h[1] - h[0]), (long long)(h[2] - h[1]), (long long)(h[3] - h[2]), (long long)(h[4] - h[3]), (long long)(h[5] - h[4]),
-              (long long)(h[6] - h[5]), (long long)(h[7] - h[6]), (long long)(h[8] - h[7]), (long long)(h[9] > h[8] ? h[9] - h[8] : 0),
-              (long long)((h[9] > h[8] ? h[9] : h[8]) - h[0]));
-    }
-    return 0;
-  }
+  // (Round 4 also built a 16-row tile kernel -- two workgroups per CU -- which lost, 25.8 against 20.9 us at cfg3: a 16-row
+  // tile's dependent pipeline is as long as a 32-row tile's.  The kernel left the tree in round 5; DESIGN_HISTORY.md and
+  // profiles/r04_chain_x16_ab.txt keep the record, git keeps csrc/ctr_chain_x16.h.)
   if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, kSym[m->x3_nch0 == 2 ? 0 : m->x3_nch0 == 9 ? 1 : 2][o.train ? 0 : 1]);
   switch (m->x3_nch0) {
     case 2: launch_chain_x3_n<2>(a, grid, e.active, !o.train); break;
@@ -2140,12 +2108,6 @@ int goctr_model_create(const goctr_ctr_cfg* cfg, goctr_model** out) {
   if (chain_x3_shape_ok(m.get())) {
     m->x3_nch0 = m->Ip / 16;
     if (m->Wx3.alloc(cx_images_elems(m->x3_nch0))) return -1;      // zero = the images of all-zero weights
-    // (the 16-row chain kernel is an opt-in experiment -- it lost to the 32-row kernel, profiles/r04_chain_x16_ab.txt -- so its
-    // images are only kept, and maintained by the Adam kernels, for models created with GOCTR_CHAIN_X16 set)
-    if (env_int("GOCTR_CHAIN_X16", 0) != 0) {
-      m->x16_nk0 = (int)cdiv(m->Ip, 32);
-      if (m->Wx16.alloc(c16_images_elems(m->x16_nk0))) return -1;
-    }
   }
   if (m->st.alloc(2) || m->costs.alloc(COST_RING)) return -1;
   std::vector<float> ones(cfg->T, 1.0f);  // din.go:181 att0 = 1
@@ -2629,7 +2591,6 @@ int model_broadcast(goctr_model* mk, int stp_root, float emb_lr_root) {
   if (bc(mk->W.p, sizeof(float) * mk->nflat) || bc(mk->Mo.p, sizeof(float) * mk->nflat) || bc(mk->Vo.p, sizeof(float) * mk->nflat) ||
       bc(mk->W1T.p, sizeof(float) * mk->W1T.n) || bc(mk->W2T.p, sizeof(float) * mk->W2T.n) || bc(mk->W0sT.p, sizeof(float) * mk->W0sT.n) ||
       bc(mk->Wimg.p, sizeof(float) * mk->Wimg.n) || bc(mk->Wx3.p, mk->x3_nch0 ? sizeof(unsigned short) * mk->Wx3.n : 0) ||
-      bc(mk->Wx16.p, mk->x16_nk0 ? sizeof(unsigned short) * mk->Wx16.n : 0) ||
       bc(mk->st.p, sizeof(StepState) * 2)) return -1;
   if (e.rank != 0) {
     mk->stp = stp_root;

@@ -45,7 +45,6 @@ namespace goctr {
 struct ChainX3Args {
   const float* h0; int Ip;                 // [B, Ip] float32 (attn_fwd)
   const unsigned short* img0; const unsigned short* img1; const unsigned short* img2; const unsigned short* img3;
-  const unsigned short* j0; const unsigned short* j1; const unsigned short* j2; const unsigned short* j3;   // x16 images (ctr_chain_x16.h)
   const float* w2;                         // the output unit's weight column, contiguous [H2p]
   int H1, H2, H1p, H2p, Dp, B; int kind;
   DropCfg d0, d1; const StepState* st;

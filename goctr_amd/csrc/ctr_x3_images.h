@@ -64,44 +64,9 @@ __device__ __forceinline__ void cx_split1(float x, unsigned short& hi, unsigned 
   hi = __builtin_bit_cast(unsigned short, h); mid = __builtin_bit_cast(unsigned short, m); lo = __builtin_bit_cast(unsigned short, l);
 }
 
-// ---- the 16-row chain kernel's images (ctr_chain_x16.h: v_mfma_f32_16x16x32_bf16 fragments, lane = 16 q + m)
-constexpr int C16_NT0 = 14;   // 16-feature tiles of H1 (H1p <= 224)
-constexpr int C16_NW = 7;     // wavefronts that own H1 tiles (two each)
-constexpr int C16_NU = 5;     // 16-feature tiles of H2 (H2p == 80)
-constexpr int C16_NK2 = 3;    // 32-k chunks of H2 (80 -> 96, the last half zero)
-constexpr int C16_NV = 2;     // 16-wide tiles of the dp product (Dp <= 32)
-
-typedef float c16_acc __attribute__((ext_vector_type(4)));
-
-// ---- image index functions (bf16 element units): host (tests of the layout) + device (the Adam kernels' scatter)
-__host__ __device__ inline void c16_perm(int f1, int& cc, int& q, int& s) {
-  const int r = f1 & 31;
-  cc = f1 >> 5; q = (r & 15) >> 2; s = 4 * (r >> 4) + (r & 3);
-}
-__host__ __device__ inline size_t c16_j0_index(int k, int f1, int nk0, int p) {
-  return ((((size_t)(f1 >> 4) * nk0 + (k >> 5)) * 3 + p) * 64 + ((k >> 3) & 3) * 16 + (f1 & 15)) * 8 + (k & 7);
-}
-__host__ __device__ inline size_t c16_j1_index(int f1, int f2, int p) {
-  int cc, q, s; c16_perm(f1, cc, q, s);
-  return ((((size_t)cc * C16_NU + (f2 >> 4)) * 3 + p) * 64 + q * 16 + (f2 & 15)) * 8 + s;
-}
-__host__ __device__ inline size_t c16_j2_index(int f1, int f2, int p) {
-  return ((((size_t)(f1 >> 4) * C16_NK2 + (f2 >> 5)) * 3 + p) * 64 + ((f2 >> 3) & 3) * 16 + (f1 & 15)) * 8 + (f2 & 7);
-}
-__host__ __device__ inline size_t c16_j3_index(int f1, int d, int p) {
-  int cc, q, s; c16_perm(f1, cc, q, s);
-  return ((((size_t)cc * C16_NV + (d >> 4)) * 3 + p) * 64 + q * 16 + (d & 15)) * 8 + s;
-}
-inline size_t c16_j0_elems(int nk0) { return (size_t)C16_NT0 * nk0 * 3 * 512; }
-inline size_t c16_j1_elems() { return (size_t)C16_NW * C16_NU * 3 * 512; }
-inline size_t c16_j2_elems() { return (size_t)C16_NT0 * C16_NK2 * 3 * 512; }
-inline size_t c16_j3_elems() { return (size_t)C16_NW * C16_NV * 3 * 512; }
-inline size_t c16_images_elems(int nk0) { return c16_j0_elems(nk0) + c16_j1_elems() + c16_j2_elems() + c16_j3_elems(); }
-
-// x3 images (32-row kernel, predict) and x16 images (16-row training kernel): j0 == null when the model keeps no x16 images
+// the bf16-plane fragment images of the 32-row chain kernels (training and predict)
 struct CxImages {
   unsigned short* img0; unsigned short* img1; unsigned short* img2; unsigned short* img3; int nch0;
-  unsigned short* j0; unsigned short* j1; unsigned short* j2; unsigned short* j3; int nk0;
 };
 
 // the image entries of ONE parameter (called by the Adam kernels right after the update; idx = index in the padded flat
@@ -123,14 +88,6 @@ __device__ __forceinline__ void cx_scatter_weight(const CxImages& im, float w, i
 #pragma unroll
       for (int p = 0; p < 3; ++p) im.img3[cx_img3_index(f1, k - U, p)] = pl[p];
     }
-    if (im.j0) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) im.j0[c16_j0_index(k, f1, im.nk0, p)] = pl[p];
-      if (k >= U && k < U + Dx && D <= 32) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) im.j3[c16_j3_index(f1, k - U, p)] = pl[p];
-      }
-    }
   } else if (idx < off2) {
     const int e = idx - off1;
     const int f1 = e / H2p, f2 = e - f1 * H2p;
@@ -139,13 +96,6 @@ __device__ __forceinline__ void cx_scatter_weight(const CxImages& im, float w, i
     for (int p = 0; p < 3; ++p) {
       im.img1[cx_img1_index(f1, f2, p)] = pl[p];
       im.img2[cx_img2_index(f1, f2, p)] = pl[p];
-    }
-    if (im.j0) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        im.j1[c16_j1_index(f1, f2, p)] = pl[p];
-        im.j2[c16_j2_index(f1, f2, p)] = pl[p];
-      }
     }
   }
 }

@@ -605,11 +605,15 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   gmax[wave][lane] = m;
   __syncthreads();
   if (wave == 0) {
-    float gm = fmaxf(fmaxf(gmax[0][lane], gmax[1][lane]), fmaxf(gmax[2][lane], gmax[3][lane]));
+    // 256 groups of tiles (tile mod 256): lane L holds the maxima of groups L, 64 + L, 128 + L, 192 + L.  (Round 4 folded them
+    // into 64 groups: the k-th largest of 64 group maxima sits near the 45th best item of a random catalogue, of 256 near the
+    // 13th -- and every listed tile is 64 KB the collect pass reads again, per query.)
+    float g4[4] = {gmax[0][lane], gmax[1][lane], gmax[2][lane], gmax[3][lane]};
     const int rounds = k + (ignore[q] >= 0 ? 1 : 0);
     float kth = 0.f;
     for (int r = 0; r < rounds; ++r) {
-      float bs = gm; int bl = lane;
+      const float mine = fmaxf(fmaxf(g4[0], g4[1]), fmaxf(g4[2], g4[3]));
+      float bs = mine; int bl = lane;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         const float so = __shfl_xor(bs, o, 64);
@@ -618,7 +622,9 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
       }
       if (!(bs > 0.f)) { kth = 0.f; break; }           // (uniform)
       kth = bs;
-      if (lane == bl) gm = -1.f;
+      if (lane == bl) {                                 // retire ONE group holding that maximum
+        if (g4[0] == bs) g4[0] = -1.f; else if (g4[1] == bs) g4[1] = -1.f; else if (g4[2] == bs) g4[2] = -1.f; else g4[3] = -1.f;
+      }
     }
     if (lane == 0) { sh_tb = kth - 2.f * E; sh_sb = kth - E; }
   } else if (threadIdx.x == 64) {

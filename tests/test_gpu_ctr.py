@@ -526,36 +526,3 @@ def test_predict_between_training_calls_leaves_training_untouched(oracle):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
-@pytest.mark.parametrize("kind,D", [(0, 16), (1, 64)])
-def test_sixteen_row_chain_kernel_experiment(oracle, kind, D):
-    """GOCTR_CHAIN_X16=2: the opt-in 16-row chain kernel (csrc/ctr_chain_x16.h -- two workgroups per CU; it lost to the default
-    32-row kernel on time, profiles/r04_chain_x16_ab.txt, and is kept as evidence) computes the same step: id mode, hash dropout,
-    the attention backward at its tail (DIN), a batch that is no multiple of 16, against the default kernel and the oracle"""
-    from goctr_amd import capi, model as gm
-    U, T, Cc, V, rows, B = 52, 50, 53, 400, 700, 200
-    rng = np.random.default_rng(31 + kind)
-    emb = (rng.standard_normal((V, D)) * 0.5).astype(np.float32)
-    ub = rng.integers(-1, V, size=(rows, T)).astype(np.int32)
-    it = rng.integers(0, V, size=rows).astype(np.int32)
-    uf = rng.random((rows, U), dtype=np.float32); cf = rng.random((rows, Cc), dtype=np.float32)
-    y = (rng.random(rows) < 0.5).astype(np.float32)
-    tab = gm.EmbeddingTable(emb)
-    ds = gm.Dataset.ids(ub, it, uf, cf, y)
-    X = tab.gather_rows(ub, it, uf, cf)
-    res = []
-    for x16 in ("0", "2"):
-        os.environ["GOCTR_CHAIN_X16"] = x16
-        try:
-            om, dm, si = pair(oracle, kind, U, T, D, Cc, np.random.default_rng(15), scale=0.15)
-            cfg = capi.default_train_cfg(batch=B, epochs=1, dropout_mode=2, p0=0.1, p1=0.1, seed=5)
-            costs = gm.train_steps(dm, ds, cfg, 7, emb=tab, want_costs=True)
-            res.append((costs, dm.get_weights("mlp0"), dm.get_weights("mlp1"), dm.get_weights("att0")))
-        finally:
-            os.environ.pop("GOCTR_CHAIN_X16", None)
-    assert np.isfinite(res[1][0]).all()
-    assert np.max(np.abs(res[0][0] - res[1][0])) <= 1e-5                        # costs: the two kernels sum K in 16- / 32-wide chunks
-    for a, b in zip(res[0][1:], res[1][1:]):
-        assert np.max(np.abs(a - b)) <= 1e-4
-    ref = om.train_batches(X, y, batch=B, steps=7, dropout=(0.1, 0.1, 5)) if hasattr(om, "train_batches") else None
-    if ref is not None:
-        assert np.max(np.abs(res[1][0] - ref)) <= 5e-5
