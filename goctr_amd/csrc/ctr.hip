@@ -83,7 +83,6 @@ struct StepGraph {
   uint64_t ds = 0, emb = 0; int B = 0; int mode = 0; float p0 = 0, p1 = 0;
   uint32_t seed = 0; double lr = 0, l2 = 0, b1 = 0, b2 = 0, eps = 0; int flags = 0; int world = 1; bool comm = false;
   bool pipelined = false;   // the captured steps are pipelined (StepOpts::pipelined): a replay needs h0 of its first step
-  bool forked = false;      // ... with the next batch's attention on the side stream (StepOpts::forked)
   void destroy() {
     // goctr_train_steps does not synchronise: replays of these execs may still be queued or running, and destroying an
     // exec in flight is not something HIP documents as safe.  The capture that follows a destroy is host-heavy anyway.
@@ -153,9 +152,6 @@ struct goctr_model {
   DevBuf<float> h0, P0, A0, P1, A1, yhat, lossrow, dz2, dz1, dz0, dp, gate, wgt, slabs0, slabs1, slabs2, attp;
   DevBuf<float> mask0, mask1, slabs3, ones16;
   size_t gw_stride = 0;           // floats between the two parity copies of gate / wgt
-  size_t h0_stride = 0;           // ... and of h0 (forked pipeline: the next step's h0 is written while this step's launches read theirs)
-  float* h0_p(int par) { return h0.p + (size_t)par * h0_stride; }
-  DevBuf<float> att0_partial; DevBuf<unsigned int> att0_ticket;   // att0_step_kernel (forked pipeline, DIN)
   float* gate_p(int par) { return gate.p + (size_t)par * gw_stride; }
   float* wgt_p(int par) { return wgt.p + (size_t)par * gw_stride; }
   DevBuf<unsigned int> ra_flag;   // pipelined steps: gstep + 1 of the last step whose att0 update is visible device-wide (reduce_attn_kernel)
@@ -234,13 +230,12 @@ int env_int(const char* name, int dflt) {
 #ifndef GOCTR_TN_CH
 #define GOCTR_TN_CH 32
 #endif
-bool att0_early_ok(const goctr_model* m);      // (below: att0's gradient does not come from this launch then)
 struct TnSchedule { int rows, S, rows_light, S_light; };
 TnSchedule tn_schedule(const goctr_model* m, int B) {
   TnSchedule t{};
   const int forced = env_int("GOCTR_TN_ROWS", 0);
   const int heavy = (int)cdiv(m->Ip / 16, 3) + (int)cdiv(m->H2p / 16, 3);
-  const int light = (m->cfg.kind == GOCTR_DIN && !att0_early_ok(m)) ? 2 : 1;
+  const int light = m->cfg.kind == GOCTR_DIN ? 2 : 1;
   int cus = engine().compute_units > 0 ? engine().compute_units : 256;
   const int lf = env_int("GOCTR_TN_LIGHT", 25);   // light slab height = lf/10 x the heavy one
   // workgroups(rows) = heavy*ceil(B/rows) + light*ceil(B/(lf rows)) <= cus ; smallest such rows (multiple of 4)
@@ -267,7 +262,7 @@ TnWide tn_schedule_wide_search(const goctr_model* m, int B);
 TnWide tn_schedule_wide(const goctr_model* m, int B) {
   static std::mutex mu;
   static std::map<std::array<int, 12>, TnWide> cache;
-  const std::array<int, 12> key{B, m->Ip, m->H1p, m->H2p, m->cfg.kind + (att0_early_ok(m) ? 16 : 0), engine().compute_units, env_int("GOCTR_TN_WIDE", 1),
+  const std::array<int, 12> key{B, m->Ip, m->H1p, m->H2p, m->cfg.kind, engine().compute_units, env_int("GOCTR_TN_WIDE", 1),
                                 env_int("GOCTR_TN_FIX0", 512), env_int("GOCTR_TN_FIX1", 384), env_int("GOCTR_TN_C0", 0),
                                 env_int("GOCTR_TN_C1", 0), env_int("GOCTR_TN_RL", 0)};
   std::lock_guard<std::mutex> lk(mu);
@@ -285,7 +280,7 @@ TnWide tn_schedule_wide_search(const goctr_model* m, int B) {
   w.ktw0 = kt0 == 9 ? 9 : 8; w.kblocks0 = (int)cdiv(kt0, w.ktw0); w.nbt = (int)cdiv(nt, 2);
   const int cols0 = w.ktw0 * 16 + w.nbt * 16, cols1 = kt1 * 16 + w.nbt * 16;
   const int colsL = 16 + kt1 * 16;
-  const int blocks0 = w.kblocks0 * 2, blocks1 = 2, light = (m->cfg.kind == GOCTR_DIN && !att0_early_ok(m)) ? 2 : 1;
+  const int blocks0 = w.kblocks0 * 2, blocks1 = 2, light = m->cfg.kind == GOCTR_DIN ? 2 : 1;
   const int cus = engine().compute_units > 0 ? engine().compute_units : 256;
   // cost of a workgroup in "staged columns": chunks x columns per chunk + a fixed part (start, first chunk, slab stores)
   const int fix0 = env_int("GOCTR_TN_FIX0", 512), fix1 = env_int("GOCTR_TN_FIX1", 384), fixL = 384;
@@ -314,15 +309,12 @@ TnWide tn_schedule_wide_search(const goctr_model* m, int B) {
   return w;
 }
 int tn_max_slabs(int B) { return (int)cdiv(B, 32); }
-constexpr int kAtt0Blocks = 64;     // workgroups of att0_step_kernel (each sums B / 64 rows of the per-sample terms)
 
 int ensure_workspace(goctr_model* m, int B) {
   if (m->wsB >= B && m->tnS > 0) return 0;
   const int S = tn_max_slabs(B);   // upper bound over every schedule tn_schedule() can pick
   m->tnS = S;
-  if (m->h0.alloc((size_t)2 * B * m->Ip)) return -1;               // two copies by step parity, like gate / wgt below
-  m->h0_stride = (size_t)B * m->Ip;
-  if (m->att0_partial.alloc((size_t)kAtt0Blocks * 64) || m->att0_ticket.alloc(1)) return -1;
+  if (m->h0.alloc((size_t)B * m->Ip)) return -1;
   if (m->P0.alloc((size_t)B * m->H1p)) return -1;
   if (m->A0.alloc((size_t)B * m->H1p)) return -1;
   if (m->P1.alloc((size_t)B * m->H2p)) return -1;
@@ -521,10 +513,6 @@ int launch_attn_fwd(const AttnArgs& a) {
     else if (fast == 2) hipLaunchKernelGGL((attn_fwd_kernel<4, L, 2>), grid, blk, 0, st, a);       \
     else hipLaunchKernelGGL((attn_fwd_kernel<4, L, 3>), grid, blk, 0, st, a);                      \
   } while (0)
-  if (fast == 1 && groups == 16 && a.next && env_int("GOCTR_ATTN_LEAN", 1) != 0) {
-    // forked pipeline, D = 64 rows: the register-capped variant fits beside a weight-gradient workgroup (attn_fwd_lean_kernel)
-    hipLaunchKernelGGL((attn_fwd_lean_kernel<4, 16, 1>), grid, blk, 0, st, a);
-  } else
   if (fast && groups <= 16) {
     if (groups == 1) GOCTR_ATTN_FWD_FAST(1);
     else if (groups == 2) GOCTR_ATTN_FWD_FAST(2);
@@ -597,12 +585,6 @@ struct StepOpts {
   // pipelined steps (graph replay, single GPU): a step's h0 was computed by the PREVIOUS step's last launch
   // (reduce_attn_kernel, ctr_kernels.h) -- launch_forward skips attn_fwd, launch_backward ends with the merged launch
   bool pipelined = false;
-  // forked pipeline (a pipelined step, frozen embeddings, no communicator): the next batch's attn_fwd runs on the engine's SIDE
-  // stream beside this step's launches instead of inside its last one.  YouTube-DNN: mean pooling depends on no weight, the
-  // fork is the step's first act (the HBM-bound gather of cfg4 under the MFMA-bound chain and weight-gradient launches).  DIN:
-  // att0_step_kernel updates att0 as soon as the chain launch has left the per-sample terms, then the attention follows --
-  // beside the weight-gradient and reduce launches.  The step's last launch is then the plain reduce_adam_kernel.
-  bool forked = false;
 };
 
 // the fused chain kernel covers the reference's fixed hidden widths (200 -> 13 tiles, 80 -> 5 tiles)
@@ -803,7 +785,7 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
 
 // forward part: kernels 1-4
 // `par`: which copy of gate / wgt the launch writes (the parity of the step the gather belongs to)
-FwdBufs train_bufs(goctr_model* m, int par) { return FwdBufs{m->h0_p(par), m->gate_p(par), m->wgt_p(par), m->yhat.p, m->P0.p, m->P1.p}; }
+FwdBufs train_bufs(goctr_model* m, int par) { return FwdBufs{m->h0.p, m->gate_p(par), m->wgt_p(par), m->yhat.p, m->P0.p, m->P1.p}; }
 AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb) {
   const goctr_ctr_cfg& c = m->cfg;
   AttnArgs aa{};
@@ -825,6 +807,9 @@ int attn_fast_mode(const goctr_model* m, const RowSource& src, int* groups) {
   const bool small_table = (unsigned long long)(src.V + 1) * (unsigned long long)c.D * 4ull < (1ull << 32);   // (32-bit row offsets in those kernels)
   return !(vec4 && small_table && g * 4 == c.D && (g & (g - 1)) == 0) ? 0 : c.kind != GOCTR_DIN ? 1 : (c.att == GOCTR_ATT_COSINE ? 2 : 3);
 }
+// (Round 5 tried the next batch's attention on a second stream BESIDE the weight-gradient and reduce launches instead of inside
+// the step's last launch: it lost, 58.5 against 46.2 us per cfg3 step -- the two branches slow each other down by what they were
+// to hide, and a cross-stream edge in a captured graph costs ~6 us here; profiles/r05_fork_ab.txt, commits 0af81b4 .. ae775f3.)
 // can the steps of a graph be pipelined (reduce_attn_kernel)?  Single GPU, fused update, the fused chain, D = 16 or 64 rows
 bool pipeline_ok(const goctr_model* m, const RowSource& src) {
   int groups = 0;
@@ -840,49 +825,6 @@ bool pipeline_ok(const goctr_model* m, const RowSource& src) {
   }
   return fast != 0 && (groups == 4 || groups == 16) && one_block && chain_ok(m) &&
          env_int("GOCTR_FUSED_UPDATE", 1) != 0 && env_int("GOCTR_PIPELINE", 1) != 0;
-}
-
-// DIN with frozen embeddings and T <= 64: att0's gradient (fused step: its update too) comes from att0_step_kernel, as soon as
-// the per-sample terms exist, in every step path (GOCTR_ATT0_EARLY=0: the ones-column product of the weight-gradient launch)
-bool att0_early_ok(const goctr_model* m) {
-  return m->cfg.kind == GOCTR_DIN && m->Tp <= 64 && m->emb_lr <= 0.f && env_int("GOCTR_ATT0_EARLY", 1) != 0;
-}
-// may a pipelined step fork the next batch's attention onto the side stream (StepOpts::forked)?
-// DIN only by default.  YouTube-DNN's gather depends on no weight and could fork anywhere, but it is the HBM-bound launch of the
-// step and nothing it can run beside gains from its company (round 5, profiles/r05_fork_ab.txt, cfg4): forked at the step's start
-// the chain workgroups (8 x 252 registers: a whole CU each) queue behind its 4096 workgroups, 108.4 vs 90.6 us per step; forked
-// beside the weight-gradient launch (register-capped to fit next to its workgroups) that launch -- itself waiting on memory
-// 53 % of its cycles -- takes 52.4 instead of 26.6 us, 106.5 vs 90.2 us per step.  GOCTR_FORK_YT=1 reproduces the second.
-bool fork_ok(const goctr_model* m, const RowSource& src) {
-  const bool kind_ok = m->cfg.kind == GOCTR_DIN ? att0_early_ok(m) : env_int("GOCTR_FORK_YT", 0) != 0;
-  return src.id_mode && !engine().comm_active() && m->emb_lr <= 0.f && kind_ok && engine().side && env_int("GOCTR_FORK_ATTN", 1) != 0;
-}
-// launches between side_begin() and side_end() go to the engine's side stream, ordered behind everything the main stream holds
-// at side_begin(); side_join() makes the main stream wait for them.  Events, so the same calls build the fork / join edges of a
-// captured graph and order two real streams when the step is issued eagerly.
-int side_begin() {
-  Engine& e = engine();
-  GOCTR_HIP(hipEventRecord(e.ev_fork[0], e.stream));
-  GOCTR_HIP(hipStreamWaitEvent(e.side, e.ev_fork[0], 0));
-  e.active = e.side;
-  return 0;
-}
-int side_end() {
-  Engine& e = engine();
-  e.active = e.stream;
-  GOCTR_HIP(hipEventRecord(e.ev_join, e.side));
-  return 0;
-}
-int side_join() {
-  Engine& e = engine();
-  GOCTR_HIP(hipStreamWaitEvent(e.stream, e.ev_join, 0));
-  return 0;
-}
-// the next batch's h0 / gates (parity stp ^ 1) from the CURRENT step's state: the launch reads cursor + 1 itself
-int launch_attn_next(goctr_model* m, const RowSource& src, int B) {
-  AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp ^ 1);
-  aa.next = 1;
-  return launch_attn_fwd(aa);
 }
 
 int launch_reduce_attn(goctr_model* m, const RowSource& src, int B, const ReduceAdamArgs& p) {
@@ -1430,35 +1372,6 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     if (launch_emb_plan_early(m, src, B, st)) return -1;
   }
 
-  if (o.pipelined && o.forked && c.kind != GOCTR_DIN) {
-    // Mean pooling depends on no weight, so the next batch's gather could leave at the step's start -- measured (round 5,
-    // profiles/r05_fork_ab.txt): 108.4 vs 90.6 us per cfg4 step, WORSE: a chain workgroup is 8 wavefronts x 252 registers, the
-    // whole register file of its CU, so nothing runs beside it and the gather's 4096 workgroups only delay its dispatch.  The
-    // weight-gradient workgroups (8 x 202 registers) leave room for one more wavefront per SIMD: the fork is here.
-    if (side_begin()) return -1;
-    const int rc = launch_attn_next(m, src, B);
-    if (side_end() || rc) return -1;
-  }
-  const bool att0_early = att0_early_ok(m);
-  if (att0_early && stage != 2) {
-    // the per-sample terms of the att0 gradient are out (chain tail / attn_bwd): att0_step_kernel sums them (and, in a fused
-    // step, updates att0).  Forked pipeline: on the side stream, with the next batch's attention behind it -- beside the
-    // weight-gradient and reduce launches below.
-    Att0StepArgs as{};
-    as.terms = m->attp.p; as.B = B; as.Tp = m->Tp; as.partial = m->att0_partial.p; as.ticket = m->att0_ticket.p;
-    as.ad = make_adam_args(m, B, *o.tc); as.update = fuse_update ? 1 : 0;
-    const bool side = o.pipelined && o.forked;
-    if (side && side_begin()) return -1;
-    hipLaunchKernelGGL(att0_step_kernel, dim3(kAtt0Blocks), dim3(256), 0, (hipStream_t)engine().active, as);
-    int rc = hipGetLastError() == hipSuccess ? 0 : -1;
-    if (rc) set_error("att0_step_kernel launch failed");
-    if (side) {
-      if (!rc) rc = launch_attn_next(m, src, B);
-      if (side_end()) rc = -1;
-    }
-    if (rc) return -1;
-  }
-
   // weight gradients: all GEMMs in one launch; dW1 and dW2 are posed transposed, datt0 is a ones-column
   // product over the per-sample terms (see mfma_gemm.h: gemm_tn_multi_kernel)
   int nt_max = m->H1p / 16;
@@ -1471,14 +1384,14 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     TnMulti tm{};
     tm.M = B; tm.np = 3;
     const int b0 = tw.kblocks0 * 2 * tw.S0, b1 = 2 * tw.S1;
-    tm.p[0] = {m->h0_p(m->stp), m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, m->slabs0.p,
+    tm.p[0] = {m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, m->slabs0.p,
                (unsigned long long)m->Ip * m->H1p, 0, m->H1p, 0, tw.rows0, tw.S0, 2, tw.nbt};
     tm.p[1] = {m->dz1.p, m->H2p, m->H2p / 16, A0, m->H1p, m->H1p / 16, m->slabs1.p,
                (unsigned long long)m->H1p * m->H2p, 1, m->H2p, b0, tw.rows1, tw.S1, 2, tw.nbt};
     tm.p[2] = {m->dz2.p, 16, 1, A1, m->H2p, m->H2p / 16, m->slabs2.p, (unsigned long long)m->H2p * 16, 1, 16,
                b0 + b1, tw.rowsL, tw.SL, 0, 0};
     int nblk = b0 + b1 + tw.SL;
-    if (c.kind == GOCTR_DIN && !att0_early) {  // datt0 = ones^T . dgs  (column sums over the batch)
+    if (c.kind == GOCTR_DIN) {  // datt0 = ones^T . dgs  (column sums over the batch)
       tm.p[3] = {m->ones16.p, 16, 1, m->attp.p, m->Tp, m->Tp / 16, m->slabs3.p, (unsigned long long)16 * m->Tp, 0, m->Tp,
                  nblk, tw.rowsL, tw.SL, 0, 0};
       tm.np = 4;
@@ -1510,14 +1423,14 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     TnMulti tm{};
     tm.M = B; tm.np = 3;
     const int kb0 = (int)cdiv(m->Ip / 16, 3), kb1 = (int)cdiv(m->H2p / 16, 3), kb2 = 1;
-    tm.p[0] = {m->h0_p(m->stp), m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, m->slabs0.p,
+    tm.p[0] = {m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, m->slabs0.p,
                (unsigned long long)m->Ip * m->H1p, 0, m->H1p, 0, rpw, S};
     tm.p[1] = {m->dz1.p, m->H2p, m->H2p / 16, A0, m->H1p, m->H1p / 16, m->slabs1.p,
                (unsigned long long)m->H1p * m->H2p, 1, m->H2p, kb0 * S, rpw, S};
     tm.p[2] = {m->dz2.p, 16, 1, A1, m->H2p, m->H2p / 16, m->slabs2.p, (unsigned long long)m->H2p * 16, 1, 16,
                (kb0 + kb1) * S, rpl, SL};
     int nblk = (kb0 + kb1) * S + kb2 * SL;
-    if (c.kind == GOCTR_DIN && !att0_early) {  // datt0 = ones^T . dgs  (column sums over the batch)
+    if (c.kind == GOCTR_DIN) {  // datt0 = ones^T . dgs  (column sums over the batch)
       tm.p[3] = {m->ones16.p, 16, 1, m->attp.p, m->Tp, m->Tp / 16, m->slabs3.p, (unsigned long long)16 * m->Tp, 0, m->Tp,
                  nblk, rpl, SL};
       tm.np = 4;
@@ -1553,12 +1466,12 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
                 (long long)(h[8 * w + 3] - h[8 * w + 1]), (long long)(h[8 * w + 4] - h[8 * w + 3]), (long long)(h[8 * w + 4] - h[8 * w]));
     }
   } else {
-    if (launch_tn(GOCTR_K_DW0, m->h0_p(m->stp), m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, B, rpw, m->slabs0.p,
+    if (launch_tn(GOCTR_K_DW0, m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, B, rpw, m->slabs0.p,
                   (size_t)m->Ip * m->H1p)) return -1;
     if (launch_tn(GOCTR_K_DW1, A0, m->H1p, m->H1p / 16, m->dz1.p, m->H2p, m->H2p / 16, B, rpw, m->slabs1.p,
                   (size_t)m->H1p * m->H2p)) return -1;
     if (launch_tn(GOCTR_K_DW2, A1, m->H2p, m->H2p / 16, m->dz2.p, 16, 1, B, rpw, m->slabs2.p, (size_t)m->H2p * 16)) return -1;
-    if (c.kind == GOCTR_DIN && !att0_early &&
+    if (c.kind == GOCTR_DIN &&
         launch_tn(GOCTR_K_DW2, m->ones16.p, 16, 1, m->attp.p, m->Tp, m->Tp / 16, B, rpw, m->slabs3.p, (size_t)16 * m->Tp))
       return -1;
   }
@@ -1570,11 +1483,10 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   ra.seg[1] = {m->slabs1.p, S1, (unsigned long long)m->H1p * m->H2p, m->off1, m->H1p * m->H2p};
   ra.seg[2] = {m->slabs2.p, multi ? SLx : S, (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
   ra.nseg = 3;
-  if (c.kind == GOCTR_DIN && !att0_early) {
+  if (c.kind == GOCTR_DIN) {
     ra.seg[3] = {m->slabs3.p, multi ? SLx : S, (unsigned long long)16 * m->Tp, m->offa, m->Tp};
     ra.nseg = 4;
   }
-  if (att0_early) { ra.skip_begin = m->offa; ra.skip_end = m->offa + m->Tp; }
   ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st_cur(); ra.st_out = m->st_next(); ra.advance = advance ? 1 : 0;
   if (stage == 1) { m->pend_ra = ra; return 0; }
   return launch_reduce_part(m, src, B, o, advance, fuse_update, ra);
@@ -1588,13 +1500,11 @@ int launch_reduce_part(goctr_model* m, const RowSource& src, int B, const StepOp
     p.r = ra; p.ad = make_adam_args(m, B, *o.tc);
     p.ra_flag = m->ra_flag.p; p.ra_block = (o.pipelined && c.kind == GOCTR_DIN) ? (m->offa * 2) / 256 : -1;
     ProfScope ps(GOCTR_K_REDUCE);
-    if (o.pipelined && !o.forked) {
+    if (o.pipelined) {
       if (launch_reduce_attn(m, src, B, p)) return -1;     // + attn_fwd of the next step's batch
     } else {
-      if (o.pipelined && o.forked) p.ra_block = -1;
       hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)cdiv((int64_t)m->nflat * 2, 256) + 1), dim3(256), 0, e.stream, p);
       GOCTR_HIP(hipGetLastError());
-      if (o.pipelined && o.forked && side_join()) return -1;     // the next step's chain needs both branches
     }
     m->stp ^= 1;   // the step is closed: later launches read the slot just written
     return 0;
@@ -1685,7 +1595,7 @@ bool graph_matches(const StepGraph& g, const goctr_dataset* d, const goctr_emb* 
   return g.a[0] && g.a[1] && g.ds == d->uid && g.emb == (e ? e->uid : 0) && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
          g.seed == o.seed && g.lr == o.tc->lr && g.l2 == o.tc->l2 && g.b1 == o.tc->beta1 && g.b2 == o.tc->beta2 &&
          g.eps == o.tc->eps && g.flags == o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div &&
-         g.world == engine().eff_world() && g.comm == engine().comm_active() && g.pipelined == o.pipelined && g.forked == o.forked;
+         g.world == engine().eff_world() && g.comm == engine().comm_active() && g.pipelined == o.pipelined;
 }
 
 int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, const RowSource& src, int B,
@@ -1732,7 +1642,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   sg.ds = d->uid; sg.emb = emb ? emb->uid : 0; sg.B = B; sg.mode = o.drop_mode; sg.p0 = o.p0; sg.p1 = o.p1; sg.seed = o.seed;
   sg.lr = o.tc->lr; sg.l2 = o.tc->l2; sg.b1 = o.tc->beta1; sg.b2 = o.tc->beta2; sg.eps = o.tc->eps;
   sg.flags = o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div; sg.world = e.eff_world(); sg.comm = e.comm_active();
-  sg.pipelined = o.pipelined; sg.forked = o.forked;
+  sg.pipelined = o.pipelined;
   stp_guard.ok = true;
   return 0;
 }
@@ -1897,7 +1807,7 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
   // (with a communicator and NO plan the sparse embedding exchange sizes its collectives from device counters read back by
   // the host: eager steps.  With the plan's fixed-size buckets the step is three captured graphs around the collectives.)
   const bool use_graph = !e.prof && env_int("GOCTR_NO_GRAPH", 0) == 0 && !(e.comm_active() && m->emb_lr > 0.f && !emb_split3(m));
-  if (use_graph) { o.pipelined = pipeline_ok(m, src); o.forked = o.pipelined && fork_ok(m, src); }
+  if (use_graph) o.pipelined = pipeline_ok(m, src);
   // The previous call ended exactly where this one starts and nothing happened in between (goctr_model::H0Carry): its last
   // launch computed this call's first h0 / gates, and its last loss block left the state this call starts from -- cursor,
   // Adam's bias corrections and all.
@@ -1970,7 +1880,7 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
     // the replayed step): the pipelined launch sequence -- chain, weight gradients, reduce_attn with the next step's attention --
     // issued eagerly, launch by launch, instead of as a captured graph
     if (!e.prof && !e.comm_active() && n_steps > 0 && env_int("GOCTR_EAGER_PIPELINE", 0) != 0 && pipeline_ok(m, src)) {
-      o.pipelined = true; o.forked = fork_ok(m, src);
+      o.pipelined = true;
       const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
       if (launch_attn_fwd(aa)) return -1;
     }

@@ -103,7 +103,6 @@ struct AttnArgs {
   float* gate;  // [B, T]
   float* wgt;   // [B, T]
   int Tp_att;   // (reduce_attn_kernel) padded length of the att0 segment of the flat parameter buffer
-  int next;     // 1: the rows of the batch AFTER the state's cursor (forked pipeline: the next step's h0 beside this step's launches)
 };
 
 // DPP lane exchanges (VALU, no LDS crossbar): quad_perm / row_half_mirror / row_mirror / row_ror
@@ -425,18 +424,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
 
 template <int VEC, int LPR, int FAST>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-  long long bi = a.st->batch_idx;
-  if (a.next) { bi += 1; if (bi >= a.st->n_batches) bi = 0; }     // advance_state()'s cursor (reduce_adam_body)
-  attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x, bi, a.att0);
-}
-// The same body under a register cap (5 wavefronts per SIMD => at most 96 VGPRs; the D = 64 instance takes 114 uncapped): the
-// forked pipeline runs the next batch's gather BESIDE the weight-gradient launch, whose workgroups hold 2 x 208 of a SIMD's 512
-// registers -- one 96-register wavefront fits next to them, a 120-register one does not.
-template <int VEC, int LPR, int FAST>
-__global__ __launch_bounds__(256, 5) void attn_fwd_lean_kernel(AttnArgs a) {
-  long long bi = a.st->batch_idx;
-  if (a.next) { bi += 1; if (bi >= a.st->n_batches) bi = 0; }
-  attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x, bi, a.att0);
+  attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x, a.st->batch_idx, a.att0);
 }
 // serving passes: the rows come from (user, item, timestamp) keys (RowSource key mode) -- key assembly and attention in one launch
 template <int LPR, int FAST>
@@ -599,7 +587,6 @@ struct ReduceArgs {
   StepState* st_out;     // advance == 1: where the NEXT step's state is written (the other ping-pong slot, so
                          // no kernel of this step can observe the update: no inter-workgroup ordering needed)
   int advance;        // 1: this launch closes the step (++gstep, next batch)
-  int skip_begin, skip_end;   // parameters [skip_begin, skip_end) -- att0 -- are att0_step_kernel's (gradient and, fused, update)
 };
 
 __device__ __forceinline__ void advance_state(const StepState* in, StepState* out) {
@@ -674,7 +661,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceArgs a) {
     acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
     acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
   }
-  if (p == 0 && e0 < a.nflat && !(e0 >= a.skip_begin && e0 < a.skip_end)) *reinterpret_cast<float4*>(a.G + e0) = acc;
+  if (p == 0 && e0 < a.nflat) *reinterpret_cast<float4*>(a.G + e0) = acc;
 }
 #endif
 
@@ -859,8 +846,7 @@ __device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int bl
   } else {
     const int gid = blk * 256 + threadIdx.x;
     const int e0 = (gid >> 3) * 4, pl = gid & 7;
-    const bool mine = pl < 4 && e0 + pl < a.nflat &&         // lanes 0..3 of a group own one parameter each
-                      !(e0 + pl >= a.skip_begin && e0 + pl < a.skip_end);
+    const bool mine = pl < 4 && e0 + pl < a.nflat;           // lanes 0..3 of a group own one parameter each
     float w0 = 0.f, m0 = 0.f, v0 = 0.f;
     if (mine) { w0 = p.ad.W[e0 + pl]; m0 = p.ad.Mo[e0 + pl]; v0 = p.ad.Vo[e0 + pl]; }
     const float corr1 = a.st->corr1, corr2 = a.st->corr2;    // (the step's bias corrections travel with its state)
@@ -886,81 +872,6 @@ __device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int bl
     }
   }
 }
-
-// ---------------------------------------------------------------- DIN: att0's gradient (and update) ahead of everything else
-// (Used by EVERY step path of a frozen-embedding DIN model with T <= 64 -- eager, graph, data parallel -- so that they keep
-// producing the same bits; round 1-4 got this gradient from a ones-column product of the weight-gradient launch.)
-// A pipelined step's last launch used to compute the NEXT batch's attention beside the slab reduce (reduce_attn_kernel), because
-// the attention needs the new att0 and att0's gradient came out of the weight-gradient launch.  But the per-sample terms of that
-// gradient (attp [B, Tp], written by the chain kernel's tail) exist as soon as the chain launch ends: this kernel sums them over
-// the batch and applies Adam to att0's Tp entries, so that the next batch's attn_fwd can run on a second stream BESIDE the
-// weight-gradient and reduce launches instead of behind them (ctr.hip: StepOpts::forked).
-//   blocks 0 .. n-1: block k sums rows [k R, (k + 1) R) (thread = column t x row phase: coalesced 256-byte rows, four phases met
-//   in LDS) -> partial[k][t]; a ticket elects the LAST block to finish, which adds the n partials in block order (fixed order:
-//   the result does not depend on which block is last) and makes the update.  Fan-in across the eight non-coherent L2s: the
-//   partials are written with device-scope stores before the ticket and read back with device-scope loads.
-struct Att0StepArgs { const float* terms; int B, Tp; float* partial; unsigned int* ticket; AdamArgs ad; int update; };
-#ifndef GOCTR_NO_PLAIN_KERNELS
-__global__ __launch_bounds__(256) void att0_step_kernel(Att0StepArgs p) {
-  __shared__ float red[4][64];
-  __shared__ unsigned int is_last;
-  const int t = threadIdx.x & 63, ph = threadIdx.x >> 6;
-  const int nb = (int)gridDim.x;
-  const int R = (p.B + nb - 1) / nb;
-  const int r0 = (int)blockIdx.x * R, r1 = r0 + R < p.B ? r0 + R : p.B;
-  float s = 0.f;
-  if (t < p.Tp) {
-    float v[8];                                             // eight rows in flight per thread
-    for (int r = r0 + ph; r < r1; r += 32) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const int rr = r + 4 * u; v[u] = rr < r1 ? p.terms[(size_t)rr * p.Tp + t] : 0.f; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-  }
-  red[ph][t] = s;
-  __syncthreads();
-  if (ph == 0 && t < p.Tp) {
-    const float tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-    __hip_atomic_store(p.partial + (size_t)blockIdx.x * 64 + t, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // No device-scope release / acquire FENCES here: a release fence writes back every dirty line of the XCD's L2 and an acquire
-  // invalidates it -- under the weight-gradient launch that runs beside this kernel (reduce_adam_body's att0 block makes the same
-  // point).  The partials are device-scope (write-through) stores, the barrier's s_waitcnt sees them acknowledged before the
-  // ticket is taken, and the last block reads them back with device-scope loads.
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // (compiler-level: the ticket must not move above the barrier)
-    const unsigned int prev = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = prev == (unsigned int)nb - 1u ? 1u : 0u;
-    if (is_last) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next step
-  }
-  __syncthreads();
-  if (!is_last) return;
-  // all nb x 64 partials into LDS first -- every thread has its 16 device-scope loads in flight at once (a loop `g += load(k)`
-  // in 64 threads is 64 dependent round trips to memory: 20-26 us measured, profiles/r05_fork_ab.txt) -- then the fixed-order sum
-  __shared__ float part[64 * 64];
-  {
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = (int)threadIdx.x + 256 * u;
-      v[u] = i < nb * 64 ? __hip_atomic_load(p.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) part[(int)threadIdx.x + 256 * u] = v[u];
-  }
-  __syncthreads();
-  if (threadIdx.x < p.Tp) {
-    float g = 0.f;
-    for (int k = 0; k < nb; ++k) g += part[k * 64 + (int)threadIdx.x];
-    // fused single-GPU step: the update itself (the step's bias corrections: reduce_adam_body).  Otherwise (gradient entry,
-    // data-parallel step: reduce | all-reduce | Adam) only the gradient, where reduce_kernel leaves the att0 segment alone.
-    if (p.update) adam_apply(p.ad, p.ad.offa + (int)threadIdx.x, g, p.ad.st->corr1, p.ad.st->corr2);
-    else p.ad.G[p.ad.offa + (int)threadIdx.x] = g;
-  }
-}
-#endif
 
 // the bias corrections of the state a call starts from (set_state / a restored checkpoint / a retargeted cursor leave them
 // to this launch; inside a call every step's loss block writes the next state's)
