@@ -12,6 +12,15 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# Multi-epoch training COSTS of the reduced-size shapes below are held to 5e-5, not to the 1e-5 of logits / loss / the full-size
+# tests (tests/test_gpu_fullsize.py holds 1e-5 at the benchmark's shapes).  Why: these tests use 0.15-0.3 N(0,1) weights on a few
+# dozen inputs, which puts single rows at |z2| ~ 10.  There one float32 ulp of the pre-activation (|z2| 2^-23 ~ 1.2e-6, and device
+# and oracle sum z2 in different orders) moves log p = -softplus(-z2) by ~1e-6 for that row; a batch of 20-50 rows holds a few such
+# rows, their signs do not cancel inside one mean, and after 2-4 epochs of updates that each saw such a cost the epoch means drift
+# by a few 1e-5 (round 3 tightened these from 1e-4 and found 1e-5 too tight for exactly these shapes).  5e-5 = that
+# drift with margin; a real defect (a wrong mask, a missing 1/B) shows up at 1e-3 and above.
+COST_TOL_SMALL_SHAPES = 5e-5
+
 LOGIT_TOL = 1e-5
 LOSS_TOL = 1e-5
 
@@ -177,7 +186,7 @@ def test_train_epochs_match_oracle(oracle, kind):
     ref = om.train(X, Y, batch=64, epochs=3)                      # 4 batches/epoch, last one padded
     costs = gm.Train(U, T, D, D, Cc, 250, 64, 3, 0, si, X, Y.reshape(-1, 1), dm)
     assert len(costs) == len(ref) == 3
-    assert np.max(np.abs(costs - ref)) <= 5e-5
+    assert np.max(np.abs(costs - ref)) <= COST_TOL_SMALL_SHAPES
     for n, r in (("mlp0", om.W0), ("mlp1", om.W1), ("mlp2", om.W2)):
         assert np.max(np.abs(dm.get_weights(n) - r)) <= 2e-4, n     # 12 Adam steps of lr 0.01
     # after training the predictions still agree
@@ -205,7 +214,7 @@ def test_train_with_hash_dropout_matches_oracle(oracle):
     ds = gm.Dataset.dense(X, Y, si)
     cfg = capi.default_train_cfg(batch=32, epochs=2, early_stop=0, dropout_mode=2, p0=0.1, p1=0.2, seed=99)
     costs = gm.train_dataset(dm, ds, cfg)
-    assert np.max(np.abs(costs - ref)) <= 5e-5
+    assert np.max(np.abs(costs - ref)) <= COST_TOL_SMALL_SHAPES
 
 
 @pytest.mark.parametrize("kind", [0, 1])
@@ -229,7 +238,7 @@ def test_id_mode_equals_dense_mode(oracle, kind):
     cfg = capi.default_train_cfg(batch=B, epochs=2, early_stop=0, dropout_mode=0)
     costs = gm.train_dataset(dm, ds, cfg, emb=tab)
     ref = om.train(X, Y, batch=B, epochs=2)
-    assert np.max(np.abs(costs - ref)) <= 5e-5
+    assert np.max(np.abs(costs - ref)) <= COST_TOL_SMALL_SHAPES
 
 
 @pytest.mark.parametrize("steps", [7, 39])     # 4 + 2 + 1 and 16 + 16 + 4 + 2 + 1 steps per graph launch (ctr.hip run_steps)
@@ -338,7 +347,7 @@ def test_id_mode_shape_sweep(oracle, kind, att, U, T, D, Cc):
     cfg = capi.default_train_cfg(batch=B, epochs=2, early_stop=0, dropout_mode=0)
     costs = gm.train_dataset(dm, ds, cfg, emb=tab)
     ref = om.train(X, Y, batch=B, epochs=2)
-    assert np.max(np.abs(costs - ref)) <= 5e-5
+    assert np.max(np.abs(costs - ref)) <= COST_TOL_SMALL_SHAPES
     for name, w in (("mlp0", om.W0), ("mlp1", om.W1), ("mlp2", om.W2)):
         assert np.max(np.abs(dm.get_weights(name) - w)) <= 2e-4 * max(1.0, np.max(np.abs(w)))
 
@@ -377,7 +386,7 @@ def test_attention_backward_in_the_chain_kernel(oracle, att, T, B, rows):
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
     ref = om.train(X, Y, batch=B, epochs=2, drop_mode=2, p0=0.01, p1=0.01, seed=9)
-    assert np.max(np.abs(res[0][0] - ref)) <= 5e-5
+    assert np.max(np.abs(res[0][0] - ref)) <= COST_TOL_SMALL_SHAPES
     assert np.max(np.abs(res[0][1].ravel() - om.att0.ravel())) <= 2e-4
     assert np.max(np.abs(res[0][2] - om.W0)) <= 2e-4 * max(1.0, np.max(np.abs(om.W0)))
 
@@ -416,7 +425,7 @@ def test_graph_is_rebuilt_for_a_new_dataset_at_a_reused_address(oracle):
             c, g, _ = om.loss_grad(X[lo:lo + B], Y[lo:lo + B], B=B)
             st = om.adam_step(g, state=st, batch=B)
             ref.append(c)
-    assert np.max(np.abs(res[0][0] - np.array(ref, np.float32))) <= 5e-5
+    assert np.max(np.abs(res[0][0] - np.array(ref, np.float32))) <= COST_TOL_SMALL_SHAPES
 
 
 def test_concurrent_handles_from_several_threads(oracle):

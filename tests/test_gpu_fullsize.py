@@ -128,7 +128,7 @@ def one_step_checks(oracle, kind, U, T, D, Cc, V, B, seed, drop):
         assert int(np.sum(out & ~near_zero[on])) == 0, (dn, int(np.sum(out & ~near_zero[on])), float(d[out & ~near_zero[on]].max()))
         assert float(out.mean()) <= 2e-3 and np.max(d) <= 2.1e-2, (dn, float(out.mean()), float(np.max(d)))
     # and the next predict sees the updated weights
-    assert np.max(np.abs(gm.predict_dataset(dm2, ds, 4096, emb=tab) - om2.predict(X, 4096))) <= 5e-5
+    assert np.max(np.abs(gm.predict_dataset(dm2, ds, 4096, emb=tab) - om2.predict(X, 4096))) <= 5e-5      # (scores AFTER 20 updates: the drift of COST_TOL_SMALL_SHAPES, test_gpu_ctr.py)
 
 
 @pytest.mark.parametrize("drop", [False, True])
