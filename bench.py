@@ -422,9 +422,27 @@ def bench_item2vec(args):
     capi.sync()
     dt = time.perf_counter() - t0
     wps = steps * n / dt
-    bytes_per_word = 19968.0                                  # 6 contexts x (12 nodes x 2 x 128 B + 2 x 128 B): the
-    #                                                           reference's pair-major row traffic, kept as the yard-stick (the
-    #                                                           node-major walk touches a node once per 4 pairs: ~ 7 KB per word)
+    # ---- roofline of the IMPLEMENTED walk (rounds 1-4 priced the reference's pair-major row traffic, 19 968 B
+    # per word, which this kernel no longer performs -- the fraction read 1.03).  w2v_hogwild_nm_kernel per corpus position: the
+    # centre word's Huffman path (L nodes) is walked once per CHUNK of up to JB = 4 context words; a node visit reads the node
+    # vector (dim x 8 B) and adds one update to it, a context word is read once and updated once.  Rows in the LDS hot tables
+    # (the 256 most frequent words and the 256 heaviest nodes at dim 16) cost no memory traffic between merges; COLD rows are
+    # device-scope loads and atomic adds, which the eight non-coherent L2s pass through to the fabric.  From this corpus' own
+    # paths and counts (window shrink uniform in 0 .. 4 => 2 (5 - shrink) contexts, ceil(. / 4) chunks: 6 and 1.8 on average):
+    off, nodes, _codes = m.get_paths()
+    off = np.asarray(off, np.int64); nodes = np.asarray(nodes, np.int64)
+    hot_rows = 256                                            # csrc/w2v.hip run_pass: rows_cached at WPS 4, dim 16 (GOCTR_W2V_HOT=1)
+    plen = np.diff(off)
+    node0 = (V - 1) - min(hot_rows, V - 1)
+    cold_nodes = np.add.reduceat((nodes < node0).astype(np.int64), off[:-1].clip(max=max(nodes.size - 1, 0))) * (plen > 0)
+    hot_word = np.zeros(V, bool); hot_word[np.argsort(-counts, kind="stable")[:hot_rows]] = True
+    freq = np.bincount(doc, minlength=V) / float(n)
+    row = dim * 8
+    chunks, ctxs = 1.8, 6.0
+    L_mean, Lc_mean = float((freq * plen).sum()), float((freq * cold_nodes).sum())
+    p_cold_ctx = float(freq[~hot_word].sum())
+    fabric_b = chunks * Lc_mean * 2 * row + ctxs * p_cold_ctx * 2 * row + 4          # cold rows + the doc id
+    all_b = chunks * L_mean * 2 * row + ctxs * 2 * row + 4                            # every row the walk touches (LDS + fabric)
     out = {"metric": "item2vec training words/sec (SkipGram + HS, float64)", "value": round(wps, 1), "unit": "words/s",
            "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -432,31 +450,32 @@ def bench_item2vec(args):
                                   "resident in HBM, one pass per step, Hogwild: 16 slices (window clipping as in the reference) x "
                                   "2048 workers, node-major walk (4 pairs per node visit), hot rows cached in LDS and averaged, "
                                   "cold rows device-scope atomics", "parallelism": "dp1"},
-           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                        "kernel": "w2v_hogwild_nm_kernel"}}
-    # achieved = ALGORITHMIC bytes (19 968 B per word, the reference's pair-major row traffic) x words per pass /
-    # pass duration, as the contract defines it; traffic = memory-side PMC bytes of the same pass.  The 2.7 MB of parameters are
-    # LDS- / L2-resident and the node-major walk touches a node once per four pairs, so the algorithmic rate EXCEEDS what the
-    # memory side sees by an order of magnitude and the HBM roof does not bind this kernel: what does is VALU issue (`valu`
-    # below, from the SQ counters of the committed summary) -- reported beside the memory-side rate and the L2 roof.
+           "roofline": {"bound": "hbm", "achieved": round(wps * fabric_b / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(wps * fabric_b / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "w2v_hogwild_nm_kernel"}}
     rl = with_traffic(out["roofline"], "item2vec", "train", "w2v_hogwild_nm_kernel*", None, dt / steps * 1e3)
-    rl["achieved"] = round(wps * bytes_per_word / 1e9, 1)
-    rl["frac"] = round(rl["achieved"] / HBM_PEAK_GBS, 4)
-    rl["algorithmic_bytes"] = int(bytes_per_word * n)
+    rl["algorithmic_bytes"] = int(fabric_b * n)
+    rl["model"] = {"bytes_per_word_fabric": round(fabric_b, 1), "bytes_per_word_all_rows": round(all_b, 1),
+                   "mean_path_nodes": round(L_mean, 2), "mean_cold_path_nodes": round(Lc_mean, 2),
+                   "cold_context_share": round(p_cold_ctx, 4), "chunks_per_position": chunks, "contexts_per_position": ctxs,
+                   "hot_rows_per_table": hot_rows,
+                   "basis": "the implemented node-major walk on this corpus' own Huffman paths and counts: cold rows = device-scope "
+                            "load + atomic add of dim x 8 B each at the fabric; hot rows live in LDS between merges"}
     if rl.get("traffic"):
         rl["memory_side_GBs"] = rl.pop("hbm_side_GBs")
         rl["memory_side_frac"] = round(rl["memory_side_GBs"] / HBM_PEAK_GBS, 4)
-    rl["note"] = ("rows are LDS/L2-resident: frac > 1 of the HBM roof means the roof does not bind; traffic / algorithmic_bytes is the "
-                  "share that reaches the memory side; the pass is bound by VALU issue under divergence (valu.issue_frac)")
+        rl["memory_side_bytes_per_word"] = round(rl["traffic"] / n, 1)
+    rl["l2"] = {"achieved": round(wps * all_b / 1e9, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(wps * all_b / 1e9 / L2_PEAK_GBS, 4),
+                "hit_rate": rl.get("l2_hit_rate"), "note": "every row of the walk (LDS-resident ones included) against the aggregate L2 roof: an upper bound on what the L2s see"}
     sq = (pmc_entry("item2vec", "train", "w2v_hogwild_nm_kernel*") or {}).get("sq") or {}
     if sq.get("sq_insts_valu") and sq.get("kernel_cycles"):
         # a wave64 VALU instruction occupies its SIMD16 for 4 cycles; 256 CUs x 4 SIMDs
         rl["valu"] = {"issue_frac": round(sq["sq_insts_valu"] * 4.0 / (sq["kernel_cycles"] * 1024.0), 3),
                       "wave_instructions_per_word": round(sq["sq_insts_valu"] / n, 1),
                       "wait_any_pct_of_wave_cycles": sq.get("wait_any_pct_of_wave_cycles")}
-    rl["l2"] = {"achieved": round(wps * bytes_per_word / 1e9, 1), "peak": L2_PEAK_GBS, "unit": "GB/s",
-                "frac": round(wps * bytes_per_word / 1e9 / L2_PEAK_GBS, 4), "hit_rate": rl.get("l2_hit_rate"),
-                "note": "algorithmic read-modify-write bytes per word x words/s against the aggregate L2 roof"}
+    rl["binds"] = ("neither roof: the fabric sees < 0.1 of the HBM rate and the L2s < 0.1 of theirs.  The pass is LATENCY-bound: a stream's "
+                   "walk is a chain of device-scope round trips (cold node: load -> inner product -> atomic add; 8 nodes prefetched), "
+                   "the wavefronts wait 60+ % of their cycles (valu.wait_any_pct_of_wave_cycles) with 16 wavefronts per CU resident "
+                   "(128 VGPRs each) -- more streams in flight, not more bandwidth, is what the kernel lacks")
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         cores = usable_cores()
@@ -495,22 +514,35 @@ def bench_knn(args):
     capi.sync()
     dt = time.perf_counter() - t0
     qps = steps * Q / dt
-    scan = qps * V * D * 8 / 1e9
+    # ---- roofline of the IMPLEMENTED call (rounds 1-4 priced the reference's loop -- every query scans
+    # V x D x 8 bytes -- which the filter + refine path does not perform: the fraction read 12).  Per call of Q queries:
+    #   scan     every normalised float32 row ONCE: V x D x 4 B (+ Q x tiles maxima written)
+    #   collect  per query the tiles whose maximum reaches the bound, again as float32 rows: listed_tiles x 1024 x D x 4 B
+    #            (measured from the device's own tile maxima would need a read-back; the bound's construction gives the
+    #            expectation: the k-th largest of 256 group maxima sits near the (k + 3)-th best item, so ~k + 3 tiles), then the
+    #            float64 rows of the few survivors
+    #   replay   ~k + 3 candidates per query: bytes negligible
+    tiles_per_query = k + 3
+    call_b = V * D * 4 + Q * (V // 1024 + 1) * 4 + Q * tiles_per_query * 1024 * D * 4
+    call_us = dt / steps * 1e6
     out = {"metric": "k-NN search queries/sec (cosine top-10 over 10^6 x 16 float64 items)", "value": round(qps, 1),
            "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "SURVEY 8(f)2: Searcher.Search, V=10^6, D=16 f64, k=10, 64 queries per call", "parallelism": "dp1"},
-           "roofline": {"bound": "hbm", "achieved": round(scan, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(scan / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel": "knn_scan_mfma_kernel (algorithmic = the reference's loop: every query scans V*D*8 bytes; the scan path "
-                                  "reads a normalised float32 copy of the items ONCE per 64-query call -- filter + exact refine, "
-                                  "csrc/search.hip -- so frac > 1 of the HBM roof means the roof does not bind the call)"}}
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "kernel": "knn_scan_mfma_kernel (the filter: every normalised float32 row once per 64-query call)"}}
     rl = with_traffic(out["roofline"], "knn", "train", "knn_scan_*", None, None)      # (knn_scan_mfma_kernel<D> from 48 queries per call on)
-    rl["algorithmic_bytes"] = int(Q * V * D * 8)
-    rl["filter_bytes_per_call"] = int(V * D * 4)           # what the dominant kernel has to read: the float32 rows, once
+    rl["algorithmic_bytes"] = int(V * D * 4 + Q * (V // 1024 + 1) * 4)                 # the dominant kernel's own bytes
     if rl.get("avg_us_rocprofv3"):
-        rl["filter_GBs"] = round(V * D * 4 / (rl["avg_us_rocprofv3"] * 1e-6) / 1e9, 1)
-        rl["filter_frac_of_hbm"] = round(rl["filter_GBs"] / HBM_PEAK_GBS, 4)
+        rl["achieved"] = round(rl["algorithmic_bytes"] / (rl["avg_us_rocprofv3"] * 1e-6) / 1e9, 1)
+        rl["frac"] = round(rl["achieved"] / HBM_PEAK_GBS, 4)
+        rl["duration_basis"] = "rocprofv3 average duration of the scan kernel (committed summary of this command)"
+    rl["call"] = {"bytes_per_call_implemented": int(call_b), "us_per_call": round(call_us, 1),
+                  "achieved_GBs": round(call_b / (call_us * 1e-6) / 1e9, 1), "frac_of_hbm": round(call_b / (call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                  "note": "whole call (H2D of the queries, scan, collect + replay, results through pinned memory, host sync) against the "
+                          "bytes the implemented path has to move; the call is a latency chain of three dependent launches and a host "
+                          "round trip, not a bandwidth problem: see the per-kernel durations in profiles/"}
+    rl["reference_loop_bytes_per_call"] = int(Q * V * D * 8)   # what search.go:92-134 reads (every query scans the f64 matrix)
     if not args.no_cpu_baseline:
         from oracle import pyoracle
         norms = np.sqrt((items * items).sum(1))
