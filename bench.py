@@ -556,6 +556,61 @@ def bench_knn(args):
     _emit(out)
 
 
+def bench_single_process(args):
+    """`--gpus N --single-process`: ONE process, N engines (goctr_init_devices), every timed call a single goctr_train_steps with
+    cfg.devices = N and the GLOBAL batch N x B -- rank r steps rows [r, r + 1) x B of every global batch on its replica, one
+    all-reduce of the flat gradient per step, the identical Adam everywhere (csrc/ctr.hip train_multi).  Same line as the
+    one-process-per-GPU run (weak scaling: B rows per GPU per step); the recommend / roofline / serving legs are the N = 1 run's."""
+    from goctr_amd import capi, model as gm
+    c = CFG
+    N = args.gpus
+    ids = [int(x) for x in os.environ.get("GOCTR_BENCH_DEVICES", ",".join(str(k) for k in range(N))).split(",")]
+    if len(ids) != N:
+        print(f"bench.py: GOCTR_BENCH_DEVICES names {len(ids)} devices, --gpus {N}", file=sys.stderr)
+        sys.exit(2)
+    capi.init_devices(ids)
+    emb, ub, it, uf, cf, y = synth(args.rows * N, 42)
+    tab = gm.EmbeddingTable(emb)
+    ds = gm.Dataset.ids(ub, it, uf, cf, y)
+    m = (gm.YoutubeDnn if c["KIND"] == "youtube" else gm.DinNet)(c["U"], c["T"], c["D"], c["D"], c["C"])
+    init_weights(m, 1, 0.05 if args.train_emb > 0 else 1.0)
+    pdrop = 0.003 if c["KIND"] == "youtube" else 0.005
+    cfg = capi.default_train_cfg(batch=c["B"] * N, epochs=1, dropout_mode=2, p0=pdrop, p1=pdrop, seed=42, devices=N)
+    if args.train_emb > 0:
+        m.set_embedding_training(args.train_emb)
+    gm.train_steps(m, ds, cfg, args.warmup, emb=tab)            # (replicas, shards, graphs: built here, outside the timed regions)
+    capi.sync()
+    regions = []
+    for r in range(max(args.regions, 1)):
+        capi.sync()
+        t0 = time.perf_counter()
+        gm.train_steps(m, ds, cfg, args.steps, first_batch=args.warmup + r * args.steps, emb=tab)
+        capi.sync()
+        regions.append(time.perf_counter() - t0)
+    dt = sorted(regions)[(len(regions) - 1) // 2]
+    # replicas must hold the same bits (same all-reduced gradient, same Adam)
+    import zlib
+    crcs = []
+    for k in range(N):
+        rep = m.replica(k) if k else m
+        crcs.append(zlib.crc32(np.concatenate([rep.get_weights(nm).ravel() for nm in ("mlp0", "mlp1", "mlp2")]).tobytes()))
+    out = {"metric": "training samples/sec (%s, MovieLens-20M-shaped synthetic)" % ("YouTube-DNN" if c["KIND"] == "youtube" else "DIN"),
+           "value": round(args.steps * c["B"] * N / dt, 1), "unit": "samples/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": ("BASELINE configs[3]" if c["KIND"] == "youtube" else "BASELINE configs[2]") +
+                                  f": batch {c['B']} per GPU, id mode, Dropout({pdrop}); SINGLE PROCESS, {N} engines on devices {ids}",
+                      "global_batch": c["B"] * N, "parallelism": f"dp{N}", "resident_rows_per_gpu": args.rows},
+           "dp_mode": "one process, goctr_init_devices + cfg.devices (RCCL ncclCommInitAll over distinct devices; loop-back communicator "
+                      "when a device id repeats)",
+           "timed_regions": len(regions), "timed_regions_ms": [round(x * 1e3, 4) for x in regions],
+           "replicas_bit_identical": len(set(crcs)) == 1}
+    print(json.dumps(out), flush=True)
+    if not out["replicas_bit_identical"]:
+        print(f"bench.py: the {N} replicas DIVERGED (weight checksums {crcs})", file=sys.stderr)
+        sys.exit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -564,6 +619,10 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 18, help="resident sample rows per GPU")
     ap.add_argument("--regions", type=int, default=9,
                     help="timed regions of exactly --steps steps, back to back; the line reports the median region (and lists all)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N > 1 WITHOUT one process per GPU: this process drives N engines (goctr_init_devices + cfg.devices = N, "
+                         "the mode a single Go host uses: recommend.Train reaches N GPUs in one call, INTEGRATION.md 5.1).  "
+                         "GOCTR_BENCH_DEVICES=0,0 names the device list (a repeated id = logical ranks on one GPU, loop-back communicator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-serving", action="store_true",
@@ -590,6 +649,8 @@ def main():
         # BASELINE configs[3] / SURVEY 8(d) cfg4: YouTube-DNN, V = 10^7, D = 64, B = 16384 per GPU
         CFG.update(D=64, V=10_000_000, B=16384, KIND="youtube")
 
+    if args.single_process and args.gpus > 1 and "RANK" not in os.environ:
+        return bench_single_process(args)
     from goctr_amd import launch
     if args.gpus > 1 and "RANK" not in os.environ:
         # no launcher around us: become one.  Rank 0 prints the JSON line.

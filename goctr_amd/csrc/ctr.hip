@@ -60,6 +60,10 @@ struct goctr_dataset {
   // batch-major, the short last batch zero-padded (model.go:357-371) -- local batch k of rank r = rows [r, r+1) * shard_B / n of
   // global batch k
   std::vector<goctr_dataset*> shards; int shard_B = 0;
+  // goctr_train_dense with cfg.devices = n > 1: the caller's HOST rows, valid for the duration of that call only.  Nothing is
+  // uploaded to engine 0 (X / Y stay empty): every rank copies ITS rows of every global batch straight from host memory into its
+  // shard, on its own device and stream (train_multi) -- round 4 staged all of X on engine 0 and scattered it over xGMI
+  const float* host_X = nullptr; const float* host_Y = nullptr;
 };
 
 struct StepGraph {
@@ -2568,7 +2572,8 @@ int train_multi(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_tr
   const bool emb_sync = emb && (new_emb || emb->reps_version != emb->version);
   // ---- root-side staging of the shards
   ShardPack pX, pY, pub, pit, puf, pcf;
-  if (need_shard) {
+  const bool from_host = d->host_X != nullptr;
+  if (need_shard && !from_host) {
     if (d->id_mode) {
       if (pack_array(pub, d->ub_ids.p, d->rows, d->T, B, N, nb, 0xFFFFFFFFu) || pack_array(pit, d->item_ids.p, d->rows, 1, B, N, nb, 0xFFFFFFFFu) ||
           pack_array(puf, d->ufeat.p, d->rows, d->U, B, N, nb, 0u) || pack_array(pcf, d->cfeat.p, d->rows, d->C, B, N, nb, 0u)) return -1;
@@ -2593,7 +2598,24 @@ int train_multi(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_tr
     int r = 0;
     if (model_sync) r = model_broadcast(mk, stp_root, emb_lr_root);
     if (!r && emb_sync) { r = comm_broadcast(ek->rows.p, sizeof(float) * (size_t)(emb->V + 1) * emb->D, 0); if (k > 0) ++ek->version; }
-    if (!r && need_shard) {
+    if (!r && need_shard && from_host) {
+      // this rank's rows of global batch b are host rows [b B + k Bl, b B + (k + 1) Bl), clipped at the dataset's end; what is
+      // missing of a short last batch is zero rows (model.go:357-371 FillTensorRows pads it to the batch size)
+      hipStream_t st = e.stream;
+      auto rows_from_host = [&](float* dst, const float* src, int cols) -> int {
+        for (long long b = 0; b < nb; ++b) {
+          const long long g0 = b * B + (long long)k * Bl;
+          const long long have = std::max<long long>(0, std::min<long long>(Bl, d->rows - g0));
+          float* to = dst + (size_t)b * Bl * cols;
+          if (have > 0) GOCTR_HIP(hipMemcpyAsync(to, src + (size_t)g0 * cols, sizeof(float) * (size_t)have * cols, hipMemcpyHostToDevice, st));
+          if (have < Bl) GOCTR_HIP(hipMemsetAsync(to + (size_t)have * cols, 0, sizeof(float) * (size_t)(Bl - have) * cols, st));
+        }
+        return 0;
+      };
+      r = rows_from_host(dk->X.p, d->host_X, d->xcols);
+      if (!r && d->has_y) r = rows_from_host(dk->Y.p, d->host_Y, 1);
+      if (!r) { const hipError_t he = hipStreamSynchronize(st); if (he != hipSuccess) { set_error("per-rank upload: %s", hipGetErrorString(he)); r = -1; } }
+    } else if (!r && need_shard) {
       if (d->id_mode) r = scatter_array(&pub, pub.per, dk->ub_ids.p) || scatter_array(&pit, pit.per, dk->item_ids.p) ||
                           scatter_array(&puf, puf.per, dk->ufeat.p) || scatter_array(&pcf, pcf.per, dk->cfeat.p);
       else r = scatter_array(&pX, pX.per, dk->X.p);
@@ -2761,7 +2783,14 @@ int goctr_train_dense(goctr_model* m, const float* X, const float* Y, int64_t ro
   goctr_dataset* d = nullptr;
   GOCTR_CHECK(m && cfg, "goctr_train_dense: null argument");
   GOCTR_CHECK(Y != nullptr, "goctr_train_dense: labels required");
-  if (goctr_dataset_create_dense(X, Y, rows, xcols, ranges, &d)) return -1;
+  if (cfg->devices > 1) {
+    // n devices: no copy of X on engine 0 -- the ranks fetch their own rows from the caller's memory (goctr_dataset::host_X)
+    GOCTR_CHECK(X && rows > 0 && xcols > 0 && ranges, "goctr_train_dense: bad arguments");
+    d = new goctr_dataset;
+    d->id_mode = false; d->rows = rows; d->xcols = xcols; d->has_y = true;
+    memcpy(d->ranges, ranges, sizeof d->ranges);
+    d->host_X = X; d->host_Y = Y;
+  } else if (goctr_dataset_create_dense(X, Y, rows, xcols, ranges, &d)) return -1;
   int rc = goctr_train_dataset(m, nullptr, d, cfg, epoch_costs, epochs_run);
   if (!rc) rc = goctr_sync();
   {

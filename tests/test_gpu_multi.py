@@ -552,3 +552,17 @@ def test_replica_and_shard_caches_follow_what_changed(tmp_path, W):
     assert np.array_equal(r["tabs"][0], r["e2"])
     assert np.isfinite(r["single"]).all()
     assert np.max(np.abs(r["reps"][0] - r["single"])) <= 2e-5
+
+
+def test_bench_single_process_two_logical_ranks():
+    """bench.py --gpus 2 --single-process: ONE process, goctr_init_devices + cfg.devices = 2 (here two logical ranks on device 0:
+    the loop-back communicator) -- the line the driver's SCALE run can take for mode 2, replicas checked bit for bit"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["GOCTR_BENCH_DEVICES"] = "0,0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--steps", "6", "--warmup", "2",
+                        "--rows", "32768", "--regions", "3"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 8192 and d["config"]["parallelism"] == "dp2"
+    assert d["replicas_bit_identical"] is True and d["value"] > 0 and len(d["timed_regions_ms"]) == 3
