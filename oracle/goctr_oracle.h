@@ -262,6 +262,9 @@ double orc_norm64(const double* v, int d);
 double orc_cosine64(const double* v1, const double* v2, int d, double n1, double n2);
 int orc_knn_search(const double* items, const double* norms, int64_t V, int D, const double* query, double qnorm,
                    int k, int64_t ignore, int64_t* out_idx, double* out_sim, int* out_rank);
+/* Q independent searches, OpenMP over the queries (each = orc_knn_search); out_* [Q][k], out_count [Q] */
+void orc_knn_search_batch(const double* items, const double* norms, int64_t V, int D, const double* queries, int Q, int k,
+                          const int64_t* ignore, int64_t* out_idx, double* out_sim, int* out_rank, int* out_count);
 
 /* ---- user-behaviour cache lookup + per-sample key assembly (orc_ubcache.c): cache.go:71-94, rcmd.go:460-536 ---- */
 int64_t orc_ubcache_filter(const int64_t* ts, const int32_t* items, int64_t len, int64_t max_ts, int64_t max_len,

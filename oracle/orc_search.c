@@ -55,3 +55,15 @@ int orc_knn_search(const double* items, const double* norms, int64_t V, int D, c
     if (out_idx[i] < 0) kk = i;
   return kk;
 }
+
+/* Q independent searches (the reference serves them from concurrent gin handler goroutines, recommend/api.go:106-131): OpenMP over
+ * the QUERIES, each the sequential loop above -- no arithmetic changes.  out_* are [Q][k]; out_count [Q]. */
+void orc_knn_search_batch(const double* items, const double* norms, int64_t V, int D, const double* queries, int Q, int k,
+                          const int64_t* ignore, int64_t* out_idx, double* out_sim, int* out_rank, int* out_count) {
+#pragma omp parallel for num_threads(orc_get_threads()) schedule(dynamic, 1)
+  for (int q = 0; q < Q; ++q) {
+    const double* qv = queries + (size_t)q * D;
+    out_count[q] = orc_knn_search(items, norms, V, D, qv, orc_norm64(qv, D), k, ignore ? ignore[q] : -1, out_idx + (size_t)q * k,
+                                  out_sim + (size_t)q * k, out_rank + (size_t)q * k);
+  }
+}

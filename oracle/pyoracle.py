@@ -645,6 +645,20 @@ def knn_search(items, query, k, ignore=-1, norms=None, qnorm=None):
     return idx[:n], sim[:n], rank[:n]
 
 
+def knn_search_batch(items, queries, k, norms, ignore=None):
+    """Q independent Searcher.Search calls, OpenMP over the queries (set_threads); returns (idx [Q,k], sim [Q,k], count [Q])"""
+    items = np.ascontiguousarray(items, np.float64)
+    queries = np.ascontiguousarray(queries, np.float64)
+    norms = np.ascontiguousarray(norms, np.float64)
+    Q, (V, D) = queries.shape[0], items.shape
+    idx = np.zeros((Q, k), np.int64); sim = np.zeros((Q, k), np.float64); rank = np.zeros((Q, k), np.int32); cnt = np.zeros(Q, np.int32)
+    ig = np.ascontiguousarray(ignore, np.int64) if ignore is not None else None
+    lib().orc_knn_search_batch(_p(items, C.c_double), _p(norms, C.c_double), C.c_int64(V), C.c_int(D), _p(queries, C.c_double), C.c_int(Q),
+                               C.c_int(k), _p(ig, C.c_int64) if ig is not None else None, _p(idx, C.c_int64), _p(sim, C.c_double),
+                               _p(rank, C.c_int32), _p(cnt, C.c_int32))
+    return idx, sim, cnt
+
+
 # ---------------------------------------------------------------- user-behaviour cache / key assembly --
 def ubcache_filter(ts, items, max_ts, max_len):
     """TimeSeq.Filter (cache.go:71-94) on a newest-first sequence -> the selected item ids"""
