@@ -515,6 +515,8 @@ __global__ __launch_bounds__(HOG_THREADS, HOG_WAVES_PER_SIMD) void w2v_hogwild_k
 // sigmoid lookup, the gradient scalar -- is paid once per group: at dim 16, 8 lanes x 2 components halve that share per stream
 // and drop one reduction step, and 128 registers (WPS = 4: one workgroup per CU, which then also has the CU's LDS to itself)
 // hold the 2 JB context / update vectors without spilling.
+// (Round 5 flattened the position > chunk > node nest -- one lockstep iteration = one chunk of each stream's own position, lane
+// efficiency 0.45 -> ~0.68: 13-18 % fewer vector instructions, the pass no shorter; profiles/r05_w2v_flat_ab.txt.  Removed.)
 template <int GS, int CPL, int JB, int WPS, int PF>
 __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev a, int streams, const long long* slice_idx, const long long* clip_lo,
                                                                          const long long* clip_hi, HogHot hot) {
@@ -696,236 +698,6 @@ __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev
       }
     }
     if ((pos + 1) % hot.merge_every == 0) merge();
-  }
-  merge();
-  if (g == 0 && l == 0) *a.trained = a.n_words;
-  if (g == streams - 1 && l == 0) *a.lr = lr;
-}
-
-template <int GS, int CPL, int JB, int WPS, int PF>
-__global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nmf_kernel(W2vDev a, int streams, const long long* slice_idx, const long long* clip_lo,
-                                                                         const long long* clip_hi, HogHot hot) {
-  constexpr int HOT = hog_hot_doubles(WPS);
-  constexpr int RS = GS * CPL;                 // row stride of the LDS tables
-  __shared__ double tab[1000];
-  __shared__ double locN[HOT], locW[HOT];
-  double* const baseN = hot.base + (size_t)blockIdx.x * 2 * HOT;      // (only this workgroup reads or writes its strip)
-  double* const baseW = baseN + HOT;
-  const int dim = a.dim, win = a.window;
-  for (int i = threadIdx.x; i < 1000; i += HOG_THREADS) tab[i] = a.sigtab[i];
-  for (int i = threadIdx.x; i < hot.n_nodes * RS; i += HOG_THREADS) {
-    const int r = i / RS, c = i % RS;
-    const double v = c < dim ? hog_load(a.aux + (hot.node0 + r) * dim + c) : 0.0;
-    locN[i] = v; baseN[i] = v;
-  }
-  for (int i = threadIdx.x; i < hot.n_words * RS; i += HOG_THREADS) {
-    const int r = i / RS, c = i % RS;
-    const double v = c < dim ? hog_load(a.param + (long long)hot.word_id[r] * dim + c) : 0.0;
-    locW[i] = v; baseW[i] = v;
-  }
-  __syncthreads();
-  auto merge = [&]() {                         // (see w2v_hogwild_kernel)
-    __syncthreads();
-    for (int i = threadIdx.x; i < hot.n_nodes * RS; i += HOG_THREADS) {
-      const int r = i / RS, c = i % RS;
-      if (c < dim) {
-        double* gp = a.aux + (hot.node0 + r) * dim + c;
-        const double d = (locN[i] - baseN[i]) * hot.merge_scale;
-        if (d != 0.0) hog_add(gp, d);
-        const double v = hog_load(gp);
-        locN[i] = v; baseN[i] = v;
-      }
-    }
-    for (int i = threadIdx.x; i < hot.n_words * RS; i += HOG_THREADS) {
-      const int r = i / RS, c = i % RS;
-      if (c < dim) {
-        double* gp = a.param + (long long)hot.word_id[r] * dim + c;
-        const double d = (locW[i] - baseW[i]) * hot.merge_scale;
-        if (d != 0.0) hog_add(gp, d);
-        const double v = hog_load(gp);
-        locW[i] = v; baseW[i] = v;
-      }
-    }
-    __syncthreads();
-  };
-  constexpr int GPB = HOG_THREADS / GS;
-  const int g = blockIdx.x * GPB + threadIdx.x / GS;
-  const int l = threadIdx.x % GS;
-  const int gs = g < streams ? g : streams - 1;
-  const long long lo0 = slice_idx[gs], len0 = g < streams ? slice_idx[gs + 1] - lo0 : 0;   // (the host refuses pieces of 2^31 words or more)
-  const long long pb = len0 * a.seg / a.nseg;                      // this launch's part of the piece (whole piece: 0 of 1)
-  const long long lo = lo0 + pb;
-  const int len = (int)(len0 * (a.seg + 1) / a.nseg - pb);
-  bool actk[CPL];
-#pragma unroll
-  for (int k = 0; k < CPL; ++k) actk[k] = l + k * GS < dim && g < streams;
-  // (stream 0 of rank 0, first segment: the reference's seed)
-  unsigned long long next = 1ULL + 0x9E3779B97F4A7C15ULL * ((unsigned long long)(a.seed_base + g) + (unsigned long long)a.seg * 0x100000000ULL);
-  double lr = *a.lr;
-  long long est = pb * streams * a.est_scale, at = est / a.update_lr_batch * a.update_lr_batch;
-  const int* doc = a.doc + lo;
-  const unsigned char* keep = a.keep ? a.keep + lo : nullptr;
-  const long long cmin = clip_lo[gs] - lo, cmax = clip_hi[gs] - lo;
-  const int gbase = (int)(threadIdx.x & 63) & ~(GS - 1);
-  auto ld_word = [&](int id, double (&v)[CPL]) {
-    const int slot = hot.n_words ? hot.word_slot[id] : -1;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k)
-      v[k] = !actk[k] ? 0.0 : (slot >= 0 ? locW[slot * RS + l + k * GS] : hog_load(a.param + (long long)id * dim + l + k * GS));
-  };
-  auto add_word = [&](int id, const double (&v)[CPL]) {
-    const int slot = hot.n_words ? hot.word_slot[id] : -1;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k)
-      if (actk[k] && v[k] != 0.0) { if (slot >= 0) locW[slot * RS + l + k * GS] += v[k]; else hog_add(a.param + (long long)id * dim + l + k * GS, v[k]); }
-  };
-  auto ld_node = [&](int nd, bool on, double (&v)[CPL]) {
-#pragma unroll
-    for (int k = 0; k < CPL; ++k)
-      v[k] = !(on && actk[k]) ? 0.0
-             : (nd >= hot.node0 ? locN[(nd - (int)hot.node0) * RS + l + k * GS] : hog_load(a.aux + (long long)nd * dim + l + k * GS));
-  };
-  auto add_node = [&](int nd, const double (&v)[CPL]) {
-#pragma unroll
-    for (int k = 0; k < CPL; ++k)
-      if (actk[k] && v[k] != 0.0) { if (nd >= hot.node0) locN[(nd - (int)hot.node0) * RS + l + k * GS] += v[k]; else hog_add(a.aux + (long long)nd * dim + l + k * GS, v[k]); }
-  };
-  // ---- FLATTENED walk (round 5).  The wavefront's lane groups walk in lockstep, and in w2v_hogwild_nm_kernel that lockstep spans
-  // the whole nest  position > chunk > node : a position costs the wavefront (max chunks over its groups) x (max path length),
-  // against (mean chunks) x (mean path length) of useful work -- 38.8 node-visit slots for 17.3 on the bench corpus, lane efficiency
-  // 0.45 (scripts: see DESIGN 4.5).  Here an iteration of the loop is ONE CHUNK of whatever position each group is at: a group
-  // opens its next position when its last chunk is done, not when the slowest group of the wavefront is.  Within a stream the
-  // order of every operation is unchanged (positions in order, chunks in order, the rate observer advanced when a position
-  // completes), so one stream still reproduces the deterministic pass.  The header of the next position (word id -> path offsets
-  // -> first GS path nodes: three dependent loads) is fetched three positions ahead -- in the nested loop all groups stalled on
-  // it together once per position, here each group would stall the wavefront on its own.
-  int pos = 0;                               // next position of this group's piece to open (pieces hold < 2^31 words)
-  bool open = false;
-  int cpos = 0, id = 0, hp0 = 0, hp1 = 0, h_nd0 = 0, h_code0 = 0, wend = 0, w = 0;
-  // header pipeline (only without a keep mask: positions are then consecutive): ids of pos, pos + 1, pos + 2; offsets of pos, pos + 1;
-  // first nodes of pos
-  const bool piped = keep == nullptr;
-  int q_id0 = 0, q_id1 = 0, q_id2 = 0, q_o00 = 0, q_o01 = 0, q_o10 = 0, q_o11 = 0, q_nd = 0, q_cd = 0;
-  if (piped && len > 0) {
-    q_id0 = doc[0]; q_id1 = len > 1 ? doc[1] : 0; q_id2 = len > 2 ? doc[2] : 0;
-    q_o00 = (int)a.path_off[q_id0]; q_o01 = (int)a.path_off[q_id0 + 1];
-    q_o10 = (int)a.path_off[q_id1]; q_o11 = (int)a.path_off[q_id1 + 1];
-    const int hn = q_o01 - q_o00 < GS ? q_o01 - q_o00 : GS;
-    q_nd = l < hn ? a.path_nodes[q_o00 + l] : 0; q_cd = l < hn ? (int)a.path_codes[q_o00 + l] : 0;
-  }
-  auto observe = [&]() {                     // word2vec.go:223-233 (see w2v_hogwild_kernel)
-    est += streams * a.est_scale;
-    if (est >= at + a.update_lr_batch) {
-      do at += a.update_lr_batch; while (est >= at + a.update_lr_batch);
-      if (lr < a.min_lr) lr = a.min_lr;
-      else lr = a.init_lr * (1.0 - (double)at / (double)a.corpus_len);
-    }
-  };
-  for (int iter = 1;; ++iter) {
-    if (!open) {
-      while (pos < len) {
-        const int p = pos++;
-        if (!keep || keep[p]) {
-          if (piped) {
-            // position p's header is complete; shift the pipeline and request what is missing of p + 1 .. p + 3
-            id = q_id0; hp0 = q_o00; hp1 = q_o01; h_nd0 = q_nd; h_code0 = q_cd;
-            q_id0 = q_id1; q_id1 = q_id2; q_o00 = q_o10; q_o01 = q_o11;
-            q_id2 = p + 3 < len ? doc[p + 3] : 0;
-            q_o10 = (int)a.path_off[q_id1]; q_o11 = (int)a.path_off[q_id1 + 1];
-            const int hn = q_o01 - q_o00 < GS ? q_o01 - q_o00 : GS;
-            q_nd = l < hn ? a.path_nodes[q_o00 + l] : 0; q_cd = l < hn ? (int)a.path_codes[q_o00 + l] : 0;
-          } else {
-            id = doc[p];
-            hp0 = (int)a.path_off[id]; hp1 = (int)a.path_off[id + 1];
-            const int hn0 = hp1 - hp0 < GS ? hp1 - hp0 : GS;
-            h_nd0 = l < hn0 ? a.path_nodes[hp0 + l] : 0;
-            h_code0 = l < hn0 ? (int)a.path_codes[hp0 + l] : 0;
-          }
-          const int del = lcg_next(next, win);
-          wend = win * 2 + 1 - del; w = del; cpos = p; open = true;
-          break;
-        }
-        observe();                           // (a position the sub-sampler dropped still counts)
-      }
-    }
-    if (open) {
-      {
-          int cid[JB]; double ctx[JB][CPL], tmp[JB][CPL];
-          int nj = 0;
-#pragma unroll
-          for (int j = 0; j < JB; ++j) {
-            cid[j] = -1;
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) { ctx[j][k] = 0.0; tmp[j][k] = 0.0; }
-            if (nj == j) {                                       // (the chunk is still open)
-              int found = -1;
-              for (; w < wend; ++w) {
-                if (w == win) continue;
-                const int c = cpos - win + w;
-                if (c < cmin || c >= cmax) continue;
-                found = doc[c];
-                break;
-              }
-              bool dup = false;
-#pragma unroll
-              for (int k = 0; k < j; ++k) dup = dup || cid[k] == found;
-              if (found >= 0 && !dup) { cid[j] = found; ++w; nj = j + 1; ld_word(found, ctx[j]); }
-            }
-          }
-          unsigned alive = (1u << nj) - 1u;                     // (nj == 0: no walk; the position closes below)
-          for (int c0 = hp0; c0 < hp1 && alive; c0 += GS) {
-            const int n = hp1 - c0 < GS ? hp1 - c0 : GS;
-            const int my_nd = c0 == hp0 ? h_nd0 : (l < n ? a.path_nodes[c0 + l] : 0);
-            const int my_code = c0 == hp0 ? h_code0 : (l < n ? (int)a.path_codes[c0 + l] : 0);
-            double pf[PF][CPL];                                   // node vectors requested PF nodes ahead
-#pragma unroll
-            for (int k = 0; k < PF; ++k) ld_node(__shfl(my_nd, gbase + (k < n ? k : 0), 64), k < n, pf[k]);
-            for (int i = 0; i < n && alive; ++i) {
-              const int nd = __shfl(my_nd, gbase + i, 64);
-              const double one_minus_code = 1.0 - (double)__shfl(my_code, gbase + i, 64);
-              double pvl[CPL], acc[CPL];
-#pragma unroll
-              for (int k = 0; k < CPL; ++k) { pvl[k] = pf[0][k]; acc[k] = 0.0; }
-#pragma unroll
-              for (int q = 0; q + 1 < PF; ++q)
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) pf[q][k] = pf[q + 1][k];
-              {
-                const int ia = i + PF;
-                ld_node(__shfl(my_nd, gbase + (ia < n ? ia : 0), 64), ia < n, pf[PF - 1]);
-              }
-#pragma unroll
-              for (int j = 0; j < JB; ++j) {
-                if (alive & (1u << j)) {
-                  double dot = ctx[j][0] * pvl[0];
-#pragma unroll
-                  for (int k = 1; k < CPL; ++k) dot += ctx[j][k] * pvl[k];
-                  const double inner = group_sum64<GS>(dot);
-                  if (inner <= -6.0 || inner >= 6.0) alive &= ~(1u << j);        // (quirk Q13: this pair's walk ends here)
-                  else {
-                    const double gg = (one_minus_code - sig_lookup(tab, inner)) * lr;
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) {
-                      tmp[j][k] += gg * pvl[k];
-                      pvl[k] += gg * ctx[j][k];                    // pv += g * ctx (optimizer.go:125): what pair j + 1 reads
-                      acc[k] += gg * ctx[j][k];
-                    }
-                  }
-                }
-              }
-              add_node(nd, acc);
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < JB; ++j)
-            if (j < nj) add_word(cid[j], tmp[j]);                  // ctx += tmp (model.go:74-76)
-      }
-      if (w >= wend) { open = false; observe(); }          // the position is complete (a chunk that found no context left ends it too)
-    }
-    if (iter % (2 * hot.merge_every) == 0) {
-      merge();
-      if (!__syncthreads_or((open || pos < len) ? 1 : 0)) break;
-    }
   }
   merge();
   if (g == 0 && l == 0) *a.trained = a.n_words;
@@ -1302,17 +1074,14 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     const dim3 grid((unsigned)nwg), block(HOG_THREADS);
 #define GOCTR_HOG_ARGS 0, e.stream, a, streams, w->slice_idx.p, w->clip_lo.p, w->clip_hi.p, hot
     bool launched = false;
-    const bool flat = env_int_w2v("GOCTR_W2V_FLAT", 1) != 0;     // the flattened walk (w2v_hogwild_nmf_kernel); 0: the nested loops
 #define GOCTR_NM(GS, CPL, JB, WPS, PF)                                                                              \
     if (!launched && GSr == GS && cpl == CPL && jb == JB && wps == WPS && pf == PF) {                                \
-      if (flat) hipLaunchKernelGGL((w2v_hogwild_nmf_kernel<GS, CPL, JB, WPS, PF>), grid, block, GOCTR_HOG_ARGS);     \
-      else hipLaunchKernelGGL((w2v_hogwild_nm_kernel<GS, CPL, JB, WPS, PF>), grid, block, GOCTR_HOG_ARGS);           \
-      launched = true;                                                                                               \
+      hipLaunchKernelGGL((w2v_hogwild_nm_kernel<GS, CPL, JB, WPS, PF>), grid, block, GOCTR_HOG_ARGS); launched = true; \
     }
     if (jb > 0) {
       GOCTR_NM(8, 2, 4, 4, 8) GOCTR_NM(16, 2, 4, 4, 8) GOCTR_NM(32, 2, 4, 4, 8)      // dim <= 16 / 32 / 64: the default shapes
       GOCTR_NM(8, 1, 3, 8, 2)                                                      // dim <= 8
-      GOCTR_NM(16, 1, 3, 8, 2) GOCTR_NM(8, 2, 4, 4, 4) GOCTR_NM(8, 2, 4, 4, 6)       // (A/B: one component per lane; shallower prefetch)
+      GOCTR_NM(16, 1, 3, 8, 2) GOCTR_NM(8, 2, 4, 4, 4)                             // (A/B: one component per lane; shallower prefetch)
       GOCTR_CHECK(launched, "goctr_w2v: no node-major kernel for lanes %d x %d components, JB %d, WPS %d, PF %d", GSr, cpl, jb, wps, pf);
     }
 #undef GOCTR_NM
