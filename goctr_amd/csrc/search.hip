@@ -56,6 +56,7 @@ struct goctr_searcher {
   // bounds, candidate lists; pinned staging for ONE upload and ONE download per call
   DevBuf<double> c_sim;
   DevBuf<float> items32, tmax;               // normalised float32 rows; per (query, tile) maxima
+  DevBuf<unsigned short> items_bf;           // the same rows as two bf16 planes [2][rows padded][D]: hi = bf16(x), lo = bf16(x - hi)
   DevBuf<long long> c_idx;
   DevBuf<int> c_cnt;
   DevBuf<unsigned int> c_done;   // folded collect + replay: workgroups of a query that have finished (self-resetting)
@@ -73,7 +74,8 @@ constexpr int KNN_TILE = 2048;     // items per workgroup
 constexpr int KNN_PER = KNN_TILE / 256;
 constexpr int KNN_MAX_K = 256;
 
-__global__ void knn_norm_kernel(const double* items, long long V, int D, double* norms, float* items32) {
+__global__ void knn_norm_kernel(const double* items, long long V, int D, double* norms, float* items32, unsigned short* items_bf,
+                                long long plane_elems) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= V) return;
   const double* v = items + (size_t)i * D;
@@ -83,7 +85,16 @@ __global__ void knn_norm_kernel(const double* items, long long V, int D, double*
   norms[i] = n;
   if (items32) {                             // scan path: v / |v| in float32 (a zero-norm item scores 0, as searchutil.go:21-23 returns)
     const double r = n != 0 ? 1.0 / n : 0.0;
-    for (int d = 0; d < D; ++d) items32[(size_t)i * D + d] = (float)(v[d] * r);
+    for (int d = 0; d < D; ++d) {
+      const float x = (float)(v[d] * r);
+      items32[(size_t)i * D + d] = x;
+      if (items_bf) {                        // x = hi + lo + rest, |rest| <= 2^-16 |x| (two round-to-nearest bf16 steps)
+        const __bf16 h = (__bf16)x;
+        const __bf16 lo = (__bf16)(x - (float)h);
+        items_bf[(size_t)i * D + d] = __builtin_bit_cast(unsigned short, h);
+        items_bf[(size_t)plane_elems + (size_t)i * D + d] = __builtin_bit_cast(unsigned short, lo);
+      }
+    }
   }
 }
 
@@ -488,6 +499,75 @@ __global__ __launch_bounds__(256) void knn_scan_mfma_kernel(const float* __restr
   }
 }
 
+// knn_scan_bf16_kernel<D>: the filter on the bf16 matrix cores (round 5).  The float32-input MFMA of knn_scan_mfma_kernel issues at
+// a sixteenth of the bf16 rate and was what bound the scan (MFMA-busy 60 %, 2.5 TB/s of rows = 0.32 of HBM).  Rows and queries are
+// kept as TWO bf16 planes, x = hi + lo + rest with |rest| <= 2^-16 |x|, and a score is hi.hi + hi.lo + lo.hi on
+// v_mfma_f32_32x32x16_bf16 (products of bf16 pairs are exact in float32; the dropped lo.lo and the two rests are <= 3 x 2^-16 of
+// sum |q_d v_d| <= 1): |a - sim| <= E' = 2^-14 with room for the float32 accumulation (tests/test_knn_filter_bound.py) -- twenty
+// times the float32 filter's E, still two orders below the spacing of the best similarities of a 10^6-item catalogue, so the
+// candidate sets hardly grow.  One MFMA step covers k = 16: at D = 16 a 32-item x 32-query block is THREE instructions.
+template <int D>
+__global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short* __restrict__ items_bf, long long plane_elems,
+                                                            const unsigned short* __restrict__ q_bf /* [2][padded Q][D] */, long long qplane,
+                                                            int Q, int nt, float* __restrict__ tmax, int* __restrict__ c_cnt) {
+  typedef float v16 __attribute__((ext_vector_type(16)));
+  typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  constexpr int KS = D / 16;                           // MFMA k-steps per row
+  __shared__ float red[4][KNN2_QB];
+  const int tile = blockIdx.x, q0 = blockIdx.y * KNN2_QB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, kg = lane >> 5;
+  if (blockIdx.x == 0 && threadIdx.x < KNN2_QB && q0 + (int)threadIdx.x < Q) c_cnt[q0 + threadIdx.x] = 0;   // (knn_collect_kernel counts)
+  // B operands: query q0 + 32 h + col, components 16 s + 8 kg .. + 8, both planes
+  bf8 qh[2][KS], ql[2][KS];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx) {
+      const size_t o = (size_t)(q0 + h * 32 + col) * D + 16 * sx + 8 * kg;
+      qh[h][sx] = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(q_bf + o));
+      ql[h][sx] = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(q_bf + qplane + o));
+    }
+  float mx[2] = {0.f, 0.f};
+  const size_t row0 = (size_t)tile * 1024 + (size_t)wave * 256;
+#pragma unroll 2
+  for (int t = 0; t < 8; ++t) {                        // 8 blocks of 32 items per wavefront; a lane loads 16 bytes per plane and k-step
+    bf8 ah[KS], al[KS];
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx) {
+      const size_t o = (row0 + (size_t)t * 32 + col) * D + 16 * sx + 8 * kg;
+      ah[sx] = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(items_bf + o));
+      al[sx] = __builtin_bit_cast(bf8, *reinterpret_cast<const u4*>(items_bf + plane_elems + o));
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      v16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int sx = 0; sx < KS; ++sx) {                // (small terms first)
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[sx], qh[h][sx], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[sx], ql[h][sx], c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int sx = 0; sx < KS; ++sx) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[sx], qh[h][sx], c, 0, 0, 0);
+      float m = mx[h];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = __builtin_fmaxf(m, c[r]);         // (a NaN score -- an item with an infinite norm -- is dropped)
+      mx[h] = m;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float m = mx[h];
+    m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));     // the other 16 rows of the column
+    if (kg == 0) red[wave][h * 32 + col] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < KNN2_QB && q0 + (int)threadIdx.x < Q) {
+    const float m = __builtin_fmaxf(__builtin_fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), __builtin_fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+    tmax[(size_t)(q0 + threadIdx.x) * nt + tile] = m;
+  }
+}
+
 // The replay of search.go:104-121 over a query's candidates (sorted by item index first: an item appears once).  FOLDED: called by
 // the query's last collect workgroup -- the other workgroups' candidates were written through other L2s, so they (and the count)
 // are read with device-scope loads.  smem: [CAP] similarities | [CAP] indices | [k] | [k].
@@ -775,6 +855,11 @@ static bool knn_scan_mfma(int D, int Q) {
   const char* v = getenv("GOCTR_KNN_MFMA");
   return (v && *v ? *v != '0' : Q >= 48) && knn_scan_tile(D) == 1024;
 }
+// the bf16-plane scan kernel: wherever the matrix-core scan applies and the planes exist (D = 16 / 32); GOCTR_KNN_BF16=0: the float32 MFMA
+static bool knn_scan_bf16(const goctr_searcher* s, int Q) {
+  const char* v = getenv("GOCTR_KNN_BF16");
+  return !(v && *v == '0') && s->items_bf.p && (s->D == 16 || s->D == 32) && knn_scan_mfma(s->D, Q);
+}
 static bool knn_scan_usable(const goctr_searcher* s, int k) {
   const char* v = getenv("GOCTR_KNN_SCAN");
   if (v && *v == '0') return false;
@@ -797,7 +882,9 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   // one upload: [Q x D queries | Q ignore | the queries normalised, float32, padded with zero rows to whole 64-query blocks],
   // one download: [Q x k idx | Q x k sim | Q count]
   const size_t in_q = sizeof(double) * (size_t)Q * D, in_ig = sizeof(long long) * (size_t)Q;
-  const size_t in_q32 = sizeof(float) * (size_t)nqb * KNN2_QB * D, in_bytes = in_q + in_ig + in_q32;
+  const size_t in_q32 = sizeof(float) * (size_t)nqb * KNN2_QB * D;
+  const bool bf = knn_scan_bf16(s, Q);               // the bf16-plane filter (from 48 queries per call on, D = 16 / 32)
+  const size_t in_qbf = bf ? sizeof(unsigned short) * 2 * (size_t)nqb * KNN2_QB * D : 0, in_bytes = in_q + in_ig + in_q32 + in_qbf;
   const size_t o_idx = sizeof(long long) * (size_t)Q * k, o_sim = sizeof(double) * (size_t)Q * k, out_bytes = o_idx + o_sim + sizeof(int) * (size_t)Q;
   if (s->h_in_bytes < in_bytes) {
     if (s->h_in) s->retired.push_back(s->h_in);
@@ -825,11 +912,28 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
     if (qn != 0 && std::isfinite(qn))
       for (int d = 0; d < D; ++d) h_q32[(size_t)i * D + d] = (float)(queries[(size_t)i * D + d] / qn);
   }
+  if (bf) {                                          // the normalised queries as two bf16 planes (round to nearest even, like the device's casts)
+    unsigned short* h_qbf = reinterpret_cast<unsigned short*>(static_cast<char*>(s->h_in) + in_q + in_ig + in_q32);
+    const size_t plane = (size_t)nqb * KNN2_QB * D;
+    auto f2bf = [](float x) -> unsigned short {
+      uint32_t u; memcpy(&u, &x, 4);
+      if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      return (unsigned short)(u >> 16);
+    };
+    auto bf2f = [](unsigned short h) -> float { uint32_t u = (uint32_t)h << 16; float x; memcpy(&x, &u, 4); return x; };
+    for (size_t i = 0; i < plane; ++i) {
+      const float x = h_q32[i];
+      const unsigned short hi = f2bf(x);
+      h_qbf[i] = hi; h_qbf[plane + i] = f2bf(x - bf2f(hi));
+    }
+  }
   GOCTR_HIP(hipMemcpyAsync(s->in_pack.p, s->h_in, in_bytes, hipMemcpyHostToDevice, e.stream));
   const double* d_q = reinterpret_cast<const double*>(s->in_pack.p);
   const long long* d_ig = reinterpret_cast<const long long*>(s->in_pack.p + in_q);
   const float* d_q32 = reinterpret_cast<const float*>(s->in_pack.p + in_q + in_ig);
-  const float E = (float)(D + 8) * 1.1920929e-07f;      // (D + 8) 2^-23
+  // the filter's error bound |a - sim|: float32 arithmetic (D + 8) 2^-23; bf16-plane arithmetic 2^-14 (knn_scan_bf16_kernel)
+  const float E = bf ? 6.103515625e-05f : (float)(D + 8) * 1.1920929e-07f;
   char* d_out = nullptr;                              // the device's view of the pinned output buffer (zero-copy: 10 KB per call)
   GOCTR_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_out), s->h_out, 0));
   long long* d_oi = reinterpret_cast<long long*>(d_out);
@@ -837,7 +941,12 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   int* d_oc = reinterpret_cast<int*>(d_out + o_idx + o_sim);
 #define GOCTR_KNN_SCAN(DD, IPT) hipLaunchKernelGGL((knn_scan_kernel<DD, IPT>), dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, \
                                                   (long long)s->V, d_q32, Q, nt, s->tmax.p, s->c_cnt.p)
-  if (knn_scan_mfma(D, Q)) {
+  if (bf) {
+    const unsigned short* d_qbf = reinterpret_cast<const unsigned short*>(s->in_pack.p + in_q + in_ig + in_q32);
+    const long long qplane = (long long)nqb * KNN2_QB * D, iplane = (long long)(s->items_bf.n / 2);
+    if (D == 16) hipLaunchKernelGGL(knn_scan_bf16_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->c_cnt.p);
+    else hipLaunchKernelGGL(knn_scan_bf16_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->c_cnt.p);
+  } else if (knn_scan_mfma(D, Q)) {
     if (D == 16) hipLaunchKernelGGL(knn_scan_mfma_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, d_q32, Q, nt, s->tmax.p, s->c_cnt.p);
     else hipLaunchKernelGGL(knn_scan_mfma_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, d_q32, Q, nt, s->tmax.p, s->c_cnt.p);
   } else if (D == 16) GOCTR_KNN_SCAN(16, 4);
@@ -879,14 +988,15 @@ int goctr_searcher_create(const double* items, int64_t V, int D, goctr_searcher*
   goctr_searcher* s = new goctr_searcher;
   s->V = V; s->D = D;
   if (s->items.alloc((size_t)V * D, false) || s->items.upload(items, (size_t)V * D) || s->norms.alloc((size_t)V, false) ||
-      (knn_scan_ipt(D) > 0 && s->items32.alloc((size_t)round_up64(V, 2048) * D, false))) {
+      (knn_scan_ipt(D) > 0 && s->items32.alloc((size_t)round_up64(V, 2048) * D, false)) ||
+      ((D == 16 || D == 32) && s->items_bf.alloc((size_t)2 * round_up64(V, 2048) * D, true))) {      // (zeroed: the pad rows score 0)
     delete s;
     return -1;
   }
   if (s->items32.p)      // (zero rows up to a whole tile: the matrix-core scan kernel reads whole tiles)
     (void)hipMemsetAsync(s->items32.p + (size_t)V * D, 0, sizeof(float) * (size_t)(round_up64(V, 2048) - V) * D, engine().stream);
   hipLaunchKernelGGL(knn_norm_kernel, dim3((unsigned)cdiv(V, 256)), dim3(256), 0, engine().stream, s->items.p, (long long)V, D,
-                     s->norms.p, s->items32.p);
+                     s->norms.p, s->items32.p, s->items_bf.p, (long long)(s->items_bf.n / 2));
   if (hipGetLastError() != hipSuccess) { set_error("knn_norm_kernel launch failed"); delete s; return -1; }
   *out = s;
   return 0;

@@ -73,7 +73,7 @@ def test_scan_path_query_blocks(oracle, V, D, k, Q):
     # tile kernels; either scan kernel; the replay as a launch of its own instead of the last collect workgroup's job; 1 / 32
     # collect workgroups per query instead of 8
     for var, val in (("GOCTR_KNN_SCAN", "0"), ("GOCTR_KNN_MFMA", "1"), ("GOCTR_KNN_MFMA", "0"), ("GOCTR_KNN_FOLD", "0"), ("GOCTR_KNN_G", "1"),
-                     ("GOCTR_KNN_G", "32")):
+                     ("GOCTR_KNN_G", "32"), ("GOCTR_KNN_BF16", "0")):
         os.environ[var] = val
         try:
             idx0, sim0, cnt0 = s.search_vectors(queries, k, ignore)
@@ -148,7 +148,7 @@ def test_large_scan_properties():
 
 def test_bench_shape_matches_oracle_bit_exact(oracle):
     """the shape bench.py --workload knn times (V = 10^6, D = 16, k = 10, the same seeded items): 64 queries per call ->
-    knn_scan_mfma_kernel<16> over 977 tiles -> knn_collect -> knn_replay.  Q = 47 is the last call size on the VALU scan
+    knn_scan_bf16_kernel<16> (round 5; round 4: knn_scan_mfma_kernel<16>) over 977 tiles -> knn_collect (+ replay).  Q = 47 is the last call size on the VALU scan
     kernel, 48 the first on the MFMA one, 64 a full query block, 65 two blocks; each call also forced onto the other scan
     kernel.  Indices, float64 similarities and counts equal the oracle's sequential loop for EVERY query."""
     from goctr_amd import search as gs
@@ -167,14 +167,17 @@ def test_bench_shape_matches_oracle_bit_exact(oracle):
     ign[5] = 123456
     want = [oracle.knn_search(items, allq[q], k, ignore=int(ign[q]), norms=norms) for q in range(65)]
     for Q in (47, 48, 64, 65):
-        for mfma in (None, "0", "1"):
+        # default dispatch (>= 48 queries: the bf16-plane matrix-core filter), the VALU filter, the float32 matrix-core filter
+        for mfma, bf16 in ((None, None), ("0", None), ("1", None), ("1", "0")):
             if mfma is not None:
                 os.environ["GOCTR_KNN_MFMA"] = mfma
+            if bf16 is not None:
+                os.environ["GOCTR_KNN_BF16"] = bf16
             try:
                 idx, sim, cnt = s.search_vectors(allq[:Q], k, ign[:Q])
             finally:
-                os.environ.pop("GOCTR_KNN_MFMA", None)
+                os.environ.pop("GOCTR_KNN_MFMA", None); os.environ.pop("GOCTR_KNN_BF16", None)
             for q in range(Q):
                 ri, rs, _ = want[q]
-                assert cnt[q] == ri.size == k, (Q, mfma, q)
-                assert np.array_equal(idx[q, :k], ri) and np.array_equal(sim[q, :k], rs), (Q, mfma, q)
+                assert cnt[q] == ri.size == k, (Q, mfma, bf16, q)
+                assert np.array_equal(idx[q, :k], ri) and np.array_equal(sim[q, :k], rs), (Q, mfma, bf16, q)

@@ -74,3 +74,42 @@ def test_candidate_set_argument():
         S = sorted(C + extra)
         assert insert_all(sims, S, k) == full
         assert insert_all(sims, sorted(C), k) == full
+
+
+def _bf16(x):
+    """float32 array -> the nearest bfloat16 (ties to even), back as float32: the device's (__bf16) cast"""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16
+    return (u & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("D", [16, 32])
+def test_bf16_plane_filter_error_is_inside_2_pow_minus_14(D):
+    """knn_scan_bf16_kernel (round 5): rows and queries as two bf16 planes, x = hi + lo + rest, score = hi.hi + hi.lo + lo.hi with
+    float32 accumulation (v_mfma_f32_32x32x16_bf16: the products of bf16 pairs are exact in float32).  |score - cosine| <= 2^-14 for
+    any accumulation order of the 3 D products, whatever the vectors' magnitudes."""
+    rng = np.random.default_rng(100 + D)
+    E = 2.0 ** -14
+    worst = 0.0
+    for trial in range(400):
+        scale_q, scale_v = 10.0 ** rng.uniform(-150, 150, size=2)
+        q = rng.standard_normal(D) * scale_q
+        if trial % 3 == 0:
+            v = (q / scale_q + 1e-3 * rng.standard_normal(D)) * scale_v
+        elif trial % 3 == 1:
+            v = rng.standard_normal(D) * scale_v * np.where(rng.random(D) < 0.2, 1.0, 1e-9)
+        else:
+            v = rng.standard_normal(D) * scale_v
+        sim = cosine64(q, v)
+        q32 = (q / np.sqrt((q * q).sum())).astype(np.float32)
+        v32 = (v / np.sqrt((v * v).sum())).astype(np.float32)
+        qh = _bf16(q32); ql = _bf16(q32 - qh)
+        vh = _bf16(v32); vl = _bf16(v32 - vh)
+        assert np.all(np.abs(q32 - qh - ql) <= 2.0 ** -16 * np.abs(q32) + 1e-45)      # the two-plane split's residual
+        terms = np.concatenate([vl * qh, vh * ql, vh * qh]).astype(np.float32)        # (each product exact in float32)
+        for order in (np.arange(3 * D), np.arange(3 * D)[::-1], rng.permutation(3 * D)):
+            acc = np.float32(0.0)
+            for i in order:
+                acc = np.float32(acc + terms[i])
+            worst = max(worst, abs(float(acc) - sim))
+    assert 0 < worst <= E, (worst, E)
