@@ -573,12 +573,12 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
 // are read with device-scope loads.  smem: [CAP] similarities | [CAP] indices | [k] | [k].
 template <bool FOLDED>
 __device__ __forceinline__ void knn_replay_body(int q, const int* c_cnt, const long long* c_idx, const double* c_sim, int k,
-                                                long long* out_idx, double* out_sim, int* out_cnt, double* smem) {
+                                                long long* out_idx, double* out_sim, int* out_cnt, double* smem, int n_known) {
   double* s_sim = smem;                                                  // [CAP] sorted by item index
   long long* s_idx = reinterpret_cast<long long*>(s_sim + KNN2_CAP);     // [CAP]
   double* nb_s = reinterpret_cast<double*>(s_idx + KNN2_CAP);            // [k]
   long long* nb_i = reinterpret_cast<long long*>(nb_s + k);              // [k]
-  const int n = FOLDED ? __hip_atomic_load(c_cnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : c_cnt[q];
+  const int n = FOLDED ? n_known : c_cnt[q];          // (folded: the ticket carried the count)
   if (n > KNN2_CAP) { if (threadIdx.x == 0) out_cnt[q] = -1; return; }
   const long long* ci = c_idx + (size_t)q * KNN2_CAP;
   const double* cs = c_sim + (size_t)q * KNN2_CAP;
@@ -719,8 +719,9 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   // tile whose maximum is <= 0 -- the list below (tm > 0) would never visit it while the reference returns it (search.go:104:
   // score > low, low = 0).  Hand the query to the exact tile kernels instead (the replay kernel reports the overflow mark).
   // (A zero query has no neighbours at all -- searchutil.go:21-23 -- and needs no second opinion.)
+  int my_n = 0;                                         // candidates this thread appended (the fan-in's ticket carries the sum)
   bool skip = false;
-  if (!(tb > 0.f)) { if (g == 0 && threadIdx.x == 0 && knn_cq[D] != 0) atomicAdd(&c_cnt[q], KNN2_CAP + 1); skip = true; }
+  if (!(tb > 0.f)) { if (g == 0 && threadIdx.x == 0 && knn_cq[D] != 0) { atomicAdd(&c_cnt[q], KNN2_CAP + 1); my_n += KNN2_CAP + 1; } skip = true; }
   if (!skip) {
   // the listed tiles in tile order: rank = (listed tiles before this one); tile of rank r belongs to workgroup r mod G
   int base = 0;
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
     __syncthreads();
   }
   int nmy = n_my;
-  if (nmy > KNN2_MY) { if (threadIdx.x == 0) atomicAdd(&c_cnt[q], KNN2_CAP + 1); nmy = 0; }     // (the replay reports it)
+  if (nmy > KNN2_MY) { if (threadIdx.x == 0) { atomicAdd(&c_cnt[q], KNN2_CAP + 1); my_n += KNN2_CAP + 1; } nmy = 0; }     // (the replay reports it)
   const double qn = knn_cq[D];
   const double bd = (double)sh_sb;
   const long long ig = ignore[q];
@@ -750,18 +751,29 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   typedef float f4 __attribute__((ext_vector_type(4)));
   // survivors of the float32 filter are scored exactly and join the query's candidates
   auto exact = [&](long long it) {
-    const double n2 = norms[it];
-    if (qn == 0 || n2 == 0) return;
+    // the norm and the whole float64 row are requested together (the early-out on a zero norm used to hold the row loads back a
+    // memory round trip)
     const double* v = items + (size_t)it * D;
+    const double n2 = norms[it];
     double dot = 0;
-    for (int d = 0; d < D; d += 2) {                 // dot += q[d] * v[d], d ascending (searchutil.go:17-20)
-      const d2 x = *reinterpret_cast<const d2*>(v + d);
-      dot += knn_cq[d] * x[0];
-      dot += knn_cq[d + 1] * x[1];
+    if (D == 16) {
+      d2 x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const d2*>(v + 2 * u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { dot += knn_cq[2 * u] * x[u][0]; dot += knn_cq[2 * u + 1] * x[u][1]; }   // d ascending (searchutil.go:17-20)
+    } else {
+      for (int d = 0; d < D; d += 2) {
+        const d2 x = *reinterpret_cast<const d2*>(v + d);
+        dot += knn_cq[d] * x[0];
+        dot += knn_cq[d + 1] * x[1];
+      }
     }
+    if (qn == 0 || n2 == 0) return;
     const double sim = dot / qn / n2;                 // searchutil.go:24-25
     if (!(sim > 0 && sim >= bd)) return;
     const int pos = atomicAdd(&c_cnt[q], 1);
+    ++my_n;
     if (pos < KNN2_CAP) {
       // (device-scope stores: the query's last workgroup -- possibly on another XCD -- reads them in this launch when folded)
       __hip_atomic_store(c_idx + (size_t)q * KNN2_CAP + pos, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -819,18 +831,25 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   if (!c_done) return;
   // ---- fan-in: the candidates went out as device-scope (write-through) stores and the barrier's s_waitcnt has seen them
   // acknowledged -- no release FENCE (it would write back this XCD's whole L2, once per workgroup) -- take a ticket
-  __shared__ unsigned int is_last;
+  // The ticket word carries the candidate count too: + (this workgroup's candidates << 8) + 1, so the last arriver knows the
+  // query's total from the value its own fetch-add returns instead of a further device-scope load (a memory round trip).
+  __shared__ unsigned int is_last, wg_n, total_n;
+  if (threadIdx.x == 0) wg_n = 0;
+  __syncthreads();
+  if (my_n) atomicAdd(&wg_n, (unsigned int)my_n);
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    const unsigned int prev = __hip_atomic_fetch_add(&c_done[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = prev == (unsigned int)G - 1u ? 1u : 0u;
+    const unsigned int mine = (wg_n << 8) + 1u;
+    const unsigned int prev = __hip_atomic_fetch_add(&c_done[q], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (prev & 255u) == (unsigned int)G - 1u ? 1u : 0u;
+    total_n = (prev + mine) >> 8;
     if (is_last) __hip_atomic_store(&c_done[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
   }
   __syncthreads();
   if (!is_last) return;
   double* rs = knn_cq + D + 1 + (D + 1) / 2;                             // behind the query operands (16-byte aligned: D is a multiple of 4)
-  knn_replay_body<true>(q, c_cnt, c_idx, c_sim, k, out_idx, out_sim, out_cnt, rs);
+  knn_replay_body<true>(q, c_cnt, c_idx, c_sim, k, out_idx, out_sim, out_cnt, rs, (int)total_n);
 }
 
 // out_cnt[q] = -1: more candidates than the replay takes (the host falls back to the tile kernels)
@@ -838,7 +857,7 @@ __global__ __launch_bounds__(256) void knn_replay_kernel(const int* __restrict__
                                                          const double* __restrict__ c_sim, int k, long long* out_idx, double* out_sim,
                                                          int* out_cnt) {
   extern __shared__ __attribute__((aligned(16))) double knn3_smem[];
-  knn_replay_body<false>((int)blockIdx.x, c_cnt, c_idx, c_sim, k, out_idx, out_sim, out_cnt, knn3_smem);
+  knn_replay_body<false>((int)blockIdx.x, c_cnt, c_idx, c_sim, k, out_idx, out_sim, out_cnt, knn3_smem, -1);
 }
 
 }  // namespace
