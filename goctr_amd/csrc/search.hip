@@ -568,6 +568,16 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
   }
 }
 
+// 64-bit v_readlane (the lane index must be wave-uniform)
+__device__ __forceinline__ long long knn_readlane(long long x, int lane) {
+  const int lo = __builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)x, lane);
+  const int hi = __builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)x >> 32), lane);
+  return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+__device__ __forceinline__ double knn_readlane(double x, int lane) {
+  return __builtin_bit_cast(double, knn_readlane(__builtin_bit_cast(long long, x), lane));
+}
+
 // The replay of search.go:104-121 over a query's candidates (sorted by item index first: an item appears once).  FOLDED: called by
 // the query's last collect workgroup -- the other workgroups' candidates were written through other L2s, so they (and the count)
 // are read with device-scope loads.  smem: [CAP] similarities | [CAP] indices | [k] | [k].
@@ -622,9 +632,11 @@ __device__ __forceinline__ void knn_replay_body(int q, const int* c_cnt, const l
       const double bs = lane < m ? s_sim[r0 + lane] : 0.0;
       const long long bi = lane < m ? s_idx[r0 + lane] : -1;
       for (int j = 0; j < m; ++j) {
-        const double ts = __shfl(bs, j, 64);
+        // (j, p and k - 1 are wave-uniform: v_readlane instead of a ds_bpermute round trip -- an insertion was ~10 dependent
+        // bpermutes, ~1.3 k cycles, and a query has a few dozen)
+        const double ts = knn_readlane(bs, j);
         if (!(ts > low)) continue;                                  // (uniform) search.go:104
-        const long long ti = __shfl(bi, j, 64);
+        const long long ti = knn_readlane(bi, j);
         const unsigned long long gt = __ballot(lane < k && ts > s);
         if (!gt) continue;
         const int p = __builtin_ctzll(gt);
@@ -637,7 +649,7 @@ __device__ __forceinline__ void knn_replay_body(int q, const int* c_cnt, const l
         const long long fid = __shfl(id, src, 64);
         if (lane == p) { s = ts; id = ti; }
         else if (start) { s = fs; id = fid; }
-        low = __shfl(s, k - 1, 64);
+        low = knn_readlane(s, k - 1);
       }
     }
     if (lane < k) { nb_s[lane] = s; nb_i[lane] = id; }
@@ -684,33 +696,27 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   for (int t = threadIdx.x; t < nt; t += 256) m = fmaxf(m, tm[t]);      // (t mod 64 == lane)
   gmax[wave][lane] = m;
   __syncthreads();
-  if (wave == 0) {
-    // 256 groups of tiles (tile mod 256): lane L holds the maxima of groups L, 64 + L, 128 + L, 192 + L.  (Round 4 folded them
-    // into 64 groups: the k-th largest of 64 group maxima sits near the 45th best item of a random catalogue, of 256 near the
-    // 13th -- and every listed tile is 64 KB the collect pass reads again, per query.)
-    float g4[4] = {gmax[0][lane], gmax[1][lane], gmax[2][lane], gmax[3][lane]};
+  {
+    // 256 groups of tiles (tile mod 256 = thread): the bound is the `rounds`-th largest of their maxima.  (Round 4 folded them into
+    // 64 groups and picked it with k rounds of a 64-lane arg-max: 6 dependent ds_bpermute steps per round, ~4 us; and the k-th
+    // largest of 64 group maxima sits near the 45th best item of a random catalogue, of 256 near the 13th -- every listed tile is
+    // 64 KB the collect pass reads again, per query.)  Every thread ranks its own group's maximum among the 256 -- broadcast LDS
+    // reads, no dependent chain; ties by group index, so exactly one thread holds rank rounds - 1.
+    const float* gflat = &gmax[0][0];
+    const float v = gflat[threadIdx.x];
     const int rounds = k + (ignore[q] >= 0 ? 1 : 0);
-    float kth = 0.f;
-    for (int r = 0; r < rounds; ++r) {
-      const float mine = fmaxf(fmaxf(g4[0], g4[1]), fmaxf(g4[2], g4[3]));
-      float bs = mine; int bl = lane;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float so = __shfl_xor(bs, o, 64);
-        const int lo = __shfl_xor(bl, o, 64);
-        if (so > bs || (so == bs && lo < bl)) { bs = so; bl = lo; }
-      }
-      if (!(bs > 0.f)) { kth = 0.f; break; }           // (uniform)
-      kth = bs;
-      if (lane == bl) {                                 // retire ONE group holding that maximum
-        if (g4[0] == bs) g4[0] = -1.f; else if (g4[1] == bs) g4[1] = -1.f; else if (g4[2] == bs) g4[2] = -1.f; else g4[3] = -1.f;
-      }
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < 256; ++j) {
+      const float o = gflat[j];
+      rank += (o > v || (o == v && j < (int)threadIdx.x)) ? 1 : 0;
     }
-    if (lane == 0) { sh_tb = kth - 2.f * E; sh_sb = kth - E; }
-  } else if (threadIdx.x == 64) {
-    double qn = 0;
-    for (int d = 0; d < D; ++d) qn += knn_cq[d] * knn_cq[d];           // embutil.Norm (search.go:86-90)
-    knn_cq[D] = sqrt(qn);
+    if (rank == rounds - 1) { const float kth = v > 0.f ? v : 0.f; sh_tb = kth - 2.f * E; sh_sb = kth - E; }
+    if (threadIdx.x == 64) {
+      double qn = 0;
+      for (int d = 0; d < D; ++d) qn += knn_cq[d] * knn_cq[d];           // embutil.Norm (search.go:86-90)
+      knn_cq[D] = sqrt(qn);
+    }
   }
   __syncthreads();
   const float tb = sh_tb;
