@@ -54,12 +54,9 @@ struct goctr_searcher {
   DevBuf<int> out_cnt, cand_cut;
   // scan path: 1 / norm per item, the call's packed input (queries | ignore) and output (idx | sim | count), per-tile maxima,
   // bounds, candidate lists; pinned staging for ONE upload and ONE download per call
-  DevBuf<double> c_sim;
   DevBuf<float> items32, tmax;               // normalised float32 rows; per (query, tile) maxima
   DevBuf<unsigned short> items_bf;           // the same rows as two bf16 planes [2][rows padded][D]: hi = bf16(x), lo = bf16(x - hi)
-  DevBuf<long long> c_idx;
-  DevBuf<int> c_cnt;
-  DevBuf<unsigned int> c_done;   // folded collect + replay: workgroups of a query that have finished (self-resetting)
+  DevBuf<float> bmax;                        // per (tile, sub-block, query) maxima [tiles][sub-blocks][padded queries]
   DevBuf<unsigned char> in_pack, out_pack;
   void* h_in = nullptr; void* h_out = nullptr; size_t h_in_bytes = 0, h_out_bytes = 0;
   bool lds_ok = false;
@@ -349,7 +346,6 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const double* __restrict
 // ------------------------------------------------------------------------------------------------------------- scan path
 constexpr int KNN2_QB = 64;        // queries per workgroup (the rows are read once per block: once per call up to 64 queries)
 constexpr int KNN2_CAP = 2048;     // candidates per query the replay kernel takes
-constexpr int KNN2_G = 8;          // collect workgroups per query (default; GOCTR_KNN_G)
 
 template <int CTRL>
 __device__ __forceinline__ float knn_dpp_f32(float v) {
@@ -366,12 +362,11 @@ __device__ __forceinline__ float knn_dpp_f32(float v) {
 template <int D, int IPT>
 __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ items32, long long V,
                                                        const float* __restrict__ q32 /* normalised, padded to whole blocks */, int Q,
-                                                       int nt, float* __restrict__ tmax, int* __restrict__ c_cnt) {
+                                                       int nt, float* __restrict__ tmax, float* __restrict__ bmax, int qpad) {
   static_assert(D % 16 == 0, "scalar-load batches of 16 floats");
   constexpr int TILE = 256 * IPT;
   __shared__ float red[16 * KNN2_QB];                  // [16 rows of 16 lanes][QB]
   const int tile = blockIdx.x, q0 = blockIdx.y * KNN2_QB;
-  if (blockIdx.x == 0 && threadIdx.x < KNN2_QB && q0 + (int)threadIdx.x < Q) c_cnt[q0 + threadIdx.x] = 0;   // (knn_collect_kernel, the next launch, appends)
   typedef float f2 __attribute__((ext_vector_type(2)));
   typedef float f4 __attribute__((ext_vector_type(4)));
   f2 rowv[IPT][D / 2];
@@ -430,8 +425,14 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
   }
   __syncthreads();
   if ((int)threadIdx.x < nq) {
+    // sub-block r of the tile = the rows of threads 16 r .. 16 r + 15 (items j 256 + 16 r + i): its maximum goes to
+    // bmax [tile][16][queries] (the collect pass reads only the sub-blocks that can hold a candidate), the tile's to tmax
     float m = 0.f;
-    for (int r = 0; r < 16; ++r) m = fmaxf(m, red[r * KNN2_QB + threadIdx.x]);
+    for (int r = 0; r < 16; ++r) {
+      const float x = red[r * KNN2_QB + threadIdx.x];
+      bmax[((size_t)tile * 16 + r) * qpad + q0 + threadIdx.x] = x;
+      m = fmaxf(m, x);
+    }
     tmax[(size_t)(q0 + threadIdx.x) * nt + tile] = m;
   }
 }
@@ -444,13 +445,12 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
 // the same bound E.  The normalised rows are padded with zero rows to whole tiles (goctr_searcher_create): no tail checks.
 template <int D>
 __global__ __launch_bounds__(256) void knn_scan_mfma_kernel(const float* __restrict__ items32, const float* __restrict__ q32 /* padded */,
-                                                            int Q, int nt, float* __restrict__ tmax, int* __restrict__ c_cnt) {
+                                                            int Q, int nt, float* __restrict__ tmax, float* __restrict__ bmax, int qpad) {
   typedef float v16 __attribute__((ext_vector_type(16)));
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ float red[4][KNN2_QB];
   const int tile = blockIdx.x, q0 = blockIdx.y * KNN2_QB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
-  if (blockIdx.x == 0 && threadIdx.x < KNN2_QB && q0 + (int)threadIdx.x < Q) c_cnt[q0 + threadIdx.x] = 0;   // (knn_collect_kernel counts)
   // this lane's query components: query q0 + h 32 + col, dimensions 2 j + half
   float qb[2][D / 2];
 #pragma unroll
@@ -480,10 +480,13 @@ __global__ __launch_bounds__(256) void knn_scan_mfma_kernel(const float* __restr
       v16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int j = 0; j < D / 2; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], qb[h][j], c, 0, 0, 0);
-      float m = mx[h];
+      float m = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) m = __builtin_fmaxf(m, c[r]);         // (a NaN score -- an item with an infinite norm -- is dropped)
-      mx[h] = m;
+      // this 32-item block's maximum per query (both row halves): bmax [tile][32 blocks][queries]
+      m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+      if (half == 0) bmax[((size_t)tile * 32 + wave * 8 + t) * qpad + q0 + h * 32 + col] = m;
+      mx[h] = __builtin_fmaxf(mx[h], m);
     }
   }
 #pragma unroll
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(256) void knn_scan_mfma_kernel(const float* __restr
 template <int D>
 __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short* __restrict__ items_bf, long long plane_elems,
                                                             const unsigned short* __restrict__ q_bf /* [2][padded Q][D] */, long long qplane,
-                                                            int Q, int nt, float* __restrict__ tmax, int* __restrict__ c_cnt) {
+                                                            int Q, int nt, float* __restrict__ tmax, float* __restrict__ bmax, int qpad) {
   typedef float v16 __attribute__((ext_vector_type(16)));
   typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -517,7 +520,6 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
   __shared__ float red[4][KNN2_QB];
   const int tile = blockIdx.x, q0 = blockIdx.y * KNN2_QB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, kg = lane >> 5;
-  if (blockIdx.x == 0 && threadIdx.x < KNN2_QB && q0 + (int)threadIdx.x < Q) c_cnt[q0 + threadIdx.x] = 0;   // (knn_collect_kernel counts)
   // B operands: query q0 + 32 h + col, components 16 s + 8 kg .. + 8, both planes
   bf8 qh[2][KS], ql[2][KS];
 #pragma unroll
@@ -549,10 +551,13 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
       }
 #pragma unroll
       for (int sx = 0; sx < KS; ++sx) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[sx], qh[h][sx], c, 0, 0, 0);
-      float m = mx[h];
+      float m = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) m = __builtin_fmaxf(m, c[r]);         // (a NaN score -- an item with an infinite norm -- is dropped)
-      mx[h] = m;
+      // this 32-item block's maximum per query (both row halves): bmax [tile][32 blocks][queries]
+      m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+      if (kg == 0) bmax[((size_t)tile * 32 + wave * 8 + t) * qpad + q0 + h * 32 + col] = m;
+      mx[h] = __builtin_fmaxf(mx[h], m);
     }
   }
 #pragma unroll
@@ -578,37 +583,206 @@ __device__ __forceinline__ double knn_readlane(double x, int lane) {
   return __builtin_bit_cast(double, knn_readlane(__builtin_bit_cast(long long, x), lane));
 }
 
-// The replay of search.go:104-121 over a query's candidates (sorted by item index first: an item appears once).  FOLDED: called by
-// the query's last collect workgroup -- the other workgroups' candidates were written through other L2s, so they (and the count)
-// are read with device-scope loads.  smem: [CAP] similarities | [CAP] indices | [k] | [k].
-template <bool FOLDED>
-__device__ __forceinline__ void knn_replay_body(int q, const int* c_cnt, const long long* c_idx, const double* c_sim, int k,
-                                                long long* out_idx, double* out_sim, int* out_cnt, double* smem, int n_known) {
-  double* s_sim = smem;                                                  // [CAP] sorted by item index
-  long long* s_idx = reinterpret_cast<long long*>(s_sim + KNN2_CAP);     // [CAP]
+// knn_collect_kernel: ONE workgroup per query does everything behind the scan -- bound, tile list, sub-block list, float32 filter
+// of the listed sub-blocks' items, exact similarities, the reference's insertion replayed over the candidates, results into the
+// pinned output buffer.  (Round 4: eight workgroups per query re-read every listed TILE -- 64 KB each, ~45 of them per query, the
+// launch at 83 % waiting -- and a third launch replayed; round 5 first folded the replay into the last workgroup to finish --
+// no faster, the dependent chain is the same -- and then cut the re-read itself: the scan kernels also leave the maximum of
+// every 32-item SUB-BLOCK, so a query re-reads ~13 sub-blocks of 2 KB instead of ~13 tiles of 64 KB, which one workgroup does in
+// two rounds of loads, with the candidates in LDS: no global candidate lists, no atomics on them, no fan-in.)
+//   bound   L = the `rounds`-th largest (k, + 1 when an item is ignored: it may own one) of 256 GROUP maxima (group = tile mod 256;
+//           the maxima belong to distinct items, so k items have a score >= L): every member of the candidate set C has
+//           similarity >= L - E and lies in a tile / sub-block whose maximum is >= L - 2 E.  Every thread ranks its own group's
+//           maximum among the 256 (broadcast LDS reads; ties by group index: exactly one thread holds the rank).
+//   lists   tiles with maximum >= L - 2 E (> 0), then their sub-blocks with maximum >= L - 2 E: compacted into LDS
+//   filter  the listed sub-blocks' items pass the float32 filter (its error is inside E whichever scan kernel made the maxima);
+//           survivors are scored EXACTLY (float64, the reference's d-order and its two divisions) and join the candidates when they
+//           reach L - E
+//   replay  the candidates sorted by item index, search.go:104-121 over them by one wavefront with the k-array in registers: an
+//           insertion into a non-increasing array puts the item at p = the first position with score > a[p]; the element it
+//           displaces is carried down PAST its equals (the reference's strict `>` for displaced elements too) and lands behind its
+//           tie run, displacing the first element of the next run, and so on; the last carry is dropped.  So: position p takes the
+//           item, every later run START takes the FIRST element of the run before it, everything else stays (quirk Q22;
+//           tests/test_knn_replay_rule.py checks the rule against the literal loop).  Two ballots, one shuffle per insertion.
+// out_cnt[q] = -1: the query is handed to the exact tile kernels (bound <= 0, or a list outgrew its LDS array).
+// sb_mode 0: sub-block b of a tile = items 32 b .. 32 b + 31 (the matrix-core scan kernels); 1: items j 256 + 16 b + i, j < tile / 256,
+// i < 16 (the VALU scan kernel: the rows of 16 adjacent threads)
+constexpr int KNN2_MYT = 256;      // listed tiles per query
+constexpr int KNN2_MYB = 1024;     // listed sub-blocks per query
+__global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restrict__ items, const double* __restrict__ norms,
+                                                          const float* __restrict__ items32, long long V, int D,
+                                                          const double* __restrict__ queries, const float* __restrict__ q32,
+                                                          const long long* __restrict__ ignore, const float* __restrict__ tmax,
+                                                          const float* __restrict__ bmax, int qpad, int nt, int tile_items, int sb_mode,
+                                                          int k, float E, long long* out_idx, double* out_sim, int* out_cnt) {
+  extern __shared__ __attribute__((aligned(16))) double knn_cq[];       // [D] the query | its norm | [D] floats: normalised | the replay's arrays
+  float* cq32 = reinterpret_cast<float*>(knn_cq + D + 1);
+  double* s_sim = knn_cq + D + 1 + (D + 1) / 2;                          // [CAP] candidates' similarities
+  long long* s_idx = reinterpret_cast<long long*>(s_sim + KNN2_CAP);     // [CAP] ... item indices
   double* nb_s = reinterpret_cast<double*>(s_idx + KNN2_CAP);            // [k]
   long long* nb_i = reinterpret_cast<long long*>(nb_s + k);              // [k]
-  const int n = FOLDED ? n_known : c_cnt[q];          // (folded: the ticket carried the count)
-  if (n > KNN2_CAP) { if (threadIdx.x == 0) out_cnt[q] = -1; return; }
-  const long long* ci = c_idx + (size_t)q * KNN2_CAP;
-  const double* cs = c_sim + (size_t)q * KNN2_CAP;
-  auto ld_i = [&](int e) { return FOLDED ? __hip_atomic_load(ci + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ci[e]; };
-  auto ld_s = [&](int e) { return FOLDED ? __hip_atomic_load(cs + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cs[e]; };
-  for (int r = threadIdx.x; r < k; r += 256) { nb_s[r] = 0.0; nb_i[r] = -1; }
-  // the unsorted list once into LDS (its second half: the sorted one is built in the first), then the rank sort out of LDS
-  long long* u_idx = s_idx;                                              // (reused: ranks are written to s_* only after the barrier)
-  double* u_sim = s_sim;
-  for (int e = threadIdx.x; e < n; e += 256) { u_idx[e] = ld_i(e); u_sim[e] = ld_s(e); }
+  __shared__ float gmax[256];
+  __shared__ float sh_tb, sh_sb;
+  __shared__ int wave_cnt[4];
+  __shared__ int my_tiles[KNN2_MYT];
+  __shared__ int my_blocks[KNN2_MYB];
+  __shared__ int n_blk, n_cand;
+  const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* tm = tmax + (size_t)q * nt;
+  for (int d = threadIdx.x; d < D; d += 256) { knn_cq[d] = queries[(size_t)q * D + d]; cq32[d] = q32[(size_t)q * D + d]; }
+  if (threadIdx.x == 0) { n_blk = 0; n_cand = 0; }
+  float m = 0.f;
+  for (int t = threadIdx.x; t < nt; t += 256) m = fmaxf(m, tm[t]);
+  gmax[threadIdx.x] = m;
+  const long long ig = ignore[q];
   __syncthreads();
+  {
+    const int rounds = k + (ig >= 0 ? 1 : 0);
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < 256; ++j) {
+      const float o = gmax[j];
+      rank += (o > m || (o == m && j < (int)threadIdx.x)) ? 1 : 0;
+    }
+    if (rank == rounds - 1) { const float kth = m > 0.f ? m : 0.f; sh_tb = kth - 2.f * E; sh_sb = kth - E; }
+    if (threadIdx.x == 64) {
+      double qn = 0;
+      for (int d = 0; d < D; ++d) qn += knn_cq[d] * knn_cq[d];           // embutil.Norm (search.go:86-90)
+      knn_cq[D] = sqrt(qn);
+    }
+  }
+  __syncthreads();
+  const float tb = sh_tb;
+  const double qn = knn_cq[D];
+  const double bd = (double)sh_sb;
+  auto give_up = [&]() { if (threadIdx.x == 0) out_cnt[q] = -1; };
+  // kth - 2E <= 0 (fewer than `rounds` positive group maxima, or a k-th maximum inside the filter's error): the candidate set
+  // reaches down to every similarity > 0, and an item whose exact similarity lies in (0, E] can have a filter score <= 0 in a
+  // tile whose maximum is <= 0 -- the lists below (maximum > 0) would never visit it while the reference returns it (search.go:104:
+  // score > low, low = 0): the exact tile kernels take the query.  (A zero query has no neighbours at all -- searchutil.go:21-23 --
+  // and goes straight to the replay of nothing.)
+  const bool nothing = !(tb > 0.f);
+  if (nothing && qn != 0) { give_up(); return; }
+  if (!nothing) {
+    // ---- listed tiles, in tile order
+    int base = 0;
+    for (int t0 = 0; t0 < nt; t0 += 256) {
+      const int t = t0 + threadIdx.x;
+      const bool on = t < nt && tm[t] > 0.f && tm[t] >= tb;
+      const unsigned long long bal = __ballot(on);
+      if (lane == 0) wave_cnt[wave] = __popcll(bal);
+      __syncthreads();
+      int before = base;
+      for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+      const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+      if (on && pos < KNN2_MYT) my_tiles[pos] = t;
+      base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+      __syncthreads();
+    }
+    if (base > KNN2_MYT) { give_up(); return; }               // (uniform)
+    // ---- their sub-blocks whose own maximum reaches the bound
+    const int sb_items = sb_mode == 0 ? 32 : 16 * (tile_items / 256);
+    const int SB = tile_items / sb_items;
+    for (int i = threadIdx.x; i < base * SB; i += 256) {
+      const int tile = my_tiles[i / SB], b = i % SB;
+      const float bm = bmax[((size_t)tile * SB + b) * qpad + q];
+      if (bm > 0.f && bm >= tb) {
+        const int pos = atomicAdd(&n_blk, 1);
+        if (pos < KNN2_MYB) my_blocks[pos] = tile * SB + b;
+      }
+    }
+    __syncthreads();
+    const int nblk = n_blk;
+    if (nblk > KNN2_MYB) { give_up(); return; }
+    // ---- float32 filter over the listed sub-blocks' items, exact similarity of the survivors
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto item_of = [&](int wi) -> long long {
+      const int blk = my_blocks[wi / sb_items], e = wi % sb_items;
+      const int tile = blk / SB, b = blk - tile * SB;
+      const long long it = sb_mode == 0 ? (long long)tile * tile_items + 32 * b + e
+                                        : (long long)tile * tile_items + (e >> 4) * 256 + 16 * b + (e & 15);
+      return (it < V && it != ig) ? it : -1;
+    };
+    auto exact = [&](long long it) {
+      // the norm and the whole float64 row are requested together
+      const double* v = items + (size_t)it * D;
+      const double n2 = norms[it];
+      double dot = 0;
+      if (D == 16) {
+        d2 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const d2*>(v + 2 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { dot += knn_cq[2 * u] * x[u][0]; dot += knn_cq[2 * u + 1] * x[u][1]; }   // d ascending (searchutil.go:17-20)
+      } else {
+        for (int d = 0; d < D; d += 2) {
+          const d2 x = *reinterpret_cast<const d2*>(v + d);
+          dot += knn_cq[d] * x[0];
+          dot += knn_cq[d + 1] * x[1];
+        }
+      }
+      if (qn == 0 || n2 == 0) return;
+      const double sim = dot / qn / n2;                 // searchutil.go:24-25
+      if (!(sim > 0 && sim >= bd)) return;
+      const int pos = atomicAdd(&n_cand, 1);
+      if (pos < KNN2_CAP) { s_sim[pos] = sim; s_idx[pos] = it; }
+    };
+    const int nwork = nblk * sb_items;
+    if (D == 16) {
+      // four items per thread at a time, all 16 row loads in flight before the first FMA
+      for (int w0 = threadIdx.x; w0 < nwork; w0 += 4 * 256) {
+        f4 x[4][4]; long long its[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int wi = w0 + u * 256;
+          its[u] = wi < nwork ? item_of(wi) : -1;
+          const float* v32 = items32 + (size_t)(its[u] >= 0 ? its[u] : 0) * 16;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) x[u][c] = *reinterpret_cast<const f4*>(v32 + 4 * c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (its[u] < 0) continue;
+          f2 acc = f2{0.f, 0.f};                         // (knn_scan_kernel's arithmetic: one packed accumulator, d ascending)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            acc = __builtin_elementwise_fma(f2{cq32[4 * c], cq32[4 * c + 1]}, f2{x[u][c][0], x[u][c][1]}, acc);
+            acc = __builtin_elementwise_fma(f2{cq32[4 * c + 2], cq32[4 * c + 3]}, f2{x[u][c][2], x[u][c][3]}, acc);
+          }
+          if (acc[0] + acc[1] >= tb) exact(its[u]);
+        }
+      }
+    } else {
+      for (int wi = threadIdx.x; wi < nwork; wi += 256) {
+        const long long it = item_of(wi);
+        if (it < 0) continue;
+        const float* v32 = items32 + (size_t)it * D;
+        f2 acc = f2{0.f, 0.f};
+        for (int d = 0; d < D; d += 4) {
+          const f4 x = *reinterpret_cast<const f4*>(v32 + d);
+          acc = __builtin_elementwise_fma(f2{cq32[d], cq32[d + 1]}, f2{x[0], x[1]}, acc);
+          acc = __builtin_elementwise_fma(f2{cq32[d + 2], cq32[d + 3]}, f2{x[2], x[3]}, acc);
+        }
+        if (acc[0] + acc[1] >= tb) exact(it);
+      }
+    }
+  }
+  __syncthreads();
+  const int n = n_cand;
+  if (n > KNN2_CAP) { give_up(); return; }
+  // ---- replay: sort by item index (an item appears once): own entries to registers, ranks from LDS, write back in order
+  for (int r = threadIdx.x; r < k; r += 256) { nb_s[r] = 0.0; nb_i[r] = -1; }
   long long me[KNN2_CAP / 256]; double ms[KNN2_CAP / 256]; int rk[KNN2_CAP / 256];
 #pragma unroll
   for (int u = 0; u < KNN2_CAP / 256; ++u) {
     const int e = threadIdx.x + 256 * u;
     me[u] = 0; ms[u] = 0.0; rk[u] = -1;
     if (e < n) {
-      me[u] = u_idx[e]; ms[u] = u_sim[e];
+      me[u] = s_idx[e]; ms[u] = s_sim[e];
       int rank = 0;
-      for (int j = 0; j < n; ++j) rank += u_idx[j] < me[u];
+      for (int j = 0; j < n; ++j) rank += s_idx[j] < me[u];
       rk[u] = rank;
     }
   }
@@ -617,24 +791,14 @@ __device__ __forceinline__ void knn_replay_body(int q, const int* c_cnt, const l
   for (int u = 0; u < KNN2_CAP / 256; ++u)
     if (rk[u] >= 0) { s_idx[rk[u]] = me[u]; s_sim[rk[u]] = ms[u]; }
   __syncthreads();
-  // The insertion loop of search.go:104-121 over the sorted candidates, by ONE WAVEFRONT with the k-array in registers (lane i =
-  // neighbors[i]; the scan path has k < 64).  knn_insert by one thread walks the array in LDS -- k dependent LDS round trips per
-  // accepted candidate, ~13 us per query for a few dozen of them (round 4: knn_replay_kernel at 92 % waiting).  What one insertion
-  // does to a non-increasing array a[]: the item lands at p = the first position with score > a[p]; the element it displaces is
-  // carried down PAST the elements equal to it (the reference's strict `>` for displaced elements too) and lands behind its tie
-  // run, displacing the first element of the next run, and so on; the last carry is dropped.  So: position p takes the item,
-  // every later run START takes the FIRST element of the run before it, everything else stays (the tie rotation, quirk Q22).
   if (threadIdx.x < 64) {
-    const int lane = (int)threadIdx.x;
     double s = 0.0; long long id = -1; double low = 0.0;
     for (int r0 = 0; r0 < n; r0 += 64) {
-      const int m = n - r0 < 64 ? n - r0 : 64;
-      const double bs = lane < m ? s_sim[r0 + lane] : 0.0;
-      const long long bi = lane < m ? s_idx[r0 + lane] : -1;
-      for (int j = 0; j < m; ++j) {
-        // (j, p and k - 1 are wave-uniform: v_readlane instead of a ds_bpermute round trip -- an insertion was ~10 dependent
-        // bpermutes, ~1.3 k cycles, and a query has a few dozen)
-        const double ts = knn_readlane(bs, j);
+      const int mm = n - r0 < 64 ? n - r0 : 64;
+      const double bs = lane < mm ? s_sim[r0 + lane] : 0.0;
+      const long long bi = lane < mm ? s_idx[r0 + lane] : -1;
+      for (int j = 0; j < mm; ++j) {
+        const double ts = knn_readlane(bs, j);                     // (j, p, k - 1 are wave-uniform: v_readlane, no LDS round trip)
         if (!(ts > low)) continue;                                  // (uniform) search.go:104
         const long long ti = knn_readlane(bi, j);
         const unsigned long long gt = __ballot(lane < k && ts > s);
@@ -659,211 +823,6 @@ __device__ __forceinline__ void knn_replay_body(int q, const int* c_cnt, const l
   for (int r = 0; r < k; ++r) cnt += nb_i[r] >= 0;
   for (int r = threadIdx.x; r < k; r += 256) { out_idx[(size_t)q * k + r] = nb_i[r]; out_sim[(size_t)q * k + r] = nb_s[r]; }
   if (threadIdx.x == 0) out_cnt[q] = cnt < k ? k - 1 : k;     // search.go:126-131 (see knn_merge_kernel)
-}
-
-// knn_collect_kernel, KNN2_G workgroups per query.  Every workgroup first derives the query's bounds itself (a launch of its own
-// for them cost 14 us of mostly launch and memory latency): L = the k-th largest of 64 group maxima (tile mod 64; the (k + 1)-th
-// when an item is ignored: it may own one of them) -- the maxima belong to distinct items, so k items have a >= L; tile bound
-// L - 2 E, similarity bound L - E (header); both <= 0 when fewer groups have a positive maximum (then every positive item is a
-// candidate and the call most likely falls back).  One pass over the query's tile maxima and k rounds inside ONE wavefront.
-// Then the tiles whose maximum reaches the tile bound are numbered in tile order (the same numbering in every workgroup of the
-// query) and dealt round-robin; a workgroup's tiles pass the float32 filter once more (its own bits: a >= L - 2 E holds for
-// every member of C), the few survivors are scored EXACTLY (the reference's similarity) and join the query's candidates when they
-// reach the similarity bound.
-constexpr int KNN2_MY = 256;       // listed tiles one workgroup takes (more: the candidate count is poisoned -> fallback)
-__global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restrict__ items, const double* __restrict__ norms,
-                                                          const float* __restrict__ items32, long long V, int D,
-                                                          const double* __restrict__ queries, const float* __restrict__ q32,
-                                                          const long long* __restrict__ ignore, const float* __restrict__ tmax, int nt,
-                                                          int tile_items, int k, float E, int* c_cnt, long long* c_idx, double* c_sim,
-                                                          unsigned int* c_done, long long* out_idx, double* out_sim, int* out_cnt) {
-  // c_done != null: FOLDED launch -- the query's last workgroup to finish replays the candidates itself (knn_replay_body) instead of
-  // a third launch doing it (round 4: knn_replay_kernel 13.5 us at 92 % waiting, plus a launch boundary, for a few hundred
-  // candidates per query).  Every workgroup of the query, whatever path it took, ends at the ticket.
-  extern __shared__ __attribute__((aligned(16))) double knn_cq[];       // [D] the query, [1] its norm, then [D] floats: normalised; folded: + the replay's arrays
-  float* cq32 = reinterpret_cast<float*>(knn_cq + D + 1);
-  const int G = (int)gridDim.x;                                          // workgroups per query
-  __shared__ float gmax[4][64];
-  __shared__ float sh_tb, sh_sb;
-  __shared__ int wave_cnt[4];
-  __shared__ int my_tiles[KNN2_MY];
-  __shared__ int n_my;
-  const int g = blockIdx.x, q = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* tm = tmax + (size_t)q * nt;
-  for (int d = threadIdx.x; d < D; d += 256) { knn_cq[d] = queries[(size_t)q * D + d]; cq32[d] = q32[(size_t)q * D + d]; }
-  if (threadIdx.x == 0) n_my = 0;
-  float m = 0.f;
-  for (int t = threadIdx.x; t < nt; t += 256) m = fmaxf(m, tm[t]);      // (t mod 64 == lane)
-  gmax[wave][lane] = m;
-  __syncthreads();
-  {
-    // 256 groups of tiles (tile mod 256 = thread): the bound is the `rounds`-th largest of their maxima.  (Round 4 folded them into
-    // 64 groups and picked it with k rounds of a 64-lane arg-max: 6 dependent ds_bpermute steps per round, ~4 us; and the k-th
-    // largest of 64 group maxima sits near the 45th best item of a random catalogue, of 256 near the 13th -- every listed tile is
-    // 64 KB the collect pass reads again, per query.)  Every thread ranks its own group's maximum among the 256 -- broadcast LDS
-    // reads, no dependent chain; ties by group index, so exactly one thread holds rank rounds - 1.
-    const float* gflat = &gmax[0][0];
-    const float v = gflat[threadIdx.x];
-    const int rounds = k + (ignore[q] >= 0 ? 1 : 0);
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < 256; ++j) {
-      const float o = gflat[j];
-      rank += (o > v || (o == v && j < (int)threadIdx.x)) ? 1 : 0;
-    }
-    if (rank == rounds - 1) { const float kth = v > 0.f ? v : 0.f; sh_tb = kth - 2.f * E; sh_sb = kth - E; }
-    if (threadIdx.x == 64) {
-      double qn = 0;
-      for (int d = 0; d < D; ++d) qn += knn_cq[d] * knn_cq[d];           // embutil.Norm (search.go:86-90)
-      knn_cq[D] = sqrt(qn);
-    }
-  }
-  __syncthreads();
-  const float tb = sh_tb;
-  // kth - 2E <= 0 (fewer than `rounds` positive group maxima, or a k-th maximum inside the filter's error): the candidate set
-  // reaches down to every similarity > 0, and an item whose exact similarity lies in (0, E] can have a float32 score <= 0 in a
-  // tile whose maximum is <= 0 -- the list below (tm > 0) would never visit it while the reference returns it (search.go:104:
-  // score > low, low = 0).  Hand the query to the exact tile kernels instead (the replay kernel reports the overflow mark).
-  // (A zero query has no neighbours at all -- searchutil.go:21-23 -- and needs no second opinion.)
-  int my_n = 0;                                         // candidates this thread appended (the fan-in's ticket carries the sum)
-  bool skip = false;
-  if (!(tb > 0.f)) { if (g == 0 && threadIdx.x == 0 && knn_cq[D] != 0) { atomicAdd(&c_cnt[q], KNN2_CAP + 1); my_n += KNN2_CAP + 1; } skip = true; }
-  if (!skip) {
-  // the listed tiles in tile order: rank = (listed tiles before this one); tile of rank r belongs to workgroup r mod G
-  int base = 0;
-  for (int t0 = 0; t0 < nt; t0 += 256) {
-    const int t = t0 + threadIdx.x;
-    const bool on = t < nt && tm[t] > 0.f && tm[t] >= tb;
-    const unsigned long long bal = __ballot(on);
-    if (lane == 0) wave_cnt[wave] = __popcll(bal);
-    __syncthreads();
-    int before = base;
-    for (int w = 0; w < wave; ++w) before += wave_cnt[w];
-    const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));
-    if (on && rank % G == g) {
-      const int pos = atomicAdd(&n_my, 1);
-      if (pos < KNN2_MY) my_tiles[pos] = t;
-    }
-    base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    __syncthreads();
-  }
-  int nmy = n_my;
-  if (nmy > KNN2_MY) { if (threadIdx.x == 0) { atomicAdd(&c_cnt[q], KNN2_CAP + 1); my_n += KNN2_CAP + 1; } nmy = 0; }     // (the replay reports it)
-  const double qn = knn_cq[D];
-  const double bd = (double)sh_sb;
-  const long long ig = ignore[q];
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  // survivors of the float32 filter are scored exactly and join the query's candidates
-  auto exact = [&](long long it) {
-    // the norm and the whole float64 row are requested together (the early-out on a zero norm used to hold the row loads back a
-    // memory round trip)
-    const double* v = items + (size_t)it * D;
-    const double n2 = norms[it];
-    double dot = 0;
-    if (D == 16) {
-      d2 x[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const d2*>(v + 2 * u);
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { dot += knn_cq[2 * u] * x[u][0]; dot += knn_cq[2 * u + 1] * x[u][1]; }   // d ascending (searchutil.go:17-20)
-    } else {
-      for (int d = 0; d < D; d += 2) {
-        const d2 x = *reinterpret_cast<const d2*>(v + d);
-        dot += knn_cq[d] * x[0];
-        dot += knn_cq[d + 1] * x[1];
-      }
-    }
-    if (qn == 0 || n2 == 0) return;
-    const double sim = dot / qn / n2;                 // searchutil.go:24-25
-    if (!(sim > 0 && sim >= bd)) return;
-    const int pos = atomicAdd(&c_cnt[q], 1);
-    ++my_n;
-    if (pos < KNN2_CAP) {
-      // (device-scope stores: the query's last workgroup -- possibly on another XCD -- reads them in this launch when folded)
-      __hip_atomic_store(c_idx + (size_t)q * KNN2_CAP + pos, it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(c_sim + (size_t)q * KNN2_CAP + pos, sim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-  const int ipt = tile_items / 256;
-  if (D == 16) {
-    // four of the workgroup's (tile, row group) pairs at a time, all 16 row loads of a thread in flight before the first FMA:
-    // the loop was one memory round trip per row group (20 in a row for a typical query: knn_collect_kernel at 83 % waiting)
-    const int nwork = nmy * ipt;
-    for (int w0 = 0; w0 < nwork; w0 += 4) {
-      f4 x[4][4]; long long its[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int wi = w0 + u;
-        const bool on = wi < nwork;
-        const int tile = my_tiles[on ? wi / ipt : 0];
-        const long long it = (long long)tile * tile_items + (wi % ipt) * 256 + threadIdx.x;
-        its[u] = (on && it < V && it != ig) ? it : -1;
-        const float* v32 = items32 + (size_t)(its[u] >= 0 ? its[u] : 0) * 16;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) x[u][c] = *reinterpret_cast<const f4*>(v32 + 4 * c);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (its[u] < 0) continue;
-        // the filter, in knn_scan_kernel's arithmetic (one packed accumulator, the same order of packed FMAs)
-        f2 acc = f2{0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          acc = __builtin_elementwise_fma(f2{cq32[4 * c], cq32[4 * c + 1]}, f2{x[u][c][0], x[u][c][1]}, acc);
-          acc = __builtin_elementwise_fma(f2{cq32[4 * c + 2], cq32[4 * c + 3]}, f2{x[u][c][2], x[u][c][3]}, acc);
-        }
-        if (acc[0] + acc[1] >= tb) exact(its[u]);
-      }
-    }
-  } else
-  for (int w = 0; w < nmy; ++w) {
-    const int tile = my_tiles[w];
-    for (int j = 0; j < ipt; ++j) {
-      const long long it = (long long)tile * tile_items + j * 256 + threadIdx.x;
-      if (it >= V || it == ig) continue;
-      const float* v32 = items32 + (size_t)it * D;
-      f2 acc = f2{0.f, 0.f};
-      for (int d = 0; d < D; d += 4) {
-        const f4 x = *reinterpret_cast<const f4*>(v32 + d);
-        acc = __builtin_elementwise_fma(f2{cq32[d], cq32[d + 1]}, f2{x[0], x[1]}, acc);
-        acc = __builtin_elementwise_fma(f2{cq32[d + 2], cq32[d + 3]}, f2{x[2], x[3]}, acc);
-      }
-      if (acc[0] + acc[1] >= tb) exact(it);
-    }
-  }
-  }   // !skip
-  if (!c_done) return;
-  // ---- fan-in: the candidates went out as device-scope (write-through) stores and the barrier's s_waitcnt has seen them
-  // acknowledged -- no release FENCE (it would write back this XCD's whole L2, once per workgroup) -- take a ticket
-  // The ticket word carries the candidate count too: + (this workgroup's candidates << 8) + 1, so the last arriver knows the
-  // query's total from the value its own fetch-add returns instead of a further device-scope load (a memory round trip).
-  __shared__ unsigned int is_last, wg_n, total_n;
-  if (threadIdx.x == 0) wg_n = 0;
-  __syncthreads();
-  if (my_n) atomicAdd(&wg_n, (unsigned int)my_n);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    const unsigned int mine = (wg_n << 8) + 1u;
-    const unsigned int prev = __hip_atomic_fetch_add(&c_done[q], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (prev & 255u) == (unsigned int)G - 1u ? 1u : 0u;
-    total_n = (prev + mine) >> 8;
-    if (is_last) __hip_atomic_store(&c_done[q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
-  }
-  __syncthreads();
-  if (!is_last) return;
-  double* rs = knn_cq + D + 1 + (D + 1) / 2;                             // behind the query operands (16-byte aligned: D is a multiple of 4)
-  knn_replay_body<true>(q, c_cnt, c_idx, c_sim, k, out_idx, out_sim, out_cnt, rs, (int)total_n);
-}
-
-// out_cnt[q] = -1: more candidates than the replay takes (the host falls back to the tile kernels)
-__global__ __launch_bounds__(256) void knn_replay_kernel(const int* __restrict__ c_cnt, const long long* __restrict__ c_idx,
-                                                         const double* __restrict__ c_sim, int k, long long* out_idx, double* out_sim,
-                                                         int* out_cnt) {
-  extern __shared__ __attribute__((aligned(16))) double knn3_smem[];
-  knn_replay_body<false>((int)blockIdx.x, c_cnt, c_idx, c_sim, k, out_idx, out_sim, out_cnt, knn3_smem, -1);
 }
 
 }  // namespace
@@ -898,8 +857,6 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   const int D = s->D, tile_items = knn_scan_tile(D), nt = (int)cdiv(s->V, tile_items), nqb = (int)cdiv(Q, KNN2_QB);
   const size_t lds_r = sizeof(double) * (2 * (size_t)KNN2_CAP + 2 * (size_t)k);
   if (!s->lds_ok) {
-    GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_replay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(sizeof(double) * (2 * (size_t)KNN2_CAP + 2 * (size_t)KNN_MAX_K))));
     GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn_collect_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(sizeof(double) * (2 * (size_t)KNN2_CAP + 2 * (size_t)KNN_MAX_K + 1024 + 2))));
     s->lds_ok = true;
@@ -923,8 +880,8 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
     GOCTR_HIP(hipHostMalloc(&s->h_out, out_bytes * 2, hipHostMallocDefault));
     s->h_out_bytes = out_bytes * 2;
   }
-  if (s->in_pack.ensure(in_bytes, false) || s->tmax.ensure((size_t)Q * nt, false) ||
-      s->c_cnt.ensure((size_t)Q, false) || s->c_idx.ensure((size_t)Q * KNN2_CAP, false) || s->c_sim.ensure((size_t)Q * KNN2_CAP, false)) return -1;
+  const int qpad = nqb * KNN2_QB;
+  if (s->in_pack.ensure(in_bytes, false) || s->tmax.ensure((size_t)Q * nt, false) || s->bmax.ensure((size_t)nt * 32 * qpad, false)) return -1;
   memcpy(s->h_in, queries, in_q);
   long long* h_ig = reinterpret_cast<long long*>(static_cast<char*>(s->h_in) + in_q);
   for (int i = 0; i < Q; ++i) h_ig[i] = ignore ? (long long)ignore[i] : -1;
@@ -965,35 +922,28 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   double* d_os = reinterpret_cast<double*>(d_out + o_idx);
   int* d_oc = reinterpret_cast<int*>(d_out + o_idx + o_sim);
 #define GOCTR_KNN_SCAN(DD, IPT) hipLaunchKernelGGL((knn_scan_kernel<DD, IPT>), dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, \
-                                                  (long long)s->V, d_q32, Q, nt, s->tmax.p, s->c_cnt.p)
+                                                  (long long)s->V, d_q32, Q, nt, s->tmax.p, s->bmax.p, qpad)
   if (bf) {
     const unsigned short* d_qbf = reinterpret_cast<const unsigned short*>(s->in_pack.p + in_q + in_ig + in_q32);
     const long long qplane = (long long)nqb * KNN2_QB * D, iplane = (long long)(s->items_bf.n / 2);
-    if (D == 16) hipLaunchKernelGGL(knn_scan_bf16_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->c_cnt.p);
-    else hipLaunchKernelGGL(knn_scan_bf16_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->c_cnt.p);
+    if (D == 16) hipLaunchKernelGGL(knn_scan_bf16_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->bmax.p, qpad);
+    else hipLaunchKernelGGL(knn_scan_bf16_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->bmax.p, qpad);
   } else if (knn_scan_mfma(D, Q)) {
-    if (D == 16) hipLaunchKernelGGL(knn_scan_mfma_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, d_q32, Q, nt, s->tmax.p, s->c_cnt.p);
-    else hipLaunchKernelGGL(knn_scan_mfma_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, d_q32, Q, nt, s->tmax.p, s->c_cnt.p);
+    if (D == 16) hipLaunchKernelGGL(knn_scan_mfma_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, d_q32, Q, nt, s->tmax.p, s->bmax.p, qpad);
+    else hipLaunchKernelGGL(knn_scan_mfma_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, d_q32, Q, nt, s->tmax.p, s->bmax.p, qpad);
   } else if (D == 16) GOCTR_KNN_SCAN(16, 4);
   else if (D == 32) GOCTR_KNN_SCAN(32, 4);
   else GOCTR_KNN_SCAN(64, 2);
 #undef GOCTR_KNN_SCAN
   GOCTR_HIP(hipGetLastError());
-  // collect (+ replay by each query's last workgroup: GOCTR_KNN_FOLD=0 launches knn_replay_kernel instead)
-  const bool fold = !(getenv("GOCTR_KNN_FOLD") && getenv("GOCTR_KNN_FOLD")[0] == '0');
-  int G = KNN2_G;
-  if (const char* gv = getenv("GOCTR_KNN_G")) { const int x = atoi(gv); if (x >= 1 && x <= 64) G = x; }
+  // collect + exact refine + replay: one workgroup per query (sub-block layout: 32 consecutive items from the matrix-core scan
+  // kernels, the rows of 16 adjacent threads from the VALU one)
+  const int sb_mode = (bf || knn_scan_mfma(D, Q)) ? 0 : 1;
   const size_t lds_q = sizeof(double) * ((size_t)D + 1 + ((size_t)D + 1) / 2);      // [D] query | norm | [D] floats (rounded up to doubles)
-  if (fold && s->c_done.ensure((size_t)Q, true)) return -1;                          // (zeroed once; the last arriver resets its word)
-  hipLaunchKernelGGL(knn_collect_kernel, dim3(G, Q), dim3(256), lds_q + (fold ? lds_r : 0), e.stream,
-                     s->items.p, s->norms.p, s->items32.p, (long long)s->V, D, d_q, d_q32, d_ig, s->tmax.p, nt, tile_items, k, E, s->c_cnt.p,
-                     s->c_idx.p, s->c_sim.p, fold ? s->c_done.p : nullptr, d_oi, d_os, d_oc);
+  hipLaunchKernelGGL(knn_collect_kernel, dim3(Q), dim3(256), lds_q + lds_r, e.stream, s->items.p, s->norms.p, s->items32.p, (long long)s->V, D,
+                     d_q, d_q32, d_ig, s->tmax.p, s->bmax.p, qpad, nt, tile_items, sb_mode, k, E, d_oi, d_os, d_oc);
   GOCTR_HIP(hipGetLastError());
-  if (!fold) {
-    hipLaunchKernelGGL(knn_replay_kernel, dim3(Q), dim3(256), lds_r, e.stream, s->c_cnt.p, s->c_idx.p, s->c_sim.p, k, d_oi, d_os, d_oc);
-    GOCTR_HIP(hipGetLastError());
-  }
-  GOCTR_HIP(hipStreamSynchronize(e.stream));         // (the replay kernel wrote the pinned host buffer itself: no copy command)
+  GOCTR_HIP(hipStreamSynchronize(e.stream));         // (the collect kernel wrote the pinned host buffer itself: no copy command)
   const long long* h_oi = static_cast<const long long*>(s->h_out);
   const double* h_os = reinterpret_cast<const double*>(static_cast<const char*>(s->h_out) + o_idx);
   const int* h_oc = reinterpret_cast<const int*>(static_cast<const char*>(s->h_out) + o_idx + o_sim);

@@ -70,10 +70,8 @@ def test_scan_path_query_blocks(oracle, V, D, k, Q):
         ri, rs, _ = oracle.knn_search(items, queries[q], k, ignore=int(ignore[q]))
         assert cnt[q] == ri.size
         assert np.array_equal(idx[q, :cnt[q]], ri) and np.array_equal(sim[q, :cnt[q]], rs)
-    # tile kernels; either scan kernel; the replay as a launch of its own instead of the last collect workgroup's job; 1 / 32
-    # collect workgroups per query instead of 8
-    for var, val in (("GOCTR_KNN_SCAN", "0"), ("GOCTR_KNN_MFMA", "1"), ("GOCTR_KNN_MFMA", "0"), ("GOCTR_KNN_FOLD", "0"), ("GOCTR_KNN_G", "1"),
-                     ("GOCTR_KNN_G", "32"), ("GOCTR_KNN_BF16", "0")):
+    # the tile kernels; the VALU / matrix-core scan kernels forced; the float32 instead of the bf16-plane matrix-core filter
+    for var, val in (("GOCTR_KNN_SCAN", "0"), ("GOCTR_KNN_MFMA", "1"), ("GOCTR_KNN_MFMA", "0"), ("GOCTR_KNN_BF16", "0")):
         os.environ[var] = val
         try:
             idx0, sim0, cnt0 = s.search_vectors(queries, k, ignore)
