@@ -26,16 +26,19 @@
 //                      registers (each row is read once per call), a query's components arrive by scalar loads as SGPR operands of
 //                      v_pk_fma_f32; per (item, query) the approximate cosine a = sum q^_d v^_d, |a - sim| <= E = (D + 8) 2^-23
 //                      (rounding of the inputs + D fused multiply-adds, products bounded by Cauchy-Schwarz); the tile's maximum
-//   knn_collect_kernel per query (8 workgroups each) L = the k-th largest of 64 group maxima (tiles dealt round-robin; the
-//                      (k + 1)-th when an item is ignored): k distinct items have a >= L, so the k-th best similarity is >= L - E,
-//                      every member of the candidate set C has sim >= L - E and lies in a tile whose maximum is >= L - 2 E -- those
-//                      tiles, a few dozen per query, pass the filter again and the survivors are scored EXACTLY (float64, the
-//                      reference's d-order and its two divisions); items with sim >= L - E join the query's candidates
-//   knn_replay_kernel  per query: candidates sorted by item index, the reference's insertion replayed over them.  Items
-//                      outside C never stand above a member of C in the k-array, so replaying any superset of C in item order
-//                      leaves the same array as the full loop -- bit-exact results from an approximate filter.  More than 2048
-//                      candidates (fewer than k positive group maxima, or masses of equal similarities): the call falls back to
-//                      the tile kernels.
+//                      per query AND the maximum of every sub-block of the tile (32 consecutive items / the rows of 16 adjacent
+//                      threads).  From 48 queries per call on the filter runs on the matrix cores: round 4 float32 MFMA
+//                      (knn_scan_mfma_kernel, MFMA-bound), round 5 two bf16 planes and three products (knn_scan_bf16_kernel,
+//                      |a - sim| <= 2^-14, HBM-bound: every row once per call at ~5 TB/s)
+//   knn_collect_kernel ONE workgroup per query: L = the k-th largest of 256 group maxima (the (k + 1)-th when an item is ignored): k
+//                      distinct items have a >= L, so the k-th best similarity is >= L - E, every member of the candidate set C has
+//                      sim >= L - E and lies in a tile AND a sub-block whose maximum is >= L - 2 E -- those sub-blocks, about k + 3
+//                      per query, pass the float32 filter again and the survivors are scored EXACTLY (float64, the reference's
+//                      d-order and its two divisions); items with sim >= L - E are the candidates (LDS), which the same workgroup
+//                      sorts by item index and replays the reference's insertion over.  Items outside C never stand above a
+//                      member of C in the k-array, so replaying any superset of C in item order leaves the same array as the
+//                      full loop -- bit-exact results from an approximate filter.  More than 2048 candidates or a bound <= 0
+//                      (fewer than k positive group maxima, masses of equal similarities): the call falls back to the tile kernels.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
