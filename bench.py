@@ -516,14 +516,14 @@ def bench_knn(args):
     qps = steps * Q / dt
     # ---- roofline of the IMPLEMENTED call (rounds 1-4 priced the reference's loop -- every query scans
     # V x D x 8 bytes -- which the filter + refine path does not perform: the fraction read 12).  Per call of Q queries:
-    #   scan     every normalised float32 row ONCE: V x D x 4 B (+ Q x tiles maxima written)
-    #   collect  per query the tiles whose maximum reaches the bound, again as float32 rows: listed_tiles x 1024 x D x 4 B
-    #            (measured from the device's own tile maxima would need a read-back; the bound's construction gives the
-    #            expectation: the k-th largest of 256 group maxima sits near the (k + 3)-th best item, so ~k + 3 tiles), then the
-    #            float64 rows of the few survivors
-    #   replay   ~k + 3 candidates per query: bytes negligible
-    tiles_per_query = k + 3
-    call_b = V * D * 4 + Q * (V // 1024 + 1) * 4 + Q * tiles_per_query * 1024 * D * 4
+    #   scan     every normalised row ONCE, as two bf16 planes: V x D x 4 B; written: the maxima of every 32-item sub-block and of
+    #            every 1024-item tile, per query: (V / 32 + V / 1024) x Q x 4 B
+    #   collect  per query (one workgroup): the tile maxima, the sub-block maxima of the listed tiles, the float32 rows of the
+    #            listed SUB-BLOCKS (the k-th largest of 256 group maxima sits near the (k + 3)-th best item: ~k + 3 sub-blocks of
+    #            32 rows), the float64 rows of the few survivors; candidates and the replay stay in LDS
+    listed = k + 3
+    scan_b = V * D * 4 + (V // 32 + V // 1024 + 2) * Q * 4
+    call_b = scan_b + Q * ((V // 1024 + 1) * 4 + listed * 32 * 4 + listed * 32 * D * 4 + listed * (D * 8 + 8))
     call_us = dt / steps * 1e6
     out = {"metric": "k-NN search queries/sec (cosine top-10 over 10^6 x 16 float64 items)", "value": round(qps, 1),
            "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
@@ -532,7 +532,7 @@ def bench_knn(args):
            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "kernel": "knn_scan_bf16_kernel (the filter: every normalised row once per 64-query call, as two bf16 planes)"}}
     rl = with_traffic(out["roofline"], "knn", "train", "knn_scan_*", None, None)      # (knn_scan_mfma_kernel<D> from 48 queries per call on)
-    rl["algorithmic_bytes"] = int(V * D * 4 + Q * (V // 1024 + 1) * 4)                 # the dominant kernel's own bytes
+    rl["algorithmic_bytes"] = int(scan_b)                                              # the dominant kernel's own bytes
     if rl.get("avg_us_rocprofv3"):
         rl["achieved"] = round(rl["algorithmic_bytes"] / (rl["avg_us_rocprofv3"] * 1e-6) / 1e9, 1)
         rl["frac"] = round(rl["achieved"] / HBM_PEAK_GBS, 4)
