@@ -550,9 +550,11 @@ def bench_knn(args):
         pyoracle.set_threads(cores)
         pyoracle.knn_search_batch(items, queries[:cores], k, norms)                  # (warm-up: pages, threads)
         t0 = time.perf_counter()
-        nq = Q * max(1, min(8, cores // 4))                                          # >= 64 queries, ~10-20 s on the quota cores
-        qs = np.concatenate([queries] * (nq // Q))
-        pyoracle.knn_search_batch(items, qs, k, norms)
+        nq = 0
+        qs = np.concatenate([queries] * 16)                                          # 1024 queries per batch, until ~12 s have passed
+        while time.perf_counter() - t0 < 12.0:
+            pyoracle.knn_search_batch(items, qs, k, norms)
+            nq += qs.shape[0]
         dtc = time.perf_counter() - t0
         pyoracle.set_threads(1)
         out["cpu_baseline"] = {"value": round(nq / dtc, 2), "unit": "queries/s", "cores": cores, "kind": "port",
