@@ -1045,9 +1045,9 @@ __global__ __launch_bounds__(256, 2) void mlp_tn64_reduce_kernel(const double* _
 }
 
 template <class K>
-int allow_big_lds(K kernel) {
+int allow_big_lds(K kernel, int kb = 160) {      // (a kernel with static LDS arrays of its own asks for less: static + dynamic <= 160 KB)
   GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(160 * 1024)));
+                                (int)(kb * 1024)));
   return 0;
 }
 
@@ -1112,7 +1112,7 @@ int init_attrs64() {
   if (allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 1>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 2>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 4>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 1>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 2>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 4>) ||
-      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_tn64_kernel<3>) || allow_big_lds(mlp_tn64_kernel<2>) || allow_big_lds(mlp_tn64_reduce_kernel<3>) || allow_big_lds(mlp_tn64_reduce_kernel<2>) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
+      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_tn64_kernel<3>) || allow_big_lds(mlp_tn64_kernel<2>) || allow_big_lds(mlp_tn64_reduce_kernel<3>, 152) || allow_big_lds(mlp_tn64_reduce_kernel<2>, 152) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
   done = true;
   return 0;
 }
