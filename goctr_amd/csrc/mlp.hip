@@ -199,15 +199,11 @@ struct MlpReduceArgs {
 
 // grad = slab sum / n + alpha/n * W (coefs), mean(delta) (intercepts)  [computeLossGrad :322-330]; then the
 // optimizer step in packed-parameter order semantics.
-// DEV: the slabs were written by OTHER workgroups of this same launch (mlp_tn64_reduce_kernel), through other XCDs' L2s: read them with
-// device-scope loads.  bx = the block of the stand-alone launch this workgroup plays.
-template <bool DEV>
-__device__ __forceinline__ void mlp_reduce_update_body(const MlpReduceArgs& a, const int bx) {
-  auto ld_slab = [](const double* p) -> double { return DEV ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; };
-  const long long idx = (long long)bx * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   __shared__ double red[256];
   const int par = (int)(a.st->t & 1);
-  if (bx == a.nblk) {
+  if ((int)blockIdx.x == a.nblk) {
     // loss = sum(terms)/n + 0.5*alpha*sum(W^2)/n (basemlp64.go:359-361) over the weights the forward pass used: their
     // squares were summed per block by the launch that wrote them (parity `par`); closes the step
     double s = 0;
@@ -271,7 +267,7 @@ __device__ __forceinline__ void mlp_reduce_update_body(const MlpReduceArgs& a, c
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
               const int j = j0 + u * d.upo;
-              const double x = ld_slab(sp + (size_t)(j < d.nslabs ? j : d.nslabs - 1) * sstr);   // unconditional load, clamped address
+              const double x = sp[(size_t)(j < d.nslabs ? j : d.nslabs - 1) * sstr];   // unconditional load, clamped address
               v[u] = j < d.nslabs ? x : 0.0;
             }
 #pragma unroll
@@ -318,7 +314,7 @@ __device__ __forceinline__ void mlp_reduce_update_body(const MlpReduceArgs& a, c
 #pragma unroll
           for (int u = 0; u < 48; ++u) {
             const int j = j0 + u;
-            v[u] = ld_slab(d.slabs + (size_t)(j < d.nslabs ? j : d.nslabs - 1) * sstr + e);
+            v[u] = d.slabs[(size_t)(j < d.nslabs ? j : d.nslabs - 1) * sstr + e];
           }
 #pragma unroll
           for (int u = 0; u < 48; ++u) s += (j0 + u < d.nslabs) ? v[u] : 0.0;
@@ -366,12 +362,10 @@ __device__ __forceinline__ void mlp_reduce_update_body(const MlpReduceArgs& a, c
   // mode 2 refreshes this step's parity; an update writes the parity the NEXT step will read; a pure gradient
   // evaluation leaves the weights -- and therefore both buffers -- alone
   if (threadIdx.x == 0) {
-    if (a.mode == 2) a.sumsq_part[(size_t)par * a.nblk + bx] = red[0];
-    else if (a.do_update) a.sumsq_part[(size_t)(par ^ 1) * a.nblk + bx] = red[0];
+    if (a.mode == 2) a.sumsq_part[(size_t)par * a.nblk + blockIdx.x] = red[0];
+    else if (a.do_update) a.sumsq_part[(size_t)(par ^ 1) * a.nblk + blockIdx.x] = red[0];
   }
 }
-
-__global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a) { mlp_reduce_update_body<false>(a, (int)blockIdx.x); }
 
 __global__ void mlp_scale_kernel(double* W, long long n, double f) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -870,11 +864,10 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainArgs a) {
 // consecutive rows a lane feeds to 4 MFMAs.
 constexpr int TN64_CH = 32, TN64_CHS = TN64_CH + 2, TN64_NTW = 2;
 
-// DEV: the slab tiles leave as device-scope (write-through) stores: another workgroup of the SAME launch sums them (mlp_tn64_reduce_kernel)
-template <int TN64_KTW, bool DEV>
-__device__ __forceinline__ void mlp_tn64_body(const double* __restrict__ A, int lda, int KT,
-                                              const double* __restrict__ Dm, int ldd, int NT, int M, int rows,
-                                              double* __restrict__ slabs, size_t slab_stride) {
+template <int TN64_KTW>
+__global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restrict__ A, int lda, int KT,
+                                                          const double* __restrict__ Dm, int ldd, int NT, int M, int rows,
+                                                          double* __restrict__ slabs, size_t slab_stride) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int CH = TN64_CH, CHS = TN64_CHS, KTW = TN64_KTW, NTW = TN64_NTW;
@@ -1000,54 +993,14 @@ __device__ __forceinline__ void mlp_tn64_body(const double* __restrict__ A, int 
       if (e < kb_t && f < ncnt) {
         const int n = (nt0 + f) * 16 + i;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double* op = out + (size_t)((kb0 + e) * 16 + q + 4 * r) * ld_out + n;
-          if (DEV) __hip_atomic_store(op, acc[e][f][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else *op = acc[e][f][r];
-        }
+        for (int r = 0; r < 4; ++r) out[(size_t)((kb0 + e) * 16 + q + 4 * r) * ld_out + n] = acc[e][f][r];
       }
 }
 
-template <int TN64_KTW>
-__global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restrict__ A, int lda, int KT,
-                                                          const double* __restrict__ Dm, int ldd, int NT, int M, int rows,
-                                                          double* __restrict__ slabs, size_t slab_stride) {
-  mlp_tn64_body<TN64_KTW, false>(A, lda, KT, Dm, ldd, NT, M, rows, slabs, slab_stride);
-}
-
-// ---- the weight-gradient launch and the reduce + update launch as ONE (round 5).  Round 4 built this behind a
-// grid barrier with __threadfence() on both sides -- every workgroup writing back and invalidating its XCD's L2 -- and measured
-// 119 against 41.5 us per step.  The fences are not needed: the slab tiles leave as device-scope (sc1, write-through) stores, every
-// thread waits for its own to be acknowledged (s_waitcnt vmcnt(0): on gfx9 stores count there) before the workgroup takes its
-// ticket, and the readers use device-scope loads, which do not look at their own XCD's L2.  All workgroups are resident (the host
-// launches this kernel only when grid <= CUs), so spinning on the ticket counter is safe; the counter only ever grows (target =
-// the next multiple of the grid size above the value the fetch-add returned), so it needs no reset between launches.
-template <int TN64_KTW>
-__global__ __launch_bounds__(256, 2) void mlp_tn64_reduce_kernel(const double* __restrict__ A, int lda, int KT,
-                                                                 const double* __restrict__ Dm, int ldd, int NT, int M, int rows,
-                                                                 double* __restrict__ slabs, size_t slab_stride, MlpReduceArgs ra,
-                                                                 unsigned long long* bar) {
-  mlp_tn64_body<TN64_KTW, true>(A, lda, KT, Dm, ldd, NT, M, rows, slabs, slab_stride);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's slab stores are acknowledged at device scope
-  __syncthreads();
-  const unsigned long long nwg = (unsigned long long)gridDim.x * gridDim.y;
-  if (threadIdx.x == 0) {
-    const unsigned long long prev = __hip_atomic_fetch_add(bar, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long target = (prev / nwg + 1ULL) * nwg;
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
-  }
-  __syncthreads();
-  const int wg = (int)(blockIdx.y * gridDim.x + blockIdx.x);
-  for (int bx = wg; bx <= ra.nblk; bx += (int)nwg) {
-    mlp_reduce_update_body<true>(ra, bx);
-    __syncthreads();                                          // (the body's shared arrays are reused by the next block)
-  }
-}
-
 template <class K>
-int allow_big_lds(K kernel, int kb = 160) {      // (a kernel with static LDS arrays of its own asks for less: static + dynamic <= 160 KB)
+int allow_big_lds(K kernel) {
   GOCTR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(kb * 1024)));
+                                (int)(160 * 1024)));
   return 0;
 }
 
@@ -1112,7 +1065,7 @@ int init_attrs64() {
   if (allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 1>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 2>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 4>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 1>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 2>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 4>) ||
-      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_tn64_kernel<3>) || allow_big_lds(mlp_tn64_kernel<2>) || allow_big_lds(mlp_tn64_reduce_kernel<3>, 152) || allow_big_lds(mlp_tn64_reduce_kernel<2>, 152) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
+      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_tn64_kernel<3>) || allow_big_lds(mlp_tn64_kernel<2>) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
   done = true;
   return 0;
 }
@@ -1137,7 +1090,6 @@ struct goctr_mlp {
   int wsN = 0, S = 0;
   DevBuf<double> A[8], D[8], Yb, lossterm, slabs[7], sumsq_part, ring;
   DevBuf<MlpState> st, st_step;   // master copy / the running step's frozen copy
-  DevBuf<unsigned long long> grid_bar;   // mlp_tn64_reduce_kernel's ticket counter (monotonic)
   // resident rows
   DevBuf<float> Xr, Yr; int64_t rows = 0; DevBuf<int> perm;
   hipGraphExec_t step_graph = nullptr; int64_t step_graph_rows = 0; bool step_graph_perm = false;   // resident training step
@@ -1265,18 +1217,7 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance, int valid = -1) 
                        p->slabs[1].p, p->zpart.p, (int)cdiv(p->up[1], 32), p->Yb.p, p->A[2].p, p->D[2].p, p->lossterm.p);
     GOCTR_HIP(hipGetLastError());
   }
-  // the chain path's one weight-gradient launch (layer 0) and the reduce + update launch as ONE (mlp_tn64_reduce_kernel): single
-  // device, an updating step, the slab kernel's shapes, and every workgroup resident at once (it spins on a grid-wide ticket)
-  bool merge = false;
-  {
-    const int KT0 = p->up[0] / 16, NT0 = p->up[1] / 16, ktw = tn64_ktw();
-    const long long wgs = cdiv(n, tn_rows64(p, n)) * cdiv(KT0, ktw);
-    merge = chain && valid == n && do_update && !e.comm_active() && NT0 <= 8 && env_int_mlp("GOCTR_MLP_OLD_TN", 0) == 0 &&
-            wgs <= (e.compute_units > 0 ? e.compute_units : 0) && env_int_mlp("GOCTR_MLP_MERGE", 1) != 0;
-    if (merge && !p->grid_bar.p && p->grid_bar.alloc(1)) return -1;
-  }
   for (int l = fused_bwd ? 0 : L - 1; l >= 0; --l) {
-    if (merge && l == 0) break;                    // (launched below, with the reduce)
     if (launch_tn64(p->A[l].p, p->up[l], p->up[l] / 16, p->D[l + 1].p, p->up[l + 1], p->up[l + 1] / 16, n, tn_rows64(p, n),
                     p->slabs[l].p)) return -1;
     if (l >= 1) {
@@ -1321,19 +1262,6 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance, int valid = -1) 
     return 0;
   }
   a.mode = 0;
-  if (merge) {
-    const int KT0 = p->up[0] / 16, NT0 = p->up[1] / 16, ktw = tn64_ktw(), rows = tn_rows64(p, n);
-    const dim3 grid((unsigned)cdiv(n, rows), (unsigned)cdiv(KT0, ktw));
-    const size_t lds = sizeof(double) * 2 * TN64_CHS * (size_t)(ktw * 16 + NT0 * 16);
-    if (ktw == 2)
-      hipLaunchKernelGGL(mlp_tn64_reduce_kernel<2>, grid, dim3(256), lds, e.stream, p->A[0].p, p->up[0], KT0, p->D[1].p, p->up[1], NT0, n, rows,
-                         p->slabs[0].p, (size_t)KT0 * 16 * NT0 * 16, a, p->grid_bar.p);
-    else
-      hipLaunchKernelGGL(mlp_tn64_reduce_kernel<3>, grid, dim3(256), lds, e.stream, p->A[0].p, p->up[0], KT0, p->D[1].p, p->up[1], NT0, n, rows,
-                         p->slabs[0].p, (size_t)KT0 * 16 * NT0 * 16, a, p->grid_bar.p);
-    GOCTR_HIP(hipGetLastError());
-    return 0;
-  }
   hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk + 1), dim3(256), 0, e.stream, a);   // block nblk: loss + state
   GOCTR_HIP(hipGetLastError());
   return 0;

@@ -257,29 +257,3 @@ def test_flagship_run_79948_rows_at_batch_200(oracle):
     assert close(clf.get_params(), theta, rtol=1e-7, atol=1e-10)
     assert ref[-1] < ref[0]
 
-
-def test_merged_gradient_update_launch_equals_separate_launches():
-    """mlp_tn64_reduce_kernel (round 5): the layer-0 weight-gradient launch and the reduce + update launch as ONE, the slab tiles
-    handed over inside the launch (device-scope stores, a grid-wide ticket, device-scope loads).  Same slab sums in the same order:
-    the parameters after 27 steps (graphs of 8 / 2 / 1) must equal the separate launches' bit for bit, adam and sgd, at cfg2's
-    shape (252 workgroups: one per CU) and a small one."""
-    import os
-    from goctr_amd import mlp as gmlp
-    for F, H, B, solver in ((281, 100, 4096, "adam"), (281, 100, 512, "sgd"), (37, 12, 96, "adam")):
-        rng = np.random.default_rng(31)
-        X, Y = make(rng, 6 * B, F)
-        res = []
-        for merge in ("0", "1"):
-            os.environ["GOCTR_MLP_MERGE"] = merge
-            try:
-                clf = gmlp.MLPClassifier([H], "relu", solver, 1e-5)
-                units = [F, H, 1]
-                clf.create(units, B, clf.init_params(units, np.random.default_rng(32)))
-                clf.upload(X, Y)
-                clf.train_steps(27)
-                res.append(clf.get_params())
-                l, _ = clf.loss_grad(X[:B], Y[:B])
-                assert np.isfinite(l)
-            finally:
-                os.environ.pop("GOCTR_MLP_MERGE", None)
-        assert np.array_equal(res[0], res[1]), (F, H, B, solver, np.max(np.abs(res[0] - res[1])))
