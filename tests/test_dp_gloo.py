@@ -138,6 +138,67 @@ def test_item2vec_delta_exchange_world2(tmp_path):
     assert moved > 1e-4                     # and the replicas really moved
 
 
+def _w2v_avg_worker(rank, world, port, out):
+    """the HOGWILD passes' exchange (round 5; csrc/w2v.hip exchange_deltas(avg = true)): a pass is cut into segments, after each
+    the ranks all-reduce their parameter deltas since the common snapshot AND a per-row 'this rank changed the row' flag, and
+    every row becomes snapshot + sum of deltas / number of ranks that changed it"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pyoracle
+    rng = np.random.default_rng(8)
+    V, n, dim, nseg = 60, 4000, 8, 3
+    doc = np.concatenate([rng.integers(0, 30, size=n // 2), rng.integers(20, V, size=n // 2)]).astype(np.int32)   # rank 0 never sees words >= 30
+    counts = np.bincount(doc, minlength=V) + 1
+    p0 = (rng.random((V, dim)) - 0.5) / dim
+    cfg = pyoracle.w2v_cfg(dim=dim, optimizer="hs")
+    paths = pyoracle.huffman_paths(counts)
+    sig = pyoracle.sigmoid_table()
+
+    def run(ranks, reduce):
+        P, A = p0.copy(), np.zeros((V - 1, dim))
+        lcg = {r: pyoracle.Lcg(1 + r) for r in ranks}
+        lr = {r: 0.025 for r in ranks}
+        for s_ in range(nseg):
+            ds = {}
+            for r in ranks:
+                lo, hi = r * n // world, (r + 1) * n // world
+                a0, a1 = lo + (hi - lo) * s_ // nseg, lo + (hi - lo) * (s_ + 1) // nseg
+                p, a = P.copy(), A.copy()
+                lr[r], _ = pyoracle.w2v_train_slice(cfg, doc[a0:a1], 0, a1 - a0, None, p, a, paths, sig, lcg[r], lr[r], world * (a0 - lo), n)
+                ds[r] = (p - P, a - A)
+            for M, k in ((P, 0), (A, 1)):
+                d = sum(ds[r][k] for r in ranks)
+                cnt = sum((np.abs(ds[r][k]).max(1) > 0).astype(np.float64) for r in ranks)
+                d, cnt = reduce(d, cnt)
+                M += d / np.maximum(cnt, 1.0)[:, None]
+        return P, A
+
+    def allreduce(d, cnt):
+        td, tc = torch.from_numpy(d.copy()), torch.from_numpy(cnt.copy())
+        dist.all_reduce(td); dist.all_reduce(tc)
+        return td.numpy(), tc.numpy()
+
+    P, A = run([rank], allreduce)                       # this rank's shard, the other rank's through the collectives
+    if rank == 0:
+        eP, eA = run(list(range(world)), lambda d, c: (d, c))      # both shards in one process
+        # a row only ONE rank trained keeps its whole update: words >= 30 occur in rank 1's half only
+        solo = np.max(np.abs(P[40:] - p0[40:]))
+        np.save(out, np.array([np.max(np.abs(P - eP)), np.max(np.abs(A - eA)), solo]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_item2vec_hogwild_exchange_rule_world2(tmp_path):
+    out = str(tmp_path / "w2v_avg.npy")
+    mp.spawn(_w2v_avg_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    ep, ea, solo = np.load(out)
+    assert ep <= 1e-15 and ea <= 1e-15      # segments + all-reduce of (delta, touched) == the rule evaluated in one process
+    assert solo > 1e-4                      # rows of one rank's shard moved by their full delta
+
+
 # ---------------------------------------------------------------- sklearn-port MLP: sharded rows == full batch
 def _mlp_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
