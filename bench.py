@@ -704,13 +704,15 @@ def main():
         m.set_embedding_training(args.train_emb)
 
     # ---- recommend QPS: rows scored per second through the predict path (PredBatch 4096).  Measured FIRST, on every rank,
-    # over at least 2000 batches (~35 ms): an MI355X that has idled for >= 10 ms (the set-up above) runs its next
+    # over at least 8000 batches (~140 ms): an MI355X that has idled for >= 10 ms (the set-up above) runs its next
     # milliseconds ~6 % slower (scripts/launch_latency.py: 20 training steps take 60.5 instead of 57.0 us each, and 5
     # warm-up steps do not change that), so the short timed regions below start on a GPU that is already under load --
-    # the state a training run is in for all but its first milliseconds.
+    # the state a training run is in for all but its first milliseconds.  Round 5 (the nine regions make it visible): behind
+    # 2000 batches (~35 ms) the regions of a --steps 20 run still fell from 1.02 to 0.97 ms, behind 8000 they are flat at
+    # 0.94-0.95 ms (and 30 000 change nothing more): the clocks need ~100 ms of load (GOCTR_BENCH_PRED_BATCHES).
     if args.phase != "predict":
         gm.train_steps(m, ds, cfg, 0, emb=tab)      # zero steps: allocates the workspace and captures the step graphs (host work)
-    pred_batches = max(args.steps, 2000) if args.phase == "all" else args.steps * 4
+    pred_batches = max(args.steps, int(os.environ.get("GOCTR_BENCH_PRED_BATCHES", "8000"))) if args.phase == "all" else args.steps * 4
     qps = None
     if args.phase != "train":
         gm.predict_steps(m, ds, c["PRED_B"], min(args.warmup, 20), emb=tab)
