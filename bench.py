@@ -340,18 +340,22 @@ def bench_mlp(args):
     clf.upload(X, y)
     # at least 1200 warm-up steps (~50 ms): the GPU idled while the rows above were generated and runs ~6 % slower for its
     # next milliseconds; the line reports the warm-up it actually did
-    warm = max(args.warmup, 1200)
+    warm = max(args.warmup, 4000)                         # (~160 ms: the clocks need ~100 ms of load, see main())
     clf.train_steps(warm)
     capi.sync()
-    t0 = time.perf_counter()
-    clf.train_steps(args.steps, first_batch=warm)
-    capi.sync()
-    dt = time.perf_counter() - t0
+    regions = []                                           # the median of --regions back-to-back regions of exactly --steps steps
+    for r in range(max(args.regions, 1)):
+        capi.sync()
+        t0 = time.perf_counter()
+        clf.train_steps(args.steps, first_batch=warm + r * args.steps)
+        capi.sync()
+        regions.append(time.perf_counter() - t0)
+    dt = sorted(regions)[(len(regions) - 1) // 2]
     flops = 3 * 2.0 * B * (F * H + H)                      # fwd + dX-free bwd (dW + dA): SURVEY 8(d) 113 000 / sample
     out = {"metric": "training samples/sec (sklearn-port MLP [281,100,1], float64)", "value": round(args.steps * B / dt, 1),
            "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": warm,
            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f64", "data": "synthetic",
+           "dtype": "f64", "data": "synthetic", "timed_regions": len(regions), "timed_regions_ms": [round(x * 1e3, 4) for x in regions],
            "config": {"workload": "BASELINE configs[1]: MLP [281,100,1] relu/adam alpha=1e-5, batch 4096, 2^20 rows resident in HBM",
                       "global_batch": B, "parallelism": "dp1"},
            "roofline": {"bound": "mfma", "achieved": round(flops / (dt / args.steps) / 1e12, 3), "peak": FP64_MFMA_PEAK_TF,
