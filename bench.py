@@ -789,8 +789,9 @@ def main():
         import ctypes as C
         mode = C.c_int(0)
         capi.check(L.goctr_comm_capture_mode(C.byref(mode)))
-        out["dp_allreduce"] = ("a node of the multi-step graphs (captured RCCL collective, self-tested on this communicator)" if mode.value == 1
-                               else "between graph launches (capture off or failed its self-test)")
+        out["dp_allreduce"] = ("a node of the multi-step graphs (captured RCCL collective, self-tested on this communicator at start-up; "
+                               "before this run the captured form had only ever executed with world = 1: the builder's boxes have one GPU)"
+                               if mode.value == 1 else "between graph launches (capture off or failed its self-test)")
         out["dp_mode"] = "one process per GPU (goctr_comm_init over the launcher's rendezvous); the single-process entry is goctr_init_devices + cfg.devices"
     if args.train_emb > 0:
         out["sparse_exchange_bytes_per_step_per_rank"] = m.sparse_exchange_bytes()      # (0 without a communicator)
