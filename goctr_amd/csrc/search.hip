@@ -73,6 +73,7 @@ namespace {
 constexpr int KNN_TILE = 2048;     // items per workgroup
 constexpr int KNN_PER = KNN_TILE / 256;
 constexpr int KNN_MAX_K = 256;
+constexpr int KNN_PENDING = INT32_MIN;   // a query's count in the pinned output while its workgroup has not finished
 
 __global__ void knn_norm_kernel(const double* items, long long V, int D, double* norms, float* items32, unsigned short* items_bf,
                                 long long plane_elems) {
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
                                                           const double* __restrict__ queries, const float* __restrict__ q32,
                                                           const long long* __restrict__ ignore, const float* __restrict__ tmax,
                                                           const float* __restrict__ bmax, int qpad, int nt, int tile_items, int sb_mode,
-                                                          int k, float E, long long* out_idx, double* out_sim, int* out_cnt) {
+                                                          int k, float E, long long* out_idx, double* out_sim, int* out_cnt, int host_polls) {
   extern __shared__ __attribute__((aligned(16))) double knn_cq[];       // [D] the query | its norm | [D] floats: normalised | the replay's arrays
   float* cq32 = reinterpret_cast<float*>(knn_cq + D + 1);
   double* s_sim = knn_cq + D + 1 + (D + 1) / 2;                          // [CAP] candidates' similarities
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   const float tb = sh_tb;
   const double qn = knn_cq[D];
   const double bd = (double)sh_sb;
-  auto give_up = [&]() { if (threadIdx.x == 0) out_cnt[q] = -1; };
+  auto give_up = [&]() { if (threadIdx.x == 0) __hip_atomic_store(out_cnt + q, -1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); };
   // kth - 2E <= 0 (fewer than `rounds` positive group maxima, or a k-th maximum inside the filter's error): the candidate set
   // reaches down to every similarity > 0, and an item whose exact similarity lies in (0, E] can have a filter score <= 0 in a
   // tile whose maximum is <= 0 -- the lists below (maximum > 0) would never visit it while the reference returns it (search.go:104:
@@ -825,7 +826,15 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   int cnt = 0;
   for (int r = 0; r < k; ++r) cnt += nb_i[r] >= 0;
   for (int r = threadIdx.x; r < k; r += 256) { out_idx[(size_t)q * k + r] = nb_i[r]; out_sim[(size_t)q * k + r] = nb_s[r]; }
-  if (threadIdx.x == 0) out_cnt[q] = cnt < k ? k - 1 : k;     // search.go:126-131 (see knn_merge_kernel)
+  const int n_out = cnt < k ? k - 1 : k;                      // search.go:126-131 (see knn_merge_kernel)
+  if (host_polls) {
+    // the host watches out_cnt[q] in the pinned buffer (knn_search_scan): the neighbours must be there before the count is.
+    // (The system-scope fence writes back whatever the L2 holds dirty -- the filter's maxima: cheap for a few queries, 5 us of a
+    // 64-query call, which therefore waits on the stream instead.)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(out_cnt + q, n_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else if (threadIdx.x == 0) out_cnt[q] = n_out;
 }
 
 }  // namespace
@@ -913,6 +922,12 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
       h_qbf[i] = hi; h_qbf[plane + i] = f2bf(x - bf2f(hi));
     }
   }
+  const char* pv = getenv("GOCTR_KNN_POLL_MAXQ");
+  const bool poll = Q <= (pv ? atoi(pv) : 32);       // profiles/r05_knn_poll.txt: -4.5 us up to 8 queries, -1.5 at 32, +9 at 64
+  if (poll) {                                        // (the previous call returned after its kernels' last stores: nothing else writes here)
+    int* h_pend = reinterpret_cast<int*>(static_cast<char*>(s->h_out) + o_idx + o_sim);
+    for (int i = 0; i < Q; ++i) __atomic_store_n(h_pend + i, KNN_PENDING, __ATOMIC_RELEASE);
+  }
   GOCTR_HIP(hipMemcpyAsync(s->in_pack.p, s->h_in, in_bytes, hipMemcpyHostToDevice, e.stream));
   const double* d_q = reinterpret_cast<const double*>(s->in_pack.p);
   const long long* d_ig = reinterpret_cast<const long long*>(s->in_pack.p + in_q);
@@ -944,12 +959,25 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   const int sb_mode = (bf || knn_scan_mfma(D, Q)) ? 0 : 1;
   const size_t lds_q = sizeof(double) * ((size_t)D + 1 + ((size_t)D + 1) / 2);      // [D] query | norm | [D] floats (rounded up to doubles)
   hipLaunchKernelGGL(knn_collect_kernel, dim3(Q), dim3(256), lds_q + lds_r, e.stream, s->items.p, s->norms.p, s->items32.p, (long long)s->V, D,
-                     d_q, d_q32, d_ig, s->tmax.p, s->bmax.p, qpad, nt, tile_items, sb_mode, k, E, d_oi, d_os, d_oc);
+                     d_q, d_q32, d_ig, s->tmax.p, s->bmax.p, qpad, nt, tile_items, sb_mode, k, E, d_oi, d_os, d_oc, poll ? 1 : 0);
   GOCTR_HIP(hipGetLastError());
-  GOCTR_HIP(hipStreamSynchronize(e.stream));         // (the collect kernel wrote the pinned host buffer itself: no copy command)
   const long long* h_oi = static_cast<const long long*>(s->h_out);
   const double* h_os = reinterpret_cast<const double*>(static_cast<const char*>(s->h_out) + o_idx);
   const int* h_oc = reinterpret_cast<const int*>(static_cast<const char*>(s->h_out) + o_idx + o_sim);
+  // The collect kernel wrote the pinned host buffer itself (no copy command), each query's count last, behind a system-scope
+  // release: the host watches the counts turn from the sentinel instead of waiting for the stream's completion signal.  A call
+  // that has not finished after 2 ms (a long queue ahead of it, or a fault) falls back to the stream wait, which reports errors.
+  bool polled = false;
+  if (poll) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int done = 0, spins = 0; !polled;) {
+      while (done < Q && __atomic_load_n(h_oc + done, __ATOMIC_ACQUIRE) != KNN_PENDING) ++done;
+      if (done == Q) { polled = true; break; }
+      if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+      __builtin_ia32_pause();
+    }
+  }
+  if (!polled) GOCTR_HIP(hipStreamSynchronize(e.stream));
   for (int i = 0; i < Q; ++i) if (h_oc[i] < 0) return 1;
   for (size_t i = 0; i < (size_t)Q * k; ++i) { out_idx[i] = h_oi[i]; out_sim[i] = h_os[i]; }
   for (int i = 0; i < Q; ++i) out_count[i] = h_oc[i];

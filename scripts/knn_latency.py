@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Searcher.Search as the reference calls it -- ONE query per call (search.go:92-134) -- and in blocks: latency per call of
 goctr_searcher_search over V = 10^6 x 16 float64 items, scan path (default) vs tile path (GOCTR_KNN_SCAN=0).
-usage: python scripts/knn_latency.py"""
+usage: [KNN_LATENCY_Q=1,8,64,256] [KNN_LATENCY_SCAN=1,0] python scripts/knn_latency.py"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,9 +12,10 @@ V, D, k = 1_000_000, 16, 10
 rng = np.random.default_rng(42)
 items = rng.standard_normal((V, D))
 s = gs.Searcher([""] * V, items)
-for scan in ("1", "0"):
+QS = tuple(int(x) for x in os.environ.get("KNN_LATENCY_Q", "1,8,64,256").split(","))
+for scan in os.environ.get("KNN_LATENCY_SCAN", "1,0").split(","):
     os.environ["GOCTR_KNN_SCAN"] = scan
-    for Q in (1, 8, 64, 256):
+    for Q in QS:
         q = rng.standard_normal((Q, D))
         for _ in range(5):
             s.search_vectors(q, k)
