@@ -728,11 +728,12 @@ bool serve16_ok(const goctr_model* m, const RowSource& src, int B) {
   return src.k_users && fast != 0 && (groups == 2 || groups == 4 || groups == 16) && chain_ok(m) && !chain_x3_ok(m, o, B) &&
          cdiv(B, 32) < engine().compute_units && env_int("GOCTR_NO_FWD16", 0) == 0 && env_int("GOCTR_SERVE_ONE_LAUNCH", 1) != 0;
 }
-int launch_serve16(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb) {
+int launch_serve16(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb, unsigned* done, unsigned epoch) {
   int groups = 0;
   const int fast = attn_fast_mode(m, src, &groups);
   StepOpts o; o.train = false;
-  const ChainArgs a = make_chain_args(m, src, B, o, st, fb);
+  ChainArgs a = make_chain_args(m, src, B, o, st, fb);
+  a.done = done; a.epoch = epoch;
   AttnArgs aa = make_attn_args(m, src, B, st, fb);
   aa.gate = nullptr; aa.wgt = nullptr;                  // (only the training step's backward reads gates and weights)
   const size_t lds = chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p);
@@ -2983,6 +2984,7 @@ struct ServeSlot {
   int64_t cap = 0; int T = 0, U = 0, C = 0;
   // pinned staging: in = [ts i64 x N | users i32 x N | items i32 x N], out = [scores f32 x Br | failed u8 x N]
   char* h_in = nullptr; char* h_out = nullptr;
+  unsigned* h_done = nullptr; unsigned epoch = 0;   // behind the failed flags in h_out: one word per 16-row workgroup (serve_keys_pass)
   std::vector<void*> retired;      // outgrown pinned buffers (see ensure_keys)
   DevBuf<char> d_in, d_out;
   DevBuf<int32_t> ub_ids, item_ids; DevBuf<float> ufeat, cfeat;
@@ -3015,7 +3017,10 @@ struct ServeSlot {
     if (h_in) { retired.push_back(h_in); h_in = nullptr; }
     if (h_out) { retired.push_back(h_out); h_out = nullptr; }
     GOCTR_HIP(hipHostMalloc((void**)&h_in, (size_t)want * 16, hipHostMallocDefault));
-    GOCTR_HIP(hipHostMalloc((void**)&h_out, Br * 4 + (size_t)want, hipHostMallocDefault));
+    const size_t done_off = (Br * 4 + (size_t)want + 63) / 64 * 64, done_n = (size_t)want / 16 + 1;
+    GOCTR_HIP(hipHostMalloc((void**)&h_out, done_off + 4 * done_n, hipHostMallocDefault));
+    h_done = reinterpret_cast<unsigned*>(h_out + done_off);
+    memset(h_done, 0, 4 * done_n); epoch = 0;
     if (d_in.alloc((size_t)want * 16, false) || d_out.alloc(Br * 4 + (size_t)want, false) ||
         ub_ids.alloc((size_t)want * Tn, false) || item_ids.alloc((size_t)want, false) ||
         ufeat.alloc((size_t)want * Un, false) || cfeat.alloc((size_t)want * Cn, false)) return -1;
@@ -3176,8 +3181,15 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   fb.yhat = dscore;
   StepOpts op;
   op.train = false;
+  // A zero-copy pass of one launch: the kernel's workgroups stamp this pass's number into the pinned buffer behind their scores,
+  // and the host watches the stamps instead of waiting for the stream's completion signal -- for passes of up to
+  // GOCTR_SERVE_POLL_ROWS rows (default 256; 0 = never): the release fence in front of a stamp writes back the rows' h0 from the
+  // L2, which costs a 2048-row pass more than the wait saves (profiles/r05_serve_poll.txt).
+  unsigned n_stamps = 0;
   if (fuse && serve16_ok(m, src, (int)N)) {          // key lookup + attention + forward chain: one launch
-    if (launch_serve16(m, src, (int)N, s->st.p, fb)) return -1;
+    const bool poll = zc && N <= (int64_t)env_int("GOCTR_SERVE_POLL_ROWS", 256);
+    if (poll) { if (++s->epoch == 0) s->epoch = 1; n_stamps = (unsigned)cdiv(N, 16); }
+    if (launch_serve16(m, src, (int)N, s->st.p, fb, poll ? s->h_done : nullptr, s->epoch)) return -1;
   } else
   if (launch_forward(m, src, (int)N, op, s->st.p, &fb)) return -1;
   bool want_failed = false;
@@ -3185,7 +3197,17 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   // scores and flags are adjacent: one copy back (the gap between them is < 128 bytes)
   const size_t out_bytes = want_failed ? 4 * Br + (size_t)N : 4 * (size_t)N;
   if (!zc) GOCTR_HIP(hipMemcpyAsync(s->h_out, s->d_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));
-  GOCTR_HIP(hipStreamSynchronize(s->stream));
+  bool stamped = false;
+  if (n_stamps) {                                    // (2 ms without the stamps: the stream wait, which also reports a fault)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned done = 0, spins = 0;;) {
+      while (done < n_stamps && __atomic_load_n(s->h_done + done, __ATOMIC_ACQUIRE) == s->epoch) ++done;
+      if (done == n_stamps) { stamped = true; break; }
+      if ((++spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+      __builtin_ia32_pause();
+    }
+  }
+  if (!stamped) GOCTR_HIP(hipStreamSynchronize(s->stream));
   const float* hs = reinterpret_cast<const float*>(s->h_out);
   const unsigned char* hf = reinterpret_cast<const unsigned char*>(s->h_out + 4 * Br);
   o = 0;

@@ -58,6 +58,9 @@ struct ChainArgs {
   // outputs (training only, except yhat)
   float* A0; float* A1; float* dz0; float* dz1; float* dz2; float* dp; float* yhat; float* lossrow;
   unsigned long long* dbg;                       // optional [CHAIN_NSTAMP] phase timestamps of block 0 / wave 0 (s_memtime)
+  // ctr_serve16_kernel only: [workgroups] words in pinned host memory; a workgroup stores `epoch` behind a system-scope release
+  // once its 16 scores are written -- the host watches them instead of waiting on the stream (null: it waits on the stream)
+  unsigned* done; unsigned epoch;
 };
 
 // floats of one LDS weight buffer: the largest staged operand (+ one tile of slack when the second half of
