@@ -98,6 +98,15 @@ def test_key_lookup_inside_the_attention_kernel_equals_assembled_rows(oracle, mo
         monkeypatch.setenv("GOCTR_SERVE_ONE_LAUNCH", one)
         ys.append(gr.BatchPredict(model, keys)[:, 0].copy())
     assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])
+    # the one-launch pass again with the host waiting on the stream for every pass / watching the workgroups' stamps in the
+    # pinned buffer whatever the pass size (default: passes of up to 256 rows -- the 256-row passes above)
+    monkeypatch.setenv("GOCTR_SERVE_FUSE", "1")
+    monkeypatch.setenv("GOCTR_SERVE_ONE_LAUNCH", "1")
+    for rows in ("0", "100000"):
+        monkeypatch.setenv("GOCTR_SERVE_POLL_ROWS", rows)
+        for _ in range(3):                             # (stamps are pass numbers: consecutive passes must not see old ones)
+            assert np.array_equal(gr.BatchPredict(model, keys)[:, 0], ys[0]), rows
+    monkeypatch.delenv("GOCTR_SERVE_POLL_ROWS")
     ref, failed = oracle_scores(oracle, rs, om, keys, 256)
     assert failed.sum() == 2
     assert np.max(np.abs(ys[0] - ref)) <= 1e-5
