@@ -49,8 +49,8 @@ __global__ __launch_bounds__(1024, 1) void ctr_serve16_kernel(AttnArgs aa, Chain
   // Wavefront 0 wrote the scores.  The failed flags left their wavefronts before the barrier above (s_waitcnt(0), then the
   // workgroup-scope barrier): both are ordered before the system-scope release below.
   if (ca.done && wave == 0) {
-    __threadfence_system();
-    if (lane == 0) __hip_atomic_store(ca.done + blockIdx.x, ca.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // (release only: no invalidate of the L2 under the workgroups still running)
+    if (lane == 0) __hip_atomic_store(ca.done + blockIdx.x, ca.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

@@ -829,10 +829,10 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   const int n_out = cnt < k ? k - 1 : k;                      // search.go:126-131 (see knn_merge_kernel)
   if (host_polls) {
     // the host watches out_cnt[q] in the pinned buffer (knn_search_scan): the neighbours must be there before the count is.
-    // (The system-scope fence writes back whatever the L2 holds dirty -- the filter's maxima: cheap for a few queries, 5 us of a
-    // 64-query call, which therefore waits on the stream instead.)
-    __threadfence_system();
-    __syncthreads();
+    // (The system-scope release writes the L2 back: cheap for a few queries, 5 us of a 64-query call, which therefore waits on
+    // the stream instead -- profiles/r05_knn_poll.txt.)
+    if ((int)(threadIdx.x >> 6) < ((k + 63) >> 6)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // the wavefronts that wrote: release only,
+    __syncthreads();                                                                                // no invalidate of the L2 under the others
     if (threadIdx.x == 0) __hip_atomic_store(out_cnt + q, n_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   } else if (threadIdx.x == 0) out_cnt[q] = n_out;
 }
