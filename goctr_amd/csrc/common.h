@@ -61,6 +61,7 @@ struct Engine {
   bool kernel_attrs_done = false, mlp_attrs_done = false;   // hipFuncSetAttribute is per device: once per engine
   void* serve_pool = nullptr;     // ctr.hip: this engine's serving slots (streams + pinned staging live on its device)
   int compute_units = 0;
+  bool large_bar = false;      // the host can write device memory through the PCIe BAR (hipDeviceProp_t::isLargeBar)
   hipStream_t stream = nullptr;   // the engine's main stream
   hipStream_t side = nullptr;     // forked inside captured step graphs for independent kernels
   // stream the launch helpers of THE CALLING THREAD currently target: the main stream unless a StreamScope switched it

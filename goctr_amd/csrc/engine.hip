@@ -282,6 +282,7 @@ int engine_bind(Engine& e, int device_ordinal) {
   GOCTR_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
               "goctr_init: device is %s; this library is built for gfx950 (MI355X) only", prop.gcnArchName);
   e.compute_units = prop.multiProcessorCount;
+  e.large_bar = prop.isLargeBar != 0;
   GOCTR_HIP(hipStreamCreateWithFlags(&e.stream, hipStreamNonBlocking));
   GOCTR_HIP(hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking));
   for (auto& ev : e.ev_fork) GOCTR_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));

@@ -62,10 +62,14 @@ struct goctr_searcher {
   DevBuf<float> bmax;                        // per (tile, sub-block, query) maxima [tiles][sub-blocks][padded queries]
   DevBuf<unsigned char> in_pack, out_pack;
   void* h_in = nullptr; void* h_out = nullptr; size_t h_in_bytes = 0, h_out_bytes = 0;
+  // the call's input in fine-grained DEVICE memory that the host writes through the PCIe BAR (large-BAR systems): no copy command
+  // in front of the scan kernel.  bar_state: 0 untried, 1 allocated, -1 refused by the runtime (the staged copy stays)
+  unsigned char* in_bar = nullptr; size_t in_bar_bytes = 0; int bar_state = 0;
+  std::vector<void*> retired_dev;            // outgrown in_bar buffers (hipFree waits for the whole device: with the handle)
   bool lds_ok = false;
   std::mutex mu;
   std::vector<void*> retired;                // outgrown pinned buffers: freed with the handle (hipHostFree waits for the whole device)
-  ~goctr_searcher() { for (void* p : retired) (void)hipHostFree(p); if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out); }
+  ~goctr_searcher() { for (void* p : retired_dev) (void)hipFree(p); if (in_bar) (void)hipFree(in_bar); for (void* p : retired) (void)hipHostFree(p); if (h_in) (void)hipHostFree(h_in); if (h_out) (void)hipHostFree(h_out); }
 };
 
 namespace {
@@ -893,7 +897,21 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
     s->h_out_bytes = out_bytes * 2;
   }
   const int qpad = nqb * KNN2_QB;
-  if (s->in_pack.ensure(in_bytes, false) || s->tmax.ensure((size_t)Q * nt, false) || s->bmax.ensure((size_t)nt * 32 * qpad, false)) return -1;
+  // Where the kernels read the input from: device memory the host wrote through the BAR (a 14 KB store burst, ~3 us, instead of a
+  // 4.4 us blit kernel on the stream in front of the scan: profiles/r05_knn_bar_input.txt), else the arena buffer behind a copy.
+  const char* bv = getenv("GOCTR_KNN_BAR");           // (0: the staged copy, for A/B runs and the tests' comparison)
+  const bool want_bar = e.large_bar && s->bar_state >= 0 && !(bv && atoi(bv) == 0);
+  if (want_bar && s->in_bar_bytes < in_bytes) {
+    if (s->in_bar) s->retired_dev.push_back(s->in_bar);
+    s->in_bar = nullptr; s->in_bar_bytes = 0;
+    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&s->in_bar), in_bytes * 2, hipDeviceMallocFinegrained) != hipSuccess || !s->in_bar) {
+      (void)hipGetLastError();
+      s->in_bar = nullptr; s->bar_state = -1;          // not on this system: the staged copy from now on
+    } else { s->in_bar_bytes = in_bytes * 2; s->bar_state = 1; }
+  }
+  const bool bar = want_bar && s->in_bar != nullptr;
+  if ((!bar && s->in_pack.ensure(in_bytes, false)) || s->tmax.ensure((size_t)Q * nt, false) || s->bmax.ensure((size_t)nt * 32 * qpad, false)) return -1;
+  unsigned char* const d_in = bar ? s->in_bar : s->in_pack.p;
   memcpy(s->h_in, queries, in_q);
   long long* h_ig = reinterpret_cast<long long*>(static_cast<char*>(s->h_in) + in_q);
   for (int i = 0; i < Q; ++i) h_ig[i] = ignore ? (long long)ignore[i] : -1;
@@ -928,10 +946,13 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
     int* h_pend = reinterpret_cast<int*>(static_cast<char*>(s->h_out) + o_idx + o_sim);
     for (int i = 0; i < Q; ++i) __atomic_store_n(h_pend + i, KNN_PENDING, __ATOMIC_RELEASE);
   }
-  GOCTR_HIP(hipMemcpyAsync(s->in_pack.p, s->h_in, in_bytes, hipMemcpyHostToDevice, e.stream));
-  const double* d_q = reinterpret_cast<const double*>(s->in_pack.p);
-  const long long* d_ig = reinterpret_cast<const long long*>(s->in_pack.p + in_q);
-  const float* d_q32 = reinterpret_cast<const float*>(s->in_pack.p + in_q + in_ig);
+  if (bar) {                                         // (the previous call's kernels have finished: the host waited for them)
+    memcpy(d_in, s->h_in, in_bytes);
+    __builtin_ia32_sfence();                         // write-combined stores out before the doorbell of the launch below
+  } else GOCTR_HIP(hipMemcpyAsync(d_in, s->h_in, in_bytes, hipMemcpyHostToDevice, e.stream));
+  const double* d_q = reinterpret_cast<const double*>(d_in);
+  const long long* d_ig = reinterpret_cast<const long long*>(d_in + in_q);
+  const float* d_q32 = reinterpret_cast<const float*>(d_in + in_q + in_ig);
   // the filter's error bound |a - sim|: float32 arithmetic (D + 8) 2^-23; bf16-plane arithmetic 2^-14 (knn_scan_bf16_kernel)
   const float E = bf ? 6.103515625e-05f : (float)(D + 8) * 1.1920929e-07f;
   char* d_out = nullptr;                              // the device's view of the pinned output buffer (zero-copy: 10 KB per call)
@@ -942,7 +963,7 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
 #define GOCTR_KNN_SCAN(DD, IPT) hipLaunchKernelGGL((knn_scan_kernel<DD, IPT>), dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, \
                                                   (long long)s->V, d_q32, Q, nt, s->tmax.p, s->bmax.p, qpad)
   if (bf) {
-    const unsigned short* d_qbf = reinterpret_cast<const unsigned short*>(s->in_pack.p + in_q + in_ig + in_q32);
+    const unsigned short* d_qbf = reinterpret_cast<const unsigned short*>(d_in + in_q + in_ig + in_q32);
     const long long qplane = (long long)nqb * KNN2_QB * D, iplane = (long long)(s->items_bf.n / 2);
     if (D == 16) hipLaunchKernelGGL(knn_scan_bf16_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->bmax.p, qpad);
     else hipLaunchKernelGGL(knn_scan_bf16_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->bmax.p, qpad);

@@ -71,9 +71,10 @@ def test_scan_path_query_blocks(oracle, V, D, k, Q):
         assert cnt[q] == ri.size
         assert np.array_equal(idx[q, :cnt[q]], ri) and np.array_equal(sim[q, :cnt[q]], rs)
     # the tile kernels; the VALU / matrix-core scan kernels forced; the float32 instead of the bf16-plane matrix-core filter
-    # the host waiting on the stream for every call / watching the pinned counts for every call (default: up to 32 queries)
+    # the host waiting on the stream for every call / watching the pinned counts for every call (default: up to 32 queries);
+    # the input through a staged copy instead of host stores into device memory over the BAR
     for var, val in (("GOCTR_KNN_SCAN", "0"), ("GOCTR_KNN_MFMA", "1"), ("GOCTR_KNN_MFMA", "0"), ("GOCTR_KNN_BF16", "0"),
-                     ("GOCTR_KNN_POLL_MAXQ", "0"), ("GOCTR_KNN_POLL_MAXQ", "100000")):
+                     ("GOCTR_KNN_POLL_MAXQ", "0"), ("GOCTR_KNN_POLL_MAXQ", "100000"), ("GOCTR_KNN_BAR", "0")):
         os.environ[var] = val
         try:
             idx0, sim0, cnt0 = s.search_vectors(queries, k, ignore)
