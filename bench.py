@@ -543,9 +543,10 @@ def bench_knn(args):
         rl["duration_basis"] = "rocprofv3 average duration of the scan kernel (committed summary of this command)"
     rl["call"] = {"bytes_per_call_implemented": int(call_b), "us_per_call": round(call_us, 1),
                   "achieved_GBs": round(call_b / (call_us * 1e-6) / 1e9, 1), "frac_of_hbm": round(call_b / (call_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                  "note": "whole call (H2D of the queries, scan, collect + replay, results through pinned memory, host sync) against the "
-                          "bytes the implemented path has to move; the call is a latency chain of three dependent launches and a host "
-                          "round trip, not a bandwidth problem: see the per-kernel durations in profiles/"}
+                  "note": "whole call (the queries stored by the host into device memory over the PCIe BAR -- a staged copy where there is "
+                          "no large BAR --, scan, collect + replay, results through pinned memory, host wait) against the bytes the "
+                          "implemented path has to move; the call is a latency chain of two dependent launches and a host round trip, "
+                          "not a bandwidth problem: see the per-kernel durations in profiles/"}
     rl["reference_loop_bytes_per_call"] = int(Q * V * D * 8)   # what search.go:92-134 reads (every query scans the f64 matrix)
     if not args.no_cpu_baseline:
         from oracle import pyoracle
