@@ -2985,6 +2985,9 @@ struct ServeSlot {
   // pinned staging: in = [ts i64 x N | users i32 x N | items i32 x N], out = [scores f32 x Br | failed u8 x N]
   char* h_in = nullptr; char* h_out = nullptr;
   unsigned* h_done = nullptr; unsigned epoch = 0;   // behind the failed flags in h_out: one word per 16-row workgroup (serve_keys_pass)
+  // the keys of a zero-copy pass in fine-grained DEVICE memory that the host stores into over the PCIe BAR (large-BAR systems): the
+  // kernel's first loads are local instead of a PCIe read round trip.  Null: the kernels read the pinned h_in.
+  char* in_bar = nullptr; std::vector<void*> retired_dev;
   std::vector<void*> retired;      // outgrown pinned buffers (see ensure_keys)
   DevBuf<char> d_in, d_out;
   DevBuf<int32_t> ub_ids, item_ids; DevBuf<float> ufeat, cfeat;
@@ -2992,6 +2995,8 @@ struct ServeSlot {
   DevBuf<StepState> st;            // one all-zero state: "batch 0 of 1"
   DevBuf<float> X; size_t capX = 0;   // dense rows (goctr_predict_dense)
   ~ServeSlot() {
+    for (void* p : retired_dev) (void)hipFree(p);
+    if (in_bar) (void)hipFree(in_bar);
     for (void* p : retired) (void)hipHostFree(p);
     if (h_in) (void)hipHostFree(h_in);
     if (h_out) (void)hipHostFree(h_out);
@@ -3017,6 +3022,12 @@ struct ServeSlot {
     if (h_in) { retired.push_back(h_in); h_in = nullptr; }
     if (h_out) { retired.push_back(h_out); h_out = nullptr; }
     GOCTR_HIP(hipHostMalloc((void**)&h_in, (size_t)want * 16, hipHostMallocDefault));
+    if (in_bar) { retired_dev.push_back(in_bar); in_bar = nullptr; }
+    if (engine().large_bar && env_int("GOCTR_SERVE_BAR", 1) != 0 &&
+        (hipExtMallocWithFlags((void**)&in_bar, (size_t)want * 16, hipDeviceMallocFinegrained) != hipSuccess || !in_bar)) {
+      (void)hipGetLastError();
+      in_bar = nullptr;                          // refused: the pinned buffer serves
+    }
     const size_t done_off = (Br * 4 + (size_t)want + 63) / 64 * 64, done_n = (size_t)want / 16 + 1;
     GOCTR_HIP(hipHostMalloc((void**)&h_out, done_off + 4 * done_n, hipHostMallocDefault));
     h_done = reinterpret_cast<unsigned*>(h_out + done_off);
@@ -3129,9 +3140,17 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   if (s->ensure_keys(cap_rows, T, r->U, r->C)) return -1;
   if (s->ws.ensure((int)cap_rows, m->Ip, T, m->H1p, m->H2p, !chain_ok(m), s->stream)) return -1;
   const size_t Br = (size_t)round_up((int)N, 32);
-  long long* hts = reinterpret_cast<long long*>(s->h_in);
-  int32_t* hus = reinterpret_cast<int32_t*>(s->h_in + 8 * N);
-  int32_t* hit = reinterpret_cast<int32_t*>(s->h_in + 12 * N);
+  // Small passes read the keys and write the scores without copy commands on the stream (GOCTR_SERVE_ZEROCOPY=rows, default 4096;
+  // 0 = never): a pass is one launch (ctr_serve16_kernel) and one wait.  The keys (16 B per row) are stored by the host straight into
+  // device memory over the PCIe BAR where the system has a large BAR (GOCTR_SERVE_BAR=0: off), else the kernels read the pinned
+  // host buffer; the scores and flags (5 B per row) are written to pinned host memory from inside the kernels.  Larger passes keep
+  // the two DMA copies.
+  const bool zc = N <= (int64_t)env_int("GOCTR_SERVE_ZEROCOPY", 4096);
+  const bool bar = zc && s->in_bar != nullptr && env_int("GOCTR_SERVE_BAR", 1) != 0;
+  char* const key_dst = bar ? s->in_bar : s->h_in;      // (written only, front to back: fine for a write-combined mapping)
+  long long* hts = reinterpret_cast<long long*>(key_dst);
+  int32_t* hus = reinterpret_cast<int32_t*>(key_dst + 8 * N);
+  int32_t* hit = reinterpret_cast<int32_t*>(key_dst + 12 * N);
   int64_t o = 0;
   for (int k = 0; k < nseg; ++k) {
     const KeySeg& g = *segs[k];
@@ -3142,13 +3161,10 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
     memcpy(hit + o, g.items, sizeof(int32_t) * (size_t)g.n);
     o += g.n;
   }
-  // Small passes read the keys and write the scores straight through the pinned staging buffers (device-visible host
-  // memory: 16 B in and 5 B out per row over PCIe from inside the kernels) -- no copy commands on the stream at all, a pass
-  // is one launch (ctr_serve16_kernel) and one wait.  Larger passes keep the two DMA copies (GOCTR_SERVE_ZEROCOPY=rows, default 4096; 0 = never).
-  const bool zc = N <= (int64_t)env_int("GOCTR_SERVE_ZEROCOPY", 4096);
+  if (bar) __builtin_ia32_sfence();                   // the key stores are out before the launch's doorbell
   if (!zc) GOCTR_HIP(hipMemcpyAsync(s->d_in.p, s->h_in, (size_t)N * 16, hipMemcpyHostToDevice, s->stream));
   if (serve_wait_weights(m, s) || serve_wait_rows(r->emb)) return -1;
-  const char* in_base = zc ? s->h_in : s->d_in.p;
+  const char* in_base = bar ? s->in_bar : (zc ? s->h_in : s->d_in.p);
   char* out_base = zc ? s->h_out : s->d_out.p;
   const long long* dts = reinterpret_cast<const long long*>(in_base);
   const int32_t* dus = reinterpret_cast<const int32_t*>(in_base + 8 * N);

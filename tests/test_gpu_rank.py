@@ -107,6 +107,11 @@ def test_key_lookup_inside_the_attention_kernel_equals_assembled_rows(oracle, mo
         for _ in range(3):                             # (stamps are pass numbers: consecutive passes must not see old ones)
             assert np.array_equal(gr.BatchPredict(model, keys)[:, 0], ys[0]), rows
     monkeypatch.delenv("GOCTR_SERVE_POLL_ROWS")
+    # ... and with the kernels reading the keys from the pinned host buffer instead of from device memory the host stored
+    # them into over the PCIe BAR (the default where the system has a large BAR)
+    monkeypatch.setenv("GOCTR_SERVE_BAR", "0")
+    assert np.array_equal(gr.BatchPredict(model, keys)[:, 0], ys[0])
+    monkeypatch.delenv("GOCTR_SERVE_BAR")
     ref, failed = oracle_scores(oracle, rs, om, keys, 256)
     assert failed.sum() == 2
     assert np.max(np.abs(ys[0] - ref)) <= 1e-5
