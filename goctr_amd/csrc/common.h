@@ -160,6 +160,10 @@ inline void prof_note_kernel(int id, const char* symbol) { engine().prof_kernel[
 // the engine sits in the same 2 MiB-fragment mapping (few TLB entries) instead of dozens of small
 // separately-mapped allocations.  Requests that do not fit fall back to a plain hipMalloc.
 void* arena_alloc(size_t bytes);              // from the calling thread's engine
+// Fine-grained DEVICE memory that the host may store into through the PCIe BAR (a k-NN call's queries, a serving pass's keys:
+// search.hip, ctr.hip), or null: no large BAR, the runtime refuses, or the range is not mapped writable into this process
+// (checked in /proc/self/maps before anybody stores into it).  Freed with hipFree.
+void* bar_alloc(size_t bytes);
 void arena_free(Engine* owner, void* p);      // back to the engine it came from (any thread)
 
 template <typename T>

@@ -3023,11 +3023,7 @@ struct ServeSlot {
     if (h_out) { retired.push_back(h_out); h_out = nullptr; }
     GOCTR_HIP(hipHostMalloc((void**)&h_in, (size_t)want * 16, hipHostMallocDefault));
     if (in_bar) { retired_dev.push_back(in_bar); in_bar = nullptr; }
-    if (engine().large_bar && env_int("GOCTR_SERVE_BAR", 1) != 0 &&
-        (hipExtMallocWithFlags((void**)&in_bar, (size_t)want * 16, hipDeviceMallocFinegrained) != hipSuccess || !in_bar)) {
-      (void)hipGetLastError();
-      in_bar = nullptr;                          // refused: the pinned buffer serves
-    }
+    if (env_int("GOCTR_SERVE_BAR", 1) != 0) in_bar = static_cast<char*>(bar_alloc((size_t)want * 16));   // (null: the pinned buffer serves)
     const size_t done_off = (Br * 4 + (size_t)want + 63) / 64 * 64, done_n = (size_t)want / 16 + 1;
     GOCTR_HIP(hipHostMalloc((void**)&h_out, done_off + 4 * done_n, hipHostMallocDefault));
     h_done = reinterpret_cast<unsigned*>(h_out + done_off);

@@ -292,6 +292,30 @@ int engine_bind(Engine& e, int device_ordinal) {
   return 0;
 }
 
+void* bar_alloc(size_t bytes) {
+  if (!engine().large_bar || bytes == 0) return nullptr;
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+  // the whole range must lie in mappings this process may write (the runtime maps host-accessible device memory at its device
+  // address; a device-only allocation is a reserved, inaccessible range or no mapping at all)
+  const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+  uintptr_t covered = lo;
+  if (FILE* f = fopen("/proc/self/maps", "r")) {
+    char line[512];
+    while (covered < hi && fgets(line, sizeof line, f)) {
+      unsigned long long a = 0, b = 0; char perm[8] = {0};
+      if (sscanf(line, "%llx-%llx %7s", &a, &b, perm) != 3) continue;
+      if (a <= covered && covered < b) {                       // (the file is sorted by address)
+        if (perm[1] != 'w') break;
+        covered = (uintptr_t)b;
+      }
+    }
+    fclose(f);
+  }
+  if (covered < hi) { (void)hipFree(p); return nullptr; }
+  return p;
+}
+
 // comm.hip: builds the communicator of a goctr_init_devices group (RCCL over the distinct devices, else loop-back)
 int comm_group_init(int n);
 

@@ -904,10 +904,9 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   if (want_bar && s->in_bar_bytes < in_bytes) {
     if (s->in_bar) s->retired_dev.push_back(s->in_bar);
     s->in_bar = nullptr; s->in_bar_bytes = 0;
-    if (hipExtMallocWithFlags(reinterpret_cast<void**>(&s->in_bar), in_bytes * 2, hipDeviceMallocFinegrained) != hipSuccess || !s->in_bar) {
-      (void)hipGetLastError();
-      s->in_bar = nullptr; s->bar_state = -1;          // not on this system: the staged copy from now on
-    } else { s->in_bar_bytes = in_bytes * 2; s->bar_state = 1; }
+    s->in_bar = static_cast<unsigned char*>(bar_alloc(in_bytes * 2));
+    if (!s->in_bar) s->bar_state = -1;                 // not on this system: the staged copy from now on
+    else { s->in_bar_bytes = in_bytes * 2; s->bar_state = 1; }
   }
   const bool bar = want_bar && s->in_bar != nullptr;
   if ((!bar && s->in_pack.ensure(in_bytes, false)) || s->tmax.ensure((size_t)Q * nt, false) || s->bmax.ensure((size_t)nt * 32 * qpad, false)) return -1;
