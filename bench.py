@@ -535,7 +535,7 @@ def bench_knn(args):
            "config": {"workload": "SURVEY 8(f)2: Searcher.Search, V=10^6, D=16 f64, k=10, 64 queries per call", "parallelism": "dp1"},
            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "kernel": "knn_scan_bf16_kernel (the filter: every normalised row once per 64-query call, as two bf16 planes)"}}
-    rl = with_traffic(out["roofline"], "knn", "train", "knn_scan_*", None, None)      # (knn_scan_mfma_kernel<D> from 48 queries per call on)
+    rl = with_traffic(out["roofline"], "knn", "train", "knn_scan_*", None, None)      # (knn_scan_bf16_kernel<D> from 12 queries per call on)
     rl["algorithmic_bytes"] = int(scan_b)                                              # the dominant kernel's own bytes
     if rl.get("avg_us_rocprofv3"):
         rl["achieved"] = round(rl["algorithmic_bytes"] / (rl["avg_us_rocprofv3"] * 1e-6) / 1e9, 1)

@@ -27,9 +27,8 @@
 //                      v_pk_fma_f32; per (item, query) the approximate cosine a = sum q^_d v^_d, |a - sim| <= E = (D + 8) 2^-23
 //                      (rounding of the inputs + D fused multiply-adds, products bounded by Cauchy-Schwarz); the tile's maximum
 //                      per query AND the maximum of every sub-block of the tile (32 consecutive items / the rows of 16 adjacent
-//                      threads).  From 48 queries per call on the filter runs on the matrix cores: round 4 float32 MFMA
-//                      (knn_scan_mfma_kernel, MFMA-bound), round 5 two bf16 planes and three products (knn_scan_bf16_kernel,
-//                      |a - sim| <= 2^-14, HBM-bound: every row once per call at ~5 TB/s)
+//                      threads).  From 12 queries per call on the filter runs on the matrix cores: two bf16 planes and three
+//                      products (knn_scan_bf16_kernel, |a - sim| <= 2^-14, HBM-bound: every row once per call at ~5 TB/s)
 //   knn_collect_kernel ONE workgroup per query: L = the k-th largest of 256 group maxima (the (k + 1)-th when an item is ignored): k
 //                      distinct items have a >= L, so the k-th best similarity is >= L - E, every member of the candidate set C has
 //                      sim >= L - E and lies in a tile AND a sub-block whose maximum is >= L - 2 E -- those sub-blocks, about k + 3
@@ -445,73 +444,12 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
   }
 }
 
-// knn_scan_mfma_kernel<D>: the same filter on the matrix cores -- the block's scores are a [1024 items] x [64 queries] product over
-// D dimensions.  A wavefront takes 32 items at a time: v_mfma_f32_32x32x2_f32 with the items as rows (lane l supplies item l % 32,
-// dimension 2 j + l / 32 of step j) and the queries as columns, D / 2 steps per 32 x 32 tile and half of the query block; a lane
-// then holds 16 items' scores of ONE query, folds them into its running maximum, and the lanes / wavefronts of a workgroup are
-// combined once at the end.  The float32 MFMA's error (1.3e-7 of sum |a b| measured on this chip, DESIGN_HISTORY 4.1) is inside
-// the same bound E.  The normalised rows are padded with zero rows to whole tiles (goctr_searcher_create): no tail checks.
-template <int D>
-__global__ __launch_bounds__(256) void knn_scan_mfma_kernel(const float* __restrict__ items32, const float* __restrict__ q32 /* padded */,
-                                                            int Q, int nt, float* __restrict__ tmax, float* __restrict__ bmax, int qpad) {
-  typedef float v16 __attribute__((ext_vector_type(16)));
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  __shared__ float red[4][KNN2_QB];
-  const int tile = blockIdx.x, q0 = blockIdx.y * KNN2_QB;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31, half = lane >> 5;
-  // this lane's query components: query q0 + h 32 + col, dimensions 2 j + half
-  float qb[2][D / 2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float* qp = q32 + (size_t)(q0 + h * 32 + col) * D;
-#pragma unroll
-    for (int d = 0; d < D; d += 4) {
-      const f4 x = *reinterpret_cast<const f4*>(qp + d);
-      qb[h][d / 2] = half ? x[1] : x[0];
-      qb[h][d / 2 + 1] = half ? x[3] : x[2];
-    }
-  }
-  float mx[2] = {0.f, 0.f};
-  const size_t row0 = (size_t)tile * 1024 + (size_t)wave * 256;
-#pragma unroll 2
-  for (int t = 0; t < 8; ++t) {                        // 8 tiles of 32 items per wavefront
-    const float* v = items32 + (row0 + (size_t)t * 32 + col) * D;
-    float a[D / 2];
-#pragma unroll
-    for (int d = 0; d < D; d += 4) {
-      const f4 x = *reinterpret_cast<const f4*>(v + d);
-      a[d / 2] = half ? x[1] : x[0];
-      a[d / 2 + 1] = half ? x[3] : x[2];
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      v16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int j = 0; j < D / 2; ++j) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], qb[h][j], c, 0, 0, 0);
-      float m = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m = __builtin_fmaxf(m, c[r]);         // (a NaN score -- an item with an infinite norm -- is dropped)
-      // this 32-item block's maximum per query (both row halves): bmax [tile][32 blocks][queries]
-      m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
-      if (half == 0) bmax[((size_t)tile * 32 + wave * 8 + t) * qpad + q0 + h * 32 + col] = m;
-      mx[h] = __builtin_fmaxf(mx[h], m);
-    }
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    float m = mx[h];
-    m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));     // the other 16 rows of the column
-    if (half == 0) red[wave][h * 32 + col] = m;
-  }
-  __syncthreads();
-  if (threadIdx.x < KNN2_QB && q0 + (int)threadIdx.x < Q) {
-    const float m = __builtin_fmaxf(__builtin_fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), __builtin_fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
-    tmax[(size_t)(q0 + threadIdx.x) * nt + tile] = m;
-  }
-}
-
-// knn_scan_bf16_kernel<D>: the filter on the bf16 matrix cores (round 5).  The float32-input MFMA of knn_scan_mfma_kernel issues at
-// a sixteenth of the bf16 rate and was what bound the scan (MFMA-busy 60 %, 2.5 TB/s of rows = 0.32 of HBM).  Rows and queries are
+// knn_scan_bf16_kernel<D>: the filter on the bf16 matrix cores (round 5) -- the block's scores are a [1024 items] x [64 queries]
+// product over D dimensions; a wavefront takes 32 items at a time as the rows of a 32 x 32 tile, the queries as its columns; a lane
+// then holds 16 items' scores of ONE query, folds them into the sub-block's and its running maximum, and the lanes / wavefronts of a
+// workgroup are combined once at the end.  (Round 4's float32-input MFMA kernel, v_mfma_f32_32x32x2_f32, issued at a sixteenth of the
+// bf16 rate and was what bound the scan: MFMA-busy 60 %, 2.5 TB/s of rows = 0.32 of HBM, 26 us; it left the tree in round 5,
+// profiles/r04_knn_scan_ab.txt and git keep it.)  The normalised rows are padded with zero rows to whole tiles: no tail checks.  Rows and queries are
 // kept as TWO bf16 planes, x = hi + lo + rest with |rest| <= 2^-16 |x|, and a score is hi.hi + hi.lo + lo.hi on
 // v_mfma_f32_32x32x16_bf16 (products of bf16 pairs are exact in float32; the dropped lo.lo and the two rests are <= 3 x 2^-16 of
 // sum |q_d v_d| <= 1): |a - sim| <= E' = 2^-14 with room for the float32 accumulation (tests/test_knn_filter_bound.py) -- twenty
@@ -833,8 +771,8 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   const int n_out = cnt < k ? k - 1 : k;                      // search.go:126-131 (see knn_merge_kernel)
   if (host_polls) {
     // the host watches out_cnt[q] in the pinned buffer (knn_search_scan): the neighbours must be there before the count is.
-    // (The system-scope release writes the L2 back: cheap for a few queries, 5 us of a 64-query call, which therefore waits on
-    // the stream instead -- profiles/r05_knn_poll.txt.)
+    // (The system-scope release writes the L2 back, once per workgroup: calls of more than 64 queries wait on the stream instead --
+    // profiles/r05_knn_poll.txt.)
     if ((int)(threadIdx.x >> 6) < ((k + 63) >> 6)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // the wavefronts that wrote: release only,
     __syncthreads();                                                                                // no invalidate of the L2 under the others
     if (threadIdx.x == 0) __hip_atomic_store(out_cnt + q, n_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -848,17 +786,13 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
 static int knn_scan_ipt(int D) { return D == 16 ? 4 : D == 32 ? 4 : D == 64 ? 2 : 0; }
 static int knn_scan_tile(int D) { return 256 * knn_scan_ipt(D); }
 static int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-// the matrix-core scan kernel: from 48 queries per call on -- its cost is per block of 64 query columns (26 us), the VALU kernel's
-// per query (13 us for one, 34 us for 64; measured cross-over between 40 and 64 queries per call, scripts/knn_latency.py: Q 32 70.0
-// vs 72.2 us, Q 40 80.1 vs 77.4 us, Q 64 80.6 vs 89.8 us).  GOCTR_KNN_MFMA=0 / 1 forces either
-static bool knn_scan_mfma(int D, int Q) {
+// The matrix-core scan kernel (knn_scan_bf16_kernel: D = 16 / 32, where the bf16 planes exist): its cost is per block of 64 query
+// columns (13.7 us), the VALU kernel's per query (13 us for one, 34 us for 64).  Measured cross-over between 8 and 16 queries per call
+// (profiles/r05_knn_scan_threshold.txt: 8 queries 44.4 vs 45.0 us, 16 46.8 vs 47.2, 24 49.9 vs 47.6, 32 53.6 vs 48.9, 47 63.6 vs
+// 51.2): from 12 queries on.  (The 48 of round 4 belonged to the float32 MFMA kernel.)  GOCTR_KNN_MFMA=0 / 1 forces either.
+static bool knn_scan_mfma(const goctr_searcher* s, int Q) {
   const char* v = getenv("GOCTR_KNN_MFMA");
-  return (v && *v ? *v != '0' : Q >= 48) && knn_scan_tile(D) == 1024;
-}
-// the bf16-plane scan kernel: wherever the matrix-core scan applies and the planes exist (D = 16 / 32); GOCTR_KNN_BF16=0: the float32 MFMA
-static bool knn_scan_bf16(const goctr_searcher* s, int Q) {
-  const char* v = getenv("GOCTR_KNN_BF16");
-  return !(v && *v == '0') && s->items_bf.p && (s->D == 16 || s->D == 32) && knn_scan_mfma(s->D, Q);
+  return (v && *v ? *v != '0' : Q >= 12) && knn_scan_tile(s->D) == 1024 && s->items_bf.p && (s->D == 16 || s->D == 32);
 }
 static bool knn_scan_usable(const goctr_searcher* s, int k) {
   const char* v = getenv("GOCTR_KNN_SCAN");
@@ -881,7 +815,7 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   // one download: [Q x k idx | Q x k sim | Q count]
   const size_t in_q = sizeof(double) * (size_t)Q * D, in_ig = sizeof(long long) * (size_t)Q;
   const size_t in_q32 = sizeof(float) * (size_t)nqb * KNN2_QB * D;
-  const bool bf = knn_scan_bf16(s, Q);               // the bf16-plane filter (from 48 queries per call on, D = 16 / 32)
+  const bool bf = knn_scan_mfma(s, Q);               // the bf16-plane matrix-core filter (from 12 queries per call on, D = 16 / 32)
   const size_t in_qbf = bf ? sizeof(unsigned short) * 2 * (size_t)nqb * KNN2_QB * D : 0, in_bytes = in_q + in_ig + in_q32 + in_qbf;
   const size_t o_idx = sizeof(long long) * (size_t)Q * k, o_sim = sizeof(double) * (size_t)Q * k, out_bytes = o_idx + o_sim + sizeof(int) * (size_t)Q;
   if (s->h_in_bytes < in_bytes) {
@@ -940,7 +874,9 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
     }
   }
   const char* pv = getenv("GOCTR_KNN_POLL_MAXQ");
-  const bool poll = Q <= (pv ? atoi(pv) : 32);       // profiles/r05_knn_poll.txt: -4.5 us up to 8 queries, -1.5 at 32, +9 at 64
+  // (profiles/r05_knn_poll.txt: with the input over the BAR polling pays up to 64 queries per call -- the bench line 1.18 -> 1.26 M
+  // queries/s --, is even at 96 and costs 3 us at 128; with the staged copy it lost 9 us at 64)
+  const bool poll = Q <= (pv ? atoi(pv) : 64);
   if (poll) {                                        // (the previous call returned after its kernels' last stores: nothing else writes here)
     int* h_pend = reinterpret_cast<int*>(static_cast<char*>(s->h_out) + o_idx + o_sim);
     for (int i = 0; i < Q; ++i) __atomic_store_n(h_pend + i, KNN_PENDING, __ATOMIC_RELEASE);
@@ -966,9 +902,6 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
     const long long qplane = (long long)nqb * KNN2_QB * D, iplane = (long long)(s->items_bf.n / 2);
     if (D == 16) hipLaunchKernelGGL(knn_scan_bf16_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->bmax.p, qpad);
     else hipLaunchKernelGGL(knn_scan_bf16_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->bmax.p, qpad);
-  } else if (knn_scan_mfma(D, Q)) {
-    if (D == 16) hipLaunchKernelGGL(knn_scan_mfma_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, d_q32, Q, nt, s->tmax.p, s->bmax.p, qpad);
-    else hipLaunchKernelGGL(knn_scan_mfma_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items32.p, d_q32, Q, nt, s->tmax.p, s->bmax.p, qpad);
   } else if (D == 16) GOCTR_KNN_SCAN(16, 4);
   else if (D == 32) GOCTR_KNN_SCAN(32, 4);
   else GOCTR_KNN_SCAN(64, 2);
@@ -976,7 +909,7 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   GOCTR_HIP(hipGetLastError());
   // collect + exact refine + replay: one workgroup per query (sub-block layout: 32 consecutive items from the matrix-core scan
   // kernels, the rows of 16 adjacent threads from the VALU one)
-  const int sb_mode = (bf || knn_scan_mfma(D, Q)) ? 0 : 1;
+  const int sb_mode = bf ? 0 : 1;
   const size_t lds_q = sizeof(double) * ((size_t)D + 1 + ((size_t)D + 1) / 2);      // [D] query | norm | [D] floats (rounded up to doubles)
   hipLaunchKernelGGL(knn_collect_kernel, dim3(Q), dim3(256), lds_q + lds_r, e.stream, s->items.p, s->norms.p, s->items32.p, (long long)s->V, D,
                      d_q, d_q32, d_ig, s->tmax.p, s->bmax.p, qpad, nt, tile_items, sb_mode, k, E, d_oi, d_os, d_oc, poll ? 1 : 0);

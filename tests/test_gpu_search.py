@@ -70,10 +70,10 @@ def test_scan_path_query_blocks(oracle, V, D, k, Q):
         ri, rs, _ = oracle.knn_search(items, queries[q], k, ignore=int(ignore[q]))
         assert cnt[q] == ri.size
         assert np.array_equal(idx[q, :cnt[q]], ri) and np.array_equal(sim[q, :cnt[q]], rs)
-    # the tile kernels; the VALU / matrix-core scan kernels forced; the float32 instead of the bf16-plane matrix-core filter
-    # the host waiting on the stream for every call / watching the pinned counts for every call (default: up to 32 queries);
+    # the tile kernels; the VALU / matrix-core scan kernels forced;
+    # the host waiting on the stream for every call / watching the pinned counts for every call (default: up to 64 queries);
     # the input through a staged copy instead of host stores into device memory over the BAR
-    for var, val in (("GOCTR_KNN_SCAN", "0"), ("GOCTR_KNN_MFMA", "1"), ("GOCTR_KNN_MFMA", "0"), ("GOCTR_KNN_BF16", "0"),
+    for var, val in (("GOCTR_KNN_SCAN", "0"), ("GOCTR_KNN_MFMA", "1"), ("GOCTR_KNN_MFMA", "0"),
                      ("GOCTR_KNN_POLL_MAXQ", "0"), ("GOCTR_KNN_POLL_MAXQ", "100000"), ("GOCTR_KNN_BAR", "0")):
         os.environ[var] = val
         try:
@@ -149,9 +149,10 @@ def test_large_scan_properties():
 
 def test_bench_shape_matches_oracle_bit_exact(oracle):
     """the shape bench.py --workload knn times (V = 10^6, D = 16, k = 10, the same seeded items): 64 queries per call ->
-    knn_scan_bf16_kernel<16> (round 5; round 4: knn_scan_mfma_kernel<16>) over 977 tiles -> knn_collect (+ replay).  Q = 47 is the last call size on the VALU scan
-    kernel, 48 the first on the MFMA one, 64 a full query block, 65 two blocks; each call also forced onto the other scan
-    kernel.  Indices, float64 similarities and counts equal the oracle's sequential loop for EVERY query."""
+    knn_scan_bf16_kernel<16> over 977 tiles -> knn_collect (+ replay).  Q = 11 is the last call size on the VALU scan kernel, 12 the
+    first on the matrix-core one, 64 a full query block (and the last size whose completion the host polls), 65 two blocks; each
+    call also forced onto the other scan kernel.  Indices, float64 similarities and counts equal the oracle's sequential loop for
+    EVERY query."""
     from goctr_amd import search as gs
     rng = np.random.default_rng(42)
     V, D, k = 1_000_000, 16, 10
@@ -167,17 +168,16 @@ def test_bench_shape_matches_oracle_bit_exact(oracle):
     ign = np.full(65, -1, np.int64)
     ign[5] = 123456
     want = [oracle.knn_search(items, allq[q], k, ignore=int(ign[q]), norms=norms) for q in range(65)]
-    for Q in (47, 48, 64, 65):
-        # default dispatch (>= 48 queries: the bf16-plane matrix-core filter), the VALU filter, the float32 matrix-core filter
-        for mfma, bf16 in ((None, None), ("0", None), ("1", None), ("1", "0")):
+    for Q in (11, 12, 47, 64, 65):
+        # default dispatch (>= 12 queries: the bf16-plane matrix-core filter), the VALU filter, the matrix-core filter
+        for mfma in (None, "0", "1"):
+            bf16 = None
             if mfma is not None:
                 os.environ["GOCTR_KNN_MFMA"] = mfma
-            if bf16 is not None:
-                os.environ["GOCTR_KNN_BF16"] = bf16
             try:
                 idx, sim, cnt = s.search_vectors(allq[:Q], k, ign[:Q])
             finally:
-                os.environ.pop("GOCTR_KNN_MFMA", None); os.environ.pop("GOCTR_KNN_BF16", None)
+                os.environ.pop("GOCTR_KNN_MFMA", None)
             for q in range(Q):
                 ri, rs, _ = want[q]
                 assert cnt[q] == ri.size == k, (Q, mfma, bf16, q)
