@@ -3195,11 +3195,11 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   op.train = false;
   // A zero-copy pass of one launch: the kernel's workgroups stamp this pass's number into the pinned buffer behind their scores,
   // and the host watches the stamps instead of waiting for the stream's completion signal -- for passes of up to
-  // GOCTR_SERVE_POLL_ROWS rows (default 256; 0 = never): the release fence in front of a stamp writes back the rows' h0 from the
-  // L2, which costs a 2048-row pass more than the wait saves (profiles/r05_serve_poll.txt).
+  // GOCTR_SERVE_POLL_ROWS rows (default 512; 0 = never): the release fence in front of a stamp writes back the rows' h0 from the
+  // L2, which costs a 2048-row pass more than the wait saves (profiles/r05_serve_poll.txt; 256 rows until the keys went over the BAR).
   unsigned n_stamps = 0;
   if (fuse && serve16_ok(m, src, (int)N)) {          // key lookup + attention + forward chain: one launch
-    const bool poll = zc && N <= (int64_t)env_int("GOCTR_SERVE_POLL_ROWS", 256);
+    const bool poll = zc && N <= (int64_t)env_int("GOCTR_SERVE_POLL_ROWS", 512);
     if (poll) { if (++s->epoch == 0) s->epoch = 1; n_stamps = (unsigned)cdiv(N, 16); }
     if (launch_serve16(m, src, (int)N, s->st.p, fb, poll ? s->h_done : nullptr, s->epoch)) return -1;
   } else

@@ -99,7 +99,7 @@ def test_key_lookup_inside_the_attention_kernel_equals_assembled_rows(oracle, mo
         ys.append(gr.BatchPredict(model, keys)[:, 0].copy())
     assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])
     # the one-launch pass again with the host waiting on the stream for every pass / watching the workgroups' stamps in the
-    # pinned buffer whatever the pass size (default: passes of up to 256 rows -- the 256-row passes above)
+    # pinned buffer whatever the pass size (default: passes of up to 512 rows -- the 256-row passes above)
     monkeypatch.setenv("GOCTR_SERVE_FUSE", "1")
     monkeypatch.setenv("GOCTR_SERVE_ONE_LAUNCH", "1")
     for rows in ("0", "100000"):
