@@ -508,15 +508,20 @@ def bench_knn(args):
     items = rng.standard_normal((V, D))
     s = gs.Searcher([""] * V, items)
     queries = rng.standard_normal((Q, D))
-    steps, warm = max(1, args.steps // 10), max(1, args.warmup // 10)
+    # (a step = one call; the median of --regions back-to-back regions of --steps calls each: one region of 20 calls, as until round 5,
+    # is a 1 ms sample -- two of eleven such runs read 1.17 M instead of 1.27 M queries/s, profiles/r05_knn_scan_threshold.txt)
+    steps, warm = max(1, args.steps), max(1, args.warmup)
     for _ in range(warm):
         s.search_vectors(queries, k)
     capi.sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        idx, sim, cnt = s.search_vectors(queries, k)
-    capi.sync()
-    dt = time.perf_counter() - t0
+    regions = []
+    for r in range(max(args.regions, 1)):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            idx, sim, cnt = s.search_vectors(queries, k)
+        capi.sync()
+        regions.append(time.perf_counter() - t0)
+    dt = sorted(regions)[(len(regions) - 1) // 2]
     qps = steps * Q / dt
     # ---- roofline of the IMPLEMENTED call (rounds 1-4 priced the reference's loop -- every query scans
     # V x D x 8 bytes -- which the filter + refine path does not perform: the fraction read 12).  Per call of Q queries:
@@ -532,6 +537,7 @@ def bench_knn(args):
     out = {"metric": "k-NN search queries/sec (cosine top-10 over 10^6 x 16 float64 items)", "value": round(qps, 1),
            "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "timed_regions": len(regions), "timed_regions_ms": [round(x * 1e3, 4) for x in regions],
            "config": {"workload": "SURVEY 8(f)2: Searcher.Search, V=10^6, D=16 f64, k=10, 64 queries per call", "parallelism": "dp1"},
            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "kernel": "knn_scan_bf16_kernel (the filter: every normalised row once per 64-query call, as two bf16 planes)"}}
