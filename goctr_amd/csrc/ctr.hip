@@ -660,6 +660,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
     a.ab_T = c.T; a.ab_Tp = m->Tp;
   }
   a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
+  a.xcd_affine = o.train ? env_int("GOCTR_XCD_AFFINE", 1) : 0;
   static DevBuf<unsigned long long> dbgbuf;
   const bool dbg = env_int("GOCTR_CHAIN_DBG", 0) != 0 && (hipStream_t)e.active == e.stream;   // (not from a serving slot)
   if (dbg && !dbgbuf.p && dbgbuf.alloc(8 * CX_NSTAMP)) return -1;
@@ -797,6 +798,7 @@ AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepS
   aa.src = src; aa.st = st; aa.B = B; aa.U = c.U; aa.T = c.T; aa.D = c.D; aa.C = c.C; aa.Ip = m->Ip;
   aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = fb.h0; aa.gate = fb.gate; aa.wgt = fb.wgt;
   aa.Tp_att = m->Tp;
+  aa.xcd_affine = env_int("GOCTR_XCD_AFFINE", 1);      // (ctr_kernels.h xcd_unit_of_block; a permutation of the workgroups' samples)
   return aa;
 }
 AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, int par) {

@@ -57,6 +57,7 @@ struct ChainX3Args {
   // follow (6.0 us at cfg3: 410 k row gathers behind a kernel boundary) becomes ~50 instructions per sample at the tail.
   const int32_t* ab_ids; const float* ab_emb; long long ab_V; const float* ab_gate; const float* ab_wgt; float* ab_out;
   int ab_T, ab_Tp;
+  int xcd_affine;     // training launches: workgroup -> tile by xcd_unit_of_block (GOCTR_XCD_AFFINE=0: workgroup b takes tile b)
 };
 
 constexpr int CX_NSTAMP = 16;
@@ -132,14 +133,14 @@ struct CxDrop {
 // 4 dl .. 4 dl + 3).  cx_ab_ids / cx_ab_gw: the slot ids / gates and similarity weights of its four samples, slot = lane;
 // cx_ab_gather_one: one pass (16 behaviour rows) of one sample, 16 bytes per lane in flight under the products that follow.
 template <class Args>
-__device__ __forceinline__ void cx_ab_ids(const Args& a, int w, int lane, int (&abid)[4]) {
+__device__ __forceinline__ void cx_ab_ids(const Args& a, int tile, int w, int lane, int (&abid)[4]) {
   const long long b0 = a.st->batch_idx * (long long)a.B;
   const int lc = lane < a.ab_T ? lane : a.ab_T - 1;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     // unconditional loads from clamped addresses, selects afterwards: a predicated load is a branch, and branches up here
     // split the scheduling region the first operand loads are issued from
-    const int b = blockIdx.x * 32 + 4 * w + s;
+    const int b = tile * 32 + 4 * w + s;
     const int bc = b < a.B ? b : a.B - 1;
     const long long gr = b0 + bc < a.rows ? b0 + bc : a.rows - 1;
     const int id = a.ab_ids[gr * a.ab_T + lc];
@@ -149,11 +150,11 @@ __device__ __forceinline__ void cx_ab_ids(const Args& a, int w, int lane, int (&
 }
 // (gates and similarity weights are only needed at the very end: requested late, 8 registers less through the products)
 template <class Args>
-__device__ __forceinline__ void cx_ab_gw(const Args& a, int w, int lane, float (&abg)[4], float (&abw)[4]) {
+__device__ __forceinline__ void cx_ab_gw(const Args& a, int tile, int w, int lane, float (&abg)[4], float (&abw)[4]) {
   const int lc = lane < a.ab_T ? lane : a.ab_T - 1;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int b = blockIdx.x * 32 + 4 * w + s;
+    const int b = tile * 32 + 4 * w + s;
     const int bc = b < a.B ? b : a.B - 1;
     const float g = a.ab_gate[(size_t)bc * a.ab_T + lc], wv = a.ab_wgt[(size_t)bc * a.ab_T + lc];
     const bool in = b < a.B && lane < a.ab_T;
@@ -193,8 +194,9 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   int n = lane & 31, h = lane >> 5;             // (not const: laundered per trip of the forward-only tile loop, see there)
   // FWD launches are persistent over row tiles (tile, tile + gridDim.x, ...: see the loop below); a training launch has one
   // tile per workgroup
-  int tile = blockIdx.x;
   const int ntiles = (a.B + 31) >> 5;
+  int tile = (!FWD && a.xcd_affine) ? xcd_unit_of_block((int)blockIdx.x, ntiles, 4) : (int)blockIdx.x;
+  const int tile_first = tile;
   int row = tile * 32 + n;
   bool vrow = row < a.B;
   int rowc = vrow ? row : a.B - 1;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   const bool ab = !FWD && din && a.ab_ids != nullptr;
   int abid[4] = {-1, -1, -1, -1}; float abg[4] = {0.f, 0.f, 0.f, 0.f}, abw[4] = {0.f, 0.f, 0.f, 0.f};
   float abx[4][4][4];
-  if (ab) cx_ab_ids(a, w, lane, abid);
+  if (ab) cx_ab_ids(a, tile, w, lane, abid);
   // layer-1 columns this wavefront finishes after the exchange: group (u = w / 4, g = w % 4) and, for wavefronts 0..3,
   // (u = 2, g = w):  f = 32 u + 8 g + 4 h + r
   const int fA = 32 * (w >> 2) + 8 * (w & 3) + 4 * h, fB = 64 + 8 * (w & 3) + 4 * h;
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     g0 = reinterpret_cast<const cx_u4*>(a.img0) + lane_v; g1 = reinterpret_cast<const cx_u4*>(a.img1) + lane_v;
     g2 = reinterpret_cast<const cx_u4*>(a.img2) + lane_v; g3 = reinterpret_cast<const cx_u4*>(a.img3) + lane_v;
   }
-  if (FWD && tile != (int)blockIdx.x) {     // (a later trip: the ring slots its predecessor could not spare registers for)
+  if (FWD && tile != tile_first) {     // (a later trip: the ring slots its predecessor could not spare registers for)
 #pragma unroll
     for (int c = CX_FWD_NFP; c < CX_PF0; ++c) load0(c, c);
   }
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   if (FWD) {
     if (writer) a.yhat[row] = yh;
     stamp(6);
-    if (a.dbg && blockIdx.x == 0 && lane == 0 && tile == (int)blockIdx.x) {
+    if (a.dbg && blockIdx.x == 0 && lane == 0 && tile == tile_first) {
 #pragma unroll
       for (int k = 0; k < CX_NSTAMP; ++k) a.dbg[w * CX_NSTAMP + k] = ts[k];
     }
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra2[c][p]);
     CX_MMA6(ahb, acb, af, bf);
   }
-  if (ab) cx_ab_gw(a, w, lane, abg, abw);
+  if (ab) cx_ab_gw(a, tile, w, lane, abg, abw);
   if (ab) {      // the behaviour rows of the remaining samples, in flight under the epilogue and the dp product
 #pragma unroll
     for (int k = 4 * CX_AB_EARLY; k < 16; ++k) cx_ab_gather_one(a, abid, lane, k >> 2, k & 3, abx);
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int b = blockIdx.x * 32 + 4 * w + s;
+      const int b = tile * 32 + 4 * w + s;
       if (b < a.B) {
         float* out = a.ab_out + (size_t)b * a.ab_Tp;
         if (lane < T) out[lane] = term[s] * (abg[s] * (1.0f - abg[s])) * abw[s];

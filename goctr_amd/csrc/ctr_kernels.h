@@ -103,7 +103,31 @@ struct AttnArgs {
   float* gate;  // [B, T]
   float* wgt;   // [B, T]
   int Tp_att;   // (reduce_attn_kernel) padded length of the att0 segment of the flat parameter buffer
+  int xcd_affine;   // training launches: workgroup -> four-sample group by xcd_unit_of_block (below)
 };
+
+// XCD affinity of batch rows (round 6, scripts/ubench/xcd_handoff.hip / profiles/r06_xcd_handoff.txt).  Workgroup b of a launch
+// runs on XCD b % 8 (observed on every box so far; HIP does not promise it, so nothing here depends on it for correctness), and
+// a tile that launch N wrote is read back by launch N + 1 in 0.4 of the time when the reader sits on the producer's XCD -- the
+// lines are still in that XCD's L2 (18 KB: 1 030 against 2 200 cycles; 32 KB: 1 360 against 3 410); across XCDs they come
+// from the Infinity Cache.  Every launch of the training step that produces or consumes BATCH ROWS therefore deals them by the
+// same rule: rows are cut into granules of 128 (four 32-row tiles = one dW0 slab = 32 four-sample attention groups), granule g
+// belongs to XCD g % 8.  unit = 32 (chain tiles per workgroup index) or 4-sample groups; `per` = units per granule.
+// Only when the unit count is a multiple of 8 * per (else identity): B = 8192 / 16384 are, the odd test shapes are not.
+__device__ __forceinline__ int xcd_unit_of_block(int b, int nunits, int per) {
+  if (nunits % (8 * per) != 0) return b;
+  const int x = b & 7, k = b >> 3;                 // the k-th workgroup of XCD x
+  return per * (x + 8 * (k / per)) + k % per;     // granule x + 8 (k / per), unit k % per of it
+}
+
+// the same for a launch whose first `first` workgroups do something else (reduce_attn_kernel, adam_attn_kernel): v = the
+// workgroup's index in the launch (XCD v % 8), the attention workgroups are v >= first
+__device__ __forceinline__ int xcd_unit_of_block_after(int v, int first, int nunits, int per) {
+  if (nunits % (8 * per) != 0) return v - first;
+  const int x = v & 7;
+  const int k = (v - (first + ((x - first) & 7))) >> 3;    // the k-th attention workgroup of XCD x
+  return per * (x + 8 * (k / per)) + k % per;
+}
 
 // DPP lane exchanges (VALU, no LDS crossbar): quad_perm / row_half_mirror / row_mirror / row_ror
 template <int CTRL>
@@ -424,7 +448,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
 
 template <int VEC, int LPR, int FAST>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-  attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x, a.st->batch_idx, a.att0);
+  const int grp = a.xcd_affine ? xcd_unit_of_block((int)blockIdx.x, (a.B + 3) >> 2, 32) : (int)blockIdx.x;
+  attn_fwd_body<VEC, LPR, FAST>(a, grp, a.st->batch_idx, a.att0);
 }
 // serving passes: the rows come from (user, item, timestamp) keys (RowSource key mode) -- key assembly and attention in one launch
 template <int LPR, int FAST>
@@ -906,7 +931,8 @@ __global__ __launch_bounds__(256) void reduce_attn_kernel(ReduceAdamArgs p, Attn
   long long nb = r.st->batch_idx + 1;                          // advance_state()'s cursor
   if (nb >= r.st->n_batches) nb = 0;
   const RaCtx ctx{p.ra_flag, r.st->gstep + 1u, a.att0};
-  attn_fwd_body<VEC, LPR, FAST>(a, (int)blockIdx.x - nred, nb, a.att0, FAST >= 2 ? &ctx : nullptr);
+  const int grp = a.xcd_affine ? xcd_unit_of_block_after((int)blockIdx.x, nred, (a.B + 3) >> 2, 32) : (int)blockIdx.x - nred;
+  attn_fwd_body<VEC, LPR, FAST>(a, grp, nb, a.att0, FAST >= 2 ? &ctx : nullptr);
 }
 
 // The data-parallel step's counterpart of reduce_attn_kernel: the step is [.. reduce] -> all-reduce -> [Adam], and what can share
@@ -952,7 +978,8 @@ __global__ __launch_bounds__(256) void adam_attn_kernel(AdamArgs ad, unsigned in
     return;
   }
   const RaCtx ctx{ra_flag, ad.st->gstep, a.att0};
-  attn_fwd_body<VEC, LPR, FAST>(a, bi - nadam, ad.st->batch_idx, a.att0, FAST >= 2 ? &ctx : nullptr);
+  const int grp = a.xcd_affine ? xcd_unit_of_block_after(bi, nadam, (a.B + 3) >> 2, 32) : bi - nadam;
+  attn_fwd_body<VEC, LPR, FAST>(a, grp, ad.st->batch_idx, a.att0, FAST >= 2 ? &ctx : nullptr);
 }
 
 // ---------------------------------------------------------------- standalone gather (bit-exact)
