@@ -59,7 +59,7 @@ SYMBOLS = [
     "goctr_dataset_create_dense", "goctr_dataset_create_ids", "goctr_dataset_destroy", "goctr_train_dataset",
     "goctr_train_steps", "goctr_predict_dataset", "goctr_predict_steps", "goctr_prof_enable", "goctr_prof_reset",
     "goctr_prof_get", "goctr_prof_name", "goctr_prof_kernel", "goctr_mlp_cfg_default", "goctr_mlp_create", "goctr_mlp_destroy",
-    "goctr_mlp_nparams", "goctr_mlp_set_params", "goctr_mlp_get_params", "goctr_mlp_loss_grad", "goctr_mlp_fit",
+    "goctr_mlp_nparams", "goctr_mlp_set_params", "goctr_mlp_get_params", "goctr_mlp_loss_grad", "goctr_mlp_fit", "goctr_mlp_fit_resident",
     "goctr_mlp_upload", "goctr_mlp_train_steps", "goctr_mlp_predict", "goctr_w2v_cfg_default", "goctr_w2v_create",
     "goctr_w2v_destroy", "goctr_w2v_set_param", "goctr_w2v_set_aux", "goctr_w2v_get_param", "goctr_w2v_get_aux",
     "goctr_w2v_get_paths", "goctr_huffman_build", "goctr_w2v_train", "goctr_w2v_upload_doc", "goctr_w2v_shard_cuts", "goctr_w2v_train_resident",

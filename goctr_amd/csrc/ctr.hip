@@ -1389,7 +1389,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   int S0 = S, S1 = S, SLx = SL;      // slabs per segment, for the reduce below
   if (multi && tw.ok) {
     TnMulti tm{};
-    tm.M = B; tm.np = 3;
+    tm.M = B; tm.np = 3; tm.wt = env_int("GOCTR_TN_WT", 2);
     const int b0 = tw.kblocks0 * 2 * tw.S0, b1 = 2 * tw.S1;
     tm.p[0] = {m->h0.p, m->Ip, m->Ip / 16, m->dz0.p, m->H1p, m->H1p / 16, m->slabs0.p,
                (unsigned long long)m->Ip * m->H1p, 0, m->H1p, 0, tw.rows0, tw.S0, 2, tw.nbt};

@@ -27,6 +27,7 @@ typedef __bf16 cx_bf8 __attribute__((ext_vector_type(8)));
 typedef float cx_acc __attribute__((ext_vector_type(16)));
 typedef float cx_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int cx_u4 __attribute__((ext_vector_type(4)));
+
 typedef unsigned int cx_u2 __attribute__((ext_vector_type(2)));
 
 // ---- image index functions (bf16 element units), shared by the builders and the tests of the layout

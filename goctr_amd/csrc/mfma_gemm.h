@@ -423,7 +423,9 @@ struct TnProblem {
   int nnb;     // (x3 wide blocks) n-blocks per k-block: the D tiles are split into nnb groups of nbt tiles; 0 = one group
   int nbt;
 };
-struct TnMulti { TnProblem p[4]; int np; int M; unsigned long long* dbg; };
+// wt (bf16-split bodies): slab stores go THROUGH the L2 (global_store ... sc1) instead of staying dirty in it until the launch
+// ends -- 1: the 16-byte stores of the transposed problems, 2: also the 4-byte stores of the untransposed ones
+struct TnMulti { TnProblem p[4]; int np; int M; unsigned long long* dbg; int wt; };
 
 // The multi-problem weight-gradient kernel.  Per workgroup: one problem, one block of KTW (3, or 1 for the
 // one-tile problems) 16-column tiles of A, ALL 16-column tiles of D split NTW = 4 per wavefront, one slab of
@@ -851,11 +853,18 @@ __device__ __forceinline__ void tn_multi_body_x3(const TnMulti& a, const TnProbl
       if (e < kb_t && f < ncnt) {
         const acc_t v = ac[e][f] + ah[e][f];
         if (P.transpose_out) {
-          *reinterpret_cast<acc_t*>(out + (o_t + (unsigned)(f * 16) * ldo + (unsigned)(e * 16))) = v;
+          const unsigned o = o_t + (unsigned)(f * 16) * ldo + (unsigned)(e * 16);
+          if (a.wt) asm volatile("global_store_dwordx4 %0, %1, %2 sc1" : : "v"(o * 4u), "v"(v), "s"(out) : "memory");
+          else *reinterpret_cast<acc_t*>(out + o) = v;
         } else {
           const unsigned o = o_n + (unsigned)(e * 16) * ldo + (unsigned)(f * 16);
+          if (a.wt >= 2) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) out[o + (unsigned)r * ldo] = v[r];
+            for (int r = 0; r < 4; ++r) asm volatile("global_store_dword %0, %1, %2 sc1" : : "v"((o + (unsigned)r * ldo) * 4u), "v"(v[r]), "s"(out) : "memory");
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[o + (unsigned)r * ldo] = v[r];
+          }
         }
       }
     }

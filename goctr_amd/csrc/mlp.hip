@@ -867,7 +867,7 @@ constexpr int TN64_CH = 32, TN64_CHS = TN64_CH + 2, TN64_NTW = 2;
 template <int TN64_KTW>
 __global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restrict__ A, int lda, int KT,
                                                           const double* __restrict__ Dm, int ldd, int NT, int M, int rows,
-                                                          double* __restrict__ slabs, size_t slab_stride) {
+                                                          double* __restrict__ slabs, size_t slab_stride, int wt) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef double d4 __attribute__((ext_vector_type(4)));
   constexpr int CH = TN64_CH, CHS = TN64_CHS, KTW = TN64_KTW, NTW = TN64_NTW;
@@ -992,8 +992,15 @@ __global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restri
     for (int f = 0; f < NTW; ++f)
       if (e < kb_t && f < ncnt) {
         const int n = (nt0 + f) * 16 + i;
+        // wt: the slabs go THROUGH the L2 (global_store_dwordx2 ... sc1) instead of staying dirty in it until the launch ends --
+        // what a launch leaves dirty is written back at its boundary, in front of the reduce launch that reads these very slabs
+        // (the CTR weight-gradient launch gained 1.5 us of a 47 us step that way, profiles/r06_write_through.txt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(size_t)((kb0 + e) * 16 + q + 4 * r) * ld_out + n] = acc[e][f][r];
+        for (int r = 0; r < 4; ++r) {
+          double* o = out + (size_t)((kb0 + e) * 16 + q + 4 * r) * ld_out + n;
+          if (wt) __hip_atomic_store(o, acc[e][f][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *o = acc[e][f][r];
+        }
       }
 }
 
@@ -1033,16 +1040,17 @@ int launch_nn64(const double* A, int lda, const double* Bm, int ldb, int M, int 
 int tn64_ktw() { return env_int_mlp("GOCTR_MLP_TN_KTW", 3) == 2 ? 2 : 3; }
 int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int NT, int M, int rows_per_wg,
                 double* slabs) {
-  if (NT <= 8 && env_int_mlp("GOCTR_MLP_OLD_TN", 0) == 0) {
+  if (NT <= 8) {
     const int Sn = (int)cdiv(M, rows_per_wg);
     const int ktw = tn64_ktw();
+    const int wt = env_int_mlp("GOCTR_MLP_TN_WT", 1);
     const size_t lds = sizeof(double) * 2 * TN64_CHS * (size_t)(ktw * 16 + NT * 16);
     if (ktw == 2)
       hipLaunchKernelGGL(mlp_tn64_kernel<2>, dim3(Sn, (unsigned)cdiv(KT, 2)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
-                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16);
+                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt);
     else
       hipLaunchKernelGGL(mlp_tn64_kernel<3>, dim3(Sn, (unsigned)cdiv(KT, 3)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
-                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16);
+                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt);
     GOCTR_HIP(hipGetLastError());
     return 0;
   }
@@ -1524,14 +1532,10 @@ int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows)
   return ensure_ws(p, p->cfg.batch);
 }
 
-int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
-  GOCTR_ENTER_H(p);
-  GOCTR_CHECK(p && p->rows > 0 && n_steps >= 0, "goctr_mlp_train_steps: upload rows first");
-  std::lock_guard<std::mutex> lk(p->mu);
-  const long long nb = p->rows / p->cfg.batch;
-  GOCTR_CHECK(nb > 0, "fewer rows than one batch");
-  if (retarget_mstate(p, first_batch % nb, nb)) return -1;
-  // every per-step scalar lives in the device MlpState, so one captured step replays for all of them
+// n whole-batch steps on the resident rows from the device step state: replayed from captured graphs of 8 / 2 / 1 steps (every
+// per-step scalar lives in the device MlpState, so one captured step replays for all of them), eagerly under the profiler,
+// on a communicator or with GOCTR_NO_GRAPH.  Asynchronous.  Caller holds p->mu.
+static int run_fused_steps(goctr_mlp* p, int n_steps) {
   Engine& e = engine();
   const bool use_graph = !e.prof && !e.comm_active() && env_int_mlp("GOCTR_NO_GRAPH", 0) == 0 && n_steps > 1;
   if (use_graph) {
@@ -1573,13 +1577,35 @@ int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
   return 0;
 }
 
+int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps) {
+  GOCTR_ENTER_H(p);
+  GOCTR_CHECK(p && p->rows > 0 && n_steps >= 0, "goctr_mlp_train_steps: upload rows first");
+  std::lock_guard<std::mutex> lk(p->mu);
+  const long long nb = p->rows / p->cfg.batch;
+  GOCTR_CHECK(nb > 0, "fewer rows than one batch");
+  if (retarget_mstate(p, first_batch % nb, nb)) return -1;
+  return run_fused_steps(p, n_steps);
+}
+
 int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, const int32_t* perm, double* loss_curve,
                   int* iters_run) {
-  GOCTR_ENTER_H(p);
-  GOCTR_CHECK(p && X && Y && rows > 0, "goctr_mlp_fit: bad arguments");
-  GOCTR_CHECK(rows >= p->cfg.batch, "goctr_mlp_fit: fewer rows (%lld) than one batch (%d) -- the reference clips BatchSize to the "
-              "sample count (basemlp64.go:517-520): create the handle with batch = rows", (long long)rows, p->cfg.batch);
+  {
+    GOCTR_ENTER_H(p);
+    GOCTR_CHECK(p && X && Y && rows > 0, "goctr_mlp_fit: bad arguments");
+    GOCTR_CHECK(rows >= p->cfg.batch, "goctr_mlp_fit: fewer rows (%lld) than one batch (%d) -- the reference clips BatchSize to the "
+                "sample count (basemlp64.go:517-520): create the handle with batch = rows", (long long)rows, p->cfg.batch);
+  }
   if (goctr_mlp_upload(p, X, Y, rows)) return -1;
+  return goctr_mlp_fit_resident(p, perm, loss_curve, iters_run);
+}
+
+// fitStochastic over the rows goctr_mlp_upload left in HBM (what goctr_mlp_fit runs after its upload; bench.py times this part:
+// the metric's inputs are resident when the timed region starts)
+int goctr_mlp_fit_resident(goctr_mlp* p, const int32_t* perm, double* loss_curve, int* iters_run) {
+  GOCTR_ENTER_H(p);
+  GOCTR_CHECK(p && p->rows > 0, "goctr_mlp_fit_resident: upload rows first");
+  const int64_t rows = p->rows;
+  GOCTR_CHECK(rows >= p->cfg.batch, "goctr_mlp_fit_resident: fewer rows (%lld) than one batch (%d)", (long long)rows, p->cfg.batch);
   std::lock_guard<std::mutex> lk(p->mu);
   // fitStochastic's batch loop (basemlp64.go:790-793): whole batches, then ONE short batch of rows % batch samples when the
   // sample count is not a multiple -- the reference's own flagship run has one (main.go:39-50: 79 948 rows at 200).  It is
@@ -1601,8 +1627,11 @@ int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, co
   for (it = 0; it < p->cfg.max_iter; ++it) {
     if (perm && p->perm.upload(reinterpret_cast<const int*>(perm) + (int64_t)it * rows, (size_t)rows)) return -1;
     if (set_mstate(p, s.t + (long long)it * nb, 0, nb, 0)) return -1;
-    for (long long b = 0; b < nfull; ++b)
-      if (train_step_resident(p, true, 0, tail && b == nfull - 1)) return -1;
+    // the whole batches replay from the captured step graphs (8 000 steps of three launches at the reference's own shape:
+    // launched one by one the host is the bottleneck); the step in front of a short batch runs on the per-layer kernels
+    const long long nfused = nfull - (tail ? 1 : 0);
+    if (nfused > 0 && run_fused_steps(p, (int)nfused)) return -1;
+    if (tail && train_step_resident(p, true, 0, true)) return -1;
     if (tail && train_step_resident(p, true, 0, true, tail)) return -1;
     GOCTR_HIP(hipStreamSynchronize(engine().stream));
     if (p->ring.download(bl.data(), (size_t)nb)) return -1;

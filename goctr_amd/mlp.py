@@ -138,12 +138,24 @@ class MLPClassifier:
         pp = np.ascontiguousarray(perm, np.int32) if perm is not None else None
         capi.check(capi.load().goctr_mlp_fit(self._h, capi.ptr(X, C.c_float), capi.ptr(Y, C.c_float), C.c_int64(rows),
                                              capi.ptr(pp, C.c_int32), capi.ptr(curve, C.c_double), C.byref(ran)))
-        self.NIter = ran.value
-        self.LossCurve = curve[:ran.value].tolist()
+        return self._fitted(curve, ran.value)
+
+    def _fitted(self, curve, ran):
+        self.NIter = ran
+        self.LossCurve = curve[:ran].tolist()
         if self.Verbose:
             for i, l in enumerate(self.LossCurve):
                 print("Iteration %d, loss = %.8f" % (i + 1, l))
         return self
+
+    def FitResident(self, perm=None):
+        """fitStochastic over the rows a previous upload() left in HBM (goctr_mlp_fit_resident: what Fit runs after its
+        upload).  perm: [MaxIter][rows] int32 row order per epoch, or None = the given order every epoch."""
+        curve = np.zeros(self.MaxIter, np.float64)
+        ran = C.c_int(0)
+        pp = np.ascontiguousarray(perm, np.int32) if perm is not None else None
+        capi.check(capi.load().goctr_mlp_fit_resident(self._h, capi.ptr(pp, C.c_int32), capi.ptr(curve, C.c_double), C.byref(ran)))
+        return self._fitted(curve, ran.value)
 
     def Predict(self, X):
         """predictProbas (basemlp64.go:897) for a binary classifier: probabilities, float32 like mlp.go:33-38"""

@@ -318,6 +318,9 @@ int goctr_mlp_loss_grad(goctr_mlp* p, const double* X, const double* Y, int n, d
  * sum(batch loss x batch rows) / rows (:806,:812).  loss_curve [max_iter]. */
 int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, const int32_t* perm,
                   double* loss_curve, int* iters_run);
+/* the same over the rows goctr_mlp_upload left in HBM (goctr_mlp_fit = goctr_mlp_upload + this): a host that keeps its
+ * TrainSample resident across several Fit calls, and the part bench.py times for BASELINE configs[0] */
+int goctr_mlp_fit_resident(goctr_mlp* p, const int32_t* perm, double* loss_curve, int* iters_run);
 /* exactly n_steps updates cycling over resident rows (async) -- bench unit */
 int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows);
 int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps);

@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
   hipMalloc(&d, (size_t)blocks * 65536 * 4); hipMalloc(&call, (size_t)iters * blocks * 8); hipMalloc(&bad, 4); hipMalloc(&sink, 4096);
   hipMemset(bad, 0, 4);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  printf("tile KB | shift | consumer wait (ticks @100 MHz: median over blocks and iterations, p90) | pair us (events) | stale words\n");
+  printf("tile KB | shift | consumer wait (s_memtime ticks: median over blocks and iterations, p90) | pair us (events) | stale words\n");
   for (int kb : {16, 32, 64}) {
     const int tile_f = kb * 256;
     for (int shift : {0, 8, 1, 3, 0, 1}) {

@@ -127,3 +127,61 @@ def test_bench_under_an_external_launcher_env(stub):
     assert outs[1][0].strip() == ""                        # only rank 0 prints
     d = json.loads(outs[0][0].strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["rccl_world"] == 2 and len(d["per_rank_ms_per_step"]) == 2
+
+
+def test_flop_constants_match_the_surveys_per_sample_figures():
+    """the numerators of every `roofline.frac` bench.py prints for the three dense models (the
+    sklearn-port MLP line priced three F x H GEMMs per step where the model has two -- no input gradient)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.mlp_flops_per_sample(281, 100) == 113_000                          # cfg2: fwd 56 400 + bwd 56 600
+    assert bench.ctr_flops_per_sample("youtube", 52, 50, 64, 53) == 282_880          # cfg4 MLP stage: fwd 125 360 + bwd 157 520
+    # cfg3 MLP stage 212 480 + what SURVEY books under the attention stage: att0's weight gradient (2 T) and the T x D dots of its backward
+    assert bench.ctr_flops_per_sample("din", 52, 50, 16, 53) == 212_480 + 2 * 50 + 2 * 50 * 16
+    # ... and the per-launch figures the DIN / YouTube lines divide by a launch's duration add up to exactly that per step
+    for kind, D, B in (("din", 16, 8192), ("youtube", 64, 16384)):
+        saved = dict(bench.CFG)
+        try:
+            bench.CFG.update(D=D, B=B, KIND=kind)
+            w = bench.kernel_work()
+            per_step = w["chain"][1] + w["dW0"][1]
+            assert per_step == pytest.approx(B * bench.ctr_flops_per_sample(kind, 52, 50, D, 53), rel=1e-12)
+        finally:
+            bench.CFG.clear(); bench.CFG.update(saved)
+
+
+def test_bench_strong_scaling_splits_baselines_global_batch(stub):
+    """--strong (the GLOBAL batch of 8192 is what shards): every rank steps 8192 / N rows"""
+    r = _run(stub, ["--strong", "--no-roofline"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 8
+    assert d["config"]["global_batch"] == 8192 and "1024 rows per GPU" in d["config"]["workload"]
+    assert d["value"] == pytest.approx(8192 / (d["ms_per_step"] * 1e-3), rel=0.02)
+    assert d["without_preload"] is None                   # N > 1 never pre-loads
+    r = _run(stub, ["--strong", "--no-roofline"], gpus=3)
+    assert r.returncode == 2 and "multiple of --gpus" in r.stderr
+
+
+def test_bench_n1_line_carries_the_figure_without_the_preload(stub):
+    """only N = 1 runs pre-load the GPU with a scratch model's training steps; the N = 1 line therefore also
+    carries the same measurement taken BEFORE that pre-load -- the protocol of every N > 1 line"""
+    r = _run(stub, ["--no-roofline"], {"GOCTR_BENCH_PRELOAD_STEPS": "40", "GOCTR_BENCH_PRED_BATCHES": "10"}, gpus=1)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][0])
+    wp = d["without_preload"]
+    assert d["n_gpus"] == 1 and d["preload"]["scratch_model_training_steps"] == 40
+    assert wp and len(wp["timed_regions_ms"]) == 9 and wp["ms_per_step"] > 0
+    assert wp["value"] == pytest.approx(8192 / (wp["ms_per_step"] * 1e-3), rel=0.02)
+
+
+def test_bench_mlp100k_line_shape(stub):
+    """BASELINE configs[0] has a workload of its own: 79 948 x 281 rows, batch 200, 20 epochs (the stub trains nothing)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(GOCTR_LIB=stub)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mlp100k", "--no-cpu-baseline", "--regions", "2"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["updates"] == 20 * 400 and d["steps"] == 20 and d["dtype"] == "f64" and "configs[0]" in d["config"]["workload"]
+    assert d["roofline"]["launch_floor"]["launches_per_update"] == 3 and d["reference_readme_s"] == 28.0
