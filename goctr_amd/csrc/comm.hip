@@ -358,7 +358,8 @@ bool comm_capturable() { return engine().comm_active() && engine().nccl_comm != 
 // rank that never arrives trips the barrier's timeout).  RCCL: ncclCommAbort is LOCAL -- it frees this rank; peers already
 // spinning inside a collective kernel only stop when THEY poll ncclCommGetAsyncError and abort, which comm_watch() below does
 // for a rank that waits on its stream; a peer blocked elsewhere is the launcher's job (goctr_amd/launch.py stops every rank
-// when one exits non-zero).  The communicator is unusable afterwards; goctr_comm_init / goctr_init_devices build a new one.
+// when one exits non-zero).  The communicator is unusable afterwards; goctr_comm_init builds a new one, and a repeated
+// goctr_init_devices notices the missing half (comm_group_live), drops the rest (comm_group_drop) and builds the group anew.
 void comm_abort_on_failure() {
   Engine& e = engine();
   if (e.loop) { e.loop->abort(); return; }
@@ -394,6 +395,32 @@ int comm_watch_stream(int timeout_override_s) {
       }
     }
   }
+}
+
+// What is left of a goctr_init_devices group's RCCL communicators after a rank aborted its own (comm_abort_on_failure is local):
+// the other ranks' halves are useless without it.  goctr_init_devices calls this before it builds the group anew.
+void comm_group_drop(int n) {
+  for (int k = 0; k < n; ++k) {
+    Engine* e = engine_at(k);
+    if (!e) continue;
+    if (e->nccl_comm) {
+      EngineScope on(e);
+      if (g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)e->nccl_comm);
+      else if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)e->nccl_comm);
+      e->nccl_comm = nullptr;
+    }
+    e->capture_state = 0; e->comm_enabled = false;
+  }
+}
+// is the group's communicator still there on every rank?  (n == 1 without GOCTR_FORCE_COMM has none by design)
+bool comm_group_live(int n) {
+  const char* force = getenv("GOCTR_FORCE_COMM");
+  if (n == 1 && !(force && *force && *force != '0')) return true;
+  for (int k = 0; k < n; ++k) {
+    Engine* e = engine_at(k);
+    if (!e || (!e->nccl_comm && !e->loop)) return false;
+  }
+  return true;
 }
 
 // The communicator of a goctr_init_devices group: RCCL when every engine has its own device (GOCTR_COMM=loopback forces the

@@ -189,6 +189,10 @@ struct goctr_model {
                    double beta1 = 0, beta2 = 0; /* (the bias corrections the last loss block left were made with these) */ } carry;
   bool attn_bwd_in_chain = false;  // launch_chain_x3 -> launch_backward: this step's chain launch wrote the att0 terms
   bool dpv_from_chain = false;    // the step's chain launch wrote dpv itself (launch_chain_x3): no dpv GEMM in this step
+  // round 6: the step's chain launch left dW2 / the att0 terms as per-tile sums (tile_dw2 / tile_att0; ctr_chain_x3.h): the
+  // weight-gradient launch only adds the tiles up (mfma_gemm.h tn_tile_sum_body) and A1, dz2, attp are not written at all
+  bool dw2_from_chain = false, att0_from_chain = false;
+  DevBuf<float> tile_dw2, tile_att0;
   DevBuf<unsigned int> emb_mark, emb_rank, emb_tiles;
   DevBuf<unsigned long long> emb_total;
   DevBuf<long long> emb_accum;
@@ -260,23 +264,27 @@ TnSchedule tn_schedule(const goctr_model* m, int B) {
 // time), so each problem gets its own slab height, in whole 32-row chunks: the pair (c0, c1) that minimises the longest
 // workgroup subject to one workgroup per CU.
 struct TnWide { bool ok; int ktw0, kblocks0, nbt; int rows0, S0, rows1, S1, rowsL, SL; };
-TnWide tn_schedule_wide_search(const goctr_model* m, int B);
+TnWide tn_schedule_wide_search(const goctr_model* m, int B, int nsum);
 // the search is O((B/32)^2) (65 k iterations at B = 8192): graph replay hides it, the eager paths (data-parallel embedding
 // training, profiling, GOCTR_NO_GRAPH) would pay it on every step -- cached per shape and experiment-knob setting
-TnWide tn_schedule_wide(const goctr_model* m, int B) {
+// slabs of a "sum problem" of the weight-gradient launch (the chain launch left per-tile sums: tn_tile_sum_body): 8, one per
+// thread of the reduce launch's 8-thread groups
+constexpr int TN_SUM_SLABS = 8;
+// nsum: how many of the light problems (dW2, att0) are sums over the chain launch's per-tile results this step
+TnWide tn_schedule_wide(const goctr_model* m, int B, int nsum = 0) {
   static std::mutex mu;
-  static std::map<std::array<int, 12>, TnWide> cache;
-  const std::array<int, 12> key{B, m->Ip, m->H1p, m->H2p, m->cfg.kind, engine().compute_units, env_int("GOCTR_TN_WIDE", 1),
+  static std::map<std::array<int, 13>, TnWide> cache;
+  const std::array<int, 13> key{B, m->Ip, m->H1p, m->H2p, m->cfg.kind, engine().compute_units, env_int("GOCTR_TN_WIDE", 1),
                                 env_int("GOCTR_TN_FIX0", 512), env_int("GOCTR_TN_FIX1", 384), env_int("GOCTR_TN_C0", 0),
-                                env_int("GOCTR_TN_C1", 0), env_int("GOCTR_TN_RL", 0)};
+                                env_int("GOCTR_TN_C1", 0), env_int("GOCTR_TN_RL", 0), nsum};
   std::lock_guard<std::mutex> lk(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
-  const TnWide w = tn_schedule_wide_search(m, B);
+  const TnWide w = tn_schedule_wide_search(m, B, nsum);
   cache.emplace(key, w);
   return w;
 }
-TnWide tn_schedule_wide_search(const goctr_model* m, int B) {
+TnWide tn_schedule_wide_search(const goctr_model* m, int B, int nsum) {
   TnWide w{};
   const int kt0 = m->Ip / 16, nt = m->H1p / 16, kt1 = m->H2p / 16;
   w.ok = (kt0 == 9 || kt0 == 15) && kt1 == 5 && nt > 8 && nt <= 16 && env_int("GOCTR_TN_WIDE", 1) != 0;
@@ -296,10 +304,13 @@ TnWide tn_schedule_wide_search(const goctr_model* m, int B) {
       if (best >= 0 && t >= best) continue;
       // the one-tile problems take what is left of the chip; their slab height follows
       const long heavy = (long)blocks0 * cdiv(B, c0 * 32) + (long)blocks1 * cdiv(B, c1 * 32);
-      const long left = (cus - heavy) / light;
-      if (left < 1) continue;
+      // (nsum of the light problems are sums over the chain launch's per-tile results: TN_SUM_SLABS small workgroups each)
+      const int mlight = light - nsum;
+      const long room = cus - heavy - (long)nsum * TN_SUM_SLABS;
+      const long left = mlight > 0 ? room / mlight : 1;
+      if (room < 0 || left < 1) continue;
       const int rl = std::max(32, round_up((int)cdiv(B, left), 4));     // (the slab buffers hold ceil(B / 32) slabs)
-      t = std::max(t, (long)cdiv(rl, 32) * colsL + fixL);
+      if (mlight > 0) t = std::max(t, (long)cdiv(rl, 32) * colsL + fixL);   // (a sum workgroup is a few hundred loads: never the longest)
       if (best >= 0 && t >= best) continue;
       best = t; bc0 = c0; bc1 = c1; brl = rl;
     }
@@ -313,6 +324,15 @@ TnWide tn_schedule_wide_search(const goctr_model* m, int B) {
   return w;
 }
 int tn_max_slabs(int B) { return (int)cdiv(B, 32); }
+// does launch_backward take the wide bf16-split weight-gradient launch for this model and batch?  (launch_chain_x3 asks: only
+// that launch knows how to add up per-tile sums)
+bool dw_wide_path(const goctr_model* m, int B) {
+  int nt_max = m->H1p / 16;
+  if (m->H2p / 16 > nt_max) nt_max = m->H2p / 16;
+  if (m->cfg.kind == GOCTR_DIN && m->Tp / 16 > nt_max) nt_max = m->Tp / 16;
+  const bool multi = nt_max <= 16 && gemm_tn_multi_fits<3, GOCTR_TN_CH>(nt_max) && env_int("GOCTR_NO_TNMULTI", 0) == 0;
+  return multi && env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32 && tn_schedule_wide(m, B).ok;
+}
 
 int ensure_workspace(goctr_model* m, int B) {
   if (m->wsB >= B && m->tnS > 0) return 0;
@@ -341,6 +361,7 @@ int ensure_workspace(goctr_model* m, int B) {
   m->attp_blocks = (int)cdiv(B, ATTN_BWD_WAVES);
   if (m->attp.alloc((size_t)B * m->Tp)) return -1;               // dgs [B, Tp]
   if (m->slabs3.alloc((size_t)S * 16 * m->Tp)) return -1;        // att0 gradient slabs (row 0 of 16)
+  if (m->tile_dw2.alloc((size_t)S * m->H2p) || m->tile_att0.alloc((size_t)S * m->Tp)) return -1;   // (S = ceil(B / 32) tiles)
   {
     std::vector<float> ones((size_t)B * 16, 0.f);
     for (int r = 0; r < B; ++r) ones[(size_t)r * 16] = 1.0f;
@@ -661,6 +682,13 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   }
   a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
   a.xcd_affine = o.train ? env_int("GOCTR_XCD_AFFINE", 1) : 0;
+  // per-tile sums of dW2 and of the att0 terms instead of their operands -- where the wide weight-gradient launch follows (it
+  // adds the tiles up; GOCTR_CHAIN_TILE_SUMS=0: the operands are stored and multiplied there, as until round 5)
+  const bool tile_sums = o.train && dw_wide_path(m, B) && env_int("GOCTR_CHAIN_TILE_SUMS", 1) != 0;
+  m->dw2_from_chain = tile_sums;
+  m->att0_from_chain = tile_sums && m->attn_bwd_in_chain;
+  a.tile_dw2 = m->dw2_from_chain ? m->tile_dw2.p : nullptr;
+  a.tile_att0 = m->att0_from_chain ? m->tile_att0.p : nullptr;
   static DevBuf<unsigned long long> dbgbuf;
   const bool dbg = env_int("GOCTR_CHAIN_DBG", 0) != 0 && (hipStream_t)e.active == e.stream;   // (not from a serving slot)
   if (dbg && !dbgbuf.p && dbgbuf.alloc(8 * CX_NSTAMP)) return -1;
@@ -866,7 +894,7 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
     if (!o.train) { aa.gate = nullptr; aa.wgt = nullptr; }     // (only the backward reads them: 13 MB less per 32 768-row launch)
     if (launch_attn_fwd(aa)) return -1;
   }
-  if (o.train) { m->dpv_from_chain = false; m->attn_bwd_in_chain = false; }   // (launch_chain_x3 sets them when it does the work itself)
+  if (o.train) { m->dpv_from_chain = false; m->attn_bwd_in_chain = false; m->dw2_from_chain = false; m->att0_from_chain = false; }   // (launch_chain_x3 sets them when it does the work itself)
   if (chain_ok(m)) return launch_chain(m, src, B, o, st, fb);  // layers + (when training) backward-data, fused
 
   const int bglobal = B * e.eff_world();
@@ -1385,8 +1413,10 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   if (m->H2p / 16 > nt_max) nt_max = m->H2p / 16;
   if (c.kind == GOCTR_DIN && m->Tp / 16 > nt_max) nt_max = m->Tp / 16;
   const bool multi = nt_max <= 16 && gemm_tn_multi_fits<3, GOCTR_TN_CH>(nt_max) && env_int("GOCTR_NO_TNMULTI", 0) == 0;
-  const TnWide tw = (multi && env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32) ? tn_schedule_wide(m, B) : TnWide{};
+  const TnWide tw = (multi && env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32)
+                        ? tn_schedule_wide(m, B, (m->dw2_from_chain ? 1 : 0) + (m->att0_from_chain ? 1 : 0)) : TnWide{};
   int S0 = S, S1 = S, SLx = SL;      // slabs per segment, for the reduce below
+  int SL2x = -1, SL3x = -1;          // (wide launch: the dW2 / att0 segments' own slab counts)
   if (multi && tw.ok) {
     TnMulti tm{};
     tm.M = B; tm.np = 3; tm.wt = env_int("GOCTR_TN_WT", 2);
@@ -1395,14 +1425,29 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
                (unsigned long long)m->Ip * m->H1p, 0, m->H1p, 0, tw.rows0, tw.S0, 2, tw.nbt};
     tm.p[1] = {m->dz1.p, m->H2p, m->H2p / 16, A0, m->H1p, m->H1p / 16, m->slabs1.p,
                (unsigned long long)m->H1p * m->H2p, 1, m->H2p, b0, tw.rows1, tw.S1, 2, tw.nbt};
-    tm.p[2] = {m->dz2.p, 16, 1, A1, m->H2p, m->H2p / 16, m->slabs2.p, (unsigned long long)m->H2p * 16, 1, 16,
-               b0 + b1, tw.rowsL, tw.SL, 0, 0};
-    int nblk = b0 + b1 + tw.SL;
+    // (round 6) where the chain launch left per-tile sums the problem is a SUM problem: KT = 0, D = the partials [tiles][lda],
+    // `rows` = tiles per slab, TN_SUM_SLABS slabs
+    const int ntiles = (int)cdiv(B, 32);
+    const int nsum = std::min(TN_SUM_SLABS, ntiles), tps = (int)cdiv(ntiles, nsum);
+    int SL2 = tw.SL, SL3 = tw.SL;
+    if (m->dw2_from_chain) {
+      SL2 = (int)cdiv(ntiles, tps);
+      tm.p[2] = {nullptr, m->H2p, 0, m->tile_dw2.p, m->H2p, 0, m->slabs2.p, (unsigned long long)m->H2p * 16, 1, 16, b0 + b1, tps, SL2, 0, 0};
+    } else {
+      tm.p[2] = {m->dz2.p, 16, 1, A1, m->H2p, m->H2p / 16, m->slabs2.p, (unsigned long long)m->H2p * 16, 1, 16,
+                 b0 + b1, tw.rowsL, tw.SL, 0, 0};
+    }
+    int nblk = b0 + b1 + SL2;
     if (c.kind == GOCTR_DIN) {  // datt0 = ones^T . dgs  (column sums over the batch)
-      tm.p[3] = {m->ones16.p, 16, 1, m->attp.p, m->Tp, m->Tp / 16, m->slabs3.p, (unsigned long long)16 * m->Tp, 0, m->Tp,
-                 nblk, tw.rowsL, tw.SL, 0, 0};
+      if (m->att0_from_chain) {
+        SL3 = (int)cdiv(ntiles, tps);
+        tm.p[3] = {nullptr, m->Tp, 0, m->tile_att0.p, m->Tp, 0, m->slabs3.p, (unsigned long long)16 * m->Tp, 0, m->Tp, nblk, tps, SL3, 0, 0};
+      } else {
+        tm.p[3] = {m->ones16.p, 16, 1, m->attp.p, m->Tp, m->Tp / 16, m->slabs3.p, (unsigned long long)16 * m->Tp, 0, m->Tp,
+                   nblk, tw.rowsL, tw.SL, 0, 0};
+      }
       tm.np = 4;
-      nblk += tw.SL;
+      nblk += SL3;
     }
     static DevBuf<unsigned long long> tndbgw;
     const bool dbg = env_int("GOCTR_TN_DBG", 0) != 0;
@@ -1425,7 +1470,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
               tw.rows0, tw.rows1, tw.rowsL, nblk, (long long)h[0], (long long)h[1], (long long)h[2], (long long)h[3], (long long)h[8],
               (long long)h[9], (long long)h[10], (long long)h[11]);
     }
-    S0 = tw.S0; S1 = tw.S1; SLx = tw.SL;
+    S0 = tw.S0; S1 = tw.S1; SLx = tw.SL; SL2x = SL2; SL3x = SL3;
   } else if (multi) {
     TnMulti tm{};
     tm.M = B; tm.np = 3;
@@ -1488,10 +1533,10 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   ReduceArgs ra{};
   ra.seg[0] = {m->slabs0.p, S0, (unsigned long long)m->Ip * m->H1p, 0, m->Ip * m->H1p};
   ra.seg[1] = {m->slabs1.p, S1, (unsigned long long)m->H1p * m->H2p, m->off1, m->H1p * m->H2p};
-  ra.seg[2] = {m->slabs2.p, multi ? SLx : S, (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
+  ra.seg[2] = {m->slabs2.p, SL2x > 0 ? SL2x : (multi ? SLx : S), (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
   ra.nseg = 3;
   if (c.kind == GOCTR_DIN) {
-    ra.seg[3] = {m->slabs3.p, multi ? SLx : S, (unsigned long long)16 * m->Tp, m->offa, m->Tp};
+    ra.seg[3] = {m->slabs3.p, SL3x > 0 ? SL3x : (multi ? SLx : S), (unsigned long long)16 * m->Tp, m->offa, m->Tp};
     ra.nseg = 4;
   }
   ra.nflat = m->nflat; ra.lossrow = m->lossrow.p; ra.B = B; ra.G = m->G.p; ra.st = m->st_cur(); ra.st_out = m->st_next(); ra.advance = advance ? 1 : 0;

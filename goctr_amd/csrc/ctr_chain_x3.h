@@ -57,6 +57,11 @@ struct ChainX3Args {
   // follow (6.0 us at cfg3: 410 k row gathers behind a kernel boundary) becomes ~50 instructions per sample at the tail.
   const int32_t* ab_ids; const float* ab_emb; long long ab_V; const float* ab_gate; const float* ab_wgt; float* ab_out;
   int ab_T, ab_Tp;
+  // Round 6: gradients whose operands this launch holds in registers leave as PER-TILE sums instead (null: the operands are
+  // stored and the weight-gradient launch multiplies them): tile_dw2 [tiles][H2p] = sum over the tile's rows of A1[row][f] *
+  // dz2[row] (then A1 and dz2 are not stored at all), tile_att0 [tiles][ab_Tp] = the tile's sum of the att0 terms (then ab_out is
+  // not stored).  The weight-gradient launch adds the tiles up (mfma_gemm.h tn_tile_sum_body).
+  float* tile_dw2; float* tile_att0;
   int xcd_affine;     // training launches: workgroup -> tile by xcd_unit_of_block (GOCTR_XCD_AFFINE=0: workgroup b takes tile b)
 };
 
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
       w2v[k][r] = wv[r];
       part += a1v[r] * wv[r];
     }
-    if (!FWD && vrow && act) *reinterpret_cast<cx_f4*>(a.A1 + (size_t)row * H2p + f0) = cx_f4{a1v[0], a1v[1], a1v[2], a1v[3]};
+    if (!FWD && vrow && act && !a.tile_dw2) *reinterpret_cast<cx_f4*>(a.A1 + (size_t)row * H2p + f0) = cx_f4{a1v[0], a1v[1], a1v[2], a1v[3]};
   }
   // ---------------------------------------------------------------- output unit: z2 = sum over the 8 x 2 partials
   part += __shfl_xor(part, 32, 64);
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   if (writer) {
     a.yhat[row] = yh;
     a.lossrow[row] = logf(yh) * y + logf(one_eps - yh) * (1.0f - y);
-    a.dz2[(size_t)row * 16] = d2;
+    if (!a.tile_dw2) a.dz2[(size_t)row * 16] = d2;
   }
   // dz1 of the own features: HBM (for dW1 / dW2) and, as bf16 planes, the B-fragment image of the next product
 #pragma unroll
@@ -510,6 +515,14 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     for (int r = 0; r < 4; ++r) {
       const float s = s1[k][r];
       dz[r] = ((d2 * w2v[k][r]) * dr1.factor(k * 4 + r)) * (s * (1.0f - s));
+    }
+    if (a.tile_dw2 && (k == 0 || hasB)) {      // (wave-uniform)
+      // dW2[f] of this tile: sum over its 32 rows (the lanes of this half) of A1[row][f] * dz2[row]; fixed lane order
+      const float dv = vrow ? d2 : 0.f;
+      cx_f4 pw;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[r] = group_sum<32>((s1[k][r] * dr1.factor(k * 4 + r)) * dv);
+      if (n == 0 && act) *reinterpret_cast<cx_f4*>(a.tile_dw2 + (size_t)tile * H2p + f0) = pw;
     }
     if (act) {
       if (vrow) *reinterpret_cast<cx_f4*>(a.dz1 + (size_t)row * H2p + f0) = cx_f4{dz[0], dz[1], dz[2], dz[3]};
@@ -635,6 +648,23 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
         if (pw == p) term[s] = dgs;
       }
     }
+    if (a.tile_att0) {
+      // the tile's att0 terms summed here: this wavefront's four samples in order, then the eight wavefronts in order
+      float tsum = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int b = tile * 32 + 4 * w + s;
+        tsum += (b < a.B && lane < T) ? term[s] * (abg[s] * (1.0f - abg[s])) * abw[s] : 0.f;
+      }
+      xch[w * 64 + lane] = tsum;                              // (the exchange area is free since barrier 6)
+      __syncthreads();                                        // (7)
+      if (w == 0 && lane < a.ab_Tp) {
+        float sacc = xch[lane];
+#pragma unroll
+        for (int ws = 1; ws < 8; ++ws) sacc += xch[ws * 64 + lane];
+        a.tile_att0[(size_t)tile * a.ab_Tp + lane] = sacc;
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int b = tile * 32 + 4 * w + s;
@@ -643,6 +673,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
         if (lane < T) out[lane] = term[s] * (abg[s] * (1.0f - abg[s])) * abw[s];
         for (int t = T + lane; t < a.ab_Tp; t += 64) out[t] = 0.f;
       }
+    }
     }
   }
   stamp(9);

@@ -318,6 +318,8 @@ void* bar_alloc(size_t bytes) {
 
 // comm.hip: builds the communicator of a goctr_init_devices group (RCCL over the distinct devices, else loop-back)
 int comm_group_init(int n);
+void comm_group_drop(int n);
+bool comm_group_live(int n);
 
 }  // namespace goctr
 
@@ -359,9 +361,13 @@ int goctr_init_devices(int n, const int* device_ids) {
     bool same = existing == n;
     for (int k = 0; same && k < n; ++k) same = engine_at(k)->inited && engine_at(k)->device == device_ids[k];
     GOCTR_CHECK(same, "goctr_init_devices: the process already runs %d engine(s); the device list cannot change", existing);
-    if (group_ready) return 0;
-    // an earlier call bound the engines and then failed to build the communicator (RCCL would not load, peer access refused):
-    // try again instead of reporting success without one
+    // ready = built once AND still there on every rank (a rank that aborted its communicator -- a timeout, a failed
+    // captured-collective self-test -- left the static flag set, and the next training call failed with "restart the process")
+    if (group_ready && comm_group_live(n)) return 0;
+    // an earlier call bound the engines and then failed to build the communicator (RCCL would not load, peer access refused),
+    // or the group lost a rank's half since: drop what is left and try again instead of reporting success without one
+    group_ready = false;
+    comm_group_drop(n);
     if (comm_group_init(n)) return -1;
     group_ready = true;
     return 0;

@@ -887,6 +887,37 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_x3_kernel(TnMulti a) {
   else tn_multi_body_x3<KTW, NTW>(a, P, kb, 0, P.NT, split, goctr_smem);
 }
 
+// Round 6: "sum problems" (TnProblem::KT == 0).  Where the chain launch has already summed a gradient over the 32 rows of each of
+// its tiles (ctr_chain_x3.h: dW2 = A1^T dz2 and the att0 terms -- their operands A1, dz2 and the per-sample terms then never
+// leave the chip, 5.2 MB less written by the chain launch and read by this one at cfg3), what is left is a sum over the TILES:
+// D = the partials [tiles][lda], workgroup `split` adds tiles [split * rows, (split + 1) * rows) in ascending order (16 loads in
+// flight) and writes slab `split` in the layout the MFMA problem wrote: transposed (dW2): out[idx * ld_out + 0] with the other
+// ld_out - 1 entries of the row zero; untransposed (att0): out[idx] (row 0 of the slab, the only one the reduce reads).
+__device__ __forceinline__ void tn_tile_sum_body(const TnMulti& a, const TnProblem& P, int split) {
+  const int ntiles = (a.M + 31) >> 5;
+  const int t0 = split * P.rows;
+  int t1 = t0 + P.rows; if (t1 > ntiles) t1 = ntiles;
+  float* out = P.slabs + (size_t)split * P.slab_stride;
+  for (int idx = threadIdx.x; idx < P.lda; idx += blockDim.x) {
+    float s = 0.f;
+    for (int tb = t0; tb < t1; tb += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int t = tb + u < t1 ? tb + u : t1 - 1; v[u] = P.D[(size_t)t * P.ldd + idx]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += tb + u < t1 ? v[u] : 0.f;
+    }
+    if (P.transpose_out) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      float* o = out + (size_t)idx * P.ld_out;
+      *reinterpret_cast<f4*>(o) = f4{s, 0.f, 0.f, 0.f};
+      for (int k = 4; k < P.ld_out; k += 4) *reinterpret_cast<f4*>(o + k) = f4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      out[idx] = s;
+    }
+  }
+}
+
 // Round 2: wide blocks.  Problem 0 (dW0) takes ALL its A tiles (KTW0 = 9 DIN / 8 per k-block YouTube) and problem 1 (dW1,
 // posed transposed) all its KTW1 = 5 against HALF of the D tiles (two n-blocks of <= 8 tiles, 2 per multiplying wavefront):
 // per slab the workgroups stage 496 + 368 operand columns instead of 768 + 496 (every D column was staged once per
@@ -901,6 +932,7 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_x3w_kernel(TnMulti a) {
   const TnProblem& P = a.p[pi];
   const int local = blockIdx.x - P.first;
   const int blk = local / P.S, split = local - blk * P.S;
+  if (P.KT == 0) { tn_tile_sum_body(a, P, local); return; }
   if (P.KT == 1) { tn_multi_body_x3<1, 4>(a, P, blk, 0, P.NT, split, goctr_smem); return; }
   const int nnb = P.nnb > 0 ? P.nnb : 1;
   const int kb = blk / nnb, nb = blk - kb * nnb;

@@ -458,9 +458,9 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__
 template <int D>
 __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short* __restrict__ items_bf, long long plane_elems,
                                                             const unsigned short* __restrict__ q_bf /* [2][padded Q][D] */, long long qplane,
-                                                            int Q, int nt, float* __restrict__ tmax, float* __restrict__ bmax, int qpad, int wt) {
-  // wt: the maxima go THROUGH the L2 (global_store ... sc1): the 8 MB this launch would otherwise leave dirty are written back at
-  // its boundary, in front of the collect launch that reads them (and again by that launch's system-scope fence when it is polled)
+                                                            int Q, int nt, float* __restrict__ tmax, float* __restrict__ bmax, int qpad) {
+  // (round 6 measured these maxima stored THROUGH the L2 -- sc1, as the weight-gradient slabs are now: no effect on the call,
+  // 9.80 vs 9.85 ms per 200 calls; profiles/r06_write_through.txt)
   typedef float v16 __attribute__((ext_vector_type(16)));
   typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -504,11 +504,7 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
       for (int r = 0; r < 16; ++r) m = __builtin_fmaxf(m, c[r]);         // (a NaN score -- an item with an infinite norm -- is dropped)
       // this 32-item block's maximum per query (both row halves): bmax [tile][32 blocks][queries]
       m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
-      if (kg == 0) {
-        float* o = bmax + ((size_t)tile * 32 + wave * 8 + t) * qpad + q0 + h * 32 + col;
-        if (wt) __hip_atomic_store(o, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *o = m;
-      }
+      if (kg == 0) bmax[((size_t)tile * 32 + wave * 8 + t) * qpad + q0 + h * 32 + col] = m;
       mx[h] = __builtin_fmaxf(mx[h], m);
     }
   }
@@ -521,9 +517,7 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
   __syncthreads();
   if (threadIdx.x < KNN2_QB && q0 + (int)threadIdx.x < Q) {
     const float m = __builtin_fmaxf(__builtin_fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), __builtin_fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
-    float* o = tmax + (size_t)(q0 + threadIdx.x) * nt + tile;
-    if (wt) __hip_atomic_store(o, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *o = m;
+    tmax[(size_t)(q0 + threadIdx.x) * nt + tile] = m;
   }
 }
 
@@ -886,8 +880,6 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   // queries/s --, is even at 96 and costs 3 us at 128; with the staged copy it lost 9 us at 64)
   // Without the BAR input (GOCTR_KNN_BAR=0, or no large BAR) the same polling lost 9 us at 64 queries: the default follows `bar`.
   const bool poll = Q <= (pv ? atoi(pv) : (bar ? 64 : 32));
-  const char* wv = getenv("GOCTR_KNN_WT");
-  const int scan_wt = wv ? atoi(wv) : 1;
   if (poll) {                                        // (the previous call returned after its kernels' last stores: nothing else writes here)
     int* h_pend = reinterpret_cast<int*>(static_cast<char*>(s->h_out) + o_idx + o_sim);
     for (int i = 0; i < Q; ++i) __atomic_store_n(h_pend + i, KNN_PENDING, __ATOMIC_RELEASE);
@@ -911,8 +903,8 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   if (bf) {
     const unsigned short* d_qbf = reinterpret_cast<const unsigned short*>(d_in + in_q + in_ig + in_q32);
     const long long qplane = (long long)nqb * KNN2_QB * D, iplane = (long long)(s->items_bf.n / 2);
-    if (D == 16) hipLaunchKernelGGL(knn_scan_bf16_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->bmax.p, qpad, scan_wt);
-    else hipLaunchKernelGGL(knn_scan_bf16_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->bmax.p, qpad, scan_wt);
+    if (D == 16) hipLaunchKernelGGL(knn_scan_bf16_kernel<16>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->bmax.p, qpad);
+    else hipLaunchKernelGGL(knn_scan_bf16_kernel<32>, dim3(nt, nqb), dim3(256), 0, e.stream, s->items_bf.p, iplane, d_qbf, qplane, Q, nt, s->tmax.p, s->bmax.p, qpad);
   } else if (D == 16) GOCTR_KNN_SCAN(16, 4);
   else if (D == 32) GOCTR_KNN_SCAN(32, 4);
   else GOCTR_KNN_SCAN(64, 2);
@@ -974,12 +966,29 @@ int goctr_searcher_create(const double* items, int64_t V, int D, goctr_searcher*
 
 void goctr_searcher_destroy(goctr_searcher* s) { delete s; }
 
+// queries per device pass: the scratch of a pass grows with Q (sub-block maxima V x Q / 8 bytes, the tile kernels' candidate
+// lists Q x tiles x k) -- V = 16 M with 4096 queries in one pass would need 8 GB that is never shrunk; a call with more
+// queries is served in passes of this many (the queries are independent: same answers)
+constexpr int KNN_PASS_MAXQ = 1024;
+static int searcher_search_pass(goctr_searcher* s, const double* queries, int Q, int k, const int64_t* ignore, int64_t* out_idx,
+                                double* out_sim, int* out_count);
+
 int goctr_searcher_search(goctr_searcher* s, const double* queries, int Q, int k, const int64_t* ignore, int64_t* out_idx,
                           double* out_sim, int* out_count) {
   GOCTR_ENTER_H(s);
   GOCTR_CHECK(s && queries && out_idx && out_sim && out_count, "goctr_searcher_search: null argument");
   GOCTR_CHECK(Q > 0 && k > 0 && k <= KNN_MAX_K, "goctr_searcher_search: Q %d, k %d (k <= %d)", Q, k, KNN_MAX_K);
   std::lock_guard<std::mutex> lk(s->mu);
+  for (int q0 = 0; q0 < Q; q0 += KNN_PASS_MAXQ) {
+    const int n = Q - q0 < KNN_PASS_MAXQ ? Q - q0 : KNN_PASS_MAXQ;
+    if (searcher_search_pass(s, queries + (size_t)q0 * s->D, n, k, ignore ? ignore + q0 : nullptr, out_idx + (size_t)q0 * k,
+                             out_sim + (size_t)q0 * k, out_count + q0)) return -1;
+  }
+  return 0;
+}
+
+static int searcher_search_pass(goctr_searcher* s, const double* queries, int Q, int k, const int64_t* ignore, int64_t* out_idx,
+                                double* out_sim, int* out_count) {
   Engine& e = engine();
   if (knn_scan_usable(s, k)) {
     const int rc = knn_search_scan(s, queries, Q, k, ignore, out_idx, out_sim, out_count);

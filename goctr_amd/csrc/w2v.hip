@@ -946,7 +946,12 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
   const bool dp = e.comm_active();
   int nseg = 1;
   if (dp && !w->cfg.deterministic) {
-    const long long every = w->cfg.exchange_every == 0 ? w->cfg.update_lr_batch : w->cfg.exchange_every;
+    // default interval: the observer's batch, but never so short that an exchange (a copy and an all-reduce of BOTH matrices and
+    // their touched flags) moves more than ~1 KB per trained word -- V = 10^6 at D = 64 is 1 GB per exchange: every 10^5 words
+    // would be all exchange; cfg5's 2.7 MB keep the 10^5
+    const long long mat_bytes = ((long long)w->V + w->aux_rows) * w->cfg.dim * (long long)sizeof(double);
+    const long long dflt = std::max<long long>(w->cfg.update_lr_batch, mat_bytes / 1024);
+    const long long every = w->cfg.exchange_every == 0 ? dflt : w->cfg.exchange_every;
     if (every > 0) nseg = (int)std::min<long long>(4096, std::max<long long>(1, cdiv(cdiv(corpus_len, e.eff_world()), every)));
     nseg = std::max(1, env_int_w2v("GOCTR_W2V_SEGMENTS", nseg));
   }
@@ -1060,7 +1065,10 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     if (dp) {
       // the observer's estimate counts the other ranks' words too (a rank that counted only its own shard let the rate
       // decay world times too slowly), and the ranks' streams draw their window shrinks from different seeds
-      a.est_scale = e.eff_world(); a.seed_base = (long long)e.rank * streams;
+      // (seed ranges: a FIXED stride per rank -- shards of unequal length give the ranks different stream counts, and rank x
+      // streams would overlap, ADVICE r5.  The estimate stays this rank's words x world: the shards end at the reference's slice
+      // boundaries, a few words apart)
+      a.est_scale = e.eff_world(); a.seed_base = (long long)e.rank << 20;
     }
     a.nseg = nseg;
     for (int seg = 0; seg < nseg; ++seg) {

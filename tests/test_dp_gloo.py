@@ -417,3 +417,107 @@ def test_embedding_sparse_exchange_bucketed(oracle, world, fixed):
     untouched = np.setdiff1d(np.arange(V), touched)
     assert np.array_equal(tables[0][untouched], E.astype(np.float32)[untouched])     # untouched rows keep their bits
     assert all(s > 0 for _, _, _, s in got)
+
+
+# ---- the FIXED bucket sizes over a whole plan: S and R are drawn once, when the plan is built, from every batch of
+# every rank; each later step only packs into them.  World 2, several batches, a hot id owned by rank 1, a batch whose bucket for one
+# owner is EMPTY -- and a batch that is NOT in the plan, whose bucket must be refused instead of silently truncated.
+def _plan_case():
+    rng = np.random.default_rng(33)
+    V, T, nb, Bg = 41, 5, 6, 8
+    ub = ((rng.zipf(1.3, size=(nb, Bg, T)) - 1) % V).astype(np.int32)
+    ub[rng.random(ub.shape) < 0.2] = -1
+    items = ((rng.zipf(1.3, size=(nb, Bg)) - 1) % V).astype(np.int32)
+    ub[:, :, 0] = 7                                   # the hot id: owner 7 % 2 = rank 1
+    ub[3] = np.where(ub[3] % 2 == 1, ub[3] - 1, ub[3])   # batch 3: only even ids ...
+    ub[3][ub[3] < 0] = -1
+    items[3] -= items[3] % 2                          # ... so owner 1's bucket is EMPTY for batch 3
+    return V, T, nb, Bg, ub, items
+
+
+def _buckets(ids, V, W):
+    """slots of one rank's batch: touched ids in owner-major order (pidx = (id % W) * Vw + id / W) and the bucket bounds"""
+    Vw = -(-(-(-V // W)) // 4) * 4
+    t = np.unique(ids[(ids >= 0) & (ids < V)])
+    slot_id = t[np.argsort((t % W) * Vw + t // W, kind="stable")]
+    off = np.searchsorted(slot_id % W, np.arange(W + 1), side="left")
+    return slot_id, off, Vw
+
+
+def _pack(slot_id, off, W, S):
+    """emb_pack_send_kernel's contract: S entries per owner, -1 padded; a bucket longer than S is an error, never a truncation"""
+    sid = np.full((W, S), -1, np.int32)
+    for o in range(W):
+        k = off[o + 1] - off[o]
+        if k > S:
+            raise OverflowError(f"bucket for owner {o} holds {k} ids, the plan's bound is {S}")
+        sid[o, :k] = slot_id[off[o]:off[o + 1]]
+    return sid
+
+
+def _plan_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    V, T, nb, Bg, ub, items = _plan_case()
+    W, n = world, Bg // world
+    sl = slice(rank * n, (rank + 1) * n)
+    per_batch = [_buckets(np.concatenate([ub[k, sl].ravel(), items[k, sl]]), V, W) for k in range(nb)]
+    # plan build: the bound is the largest bucket of ANY batch on ANY rank (ctr.hip: one all-gather of the local maxima)
+    smax = torch.tensor([max(int(np.diff(off).max()) for _, off, _ in per_batch)], dtype=torch.int32)
+    dist.all_reduce(smax, op=dist.ReduceOp.MAX)
+    S = max(4, -(-int(smax.item()) // 4) * 4)
+    Vw = per_batch[0][2]
+    R = min(Vw, W * S)
+    seen_empty, worst_owner = False, 0
+    for k in range(nb):
+        slot_id, off, _ = per_batch[k]
+        sid = _pack(slot_id, off, W, S)                                  # never raises for a batch of the plan
+        seen_empty |= bool(np.any(np.diff(off) == 0))
+        rid = np.full((W, S), -1, np.int32)
+        reqs, bufs = [], []
+        for p in range(W):
+            if p == rank:
+                rid[rank] = sid[rank]
+                continue
+            ri = torch.zeros(S, dtype=torch.int32)
+            bufs.append((p, ri))
+            reqs += [dist.isend(torch.from_numpy(sid[p].copy()), p, tag=k), dist.irecv(ri, p, tag=k)]
+        for q in reqs:
+            q.wait()
+        for p, ri in bufs:
+            rid[p] = ri.numpy()
+        live = rid[rid >= 0]
+        assert np.all(live % W == rank)                                  # only ids this rank owns arrive
+        n_red = np.unique(live).size
+        assert n_red <= R, (n_red, R)                                    # the owner-side list fits its fixed size
+        worst_owner = max(worst_owner, n_red)
+    # a batch that was not in the plan: rank 0 suddenly touches more ids of one owner than any planned batch did
+    refused = False
+    try:
+        rogue = np.arange(1, 2 * (S + 2), 2, dtype=np.int32) % V        # S + 2 distinct odd ids: owner 1
+        sid_, off_, _ = _buckets(rogue, V, W)
+        _pack(sid_, off_, W, S)
+    except OverflowError:
+        refused = True
+    out.put((rank, S, R, seen_empty, worst_owner, refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_embedding_fixed_buckets_hold_every_batch_of_the_plan():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0][1] == got[1][1] and got[0][2] == got[1][2]             # both ranks drew the same S and R
+    assert any(g[3] for g in got)                                        # an empty bucket was exercised
+    assert all(g[5] for g in got)                                        # the unplanned batch was refused on both ranks
+    V, T, nb, Bg, ub, items = _plan_case()
+    assert got[0][1] >= 4 and got[0][2] <= -(-(-(-V // 2)) // 4) * 4     # R never exceeds the owner's share of the vocabulary

@@ -40,15 +40,37 @@ def reference_test_data(n, seed):
     return X, Y
 
 
-# ---- tolerances, and where they come from (scripts/e2e_model_test_probe.py on an MI355X, profiles/r06_e2e_drift.txt) --------
-# Device and oracle run the same arithmetic in different float32 summation orders (MFMA k-order, slab sums, the 6-product
-# bf16 split against the oracle's sequential loops): ~1e-7 relative per step.  Adam turns a gradient entry whose value passes
-# within that noise of zero into a +-lr update, so the two trajectories separate slowly instead of staying 1e-7 apart; what is
-# compared after 10 000 steps is therefore two members of the same family of float32 runs, not one run twice.
-#   * an epoch's cost is its LAST batch's cost (model.go:186-199): a mean over 200 rows of a model that has drifted by the
-#     weight differences below.
-COST_TOL_E2E = 5e-3           # measured: see profiles/r06_e2e_drift.txt (filled in by the round-6 GPU session)
+# ---- tolerances, and where they come from (profiles/r06_e2e_drift.txt: scripts/e2e_model_test_probe.py on an MI355X, -------------
+# scripts/e2e_oracle_sensitivity.py on the CPU) ------------------------------------------------------------------------------
+# Device and oracle run the same arithmetic in different float32 summation orders (MFMA k-order, slab sums, the 6-product bf16
+# split against the oracle's sequential loops): ~1e-7 relative per step.  Over 10 000 Adam steps from the reference's N(0,1) init
+# (saturated sigmoids, gradients that pass through zero) such differences do not stay 1e-7: Adam turns a gradient entry within
+# rounding noise of zero into a +-lr update.  MEASURED: the ORACLE against itself after a ONE-ulp change of its initial weights
+# moves its epoch costs by 3e-7 ... 2.3e-3 (six runs) and its weights by up to 0.08; the device against the oracle: 7e-7 ... 1.6e-3
+# in five of six runs, 1.2e-2 in one (a trajectory whose weights end 4.1 apart).  Even the oracle binary gives different
+# trajectories on different hosts (glibc picks expf / logf variants by CPU).  What is compared after 10 000 steps is therefore two
+# members of one family of float32 runs.  The bar:
+#   * tier 1 (what seed 1 measured on the MI355X boxes: 7e-6 DIN, 1.1e-4 YouTube-DNN; AUCs equal to four digits):
+#       every epoch cost within COST_TOL_E2E = 2e-3 (the size of the oracle's own response to one ulp), AUC within 0.005;
+#   * tier 2, only if tier 1 fails (a host whose libm puts seed 1 on a sensitive trajectory): the oracle is run twice more with
+#     its initial W0 / W1 moved by one ulp; the device must then stay within 5 x the spread of that family (costs and AUC),
+#     and the first two epochs (1 000 steps, before trajectories separate: <= 8.5e-5 in all six measured runs) within 2e-4.
+COST_TOL_E2E = 2e-3
 AUC_TOL_E2E = 0.005
+EARLY_COST_TOL = 2e-4
+FAMILY_FACTOR = 5.0
+
+
+def _oracle_run(oracle, kind, seed, early_stop, X, Y, p, pert=0):
+    U, T, D, Cc = DIMS_E2E
+    om = oracle.CtrModel(oracle.DIN if kind == 0 else oracle.YOUTUBE, U, T, D, Cc).init_gaussian(np.random.default_rng(seed))
+    if pert == 1:
+        om.W0[:] = om.W0 * np.float32(1 + 2.0 ** -23)
+    if pert == 2:
+        om.W1[:] = om.W1 * np.float32(1 - 2.0 ** -23)
+    w0 = (om.W0.copy(), om.W1.copy(), om.W2.copy(), om.att0.copy())
+    costs = om.train(X, Y, batch=200, epochs=20, early_stop=early_stop, drop_mode=2, p0=p, p1=p, seed=42)
+    return om, w0, costs
 
 
 @pytest.mark.parametrize("kind,early_stop", [(0, 0), (1, 10)], ids=["din", "youtube_early_stop_10"])
@@ -59,26 +81,37 @@ def test_reference_model_test_end_to_end(oracle, kind, early_stop):
     n, B, epochs, n_test, test_B = 100_000, 200, 20, 118, 20                      # model_test.go:21-33
     X, Y = reference_test_data(n, 42)
     si = SampleInfo.from_dims(U, T, D, Cc)
-    om = oracle.CtrModel(oracle.DIN if kind == 0 else oracle.YOUTUBE, U, T, D, Cc).init_gaussian(np.random.default_rng(1))
     dm = (gm.DinNet if kind == 0 else gm.YoutubeDnn)(U, T, D, D, Cc)              # NewDinNet / NewYoutubeDnn (:80, :119)
-    dm.set_weights("mlp0", om.W0); dm.set_weights("mlp1", om.W1); dm.set_weights("mlp2", om.W2)
-    if kind == 0:
-        dm.set_weights("att0", om.att0)
-    costs = gm.Train(U, T, D, D, Cc, n, B, epochs, early_stop, si, X, Y.reshape(-1, 1), dm, dropout_seed=42)     # :82-88 / :121-127
     oracle.set_threads(min(16, len(os.sched_getaffinity(0))))                     # (row-parallel loops: no summation order depends on it)
     try:
-        ref = om.train(X, Y, batch=B, epochs=epochs, early_stop=early_stop, drop_mode=2, p0=dm.d0, p1=dm.d1, seed=42)
+        om, (W0, W1, W2, att0), ref = _oracle_run(oracle, kind, 1, early_stop, X, Y, dm.d0)
+        dm.set_weights("mlp0", W0); dm.set_weights("mlp1", W1); dm.set_weights("mlp2", W2)
+        if kind == 0:
+            dm.set_weights("att0", att0)
+        costs = gm.Train(U, T, D, D, Cc, n, B, epochs, early_stop, si, X, Y.reshape(-1, 1), dm, dropout_seed=42)     # :82-88 / :121-127
+        assert len(costs) == len(ref), "device and oracle stopped at different epochs"
+        assert np.all(np.isfinite(costs))
+        blob = dm.Marshal()                                                           # :93 / :132
+        dp = (gm.NewDinNetFromJson if kind == 0 else gm.NewYoutubeDnnFromJson)(blob)  # :96 / :135
+        gm.InitForwardOnlyVm(U, T, D, D, Cc, test_B, dp)                              # :101 / :140
+        y = gm.Predict(dp, n_test, test_B, si, X)                                     # :103 / :142
+        assert y.shape == (n_test,) and np.all(np.isfinite(y))
+        auc = oracle.roc_auc32(y, Y[:n_test])                                         # :108 / :147 utils.RocAuc32
+        assert auc > 0.5                                                              # the reference's own assertion
+        auc_ref = oracle.roc_auc32(om.predict(X[:n_test], test_B), Y[:n_test])
+        diff = np.abs(costs - ref)
+        if diff.max() <= COST_TOL_E2E and abs(auc - auc_ref) <= AUC_TOL_E2E:
+            return                                                                    # tier 1
+        # tier 2: the oracle's own one-ulp family on THIS host as the yard-stick
+        fam_c, fam_a = [ref], [auc_ref]
+        for pert in (1, 2):
+            op, _, cp = _oracle_run(oracle, kind, 1, early_stop, X, Y, dm.d0, pert)
+            assert len(cp) == len(ref)
+            fam_c.append(cp); fam_a.append(oracle.roc_auc32(op.predict(X[:n_test], test_B), Y[:n_test]))
+        fam_c = np.stack(fam_c)
+        spread = fam_c.max(0) - fam_c.min(0)
+        assert np.all(diff[:2] <= EARLY_COST_TOL), diff[:2]
+        assert np.all(diff <= FAMILY_FACTOR * spread.max() + 1e-5), (diff, spread)
+        assert abs(auc - auc_ref) <= max(AUC_TOL_E2E, FAMILY_FACTOR * (max(fam_a) - min(fam_a))), (auc, fam_a)
     finally:
         oracle.set_threads(1)
-    assert len(costs) == len(ref), "device and oracle stopped at different epochs"
-    assert np.all(np.isfinite(costs))
-    assert np.max(np.abs(costs - ref)) <= COST_TOL_E2E, np.abs(costs - ref)
-    blob = dm.Marshal()                                                           # :93 / :132
-    dp = (gm.NewDinNetFromJson if kind == 0 else gm.NewYoutubeDnnFromJson)(blob)  # :96 / :135
-    gm.InitForwardOnlyVm(U, T, D, D, Cc, test_B, dp)                              # :101 / :140
-    y = gm.Predict(dp, n_test, test_B, si, X)                                     # :103 / :142
-    assert y.shape == (n_test,) and np.all(np.isfinite(y))
-    auc = oracle.roc_auc32(y, Y[:n_test])                                         # :108 / :147 utils.RocAuc32
-    assert auc > 0.5                                                              # the reference's own assertion
-    auc_ref = oracle.roc_auc32(om.predict(X[:n_test], test_B), Y[:n_test])
-    assert abs(auc - auc_ref) <= AUC_TOL_E2E, (auc, auc_ref)

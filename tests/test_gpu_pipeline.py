@@ -83,7 +83,8 @@ def test_cfg4_youtube_6_pipelined_graph_steps_vs_oracle(oracle):
     _free_running_steps_vs_oracle(oracle, 1, 52, 50, 64, 53, 10_000_000, 16384, 6, 301, 0.003)
 
 
-@pytest.mark.parametrize("knob", ["GOCTR_PIPELINE", "GOCTR_GRAPH_STEPS", "GOCTR_NO_GRAPH", "GOCTR_CHAIN_ATTN_BWD"])
+@pytest.mark.parametrize("knob", ["GOCTR_PIPELINE", "GOCTR_GRAPH_STEPS", "GOCTR_NO_GRAPH", "GOCTR_CHAIN_ATTN_BWD", "GOCTR_CHAIN_TILE_SUMS",
+                                  "GOCTR_XCD_AFFINE", "GOCTR_TN_WT"])
 def test_id_mode_pipelined_graphs_equal_unpipelined_and_eager(knob):
     """id mode, B = 8192 (377 reduce blocks beside 2048 attention workgroups in the merged launch), dropout on, 39 steps =
     16 + 16 + 4 + 2 + 1: the default path and the path with the knob flipped must land on the same bits"""
@@ -96,10 +97,17 @@ def test_id_mode_pipelined_graphs_equal_unpipelined_and_eager(knob):
     res = []
     # (GOCTR_CHAIN_ATTN_BWD=0: the att0 gradient's per-sample terms from the separate attn_bwd_kernel instead of the chain
     # kernel's tail -- same arithmetic in the same order)
-    flipped = {"GOCTR_PIPELINE": "0", "GOCTR_GRAPH_STEPS": "0", "GOCTR_NO_GRAPH": "1", "GOCTR_CHAIN_ATTN_BWD": "0"}[knob]
+    # (round 6 -- GOCTR_XCD_AFFINE=0: workgroup b takes tile / sample group b instead of its XCD's; GOCTR_TN_WT=0: plain slab stores:
+    # same bits.  GOCTR_CHAIN_TILE_SUMS=0: dW2 and the att0 terms leave the chain launch as operands and are summed by the
+    # weight-gradient launch's MFMA problems instead of per tile in the chain launch -- another float32 summation order, compared
+    # at 2e-6 below; the GOCTR_CHAIN_ATTN_BWD comparison is between the two stored-terms paths, i.e. with the tile sums off)
+    flipped = {"GOCTR_PIPELINE": "0", "GOCTR_GRAPH_STEPS": "0", "GOCTR_NO_GRAPH": "1", "GOCTR_CHAIN_ATTN_BWD": "0",
+               "GOCTR_CHAIN_TILE_SUMS": "0", "GOCTR_XCD_AFFINE": "0", "GOCTR_TN_WT": "0"}[knob]
     for val in (None, flipped):
         if val is not None:
             os.environ[knob] = val
+        if knob == "GOCTR_CHAIN_ATTN_BWD":
+            os.environ["GOCTR_CHAIN_TILE_SUMS"] = "0"
         try:
             m = gm.DinNet(U, T, D, D, Cc)
             r = np.random.default_rng(311)
@@ -112,9 +120,16 @@ def test_id_mode_pipelined_graphs_equal_unpipelined_and_eager(knob):
             res.append((costs, m.get_weights("mlp0"), m.get_weights("mlp1"), m.get_weights("att0")))
         finally:
             os.environ.pop(knob, None)
+            if knob == "GOCTR_CHAIN_ATTN_BWD":
+                os.environ.pop("GOCTR_CHAIN_TILE_SUMS", None)
     assert np.all(np.isfinite(res[0][0]))
     for a, b in zip(res[0], res[1]):
-        assert np.array_equal(a, b)
+        if knob == "GOCTR_CHAIN_TILE_SUMS":
+            # 39 Adam steps of lr 0.01 on gradients that differ in rounding: an entry whose gradient passes within float32 noise of
+            # zero takes a different +-lr step (the same effect as against the oracle, tests/test_gpu_fullsize.py)
+            assert np.mean(np.abs(a - b) <= 1e-5) >= 0.999 and np.max(np.abs(a - b)) <= 0.05
+        else:
+            assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("att", [0, 1])
