@@ -633,6 +633,15 @@ def bench_knn(args):
     for _ in range(warm):
         s.search_vectors(queries, k)
     capi.sync()
+    # (round 6: the "two slow regions" of round 5's lines -- regions 1 and 5 of nine in EVERY process, +1.5 ms each -- are the
+    # HARNESS: a call allocates a few dozen Python containers, and CPython's oldest-generation collection falls due every ~800
+    # calls and takes ~1.5 ms over this process' heap (profiles/r06_knn_slow_regions.txt: GOCTR_BENCH_GC=1 brings them back).
+    # A Go host has no such pause per 800 calls; the timed regions run with the collector paused.)
+    import gc
+    gc_off = os.environ.get("GOCTR_BENCH_GC", "0") != "1"
+    if gc_off:
+        gc.collect()
+        gc.disable()
     regions = []
     for r in range(max(args.regions, 1)):
         t0 = time.perf_counter()
@@ -640,6 +649,8 @@ def bench_knn(args):
             idx, sim, cnt = s.search_vectors(queries, k)
         capi.sync()
         regions.append(time.perf_counter() - t0)
+    if gc_off:
+        gc.enable()
     dt = sorted(regions)[(len(regions) - 1) // 2]
     qps = steps * Q / dt
     # ---- roofline of the IMPLEMENTED call (rounds 1-4 priced the reference's loop -- every query scans

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
       cx_f4 z = cx_f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ws = 0; ws < CX_NT0; ++ws) z += *reinterpret_cast<const cx_f4*>(xch + ((size_t)(ws * 4 + w) * 64 + lane) * 4);
-      if (vrow) *reinterpret_cast<cx_f4*>(a.dp + (size_t)row * a.Dp + d0) = z;
+      if (vrow && !a.tile_att0) *reinterpret_cast<cx_f4*>(a.dp + (size_t)row * a.Dp + d0) = z;   // (tile_att0: its only reader is this launch's own tail)
       if (ab && d0 < 16) {
         // dp / T once per element here (attn_bwd_kernel's first step), not once per consumer lane
         const float Tf = (float)a.ab_T;
