@@ -287,7 +287,7 @@ int comm_capture_selftest() {
   if (!comm_capturable()) { e.capture_state = -1; return 0; }
   const int n = 4096;
   // (generous: the first collective of a fresh 8-rank communicator builds its connections -- and a timeout here is fatal for the rank)
-  const int wait_s = std::max(1, env_int_comm("GOCTR_CAPTURE_TEST_TIMEOUT_S", 180));
+  const int wait_s = 180;
   auto lost = [&](const char* what) {
     // (comm_watch_stream has already aborted on a timeout / asynchronous error; abort here for the synchronous failures, which
     // would otherwise leave the peers waiting inside the next collective of the probe)

@@ -134,6 +134,12 @@ int run_on_engines(int n, const std::function<int(int)>& fn);
 #define GOCTR_SAME_ENGINE(a, b) \
   GOCTR_CHECK(!(a) || !(b) || (a)->eng == (b)->eng, "%s: the handles were created on different engines (devices)", __func__)
 
+// phase stamps / debug prints of one kernel family: GOCTR_DBG=chain,tn,mlp (any subset; read at call time)
+inline bool dbg_on(const char* what) {
+  const char* v = getenv("GOCTR_DBG");
+  return v && *v && strstr(v, what) != nullptr;
+}
+
 // generation ids for handles whose device pointers get baked into captured graphs (a freed handle's host address may be
 // handed out again by malloc; its uid never is)
 uint64_t next_uid();

@@ -241,19 +241,15 @@ int env_int(const char* name, int dflt) {
 struct TnSchedule { int rows, S, rows_light, S_light; };
 TnSchedule tn_schedule(const goctr_model* m, int B) {
   TnSchedule t{};
-  const int forced = env_int("GOCTR_TN_ROWS", 0);
   const int heavy = (int)cdiv(m->Ip / 16, 3) + (int)cdiv(m->H2p / 16, 3);
   const int light = m->cfg.kind == GOCTR_DIN ? 2 : 1;
   int cus = engine().compute_units > 0 ? engine().compute_units : 256;
-  const int lf = env_int("GOCTR_TN_LIGHT", 25);   // light slab height = lf/10 x the heavy one
+  const int lf = 25;   // light slab height = lf/10 x the heavy one
   // workgroups(rows) = heavy*ceil(B/rows) + light*ceil(B/(lf rows)) <= cus ; smallest such rows (multiple of 4)
-  int rows = forced > 0 ? round_up(forced, 4) : 32;
-  if (forced <= 0) {
-    for (;; rows += 4) {
-      const long wgs = (long)heavy * cdiv(B, rows) + (long)light * cdiv(B, round_up(rows * lf / 10, 4));
-      if (wgs <= cus || rows >= B) break;
-    }
-    if (rows < 32) rows = 32;
+  int rows = 32;
+  for (;; rows += 4) {
+    const long wgs = (long)heavy * cdiv(B, rows) + (long)light * cdiv(B, round_up(rows * lf / 10, 4));
+    if (wgs <= cus || rows >= B) break;
   }
   t.rows = rows; t.S = (int)cdiv(B, rows);
   t.rows_light = round_up(rows * lf / 10, 4); t.S_light = (int)cdiv(B, t.rows_light);
@@ -273,10 +269,8 @@ constexpr int TN_SUM_SLABS = 8;
 // nsum: how many of the light problems (dW2, att0) are sums over the chain launch's per-tile results this step
 TnWide tn_schedule_wide(const goctr_model* m, int B, int nsum = 0) {
   static std::mutex mu;
-  static std::map<std::array<int, 13>, TnWide> cache;
-  const std::array<int, 13> key{B, m->Ip, m->H1p, m->H2p, m->cfg.kind, engine().compute_units, env_int("GOCTR_TN_WIDE", 1),
-                                env_int("GOCTR_TN_FIX0", 512), env_int("GOCTR_TN_FIX1", 384), env_int("GOCTR_TN_C0", 0),
-                                env_int("GOCTR_TN_C1", 0), env_int("GOCTR_TN_RL", 0), nsum};
+  static std::map<std::array<int, 7>, TnWide> cache;
+  const std::array<int, 7> key{B, m->Ip, m->H1p, m->H2p, m->cfg.kind, engine().compute_units, nsum};
   std::lock_guard<std::mutex> lk(mu);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
@@ -287,7 +281,7 @@ TnWide tn_schedule_wide(const goctr_model* m, int B, int nsum = 0) {
 TnWide tn_schedule_wide_search(const goctr_model* m, int B, int nsum) {
   TnWide w{};
   const int kt0 = m->Ip / 16, nt = m->H1p / 16, kt1 = m->H2p / 16;
-  w.ok = (kt0 == 9 || kt0 == 15) && kt1 == 5 && nt > 8 && nt <= 16 && env_int("GOCTR_TN_WIDE", 1) != 0;
+  w.ok = (kt0 == 9 || kt0 == 15) && kt1 == 5 && nt > 8 && nt <= 16;
   if (!w.ok) return w;
   w.ktw0 = kt0 == 9 ? 9 : 8; w.kblocks0 = (int)cdiv(kt0, w.ktw0); w.nbt = (int)cdiv(nt, 2);
   const int cols0 = w.ktw0 * 16 + w.nbt * 16, cols1 = kt1 * 16 + w.nbt * 16;
@@ -295,7 +289,7 @@ TnWide tn_schedule_wide_search(const goctr_model* m, int B, int nsum) {
   const int blocks0 = w.kblocks0 * 2, blocks1 = 2, light = m->cfg.kind == GOCTR_DIN ? 2 : 1;
   const int cus = engine().compute_units > 0 ? engine().compute_units : 256;
   // cost of a workgroup in "staged columns": chunks x columns per chunk + a fixed part (start, first chunk, slab stores)
-  const int fix0 = env_int("GOCTR_TN_FIX0", 512), fix1 = env_int("GOCTR_TN_FIX1", 384), fixL = 384;
+  const int fix0 = 512, fix1 = 384, fixL = 384;
   long best = -1; int bc0 = 0, bc1 = 0, brl = 0;
   const int cmax = (int)cdiv(B, 32);
   for (int c0 = 1; c0 <= cmax; ++c0)
@@ -315,9 +309,6 @@ TnWide tn_schedule_wide_search(const goctr_model* m, int B, int nsum) {
       best = t; bc0 = c0; bc1 = c1; brl = rl;
     }
   if (best < 0) { bc0 = bc1 = cmax; brl = B; }
-  if (env_int("GOCTR_TN_C0", 0) > 0) bc0 = env_int("GOCTR_TN_C0", 0);     // (experiments)
-  if (env_int("GOCTR_TN_C1", 0) > 0) bc1 = env_int("GOCTR_TN_C1", 0);
-  if (env_int("GOCTR_TN_RL", 0) > 0) brl = std::max(32, round_up(env_int("GOCTR_TN_RL", 0), 4));
   w.rows0 = bc0 * 32; w.S0 = (int)cdiv(B, w.rows0);
   w.rows1 = bc1 * 32; w.S1 = (int)cdiv(B, w.rows1);
   w.rowsL = brl; w.SL = (int)cdiv(B, w.rowsL);
@@ -330,8 +321,8 @@ bool dw_wide_path(const goctr_model* m, int B) {
   int nt_max = m->H1p / 16;
   if (m->H2p / 16 > nt_max) nt_max = m->H2p / 16;
   if (m->cfg.kind == GOCTR_DIN && m->Tp / 16 > nt_max) nt_max = m->Tp / 16;
-  const bool multi = nt_max <= 16 && gemm_tn_multi_fits<3, GOCTR_TN_CH>(nt_max) && env_int("GOCTR_NO_TNMULTI", 0) == 0;
-  return multi && env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32 && tn_schedule_wide(m, B).ok;
+  const bool multi = nt_max <= 16 && gemm_tn_multi_fits<3, GOCTR_TN_CH>(nt_max);
+  return multi && GOCTR_TN_CH == 32 && tn_schedule_wide(m, B).ok;
 }
 
 int ensure_workspace(goctr_model* m, int B) {
@@ -420,7 +411,7 @@ int launch_nn(int kid, const float* A, int lda, const float* Bm, int ldb, int M,
   hipStream_t st = engine().active;
   ProfScope ps(kid);
   // B fits one LDS phase and there are many more row tiles than CUs: the persistent variant parks B once per workgroup
-  if (KPH >= Kp && ntw == 4 && (int)grid.x >= 2 * engine().compute_units && env_int("GOCTR_NN_ROWS", 1) != 0) {
+  if (KPH >= Kp && ntw == 4 && (int)grid.x >= 2 * engine().compute_units) {
     const dim3 g2((unsigned)engine().compute_units, grid.y);
     hipLaunchKernelGGL((gemm_nn_rows_kernel<float, Epi, 4>), g2, dim3(256), lds, st, A, lda, Bm, ldb, M, Kp, Np, WN, epi);
     GOCTR_HIP(hipGetLastError());
@@ -631,10 +622,10 @@ bool chain_x3_shape_ok(const goctr_model* m) {
 // training steps, and predict launches large enough to give every CU a 32-row tile (the forward-only variant; smaller
 // predict launches are latency-bound and keep ctr_fwd16_kernel)
 bool chain_x3_ok(const goctr_model* m, const StepOpts& o, int B) {
-  if (m->x3_nch0 == 0 || env_int("GOCTR_CHAIN_X3", 1) == 0) return false;
+  if (m->x3_nch0 == 0) return false;
   if (o.train) return o.drop_mode != 1;
   const int cus = engine().compute_units > 0 ? engine().compute_units : 256;
-  return cdiv(B, 32) >= cus && env_int("GOCTR_PREDICT_X3", 1) != 0;
+  return cdiv(B, 32) >= cus;
 }
 
 int rebuild_x3_images(goctr_model* m) {
@@ -669,8 +660,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   a.A0 = m->A0.p; a.A1 = m->A1.p; a.dz0 = m->dz0.p; a.dz1 = m->dz1.p; a.dz2 = m->dz2.p; a.dp = m->dp.p;   // (forward only: none of these is touched)
   // trainable embeddings, DIN, 2 D <= 32: the 32-wide dp product of this kernel also yields d cost / d candidate-item segment
   // (IMG3 holds W0[U : U+2D]^T) -- it writes dpv = [dp | dvh] itself and the step needs no GEMM launch for it (6.9 us at cfg3)
-  m->dpv_from_chain = o.train && emb_plan_active(m) && src.id_mode && c.kind == GOCTR_DIN && 2 * c.D <= 32 &&
-                      env_int("GOCTR_EMB_DPV_CHAIN", 1) != 0;
+  m->dpv_from_chain = o.train && emb_plan_active(m) && src.id_mode && c.kind == GOCTR_DIN && 2 * c.D <= 32;
   if (m->dpv_from_chain) { a.dp = m->dpv.p; a.Dp = round_up(2 * c.D, 16); }
   // frozen embeddings, DIN, D = 16, T <= 64: the att0 gradient's per-sample terms come out of this kernel's tail
   // (ChainX3Args::ab_*), launch_backward skips attn_bwd (GOCTR_CHAIN_ATTN_BWD=0: the separate kernel)
@@ -681,7 +671,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
     a.ab_T = c.T; a.ab_Tp = m->Tp;
   }
   a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
-  a.xcd_affine = o.train ? env_int("GOCTR_XCD_AFFINE", 1) : 0;
+  a.xcd_affine = env_int("GOCTR_XCD_AFFINE", 1);
   // per-tile sums of dW2 and of the att0 terms instead of their operands -- where the wide weight-gradient launch follows (it
   // adds the tiles up; GOCTR_CHAIN_TILE_SUMS=0: the operands are stored and multiplied there, as until round 5)
   const bool tile_sums = o.train && dw_wide_path(m, B) && env_int("GOCTR_CHAIN_TILE_SUMS", 1) != 0;
@@ -690,7 +680,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   a.tile_dw2 = m->dw2_from_chain ? m->tile_dw2.p : nullptr;
   a.tile_att0 = m->att0_from_chain ? m->tile_att0.p : nullptr;
   static DevBuf<unsigned long long> dbgbuf;
-  const bool dbg = env_int("GOCTR_CHAIN_DBG", 0) != 0 && (hipStream_t)e.active == e.stream;   // (not from a serving slot)
+  const bool dbg = dbg_on("chain") && (hipStream_t)e.active == e.stream;   // (not from a serving slot)
   if (dbg && !dbgbuf.p && dbgbuf.alloc(8 * CX_NSTAMP)) return -1;
   a.dbg = dbg ? dbgbuf.p : nullptr;
   ProfScope ps(GOCTR_K_CHAIN);
@@ -755,7 +745,7 @@ bool serve16_ok(const goctr_model* m, const RowSource& src, int B) {
   const int fast = attn_fast_mode(m, src, &groups);
   StepOpts o; o.train = false;
   return src.k_users && fast != 0 && (groups == 2 || groups == 4 || groups == 16) && chain_ok(m) && !chain_x3_ok(m, o, B) &&
-         cdiv(B, 32) < engine().compute_units && env_int("GOCTR_NO_FWD16", 0) == 0 && env_int("GOCTR_SERVE_ONE_LAUNCH", 1) != 0;
+         cdiv(B, 32) < engine().compute_units && env_int("GOCTR_SERVE_ONE_LAUNCH", 1) != 0;
 }
 int launch_serve16(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb, unsigned* done, unsigned epoch) {
   int groups = 0;
@@ -789,7 +779,7 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
   Engine& e = engine();
   ChainArgs a = make_chain_args(m, src, B, o, st, fb);
   static DevBuf<unsigned long long> dbgbuf;
-  const bool dbg = o.train && env_int("GOCTR_CHAIN_DBG", 0) != 0;
+  const bool dbg = o.train && dbg_on("chain");
   if (dbg && !dbgbuf.p && dbgbuf.alloc(CHAIN_NSTAMP)) return -1;
   a.dbg = dbg ? dbgbuf.p : nullptr;
   ProfScope ps(GOCTR_K_CHAIN);
@@ -797,7 +787,7 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
   const size_t lds = chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p);
   const int dmode = (a.d0.mode || a.d1.mode) ? o.drop_mode : 0;
   // forward only and too few rows to give every CU a 32-row workgroup: 16-row workgroups, H1 split over 4 wavefronts
-  if (!o.train && cdiv(B, 32) < e.compute_units && env_int("GOCTR_NO_FWD16", 0) == 0) {
+  if (!o.train && cdiv(B, 32) < e.compute_units) {
     if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, "ctr_fwd16_kernel<4,5>");
     hipLaunchKernelGGL((ctr_fwd16_kernel<4, 5>), dim3((unsigned)cdiv(B, 16)), dim3(512), lds, e.active, a);
   } else
@@ -856,10 +846,10 @@ bool pipeline_ok(const goctr_model* m, const RowSource& src) {
     // attention (adam_attn_kernel); one 256-parameter Adam block must own the att0 segment
     const bool one_adam_block = m->cfg.kind != GOCTR_DIN || m->offa / 256 == (m->offa + m->Tp - 1) / 256;
     return fast != 0 && (groups == 4 || groups == 16) && one_adam_block && chain_ok(m) && m->emb_lr <= 0.f &&
-           env_int("GOCTR_PIPELINE", 1) != 0 && env_int("GOCTR_PIPELINE_DP", 1) != 0;
+           env_int("GOCTR_PIPELINE", 1) != 0;
   }
   return fast != 0 && (groups == 4 || groups == 16) && one_block && chain_ok(m) &&
-         env_int("GOCTR_FUSED_UPDATE", 1) != 0 && env_int("GOCTR_PIPELINE", 1) != 0;
+         env_int("GOCTR_PIPELINE", 1) != 0;
 }
 
 int launch_reduce_attn(goctr_model* m, const RowSource& src, int B, const ReduceAdamArgs& p) {
@@ -1142,7 +1132,7 @@ int launch_emb_slot_gv(int mode, bool direct, long long max_pairs, hipStream_t s
 // cfg3 got SLOWER, 30.7 -> 33.5 us -- fewer, fatter wavefronts hide less of the latency that bounds it -- so DIN keeps one)
 bool emb_slot_vec4(const goctr_model* m) {
   const goctr_ctr_cfg& c = m->cfg;
-  const int want = env_int("GOCTR_EMB_SLOT_VEC", c.kind != GOCTR_DIN ? 4 : 1);
+  const int want = c.kind != GOCTR_DIN ? 4 : 1;
   return (c.D == 16 || c.D == 32 || c.D == 64) && want == 4;
 }
 
@@ -1241,7 +1231,7 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   a.src = src; a.st = st; a.B = B; a.T = c.T; a.D = c.D; a.kind = c.kind; a.att = c.att;
   a.dpv = m->dpv.p; a.ldp = Np; a.gate = m->gate_p(m->stp); a.wgt = m->wgt_p(m->stp); a.att0 = m->W.p + m->offa;
   a.emb = const_cast<float*>(src.emb); a.V = V;
-  a.mark = m->emb_mark.p; a.rank = m->emb_rank.p; a.accum = m->emb_accum.p; a.lr = m->emb_lr; a.dbg = env_int("GOCTR_EMB_DBG", 0);
+  a.mark = m->emb_mark.p; a.rank = m->emb_rank.p; a.accum = m->emb_accum.p; a.lr = m->emb_lr; a.dbg = 0;
   a.W = W; a.Vw = m->emb_Vw;
   hipStream_t s = e.stream;
   if (m->plan.valid) {
@@ -1273,17 +1263,16 @@ int launch_emb_train(goctr_model* m, const RowSource& src, int B, const StepStat
   // attention modes: one 1024-thread workgroup per CU (~90 VGPRs allow no second one) with a <= 136 KB LDS cache of hot
   // rows; mean pooling fits two per CU (GOCTR_EMB_WGS=2, <= 72 KB each) but measured no faster (184 vs 178 us at cfg4)
   const int mode = c.kind != GOCTR_DIN ? 0 : (c.att == GOCTR_ATT_COSINE ? 1 : 2);
-  const int wg_per_cu = mode == 0 ? env_int("GOCTR_EMB_WGS", 1) : 1;
+  const int wg_per_cu = 1;
   const size_t budget = wg_per_cu > 1 ? 72u * 1024u : 136u * 1024u;
   int nslot = 1;
   while ((size_t)nslot * 2 * (c.D * sizeof(long long) + sizeof(int)) <= budget) nslot *= 2;
-  if (env_int("GOCTR_EMB_NSLOT", 0) > 0) nslot = env_int("GOCTR_EMB_NSLOT", 0);   // (experiments: power of two)
   const size_t lds = (size_t)nslot * (c.D * sizeof(long long) + sizeof(int));
   const int cus = e.compute_units > 0 ? e.compute_units : 256;
   const dim3 gb((unsigned)std::min<long long>(cdiv(B, EMB_GRAD_THREADS / 64), (long long)wg_per_cu * cus));
   // GOCTR_EMB_CACHE=0 (experiments) sends every add straight to HBM: 5x slower at cfg3 AND at cfg4 — a Zipfian head is
   // hot in a 10^7-row vocabulary too
-  const bool cache = env_int("GOCTR_EMB_CACHE", 1) != 0;
+  const bool cache = true;
   const dim3 gg = cache ? gb : dim3((unsigned)std::min<long long>(cdiv(B, EMB_GRAD_THREADS / 64), 8 * cus));
   {
     ProfScope ps(GOCTR_K_EMB_GRAD);
@@ -1412,8 +1401,8 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   int nt_max = m->H1p / 16;
   if (m->H2p / 16 > nt_max) nt_max = m->H2p / 16;
   if (c.kind == GOCTR_DIN && m->Tp / 16 > nt_max) nt_max = m->Tp / 16;
-  const bool multi = nt_max <= 16 && gemm_tn_multi_fits<3, GOCTR_TN_CH>(nt_max) && env_int("GOCTR_NO_TNMULTI", 0) == 0;
-  const TnWide tw = (multi && env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32)
+  const bool multi = nt_max <= 16 && gemm_tn_multi_fits<3, GOCTR_TN_CH>(nt_max);
+  const TnWide tw = (multi && GOCTR_TN_CH == 32)
                         ? tn_schedule_wide(m, B, (m->dw2_from_chain ? 1 : 0) + (m->att0_from_chain ? 1 : 0)) : TnWide{};
   int S0 = S, S1 = S, SLx = SL;      // slabs per segment, for the reduce below
   int SL2x = -1, SL3x = -1;          // (wide launch: the dW2 / att0 segments' own slab counts)
@@ -1450,7 +1439,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
       nblk += SL3;
     }
     static DevBuf<unsigned long long> tndbgw;
-    const bool dbg = env_int("GOCTR_TN_DBG", 0) != 0;
+    const bool dbg = dbg_on("tn");
     if (dbg && !tndbgw.p && tndbgw.alloc(16)) return -1;
     tm.dbg = dbg ? tndbgw.p : nullptr;
     {
@@ -1490,20 +1479,20 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     }
     const size_t lds_tm = gemm_tn_multi_lds_bytes<3, 4, GOCTR_TN_CH>(nt_max);
     static DevBuf<unsigned long long> tndbg;
-    const bool dbg = env_int("GOCTR_TN_DBG", 0) != 0;
+    const bool dbg = dbg_on("tn");
     if (dbg && !tndbg.p && tndbg.alloc(16)) return -1;
     tm.dbg = dbg ? tndbg.p : nullptr;
     {
       ProfScope ps(GOCTR_K_DW0);
-      if (ps.on) prof_note_kernel(GOCTR_K_DW0, (env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32) ? "gemm_tn_multi_x3_kernel<3,4>" : "gemm_tn_multi_kernel<3,4,32>");
+      if (ps.on) prof_note_kernel(GOCTR_K_DW0, (GOCTR_TN_CH == 32) ? "gemm_tn_multi_x3_kernel<3,4>" : "gemm_tn_multi_kernel<3,4,32>");
       // default: the 6-product bf16 split (mfma_gemm.h); GOCTR_TN_F32=1 selects the v_mfma_f32_16x16x4_f32 body
-      if (env_int("GOCTR_TN_F32", 0) == 0 && GOCTR_TN_CH == 32)
+      if (GOCTR_TN_CH == 32)
         hipLaunchKernelGGL((gemm_tn_multi_x3_kernel<3, 4>), dim3((unsigned)nblk), dim3(512), gemm_tn_multi_x3_lds_bytes<3>(nt_max), e.stream, tm);
       else
         hipLaunchKernelGGL((gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>), dim3((unsigned)nblk), dim3(256), lds_tm, e.stream, tm);
       GOCTR_HIP(hipGetLastError());
     }
-    if (dbg && env_int("GOCTR_TN_F32", 0) == 0) {
+    if (dbg) {
       unsigned long long h[16];
       if (tndbg.download(h, 16)) return -1;
       fprintf(stderr, "dW x3 wg 0: multiplier wave: wait for chunk 0 %lld, in MFMA sections %lld, loop total %lld, epilogue %lld | stager wave: first chunk %lld, "
@@ -1630,7 +1619,7 @@ int allreduce_grads(goctr_model* m) {
 // one full training step, eager
 int train_step_eager(goctr_model* m, const RowSource& src, int B, const StepOpts& o) {
   if (launch_forward(m, src, B, o)) return -1;
-  const bool fuse = !engine().comm_active() && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
+  const bool fuse = !engine().comm_active();
   if (emb_split3(m)) {
     if (launch_backward(m, src, B, o, true, false, 1) || emb_exchange_a2a(m) || emb_exchange_owner(m) ||
         launch_backward(m, src, B, o, true, false, 2) || emb_exchange_gather(m) || allreduce_grads(m) ||
@@ -1654,7 +1643,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
                 const StepOpts& o) {
   Engine& e = engine();
   m->graph.destroy();
-  const bool fuse = !e.comm_active() && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
+  const bool fuse = !e.comm_active();
   const int stp_now = m->stp;
   struct StpGuard {      // every exit path (the GOCTR_HIP returns included) restores the parity and drops a half-built graph set
     goctr_model* m; int stp; bool ok = false;
@@ -1680,7 +1669,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
       back = m->stp;                   // (flipped by launch_backward: Adam reads the new slot)
       if (capture_graph(e.stream, &m->graph.b[par], [&] { return (split3 && emb_exchange_apply(m, src)) || launch_adam_step(m, src, B, o); },
                         restore)) return -1;
-      if (!split3 && env_int("GOCTR_DP_JOIN_GRAPHS", 1) != 0) {
+      if (!split3) {
         // b[par] + the next step's a (parity par ^ 1, where m->stp stands now): launch_backward flips m->stp back to par
         back = m->stp;
         if (capture_graph(e.stream, &m->graph.ba[par], [&] {
@@ -1719,12 +1708,7 @@ int build_multi_graphs(goctr_model* m, const RowSource& src, int B, const StepOp
   StepGraph& sg = m->graph;
   const int stp_now = m->stp;
   const bool dp = e.comm_active();
-  const bool fuse = !dp && env_int("GOCTR_FUSED_UPDATE", 1) != 0;
-  if (const char* v = getenv("GOCTR_GRAPH_SIZES")) {
-    int x[3] = {0, 0, 0};
-    if (sscanf(v, "%d,%d,%d", &x[0], &x[1], &x[2]) >= 1)
-      for (int z = 0; z < StepGraph::kNMulti; ++z) sg.kMulti[z] = x[z] & ~1;
-  }
+  const bool fuse = !dp;
   for (int z = 0; z < StepGraph::kNMulti; ++z)
     for (int par = 0; par < 2 && sg.kMulti[z] >= 2; ++par) {
       m->stp = par;
@@ -3188,7 +3172,7 @@ int serve_keys_pass(goctr_model* m, goctr_recsys* r, ServeSlot* s, KeySeg* const
   // device memory over the PCIe BAR where the system has a large BAR (GOCTR_SERVE_BAR=0: off), else the kernels read the pinned
   // host buffer; the scores and flags (5 B per row) are written to pinned host memory from inside the kernels.  Larger passes keep
   // the two DMA copies.
-  const bool zc = N <= (int64_t)env_int("GOCTR_SERVE_ZEROCOPY", 4096);
+  const bool zc = N <= 4096;
   const bool bar = zc && s->in_bar != nullptr && env_int("GOCTR_SERVE_BAR", 1) != 0;
   char* const key_dst = bar ? s->in_bar : s->h_in;      // (written only, front to back: fine for a write-combined mapping)
   long long* hts = reinterpret_cast<long long*>(key_dst);
@@ -3376,7 +3360,7 @@ int serve_keys(goctr_model* m, goctr_recsys* r, KeySeg& g, int64_t* n_failed) {
   // when every slot is busy they join the combining queue, whose next leader scores everything that queued up in ONE pass.
   int rc;
   if (g.n <= coalesce) {
-    ServeSlot* free_slot = env_int("GOCTR_SERVE_ADAPTIVE", 1) != 0 ? serve_pool().acquire(true) : nullptr;
+    ServeSlot* free_slot = serve_pool().acquire(true);
     if (free_slot) {
       KeySeg* one = &g;
       const int64_t want_failed = g.n_failed;

@@ -200,7 +200,10 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   // FWD launches are persistent over row tiles (tile, tile + gridDim.x, ...: see the loop below); a training launch has one
   // tile per workgroup
   const int ntiles = (a.B + 31) >> 5;
-  int tile = (!FWD && a.xcd_affine) ? xcd_unit_of_block((int)blockIdx.x, ntiles, 4) : (int)blockIdx.x;
+  // (FWD: the persistent workgroup's k-th tile is that of "workgroup" blockIdx + k * gridDim -- the same XCD when the grid is a
+  // multiple of 8)
+  int vblk = (int)blockIdx.x;
+  int tile = a.xcd_affine ? xcd_unit_of_block(vblk, ntiles, 4) : vblk;
   const int tile_first = tile;
   int row = tile * 32 + n;
   bool vrow = row < a.B;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     if (hasB && fB < H2p) w2pre[1] = *reinterpret_cast<const cx_f4*>(a.w2 + fB);
   }
   // Forward-only launches loop over their row tiles here.  A tile's start -- its h0 rows and the first six W0 chunks arriving,
-  // 5.2 k of a tile's 18.3 k cycles (s_memtime of workgroup 0, GOCTR_CHAIN_DBG=1) -- is requested while the previous tile's
+  // 5.2 k of a tile's 18.3 k cycles (s_memtime of workgroup 0, GOCTR_DBG=chain) -- is requested while the previous tile's
   // exchange and output unit run (below, behind F1), so only a launch's first tile per CU pays it.  (Training: one trip.)
   for (;;) {
   if (FWD) {
@@ -438,7 +441,8 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     // the next tile's rows and first weight chunks (workgroup-uniform branch): hv and the ring are free since F0, the layer-1
     // accumulators have just left for LDS.  In program order BEHIND every other load of this trip (the output unit's weights
     // are fetched before the loop): a wait for an earlier load never waits for these
-    next_tile = tile + (int)gridDim.x;
+    vblk += (int)gridDim.x;
+    next_tile = vblk < ntiles ? (a.xcd_affine ? xcd_unit_of_block(vblk, ntiles, 4) : vblk) : ntiles;
     if (next_tile < ntiles) {
       const int nrow = next_tile * 32 + n;
       load_hv(nrow < a.B ? nrow : a.B - 1);

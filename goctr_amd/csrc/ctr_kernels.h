@@ -272,9 +272,11 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
     }
   }
   // user / context side features: issue the loads first so they overlap the gather chain
-  float uside[2], cside[2];
+  float uside[2] = {0.f, 0.f}, cside[2] = {0.f, 0.f};
+  const bool side2 = a.U > 64 || a.C > 64;          // (wave-uniform: the reference's 52 / 53 columns fit one pass of the 64 lanes)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
+    if (k == 1 && !side2) break;
     const int ju = lane + 64 * k;
     if (KEYS) {
       uside[k] = (kurow && ju < a.U) ? kurow[ju] : 0.f;
@@ -319,13 +321,16 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
     if (KEYS) { if (tb0 + lane < kcnt) ids64 = s.ub_items[kb + tb0 + lane]; }
     else if (idm && valid && tb0 + lane < T) ids64 = s.ub_ids[gr * T + tb0 + lane];
   }
+  // (compile-time modes: a slot's id is checked ONCE, in its own lane -- missing, out of range and slots past T all become the
+  // all-zero row V -- instead of once per pass behind the shuffle)
+  if (FAST) ids64 = (unsigned)ids64 < (unsigned)s.V ? ids64 : (int)s.V;
   auto load_block = [&](int tbx, float (&xx)[NPB][VEC]) {
 #pragma unroll
     for (int p = 0; p < NPB; ++p) {
       const int t = tbx + p * RPP + rl;
       if (idm) {
         const int id = __shfl(ids64, (tbx - tb0) + p * RPP + rl, 64);
-        if (FAST) load_row_off32<VEC>(s.emb, (t < T && id >= 0 && id < s.V) ? id : (int)s.V, D, d0, xx[p]);
+        if (FAST) load_row_off32<VEC>(s.emb, id, D, d0, xx[p]);
         else load_row_nn<VEC>(s.emb + (long long)((t < T && id >= 0 && id < s.V) ? id : s.V) * D, d0, D, full, xx[p]);
       } else {
         load_row<VEC>((valid && t < T) ? s.X + gr * (long long)s.xcols + s.r_ub + t * D : nullptr, d0, D, xx[p]);
@@ -404,7 +409,8 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
     for (int p = 0; p < NPB; ++p) {
       const int t = tb + p * RPP + rl;
       const float g = din ? __shfl(g_l, p * RPP + rl, 64) : 1.0f;
-      if (t < T) {
+      // (compile-time modes: a slot past T holds the all-zero row and a finite gate -- adding g * 0 leaves the same bits)
+      if (FAST || t < T) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) psum[e] += g * x[p][e];
       }
@@ -436,6 +442,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
+    if (k == 1 && !side2) break;
     const int j = lane + 64 * k;
     if (j < a.U) hrow[j] = uside[k];
     if (j < a.C) hrow[a.U + 2 * D + j] = cside[k];

@@ -50,7 +50,7 @@ struct EmbTrainArgs {
   int W; long long Vw;
   long long* accum;                // [min(V, B (T+1)), D]
   float lr;
-  int dbg;                         // timing experiments only (GOCTR_EMB_DBG): 1 skip the flush, 2 skip cache misses, 4 skip LDS adds
+  int dbg;                         // timing experiments only (always 0 in the library; scripts/ubench builds set bits): 1 skip the flush, 2 skip cache misses, 4 skip LDS adds
 };
 
 constexpr unsigned int EMB_MULTI = 0xFFFFFFFFu;

@@ -268,15 +268,6 @@ int engine_bind(Engine& e, int device_ordinal) {
   GOCTR_CHECK(!e.inited, "goctr_init: engine %d is already bound to device %d (asked for %d); one engine, one device", e.index,
               e.device, device_ordinal);
   GOCTR_HIP(hipSetDevice(device_ordinal));
-  {
-    // GOCTR_SYNC=spin|yield|block (experiments): how the host waits in goctr_sync / blocking copies
-    const char* sm = getenv("GOCTR_SYNC");
-    if (sm && *sm) {
-      const unsigned f = sm[0] == 's' ? hipDeviceScheduleSpin : (sm[0] == 'y' ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync);
-      (void)hipSetDeviceFlags(f);
-      (void)hipGetLastError();
-    }
-  }
   hipDeviceProp_t prop;
   GOCTR_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   GOCTR_CHECK(strncmp(prop.gcnArchName, "gfx950", 6) == 0,

@@ -631,7 +631,7 @@ struct MlpChainArgs {
   int n, F, up0, units1, up1, upL, act;
   const double* W0img; const double* W2;
   double* A0; double* D1; double* A2; double* D2; double* lossterm; double* slab1;
-  unsigned long long* dbg;    // GOCTR_MLP_DBG: cycle stamps of workgroup 0, [wave][5]
+  unsigned long long* dbg;    // GOCTR_DBG=mlp: cycle stamps of workgroup 0, [wave][5]
 };
 
 // NFULL >= 0: the number of full 16-k chunks of a row (F / 16) is a compile-time constant and the product loop is
@@ -1037,7 +1037,7 @@ int launch_nn64(const double* A, int lda, const double* Bm, int ldb, int M, int 
 // A tiles per workgroup of mlp_tn64_kernel: 3; GOCTR_MLP_TN_KTW=2 (78 KB of LDS: two workgroups fit a CU) exists for the
 // experiment "one workgroup's start-up, first loads and slab stores under the other's MFMAs" -- measured slower at cfg2
 // (45.4 vs 42.3 us per step with two per CU, 42.8 with one): co-resident f64-MFMA workgroups serialise
-int tn64_ktw() { return env_int_mlp("GOCTR_MLP_TN_KTW", 3) == 2 ? 2 : 3; }
+int tn64_ktw() { return 3; }
 int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int NT, int M, int rows_per_wg,
                 double* slabs) {
   if (NT <= 8) {
@@ -1120,7 +1120,6 @@ int tn_rows64(const goctr_mlp* p, int n) {
     if (k > kb) kb = k;
   }
   int cus = engine().compute_units > 0 ? engine().compute_units : 256;
-  cus *= env_int_mlp("GOCTR_MLP_TN_WGS_PER_CU", 1);
   const int S = cus / kb > 0 ? cus / kb : 1;
   int rows = (int)cdiv(n, S);
   rows = rows < 32 ? 32 : round_up(rows, 2);
@@ -1152,13 +1151,13 @@ int ensure_ws(goctr_mlp* p, int n) {
 // the max-abs normalisation run over all n rows (forward_rows in oracle/orc_sklmlp.c spells out the row counts).
 int forward(goctr_mlp* p, int n, bool train, bool generic = false, int valid = -1) {
   if (valid < 0) valid = n;
-  if (!generic && valid == n && p->fused_ok() && p->W0img.p && env_int_mlp("GOCTR_MLP_NO_FUSED", 0) == 0) {
+  if (!generic && valid == n && p->fused_ok() && p->W0img.p) {
     const int up0 = p->up[0], up1 = p->up[1], upL = p->up[2];
     const int ng = (int)cdiv(up1, 32);
     if (p->zpart.ensure((size_t)ng * n, false)) return -1;
     const size_t lds = sizeof(double) * (size_t)up0 * 32;
     static DevBuf<unsigned long long> dbgb;
-    const bool dbg = env_int_mlp("GOCTR_MLP_DBG", 0) != 0;
+    const bool dbg = dbg_on("mlp");
     if (dbg && !dbgb.p && dbgb.alloc(4)) return -1;
     unsigned long long* dbgp = dbg ? dbgb.p : nullptr;
     hipLaunchKernelGGL((mlp_fwd_kernel<24>), dim3((unsigned)cdiv(n, 64), ng), dim3(256), lds, engine().stream, p->A[0].p, up0,
@@ -1239,7 +1238,7 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance, int valid = -1) 
   for (int l = 0; l < L; ++l)
     a.L[l] = {p->units[l], p->units[l + 1], p->up[l], p->up[l + 1], p->woff[l], p->poff[l], p->slabs[l].p,
               (int)cdiv(n, tn_rows64(p, n)), p->WT[l].p, 0};
-  if (chain) { a.L[1].nslabs = (int)cdiv(n, 16); a.L[1].coop = env_int_mlp("GOCTR_MLP_COOP", 1); }
+  if (chain) { a.L[1].nslabs = (int)cdiv(n, 16); a.L[1].coop = 1; }
   a.nflat = p->nflat; a.nparams = p->nparams;
   a.W = p->W.p; a.G = p->G.p; a.Mo = p->Mo.p; a.Vo = p->Vo.p; a.Vel = p->Vel.p;
   a.alpha = p->cfg.alpha; a.n = valid; a.solver = p->cfg.solver; a.do_update = do_update ? 1 : 0;
@@ -1340,7 +1339,7 @@ int train_step_resident(goctr_mlp* p, bool use_state, long long start, bool gene
   if (valid < 0) valid = B;
   if (valid < B) generic = true;
   if (weight_decay(p)) return -1;
-  if (!generic && p->chain_ok() && p->W0img.p && env_int_mlp("GOCTR_MLP_CHAIN", 1) != 0 && env_int_mlp("GOCTR_MLP_NO_FUSED", 0) == 0) {
+  if (!generic && p->chain_ok() && p->W0img.p) {
     MlpChainArgs c{};
     c.X = p->Xr.p; c.Y = p->Yr.p; c.perm = p->perm.n > 1 ? p->perm.p : nullptr;
     c.st = p->st.p; c.st_step = p->st_step.p; c.start_fixed = start; c.use_state = use_state ? 1 : 0; c.batch = B;
@@ -1349,12 +1348,12 @@ int train_step_resident(goctr_mlp* p, bool use_state, long long start, bool gene
     c.A0 = p->A[0].p; c.D1 = p->D[1].p; c.A2 = p->A[2].p; c.D2 = p->D[2].p; c.lossterm = p->lossterm.p; c.slab1 = p->slabs[1].p;
     const int ng = (int)cdiv(p->up[1], 32);
     static DevBuf<unsigned long long> dbgb;
-    const bool dbg = env_int_mlp("GOCTR_MLP_DBG", 0) != 0;
+    const bool dbg = dbg_on("mlp");
     if (dbg && !dbgb.p && dbgb.alloc(20)) return -1;
     c.dbg = dbg ? dbgb.p : nullptr;
     const dim3 cg((unsigned)cdiv(B, 16)), cb(64 * ng);
     // F = 281 (BASELINE configs[1], the MovieLens feature row of example/movielens) gets the straight-line product loop
-    const bool s17 = (p->units[0] >> 4) == 17 && env_int_mlp("GOCTR_MLP_CHAIN_STATIC", 1) != 0;
+    const bool s17 = (p->units[0] >> 4) == 17;
     switch (p->cfg.activation) {
       case GOCTR_ACT_LOGISTIC:
         if (s17) hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_LOGISTIC, 17>), cg, cb, 0, engine().stream, c);
@@ -1556,7 +1555,7 @@ static int run_fused_steps(goctr_mlp* p, int n_steps) {
     // Built with the single-step graph, so that a first call inside a timed region does not pay for a capture.
     static const int kMulti[2] = {8, 2};
     int i = 0;
-    if (env_int_mlp("GOCTR_MLP_GRAPH_STEPS", 1) != 0) {
+    {
       for (int z = 0; z < 2; ++z) {
         if (!p->multi_graph[z]) {
           if (capture_graph(e.stream, &p->multi_graph[z], [&] {

@@ -984,8 +984,8 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     // what the ranks learn beside each other is AVERAGED at the exchange (exchange_deltas), so the learning of an interval is
     // what ONE rank's streams make of it -- more, shorter streams per rank make less of it.  Measured at cfg5 on W = 8 ranks
     // (profiles/r05_w2v_dp_gpu_sweep.txt; oracle 0.5587): 256 positions per stream 0.5962, 1024 0.5738, 4096 0.5679.
-    const int min_pos = env_int_w2v(dp ? "GOCTR_W2V_MIN_POS_DP" : "GOCTR_W2V_MIN_POS", dp ? 2048 : 256);
-    if (env_int_w2v("GOCTR_W2V_MIN_POS", 256) > 0 && min_pos > 0) {
+    const int min_pos = dp ? 2048 : 256;
+    {
       const int64_t cap = std::max<int64_t>(1, w->n_words / min_pos);
       if ((int64_t)streams > cap) streams = (int)cap;
     }
@@ -1022,9 +1022,9 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     //   JB 4,  8 lanes x 2, WPS 4, PF 8, 384 hot rows       426 M           1.55                       0.5695
     //   JB 4,  8 lanes x 2, WPS 4, PF 8, 256 hot rows       412 M                                      0.5654   <- default
     const int jb = sg_hs ? env_int_w2v("GOCTR_W2V_JB", dimr >= 16 ? 4 : 3) : 0;
-    const int cpl = jb > 0 && dimr >= 16 ? env_int_w2v("GOCTR_W2V_CPL", 2) : 1;
-    const int wps = jb > 0 ? env_int_w2v("GOCTR_W2V_WPS", cpl > 1 ? 4 : 8) : 8;
-    const int pf = env_int_w2v("GOCTR_W2V_PF", cpl > 1 ? 8 : 2);
+    const int cpl = jb > 0 && dimr >= 16 ? 2 : 1;
+    const int wps = jb > 0 && cpl > 1 ? 4 : 8;
+    const int pf = cpl > 1 ? 8 : 2;
     const int GSr = dimr / (cpl > 1 ? 2 : 1);                                  // lanes per group
     const int HOT = jb > 0 ? hog_hot_doubles(wps) : HOG_HOT_DOUBLES;
     // hot rows cached in LDS per workgroup: the heaviest Huffman nodes are the LAST merges (weights are non-decreasing
@@ -1052,11 +1052,11 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
       w->n_hot_words = nh;
     }
     hot.n_words = w->n_hot_words; hot.word_slot = w->hot_word_slot.p; hot.word_id = w->hot_word_id.p;
-    hot.merge_every = std::max(1, env_int_w2v("GOCTR_W2V_MERGE", 32));   // (round 4: 16 -> 32 with the larger hot set: 229 -> 235 M words/s, same loss; 64: no further gain)
+    hot.merge_every = 32;   // (round 4: 16 -> 32 with the larger hot set: 229 -> 235 M words/s, same loss; 64: no further gain)
     const int nwg = (int)cdiv(streams, HOG_THREADS / GSr);
     if (w->hot_base.ensure((size_t)nwg * 2 * HOT, false)) return -1;
     hot.base = w->hot_base.p;
-    hot.merge_scale = env_int_w2v("GOCTR_W2V_AVG", 1) ? 1.0 / (double)nwg : 1.0;
+    hot.merge_scale = 1.0 / (double)nwg;
     {
       long long longest = 0;
       for (int k = 0; k < streams; ++k) longest = std::max(longest, idx[k + 1] - idx[k]);
@@ -1108,7 +1108,7 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
 #undef GOCTR_HOG_MO
 #undef GOCTR_HOG_ARGS
     GOCTR_HIP(hipGetLastError());
-    if (dp && exchange_deltas(w, env_int_w2v("GOCTR_W2V_EXCHANGE_SUM", 0) == 0)) return -1;
+    if (dp && exchange_deltas(w, true)) return -1;
     }   // segments
   }
   if (dp && w->cfg.deterministic && exchange_deltas(w, false)) return -1;
@@ -1310,8 +1310,6 @@ int goctr_huffman_build(const int64_t* counts, int64_t V, int max_depth, int64_t
     std::vector<long long> c64(counts, counts + V);
     if (huffman_build_device(c64.data(), V, max_depth, off, nd, cd, &tot, parts)) return -1;
     if (build_ms) *build_ms = parts[3];
-    if (getenv("GOCTR_HUFFMAN_PARTS")) fprintf(stderr, "huffman V=%lld: sort+d2h %.2f ms, host merge %.2f ms, device lengths+scan+fill %.2f ms, total %.2f ms\n",
-                                             (long long)V, parts[0], parts[1], parts[2], parts[3]);
     std::vector<long long> ho((size_t)V + 1);
     if (off.download(ho.data(), ho.size())) return -1;
     for (size_t i = 0; i < ho.size(); ++i) path_off[i] = ho[i];

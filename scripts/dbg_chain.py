@@ -8,5 +8,5 @@ tab = gm.EmbeddingTable(emb); ds = gm.Dataset.ids(ub, it, uf, cf, y)
 m = gm.DinNet(52,50,16,16,53); bench.init_weights(m,1)
 cfg = capi.default_train_cfg(batch=8192, epochs=1)
 gm.train_steps(m, ds, cfg, 20, emb=tab); capi.sync()
-os.environ["GOCTR_CHAIN_DBG"]="1"; os.environ["GOCTR_TN_DBG"]="1"
+os.environ["GOCTR_DBG"]="chain,tn"
 gm.train_steps(m, ds, cfg, 4, emb=tab); capi.sync()

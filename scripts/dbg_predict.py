@@ -10,5 +10,5 @@ m = gm.DinNet(52, 50, 16, 16, 53); bench.init_weights(m, 1)
 for _ in range(3):
     gm.predict_dataset(m, ds, 4096, emb=tab)
 capi.sync()
-os.environ["GOCTR_CHAIN_DBG"] = "1"
+os.environ["GOCTR_DBG"] = "chain"
 gm.predict_dataset(m, ds, 4096, emb=tab); capi.sync()
