@@ -1088,6 +1088,9 @@ int run_pass(goctr_w2v* w, int64_t corpus_len, double* lr_io) {
     }
     if (jb > 0) {
       GOCTR_NM(8, 2, 4, 4, 8) GOCTR_NM(16, 2, 4, 4, 8) GOCTR_NM(32, 2, 4, 4, 8)      // dim <= 16 / 32 / 64: the default shapes
+      // (round 6, VERDICT r5 item 5 -- the 2-pair chunk on 8 wavefronts per SIMD, <8, 2, 2, 8, 4>: the compiler's resource report at
+      // 64 registers is 63 spilled (the 1-pair chunk: 41; round 4's 4-pair chunk: 38-43) -- the walk's addresses, stream state and
+      // float64 pairs alone exceed 64 registers, so 8 wavefronts per SIMD would run out of scratch memory; profiles/r06_w2v_regs.txt)
       GOCTR_NM(8, 1, 3, 8, 2)                                                      // dim <= 8
       GOCTR_NM(16, 1, 3, 8, 2) GOCTR_NM(8, 2, 4, 4, 4)                             // (A/B: one component per lane; shallower prefetch)
       GOCTR_CHECK(launched, "goctr_w2v: no node-major kernel for lanes %d x %d components, JB %d, WPS %d, PF %d", GSr, cpl, jb, wps, pf);
