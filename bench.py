@@ -651,6 +651,30 @@ def bench_knn(args):
         regions.append(time.perf_counter() - t0)
     if gc_off:
         gc.enable()
+    dt_py = sorted(regions)[(len(regions) - 1) // 2]
+    regions_py = regions
+    # The same closed loop from a COMPILED host (goctr_amd/host/knn_bench.cpp: C++ above the C-ABI, the catalogue and queries drawn the
+    # same way): this Python loop pays ~10 us of interpreter per call (numpy allocations, ctypes marshalling) on top of a ~40 us call;
+    # the reference's host is Go.  `value` is the compiled host's figure when the binary is there, the Python loop's is on the line
+    # beside it (`python_loop`).
+    compiled = None
+    exe = os.path.join(ROOT, "goctr_amd", "host", "knn_bench")
+    if os.path.exists(exe) and os.environ.get("GOCTR_BENCH_KNN_COMPILED", "1") != "0":
+        import subprocess
+        try:
+            capi.sync()
+            r = subprocess.run([exe, "--items", str(V), "--dim", str(D), "--queries", str(Q), "--k", str(k), "--steps", str(steps),
+                                "--warmup", str(max(warm, 200)), "--regions", str(max(args.regions, 1))], capture_output=True, text=True, timeout=300)
+            compiled = json.loads(r.stdout.strip().splitlines()[-1])
+            # (64 queries per call is this line's choice; the same loop at 256 per call beside it)
+            r2 = subprocess.run([exe, "--items", str(V), "--dim", str(D), "--queries", "256", "--k", str(k), "--steps", str(steps),
+                                 "--warmup", "200", "--regions", "5"], capture_output=True, text=True, timeout=300)
+            compiled["at_256_queries_per_call"] = json.loads(r2.stdout.strip().splitlines()[-1])
+        except Exception as e:                       # noqa: BLE001
+            compiled = None
+            print(f"bench.py: knn_bench failed ({e}); reporting the Python loop", file=sys.stderr)
+    if compiled:
+        regions = [x * 1e-3 for x in compiled["timed_regions_ms"]]
     dt = sorted(regions)[(len(regions) - 1) // 2]
     qps = steps * Q / dt
     # ---- roofline of the IMPLEMENTED call (rounds 1-4 priced the reference's loop -- every query scans
@@ -668,6 +692,13 @@ def bench_knn(args):
            "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warm, "ms_per_step": round(dt / steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "timed_regions": len(regions), "timed_regions_ms": [round(x * 1e3, 4) for x in regions],
+           "harness": ("goctr_amd/host/knn_bench (C++ above the C-ABI: a closed loop of goctr_searcher_search calls, no interpreter between them)"
+                       if compiled else "this Python loop (ctypes)"),
+           "at_256_queries_per_call": ({k2: compiled["at_256_queries_per_call"][k2] for k2 in ("us_per_call", "queries_per_s", "timed_regions_ms")}
+                                       if compiled and compiled.get("at_256_queries_per_call") else None),
+           "python_loop": {"value": round(steps * Q / dt_py, 1), "ms_per_step": round(dt_py / steps * 1e3, 3),
+                           "timed_regions_ms": [round(x * 1e3, 4) for x in regions_py],
+                           "note": "the same calls driven from CPython: + the interpreter's per-call cost (numpy allocations, ctypes marshalling)"},
            "config": {"workload": "SURVEY 8(f)2: Searcher.Search, V=10^6, D=16 f64, k=10, 64 queries per call", "parallelism": "dp1"},
            "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "kernel": "knn_scan_bf16_kernel (the filter: every normalised row once per 64-query call, as two bf16 planes)"}}
@@ -728,14 +759,22 @@ def bench_single_process(args):
         m.set_embedding_training(args.train_emb)
     gm.train_steps(m, ds, cfg, args.warmup, emb=tab)            # (replicas, shards, graphs: built here, outside the timed regions)
     capi.sync()
-    regions = []
+    regions, per_rank = [], []
     for r in range(max(args.regions, 1)):
         capi.sync()
         t0 = time.perf_counter()
         gm.train_steps(m, ds, cfg, args.steps, first_batch=args.warmup + r * args.steps, emb=tab)
         capi.sync()
         regions.append(time.perf_counter() - t0)
-    dt = sorted(regions)[(len(regions) - 1) // 2]
+        # every rank's own span of the call on its own stream (goctr_engine_call_ms): the counterpart of the per-process wall times
+        # of the one-process-per-GPU line
+        try:
+            per_rank.append([capi.engine_call_ms(k) / 1e3 for k in range(N)])
+        except Exception:                       # noqa: BLE001
+            per_rank.append([regions[-1]] * N)
+    order = sorted(range(len(regions)), key=lambda i: regions[i])
+    med = order[(len(order) - 1) // 2]
+    dt = regions[med]
     # replicas must hold the same bits (same all-reduced gradient, same Adam)
     import zlib
     crcs = []
@@ -752,6 +791,8 @@ def bench_single_process(args):
            "dp_mode": "one process, goctr_init_devices + cfg.devices (RCCL ncclCommInitAll over distinct devices; loop-back communicator "
                       "when a device id repeats)",
            "timed_regions": len(regions), "timed_regions_ms": [round(x * 1e3, 4) for x in regions],
+           "per_rank_ms_per_step": [round(x / args.steps * 1e3, 4) for x in per_rank[med]],
+           "per_rank_basis": "device time of each rank's steps in the median region (events on the rank's own stream)",
            "replicas_bit_identical": len(set(crcs)) == 1}
     print(json.dumps(out), flush=True)
     if not out["replicas_bit_identical"]:

@@ -50,7 +50,7 @@ class W2vCfg(C.Structure):
 
 # every symbol include/goctr.h declares (tests/test_capi_symbols.py checks the list against the header)
 SYMBOLS = [
-    "goctr_init", "goctr_init_devices", "goctr_engine_count", "goctr_engine_select", "goctr_comm_group_enable", "goctr_device_count", "goctr_sync", "goctr_last_error", "goctr_version", "goctr_device_info",
+    "goctr_init", "goctr_init_devices", "goctr_engine_count", "goctr_engine_call_ms", "goctr_engine_select", "goctr_comm_group_enable", "goctr_device_count", "goctr_sync", "goctr_last_error", "goctr_version", "goctr_device_info",
     "goctr_comm_unique_id", "goctr_comm_init", "goctr_comm_world", "goctr_comm_capture_mode", "goctr_comm_allreduce_f64", "goctr_comm_destroy",
     "goctr_model_replica", "goctr_emb_replica", "goctr_model_create", "goctr_model_destroy", "goctr_model_set_weights", "goctr_model_get_weights",
     "goctr_model_reset_optimizer", "goctr_model_get_moments", "goctr_model_set_moments", "goctr_model_get_step",
@@ -145,6 +145,13 @@ def engine_count() -> int:
     n = C.c_int(0)
     check(load().goctr_engine_count(C.byref(n)))
     return n.value
+
+
+def engine_call_ms(k: int) -> float:
+    """device time rank k spent in its part of the last multi-device training call (goctr_engine_call_ms)"""
+    ms = C.c_double(0.0)
+    check(load().goctr_engine_call_ms(C.c_int(k), C.byref(ms)))
+    return ms.value
 
 
 def engine_select(k: int):

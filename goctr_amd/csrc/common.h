@@ -82,6 +82,8 @@ struct Engine {
   // of the group is a single-device call.  goctr_comm_init's communicator (one process per GPU) is always on.
   bool comm_enabled = true;
   int capture_state = 0;          // comm_capture_selftest: 0 not tested, 1 captured collectives work, -1 they do not
+  // goctr_engine_call_ms: events around this rank's part of the last multi-device training call (train_multi)
+  hipEvent_t call_begin = nullptr, call_end = nullptr; bool call_timed = false;
   bool comm_active() const { return (nccl_comm != nullptr || loop != nullptr) && comm_enabled; }
   // rank / world of the CALL in flight: a group engine running a single-device call is rank 0 of 1
   int eff_rank() const { return comm_active() ? rank : 0; }

@@ -2654,7 +2654,12 @@ int train_multi(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr_tr
       if (!r && d->has_y) r = scatter_array(&pY, pY.per, dk->Y.p);
       if (!r && k == 0) r = hipStreamSynchronize(e.stream) == hipSuccess ? 0 : -1;     // (the staging buffers are released after the call)
     }
+    // (goctr_engine_call_ms: this rank's own span of the call on its own stream -- bench.py --single-process reports it per rank)
+    if (!e.call_begin) { (void)hipEventCreate(&e.call_begin); (void)hipEventCreate(&e.call_end); }
+    e.call_timed = false;
+    if (!r && e.call_begin) (void)hipEventRecord(e.call_begin, e.stream);
     if (!r) r = per_rank(mk, ek, dk, &lcfg, k);
+    if (!r && e.call_end) e.call_timed = hipEventRecord(e.call_end, e.stream) == hipSuccess;
     if (r) {
       const std::string msg = goctr_last_error();
       comm_abort_on_failure();

@@ -382,6 +382,18 @@ int goctr_engine_count(int* n) {
   return 0;
 }
 
+int goctr_engine_call_ms(int k, double* ms) {
+  Engine* e = engine_at(k);
+  GOCTR_CHECK(e && e->inited && ms, "goctr_engine_call_ms: engine %d does not exist (goctr_init_devices made %d)", k, engine_count());
+  GOCTR_CHECK(e->call_timed, "goctr_engine_call_ms: engine %d has not taken part in a multi-device training call", k);
+  EngineScope on(e);
+  GOCTR_HIP(hipEventSynchronize(e->call_end));
+  float f = 0.f;
+  GOCTR_HIP(hipEventElapsedTime(&f, e->call_begin, e->call_end));
+  *ms = (double)f;
+  return 0;
+}
+
 int goctr_engine_select(int k) {
   Engine* e = engine_at(k);
   GOCTR_CHECK(e && e->inited, "goctr_engine_select: engine %d does not exist (goctr_init_devices made %d)", k, engine_count());

@@ -50,6 +50,9 @@ int goctr_init(int device_ordinal);
  * process of recommend.Train (recommend/rcmd.go:196-246) needs no launcher.  Idempotent for the same list. */
 int goctr_init_devices(int n, const int* device_ids);
 int goctr_engine_count(int* n);
+/* Tools: device time engine k (rank k) spent in its part of the LAST multi-device training call (cfg.devices = n): events on
+ * the rank's own stream around its steps; waits for that rank's part to finish.  bench.py --single-process reports it per rank. */
+int goctr_engine_call_ms(int k, double* ms);
 /* Tools / tests: bind the CALLING THREAD to engine k for the handles it creates from now on (a Go caller would need
  * runtime.LockOSThread; the single-call entries above need neither this nor the next function). */
 int goctr_engine_select(int k);

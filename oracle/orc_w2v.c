@@ -285,6 +285,31 @@ void orc_w2v_train_slice(const orc_w2v_cfg* cfg, const int32_t* doc, int64_t lo,
   }
 }
 
+/* The same walk over positions [walk_lo, walk_hi) of a slice [clip_lo, clip_hi): windows are clipped at the SLICE's ends
+ * (model.go:60-77 clips to the goroutine's slice), not at the walked range's -- what one SEGMENT of a data-parallel pass of the
+ * device library does (csrc/w2v.hip: a pass is cut into segments with a parameter exchange after each; a stream's windows still
+ * reach into the neighbouring segments of its own piece).  Test infrastructure for tests/test_gpu_multi.py. */
+void orc_w2v_train_range(const orc_w2v_cfg* cfg, const int32_t* doc, int64_t clip_lo, int64_t clip_hi, int64_t walk_lo,
+                         int64_t walk_hi, const uint8_t* keep_mask, double* param, double* aux, int64_t V,
+                         const int64_t* path_off, const int32_t* path_nodes, const uint8_t* path_codes,
+                         const double* sigtab, orc_lcg* lcg, double* lr, int64_t* trained_cnt, int64_t corpus_len) {
+  w2v_ctx c = {cfg, param, aux, V, path_off, path_nodes, path_codes, sigtab, lcg};
+  double tmp[1024], agg[1024];
+  const int32_t* sl = doc + clip_lo;
+  const int64_t len = clip_hi - clip_lo;
+  for (int64_t pos = walk_lo - clip_lo; pos < walk_hi - clip_lo; pos++) {
+    if (!keep_mask || keep_mask[clip_lo + pos]) {
+      if (cfg->model == 0) skipgram_one(&c, sl, len, pos, *lr, tmp);
+      else cbow_one(&c, sl, len, pos, *lr, agg, tmp);
+    }
+    int64_t cnt = ++(*trained_cnt);
+    if (cnt % cfg->update_lr_batch == 0) {
+      if (*lr < cfg->min_lr) *lr = cfg->min_lr;
+      else *lr = cfg->init_lr * (1.0 - (double)cnt / (double)corpus_len);
+    }
+  }
+}
+
 /* Hogwild CPU baseline: word2vec.go:151-175 (threads = goroutines). Shared, unsynchronised
  * param / aux / LCG / lr, as in the reference; the per-word channel send is replaced by an atomic
  * counter (a faster observer than the reference's unbuffered channel). */

@@ -598,6 +598,20 @@ def w2v_train_slice(cfg, doc, lo, hi, keep_mask, param, aux, paths, sigtab, lcg,
     return lr_c.value, cnt_c.value
 
 
+def w2v_train_range(cfg, doc, clip_lo, clip_hi, walk_lo, walk_hi, param, aux, paths, sigtab, lcg, lr, trained_cnt, corpus_len):
+    """positions [walk_lo, walk_hi) of the slice [clip_lo, clip_hi) (windows clipped at the SLICE's ends): one segment of a
+    data-parallel pass of the device library.  In-place on param/aux; returns (lr, trained_cnt)."""
+    off, nodes, codes = paths
+    doc = np.ascontiguousarray(doc, np.int32)
+    lr_c = C.c_double(lr)
+    cnt_c = C.c_int64(trained_cnt)
+    lib().orc_w2v_train_range(C.byref(cfg), _p(doc, C.c_int32), C.c_int64(clip_lo), C.c_int64(clip_hi), C.c_int64(walk_lo),
+                              C.c_int64(walk_hi), None, _p(param, C.c_double), _p(aux, C.c_double), C.c_int64(param.shape[0]),
+                              _p(off, C.c_int64), _p(nodes, C.c_int32), _p(codes, C.c_uint8), _p(sigtab, C.c_double), C.byref(lcg),
+                              C.byref(lr_c), C.byref(cnt_c), C.c_int64(corpus_len))
+    return lr_c.value, cnt_c.value
+
+
 def w2v_train_hogwild(cfg, doc, threads, keep_mask, param, aux, paths, sigtab, lr, corpus_len):
     off, nodes, codes = paths
     doc = np.ascontiguousarray(doc, np.int32)

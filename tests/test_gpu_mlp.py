@@ -161,6 +161,32 @@ def test_multi_step_graphs_equal_eager_steps():
         assert np.array_equal(res[0], res[1])
 
 
+def test_slabs_through_the_l2_leave_the_same_bits():
+    """GOCTR_MLP_TN_WT=0 (plain slab stores in mlp_tn64_kernel) against the default (stores through the L2, sc1): where a store goes
+    does not change what is stored"""
+    import os
+    from goctr_amd import capi, mlp as gmlp
+    rng = np.random.default_rng(15)
+    n, F, B = 4096, 281, 1024
+    X = rng.random((n, F), dtype=np.float32)
+    Y = (rng.random(n) < 0.5).astype(np.float32)
+    units = [F, 100, 1]
+    res = []
+    for knob in (None, "0"):
+        if knob is not None:
+            os.environ["GOCTR_MLP_TN_WT"] = knob
+        try:
+            clf = gmlp.MLPClassifier([100], "relu", "adam", 1e-5)
+            clf.create(units, B, clf.init_params(units, np.random.default_rng(3)))
+            clf.upload(X, Y)
+            clf.train_steps(11)
+            capi.sync()
+            res.append(clf.get_params())
+        finally:
+            os.environ.pop("GOCTR_MLP_TN_WT", None)
+    assert np.array_equal(res[0], res[1])
+
+
 def test_reference_nn_forward_kat():
     """the reference-held 3-3-3 forward vector (nn/network_test.go:25-83, tests/golden/ref_kats.json) through the device
     MLP: units [3,3,3], relu hidden, logistic output = the KAT's ReLU and Sigmoid layers; float32 out (mlp.go:33-38)"""

@@ -341,6 +341,57 @@ def test_item2vec_single_call_hogwild(tmp_path, W):
     assert within > across + 0.2, (within, across)
 
 
+W2V_SEGMENTED_RULE = r'''
+from goctr_amd import embedding as ge
+sys.path.insert(0, %(root)r)
+from oracle import pyoracle as o
+rng = np.random.default_rng(8)
+V, n, dim, nseg = 60, 4000, 8, 3
+doc = np.concatenate([rng.integers(0, 30, size=n // 2), rng.integers(20, V, size=n // 2)]).astype(np.int32)   # rank 0 never sees words >= 30
+counts = np.bincount(doc, minlength=V) + 1
+p0 = (rng.random((V, dim)) - 0.5) / dim
+capi.engine_select(0)
+m = ge.Word2Vec(dim=dim, deterministic=False, streams=1, slices=1, rng=np.random.default_rng(4), devices=W)
+m.create(counts, param0=p0)
+m.train_pass(doc, n, None, lr=0.025)
+cuts = np.zeros(W + 1, np.int64)
+capi.check(capi.load().goctr_w2v_shard_cuts(C.c_int64(n), C.c_int(1), C.c_int(W), capi.ptr(cuts, C.c_int64)))
+# the rule, evaluated by the oracle: every rank walks segment s of ITS shard from the common snapshot (windows clipped at the shard's
+# ends, a fresh window-shrink stream per (rank, segment): csrc/w2v.hip seeds 1 + K ((rank << 20) + (segment << 32))), then every
+# row moves by the sum of the ranks' deltas divided by the number of ranks that changed it
+cfg = o.w2v_cfg(dim=dim, optimizer="hs")
+paths = o.huffman_paths(counts)
+sig = o.sigmoid_table()
+P, A = p0.copy(), np.zeros((V - 1, dim))
+K = 0x9E3779B97F4A7C15
+for s_ in range(nseg):
+    ds = []
+    for r in range(W):
+        lo, hi = int(cuts[r]), int(cuts[r + 1])
+        a0, a1 = lo + (hi - lo) * s_ // nseg, lo + (hi - lo) * (s_ + 1) // nseg
+        p, a = P.copy(), A.copy()
+        lcg = o.Lcg((1 + K * ((r << 20) + (s_ << 32))) %% (1 << 64))
+        o.w2v_train_range(cfg, doc, lo, hi, a0, a1, p, a, paths, sig, lcg, 0.025, 0, n)
+        ds.append((p - P, a - A))
+    for M, k in ((P, 0), (A, 1)):
+        d = sum(x[k] for x in ds)
+        cnt = sum((np.abs(x[k]).max(1) > 0).astype(np.float64) for x in ds)
+        M += d / np.maximum(cnt, 1.0)[:, None]
+np.savez(%(out)r, p=m.get_param(), a=m.get_aux(), ep=P, ea=A, p0=p0)
+'''
+
+
+def test_item2vec_segmented_exchange_matches_the_rule_per_segment(tmp_path):
+    """ADVICE r5: the Hogwild passes' exchange (csrc/w2v.hip exchange_deltas(avg): snapshot, w2v_touched_kernel, the all-reduce of
+    deltas and touched flags, w2v_apply_avg_kernel, the segmented launches) on TWO logical ranks with ONE stream each -- nothing to
+    race with, so the device must reproduce the rule evaluated by the oracle segment by segment (three segments, GOCTR_W2V_SEGMENTS=3;
+    words >= 30 only occur in rank 1's shard: those rows keep their whole update)"""
+    r = run_script(W2V_SEGMENTED_RULE, tmp_path, "w2vseg", W=2, env={"GOCTR_W2V_SEGMENTS": "3"})
+    assert np.max(np.abs(r["ep"] - r["p0"])) > 1e-3
+    assert np.max(np.abs(r["p"] - r["ep"])) <= 1e-9 and np.max(np.abs(r["a"] - r["ea"])) <= 1e-9
+    assert np.max(np.abs(r["p"][40:] - r["p0"][40:])) > 1e-4
+
+
 @pytest.mark.parametrize("W", [2, 4])
 def test_item2vec_delta_exchange(tmp_path, W):
     """item2vec, W ranks from W host threads: snapshot, local deterministic pass on the rank's corpus shard, all-reduce of
@@ -566,3 +617,6 @@ def test_bench_single_process_two_logical_ranks():
     d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * 8192 and d["config"]["parallelism"] == "dp2"
     assert d["replicas_bit_identical"] is True and d["value"] > 0 and len(d["timed_regions_ms"]) == 3
+    # (round 6) every rank's own device time of the median region, like the per-process wall times of the one-process-per-GPU line
+    per = d["per_rank_ms_per_step"]
+    assert len(per) == 2 and all(0 < p <= d["ms_per_step"] * 1.05 for p in per), (per, d["ms_per_step"])

@@ -122,14 +122,17 @@ def test_deterministic_lr_schedule_and_second_iteration(oracle):
     assert np.array_equal(m.get_param(), rp) and np.array_equal(m.get_aux(), rn)
 
 
+@pytest.mark.parametrize("jb", [None, "0"], ids=["node_major", "pair_major_GOCTR_W2V_JB_0"])
 @pytest.mark.parametrize("dim", [5, 8, 16, 20, 32, 64])
-def test_hogwild_one_stream_is_the_sequential_pass(dim):
+def test_hogwild_one_stream_is_the_sequential_pass(dim, jb, monkeypatch):
     """The node-major Hogwild kernel (JB pairs of a position per node visit, 1 or 2 components per lane, hot rows in LDS with
     merges) claims the SEQUENTIAL arithmetic within a stream.  With one stream there is nothing to race with, stream 0 draws its
     window shrinks from the reference's seed, and the observer estimate is the exact word count -- so a pass must reproduce
     the deterministic kernel (bit-exact vs the oracle, tests above) up to float64 rounding: the inner product is a DPP tree
     instead of the j = 0 .. dim - 1 loop, and a hot row's update goes through (copy - base)."""
     from goctr_amd import embedding as ge
+    if jb is not None:
+        monkeypatch.setenv("GOCTR_W2V_JB", jb)        # (the pair-major kernel, CBOW's and negative sampling's, for skip-gram + HS too)
     rng = np.random.default_rng(11)
     V, n = 70, 6000
     doc = corpus(rng, V, n)
