@@ -123,18 +123,25 @@ def kernel_work(train_emb=False):
 
 
 def chain_algorithmic_bytes(train_emb=False):
-    """HBM bytes the fused chain launch must move per training launch: h0 in; A0, A1, dz0, dz1, dz2, (DIN: dp,) yhat, loss
-    terms out -- padded widths, as stored (3 020 B per row at cfg3).  Where the launch ends with the
+    """HBM bytes the fused chain launch must move per training launch: h0 in; A0, dz0, dz1, yhat, loss terms out (until round 5 also
+    A1, dz2 and, DIN, dp) -- padded widths, as stored.  Where the launch ends with the
     attention backward: + the behaviour ids, gates and similarity weights in, the per-sample att0 terms out, and every
     distinct table row once (the rows themselves are gathered B x T times, from L2 at cfg3's 1.7 MB table)."""
     c = CFG
     I = c["U"] + 2 * c["D"] + c["C"]
     Ip, H1p, H2p = -(-I // 16) * 16, 208, 80
     Dp = -(-c["D"] // 16) * 16 if c["KIND"] == "din" else 0
-    n = 4 * c["B"] * (Ip + Dp + 2 * H1p + 2 * H2p + 16 + 3)
-    if attn_bwd_in_chain(train_emb):
-        Tp = -(-c["T"] // 16) * 16
-        n += 4 * c["B"] * (3 * c["T"] + Tp) + 4 * c["D"] * min(c["B"] * c["T"], c["V"])
+    Tp = -(-c["T"] // 16) * 16
+    ab = attn_bwd_in_chain(train_emb)
+    # round 6 (GOCTR_CHAIN_TILE_SUMS, default): dW2 and the att0 terms leave as per-tile sums ([B / 32] x (H2p + Tp) floats) instead of
+    # their operands A1 [B, H2p], dz2 [B, 16], the per-sample terms [B, Tp] -- and dp [B, Dp], whose only reader was the launch's own tail
+    sums = os.environ.get("GOCTR_CHAIN_TILE_SUMS", "1") != "0"
+    if sums:
+        n = 4 * c["B"] * (Ip + 2 * H1p + H2p + 3) + 4 * (c["B"] // 32) * (H2p + (Tp if ab else 0)) + (0 if ab else 4 * c["B"] * Dp)
+    else:
+        n = 4 * c["B"] * (Ip + Dp + 2 * H1p + 2 * H2p + 16 + 3)
+    if ab:
+        n += 4 * c["B"] * (3 * c["T"] + (0 if sums else Tp)) + 4 * c["D"] * min(c["B"] * c["T"], c["V"])
     return n
 
 
@@ -659,7 +666,9 @@ def bench_knn(args):
     # beside it (`python_loop`).
     compiled = None
     exe = os.path.join(ROOT, "goctr_amd", "host", "knn_bench")
-    if os.path.exists(exe) and os.environ.get("GOCTR_BENCH_KNN_COMPILED", "1") != "0":
+    # (not under the profiler: scripts/prof_workload.sh passes --no-serving, and a child process of a rocprofv3 --pmc run competes with
+    # its parent for the counters -- session r06_prof1 lost 40 minutes to ten 300-second time-outs)
+    if os.path.exists(exe) and os.environ.get("GOCTR_BENCH_KNN_COMPILED", "1") != "0" and not args.no_serving:
         import subprocess
         try:
             capi.sync()
