@@ -478,7 +478,7 @@ int init_kernel_attrs() {
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
       allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(gemm_tn_multi_x3w_kernel<9, 5>) || allow_big_lds(gemm_tn_multi_x3w_kernel<8, 5>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
-      allow_big_lds(ctr_chain_x3_kernel<15>) || allow_big_lds(ctr_chain_x3_kernel<9, false, true>) || chain_x3_fwd_attributes() ||
+      allow_big_lds(ctr_chain_x3_kernel<15>) || chain_x3_fwd_attributes() ||
       serve16_attributes()) return -1;
   done = true;
   return 0;
@@ -637,26 +637,9 @@ int rebuild_x3_images(goctr_model* m) {
 }
 
 template <int NCH0>
-void launch_chain_x3_n(const ChainX3Args& a, dim3 grid, hipStream_t s, bool fwd, bool head = false) {
+void launch_chain_x3_n(const ChainX3Args& a, dim3 grid, hipStream_t s, bool fwd) {
   if (fwd) launch_chain_x3_fwd(NCH0, a, grid, s);       // (ctr_fwd.hip: its own translation unit, see there)
-  else if (head && NCH0 == 9) hipLaunchKernelGGL((ctr_chain_x3_kernel<NCH0 == 9 ? 9 : 2, false, NCH0 == 9>), grid, dim3(512), chain_x3_lds_bytes<NCH0>(true), s, a);
   else hipLaunchKernelGGL((ctr_chain_x3_kernel<NCH0, false>), grid, dim3(512), chain_x3_lds_bytes<NCH0>(), s, a);
-}
-
-int attn_fast_mode(const goctr_model* m, const RowSource& src, int* groups);
-bool emb_plan_active(const goctr_model* m);
-bool chain_x3_ok(const goctr_model* m, const struct StepOpts& o, int B);
-// Round 6 experiment (GOCTR_CHAIN_HEAD=1): the attention forward as the training chain launch's head
-// (ctr_chain_x3.h cx_attn_head) -- the cfg3 shape family: DIN in id mode on a frozen D = 16 table, T <= 64, side blocks of at most 64
-// columns with U a multiple of 4 (the pooled segment's 16-byte stores), the 9-chunk input.  Then no launch computes h0 ahead of the
-// step (launch_forward skips attn_fwd, the step graphs are not pipelined: the step's last launch is reduce + Adam).
-bool chain_head_mode(const goctr_model* m, const RowSource& src) {
-  const goctr_ctr_cfg& c = m->cfg;
-  int groups = 0;
-  const int fast = attn_fast_mode(m, src, &groups);
-  return env_int("GOCTR_CHAIN_HEAD", 0) != 0 && c.kind == GOCTR_DIN && src.id_mode && c.D == 16 && c.T <= 64 && c.U <= 64 && c.C <= 64 &&
-         (c.U & 3) == 0 && m->x3_nch0 == 9 && m->emb_lr <= 0.f && (fast == 2 || fast == 3) && groups == 4 && !engine().comm_active() &&
-         env_int("GOCTR_CHAIN_ATTN_BWD", 1) != 0;
 }
 
 bool emb_plan_active(const goctr_model* m) { return m->emb_lr > 0.f && m->plan.valid; }
@@ -696,11 +679,6 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   m->att0_from_chain = tile_sums && m->attn_bwd_in_chain;
   a.tile_dw2 = m->dw2_from_chain ? m->tile_dw2.p : nullptr;
   a.tile_att0 = m->att0_from_chain ? m->tile_att0.p : nullptr;
-  const bool head = o.train && m->attn_bwd_in_chain && chain_head_mode(m, src);
-  if (head) {
-    a.hd_items = src.item_ids; a.hd_ufeat = src.ufeat; a.hd_cfeat = src.cfeat; a.hd_att0 = m->W.p + m->offa; a.hd_h0 = fb.h0;
-    a.hd_U = c.U; a.hd_C = c.C; a.hd_cos = c.att == GOCTR_ATT_COSINE ? 1 : 0;
-  }
   static DevBuf<unsigned long long> dbgbuf;
   const bool dbg = dbg_on("chain") && (hipStream_t)e.active == e.stream;   // (not from a serving slot)
   if (dbg && !dbgbuf.p && dbgbuf.alloc(8 * CX_NSTAMP)) return -1;
@@ -719,7 +697,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, kSym[m->x3_nch0 == 2 ? 0 : m->x3_nch0 == 9 ? 1 : 2][o.train ? 0 : 1]);
   switch (m->x3_nch0) {
     case 2: launch_chain_x3_n<2>(a, grid, e.active, !o.train); break;
-    case 9: launch_chain_x3_n<9>(a, grid, e.active, !o.train, head); break;
+    case 9: launch_chain_x3_n<9>(a, grid, e.active, !o.train); break;
     default: launch_chain_x3_n<15>(a, grid, e.active, !o.train); break;
   }
   GOCTR_HIP(hipGetLastError());
@@ -859,7 +837,6 @@ int attn_fast_mode(const goctr_model* m, const RowSource& src, int* groups) {
 // to hide, and a cross-stream edge in a captured graph costs ~6 us here; profiles/r05_fork_ab.txt, commits 0af81b4 .. ae775f3.)
 // can the steps of a graph be pipelined (reduce_attn_kernel)?  Single GPU, fused update, the fused chain, D = 16 or 64 rows
 bool pipeline_ok(const goctr_model* m, const RowSource& src) {
-  if (chain_head_mode(m, src)) return false;       // (the chain launch computes its own h0: nothing to pipeline)
   int groups = 0;
   const int fast = attn_fast_mode(m, src, &groups);
   // (DIN: one reduce block must own the whole att0 segment -- it publishes the flag the attention workgroups wait for)
@@ -902,7 +879,7 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
   Engine& e = engine();
   const StepState* st = st_override ? st_override : m->st_cur();
   const FwdBufs fb = fbp ? *fbp : train_bufs(m, m->stp);
-  if (!o.pipelined && !(o.train && chain_head_mode(m, src) && chain_x3_ok(m, o, B))) {
+  if (!o.pipelined) {
     AttnArgs aa = make_attn_args(m, src, B, st, fb);
     if (!o.train) { aa.gate = nullptr; aa.wgt = nullptr; }     // (only the backward reads them: 13 MB less per 32 768-row launch)
     if (launch_attn_fwd(aa)) return -1;

@@ -62,23 +62,15 @@ struct ChainX3Args {
   // dz2[row] (then A1 and dz2 are not stored at all), tile_att0 [tiles][ab_Tp] = the tile's sum of the att0 terms (then ab_out is
   // not stored).  The weight-gradient launch adds the tiles up (mfma_gemm.h tn_tile_sum_body).
   float* tile_dw2; float* tile_att0;
-  // Round 6: the attention FORWARD as this launch's head (HEAD = true instantiations; DIN, id mode, D = 16,
-  // T <= 64, U, C <= 64, frozen table).  Wavefront w gathers the rows of samples 4 w .. 4 w + 3 of the tile, computes their gates
-  // and pooled vectors with attn_fwd_body's arithmetic (ctr_kernels.h: same expressions in the same order => same bits), leaves the
-  // tile's h0 rows in LDS (the exchange area, free until F1) for the split into the fragment image and in hd_h0 for the
-  // weight-gradient launch, and the gates / similarity weights in LDS for the tail -- no h0, gate or weight round trip through memory,
-  // and the step's last launch is the plain reduce + Adam.
-  const int32_t* hd_items; const float* hd_ufeat; const float* hd_cfeat; const float* hd_att0; float* hd_h0;
-  int hd_U, hd_C, hd_cos;
   int xcd_affine;     // training launches: workgroup -> tile by xcd_unit_of_block (GOCTR_XCD_AFFINE=0: workgroup b takes tile b)
 };
 
 constexpr int CX_NSTAMP = 16;
 
 template <int NCH0>
-inline size_t chain_x3_lds_bytes(bool head = false) {
-  // h0 fragment image | Z1 / dp exchange (8 partials) | dz1 fragment image | z2 partials | (HEAD) gates, similarity weights [32][64]
-  return (size_t)NCH0 * 3 * 1024 + (size_t)8 * CX_NU * 4 * 1024 + (size_t)CX_NCH2 * 3 * 1024 + 8 * 32 * 4 + (head ? 2 * 32 * 64 * 4 : 0);
+inline size_t chain_x3_lds_bytes() {
+  // h0 fragment image | Z1 / dp exchange (8 partials) | dz1 fragment image | z2 partials
+  return (size_t)NCH0 * 3 * 1024 + (size_t)8 * CX_NU * 4 * 1024 + (size_t)CX_NCH2 * 3 * 1024 + 8 * 32 * 4;
 }
 
 // Experiment switches of scripts/ubench/chain_x3_bench.hip (never set in the library build): CX_EXP bit 0 = no A-operand
@@ -189,110 +181,23 @@ __device__ __forceinline__ void cx_ab_gather_one(const Args& a, const int (&abid
   abx[s][p][0] = t4.x; abx[s][p][1] = t4.y; abx[s][p][2] = t4.z; abx[s][p][3] = t4.w;
 }
 
-// The attention forward of wavefront w's four samples (ChainX3Args::hd_*).  attn_fwd_body<4, 4, 2 / 3>'s arithmetic, statement by
-// statement (lane = 4 rl + dl: slot 16 p + rl of pass p, embedding columns 4 dl .. 4 dl + 3); what differs is the ORDER OF THE
-// LOADS: one wavefront per sample at eight wavefronts per SIMD hides its three dependent round trips behind the others' work,
-// two wavefronts per SIMD do not -- so the four samples' loads go out together: ids, candidate ids and side features (round 1, the
-// ids by cx_ab_ids), then all 16 + 4 row gathers (round 2), then the arithmetic.
-template <class Args>
-__device__ __forceinline__ void cx_attn_head(const Args& a, int tile, int w, int lane, const int (&abid)[4], float* stage, float* lgate,
-                                             float* lwgt) {
-  const int T = a.ab_T, U = a.hd_U, Cn = a.hd_C, Ip = a.Ip, I = U + 32 + Cn;
-  const int dl = lane & 3, rl = lane >> 2;
-  const long long b0 = a.st->batch_idx * (long long)a.B;
-  const bool cosine = a.hd_cos != 0;
-  int it[4]; float us[4], cs[4]; bool val[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int b = tile * 32 + 4 * w + s;
-    const long long gr = b0 + b;
-    val[s] = b < a.B && gr < a.rows;
-    const long long grc = val[s] ? gr : 0;
-    const int itv = a.hd_items[grc];
-    it[s] = val[s] && (unsigned)itv < (unsigned)a.ab_V ? itv : (int)a.ab_V;
-    const float uv = a.hd_ufeat[grc * U + (lane < U ? lane : 0)], cv = a.hd_cfeat[grc * Cn + (lane < Cn ? lane : 0)];
-    us[s] = val[s] && lane < U ? uv : 0.f;
-    cs[s] = val[s] && lane < Cn ? cv : 0.f;
-  }
-  float x[4][4][4], vv[4][4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) load_row_off32<4>(a.ab_emb, __shfl(abid[s], 16 * p + rl, 64), 16, 4 * dl, x[s][p]);
-    load_row_off32<4>(a.ab_emb, it[s], 16, 4 * dl, vv[s]);
-  }
-  const float aw = lane < T ? a.hd_att0[lane < T ? lane : 0] : 0.f;
-  const float invT = 1.0f / (float)T;
-  const int src = (lane & 15) * 4, pw = lane >> 4;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int n = 4 * w + s;
-    float syy = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) syy += vv[s][e] * vv[s][e];
-    const float yn = sqrtf(group_sum<4>(syy));
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      float u0 = 0.f, u1 = 0.f;
-      if (cosine) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { u0 += x[s][p][e] * x[s][p][e]; u1 += x[s][p][e] * vv[s][e]; }
-        u0 = group_sum<4>(u0);
-        u1 = group_sum<4>(u1);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { const float df = x[s][p][e] - vv[s][e]; u0 += df * df; }
-        u0 = group_sum<4>(u0);
-      }
-      const float v0 = __shfl(u0, src, 64), v1 = __shfl(u1, src, 64);
-      if (pw == p) { s0 = v0; s1 = v1; }
-    }
-    float w_l;
-    if (cosine) {
-      const float cosv = s1 / (sqrtf(s0) * yn + 1e-8f);
-      w_l = (cosv + 1.0f) / 2.0f;
-    } else {
-      w_l = 1.0f - sqrtf(s0);
-    }
-    const float g_l = sigm_hidden(w_l * aw);
-    lgate[n * 64 + lane] = g_l;
-    lwgt[n * 64 + lane] = w_l;
-    float psum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const float g = __shfl(g_l, 16 * p + rl, 64);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) psum[e] += g * x[s][p][e];
-    }
-    cx_f4 pv;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) pv[e] = cross_row_sum<4>(psum[e]) * invT;
-    float* hrow = stage + n * Ip;
-    if (rl == 0) {
-      *reinterpret_cast<cx_f4*>(hrow + U + 4 * dl) = pv;
-      *reinterpret_cast<cx_f4*>(hrow + U + 16 + 4 * dl) = cx_f4{vv[s][0], vv[s][1], vv[s][2], vv[s][3]};
-    }
-    if (lane < U) hrow[lane] = us[s];
-    if (lane < Cn) hrow[U + 32 + lane] = cs[s];
-    if (I + lane < Ip) hrow[I + lane] = 0.f;
-  }
-}
-
+// (Round 6 built the attention FORWARD as this launch's head, as VERDICT r5 asked -- wavefront w gathering and pooling samples
+// 4 w .. 4 w + 3 with attn_fwd_body's arithmetic, h0 rows / gates / weights handed on in LDS, the step's last launch a plain reduce +
+// Adam: bit-identical to the separate launches, and 1.9 us per cfg3 step SLOWER (chain 20.8 -> 28.1 us, last launch 11.8 -> 6.0): the
+// ~330 vector instructions per sample cost the same wherever they run, and here they sit in front of a dependent pipeline instead of
+// beside a launch that waits on memory.  profiles/r06_chain_head.txt; commit 19008cd holds the code.)
 // FWD: forward only (predict at launch sizes that give every CU a 32-row tile: the products and epilogues up to the output
 // unit, no activations or deltas stored, no backward operands requested)
 #ifndef CX_FWD_NFP
 #define CX_FWD_NFP 4      // W0 chunks of the next tile requested a trip ahead by a forward-only launch (of the ring's 6)
 #endif
-template <int NCH0, bool FWD = false, bool HEAD = false>
+template <int NCH0, bool FWD = false>
 __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char cx_smem[];
   unsigned char* const h0img = cx_smem;                                         // [NCH0][3][64 lanes][16 B]
   float* const xch = reinterpret_cast<float*>(cx_smem + (size_t)NCH0 * 3 * 1024);   // [8 waves][NU][4 g][64][4]
   unsigned char* const dz1img = reinterpret_cast<unsigned char*>(xch) + (size_t)8 * CX_NU * 4 * 1024;   // [NCH2][3][64][16 B]
   float* const z2p = reinterpret_cast<float*>(dz1img + (size_t)CX_NCH2 * 3 * 1024);                     // [8][32]
-  float* const lgate = z2p + 8 * 32;                                                                    // (HEAD) [32][64] gates
-  float* const lwgt = lgate + 32 * 64;                                                                  // (HEAD) [32][64] similarity weights
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -333,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
       hv[cq][1] = *reinterpret_cast<const cx_f4*>(hp + c * 16 + 4);
     }
   };
-  if (!HEAD) load_hv(rowc);
+  load_hv(rowc);
   // ---------------------------------------------------------------- A-operand streams (global -> registers)
   // (not const: the forward-only tile loop re-derives them per trip from a laundered lane index -- otherwise the ~60
   // loop-invariant 64-bit fragment addresses are hoisted out of the loop and spilled, 138 registers' worth)
@@ -362,24 +267,6 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   int abid[4] = {-1, -1, -1, -1}; float abg[4] = {0.f, 0.f, 0.f, 0.f}, abw[4] = {0.f, 0.f, 0.f, 0.f};
   float abx[4][4][4];
   if (ab) cx_ab_ids(a, tile, w, lane, abid);
-  if (HEAD) {
-    // the tile's h0 rows: computed here, left in the exchange area (free until F1) and read back in load_hv's lane layout
-    float* const stage = xch;
-    cx_attn_head(a, tile, w, lane, abid, stage, lgate, lwgt);
-    __syncthreads();                                          // (0) the tile's h0 rows, gates and weights are in LDS
-    const float* hp = stage + (size_t)n * Ip + 8 * h;
-#pragma unroll
-    for (int cq = 0; cq < NHQ; ++cq) {
-      const int c = cq * 8 + w < NCH0 ? cq * 8 + w : NCH0 - 1;
-      hv[cq][0] = *reinterpret_cast<const cx_f4*>(hp + c * 16);
-      hv[cq][1] = *reinterpret_cast<const cx_f4*>(hp + c * 16 + 4);
-      if (vrow && cq * 8 + w < NCH0) {                        // the float32 rows for the weight-gradient launch
-        *reinterpret_cast<cx_f4*>(a.hd_h0 + (size_t)row * Ip + c * 16 + 8 * h) = hv[cq][0];
-        *reinterpret_cast<cx_f4*>(a.hd_h0 + (size_t)row * Ip + c * 16 + 8 * h + 4) = hv[cq][1];
-      }
-    }
-    // (the exchange area is written again behind F1, two barriers from here)
-  }
   // layer-1 columns this wavefront finishes after the exchange: group (u = w / 4, g = w % 4) and, for wavefronts 0..3,
   // (u = 2, g = w):  f = 32 u + 8 g + 4 h + r
   const int fA = 32 * (w >> 2) + 8 * (w & 3) + 4 * h, fB = 64 + 8 * (w & 3) + 4 * h;
@@ -683,15 +570,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra2[c][p]);
     CX_MMA6(ahb, acb, af, bf);
   }
-  if (ab && !HEAD) cx_ab_gw(a, tile, w, lane, abg, abw);
-  if (ab && HEAD) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bool in = tile * 32 + 4 * w + s < a.B && lane < a.ab_T;
-      abg[s] = in ? lgate[(4 * w + s) * 64 + lane] : 0.f;
-      abw[s] = in ? lwgt[(4 * w + s) * 64 + lane] : 0.f;
-    }
-  }
+  if (ab) cx_ab_gw(a, tile, w, lane, abg, abw);
   if (ab) {      // the behaviour rows of the remaining samples, in flight under the epilogue and the dp product
 #pragma unroll
     for (int k = 4 * CX_AB_EARLY; k < 16; ++k) cx_ab_gather_one(a, abid, lane, k >> 2, k & 3, abx);

@@ -84,7 +84,7 @@ def test_cfg4_youtube_6_pipelined_graph_steps_vs_oracle(oracle):
 
 
 @pytest.mark.parametrize("knob", ["GOCTR_PIPELINE", "GOCTR_GRAPH_STEPS", "GOCTR_NO_GRAPH", "GOCTR_CHAIN_ATTN_BWD", "GOCTR_CHAIN_TILE_SUMS",
-                                  "GOCTR_XCD_AFFINE", "GOCTR_TN_WT", "GOCTR_CHAIN_HEAD"])
+                                  "GOCTR_XCD_AFFINE", "GOCTR_TN_WT"])
 def test_id_mode_pipelined_graphs_equal_unpipelined_and_eager(knob):
     """id mode, B = 8192 (377 reduce blocks beside 2048 attention workgroups in the merged launch), dropout on, 39 steps =
     16 + 16 + 4 + 2 + 1: the default path and the path with the knob flipped must land on the same bits"""
@@ -102,8 +102,7 @@ def test_id_mode_pipelined_graphs_equal_unpipelined_and_eager(knob):
     # weight-gradient launch's MFMA problems instead of per tile in the chain launch -- another float32 summation order, compared
     # at 2e-6 below; the GOCTR_CHAIN_ATTN_BWD comparison is between the two stored-terms paths, i.e. with the tile sums off)
     flipped = {"GOCTR_PIPELINE": "0", "GOCTR_GRAPH_STEPS": "0", "GOCTR_NO_GRAPH": "1", "GOCTR_CHAIN_ATTN_BWD": "0",
-               "GOCTR_CHAIN_TILE_SUMS": "0", "GOCTR_XCD_AFFINE": "0", "GOCTR_TN_WT": "0", "GOCTR_CHAIN_HEAD": "1"}[knob]
-    # (GOCTR_CHAIN_HEAD=1: the attention forward as the chain launch's head -- attn_fwd_body's arithmetic statement by statement)
+               "GOCTR_CHAIN_TILE_SUMS": "0", "GOCTR_XCD_AFFINE": "0", "GOCTR_TN_WT": "0"}[knob]
     for val in (None, flipped):
         if val is not None:
             os.environ[knob] = val
