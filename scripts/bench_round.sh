@@ -9,6 +9,7 @@ timeout 400 python bench.py --workload youtube > $O/youtube.json 2> $O/youtube.e
 timeout 300 python bench.py --train-emb 0.05 > $O/din_trainemb.json 2> $O/din_trainemb.err
 timeout 400 python bench.py --workload youtube --train-emb 0.05 > $O/youtube_trainemb.json 2> $O/youtube_trainemb.err
 timeout 300 python bench.py --workload mlp > $O/mlp.json 2> $O/mlp.err
+timeout 300 python bench.py --workload mlp100k > $O/mlp100k.json 2> $O/mlp100k.err
 timeout 400 python bench.py --workload item2vec > $O/item2vec.json 2> $O/item2vec.err
 timeout 300 python bench.py --workload knn > $O/knn.json 2> $O/knn.err
 for f in $O/*.json; do python3 -c "
