@@ -136,7 +136,7 @@ int run_on_engines(int n, const std::function<int(int)>& fn);
 #define GOCTR_SAME_ENGINE(a, b) \
   GOCTR_CHECK(!(a) || !(b) || (a)->eng == (b)->eng, "%s: the handles were created on different engines (devices)", __func__)
 
-// phase stamps / debug prints of one kernel family: GOCTR_DBG=chain,tn,mlp (any subset; read at call time)
+// phase stamps / debug prints of one kernel family: GOCTR_DBG=chain,tn,mlp,knn (any subset; read at call time)
 inline bool dbg_on(const char* what) {
   const char* v = getenv("GOCTR_DBG");
   return v && *v && strstr(v, what) != nullptr;

@@ -817,6 +817,7 @@ AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepS
   aa.kind = c.kind; aa.att = c.att; aa.att0 = m->W.p + m->offa; aa.h0 = fb.h0; aa.gate = fb.gate; aa.wgt = fb.wgt;
   aa.Tp_att = m->Tp;
   aa.xcd_affine = env_int("GOCTR_XCD_AFFINE", 1);      // (ctr_kernels.h xcd_unit_of_block; a permutation of the workgroups' samples)
+  aa.inv_T = 1.0f / (float)c.T;
   return aa;
 }
 AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, int par) {

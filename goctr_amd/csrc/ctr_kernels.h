@@ -104,7 +104,15 @@ struct AttnArgs {
   float* wgt;   // [B, T]
   int Tp_att;   // (reduce_attn_kernel) padded length of the att0 segment of the flat parameter buffer
   int xcd_affine;   // training launches: workgroup -> four-sample group by xcd_unit_of_block (below)
+  float inv_T;      // 1.0f / (float)T, computed once on the host (the same IEEE division the kernels did per sample)
 };
+
+// Round 6: the attention's two square roots and its division as single v_sqrt_f32 / v_rcp_f32 issues (1 ulp each) instead of the
+// correctly rounded ~9- and ~11-instruction sequences -- like sigm_hidden's exp / rcp since round 1.  A similarity weight moves by
+// <= 3 ulp (4e-7), two orders below the 1e-5 the logits are held to; every attention variant shares attn_fwd_body, so all of this
+// library's paths still agree bit for bit.
+__device__ __forceinline__ float attn_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float attn_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // XCD affinity of batch rows (round 6, scripts/ubench/xcd_handoff.hip / profiles/r06_xcd_handoff.txt).  Workgroup b of a launch
 // runs on XCD b % 8 (observed on every box so far; HIP does not promise it, so nothing here depends on it for correctness), and
@@ -304,7 +312,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
   float syy = 0.f;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) syy += vv[e] * vv[e];
-  const float yn = sqrtf(group_sum<LPR>(syy));
+  const float yn = attn_sqrt(group_sum<LPR>(syy));
 
   float psum[VEC];
 #pragma unroll
@@ -371,10 +379,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
         if (pw == p) { s0 = v0; s1 = v1; }
       }
       if (cosine) {
-        const float cosv = s1 / (sqrtf(s0) * yn + 1e-8f);
+        const float cosv = s1 * attn_rcp(attn_sqrt(s0) * yn + 1e-8f);
         w_l = (cosv + 1.0f) / 2.0f;
       } else {
-        w_l = 1.0f - sqrtf(s0);
+        w_l = 1.0f - attn_sqrt(s0);
       }
       const int tl = tb + lane;
       float aw = 0.f;
@@ -418,7 +426,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
   }
   }
   // mean over T as a multiply by 1/T (one division per sample instead of one per column; <= 1 ulp from x / T)
-  const float invT = 1.0f / (float)T;
+  const float invT = a.inv_T;
   float* hrow = a.h0 + (size_t)b * a.Ip;
   if (VEC == 4 && (a.U & 3) == 0 && (a.Ip & 3) == 0 && (D & 3) == 0) {
     // pooled sum and candidate embedding as two 16-byte stores from the first row group

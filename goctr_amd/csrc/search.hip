@@ -562,7 +562,8 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
                                                           const double* __restrict__ queries, const float* __restrict__ q32,
                                                           const long long* __restrict__ ignore, const float* __restrict__ tmax,
                                                           const float* __restrict__ bmax, int qpad, int nt, int tile_items, int sb_mode,
-                                                          int k, float E, long long* out_idx, double* out_sim, int* out_cnt, int host_polls) {
+                                                          int k, float E, long long* out_idx, double* out_sim, int* out_cnt, int host_polls,
+                                                          unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) double knn_cq[];       // [D] the query | its norm | [D] floats: normalised | the replay's arrays
   float* cq32 = reinterpret_cast<float*>(knn_cq + D + 1);
   double* s_sim = knn_cq + D + 1 + (D + 1) / 2;                          // [CAP] candidates' similarities
@@ -576,6 +577,9 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   __shared__ int my_blocks[KNN2_MYB];
   __shared__ int n_blk, n_cand;
   const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // GOCTR_DBG=knn: phase stamps of workgroup 0, thread 0
+  auto stamp = [&](int i) { if (dbg && q == 0 && threadIdx.x == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
   const float* tm = tmax + (size_t)q * nt;
   for (int d = threadIdx.x; d < D; d += 256) { knn_cq[d] = queries[(size_t)q * D + d]; cq32[d] = q32[(size_t)q * D + d]; }
   if (threadIdx.x == 0) { n_blk = 0; n_cand = 0; }
@@ -584,6 +588,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   gmax[threadIdx.x] = m;
   const long long ig = ignore[q];
   __syncthreads();
+  stamp(1);
   {
     const int rounds = k + (ig >= 0 ? 1 : 0);
     int rank = 0;
@@ -600,6 +605,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
     }
   }
   __syncthreads();
+  stamp(2);
   const float tb = sh_tb;
   const double qn = knn_cq[D];
   const double bd = (double)sh_sb;
@@ -628,6 +634,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
       __syncthreads();
     }
     if (base > KNN2_MYT) { give_up(); return; }               // (uniform)
+    stamp(3);
     // ---- their sub-blocks whose own maximum reaches the bound
     const int sb_items = sb_mode == 0 ? 32 : 16 * (tile_items / 256);
     const int SB = tile_items / sb_items;
@@ -640,6 +647,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
       }
     }
     __syncthreads();
+    stamp(4);
     const int nblk = n_blk;
     if (nblk > KNN2_MYB) { give_up(); return; }
     // ---- float32 filter over the listed sub-blocks' items, exact similarity of the survivors
@@ -718,6 +726,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
     }
   }
   __syncthreads();
+  stamp(5);
   const int n = n_cand;
   if (n > KNN2_CAP) { give_up(); return; }
   // ---- replay: sort by item index (an item appears once): own entries to registers, ranks from LDS, write back in order
@@ -767,6 +776,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
     if (lane < k) { nb_s[lane] = s; nb_i[lane] = id; }
   }
   __syncthreads();
+  stamp(6);
   int cnt = 0;
   for (int r = 0; r < k; ++r) cnt += nb_i[r] >= 0;
   for (int r = threadIdx.x; r < k; r += 256) { out_idx[(size_t)q * k + r] = nb_i[r]; out_sim[(size_t)q * k + r] = nb_s[r]; }
@@ -779,6 +789,12 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
     __syncthreads();                                                                                // no invalidate of the L2 under the others
     if (threadIdx.x == 0) __hip_atomic_store(out_cnt + q, n_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   } else if (threadIdx.x == 0) out_cnt[q] = n_out;
+  stamp(7);
+  if (dbg && q == 0 && threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dbg[i] = ts[i];
+    dbg[8] = (unsigned long long)n; dbg[9] = (unsigned long long)n_blk;
+  }
 }
 
 }  // namespace
@@ -913,10 +929,22 @@ static int knn_search_scan(goctr_searcher* s, const double* queries, int Q, int 
   // collect + exact refine + replay: one workgroup per query (sub-block layout: 32 consecutive items from the matrix-core scan
   // kernels, the rows of 16 adjacent threads from the VALU one)
   const int sb_mode = bf ? 0 : 1;
+  static DevBuf<unsigned long long> knn_dbg;
+  const bool want_dbg = dbg_on("knn");
+  if (want_dbg && !knn_dbg.p && knn_dbg.alloc(16)) return -1;
+  unsigned long long* kdbg = want_dbg ? knn_dbg.p : nullptr;
   const size_t lds_q = sizeof(double) * ((size_t)D + 1 + ((size_t)D + 1) / 2);      // [D] query | norm | [D] floats (rounded up to doubles)
   hipLaunchKernelGGL(knn_collect_kernel, dim3(Q), dim3(256), lds_q + lds_r, e.stream, s->items.p, s->norms.p, s->items32.p, (long long)s->V, D,
-                     d_q, d_q32, d_ig, s->tmax.p, s->bmax.p, qpad, nt, tile_items, sb_mode, k, E, d_oi, d_os, d_oc, poll ? 1 : 0);
+                     d_q, d_q32, d_ig, s->tmax.p, s->bmax.p, qpad, nt, tile_items, sb_mode, k, E, d_oi, d_os, d_oc, poll ? 1 : 0, kdbg);
   GOCTR_HIP(hipGetLastError());
+  if (kdbg) {
+    unsigned long long h[10];
+    if (knn_dbg.download(h, 10)) return -1;
+    fprintf(stderr, "knn_collect query 0 (s_memtime ticks): query + tile maxima %llu | bound (rank of 256 group maxima) %llu | tile list %llu | "
+            "sub-block maxima + list %llu | float32 filter + exact scores %llu | sort + replay %llu | results out %llu | total %llu "
+            "(%llu candidates, %llu sub-blocks)\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[5] - h[4], h[6] - h[5], h[7] - h[6],
+            h[7] - h[0], h[8], h[9]);
+  }
   const long long* h_oi = static_cast<const long long*>(s->h_out);
   const double* h_os = reinterpret_cast<const double*>(static_cast<const char*>(s->h_out) + o_idx);
   const int* h_oc = reinterpret_cast<const int*>(static_cast<const char*>(s->h_out) + o_idx + o_sim);
