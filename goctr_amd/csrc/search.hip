@@ -521,6 +521,11 @@ __global__ __launch_bounds__(256) void knn_scan_bf16_kernel(const unsigned short
   }
 }
 
+// DPP lane exchange (quad_perm / row_half_mirror / row_mirror), as ctr_kernels.h dpp_f32
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32k(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 // 64-bit v_readlane (the lane index must be wave-uniform)
 __device__ __forceinline__ long long knn_readlane(long long x, int lane) {
   const int lo = __builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)x, lane);
@@ -529,6 +534,16 @@ __device__ __forceinline__ long long knn_readlane(long long x, int lane) {
 }
 __device__ __forceinline__ double knn_readlane(double x, int lane) {
   return __builtin_bit_cast(double, knn_readlane(__builtin_bit_cast(long long, x), lane));
+}
+
+// DPP wave_shr:1 (gfx9): lane l gets lane l - 1's value, lane 0 its own -- a pure vector move, no LDS crossbar
+__device__ __forceinline__ int knn_wave_shr1(int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ long long knn_wave_shr1(long long x) {
+  const int lo = knn_wave_shr1((int)(unsigned int)(unsigned long long)x), hi = knn_wave_shr1((int)(unsigned int)((unsigned long long)x >> 32));
+  return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo);
+}
+__device__ __forceinline__ double knn_wave_shr1(double x) {
+  return __builtin_bit_cast(double, knn_wave_shr1(__builtin_bit_cast(long long, x)));
 }
 
 // knn_collect_kernel: ONE workgroup per query does everything behind the scan -- bound, tile list, sub-block list, float32 filter
@@ -583,25 +598,52 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   const float* tm = tmax + (size_t)q * nt;
   for (int d = threadIdx.x; d < D; d += 256) { knn_cq[d] = queries[(size_t)q * D + d]; cq32[d] = q32[(size_t)q * D + d]; }
   if (threadIdx.x == 0) { n_blk = 0; n_cand = 0; }
+  // (round 6: the first KNN2_TMR x 256 tile maxima stay in registers for the tile list below -- nt <= 1024 at V = 10^6: no re-read)
+  constexpr int KNN2_TMR = 4;
+  float tmv[KNN2_TMR];
   float m = 0.f;
-  for (int t = threadIdx.x; t < nt; t += 256) m = fmaxf(m, tm[t]);
-  gmax[threadIdx.x] = m;
+#pragma unroll
+  for (int u = 0; u < KNN2_TMR; ++u) {
+    const int t = u * 256 + (int)threadIdx.x;
+    tmv[u] = t < nt ? tm[t] : 0.f;
+    m = fmaxf(m, tmv[u]);
+  }
+  for (int t = KNN2_TMR * 256 + threadIdx.x; t < nt; t += 256) m = fmaxf(m, tm[t]);
   const long long ig = ignore[q];
-  __syncthreads();
-  stamp(1);
   {
-    const int rounds = k + (ig >= 0 ? 1 : 0);
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < 256; ++j) {
-      const float o = gmax[j];
-      rank += (o > m || (o == m && j < (int)threadIdx.x)) ? 1 : 0;
+    // The bound: the `rounds`-th largest of the 256 group maxima, duplicates counted.  Round 5 ranked every maximum against all 256
+    // (256 broadcast LDS reads and ~5 instructions each per thread: 12.6 k of the launch's 43 k cycles, GOCTR_DBG=knn).  Now every
+    // wavefront peels off its own `rounds` largest -- a DPP maximum over the rows, four v_readlane, the first lane that holds the
+    // maximum drops out -- and the 4 x rounds survivors are ranked among themselves: the same value, ~2 k cycles.
+    const int rounds = k + (ig >= 0 ? 1 : 0);                          // <= 64 (knn_scan_usable)
+    float mine = m;
+    for (int r = 0; r < rounds; ++r) {
+      float v = mine;
+      v = fmaxf(v, dpp_f32k<0xB1>(v)); v = fmaxf(v, dpp_f32k<0x4E>(v)); v = fmaxf(v, dpp_f32k<0x141>(v)); v = fmaxf(v, dpp_f32k<0x140>(v));
+      const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+      const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+      const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+      const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+      const float wmax = fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+      const unsigned long long hold = __ballot(mine == wmax);
+      if (lane == (int)__builtin_ctzll(hold | (1ull << 63))) mine = -1.f;     // (maxima are >= 0: -1 = peeled off)
+      if (lane == 0) gmax[wave * rounds + r] = wmax;                          // (the four lists back to back: 4 x rounds <= 256)
     }
-    if (rank == rounds - 1) { const float kth = m > 0.f ? m : 0.f; sh_tb = kth - 2.f * E; sh_sb = kth - E; }
     if (threadIdx.x == 64) {
       double qn = 0;
       for (int d = 0; d < D; ++d) qn += knn_cq[d] * knn_cq[d];           // embutil.Norm (search.go:86-90)
       knn_cq[D] = sqrt(qn);
+    }
+    __syncthreads();
+    stamp(1);
+    if ((int)threadIdx.x < 4 * rounds) {
+      const float c = gmax[threadIdx.x];
+      int rank = 0;
+      for (int u = 0; u < 4 * rounds; ++u) {
+        const float o = gmax[u];
+        rank += (o > c || (o == c && u < (int)threadIdx.x)) ? 1 : 0;
+      }
+      if (rank == rounds - 1) { const float kth = c > 0.f ? c : 0.f; sh_tb = kth - 2.f * E; sh_sb = kth - E; }
     }
   }
   __syncthreads();
@@ -620,7 +662,28 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   if (!nothing) {
     // ---- listed tiles, in tile order
     int base = 0;
-    for (int t0 = 0; t0 < nt; t0 += 256) {
+    {
+      // the register-cached maxima: every (pass, wavefront) count first, ONE barrier, then the positions (round 5: two barriers per pass)
+      __shared__ int pass_cnt[KNN2_TMR][4];
+      unsigned long long bal[KNN2_TMR]; bool onv[KNN2_TMR];
+#pragma unroll
+      for (int u = 0; u < KNN2_TMR; ++u) {
+        onv[u] = u * 256 + (int)threadIdx.x < nt && tmv[u] > 0.f && tmv[u] >= tb;
+        bal[u] = __ballot(onv[u]);
+        if (lane == 0) pass_cnt[u][wave] = __popcll(bal[u]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < KNN2_TMR; ++u) {
+        int before = base;
+        for (int w = 0; w < wave; ++w) before += pass_cnt[u][w];
+        const int pos = before + __popcll(bal[u] & ((1ull << lane) - 1ull));
+        if (onv[u] && pos < KNN2_MYT) my_tiles[pos] = u * 256 + (int)threadIdx.x;
+        base += pass_cnt[u][0] + pass_cnt[u][1] + pass_cnt[u][2] + pass_cnt[u][3];
+      }
+      __syncthreads();
+    }
+    for (int t0 = KNN2_TMR * 256; t0 < nt; t0 += 256) {
       const int t = t0 + threadIdx.x;
       const bool on = t < nt && tm[t] > 0.f && tm[t] >= tb;
       const unsigned long long bal = __ballot(on);
@@ -731,6 +794,16 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   if (n > KNN2_CAP) { give_up(); return; }
   // ---- replay: sort by item index (an item appears once): own entries to registers, ranks from LDS, write back in order
   for (int r = threadIdx.x; r < k; r += 256) { nb_s[r] = 0.0; nb_i[r] = -1; }
+  if (n <= 64) {
+    // (round 6: a few dozen candidates at most -- the usual case is k + a handful -- are ordered by ONE wavefront, which then replays
+    // them: no workgroup barriers around the sort; the other wavefronts wait at the barrier behind the replay)
+    if (threadIdx.x < 64) {
+      const long long mi = lane < n ? s_idx[lane] : 0; const double msim = lane < n ? s_sim[lane] : 0.0;
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += knn_readlane(mi, j) < mi ? 1 : 0;
+      if (lane < n) { s_idx[rank] = mi; s_sim[rank] = msim; }
+    }
+  } else {
   long long me[KNN2_CAP / 256]; double ms[KNN2_CAP / 256]; int rk[KNN2_CAP / 256];
 #pragma unroll
   for (int u = 0; u < KNN2_CAP / 256; ++u) {
@@ -748,6 +821,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   for (int u = 0; u < KNN2_CAP / 256; ++u)
     if (rk[u] >= 0) { s_idx[rk[u]] = me[u]; s_sim[rk[u]] = ms[u]; }
   __syncthreads();
+  }
   if (threadIdx.x < 64) {
     double s = 0.0; long long id = -1; double low = 0.0;
     for (int r0 = 0; r0 < n; r0 += 64) {
@@ -761,7 +835,17 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
         const unsigned long long gt = __ballot(lane < k && ts > s);
         if (!gt) continue;
         const int p = __builtin_ctzll(gt);
-        const double sprev = __shfl_up(s, 1, 64);
+        const double sprev = knn_wave_shr1(s);                     // (DPP wave_shr:1: no LDS round trip)
+        // Round 6: no run of EQUAL similarities among the real entries behind p (empty slots are all (0.0, -1): shifting them changes
+        // nothing) => the rule below is a plain shift by one -- every lane behind p takes its predecessor, which the DPP move above
+        // already delivered; the general path's two ballots and two LDS shuffles are only for tie groups (quirk Q22).
+        if (!__ballot(lane < k && lane > p && sprev == s && s > 0.0)) {
+          const long long idprev = knn_wave_shr1(id);
+          if (lane == p) { s = ts; id = ti; }
+          else if (lane > p && lane < k) { s = sprev; id = idprev; }
+          low = knn_readlane(s, k - 1);
+          continue;
+        }
         const bool start = lane < k && (lane == p || (lane > p && sprev != s));
         const unsigned long long S = __ballot(start);
         const unsigned long long below = lane > 0 ? S & ((1ull << lane) - 1ull) : 0ull;
