@@ -247,6 +247,13 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     return;
   }
   double sq = 0;
+  // (round 6: the parameter and its moments are requested HERE, in front of the slab sums -- behind them they were two more dependent
+  // round trips of a launch that is nothing but round trips: state -> slabs -> W -> moments -> stores)
+  const bool pre = idx < a.nflat && a.mode != 2;
+  const double w_pre = pre ? a.W[idx] : 0.0;
+  const double m_pre = pre && a.do_update && a.solver == GOCTR_SOLVER_ADAM ? a.Mo[idx] : 0.0;
+  const double v_pre = pre && a.do_update && a.solver == GOCTR_SOLVER_ADAM ? a.Vo[idx] : 0.0;
+  const double vel_pre = pre && a.do_update && a.solver != GOCTR_SOLVER_ADAM ? a.Vel[idx] : 0.0;
   double coop_sum = 0; bool coop_have = false;
   if (a.mode == 0 || a.mode == 3) {
     __shared__ double red2[256];
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
           for (int u = 0; u < 48; ++u) s += (j0 + u < d.nslabs) ? v[u] : 0.0;
         }
       }
-      const double w = a.W[idx];
+      const double w = w_pre;
       double g;
       if (a.mode == 1) {
         g = a.G[idx];                                         // summed over the ranks by the all-reduce
@@ -333,8 +340,8 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
         const long long pidx = d.poff + (is_b ? c : (long long)d.fo + (long long)r * d.fo + c);
         double wn = w;
         if (a.solver == GOCTR_SOLVER_ADAM) {
-          const double m = a.beta1 * a.Mo[idx] + (1 - a.beta1) * g;
-          const double v = a.beta2 * a.Vo[idx] + (1 - a.beta2) * g * g;
+          const double m = a.beta1 * m_pre + (1 - a.beta1) * g;
+          const double v = a.beta2 * v_pre + (1 - a.beta2) * g * g;
           a.Mo[idx] = m; a.Vo[idx] = v;
           // quirk Q7: beta powers advance once per parameter: exponent (t-1)*n + i + 1
           const double ex = (double)((a.st->t) * a.nparams + pidx + 1);
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
           const double lr = a.lr_init * sqrt(1 - b2t) / (1. - b1t);
           wn = w + (-lr * m / (sqrt(v) + a.eps));
         } else {
-          const double upd = a.momentum * a.Vel[idx] - a.lr_init * g;
+          const double upd = a.momentum * vel_pre - a.lr_init * g;
           a.Vel[idx] = upd;
           wn = a.nesterov ? w + (a.momentum * upd - a.lr_init * g) : w + upd;
         }
