@@ -225,6 +225,10 @@ struct AttnKey { int user, item; long long ts; };
 template <int VEC, int LPR, int FAST, bool KEYS = false>
 __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long long batch_idx, const float* att0w,
                                               const RaCtx* ra = nullptr, int sample = -1, const AttnKey* key = nullptr) {
+  // (round 6: this body's sums of products may contract to fused multiply-adds -- one rounding instead of two per term, and 4 v_fma_f32
+  // where the uncontracted code issued 2 v_pk_mul_f32 + 3 v_add_f32; the file's -ffp-contract=off stays for everything that must
+  // match another path's bits.  Every attention-forward variant shares this body.)
+#pragma clang fp contract(fast)
   const bool idm = FAST ? true : (bool)a.src.id_mode;
   const bool din = FAST ? FAST >= 2 : a.kind == GOCTR_DIN;
   const bool cosine = FAST ? FAST == 2 : a.att == GOCTR_ATT_COSINE;
