@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, session 15: the attention's square roots and division as single v_sqrt_f32 / v_rcp_f32 issues, 1 / T from the host: tests + A/B
+# round 6, session 15 / 19: attention fast math, then FMA contraction inside attn_fwd_body: tests + A/B against the previous library
 # against the previous library (goctr_amd/libgoctr_hip_prev.so)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R; O=gpurun_out/r06_s15; mkdir -p $O
