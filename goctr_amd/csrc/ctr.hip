@@ -478,7 +478,7 @@ int init_kernel_attrs() {
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
       allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(gemm_tn_multi_x3w_kernel<9, 5>) || allow_big_lds(gemm_tn_multi_x3w_kernel<8, 5>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
-      allow_big_lds(ctr_chain_x3_kernel<15>) || chain_x3_fwd_attributes() ||
+      allow_big_lds(ctr_chain_x3_kernel<15>) || chain_x3_fwd_attributes() || fwd4_attributes() ||
       serve16_attributes()) return -1;
   done = true;
   return 0;
@@ -681,20 +681,25 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   a.tile_att0 = m->att0_from_chain ? m->tile_att0.p : nullptr;
   static DevBuf<unsigned long long> dbgbuf;
   const bool dbg = dbg_on("chain") && (hipStream_t)e.active == e.stream;   // (not from a serving slot)
-  if (dbg && !dbgbuf.p && dbgbuf.alloc(8 * CX_NSTAMP)) return -1;
+  if (dbg && !dbgbuf.p && dbgbuf.alloc(4096)) return -1;
   a.dbg = dbg ? dbgbuf.p : nullptr;
   ProfScope ps(GOCTR_K_CHAIN);
-  // (forward only: one persistent workgroup per CU walks the row tiles, GOCTR_FWD_PERSIST=0: one workgroup per tile)
+  // (forward only: persistent workgroups walk the row tiles -- one workgroup per tile measured 34.8 against 33.4 us per 32 768 rows)
   const int ntiles = (int)cdiv(B, 32);
-  const bool persist = !o.train && e.compute_units > 0 && env_int("GOCTR_FWD_PERSIST", 1) != 0;
-  const dim3 grid((unsigned)(persist ? std::min(ntiles, e.compute_units) : ntiles));
+  const bool persist = !o.train && e.compute_units > 0;
+  // forward only, Ip <= 144: four wavefronts per tile and two workgroups per CU (ctr_fwd4.h; GOCTR_FWD4=0: the 8-wavefront kernel)
+  const bool fwd4 = !o.train && m->x3_nch0 <= 9 && env_int("GOCTR_FWD4", 1) != 0;
+  const dim3 grid((unsigned)(persist ? std::min(ntiles, (fwd4 ? 2 : 1) * e.compute_units) : ntiles));
   static const char* const kSym[3][2] = {{"ctr_chain_x3_kernel<2,false>", "ctr_chain_x3_kernel<2,true>"},
                                          {"ctr_chain_x3_kernel<9,false>", "ctr_chain_x3_kernel<9,true>"},
                                          {"ctr_chain_x3_kernel<15,false>", "ctr_chain_x3_kernel<15,true>"}};
   // (Round 4 also built a 16-row tile kernel -- two workgroups per CU -- which lost, 25.8 against 20.9 us at cfg3: a 16-row
   // tile's dependent pipeline is as long as a 32-row tile's.  The kernel left the tree in round 5; DESIGN_HISTORY.md and
   // profiles/r04_chain_x16_ab.txt keep the record, git keeps csrc/ctr_chain_x16.h.)
-  if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, kSym[m->x3_nch0 == 2 ? 0 : m->x3_nch0 == 9 ? 1 : 2][o.train ? 0 : 1]);
+  if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, fwd4 ? (m->x3_nch0 == 2 ? "ctr_fwd4_kernel<2>" : "ctr_fwd4_kernel<9>")
+                                                  : kSym[m->x3_nch0 == 2 ? 0 : m->x3_nch0 == 9 ? 1 : 2][o.train ? 0 : 1]);
+  if (fwd4) launch_fwd4(m->x3_nch0, a, grid, e.active);
+  else
   switch (m->x3_nch0) {
     case 2: launch_chain_x3_n<2>(a, grid, e.active, !o.train); break;
     case 9: launch_chain_x3_n<9>(a, grid, e.active, !o.train); break;
@@ -704,15 +709,37 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   if (dbg) {
     unsigned long long h[CX_NSTAMP];
     if (dbgbuf.download(h, CX_NSTAMP)) return -1;
-    if (!o.train)
+    if (fwd4) {
+      fprintf(stderr, "fwd4 phases (s_memtime ticks): h0 split+barrier %lld | F0 %lld | epi0+F1 %lld | xchg barrier %lld | epi1+z2 %lld | total %lld\n",
+              (long long)(h[1] - h[0]), (long long)(h[2] - h[1]), (long long)(h[3] - h[2]), (long long)(h[4] - h[3]), (long long)(h[5] - h[4]),
+              (long long)(h[5] - h[0]));
+      fprintf(stderr, "fwd4 workgroup 0: %lld shader cycles in %.2f us (100 MHz clock) = %.2f GHz\n", (long long)(h[5] - h[6]),
+              (double)(h[8] - h[7]) * 0.01, (double)(h[5] - h[6]) / ((double)(h[8] - h[7]) * 10.0));
+      // every workgroup's lifetime (100 MHz clock) and where it ran
+      std::vector<unsigned long long> all(4096);
+      if (dbgbuf.download(all.data(), 4096)) return -1;
+      std::vector<double> life; std::vector<unsigned long long> where;
+      for (unsigned b = 0; b < grid.x && b < 960; ++b) {
+        life.push_back((double)(all[128 + 4 * b + 1] - all[128 + 4 * b]) * 0.01);
+        where.push_back((all[128 + 4 * b + 3] & 0xf) << 16 | (all[128 + 4 * b + 2] & 0xff00));      // XCC | SE, SH, CU of HW_ID
+      }
+      std::sort(life.begin(), life.end()); std::sort(where.begin(), where.end());
+      const size_t cus = (size_t)(std::unique(where.begin(), where.end()) - where.begin());
+      if (!life.empty())
+        fprintf(stderr, "fwd4 workgroups: %zu on %zu CUs, lifetimes min %.2f / median %.2f / max %.2f us\n", life.size(), cus, life.front(),
+                life[life.size() / 2], life.back());
+    } else if (!o.train) {
       fprintf(stderr, "chain_x3 forward-only phases (s_memtime ticks): h0 split+barrier %lld | F0 %lld | epi0 %lld | F1 %lld | xchg barrier %lld | epi1+z2 %lld | total %lld\n",
               (long long)(h[1] - h[0]), (long long)(h[2] - h[1]), (long long)(h[3] - h[2]), (long long)(h[4] - h[3]), (long long)(h[5] - h[4]),
               (long long)(h[6] - h[5]), (long long)(h[6] - h[0]));
-    else
-    fprintf(stderr, "chain_x3 phases (s_memtime ticks): h0 split+barrier %lld | F0(+epi tile0) %lld | F1(+epi tile1) %lld | xchg barrier %lld | epi1+z2+dz1 %lld | B0(+epi) %lld | dp %lld + xchg %lld | total %lld\n",
-            (long long)(h[1] - h[0]), (long long)(h[2] - h[1]), (long long)(h[4] - h[2]), (long long)(h[5] - h[4]), (long long)(h[6] - h[5]),
-            (long long)(h[7] - h[6]), (long long)(h[8] - h[7]), (long long)(h[9] > h[8] ? h[9] - h[8] : 0),
-            (long long)((h[9] > h[8] ? h[9] : h[8]) - h[0]));
+      fprintf(stderr, "chain_x3 forward-only workgroup 0: %lld shader cycles in %.2f us (100 MHz clock) = %.2f GHz\n", (long long)(h[6] - h[14]),
+              (double)(h[13] - h[15]) * 0.01, (double)(h[6] - h[14]) / ((double)(h[13] - h[15]) * 10.0));
+    } else {
+      fprintf(stderr, "chain_x3 phases (s_memtime ticks): h0 split+barrier %lld | F0(+epi tile0) %lld | F1(+epi tile1) %lld | xchg barrier %lld | epi1+z2+dz1 %lld | B0(+epi) %lld | dp %lld + xchg %lld | total %lld\n",
+              (long long)(h[1] - h[0]), (long long)(h[2] - h[1]), (long long)(h[4] - h[2]), (long long)(h[5] - h[4]), (long long)(h[6] - h[5]),
+              (long long)(h[7] - h[6]), (long long)(h[8] - h[7]), (long long)(h[9] > h[8] ? h[9] - h[8] : 0),
+              (long long)((h[9] > h[8] ? h[9] : h[8]) - h[0]));
+    }
   }
   return 0;
 }

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   for (int k = 0; k < CX_NSTAMP; ++k) ts[k] = 0;
   auto stamp = [&](int k) { if (a.dbg) ts[k] = __builtin_amdgcn_s_memtime(); };
   stamp(0);
+  if (FWD && a.dbg) { ts[14] = ts[0]; ts[15] = __builtin_amdgcn_s_memrealtime(); }   // (launch-wide: shader cycles against the 100 MHz clock)
 
   // ---------------------------------------------------------------- h0 rows of this wavefront's chunks: first loads out
   // chunk c is split by wavefront c % 8: lane (n, h) owns h0[row n][16c + 8h .. + 8]
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     g2 = reinterpret_cast<const cx_u4*>(a.img2) + lane_v; g3 = reinterpret_cast<const cx_u4*>(a.img3) + lane_v;
   }
   if (FWD && tile != tile_first) {     // (a later trip: the ring slots its predecessor could not spare registers for)
+    stamp(0);
 #pragma unroll
     for (int c = CX_FWD_NFP; c < CX_PF0; ++c) load0(c, c);
   }
@@ -497,7 +499,8 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   if (FWD) {
     if (writer) a.yhat[row] = yh;
     stamp(6);
-    if (a.dbg && blockIdx.x == 0 && lane == 0 && tile == tile_first) {
+    if (a.dbg) ts[13] = __builtin_amdgcn_s_memrealtime();
+    if (a.dbg && blockIdx.x == 0 && lane == 0) {      // (every trip: the last one's stamps survive -- a steady-state tile)
 #pragma unroll
       for (int k = 0; k < CX_NSTAMP; ++k) a.dbg[w * CX_NSTAMP + k] = ts[k];
     }
@@ -696,6 +699,9 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
 
 // (defined in ctr_fwd.hip)
 int chain_x3_fwd_attributes();
+// ctr_fwd4.h (also instantiated in ctr_fwd.hip): four wavefronts per tile, two workgroups per CU; Ip = 32 or 144
+int fwd4_attributes();
+void launch_fwd4(int nch0, const ChainX3Args& a, dim3 grid, hipStream_t s);
 void launch_chain_x3_fwd(int nch0, const ChainX3Args& a, dim3 grid, hipStream_t s);
 
 }  // namespace goctr

@@ -9,6 +9,7 @@
 #define GOCTR_NO_PLAIN_KERNELS      // the headers' plain (non-template) kernels belong to ctr.hip
 #include "common.h"
 #include "ctr_chain_x3.h"
+#include "ctr_fwd4.h"
 
 namespace goctr {
 
@@ -27,6 +28,17 @@ void launch_chain_x3_fwd(int nch0, const ChainX3Args& a, dim3 grid, hipStream_t 
     case 9: hipLaunchKernelGGL((ctr_chain_x3_kernel<9, true>), grid, dim3(512), chain_x3_lds_bytes<9>(), s, a); break;
     default: hipLaunchKernelGGL((ctr_chain_x3_kernel<15, true>), grid, dim3(512), chain_x3_lds_bytes<15>(), s, a); break;
   }
+}
+
+int fwd4_attributes() {
+  const void* const ks[2] = {reinterpret_cast<const void*>(ctr_fwd4_kernel<2>), reinterpret_cast<const void*>(ctr_fwd4_kernel<9>)};
+  for (const void* k : ks) GOCTR_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
+  return 0;
+}
+
+void launch_fwd4(int nch0, const ChainX3Args& a, dim3 grid, hipStream_t s) {
+  if (nch0 == 2) hipLaunchKernelGGL((ctr_fwd4_kernel<2>), grid, dim3(256), fwd4_lds_bytes<2>(), s, a);
+  else hipLaunchKernelGGL((ctr_fwd4_kernel<9>), grid, dim3(256), fwd4_lds_bytes<9>(), s, a);
 }
 
 }  // namespace goctr
