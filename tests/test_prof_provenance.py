@@ -66,5 +66,5 @@ def test_step_total_is_the_sum_of_the_replayed_steps_launches():
         assert st["algorithmic_bytes"] == per_sample * batch
         assert abs(st["traffic_ratio"] - st["sum_hbm_bytes"] / st["algorithmic_bytes"]) < 1e-3
         # the predict phase has SQ counters and an L2 hit rate too
-        pred = [e for e in doc["phases"]["predict"].values() if e["kernel"].startswith("ctr_chain_x3_kernel") and e.get("calls", 0) > 10]
+        pred = [e for e in doc["phases"]["predict"].values() if e["kernel"].startswith(("ctr_chain_x3_kernel", "ctr_fwd4_kernel")) and e.get("calls", 0) > 10]
         assert pred and pred[0].get("sq") and pred[0].get("l2_hit_rate") is not None
