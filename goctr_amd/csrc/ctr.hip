@@ -687,8 +687,8 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   // (forward only: persistent workgroups walk the row tiles -- one workgroup per tile measured 34.8 against 33.4 us per 32 768 rows)
   const int ntiles = (int)cdiv(B, 32);
   const bool persist = !o.train && e.compute_units > 0;
-  // forward only, Ip <= 144: four wavefronts per tile and two workgroups per CU (ctr_fwd4.h; GOCTR_FWD4=0: the 8-wavefront kernel)
-  const bool fwd4 = !o.train && m->x3_nch0 <= 9 && env_int("GOCTR_FWD4", 1) != 0;
+  // forward only: four wavefronts per tile and two workgroups per CU (ctr_fwd4.h; GOCTR_FWD4=0: the 8-wavefront kernel)
+  const bool fwd4 = !o.train && env_int("GOCTR_FWD4", 1) != 0;
   const dim3 grid((unsigned)(persist ? std::min(ntiles, (fwd4 ? 2 : 1) * e.compute_units) : ntiles));
   static const char* const kSym[3][2] = {{"ctr_chain_x3_kernel<2,false>", "ctr_chain_x3_kernel<2,true>"},
                                          {"ctr_chain_x3_kernel<9,false>", "ctr_chain_x3_kernel<9,true>"},
@@ -696,7 +696,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   // (Round 4 also built a 16-row tile kernel -- two workgroups per CU -- which lost, 25.8 against 20.9 us at cfg3: a 16-row
   // tile's dependent pipeline is as long as a 32-row tile's.  The kernel left the tree in round 5; DESIGN_HISTORY.md and
   // profiles/r04_chain_x16_ab.txt keep the record, git keeps csrc/ctr_chain_x16.h.)
-  if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, fwd4 ? (m->x3_nch0 == 2 ? "ctr_fwd4_kernel<2>" : "ctr_fwd4_kernel<9>")
+  if (ps.on) prof_note_kernel(GOCTR_K_CHAIN, fwd4 ? (m->x3_nch0 == 2 ? "ctr_fwd4_kernel<2,false>" : m->x3_nch0 == 9 ? "ctr_fwd4_kernel<9,false>" : "ctr_fwd4_kernel<15,true>")
                                                   : kSym[m->x3_nch0 == 2 ? 0 : m->x3_nch0 == 9 ? 1 : 2][o.train ? 0 : 1]);
   if (fwd4) launch_fwd4(m->x3_nch0, a, grid, e.active);
   else

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
 
 // (defined in ctr_fwd.hip)
 int chain_x3_fwd_attributes();
-// ctr_fwd4.h (also instantiated in ctr_fwd.hip): four wavefronts per tile, two workgroups per CU; Ip = 32 or 144
+// ctr_fwd4.h (also instantiated in ctr_fwd.hip): four wavefronts per tile, two workgroups per CU; Ip = 32, 144 or 240
 int fwd4_attributes();
 void launch_fwd4(int nch0, const ChainX3Args& a, dim3 grid, hipStream_t s);
 void launch_chain_x3_fwd(int nch0, const ChainX3Args& a, dim3 grid, hipStream_t s);

@@ -31,14 +31,18 @@ void launch_chain_x3_fwd(int nch0, const ChainX3Args& a, dim3 grid, hipStream_t 
 }
 
 int fwd4_attributes() {
-  const void* const ks[2] = {reinterpret_cast<const void*>(ctr_fwd4_kernel<2>), reinterpret_cast<const void*>(ctr_fwd4_kernel<9>)};
+  const void* const ks[3] = {reinterpret_cast<const void*>(ctr_fwd4_kernel<2, false>), reinterpret_cast<const void*>(ctr_fwd4_kernel<9, false>),
+                             reinterpret_cast<const void*>(ctr_fwd4_kernel<15, true>)};
   for (const void* k : ks) GOCTR_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024)));
   return 0;
 }
 
+// (Ip = 144 with the exchange one H2 tile at a time measured the same as with one exchange: 626 / 627 / 614 against 631 / 612 / 608 M
+// rows/s; Ip = 240 needs it to fit two workgroups per CU)
 void launch_fwd4(int nch0, const ChainX3Args& a, dim3 grid, hipStream_t s) {
-  if (nch0 == 2) hipLaunchKernelGGL((ctr_fwd4_kernel<2>), grid, dim3(256), fwd4_lds_bytes<2>(), s, a);
-  else hipLaunchKernelGGL((ctr_fwd4_kernel<9>), grid, dim3(256), fwd4_lds_bytes<9>(), s, a);
+  if (nch0 == 2) hipLaunchKernelGGL((ctr_fwd4_kernel<2, false>), grid, dim3(256), (fwd4_lds_bytes<2, false>()), s, a);
+  else if (nch0 == 9) hipLaunchKernelGGL((ctr_fwd4_kernel<9, false>), grid, dim3(256), (fwd4_lds_bytes<9, false>()), s, a);
+  else hipLaunchKernelGGL((ctr_fwd4_kernel<15, true>), grid, dim3(256), (fwd4_lds_bytes<15, true>()), s, a);
 }
 
 }  // namespace goctr

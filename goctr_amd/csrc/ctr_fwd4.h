@@ -7,7 +7,8 @@
 // exchange of the layer-1 partials, the second epilogue, the output unit behind two more barriers -- runs with the matrix
 // cores idle: s_memtime of a steady-state tile (GOCTR_DBG=chain, profiles/r06_fwd4.txt) gives F0 3.4 k + F1 3.2 k cycles of
 // products in a 13.4 k-cycle tile.  Here a tile belongs to FOUR wavefronts (one per SIMD) holding two H1 tiles each, the
-// workgroup needs 75 KiB of LDS at Ip = 144, and the CU holds two such workgroups that drift apart by themselves: while
+// workgroup needs 75 KiB of LDS at Ip = 144 (77.5 KiB at Ip = 240 with the exchange one H2 tile at a time, template XU), and
+// the CU holds two such workgroups that drift apart by themselves: while
 // one sits in its exchange or output unit the other one's products have the matrix cores.  Same arithmetic as the
 // 8-wavefront kernel up to the order in which the layer-1 partial sums are added (four partials of four k chunks instead of
 // seven of two): float32 rounding, inside the 1e-5 parity bar like the 16-row kernel's (tests/test_gpu_ctr.py).
@@ -29,18 +30,20 @@ namespace goctr {
 constexpr int F4_D0 = 2;       // W0 chunks (of both tiles) in flight per wavefront
 constexpr int F4_R1 = 4;       // W1 pieces (one k chunk x one H2 tile) in flight per wavefront
 
-template <int NCH0>
+// XU: the exchange one H2 tile at a time through two 16 KiB halves (a barrier per tile instead of one for all three): 32 instead
+// of 48 KiB, which is what lets Ip = 240 (45 KiB of h0 image) keep two workgroups per CU
+template <int NCH0, bool XU>
 inline size_t fwd4_lds_bytes() {
   // h0 fragment image | Z1 exchange (4 partials) | z2 partials
-  return (size_t)NCH0 * 3 * 1024 + (size_t)4 * CX_NU * 4 * 1024 + 4 * 32 * 4;
+  return (size_t)NCH0 * 3 * 1024 + (size_t)4 * (XU ? 2 : CX_NU) * 4 * 1024 + 4 * 32 * 4;
 }
 
-template <int NCH0>
+template <int NCH0, bool XU>
 __global__ __launch_bounds__(256, 2) void ctr_fwd4_kernel(ChainX3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char f4_smem[];
   unsigned char* const h0img = f4_smem;                                              // [NCH0][3][64 lanes][16 B]
   float* const xch = reinterpret_cast<float*>(f4_smem + (size_t)NCH0 * 3 * 1024);   // [4 waves][NU][4 g][64][4]
-  float* const z2p = xch + (size_t)4 * CX_NU * 4 * 256;                              // [4][32]
+  float* const z2p = xch + (size_t)4 * (XU ? 2 : CX_NU) * 4 * 256;                   // [4][32]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -178,6 +181,34 @@ __global__ __launch_bounds__(256, 2) void ctr_fwd4_kernel(ChainX3Args a) {
     // ---------------------------------------------------------------- F1: partial Z1^T = W1^T[:, own K] . A0^T[own K], one H2
     // tile at a time (32 accumulator registers live instead of 96), each handed to the exchange as soon as it is complete
     float* const xw = xch + ((size_t)(w * CX_NU) * 4 * 64 + lane) * 4;
+    float part = 0.f;
+    int next_tile = ntiles;
+    // the next tile's rows and first weight chunks (workgroup-uniform branch), in program order behind every other load
+    auto prefetch_next = [&]() {
+      vblk += (int)gridDim.x;
+      next_tile = vblk < ntiles ? (a.xcd_affine ? xcd_unit_of_block(vblk, ntiles, 4) : vblk) : ntiles;
+      if (next_tile < ntiles) {
+        const int nrow = next_tile * 32 + n;
+        load_hv(nrow < a.B ? nrow : a.B - 1);
+#pragma unroll
+        for (int c = 0; c < D0; ++c) load0(c, c);
+      }
+    };
+    // wavefront w finishes columns 32 u + 8 w + 4 h + r of H2 tile u from the four partials at `xb` ([ws][g = w][lane])
+    auto finish = [&](int u, const float* xb, int ustride) {
+      const int f0 = 32 * u + 8 * w + 4 * h;
+      if (32 * u + 8 * w < H2p) {                               // (wave-uniform)
+        cx_f4 z = cx_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ws = 0; ws < 4; ++ws)   // fixed wavefront order: bitwise reproducible
+          z += *reinterpret_cast<const cx_f4*>(xb + ((size_t)(ws * ustride * 4 + w) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s = chain_sigm(z[r]);
+          part += (f0 + r < a.H2 ? s : 0.f) * w2pre[u][r];
+        }
+      }
+    };
 #pragma unroll
     for (int u = 0; u < CX_NU; ++u) {
       cx_acc ah1, ac1;
@@ -193,38 +224,29 @@ __global__ __launch_bounds__(256, 2) void ctr_fwd4_kernel(ChainX3Args a) {
         CX_MMA6(ah1, ac1, af, bfs[jj]);
         __builtin_amdgcn_sched_barrier(0);
       }
+      // this wavefront's partial of tile u: [w][u][g][lane], or (XU) half u % 2: [w][g][lane]
+      float* const xu = XU ? xch + (size_t)(u & 1) * 4 * 4 * 256 + ((size_t)(w * 4) * 64 + lane) * 4 : xw + (size_t)(u * 4) * 256;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<cx_f4*>(xw + (size_t)(u * 4 + g) * 256) =
+        *reinterpret_cast<cx_f4*>(xu + (size_t)g * 256) =
             cx_f4{ah1[4 * g] + ac1[4 * g], ah1[4 * g + 1] + ac1[4 * g + 1], ah1[4 * g + 2] + ac1[4 * g + 2], ah1[4 * g + 3] + ac1[4 * g + 3]};
-    }
-    stamp(3);
-    // the next tile's rows and first weight chunks (workgroup-uniform branch), in program order behind every other load
-    vblk += (int)gridDim.x;
-    const int next_tile = vblk < ntiles ? (a.xcd_affine ? xcd_unit_of_block(vblk, ntiles, 4) : vblk) : ntiles;
-    if (next_tile < ntiles) {
-      const int nrow = next_tile * 32 + n;
-      load_hv(nrow < a.B ? nrow : a.B - 1);
-#pragma unroll
-      for (int c = 0; c < D0; ++c) load0(c, c);
-    }
-    __syncthreads();                                            // (2) partial Z1 visible
-    stamp(4);
-    float part = 0.f;
-#pragma unroll
-    for (int u = 0; u < CX_NU; ++u) {
-      const int f0 = 32 * u + 8 * w + 4 * h;
-      cx_f4 z = cx_f4{0.f, 0.f, 0.f, 0.f};
-      if (32 * u + 8 * w < H2p) {                               // (wave-uniform)
-#pragma unroll
-        for (int ws = 0; ws < 4; ++ws)   // fixed wavefront order: bitwise reproducible
-          z += *reinterpret_cast<const cx_f4*>(xch + ((size_t)((ws * CX_NU + u) * 4 + w) * 64 + lane) * 4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float s = chain_sigm(z[r]);
-          part += (f0 + r < a.H2 ? s : 0.f) * w2pre[u][r];
-        }
+      if (XU) {
+        // a half is rewritten by tile u + 2: every wavefront has read tile u's partials before it arrives at the barrier of
+        // tile u + 1, which the writers of tile u + 2 are behind
+        if (u == CX_NU - 1) { stamp(3); prefetch_next(); }
+        __syncthreads();                                        // (2.u) tile u's partials visible
+        finish(u, xch + (size_t)(u & 1) * 4 * 4 * 256, 1);
       }
+    }
+    if (!XU) {
+      stamp(3);
+      prefetch_next();
+      __syncthreads();                                          // (2) partial Z1 visible
+    }
+    stamp(4);
+    if (!XU) {
+#pragma unroll
+      for (int u = 0; u < CX_NU; ++u) finish(u, xch + (size_t)(u * 4) * 256, CX_NU);
     }
     // ---------------------------------------------------------------- output unit: z2 = sum over the 4 x 2 partials
     part += __shfl_xor(part, 32, 64);

@@ -161,19 +161,21 @@ def test_din_predict_of_16384_row_launches_vs_oracle(oracle, att):
     assert np.max(np.abs(y - ry)) <= LOGIT_TOL
 
 
-@pytest.mark.parametrize("PB,rows", [(1100, 8 * 1100), (4096, 8 * 4096), (1037, 8 * 1037 - 5), (4096, 3 * 8 * 4096 + 100)])
-def test_four_wavefront_forward_kernel_against_the_eight_wavefront_one(PB, rows):
+@pytest.mark.parametrize("kind,D,PB,rows", [("din", 16, 1100, 8 * 1100), ("din", 16, 4096, 8 * 4096), ("din", 16, 1037, 8 * 1037 - 5),
+                                            ("din", 16, 4096, 3 * 8 * 4096 + 100), ("youtube", 64, 2048, 8 * 2048), ("youtube", 64, 1100, 3 * 8 * 1100 - 9)])
+def test_four_wavefront_forward_kernel_against_the_eight_wavefront_one(kind, D, PB, rows):
     """forward-only launches at Ip <= 144: four wavefronts per 32-row tile and two workgroups per CU (ctr_fwd4.h, default)
     against the 8-wavefront kernel (GOCTR_FWD4=0).  The two add the layer-1 partial sums in different orders (four partials of
     four k chunks / seven of two), so the scores agree to float32 rounding, not bit for bit; each is inside the 1e-5 bar against
     the oracle (test_gpu_fullsize.py runs the default).  Both walk their tiles as persistent workgroups: 275 tiles (a second trip
     for 19 of the 8-wavefront kernel's 256 workgroups, none for the 512 four-wavefront ones), 1024 tiles (4 / 2 trips each), a
-    launch whose last tile is partly past the dataset's end, and a dataset of several launches"""
+    launch whose last tile is partly past the dataset's end, and a dataset of several launches; YouTube-DNN at Ip = 240 (the
+    exchange one H2 tile at a time through two 16 KiB halves)"""
     from goctr_amd import model as gm
-    U, T, D, Cc, V = 52, 50, 16, 53, 5000
+    U, T, Cc, V = 52, 50, 53, 5000
     rng = np.random.default_rng(rows + 2)
     emb, ub, it, uf, cf, _ = synth(rng, rows, U, T, D, Cc, V)
-    dm = gm.DinNet(U, T, D, D, Cc)
+    dm = gm.DinNet(U, T, D, D, Cc) if kind == "din" else gm.YoutubeDnn(U, T, D, D, Cc)
     r = np.random.default_rng(7)
     dm.set_weights("mlp0", (r.standard_normal((U + 2 * D + Cc, 200)) * 0.15).astype(np.float32))
     dm.set_weights("mlp1", (r.standard_normal((200, 80)) * 0.15).astype(np.float32))
