@@ -636,6 +636,7 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
     }
     __syncthreads();
     stamp(1);
+    // (ranking the survivors over v_readlane broadcasts in ONE wavefront instead measured 4.2 k against 2.7 k cycles for this phase)
     if ((int)threadIdx.x < 4 * rounds) {
       const float c = gmax[threadIdx.x];
       int rank = 0;
@@ -863,16 +864,23 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   stamp(6);
   int cnt = 0;
   for (int r = 0; r < k; ++r) cnt += nb_i[r] >= 0;
-  for (int r = threadIdx.x; r < k; r += 256) { out_idx[(size_t)q * k + r] = nb_i[r]; out_sim[(size_t)q * k + r] = nb_s[r]; }
   const int n_out = cnt < k ? k - 1 : k;                      // search.go:126-131 (see knn_merge_kernel)
   if (host_polls) {
     // the host watches out_cnt[q] in the pinned buffer (knn_search_scan): the neighbours must be there before the count is.
-    // (The system-scope release writes the L2 back, once per workgroup: calls of more than 64 queries wait on the stream instead --
-    // profiles/r05_knn_poll.txt.)
-    if ((int)(threadIdx.x >> 6) < ((k + 63) >> 6)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // the wavefronts that wrote: release only,
-    __syncthreads();                                                                                // no invalidate of the L2 under the others
-    if (threadIdx.x == 0) __hip_atomic_store(out_cnt + q, n_out, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  } else if (threadIdx.x == 0) out_cnt[q] = n_out;
+    // Round 6: the neighbours leave as system-scope stores (written through when issued, nothing left dirty), each writer waits for
+    // its stores' acknowledgements, and the count follows behind the barrier -- no release fence, whose write-back walk of the
+    // XCD's L2 was most of this phase's 4.3 k cycles (round 5: profiles/r05_knn_poll.txt).
+    for (int r = threadIdx.x; r < k; r += 256) {
+      __hip_atomic_store(out_idx + (size_t)q * k + r, nb_i[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(out_sim + (size_t)q * k + r, nb_s[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(out_cnt + q, n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    for (int r = threadIdx.x; r < k; r += 256) { out_idx[(size_t)q * k + r] = nb_i[r]; out_sim[(size_t)q * k + r] = nb_s[r]; }
+    if (threadIdx.x == 0) out_cnt[q] = n_out;
+  }
   stamp(7);
   if (dbg && q == 0 && threadIdx.x == 0) {
 #pragma unroll
