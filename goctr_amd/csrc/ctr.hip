@@ -688,7 +688,9 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
   const int ntiles = (int)cdiv(B, 32);
   const bool persist = !o.train && e.compute_units > 0;
   // forward only: four wavefronts per tile and two workgroups per CU (ctr_fwd4.h; GOCTR_FWD4=0: the 8-wavefront kernel)
-  const bool fwd4 = !o.train && env_int("GOCTR_FWD4", 1) != 0;
+  // (a launch of at most one tile per CU keeps the 8-wavefront kernel: 470 against 459 M rows/s at 256 tiles per launch; 512 tiles 551 -> 575 M,
+  // 1024 tiles 608 -> 637 M -- profiles/r06_fwd4.txt)
+  const bool fwd4 = !o.train && ntiles > e.compute_units && env_int("GOCTR_FWD4", 1) != 0;
   const dim3 grid((unsigned)(persist ? std::min(ntiles, (fwd4 ? 2 : 1) * e.compute_units) : ntiles));
   static const char* const kSym[3][2] = {{"ctr_chain_x3_kernel<2,false>", "ctr_chain_x3_kernel<2,true>"},
                                          {"ctr_chain_x3_kernel<9,false>", "ctr_chain_x3_kernel<9,true>"},
