@@ -14,10 +14,12 @@
 // seven of two): float32 rounding, inside the 1e-5 parity bar like the 16-row kernel's (tests/test_gpu_ctr.py).
 //
 // Layout per wavefront w = 0..3, lane = 32 h + n (n = row of the tile):
-//   F0   H1 tiles 2 w, 2 w + 1 (wavefront 3 has no second tile: it multiplies tile 6 again and zeroes the result -- its SIMD
-//        would wait at the next barrier anyway, and a conditional product costs the register allocation its straight line):
-//        Z0^T tile = W0^T tile . h0^T, A operands (IMG0) streamed through a register ring F4_D0 chunks deep, B operand =
-//        the tile's h0 image in LDS, shared by both tiles
+//   F0   H1 tiles 2 w, 2 w + 1, ONE AFTER THE OTHER (wavefront 3 has no second tile: it multiplies tile 6 again and zeroes the
+//        result -- its SIMD would wait at the next barrier anyway, and a conditional product costs the register allocation its
+//        straight line): Z0^T tile = W0^T tile . h0^T, A operands (IMG0) streamed through a register ring, B operand = the
+//        tile's h0 image in LDS.  The first tile's epilogue (16 sigmoids + the bf16 x 3 split of its activations, ~220 vector
+//        instructions) rides under the second tile's MFMAs, the second tile's under the first two k chunks of F1's first H2 tile
+//        (which need only the first tile's fragments): recommend +3 ... 5 % against both epilogues behind both products
 //   F1   k chunks 4 w .. 4 w + 3 of H1 (its own activations, straight from the accumulators) x the 3 H2 tiles: partial Z1^T,
 //        A operands (IMG1) as 12 pieces through a ring of F4_R1
 //   exchange through LDS, wavefront w finishes columns 32 u + 8 w + 4 h + r (u = 0..2), then the output unit.
@@ -26,9 +28,8 @@
 
 namespace goctr {
 
-// (3 chunks / 6 pieces in flight spill 26 / 40 registers; 3 pieces measure the same as 4)
-constexpr int F4_D0 = 2;       // W0 chunks (of both tiles) in flight per wavefront
-constexpr int F4_R1 = 4;       // W1 pieces (one k chunk x one H2 tile) in flight per wavefront
+constexpr int F4_D0 = 2;       // W0 ring: 2 F4_D0 single-tile slots at Ip = 32, 3 at Ip >= 144 (4 spill 26 / 8 registers at Ip = 144 / 240)
+constexpr int F4_R1 = 4;       // W1 pieces (one k chunk x one H2 tile) in flight per wavefront (3 measure the same, 6 spill 40 registers)
 
 // XU: the exchange one H2 tile at a time through two 16 KiB halves (a barrier per tile instead of one for all three): 32 instead
 // of 48 KiB, which is what lets Ip = 240 (45 KiB of h0 image) keep two workgroups per CU
@@ -82,16 +83,19 @@ __global__ __launch_bounds__(256, 2) void ctr_fwd4_kernel(ChainX3Args a) {
   const cx_u4* g0 = reinterpret_cast<const cx_u4*>(a.img0) + lane_v;        // + (((t*NCH0 + c)*3 + p) * 64)
   const cx_u4* g1 = reinterpret_cast<const cx_u4*>(a.img1) + lane_v;        // + (((cc*NU + u)*3 + p) * 64)
 
-  constexpr int D0 = NCH0 < F4_D0 ? NCH0 : F4_D0;
-  cx_u4 ra0[D0][2][3];
-  auto load0 = [&](int c, int slot) {
+  // F0 runs its two H1 tiles one after the other (step sq = t NCH0 + c): the first tile's epilogue -- 16 sigmoids and the bf16 x 3
+  // split of its activations, ~220 vector instructions -- rides under the second tile's MFMAs instead of running behind both with
+  // the matrix cores idle.  One tile's fragments per ring slot.
+  constexpr int NSQ = 2 * NCH0;
+  constexpr int D0 = NSQ < 2 * F4_D0 ? NSQ : (NCH0 >= 9 ? 3 : 2 * F4_D0);     // (4 slots spill 26 / 8 registers at Ip = 144 / 240)
+  cx_u4 ra0[D0][3];
+  auto load0 = [&](int sq, int slot) {
+    const int tt = sq < NCH0 ? t0 : t1, c = sq < NCH0 ? sq : sq - NCH0;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) ra0[slot][0][p] = *(g0 + (size_t)((t0 * NCH0 + c) * 3 + p) * 64);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) ra0[slot][1][p] = *(g0 + (size_t)((t1 * NCH0 + c) * 3 + p) * 64);
+    for (int p = 0; p < 3; ++p) ra0[slot][p] = *(g0 + (size_t)((tt * NCH0 + c) * 3 + p) * 64);
   };
 #pragma unroll
-  for (int c = 0; c < D0; ++c) load0(c, c);
+  for (int sq = 0; sq < D0; ++sq) load0(sq, sq);
 
   // the output unit's weight columns of this wavefront: f = 32 u + 8 w + 4 h + r (the same for every tile)
   cx_f4 w2pre[CX_NU];
@@ -141,42 +145,44 @@ __global__ __launch_bounds__(256, 2) void ctr_fwd4_kernel(ChainX3Args a) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) ra1[q % F4_R1][p] = *(g1 + (size_t)((cc * CX_NU + u) * 3 + p) * 64);
     };
-    constexpr int QPC = (F4_R1 + D0 - 1) / D0;       // pieces requested per chunk of F0's tail
+    constexpr int QPC = (F4_R1 + D0 - 1) / D0;       // pieces requested per step of F0's tail
+    cx_bf8 bfs[4][3];
+    float a0[16];
+    // the layer-0 epilogue of one H1 tile in six jobs: sigmoid (pad columns are zero) of four accumulator slots at a time, the
+    // B fragments of a k chunk (cx_split8) after every second one
+    auto epi_job = [&](int t, int j) {
+      const int k = j / 3, r = j - 3 * k;              // k chunk 2 t + k: jobs 3 k, 3 k + 1 = its eight slots, 3 k + 2 = the split
+      if (r < 2) {
 #pragma unroll
-    for (int c = 0; c < NCH0; ++c) {
-      cx_bf8 bf[3], af[2][3];
+        for (int i = 8 * k + 4 * r; i < 8 * k + 4 * r + 4; ++i) {
+          const int col = 32 * (2 * w + t) + 8 * (i >> 2) + 4 * h + (i & 3);
+          const float sg = chain_sigm(ah0[t][i] + ac0[t][i]);
+          a0[i] = (col < a.H1 && (t == 0 || has1)) ? sg : 0.f;
+        }
+      } else cx_split8(&a0[8 * k], bfs[2 * t + k]);
+    };
+#pragma unroll
+    for (int sq = 0; sq < NSQ; ++sq) {
+      const int t = sq < NCH0 ? 0 : 1, c = sq < NCH0 ? sq : sq - NCH0;
+      cx_bf8 bf[3], af[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const cx_bf8*>(h0img + ((size_t)(c * 3 + p) * 64 + lane) * 16);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) af[t][p] = __builtin_bit_cast(cx_bf8, ra0[c % D0][t][p]);
-      if (c + D0 < NCH0) load0(c + D0, c % D0);
+      for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra0[sq % D0][p]);
+      if (sq + D0 < NSQ) load0(sq + D0, sq % D0);
       else {
 #pragma unroll
-        for (int q = (c + D0 - NCH0) * QPC; q < (c + D0 - NCH0 + 1) * QPC && q < F4_R1; ++q) load1(q);
+        for (int q = (sq + D0 - NSQ) * QPC; q < (sq + D0 - NSQ + 1) * QPC && q < F4_R1; ++q) load1(q);
       }
-      CX_MMA6(ah0[0], ac0[0], af[0], bf);
-      CX_MMA6(ah0[1], ac0[1], af[1], bf);
+      CX_MMA6(ah0[t], ac0[t], af, bf);
+      if (t == 1) {
+#pragma unroll
+        for (int j = c * 6 / NCH0; j < (c + 1) * 6 / NCH0; ++j) epi_job(0, j);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     stamp(2);
-
-    // ---------------------------------------------------------------- layer-0 epilogue: sigmoid (pad columns are zero), and
-    // the activations as the B fragments of this wavefront's four k chunks (48 registers; the float32 values are not kept)
-    cx_bf8 bfs[4][3];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float a0[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int col = 32 * (2 * w + t) + 8 * (i >> 2) + 4 * h + (i & 3);
-        const float s = chain_sigm(ah0[t][i] + ac0[t][i]);
-        a0[i] = (col < a.H1 && (t == 0 || has1)) ? s : 0.f;
-      }
-      cx_split8(&a0[0], bfs[2 * t]);
-      cx_split8(&a0[8], bfs[2 * t + 1]);
-    }
+    // (the second tile's epilogue rides under the first two k chunks of F1's first H2 tile, which need only the first tile's fragments)
 
     // ---------------------------------------------------------------- F1: partial Z1^T = W1^T[:, own K] . A0^T[own K], one H2
     // tile at a time (32 accumulator registers live instead of 96), each handed to the exchange as soon as it is complete
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void ctr_fwd4_kernel(ChainX3Args a) {
         const int nrow = next_tile * 32 + n;
         load_hv(nrow < a.B ? nrow : a.B - 1);
 #pragma unroll
-        for (int c = 0; c < D0; ++c) load0(c, c);
+        for (int sq = 0; sq < D0; ++sq) load0(sq, sq);
       }
     };
     // wavefront w finishes columns 32 u + 8 w + 4 h + r of H2 tile u from the four partials at `xb` ([ws][g = w][lane])
@@ -222,6 +228,10 @@ __global__ __launch_bounds__(256, 2) void ctr_fwd4_kernel(ChainX3Args a) {
         for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra1[q % F4_R1][p]);
         if (q + F4_R1 < 4 * CX_NU) load1(q + F4_R1);
         CX_MMA6(ah1, ac1, af, bfs[jj]);
+        if (u == 0 && jj < 2) {
+#pragma unroll
+          for (int j = 3 * jj; j < 3 * jj + 3; ++j) epi_job(1, j);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       // this wavefront's partial of tile u: [w][u][g][lane], or (XU) half u % 2: [w][g][lane]
