@@ -87,6 +87,7 @@ struct StepGraph {
   uint64_t ds = 0, emb = 0; int B = 0; int mode = 0; float p0 = 0, p1 = 0;
   uint32_t seed = 0; double lr = 0, l2 = 0, b1 = 0, b2 = 0, eps = 0; int flags = 0; int world = 1; bool comm = false;
   bool pipelined = false;   // the captured steps are pipelined (StepOpts::pipelined): a replay needs h0 of its first step
+  bool fac = false;         // gate_fac_mode() when the steps were captured (their attention launches leave the one factor)
   void destroy() {
     // goctr_train_steps does not synchronise: replays of these execs may still be queued or running, and destroying an
     // exec in flight is not something HIP documents as safe.  The capture that follows a destroy is host-heavy anyway.
@@ -111,7 +112,7 @@ struct StepGraph {
 // Where a forward pass keeps its per-row buffers: the training workspace (parity copies of gate / wgt), the model's
 // predict workspace, or a serving slot's.  A forward-only launch touches nothing else (the fused chain kernels write
 // yhat only; the modular per-layer path also needs P0 / P1).
-struct FwdBufs { float* h0; float* gate; float* wgt; float* yhat; float* P0; float* P1; };
+struct FwdBufs { float* h0; float* gate; float* wgt; float* yhat; float* P0; float* P1; float* fac = nullptr; };
 struct FwdWs {
   DevBuf<float> h0, gate, wgt, yhat, P0, P1;
   int B = 0, Ip = 0, T = 0;
@@ -153,10 +154,11 @@ struct goctr_model {
   float* img(int which) { return Wimg.p + (which == 0 ? 0 : which == 1 ? off1 : which == 2 ? off1 + H1p * H2p : off1 + 2 * H1p * H2p); }
   // per-batch workspace
   int wsB = 0, tnS = 0;
-  DevBuf<float> h0, P0, A0, P1, A1, yhat, lossrow, dz2, dz1, dz0, dp, gate, wgt, slabs0, slabs1, slabs2, attp;
+  DevBuf<float> h0, P0, A0, P1, A1, yhat, lossrow, dz2, dz1, dz0, dp, gate, wgt, gfac, slabs0, slabs1, slabs2, attp;
   DevBuf<float> mask0, mask1, slabs3, ones16;
   size_t gw_stride = 0;           // floats between the two parity copies of gate / wgt
   float* gate_p(int par) { return gate.p + (size_t)par * gw_stride; }
+  float* gfac_p(int par) { return gfac.p + (size_t)par * gw_stride; }
   float* wgt_p(int par) { return wgt.p + (size_t)par * gw_stride; }
   DevBuf<unsigned int> ra_flag;   // pipelined steps: gstep + 1 of the last step whose att0 update is visible device-wide (reduce_attn_kernel)
   DevBuf<float> yall;          // scores of a whole predict call (one device-to-host copy at the end)
@@ -186,7 +188,8 @@ struct goctr_model {
   // table's version its row updates; dataset and table are identified by their never-reused uids.
   uint64_t gen = 0;
   struct H0Carry { bool valid = false; uint64_t gen = 0, ds_uid = 0, emb_uid = 0, emb_version = 0; int B = 0, stp = 0; long long batch = -1;
-                   double beta1 = 0, beta2 = 0; /* (the bias corrections the last loss block left were made with these) */ } carry;
+                   double beta1 = 0, beta2 = 0; /* (the bias corrections the last loss block left were made with these) */
+                   bool fac = false; /* (gate and weight left as one factor: gate_fac_mode) */ } carry;
   bool attn_bwd_in_chain = false;  // launch_chain_x3 -> launch_backward: this step's chain launch wrote the att0 terms
   bool dpv_from_chain = false;    // the step's chain launch wrote dpv itself (launch_chain_x3): no dpv GEMM in this step
   // round 6: the step's chain launch left dW2 / the att0 terms as per-tile sums (tile_dw2 / tile_att0; ctr_chain_x3.h): the
@@ -344,6 +347,7 @@ int ensure_workspace(goctr_model* m, int B) {
   // step's backward still reads its own
   if (m->gate.alloc((size_t)2 * B * m->cfg.T)) return -1;
   if (m->wgt.alloc((size_t)2 * B * m->cfg.T)) return -1;
+  if (m->gfac.alloc((size_t)2 * B * m->cfg.T)) return -1;
   m->gw_stride = (size_t)B * m->cfg.T;
   if (m->ra_flag.alloc(1)) return -1;
   if (m->slabs0.alloc((size_t)S * m->Ip * m->H1p)) return -1;
@@ -644,6 +648,7 @@ void launch_chain_x3_n(const ChainX3Args& a, dim3 grid, hipStream_t s, bool fwd)
 
 bool emb_plan_active(const goctr_model* m) { return m->emb_lr > 0.f && m->plan.valid; }
 
+bool gate_fac_mode(const goctr_model* m, const RowSource& src, const StepOpts& o, int B);
 int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const StepState* st, const FwdBufs& fb) {
   const goctr_ctr_cfg& c = m->cfg;
   Engine& e = engine();
@@ -668,6 +673,7 @@ int launch_chain_x3(goctr_model* m, const RowSource& src, int B, const StepOpts&
                          env_int("GOCTR_CHAIN_ATTN_BWD", 1) != 0;
   if (m->attn_bwd_in_chain) {
     a.ab_ids = src.ub_ids; a.ab_emb = src.emb; a.ab_V = src.V; a.ab_gate = fb.gate; a.ab_wgt = fb.wgt; a.ab_out = m->attp.p;
+    a.ab_fac = gate_fac_mode(m, src, o, B) ? fb.fac : nullptr;
     a.ab_T = c.T; a.ab_Tp = m->Tp;
   }
   a.yhat = fb.yhat; a.lossrow = m->lossrow.p;
@@ -765,7 +771,7 @@ ChainArgs make_chain_args(goctr_model* m, const RowSource& src, int B, const Ste
   return a;
 }
 
-AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb);
+AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb, bool fac);
 int attn_fast_mode(const goctr_model* m, const RowSource& src, int* groups);
 // A small serving pass in key mode as ONE launch (ctr_serve.h): the shapes with a compile-time attention variant at 8, 16
 // or 64 embedding columns, launches the 16-row forward kernel would take (too few rows for a 32-row tile per CU)
@@ -782,7 +788,7 @@ int launch_serve16(goctr_model* m, const RowSource& src, int B, const StepState*
   StepOpts o; o.train = false;
   ChainArgs a = make_chain_args(m, src, B, o, st, fb);
   a.done = done; a.epoch = epoch;
-  AttnArgs aa = make_attn_args(m, src, B, st, fb);
+  AttnArgs aa = make_attn_args(m, src, B, st, fb, false);
   aa.gate = nullptr; aa.wgt = nullptr;                  // (only the training step's backward reads gates and weights)
   const size_t lds = chain_lds_bytes<5>(m->Ip, m->H1p, m->H2p);
   const dim3 grid((unsigned)cdiv(B, 16)), blk(1024);
@@ -838,8 +844,19 @@ int launch_chain(goctr_model* m, const RowSource& src, int B, const StepOpts& o,
 
 // forward part: kernels 1-4
 // `par`: which copy of gate / wgt the launch writes (the parity of the step the gather belongs to)
-FwdBufs train_bufs(goctr_model* m, int par) { return FwdBufs{m->h0.p, m->gate_p(par), m->wgt_p(par), m->yhat.p, m->P0.p, m->P1.p}; }
-AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb) {
+FwdBufs train_bufs(goctr_model* m, int par) { return FwdBufs{m->h0.p, m->gate_p(par), m->wgt_p(par), m->yhat.p, m->P0.p, m->P1.p, m->gfac_p(par)}; }
+// Round 6: where the ONLY reader of a training step's gates and similarity weights is the attention backward at the chain launch's
+// tail (DIN, frozen embeddings, id mode, the bf16-split chain: launch_chain_x3's attn_bwd_in_chain, which this predicate implies), the
+// attention forward leaves the one factor (g (1 - g)) w that backward multiplies with (AttnArgs::fac) instead of the two arrays.  The
+// producer -- the step's own attention launch, or the previous step's last launch -- and the consumer evaluate this with the same
+// (model, rows, options, batch); a start carried over from another call compares H0Carry::fac.  GOCTR_GATE_FAC=0: both arrays.
+bool gate_fac_mode(const goctr_model* m, const RowSource& src, const StepOpts& o, int B) {
+  const goctr_ctr_cfg& c = m->cfg;
+  return o.train && c.kind == GOCTR_DIN && src.id_mode && m->emb_lr <= 0.f && c.D == 16 && c.T <= 64 && chain_ok(m) &&
+         chain_x3_ok(m, o, B) && env_int("GOCTR_CHAIN_ATTN_BWD", 1) != 0 && env_int("GOCTR_GATE_FAC", 1) != 0;
+}
+// fac: gate_fac_mode() of the step that will consume the launch's rows
+AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, const FwdBufs& fb, bool fac) {
   const goctr_ctr_cfg& c = m->cfg;
   AttnArgs aa{};
   aa.src = src; aa.st = st; aa.B = B; aa.U = c.U; aa.T = c.T; aa.D = c.D; aa.C = c.C; aa.Ip = m->Ip;
@@ -847,10 +864,11 @@ AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepS
   aa.Tp_att = m->Tp;
   aa.xcd_affine = env_int("GOCTR_XCD_AFFINE", 1);      // (ctr_kernels.h xcd_unit_of_block; a permutation of the workgroups' samples)
   aa.inv_T = 1.0f / (float)c.T;
+  if (fac && fb.fac) { aa.fac = fb.fac; aa.gate = nullptr; aa.wgt = nullptr; }
   return aa;
 }
-AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, int par) {
-  return make_attn_args(m, src, B, st, train_bufs(m, par));
+AttnArgs make_attn_args(goctr_model* m, const RowSource& src, int B, const StepState* st, int par, bool fac) {
+  return make_attn_args(m, src, B, st, train_bufs(m, par), fac);
 }
 
 // the compile-time mode launch_attn_fwd picks for this model's rows, or 0; `groups` = lanes per embedding row
@@ -882,10 +900,10 @@ bool pipeline_ok(const goctr_model* m, const RowSource& src) {
          env_int("GOCTR_PIPELINE", 1) != 0;
 }
 
-int launch_reduce_attn(goctr_model* m, const RowSource& src, int B, const ReduceAdamArgs& p) {
+int launch_reduce_attn(goctr_model* m, const RowSource& src, int B, const StepOpts& o, const ReduceAdamArgs& p) {
   int groups = 0;
   const int fast = attn_fast_mode(m, src, &groups);
-  const AttnArgs aa = make_attn_args(m, src, B, p.r.st, m->stp ^ 1);      // the NEXT step's gates
+  const AttnArgs aa = make_attn_args(m, src, B, p.r.st, m->stp ^ 1, gate_fac_mode(m, src, o, B));      // the NEXT step's gates
   const int nred = (int)cdiv((int64_t)m->nflat * 2, 256) + 1;
   const dim3 grid((unsigned)(nred + cdiv(B, 4))), blk(256);
   hipStream_t st = engine().active;
@@ -910,7 +928,7 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
   const StepState* st = st_override ? st_override : m->st_cur();
   const FwdBufs fb = fbp ? *fbp : train_bufs(m, m->stp);
   if (!o.pipelined) {
-    AttnArgs aa = make_attn_args(m, src, B, st, fb);
+    AttnArgs aa = make_attn_args(m, src, B, st, fb, gate_fac_mode(m, src, o, B));
     if (!o.train) { aa.gate = nullptr; aa.wgt = nullptr; }     // (only the backward reads them: 13 MB less per 32 768-row launch)
     if (launch_attn_fwd(aa)) return -1;
   }
@@ -1572,7 +1590,7 @@ int launch_reduce_part(goctr_model* m, const RowSource& src, int B, const StepOp
     p.ra_flag = m->ra_flag.p; p.ra_block = (o.pipelined && c.kind == GOCTR_DIN) ? (m->offa * 2) / 256 : -1;
     ProfScope ps(GOCTR_K_REDUCE);
     if (o.pipelined) {
-      if (launch_reduce_attn(m, src, B, p)) return -1;     // + attn_fwd of the next step's batch
+      if (launch_reduce_attn(m, src, B, o, p)) return -1;     // + attn_fwd of the next step's batch
     } else {
       hipLaunchKernelGGL(reduce_adam_kernel, dim3((unsigned)cdiv((int64_t)m->nflat * 2, 256) + 1), dim3(256), 0, e.stream, p);
       GOCTR_HIP(hipGetLastError());
@@ -1621,7 +1639,7 @@ int launch_adam_step(goctr_model* m, const RowSource& src, int B, const StepOpts
   int groups = 0;
   const int fast = attn_fast_mode(m, src, &groups);
   const AdamArgs ad = make_adam_args(m, B, *o.tc);
-  const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
+  const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp, gate_fac_mode(m, src, o, B));
   const int nadam = (int)cdiv(m->nflat, 256) + 1;
   const int ra_block = m->cfg.kind == GOCTR_DIN ? m->offa / 256 : -1;
   const dim3 grid((unsigned)(nadam + cdiv(B, 4))), blk(256);
@@ -1662,8 +1680,8 @@ int train_step_eager(goctr_model* m, const RowSource& src, int B, const StepOpts
   return launch_adam(m, B, *o.tc);
 }
 
-bool graph_matches(const StepGraph& g, const goctr_dataset* d, const goctr_emb* e, int B, const StepOpts& o) {
-  return g.a[0] && g.a[1] && g.ds == d->uid && g.emb == (e ? e->uid : 0) && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
+bool graph_matches(const StepGraph& g, const goctr_dataset* d, const goctr_emb* e, int B, const StepOpts& o, bool fac) {
+  return g.fac == fac && g.a[0] && g.a[1] && g.ds == d->uid && g.emb == (e ? e->uid : 0) && g.B == B && g.mode == o.drop_mode && g.p0 == o.p0 && g.p1 == o.p1 &&
          g.seed == o.seed && g.lr == o.tc->lr && g.l2 == o.tc->l2 && g.b1 == o.tc->beta1 && g.b2 == o.tc->beta2 &&
          g.eps == o.tc->eps && g.flags == o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div &&
          g.world == engine().eff_world() && g.comm == engine().comm_active() && g.pipelined == o.pipelined;
@@ -1713,7 +1731,7 @@ int build_graph(goctr_model* m, const goctr_dataset* d, const goctr_emb* emb, co
   sg.ds = d->uid; sg.emb = emb ? emb->uid : 0; sg.B = B; sg.mode = o.drop_mode; sg.p0 = o.p0; sg.p1 = o.p1; sg.seed = o.seed;
   sg.lr = o.tc->lr; sg.l2 = o.tc->l2; sg.b1 = o.tc->beta1; sg.b2 = o.tc->beta2; sg.eps = o.tc->eps;
   sg.flags = o.tc->adam_div_by_batch * 2 + o.tc->adam_l2_before_batch_div; sg.world = e.eff_world(); sg.comm = e.comm_active();
-  sg.pipelined = o.pipelined;
+  sg.pipelined = o.pipelined; sg.fac = gate_fac_mode(m, src, o, B);
   stp_guard.ok = true;
   return 0;
 }
@@ -1882,6 +1900,7 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
   const bool carried = use_graph && o.pipelined && n_steps > 0 && cy.valid && retargeted && cy.gen + 1 == m->gen && cy.ds_uid == d->uid &&
                        emb && cy.emb_uid == emb->uid && cy.emb_version == emb->version && cy.B == B && cy.stp == m->stp &&
                        cy.batch == start_batch && cy.beta1 == (double)o.tc->beta1 && cy.beta2 == (double)o.tc->beta2 &&
+                       cy.fac == gate_fac_mode(m, src, o, B) &&
                        env_int("GOCTR_H0_CARRY", 1) != 0;
   // The state-preparation launch: the cursor retarget of goctr_train_steps + the bias corrections of the state the call starts
   // from (ctr_kernels.h: StepState::corr1/2; later states get theirs from the loss block of the step before them).  A carried
@@ -1893,10 +1912,10 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
   }
   m->pend_retarget = false;
   if (use_graph) {
-    if (!graph_matches(m->graph, d, emb, B, o) && build_graph(m, d, emb, src, B, o)) return -1;
+    if (!graph_matches(m->graph, d, emb, B, o, gate_fac_mode(m, src, o, B)) && build_graph(m, d, emb, src, B, o)) return -1;
     if (o.pipelined && n_steps > 0 && !carried) {
       // the first step's h0 (every later step gets it from its predecessor's last launch)
-      const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
+      const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp, gate_fac_mode(m, src, o, B));
       if (launch_attn_fwd(aa)) return -1;
     }
     m->carry.valid = false;
@@ -1937,7 +1956,7 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
     }
     if (o.pipelined && n_steps > 0 && retargeted && emb && start_nb > 0) {
       m->carry = goctr_model::H0Carry{true, m->gen, d->uid, emb->uid, emb->version, B, m->stp, (start_batch + n_steps) % start_nb,
-                                      (double)o.tc->beta1, (double)o.tc->beta2};
+                                      (double)o.tc->beta1, (double)o.tc->beta2, gate_fac_mode(m, src, o, B)};
     }
   } else {
     if (m->emb_lr > 0.f && emb && n_steps > 0) ++emb->version;
@@ -1947,7 +1966,7 @@ int run_steps_impl(goctr_model* m, goctr_emb* emb, goctr_dataset* d, const goctr
     // issued eagerly, launch by launch, instead of as a captured graph
     if (!e.prof && !e.comm_active() && n_steps > 0 && env_int("GOCTR_EAGER_PIPELINE", 0) != 0 && pipeline_ok(m, src)) {
       o.pipelined = true;
-      const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp);
+      const AttnArgs aa = make_attn_args(m, src, B, m->st_cur(), m->stp, gate_fac_mode(m, src, o, B));
       if (launch_attn_fwd(aa)) return -1;
     }
     for (int s = 0; s < n_steps; ++s)

@@ -55,7 +55,7 @@ struct ChainX3Args {
   // attn_bwd_kernel does it).  The per-sample terms of the att0 gradient need dp -- which this kernel ends with -- and the
   // behaviour rows again; ids, gates and rows are requested while B0 / the dp product run, so the launch that used to
   // follow (6.0 us at cfg3: 410 k row gathers behind a kernel boundary) becomes ~50 instructions per sample at the tail.
-  const int32_t* ab_ids; const float* ab_emb; long long ab_V; const float* ab_gate; const float* ab_wgt; float* ab_out;
+  const int32_t* ab_ids; const float* ab_emb; long long ab_V; const float* ab_gate; const float* ab_wgt; const float* ab_fac; float* ab_out;   // ab_fac: (g (1 - g)) w ready-made (AttnArgs::fac), else gate and weight
   int ab_T, ab_Tp;
   // Round 6: gradients whose operands this launch holds in registers leave as PER-TILE sums instead (null: the operands are
   // stored and the weight-gradient launch multiplies them): tile_dw2 [tiles][H2p] = sum over the tile's rows of A1[row][f] *
@@ -79,6 +79,7 @@ inline size_t chain_x3_lds_bytes() {
 #ifndef CX_EXP
 #define CX_EXP 0
 #endif
+
 // 6-product bf16-split MFMA step for one 32x32x16 block: ah += hi*hi ; ac += everything else (smallest terms first)
 #define CX_MMA6(AH, AC, A, B)                                                         \
   do {                                                                                \
@@ -155,16 +156,24 @@ __device__ __forceinline__ void cx_ab_ids(const Args& a, int tile, int w, int la
 }
 // (gates and similarity weights are only needed at the very end: requested late, 8 registers less through the products)
 template <class Args>
-__device__ __forceinline__ void cx_ab_gw(const Args& a, int tile, int w, int lane, float (&abg)[4], float (&abw)[4]) {
+__device__ __forceinline__ void cx_ab_gw(const Args& a, int tile, int w, int lane, float (&abf)[4]) {
   const int lc = lane < a.ab_T ? lane : a.ab_T - 1;
+  if (a.ab_fac) {           // (uniform) the factor as the attention forward left it: one load per sample instead of two
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int b = tile * 32 + 4 * w + s;
+      const int bc = b < a.B ? b : a.B - 1;
+      const float f = a.ab_fac[(size_t)bc * a.ab_T + lc];
+      abf[s] = (b < a.B && lane < a.ab_T) ? f : 0.f;
+    }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int b = tile * 32 + 4 * w + s;
     const int bc = b < a.B ? b : a.B - 1;
     const float g = a.ab_gate[(size_t)bc * a.ab_T + lc], wv = a.ab_wgt[(size_t)bc * a.ab_T + lc];
-    const bool in = b < a.B && lane < a.ab_T;
-    abg[s] = in ? g : 0.f;
-    abw[s] = in ? wv : 0.f;
+    abf[s] = (b < a.B && lane < a.ab_T) ? (g * (1.0f - g)) * wv : 0.f;      // (the same statement as AttnArgs::fac: the same bits)
   }
 }
 // Samples whose rows are requested inside F0's chunk loop, one or two gathers per chunk (the others: behind B0).  A gather
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     y = (a.Y && vrow && gr < a.rows) ? a.Y[gr] : 0.f;
   }
   const bool ab = !FWD && din && a.ab_ids != nullptr;
-  int abid[4] = {-1, -1, -1, -1}; float abg[4] = {0.f, 0.f, 0.f, 0.f}, abw[4] = {0.f, 0.f, 0.f, 0.f};
+  int abid[4] = {-1, -1, -1, -1}; float abf[4] = {0.f, 0.f, 0.f, 0.f};
   float abx[4][4][4];
   if (ab) cx_ab_ids(a, tile, w, lane, abid);
   // layer-1 columns this wavefront finishes after the exchange: group (u = w / 4, g = w % 4) and, for wavefronts 0..3,
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     for (int p = 0; p < 3; ++p) af[p] = __builtin_bit_cast(cx_bf8, ra2[c][p]);
     CX_MMA6(ahb, acb, af, bf);
   }
-  if (ab) cx_ab_gw(a, tile, w, lane, abg, abw);
+  if (ab) cx_ab_gw(a, tile, w, lane, abf);
   if (ab) {      // the behaviour rows of the remaining samples, in flight under the epilogue and the dp product
 #pragma unroll
     for (int k = 4 * CX_AB_EARLY; k < 16; ++k) cx_ab_gather_one(a, abid, lane, k >> 2, k & 3, abx);
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int b = tile * 32 + 4 * w + s;
-        tsum += (b < a.B && lane < T) ? term[s] * (abg[s] * (1.0f - abg[s])) * abw[s] : 0.f;
+        tsum += (b < a.B && lane < T) ? term[s] * abf[s] : 0.f;
       }
       xch[w * 64 + lane] = tsum;                              // (the exchange area is free since barrier 6)
       __syncthreads();                                        // (7)
@@ -682,7 +691,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
       const int b = tile * 32 + 4 * w + s;
       if (b < a.B) {
         float* out = a.ab_out + (size_t)b * a.ab_Tp;
-        if (lane < T) out[lane] = term[s] * (abg[s] * (1.0f - abg[s])) * abw[s];
+        if (lane < T) out[lane] = term[s] * abf[s];
         for (int t = T + lane; t < a.ab_Tp; t += 64) out[t] = 0.f;
       }
     }

@@ -102,6 +102,10 @@ struct AttnArgs {
   float* h0;    // [B, Ip]
   float* gate;  // [B, T]
   float* wgt;   // [B, T]
+  // [B, T] or null.  Where the only reader of gate and weight is the chain launch's attention backward (DIN, frozen embeddings, id mode:
+  // ctr.hip gate_fac_mode) the two leave as ONE factor (g (1 - g)) w -- what that backward multiplies its term with -- and gate / wgt
+  // are not written: 2 x 1.6 MB less written by this launch and read by the chain launch at cfg3
+  float* fac;
   int Tp_att;   // (reduce_attn_kernel) padded length of the att0 segment of the flat parameter buffer
   int xcd_affine;   // training launches: workgroup -> four-sample group by xcd_unit_of_block (below)
   float inv_T;      // 1.0f / (float)T, computed once on the host (the same IEEE division the kernels did per sample)
@@ -413,7 +417,9 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
       }
       g_l = sigm_hidden(w_l * aw);
     }
-    if (a.gate && lane < NPB * RPP && tb + lane < T) {      // (forward-only passes hand no gate / weight buffers: nobody reads them)
+    if (a.fac) {
+      if (lane < NPB * RPP && tb + lane < T) a.fac[(size_t)b * T + tb + lane] = (g_l * (1.0f - g_l)) * w_l;
+    } else if (a.gate && lane < NPB * RPP && tb + lane < T) {      // (forward-only passes hand no gate / weight buffers: nobody reads them)
       a.gate[(size_t)b * T + tb + lane] = g_l;
       a.wgt[(size_t)b * T + tb + lane] = w_l;
     }
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(64 * ATTN_BWD_WAVES) void attn_bwd_kernel(AttnBwdAr
       const float dgs = __shfl(dg, src, 64);   // the row group of slot (p, lane % RPP)
       if (pw == p) term = dgs;
     }
-    if (lane < NPB * RPP && tb + lane < T) out[tb + lane] = term * gw * wl;   // one coalesced store
+    if (lane < NPB * RPP && tb + lane < T) out[tb + lane] = term * (gw * wl);   // one coalesced store (the factor first: AttnArgs::fac)
   }
 }
 
