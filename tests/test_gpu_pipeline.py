@@ -197,7 +197,7 @@ def test_four_wavefront_forward_kernel_against_the_eight_wavefront_one(kind, D, 
     assert not np.array_equal(ys[0], np.full(rows, ys[0][0]))
 
 
-@pytest.mark.parametrize("between", ["nothing", "set_att0", "set_rows", "predict", "jump", "other_steps"])
+@pytest.mark.parametrize("between", ["nothing", "set_att0", "set_rows", "predict", "jump", "other_steps", "train_emb"])
 def test_h0_carried_from_the_previous_call_only_when_nothing_touched_it(between):
     """the last launch of a goctr_train_steps call has computed the next batch's h0 / gates; the next call skips its first
     attn_fwd when it starts at exactly that batch and no entry point that could touch weights, table, dataset or workspace ran
@@ -235,6 +235,10 @@ def test_h0_carried_from_the_previous_call_only_when_nothing_touched_it(between)
                 nxt = 3
             elif between == "other_steps":
                 gm.train_steps(m, ds, cfg, 2, first_batch=20, emb=tab)
+            elif between == "train_emb":
+                # (the first call's attention launches left the one factor (g (1 - g)) w, AttnArgs::fac; with the table trainable the
+                # backward reads gate and weight themselves: what the first call's last launch computed must not be carried)
+                m.set_embedding_training(0.05)
             c2 = gm.train_steps(m, ds, cfg, 10, first_batch=nxt, emb=tab, want_costs=True)
             res.append((c1, c2, m.get_weights("mlp0"), m.get_weights("att0")))
         finally:
