@@ -814,13 +814,12 @@ void build_huffman(const int64_t* counts, int64_t V, int max_depth, std::vector<
   }
 }
 
-// vocabularies from GOCTR_HUFFMAN_DEVICE_MIN words on (default 50 000) are built with the device (huffman.hip); below that the
-// host builder is faster than the copies.  GOCTR_HUFFMAN_DEVICE=0 / 1 forces either.
+// vocabularies from 50 000 words on are built with the device (huffman.hip); below that the host builder is faster than the
+// copies.  GOCTR_HUFFMAN_DEVICE=0 / 1 forces either.
 bool huffman_on_device(int64_t V) {
   const char* f = getenv("GOCTR_HUFFMAN_DEVICE");
   if (f && *f) return *f != '0';
-  const char* m = getenv("GOCTR_HUFFMAN_DEVICE_MIN");
-  return V >= (m && *m ? atoll(m) : 50000);
+  return V >= 50000;
 }
 
 }  // namespace
