@@ -195,6 +195,7 @@ struct goctr_model {
   // round 6: the step's chain launch left dW2 / the att0 terms as per-tile sums (tile_dw2 / tile_att0; ctr_chain_x3.h): the
   // weight-gradient launch only adds the tiles up (mfma_gemm.h tn_tile_sum_body) and A1, dz2, attp are not written at all
   bool dw2_from_chain = false, att0_from_chain = false;
+  bool att0_early = false;       // this step's weight-gradient launch has already updated att0 (ctr_chain_x3.h att0_early_body): launch_backward -> launch_reduce_part
   DevBuf<float> tile_dw2, tile_att0;
   DevBuf<unsigned int> emb_mark, emb_rank, emb_tiles;
   DevBuf<unsigned long long> emb_total;
@@ -481,7 +482,8 @@ int init_kernel_attrs() {
       allow_big_lds(emb_grad_kernel<32, 1, true>) || allow_big_lds(emb_grad_kernel<32, 2, true>) || allow_big_lds(emb_grad_kernel<64, 0, true>) || allow_big_lds(emb_grad_kernel<64, 1, true>) ||
       allow_big_lds(emb_grad_kernel<64, 2, true>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 16>) || allow_big_lds(gemm_tn_kernel<float, 4, 3, 32>) ||
       allow_big_lds(gemm_tn_kernel<float, 3, 4, 32>) || allow_big_lds(gemm_tn_multi_kernel<3, 4, GOCTR_TN_CH>) ||
-      allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(gemm_tn_multi_x3w_kernel<9, 5>) || allow_big_lds(gemm_tn_multi_x3w_kernel<8, 5>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
+      allow_big_lds(gemm_tn_multi_x3_kernel<3, 4>) || allow_big_lds(gemm_tn_multi_x3w_kernel<9, 5>) || allow_big_lds(gemm_tn_multi_x3w_kernel<8, 5>) ||
+      allow_big_lds(gemm_tn_multi_x3w_att0_kernel<9, 5>) || allow_big_lds(gemm_tn_multi_x3w_att0_kernel<8, 5>) || allow_big_lds(ctr_chain_x3_kernel<2>) || allow_big_lds(ctr_chain_x3_kernel<9>) ||
       allow_big_lds(ctr_chain_x3_kernel<15>) || chain_x3_fwd_attributes() || fwd4_attributes() ||
       serve16_attributes()) return -1;
   done = true;
@@ -932,7 +934,7 @@ int launch_forward(goctr_model* m, const RowSource& src, int B, const StepOpts& 
     if (!o.train) { aa.gate = nullptr; aa.wgt = nullptr; }     // (only the backward reads them: 13 MB less per 32 768-row launch)
     if (launch_attn_fwd(aa)) return -1;
   }
-  if (o.train) { m->dpv_from_chain = false; m->attn_bwd_in_chain = false; m->dw2_from_chain = false; m->att0_from_chain = false; }   // (launch_chain_x3 sets them when it does the work itself)
+  if (o.train) { m->dpv_from_chain = false; m->attn_bwd_in_chain = false; m->dw2_from_chain = false; m->att0_from_chain = false; m->att0_early = false; }   // (launch_chain_x3 / launch_backward set them when they do the work themselves)
   if (chain_ok(m)) return launch_chain(m, src, B, o, st, fb);  // layers + (when training) backward-data, fused
 
   const int bglobal = B * e.eff_world();
@@ -1475,6 +1477,16 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
                  b0 + b1, tw.rowsL, tw.SL, 0, 0};
     }
     int nblk = b0 + b1 + SL2;
+    // att0's update inside this launch (ctr_chain_x3.h att0_early_body): the single-GPU pipelined step with the per-tile sums of the
+    // att0 terms, where the step's last launch also runs the next batch's attention -- which then needs no flag (launch_reduce_part).
+    // GOCTR_ATT0_EARLY=0: the sum problem below + the reduce block + the flag, as until round 6's last session.
+    m->att0_early = c.kind == GOCTR_DIN && m->att0_from_chain && o.pipelined && fuse_update && stage == 0 && !e.comm_active() &&
+                    m->Tp % 32 == 0 && env_int("GOCTR_ATT0_EARLY", 1) != 0;
+    Att0EarlyArgs ae{};
+    if (m->att0_early) {
+      ae.tile_att0 = m->tile_att0.p; ae.ntiles = ntiles; ae.Tp = m->Tp; ae.tps = tps; ae.nslabs = (int)cdiv(ntiles, tps);
+      ae.ad = make_adam_args(m, B, *o.tc); ae.st = st;
+    } else
     if (c.kind == GOCTR_DIN) {  // datt0 = ones^T . dgs  (column sums over the batch)
       if (m->att0_from_chain) {
         SL3 = (int)cdiv(ntiles, tps);
@@ -1493,6 +1505,13 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
     {
       ProfScope ps(GOCTR_K_DW0);
       if (ps.on) prof_note_kernel(GOCTR_K_DW0, tw.ktw0 == 9 ? "gemm_tn_multi_x3w_kernel<9,5>" : "gemm_tn_multi_x3w_kernel<8,5>");
+      if (m->att0_early) {      // (one more workgroup, the last: att0's sum and update)
+        if (ps.on) prof_note_kernel(GOCTR_K_DW0, tw.ktw0 == 9 ? "gemm_tn_multi_x3w_att0_kernel<9,5>" : "gemm_tn_multi_x3w_att0_kernel<8,5>");
+        if (tw.ktw0 == 9)
+          hipLaunchKernelGGL((gemm_tn_multi_x3w_att0_kernel<9, 5>), dim3((unsigned)nblk + 1), dim3(512), gemm_tn_multi_x3w_lds_bytes<9>(), e.stream, tm, ae);
+        else
+          hipLaunchKernelGGL((gemm_tn_multi_x3w_att0_kernel<8, 5>), dim3((unsigned)nblk + 1), dim3(512), gemm_tn_multi_x3w_lds_bytes<8>(), e.stream, tm, ae);
+      } else
       if (tw.ktw0 == 9)
         hipLaunchKernelGGL((gemm_tn_multi_x3w_kernel<9, 5>), dim3((unsigned)nblk), dim3(512), gemm_tn_multi_x3w_lds_bytes<9>(), e.stream, tm);
       else
@@ -1572,7 +1591,7 @@ int launch_backward(goctr_model* m, const RowSource& src, int B, const StepOpts&
   ra.seg[1] = {m->slabs1.p, S1, (unsigned long long)m->H1p * m->H2p, m->off1, m->H1p * m->H2p};
   ra.seg[2] = {m->slabs2.p, SL2x > 0 ? SL2x : (multi ? SLx : S), (unsigned long long)m->H2p * 16, m->off2, m->H2p * 16};
   ra.nseg = 3;
-  if (c.kind == GOCTR_DIN) {
+  if (c.kind == GOCTR_DIN && !m->att0_early) {      // (att0_early: no slabs, the weight-gradient launch has updated att0 itself)
     ra.seg[3] = {m->slabs3.p, SL3x > 0 ? SL3x : (multi ? SLx : S), (unsigned long long)16 * m->Tp, m->offa, m->Tp};
     ra.nseg = 4;
   }
@@ -1588,6 +1607,9 @@ int launch_reduce_part(goctr_model* m, const RowSource& src, int B, const StepOp
     ReduceAdamArgs p{};
     p.r = ra; p.ad = make_adam_args(m, B, *o.tc);
     p.ra_flag = m->ra_flag.p; p.ra_block = (o.pipelined && c.kind == GOCTR_DIN) ? (m->offa * 2) / 256 : -1;
+    if (m->att0_early) {      // att0 is already this step's: no flag for the attention part, and the reduce part keeps its hands off
+      p.ra_flag = nullptr; p.ra_block = -1; p.skip_begin = m->offa; p.skip_len = m->Tp;
+    }
     ProfScope ps(GOCTR_K_REDUCE);
     if (o.pipelined) {
       if (launch_reduce_attn(m, src, B, o, p)) return -1;     // + attn_fwd of the next step's batch

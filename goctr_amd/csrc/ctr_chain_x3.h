@@ -706,6 +706,72 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   }   // (tile loop)
 }
 
+// ---------------------------------------------------------------- att0's update inside the weight-gradient launch
+// The attention weights att0 (T floats) are the one parameter the step's LAST launch both updates and uses: reduce_attn_kernel's
+// attention wavefronts -- the next batch's gather, gate and pooling -- wait ~2 us into their life for the flag of the reduce block that
+// owns att0 (state -> slabs -> moments -> Adam -> write-through -> flag), and every one of the launch's 8192 wavefronts is resident and
+// waiting by then: measured with the wait taken out (stale weights, same work) the step is 2.2 us shorter (profiles/r06_att0_early.txt).
+// With the per-tile sums of the att0 terms out of the chain launch (ChainX3Args::tile_att0) their total needs no MFMA problem, only
+// additions -- so ONE extra workgroup of the weight-gradient launch adds the tiles up and applies Adam to att0 right there: the new
+// weights are in memory a launch boundary before anybody reads them, the last launch's attention part needs no flag and its reduce part
+// leaves [offa, offa + Tp) alone (ReduceAdamArgs::skip_*).
+// Same bits as the path it replaces, addition for addition: that path summed tiles [j tps, (j + 1) tps) in ascending order into slab j
+// (mfma_gemm.h tn_tile_sum_body), then per float4 group lane pl of 8 added slabs [pl spp, (pl + 1) spp) in ascending order onto 0 and a
+// xor-butterfly (1, 2, 4) added the eight lanes (ctr_kernels.h slab_group_sum), then adam_apply_pre with the step's corr1 / corr2.
+struct Att0EarlyArgs {
+  const float* tile_att0; int ntiles, Tp, tps, nslabs;     // [ntiles][Tp]; tiles per slab and slab count of the path this replaces
+  AdamArgs ad; const StepState* st;
+};
+__device__ __forceinline__ void att0_early_body(const Att0EarlyArgs& e) {
+  const int gid = (int)threadIdx.x;
+  if (gid >= 2 * e.Tp) return;                               // 8 lanes per float4 group, Tp / 4 groups (whole wavefronts: Tp % 32 == 0)
+  const int c0 = (gid >> 3) * 4, pl = gid & 7;               // columns c0 .. c0 + 3 of att0
+  const int idx = e.ad.offa + c0 + pl;
+  const bool mine = pl < 4 && c0 + pl < e.Tp;
+  float w0 = 0.f, m0 = 0.f, v0 = 0.f;
+  if (mine) { w0 = e.ad.W[idx]; m0 = e.ad.Mo[idx]; v0 = e.ad.Vo[idx]; }
+  const float corr1 = e.st->corr1, corr2 = e.st->corr2;
+  const int spp = (e.nslabs + 7) >> 3;
+  const int lo = pl * spp;
+  int hi = lo + spp; if (hi > e.nslabs) hi = e.nslabs;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = lo; j < hi; ++j) {
+    const int t0 = j * e.tps;
+    int t1 = t0 + e.tps; if (t1 > e.ntiles) t1 = e.ntiles;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int tb = t0; tb < t1; tb += 16) {
+      float4 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int t = tb + u < t1 ? tb + u : t1 - 1;
+        v[u] = *reinterpret_cast<const float4*>(e.tile_att0 + (size_t)t * e.Tp + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const bool in = tb + u < t1;
+        s.x += in ? v[u].x : 0.f; s.y += in ? v[u].y : 0.f; s.z += in ? v[u].z : 0.f; s.w += in ? v[u].w : 0.f;
+      }
+    }
+    acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  if (mine) {
+    const float g = pl == 0 ? acc.x : (pl == 1 ? acc.y : (pl == 2 ? acc.z : acc.w));
+    adam_apply_pre(e.ad, idx, g, corr1, corr2, w0, m0, v0);
+  }
+}
+// the wide weight-gradient launch with that workgroup behind its own (the last one: every workgroup of the launch has a CU to itself)
+template <int KTW0, int KTW1>
+__global__ __launch_bounds__(512) void gemm_tn_multi_x3w_att0_kernel(TnMulti a, Att0EarlyArgs e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
+  if (blockIdx.x == gridDim.x - 1) { att0_early_body(e); return; }
+  tn_multi_x3w_block<KTW0, KTW1>(a, goctr_smem);
+}
+
 // (defined in ctr_fwd.hip)
 int chain_x3_fwd_attributes();
 // ctr_fwd4.h (also instantiated in ctr_fwd.hip): four wavefronts per tile, two workgroups per CU; Ip = 32, 144 or 240

@@ -824,6 +824,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
 struct ReduceAdamArgs {
   ReduceArgs r; AdamArgs ad;
   unsigned int* ra_flag; int ra_block;    // reduce_attn_kernel: block ra_block owns the att0 segment and publishes gstep + 1 (-1: none)
+  int skip_begin, skip_len;               // parameters [skip_begin, skip_begin + skip_len) were already updated by an earlier launch of
+                                          // this step (ctr_chain_x3.h att0_early_body: att0 inside the weight-gradient launch): hands off
 };
 
 // sum of one float4 parameter group (elements e0 .. e0 + 3) over the slabs of its segment: the 8 lanes of the group take a
@@ -896,7 +898,8 @@ __device__ __forceinline__ void reduce_adam_body(const ReduceAdamArgs& p, int bl
   } else {
     const int gid = blk * 256 + threadIdx.x;
     const int e0 = (gid >> 3) * 4, pl = gid & 7;
-    const bool mine = pl < 4 && e0 + pl < a.nflat;           // lanes 0..3 of a group own one parameter each
+    const bool mine = pl < 4 && e0 + pl < a.nflat &&         // lanes 0..3 of a group own one parameter each
+                      !(e0 + pl >= p.skip_begin && e0 + pl < p.skip_begin + p.skip_len);
     float w0 = 0.f, m0 = 0.f, v0 = 0.f;
     if (mine) { w0 = p.ad.W[e0 + pl]; m0 = p.ad.Mo[e0 + pl]; v0 = p.ad.Vo[e0 + pl]; }
     const float corr1 = a.st->corr1, corr2 = a.st->corr2;    // (the step's bias corrections travel with its state)
@@ -957,7 +960,7 @@ __global__ __launch_bounds__(256) void reduce_attn_kernel(ReduceAdamArgs p, Attn
   if (nb >= r.st->n_batches) nb = 0;
   const RaCtx ctx{p.ra_flag, r.st->gstep + 1u, a.att0};
   const int grp = a.xcd_affine ? xcd_unit_of_block_after((int)blockIdx.x, nred, (a.B + 3) >> 2, 32) : (int)blockIdx.x - nred;
-  attn_fwd_body<VEC, LPR, FAST>(a, grp, nb, a.att0, FAST >= 2 ? &ctx : nullptr);
+  attn_fwd_body<VEC, LPR, FAST>(a, grp, nb, a.att0, FAST >= 2 && p.ra_flag ? &ctx : nullptr);
 }
 
 // The data-parallel step's counterpart of reduce_attn_kernel: the step is [.. reduce] -> all-reduce -> [Adam], and what can share

@@ -923,9 +923,9 @@ __device__ __forceinline__ void tn_tile_sum_body(const TnMulti& a, const TnProbl
 // per slab the workgroups stage 496 + 368 operand columns instead of 768 + 496 (every D column was staged once per
 // 3-tile k-block: dz0 three times, A0 twice), and the slabs of the two problems get their own heights so that the
 // differently sized blocks cost the same.  One-tile problems keep the <1, 4> body.
+// (the kernel's body as a function: ctr_chain_x3.h's gemm_tn_multi_x3w_att0_kernel runs it in all of its workgroups but the last)
 template <int KTW0, int KTW1>
-__global__ __launch_bounds__(512) void gemm_tn_multi_x3w_kernel(TnMulti a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
+__device__ __forceinline__ void tn_multi_x3w_block(const TnMulti& a, unsigned char* goctr_smem) {
   int pi = 0;
 #pragma unroll
   for (int k = 1; k < 4; ++k) if (k < a.np && (int)blockIdx.x >= a.p[k].first) pi = k;
@@ -940,6 +940,11 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_x3w_kernel(TnMulti a) {
   int nb_t = P.NT - n0t; if (nb_t > P.nbt) nb_t = P.nbt;
   if (pi == 0) tn_multi_body_x3<KTW0, 2>(a, P, kb, n0t, nb_t, split, goctr_smem);
   else tn_multi_body_x3<KTW1, 2>(a, P, kb, n0t, nb_t, split, goctr_smem);
+}
+template <int KTW0, int KTW1>
+__global__ __launch_bounds__(512) void gemm_tn_multi_x3w_kernel(TnMulti a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char goctr_smem[];
+  tn_multi_x3w_block<KTW0, KTW1>(a, goctr_smem);
 }
 template <int KTW>
 inline size_t gemm_tn_multi_x3w_lds_bytes() {

@@ -84,7 +84,7 @@ def test_cfg4_youtube_6_pipelined_graph_steps_vs_oracle(oracle):
 
 
 @pytest.mark.parametrize("knob", ["GOCTR_PIPELINE", "GOCTR_GRAPH_STEPS", "GOCTR_NO_GRAPH", "GOCTR_CHAIN_ATTN_BWD", "GOCTR_CHAIN_TILE_SUMS",
-                                  "GOCTR_XCD_AFFINE", "GOCTR_TN_WT", "GOCTR_GATE_FAC"])
+                                  "GOCTR_XCD_AFFINE", "GOCTR_TN_WT", "GOCTR_GATE_FAC", "GOCTR_ATT0_EARLY"])
 def test_id_mode_pipelined_graphs_equal_unpipelined_and_eager(knob):
     """id mode, B = 8192 (377 reduce blocks beside 2048 attention workgroups in the merged launch), dropout on, 39 steps =
     16 + 16 + 4 + 2 + 1: the default path and the path with the knob flipped must land on the same bits"""
@@ -102,9 +102,12 @@ def test_id_mode_pipelined_graphs_equal_unpipelined_and_eager(knob):
     # weight-gradient launch's MFMA problems instead of per tile in the chain launch -- another float32 summation order, compared
     # at 2e-6 below; the GOCTR_CHAIN_ATTN_BWD comparison is between the two stored-terms paths, i.e. with the tile sums off.
     # GOCTR_GATE_FAC=0: the attention forward stores gate and similarity weight and the chain launch's tail forms (g (1 - g)) w itself
-    # instead of reading that factor ready-made -- the same statement on the same values, the same bits)
+    # instead of reading that factor ready-made -- the same statement on the same values, the same bits.
+    # GOCTR_ATT0_EARLY=0: att0's tile sums go through slabs and the last launch's reduce block, whose flag the attention wavefronts
+    # wait for, instead of one workgroup of the weight-gradient launch adding them up and applying Adam -- the same additions in the
+    # same order, the same bits)
     flipped = {"GOCTR_PIPELINE": "0", "GOCTR_GRAPH_STEPS": "0", "GOCTR_NO_GRAPH": "1", "GOCTR_CHAIN_ATTN_BWD": "0",
-               "GOCTR_CHAIN_TILE_SUMS": "0", "GOCTR_XCD_AFFINE": "0", "GOCTR_TN_WT": "0", "GOCTR_GATE_FAC": "0"}[knob]
+               "GOCTR_CHAIN_TILE_SUMS": "0", "GOCTR_XCD_AFFINE": "0", "GOCTR_TN_WT": "0", "GOCTR_GATE_FAC": "0", "GOCTR_ATT0_EARLY": "0"}[knob]
     for val in (None, flipped):
         if val is not None:
             os.environ[knob] = val
