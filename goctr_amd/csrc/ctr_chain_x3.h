@@ -739,15 +739,15 @@ __device__ __forceinline__ void att0_early_body(const Att0EarlyArgs& e) {
     const int t0 = j * e.tps;
     int t1 = t0 + e.tps; if (t1 > e.ntiles) t1 = e.ntiles;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int tb = t0; tb < t1; tb += 16) {
-      float4 v[16];
+    for (int tb = t0; tb < t1; tb += 32) {                   // (32 tiles in flight: a slab of the cfg3 step in ONE round of loads)
+      float4 v[32];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < 32; ++u) {
         const int t = tb + u < t1 ? tb + u : t1 - 1;
         v[u] = *reinterpret_cast<const float4*>(e.tile_att0 + (size_t)t * e.Tp + c0);
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < 32; ++u) {
         const bool in = tb + u < t1;
         s.x += in ? v[u].x : 0.f; s.y += in ? v[u].y : 0.f; s.z += in ? v[u].z : 0.f; s.w += in ? v[u].w : 0.f;
       }

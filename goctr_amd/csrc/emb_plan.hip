@@ -8,7 +8,7 @@
 // many batches at once, key = (batch, owner-major row index) -- the pairs of a row keep their (sample, slot) order, so two
 // builds are byte identical -- followed by one head-flag pass, one prefix sum, one offsets pass and one fill.  No atomics,
 // no per-batch launches or read-backs (sorting a 420 k-key batch on its own is launch-latency: ~20 launches of a few us; 32
-// batches in one sort are bandwidth), temporaries bounded by GOCTR_EMB_PLAN_TMP_MB.
+// batches in one sort are bandwidth), temporaries bounded by 1 GiB (EMB_PLAN_TMP_MB).
 //   keys     key[p] = batch-in-chunk << bits | owner-major index of pair p's row (sentinel Vp for pad slots / missing ids:
 //            sorts behind the batch's real rows), val[p] = b << 12 | t
 //   sort     rocprim::radix_sort_pairs over the significant bits (stable); batch kb then occupies keys [kb P, (kb + 1) P)
@@ -30,10 +30,7 @@ namespace {
 
 constexpr int PAIR_TBITS = 12;       // = EMB_PAIR_TBITS (emb_train.h): pair code = b << 12 | t
 
-int env_int_plan(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
+constexpr long long EMB_PLAN_TMP_MB = 1024;     // budget of the sort's temporaries
 
 struct KeysArgs {
   const int32_t* ub_ids; const int32_t* item_ids; long long rows;
@@ -123,9 +120,9 @@ int emb_plan_build(const EmbPlanSource& src, int B, int T, int W, long long Vw, 
   unsigned int bits = 1;
   while ((1ull << bits) <= (unsigned long long)Vp) ++bits;
   // batches per sort: as many as fit the 32-bit key next to the row index and the temporaries' budget (20 B per key + the sort's
-  // own storage; GOCTR_EMB_PLAN_TMP_MB, default 1024)
+  // own storage; EMB_PLAN_TMP_MB)
   const long long by_bits = 1ll << (32 - bits);
-  const long long by_mem = std::max<long long>(1, ((long long)env_int_plan("GOCTR_EMB_PLAN_TMP_MB", 1024) << 20) / (32 * P));
+  const long long by_mem = std::max<long long>(1, (EMB_PLAN_TMP_MB << 20) / (32 * P));
   const long long chunk = std::max<long long>(1, std::min<long long>(std::min(by_bits, by_mem), nb));
   const long long nmax = chunk * P;
   GOCTR_CHECK(nmax < (1ll << 32), "embedding plan: chunk of %lld pairs does not fit 32-bit ranks", nmax);

@@ -131,8 +131,8 @@ def summarize_phase(src, phase, legs):
 
 # the launches of ONE graph-replayed training step per workload (what bench.py's `value` times), and the step's algorithmic bytes
 # per sample (cfg3 whole step ~3 900 B; cfg4: rows 13 056 + ids 204 + side features 420 = 13 680 B)
-STEP_KERNELS = {"din": (("ctr_chain_x3_kernel<", ",false>"), ("gemm_tn_multi_x3w_kernel<", ""), ("reduce_attn_kernel<", "")),
-                "youtube": (("ctr_chain_x3_kernel<", ",false>"), ("gemm_tn_multi_x3w_kernel<", ""), ("reduce_attn_kernel<", ""))}
+STEP_KERNELS = {"din": (("ctr_chain_x3_kernel<", ",false>"), ("gemm_tn_multi_x3w_", ""), ("reduce_attn_kernel<", "")),
+                "youtube": (("ctr_chain_x3_kernel<", ",false>"), ("gemm_tn_multi_x3w_", ""), ("reduce_attn_kernel<", ""))}
 STEP_ALG_BYTES_PER_SAMPLE = {"din": 3900, "youtube": 13680}
 STEP_BATCH = {"din": 8192, "youtube": 16384}
 
