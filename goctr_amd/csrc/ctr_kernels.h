@@ -394,7 +394,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnArgs& a, int blk, long l
       }
       const int tl = tb + lane;
       float aw = 0.f;
-      if (ra) {
+      if (ra && ra->flag) {
         // merged kernel: the weights are being written by the att0 block of this very launch (dispatched before any
         // attention workgroup, so it is resident); wait for its flag, then read them past the non-coherent L2.  Relaxed
         // device-scope loads throughout: they go to memory themselves, and an acquire per poll would invalidate the L2
@@ -960,7 +960,7 @@ __global__ __launch_bounds__(256) void reduce_attn_kernel(ReduceAdamArgs p, Attn
   if (nb >= r.st->n_batches) nb = 0;
   const RaCtx ctx{p.ra_flag, r.st->gstep + 1u, a.att0};
   const int grp = a.xcd_affine ? xcd_unit_of_block_after((int)blockIdx.x, nred, (a.B + 3) >> 2, 32) : (int)blockIdx.x - nred;
-  attn_fwd_body<VEC, LPR, FAST>(a, grp, nb, a.att0, FAST >= 2 && p.ra_flag ? &ctx : nullptr);
+  attn_fwd_body<VEC, LPR, FAST>(a, grp, nb, a.att0, FAST >= 2 ? &ctx : nullptr);      // (ctx.flag == null: att0 is already this step's, no wait)
 }
 
 // The data-parallel step's counterpart of reduce_attn_kernel: the step is [.. reduce] -> all-reduce -> [Adam], and what can share
