@@ -107,6 +107,18 @@ __global__ __launch_bounds__(256) void mlp_copy_f64_kernel(const double* X, cons
 }
 
 // delta_last = h - y and the binary log-loss terms (basemlp64.go:180-195,373-381); one block per row group
+// the resident rows ONCE as the float64 operand image of the weight-gradient GEMM (round 6, GOCTR_MLP_X64): row r =
+// [ (double)X[r][0 .. F) | 1 | 0 ... ] at stride up0 -- exactly the row mlp_chain_kernel otherwise writes into A[0] for every
+// batch it trains on (its tail and 9.4 MB of its launch boundary at cfg2).  With the image resident the chain launch writes the
+// batch's row INDICES (16 KB) and mlp_tn64_kernel reads its A rows through them: 16-byte-aligned float64 loads, no conversion
+// (what lost in profiles/r06_mlp_tn_gather.txt were the 4-byte-aligned float32 pieces and the conversions in the staging step).
+__global__ __launch_bounds__(256) void mlp_widen_rows_kernel(const float* __restrict__ X, long long rows, int F, int up0,
+                                                             double* __restrict__ X64) {
+  const long long r = blockIdx.x;
+  if (r >= rows) return;
+  for (int j = threadIdx.x; j < up0; j += 256) X64[(size_t)r * up0 + j] = j < F ? (double)X[(size_t)r * F + j] : (j == F ? 1.0 : 0.0);
+}
+
 __global__ __launch_bounds__(256) void mlp_delta_last_kernel(const double* H, const double* Yb, int n, int no, int upL,
                                                              double* delta, double* lossterm, int valid) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -638,12 +650,14 @@ struct MlpChainArgs {
   int n, F, up0, units1, up1, upL, act;
   const double* W0img; const double* W2;
   double* A0; double* D1; double* A2; double* D2; double* lossterm; double* slab1;
+  int* ridx;                  // X64: the batch's dataset row indices for mlp_tn64_kernel instead of the float64 copy A0
   unsigned long long* dbg;    // GOCTR_DBG=mlp: cycle stamps of workgroup 0, [wave][5]
 };
 
 // NFULL >= 0: the number of full 16-k chunks of a row (F / 16) is a compile-time constant and the product loop is
 // straight-line code (no selects, no clamps, accumulators never leave the AGPRs); NFULL < 0: run-time loop, any F.
-template <int ACT, int NFULL>
+// X64: the float64 image of the resident rows exists (goctr_mlp::X64): no A0 copy, the batch's row indices instead.
+template <int ACT, int NFULL, bool X64 = false>
 __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainArgs a) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef double d4 __attribute__((ext_vector_type(4)));
@@ -692,6 +706,7 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainArgs a) {
     const int cx = c < nfull ? c : (nfull > 0 ? nfull - 1 : 0);
     xr[c] = *reinterpret_cast<const f4u*>(xp + cx * 16);
   }
+  if constexpr (X64) { if (g == 0 && q == 0 && vrow) a.ridx[row] = (int)src; }
   // the tail chunk of the row: k < F from the row, k == F the ones column, zeros behind (unconditional loads, clamped)
   double xt[4];
 #pragma unroll
@@ -769,11 +784,13 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainArgs a) {
   // second read of the row for the A0 copy at the end (chunk c belongs to wavefront c % ng): issued here, consumed after the
   // epilogue; the ring's registers are free now
   constexpr int NS = 6;
-  f4u xs[NS];
+  [[maybe_unused]] f4u xs[NS];
+  if constexpr (!X64) {
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     const int c = g + k * ng;
     xs[k] = *reinterpret_cast<const f4u*>(xp + (c < nfull ? c : (nfull > 0 ? nfull - 1 : 0)) * 16);
+  }
   }
   // accumulator of lane (row = i, q): Z[row][32 g + 16 t + q + 4 r]
   double av[2][4];
@@ -829,6 +846,7 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainArgs a) {
   // the float64 operand A0 of the weight-gradient GEMM: chunk c of the row is written by wavefront c % ng from a second
   // read of the row (L2 hits now).  Not inside the MFMA loop: guarded stores there cost accumulator copies (see
   // mlp_fwd_kernel); not before it: the stores would wait for the row's first, cold reads
+  if constexpr (!X64)
   if (vrow) {
     double* a0row = a.A0 + (size_t)row * up0 + 4 * q;
 #pragma unroll
@@ -871,12 +889,18 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainArgs a) {
 // consecutive rows a lane feeds to 4 MFMAs.
 constexpr int TN64_CH = 32, TN64_CHS = TN64_CH + 2, TN64_NTW = 2;
 
-template <int TN64_KTW>
+// IDX: A is the float64 image of ALL resident rows (mlp_widen_rows_kernel) and batch row m is its row ridx[m] (written by
+// mlp_chain_kernel<.., true>; the buffer is padded with zeros past the batch, so the unconditional loads of a slab's last chunk
+// stay inside the image).  The indices of chunk c + 1 are requested with the rows of chunk c: no dependent pair of loads inside
+// the loop, one more memory latency at the launch's start.
+template <int TN64_KTW, bool IDX = false>
 __global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restrict__ A, int lda, int KT,
                                                           const double* __restrict__ Dm, int ldd, int NT, int M, int rows,
-                                                          double* __restrict__ slabs, size_t slab_stride, int wt) {
+                                                          double* __restrict__ slabs, size_t slab_stride, int wt,
+                                                          const int* __restrict__ ridx) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef double d4 __attribute__((ext_vector_type(4)));
+  typedef int i4u __attribute__((ext_vector_type(4), aligned(4)));
   constexpr int CH = TN64_CH, CHS = TN64_CHS, KTW = TN64_KTW, NTW = TN64_NTW;
   constexpr int MAXB = ((CH / 4) * (KTW * 4 + 8 * 4) + 255) / 256;     // 4x4 blocks per thread and chunk (NT <= 8)
   extern __shared__ __attribute__((aligned(16))) double tn64_smem[];
@@ -920,17 +944,31 @@ __global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restri
     }
   }
   d2 st[MAXB][4][2];   // [slot][row][column pair]
+  [[maybe_unused]] i4u nix[MAXB];   // IDX: image rows of the NEXT chunk's A blocks
+  auto iload = [&](int m0) {
+    if constexpr (IDX) {
+#pragma unroll
+      for (int s = 0; s < MAXB; ++s) {
+        const bool isa = lofs[s] >= 0 && lofs[s] < 2 * a_buf;
+        nix[s] = *reinterpret_cast<const i4u*>(ridx + (isa ? m0 + 4 * rg[s] : 0));
+      }
+    }
+  };
   auto gload = [&](int m0) {
 #pragma unroll
-    for (int s = 0; s < MAXB; ++s)
+    for (int s = 0; s < MAXB; ++s) {
+      [[maybe_unused]] const bool isa = lofs[s] >= 0 && lofs[s] < 2 * a_buf;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int rr = m0 + 4 * rg[s] + r;
         rr = rr < m_end ? rr : m_end - 1;
+        if constexpr (IDX) rr = isa ? nix[s][r] : rr;
         const double* p = gsrc[s] + (size_t)rr * ld[s];
         st[s][r][0] = *reinterpret_cast<const d2*>(p);
         st[s][r][1] = *reinterpret_cast<const d2*>(p + 2);
       }
+    }
+    iload(m0 + CH);
   };
   auto lstore = [&](int buf, int m0) {
 #pragma unroll
@@ -955,6 +993,7 @@ __global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restri
   for (int f = 0; f < NTW; ++f) { int c = (nt0 + f) * 16 + i; c = c < Nc ? c : Nc - 1; dofs[f] = c * CHS + 4 * q; }
 
   if (m_begin < m_end) {
+    iload(m_begin);
     gload(m_begin);
     lstore(0, m_begin);
     __syncthreads();
@@ -1046,18 +1085,22 @@ int launch_nn64(const double* A, int lda, const double* Bm, int ldb, int M, int 
 // (45.4 vs 42.3 us per step with two per CU, 42.8 with one): co-resident f64-MFMA workgroups serialise
 int tn64_ktw() { return 3; }
 int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int NT, int M, int rows_per_wg,
-                double* slabs) {
+                double* slabs, const int* ridx = nullptr) {
+  GOCTR_CHECK(!ridx || (NT <= 8 && tn64_ktw() == 3), "launch_tn64: indexed rows only on mlp_tn64_kernel<3>");
   if (NT <= 8) {
     const int Sn = (int)cdiv(M, rows_per_wg);
     const int ktw = tn64_ktw();
     const int wt = env_int_mlp("GOCTR_MLP_TN_WT", 1);
     const size_t lds = sizeof(double) * 2 * TN64_CHS * (size_t)(ktw * 16 + NT * 16);
-    if (ktw == 2)
+    if (ridx)
+      hipLaunchKernelGGL((mlp_tn64_kernel<3, true>), dim3(Sn, (unsigned)cdiv(KT, 3)), dim3(256), lds, engine().stream, A, lda, KT,
+                         Dm, ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, ridx);
+    else if (ktw == 2)
       hipLaunchKernelGGL(mlp_tn64_kernel<2>, dim3(Sn, (unsigned)cdiv(KT, 2)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
-                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt);
+                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, (const int*)nullptr);
     else
       hipLaunchKernelGGL(mlp_tn64_kernel<3>, dim3(Sn, (unsigned)cdiv(KT, 3)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
-                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt);
+                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, (const int*)nullptr);
     GOCTR_HIP(hipGetLastError());
     return 0;
   }
@@ -1080,7 +1123,7 @@ int init_attrs64() {
   if (allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 1>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 2>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpAct, 4>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 1>) ||
       allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 2>) || allow_big_lds(gemm_nn_kernel<double, EpiMlpDAct, 4>) ||
-      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_tn64_kernel<3>) || allow_big_lds(mlp_tn64_kernel<2>) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
+      allow_big_lds(gemm_tn_kernel<double, 3, 2, 16>) || allow_big_lds(mlp_tn64_kernel<3>) || allow_big_lds(mlp_tn64_kernel<3, true>) || allow_big_lds(mlp_tn64_kernel<2>) || allow_big_lds(mlp_fwd_kernel<24>)) return -1;
   done = true;
   return 0;
 }
@@ -1107,9 +1150,13 @@ struct goctr_mlp {
   DevBuf<MlpState> st, st_step;   // master copy / the running step's frozen copy
   // resident rows
   DevBuf<float> Xr, Yr; int64_t rows = 0; DevBuf<int> perm;
+  // the resident rows as the float64 operand image of the weight-gradient GEMM (mlp_widen_rows_kernel; GOCTR_MLP_X64, default on
+  // while the image stays under GOCTR_MLP_X64_MAX_MB) and the running batch's row indices into it (batch + 64 ints, zero padded)
+  DevBuf<double> X64; DevBuf<int> ridx;
+  bool x64() const { return X64.p != nullptr && ridx.p != nullptr; }
   hipGraphExec_t step_graph = nullptr; int64_t step_graph_rows = 0; bool step_graph_perm = false;   // resident training step
   hipGraphExec_t multi_graph[2] = {nullptr, nullptr};           // the same step captured 8 / 2 times back to back
-  const void* step_graph_x = nullptr; const void* step_graph_y = nullptr; const void* step_graph_p = nullptr; const void* step_graph_w = nullptr;
+  const void* step_graph_x = nullptr; const void* step_graph_y = nullptr; const void* step_graph_p = nullptr; const void* step_graph_w = nullptr; const void* step_graph_x64 = nullptr;
   ~goctr_mlp() { if (step_graph) (void)hipGraphExecDestroy(step_graph); for (auto g : multi_graph) if (g) (void)hipGraphExecDestroy(g); }
   std::mutex mu;
 };
@@ -1232,8 +1279,9 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance, int valid = -1) 
     GOCTR_HIP(hipGetLastError());
   }
   for (int l = fused_bwd ? 0 : L - 1; l >= 0; --l) {
-    if (launch_tn64(p->A[l].p, p->up[l], p->up[l] / 16, p->D[l + 1].p, p->up[l + 1], p->up[l + 1] / 16, n, tn_rows64(p, n),
-                    p->slabs[l].p)) return -1;
+    const bool img = l == 0 && chain && p->x64();     // the chain launch left row indices, not a copy of the rows
+    if (launch_tn64(img ? p->X64.p : p->A[l].p, p->up[l], p->up[l] / 16, p->D[l + 1].p, p->up[l + 1], p->up[l + 1] / 16, n,
+                    tn_rows64(p, n), p->slabs[l].p, img ? p->ridx.p : nullptr)) return -1;
     if (l >= 1) {
       EpiMlpDAct d{p->D[l].p, p->A[l].p, p->up[l], p->units[l], p->cfg.activation,
                    p->cfg.batch_normalize ? p->bn[l - 1].p : nullptr};
@@ -1353,6 +1401,8 @@ int train_step_resident(goctr_mlp* p, bool use_state, long long start, bool gene
     c.n = B; c.F = p->units[0]; c.up0 = p->up[0]; c.units1 = p->units[1]; c.up1 = p->up[1]; c.upL = p->up[2];
     c.act = p->cfg.activation; c.W0img = p->W0img.p; c.W2 = p->W.p + p->woff[1];
     c.A0 = p->A[0].p; c.D1 = p->D[1].p; c.A2 = p->A[2].p; c.D2 = p->D[2].p; c.lossterm = p->lossterm.p; c.slab1 = p->slabs[1].p;
+    const bool x64 = p->x64();
+    c.ridx = x64 ? p->ridx.p : nullptr;
     const int ng = (int)cdiv(p->up[1], 32);
     static DevBuf<unsigned long long> dbgb;
     const bool dbg = dbg_on("mlp");
@@ -1361,24 +1411,23 @@ int train_step_resident(goctr_mlp* p, bool use_state, long long start, bool gene
     const dim3 cg((unsigned)cdiv(B, 16)), cb(64 * ng);
     // F = 281 (BASELINE configs[1], the MovieLens feature row of example/movielens) gets the straight-line product loop
     const bool s17 = (p->units[0] >> 4) == 17;
+#define GOCTR_CHAIN(ACT)                                                                                        \
+    do {                                                                                                        \
+      if (x64) {                                                                                                \
+        if (s17) hipLaunchKernelGGL((mlp_chain_kernel<ACT, 17, true>), cg, cb, 0, engine().stream, c);          \
+        else hipLaunchKernelGGL((mlp_chain_kernel<ACT, -1, true>), cg, cb, 0, engine().stream, c);              \
+      } else {                                                                                                  \
+        if (s17) hipLaunchKernelGGL((mlp_chain_kernel<ACT, 17>), cg, cb, 0, engine().stream, c);                \
+        else hipLaunchKernelGGL((mlp_chain_kernel<ACT, -1>), cg, cb, 0, engine().stream, c);                    \
+      }                                                                                                         \
+    } while (0)
     switch (p->cfg.activation) {
-      case GOCTR_ACT_LOGISTIC:
-        if (s17) hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_LOGISTIC, 17>), cg, cb, 0, engine().stream, c);
-        else hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_LOGISTIC, -1>), cg, cb, 0, engine().stream, c);
-        break;
-      case GOCTR_ACT_TANH:
-        if (s17) hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_TANH, 17>), cg, cb, 0, engine().stream, c);
-        else hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_TANH, -1>), cg, cb, 0, engine().stream, c);
-        break;
-      case GOCTR_ACT_RELU:
-        if (s17) hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_RELU, 17>), cg, cb, 0, engine().stream, c);
-        else hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_RELU, -1>), cg, cb, 0, engine().stream, c);
-        break;
-      default:
-        if (s17) hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_IDENTITY, 17>), cg, cb, 0, engine().stream, c);
-        else hipLaunchKernelGGL((mlp_chain_kernel<GOCTR_ACT_IDENTITY, -1>), cg, cb, 0, engine().stream, c);
-        break;
+      case GOCTR_ACT_LOGISTIC: GOCTR_CHAIN(GOCTR_ACT_LOGISTIC); break;
+      case GOCTR_ACT_TANH: GOCTR_CHAIN(GOCTR_ACT_TANH); break;
+      case GOCTR_ACT_RELU: GOCTR_CHAIN(GOCTR_ACT_RELU); break;
+      default: GOCTR_CHAIN(GOCTR_ACT_IDENTITY); break;
     }
+#undef GOCTR_CHAIN
     GOCTR_HIP(hipGetLastError());
     if (dbg) {
       unsigned long long h[20];
@@ -1535,6 +1584,16 @@ int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows)
   if (p->Yr.alloc((size_t)rows * no, false) || p->Yr.upload(Y, (size_t)rows * no)) return -1;
   p->rows = rows;
   p->perm.release();
+  // the float64 image of the rows for the weight-gradient launch (up0 doubles per row: 2.05 x the float32 rows at F = 281)
+  p->X64.release(); p->ridx.release();
+  const size_t img_bytes = (size_t)rows * p->up[0] * sizeof(double);
+  if (p->chain_ok() && tn64_ktw() == 3 && p->up[1] / 16 <= 8 && rows < (1LL << 31) && env_int_mlp("GOCTR_MLP_X64", 1) &&
+      img_bytes <= (size_t)env_int_mlp("GOCTR_MLP_X64_MAX_MB", 65536) * (1u << 20)) {
+    if (p->X64.alloc((size_t)rows * p->up[0], false) || p->ridx.alloc((size_t)p->cfg.batch + 64, true)) return -1;
+    hipLaunchKernelGGL(mlp_widen_rows_kernel, dim3((unsigned)rows), dim3(256), 0, engine().stream, p->Xr.p, (long long)rows, F,
+                       p->up[0], p->X64.p);
+    GOCTR_HIP(hipGetLastError());
+  }
   return ensure_ws(p, p->cfg.batch);
 }
 
@@ -1548,7 +1607,8 @@ static int run_fused_steps(goctr_mlp* p, int n_steps) {
     if (ensure_ws(p, p->cfg.batch)) return -1;                 // no allocation inside the capture
     if (p->fused_ok() && p->zpart.ensure((size_t)cdiv(p->up[1], 32) * p->cfg.batch, false)) return -1;
     if (!p->step_graph || p->step_graph_rows != p->rows || p->step_graph_perm != (p->perm.n > 1) ||
-        p->step_graph_x != p->Xr.p || p->step_graph_y != p->Yr.p || p->step_graph_p != p->perm.p || p->step_graph_w != p->W0img.p) {
+        p->step_graph_x != p->Xr.p || p->step_graph_y != p->Yr.p || p->step_graph_p != p->perm.p || p->step_graph_w != p->W0img.p ||
+        p->step_graph_x64 != p->X64.p) {
       // (goctr_mlp_train_steps is asynchronous: replays of the old execs may still be queued -- never destroy one in flight)
       if (p->step_graph || p->multi_graph[0] || p->multi_graph[1]) GOCTR_HIP(hipStreamSynchronize(e.stream));
       if (p->step_graph) { (void)hipGraphExecDestroy(p->step_graph); p->step_graph = nullptr; }
@@ -1556,6 +1616,7 @@ static int run_fused_steps(goctr_mlp* p, int n_steps) {
       if (capture_graph(e.stream, &p->step_graph, [&] { return train_step_resident(p, true, 0); }, [] {})) return -1;
       p->step_graph_rows = p->rows; p->step_graph_perm = p->perm.n > 1;
       p->step_graph_x = p->Xr.p; p->step_graph_y = p->Yr.p; p->step_graph_p = p->perm.p; p->step_graph_w = p->W0img.p;
+      p->step_graph_x64 = p->X64.p;
     }
     // every per-step scalar is device state, so a graph may as well hold several steps: one graph launch per 8 (2) steps
     // instead of one per step (the boundary between two graph launches costs about two kernel-to-kernel edges inside one).
