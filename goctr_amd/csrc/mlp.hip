@@ -207,13 +207,46 @@ struct MlpReduceArgs {
   int nblk;                   // blocks that own parameters; block nblk is the loss block
   const double* lossterm; int upL, no; double* ring; int advance;
   double* W0img; int up1_img; // LDS image of layer 0 for the fused forward (or null)
+  // blocks behind the loss block (GOCTR_MLP_PREFETCH): the NEXT batch's permutation entries, float32 rows and float64 image rows
+  // requested one launch ahead of their readers (mlp_chain_kernel's prologue, mlp_tn64_kernel's cold gather); block j asks for the rows
+  // of the chain workgroups w = (j + pf_xcd_shift) mod 8 (workgroup b of a launch runs on XCD b % 8 -- observed, not promised: nothing
+  // but the next launches' first latencies depends on it)
+  const float* pf_X; const float* pf_Y; const int* pf_perm; long long pf_rows; int pf_F, pf_batch; float* pf_sink;
+  const double* pf_X64; int pf_up0; int pf_xcd_shift;
 };
+constexpr int MLP_PF_BLOCKS = 64;
 
 // grad = slab sum / n + alpha/n * W (coefs), mean(delta) (intercepts)  [computeLossGrad :322-330]; then the
 // optimizer step in packed-parameter order semantics.
 __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   __shared__ double red[256];
+  if ((int)blockIdx.x > a.nblk) {
+    // the rows the next step's chain launch starts with: its prologue is three dependent memory latencies (state -> permutation ->
+    // row, 6.5 k cycles at cfg2); this launch leaves 100+ CUs idle, so eight blocks per XCD walk the same chain one step ahead and
+    // leave the lines in the L2 their readers sit on.  Four threads per row, every 128-byte piece of it (and its label) touched once.
+    const int k = ((int)blockIdx.x - a.nblk - 1) >> 3, xcd = ((int)blockIdx.x + a.pf_xcd_shift) & 7;
+    long long nb = a.st->batch_idx + 1;
+    if (nb >= a.st->n_batches) nb = 0;
+    const int t = k * 256 + (int)threadIdx.x, sub = t & 3, rl = t >> 2;
+    for (int w = xcd + 8 * (rl >> 4); w * 16 < a.pf_batch; w += 8 * (MLP_PF_BLOCKS / 8) * 4) {
+      const int row = w * 16 + (rl & 15);
+      long long pos = nb * a.pf_batch + (row < a.pf_batch ? row : a.pf_batch - 1);
+      pos = pos < a.pf_rows ? pos : a.pf_rows - 1;
+      const long long src = a.pf_perm ? a.pf_perm[pos] : pos;
+      const float* xr = a.pf_X + src * a.pf_F;
+      float acc = sub == 0 ? a.pf_Y[src] : xr[a.pf_F - 1];
+      for (int c = sub * 32; c < a.pf_F; c += 128) acc += xr[c];
+      if (a.pf_X64) {       // the same rows of the float64 image, for the weight-gradient launch (memory-side cache: any XCD reads them)
+        const double* x64 = a.pf_X64 + (size_t)src * a.pf_up0;
+        double a64 = 0;
+        for (int c = sub * 16; c < a.pf_up0; c += 64) a64 += x64[c];
+        acc += (float)a64;
+      }
+      if (acc == 1.2345678e-30f) a.pf_sink[t] = acc;    // (keeps the loads; a scratch word nobody reads)
+    }
+    return;
+  }
   const int par = (int)(a.st->t & 1);
   if ((int)blockIdx.x == a.nblk) {
     // loss = sum(terms)/n + 0.5*alpha*sum(W^2)/n (basemlp64.go:359-361) over the weights the forward pass used: their
@@ -897,14 +930,23 @@ template <int TN64_KTW, bool IDX = false>
 __global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restrict__ A, int lda, int KT,
                                                           const double* __restrict__ Dm, int ldd, int NT, int M, int rows,
                                                           double* __restrict__ slabs, size_t slab_stride, int wt,
-                                                          const int* __restrict__ ridx) {
+                                                          const int* __restrict__ ridx, int nkb) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef double d4 __attribute__((ext_vector_type(4)));
   typedef int i4u __attribute__((ext_vector_type(4), aligned(4)));
   constexpr int CH = TN64_CH, CHS = TN64_CHS, KTW = TN64_KTW, NTW = TN64_NTW;
   constexpr int MAXB = ((CH / 4) * (KTW * 4 + 8 * 4) + 255) / 256;     // 4x4 blocks per thread and chunk (NT <= 8)
   extern __shared__ __attribute__((aligned(16))) double tn64_smem[];
-  const int split = blockIdx.x, kb = blockIdx.y;
+  // nkb > 0: one-dimensional grid dealt XCD-affine -- workgroup L runs on XCD L % 8 (observed, not promised: only the L2 hit rate
+  // depends on it), and the nkb workgroups that share a slab's delta rows (each reads ALL of them beside its own strip of A) are
+  // neighbours on ONE XCD: slab = x + 8 (j / nkb), k-block = j % nkb with x = L % 8, j = L / 8.  Dealt by (slab, k-block) = blockIdx
+  // the six readers of a slab sat on four XCDs and the launch fetched the deltas six times (38 MB memory-side, L2 hit 16 %).
+  int split = blockIdx.x, kb = blockIdx.y;
+  if (nkb > 0) {
+    const int L = blockIdx.x, j = L >> 3;
+    split = (L & 7) + 8 * (j / nkb); kb = j % nkb;
+    if (split * rows >= M) return;
+  }
   const int kb0 = kb * KTW;
   int kb_t = KT - kb0; if (kb_t > KTW) kb_t = KTW;
   const int Kc = kb_t * 16, Nc = NT * 16;
@@ -1092,15 +1134,18 @@ int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int
     const int ktw = tn64_ktw();
     const int wt = env_int_mlp("GOCTR_MLP_TN_WT", 1);
     const size_t lds = sizeof(double) * 2 * TN64_CHS * (size_t)(ktw * 16 + NT * 16);
+    const int xcd = env_int_mlp("GOCTR_MLP_TN_XCD", 1);
+    const int nkb = xcd ? (int)cdiv(KT, ktw) : 0;
+    const dim3 grid = xcd ? dim3(8u * (unsigned)nkb * (unsigned)cdiv(Sn, 8)) : dim3(Sn, (unsigned)cdiv(KT, ktw));
     if (ridx)
-      hipLaunchKernelGGL((mlp_tn64_kernel<3, true>), dim3(Sn, (unsigned)cdiv(KT, 3)), dim3(256), lds, engine().stream, A, lda, KT,
-                         Dm, ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, ridx);
+      hipLaunchKernelGGL((mlp_tn64_kernel<3, true>), grid, dim3(256), lds, engine().stream, A, lda, KT,
+                         Dm, ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, ridx, nkb);
     else if (ktw == 2)
-      hipLaunchKernelGGL(mlp_tn64_kernel<2>, dim3(Sn, (unsigned)cdiv(KT, 2)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
-                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, (const int*)nullptr);
+      hipLaunchKernelGGL(mlp_tn64_kernel<2>, grid, dim3(256), lds, engine().stream, A, lda, KT, Dm,
+                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, (const int*)nullptr, nkb);
     else
-      hipLaunchKernelGGL(mlp_tn64_kernel<3>, dim3(Sn, (unsigned)cdiv(KT, 3)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
-                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, (const int*)nullptr);
+      hipLaunchKernelGGL(mlp_tn64_kernel<3>, grid, dim3(256), lds, engine().stream, A, lda, KT, Dm,
+                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, (const int*)nullptr, nkb);
     GOCTR_HIP(hipGetLastError());
     return 0;
   }
@@ -1151,8 +1196,9 @@ struct goctr_mlp {
   // resident rows
   DevBuf<float> Xr, Yr; int64_t rows = 0; DevBuf<int> perm;
   // the resident rows as the float64 operand image of the weight-gradient GEMM (mlp_widen_rows_kernel; GOCTR_MLP_X64, default on
-  // while the image stays under GOCTR_MLP_X64_MAX_MB) and the running batch's row indices into it (batch + 64 ints, zero padded)
+  // while the image stays under 64 GiB) and the running batch's row indices into it (batch + 64 ints, zero padded)
   DevBuf<double> X64; DevBuf<int> ridx;
+  DevBuf<float> pf_sink;         // GOCTR_MLP_PREFETCH (default on): scratch of the reduce launch's prefetch blocks
   bool x64() const { return X64.p != nullptr && ridx.p != nullptr; }
   hipGraphExec_t step_graph = nullptr; int64_t step_graph_rows = 0; bool step_graph_perm = false;   // resident training step
   hipGraphExec_t multi_graph[2] = {nullptr, nullptr};           // the same step captured 8 / 2 times back to back
@@ -1174,7 +1220,10 @@ int tn_rows64(const goctr_mlp* p, int n) {
     if (k > kb) kb = k;
   }
   int cus = engine().compute_units > 0 ? engine().compute_units : 256;
-  const int S = cus / kb > 0 ? cus / kb : 1;
+  int S = cus / kb > 0 ? cus / kb : 1;
+  // a multiple of eight slabs: mlp_tn64_kernel deals whole slabs to XCDs (all k-blocks of a slab on one), and a ninth slab on an
+  // XCD would be a second round of workgroups there (cfg2: 40 slabs of 104 rows x 6 k-blocks = 240 workgroups, 30 per XCD)
+  if (S >= 16 && env_int_mlp("GOCTR_MLP_TN_XCD", 1)) S &= ~7;
   int rows = (int)cdiv(n, S);
   rows = rows < 32 ? 32 : round_up(rows, 2);
   return rows;
@@ -1324,7 +1373,18 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance, int valid = -1) 
     return 0;
   }
   a.mode = 0;
-  hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk + 1), dim3(256), 0, e.stream, a);   // block nblk: loss + state
+  int pf_blocks = 0;
+  if (chain && advance && p->rows > 0 && p->pf_sink.p) {
+    a.pf_X = p->Xr.p; a.pf_Y = p->Yr.p; a.pf_perm = p->perm.n > 1 ? p->perm.p : nullptr; a.pf_rows = p->rows;
+    a.pf_F = p->units[0]; a.pf_batch = p->cfg.batch; a.pf_sink = p->pf_sink.p;
+    pf_blocks = MLP_PF_BLOCKS;
+    a.pf_X64 = p->x64() ? p->X64.p : nullptr; a.pf_up0 = p->up[0];
+    // which XCD's rows a prefetch block requests, measured over all eight shifts (profiles/r06_mlp_prefetch.txt): at cfg2 (256 chain
+    // workgroups) the readers' own XCD is the WORST choice (36.8 us per step against 36.3 - 36.5 for each of the other seven: what the
+    // prefetch fills is the memory-side cache); at B 200 (13 workgroups) it is the best (24.9 against 25.3 us per update)
+    a.pf_xcd_shift = cdiv(p->cfg.batch, 16) >= 64 ? 4 : 0;
+  }
+  hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk + 1 + pf_blocks), dim3(256), 0, e.stream, a);   // block nblk: loss + state
   GOCTR_HIP(hipGetLastError());
   return 0;
 }
@@ -1588,12 +1648,14 @@ int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows)
   p->X64.release(); p->ridx.release();
   const size_t img_bytes = (size_t)rows * p->up[0] * sizeof(double);
   if (p->chain_ok() && tn64_ktw() == 3 && p->up[1] / 16 <= 8 && rows < (1LL << 31) && env_int_mlp("GOCTR_MLP_X64", 1) &&
-      img_bytes <= (size_t)env_int_mlp("GOCTR_MLP_X64_MAX_MB", 65536) * (1u << 20)) {
+      img_bytes <= ((size_t)64 << 30)) {
     if (p->X64.alloc((size_t)rows * p->up[0], false) || p->ridx.alloc((size_t)p->cfg.batch + 64, true)) return -1;
     hipLaunchKernelGGL(mlp_widen_rows_kernel, dim3((unsigned)rows), dim3(256), 0, engine().stream, p->Xr.p, (long long)rows, F,
                        p->up[0], p->X64.p);
     GOCTR_HIP(hipGetLastError());
   }
+  if (env_int_mlp("GOCTR_MLP_PREFETCH", 1)) { if (p->pf_sink.ensure((size_t)MLP_PF_BLOCKS / 8 * 256, true)) return -1; }
+  else p->pf_sink.release();
   return ensure_ws(p, p->cfg.batch);
 }
 

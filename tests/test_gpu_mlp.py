@@ -187,6 +187,42 @@ def test_slabs_through_the_l2_leave_the_same_bits():
     assert np.array_equal(res[0], res[1])
 
 
+@pytest.mark.parametrize("knob", ["GOCTR_MLP_X64", "GOCTR_MLP_PREFETCH"])
+@pytest.mark.parametrize("B", [1024, 200])
+def test_float64_row_image_and_prefetch_blocks_leave_the_same_bits(knob, B):
+    """GOCTR_MLP_X64=0 (mlp_chain_kernel writes the float64 copy of its rows for the weight-gradient launch) against the default
+    (the rows kept once as a float64 image, the chain launch writes row indices, mlp_tn64_kernel<3, true> reads through them), and
+    GOCTR_MLP_PREFETCH=0 (no prefetch blocks behind the reduce launch): the same values enter the same products in the same order;
+    with a permutation, over an epoch boundary (the prefetch of the last batch asks for batch 0 of the OLD permutation: harmless)"""
+    import os
+    from goctr_amd import capi, mlp as gmlp
+    rng = np.random.default_rng(16)
+    n, F = 4096 + 40, 281
+    X = rng.random((n, F), dtype=np.float32)
+    Y = (rng.random(n) < 0.5).astype(np.float32)
+    units = [F, 100, 1]
+    perm = np.stack([np.random.default_rng(5 + e).permutation(n).astype(np.int32) for e in range(2)])
+    res = []
+    for val in (None, "0"):
+        if val is not None:
+            os.environ[knob] = val
+        try:
+            clf = gmlp.MLPClassifier([100], "relu", "adam", 1e-5)
+            clf.create(units, B, clf.init_params(units, np.random.default_rng(3)))
+            clf.upload(X, Y)
+            clf.train_steps(n // B + 3)
+            capi.sync()
+            p1 = clf.get_params()
+            clf2 = gmlp.MLPClassifier([100], "relu", "adam", 1e-5)
+            clf2.MaxIter, clf2.BatchSize = 2, B
+            clf2.Fit(X, Y, theta0=clf2.init_params(units, np.random.default_rng(3)), perm=perm)   # two epochs, each with a short batch
+            res.append((p1, clf2.get_params(), np.array(clf2.LossCurve)))
+        finally:
+            os.environ.pop(knob, None)
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
 def test_reference_nn_forward_kat():
     """the reference-held 3-3-3 forward vector (nn/network_test.go:25-83, tests/golden/ref_kats.json) through the device
     MLP: units [3,3,3], relu hidden, logistic output = the KAT's ReLU and Sigmoid layers; float32 out (mlp.go:33-38)"""
