@@ -1127,14 +1127,13 @@ int launch_nn64(const double* A, int lda, const double* Bm, int ldb, int M, int 
 // (45.4 vs 42.3 us per step with two per CU, 42.8 with one): co-resident f64-MFMA workgroups serialise
 int tn64_ktw() { return 3; }
 int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int NT, int M, int rows_per_wg,
-                double* slabs, const int* ridx = nullptr) {
+                double* slabs, const int* ridx = nullptr, int xcd = 0) {
   GOCTR_CHECK(!ridx || (NT <= 8 && tn64_ktw() == 3), "launch_tn64: indexed rows only on mlp_tn64_kernel<3>");
   if (NT <= 8) {
     const int Sn = (int)cdiv(M, rows_per_wg);
     const int ktw = tn64_ktw();
     const int wt = env_int_mlp("GOCTR_MLP_TN_WT", 1);
     const size_t lds = sizeof(double) * 2 * TN64_CHS * (size_t)(ktw * 16 + NT * 16);
-    const int xcd = env_int_mlp("GOCTR_MLP_TN_XCD", 1);
     const int nkb = xcd ? (int)cdiv(KT, ktw) : 0;
     const dim3 grid = xcd ? dim3(8u * (unsigned)nkb * (unsigned)cdiv(Sn, 8)) : dim3(Sn, (unsigned)cdiv(KT, ktw));
     if (ridx)
@@ -1198,6 +1197,7 @@ struct goctr_mlp {
   // the resident rows as the float64 operand image of the weight-gradient GEMM (mlp_widen_rows_kernel; GOCTR_MLP_X64, default on
   // while the image stays under 64 GiB) and the running batch's row indices into it (batch + 64 ints, zero padded)
   DevBuf<double> X64; DevBuf<int> ridx;
+  const int tn_xcd = env_int_mlp("GOCTR_MLP_TN_XCD", 1);   // read once per handle: the slab count (workspace sizes) follows it
   DevBuf<float> pf_sink;         // GOCTR_MLP_PREFETCH (default on): scratch of the reduce launch's prefetch blocks
   bool x64() const { return X64.p != nullptr && ridx.p != nullptr; }
   hipGraphExec_t step_graph = nullptr; int64_t step_graph_rows = 0; bool step_graph_perm = false;   // resident training step
@@ -1223,7 +1223,7 @@ int tn_rows64(const goctr_mlp* p, int n) {
   int S = cus / kb > 0 ? cus / kb : 1;
   // a multiple of eight slabs: mlp_tn64_kernel deals whole slabs to XCDs (all k-blocks of a slab on one), and a ninth slab on an
   // XCD would be a second round of workgroups there (cfg2: 40 slabs of 104 rows x 6 k-blocks = 240 workgroups, 30 per XCD)
-  if (S >= 16 && env_int_mlp("GOCTR_MLP_TN_XCD", 1)) S &= ~7;
+  if (S >= 16 && p->tn_xcd) S &= ~7;
   int rows = (int)cdiv(n, S);
   rows = rows < 32 ? 32 : round_up(rows, 2);
   return rows;
@@ -1330,7 +1330,7 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance, int valid = -1) 
   for (int l = fused_bwd ? 0 : L - 1; l >= 0; --l) {
     const bool img = l == 0 && chain && p->x64();     // the chain launch left row indices, not a copy of the rows
     if (launch_tn64(img ? p->X64.p : p->A[l].p, p->up[l], p->up[l] / 16, p->D[l + 1].p, p->up[l + 1], p->up[l + 1] / 16, n,
-                    tn_rows64(p, n), p->slabs[l].p, img ? p->ridx.p : nullptr)) return -1;
+                    tn_rows64(p, n), p->slabs[l].p, img ? p->ridx.p : nullptr, p->tn_xcd)) return -1;
     if (l >= 1) {
       EpiMlpDAct d{p->D[l].p, p->A[l].p, p->up[l], p->units[l], p->cfg.activation,
                    p->cfg.batch_normalize ? p->bn[l - 1].p : nullptr};
