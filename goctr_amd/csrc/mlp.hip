@@ -930,23 +930,14 @@ template <int TN64_KTW, bool IDX = false>
 __global__ __launch_bounds__(256, 2) void mlp_tn64_kernel(const double* __restrict__ A, int lda, int KT,
                                                           const double* __restrict__ Dm, int ldd, int NT, int M, int rows,
                                                           double* __restrict__ slabs, size_t slab_stride, int wt,
-                                                          const int* __restrict__ ridx, int nkb) {
+                                                          const int* __restrict__ ridx) {
   typedef double d2 __attribute__((ext_vector_type(2)));
   typedef double d4 __attribute__((ext_vector_type(4)));
   typedef int i4u __attribute__((ext_vector_type(4), aligned(4)));
   constexpr int CH = TN64_CH, CHS = TN64_CHS, KTW = TN64_KTW, NTW = TN64_NTW;
   constexpr int MAXB = ((CH / 4) * (KTW * 4 + 8 * 4) + 255) / 256;     // 4x4 blocks per thread and chunk (NT <= 8)
   extern __shared__ __attribute__((aligned(16))) double tn64_smem[];
-  // nkb > 0: one-dimensional grid dealt XCD-affine -- workgroup L runs on XCD L % 8 (observed, not promised: only the L2 hit rate
-  // depends on it), and the nkb workgroups that share a slab's delta rows (each reads ALL of them beside its own strip of A) are
-  // neighbours on ONE XCD: slab = x + 8 (j / nkb), k-block = j % nkb with x = L % 8, j = L / 8.  Dealt by (slab, k-block) = blockIdx
-  // the six readers of a slab sat on four XCDs and the launch fetched the deltas six times (38 MB memory-side, L2 hit 16 %).
-  int split = blockIdx.x, kb = blockIdx.y;
-  if (nkb > 0) {
-    const int L = blockIdx.x, j = L >> 3;
-    split = (L & 7) + 8 * (j / nkb); kb = j % nkb;
-    if (split * rows >= M) return;
-  }
+  const int split = blockIdx.x, kb = blockIdx.y;
   const int kb0 = kb * KTW;
   int kb_t = KT - kb0; if (kb_t > KTW) kb_t = KTW;
   const int Kc = kb_t * 16, Nc = NT * 16;
@@ -1127,24 +1118,22 @@ int launch_nn64(const double* A, int lda, const double* Bm, int ldb, int M, int 
 // (45.4 vs 42.3 us per step with two per CU, 42.8 with one): co-resident f64-MFMA workgroups serialise
 int tn64_ktw() { return 3; }
 int launch_tn64(const double* A, int lda, int KT, const double* Dm, int ldd, int NT, int M, int rows_per_wg,
-                double* slabs, const int* ridx = nullptr, int xcd = 0) {
+                double* slabs, const int* ridx = nullptr) {
   GOCTR_CHECK(!ridx || (NT <= 8 && tn64_ktw() == 3), "launch_tn64: indexed rows only on mlp_tn64_kernel<3>");
   if (NT <= 8) {
     const int Sn = (int)cdiv(M, rows_per_wg);
     const int ktw = tn64_ktw();
     const int wt = env_int_mlp("GOCTR_MLP_TN_WT", 1);
     const size_t lds = sizeof(double) * 2 * TN64_CHS * (size_t)(ktw * 16 + NT * 16);
-    const int nkb = xcd ? (int)cdiv(KT, ktw) : 0;
-    const dim3 grid = xcd ? dim3(8u * (unsigned)nkb * (unsigned)cdiv(Sn, 8)) : dim3(Sn, (unsigned)cdiv(KT, ktw));
     if (ridx)
-      hipLaunchKernelGGL((mlp_tn64_kernel<3, true>), grid, dim3(256), lds, engine().stream, A, lda, KT,
-                         Dm, ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, ridx, nkb);
+      hipLaunchKernelGGL((mlp_tn64_kernel<3, true>), dim3(Sn, (unsigned)cdiv(KT, 3)), dim3(256), lds, engine().stream, A, lda, KT,
+                         Dm, ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, ridx);
     else if (ktw == 2)
-      hipLaunchKernelGGL(mlp_tn64_kernel<2>, grid, dim3(256), lds, engine().stream, A, lda, KT, Dm,
-                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, (const int*)nullptr, nkb);
+      hipLaunchKernelGGL(mlp_tn64_kernel<2>, dim3(Sn, (unsigned)cdiv(KT, 2)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
+                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, (const int*)nullptr);
     else
-      hipLaunchKernelGGL(mlp_tn64_kernel<3>, grid, dim3(256), lds, engine().stream, A, lda, KT, Dm,
-                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, (const int*)nullptr, nkb);
+      hipLaunchKernelGGL(mlp_tn64_kernel<3>, dim3(Sn, (unsigned)cdiv(KT, 3)), dim3(256), lds, engine().stream, A, lda, KT, Dm,
+                         ldd, NT, M, rows_per_wg, slabs, (size_t)KT * 16 * NT * 16, wt, (const int*)nullptr);
     GOCTR_HIP(hipGetLastError());
     return 0;
   }
@@ -1197,7 +1186,6 @@ struct goctr_mlp {
   // the resident rows as the float64 operand image of the weight-gradient GEMM (mlp_widen_rows_kernel; GOCTR_MLP_X64, default on
   // while the image stays under 64 GiB) and the running batch's row indices into it (batch + 64 ints, zero padded)
   DevBuf<double> X64; DevBuf<int> ridx;
-  const int tn_xcd = env_int_mlp("GOCTR_MLP_TN_XCD", 1);   // read once per handle: the slab count (workspace sizes) follows it
   DevBuf<float> pf_sink;         // GOCTR_MLP_PREFETCH (default on): scratch of the reduce launch's prefetch blocks
   bool x64() const { return X64.p != nullptr && ridx.p != nullptr; }
   hipGraphExec_t step_graph = nullptr; int64_t step_graph_rows = 0; bool step_graph_perm = false;   // resident training step
@@ -1220,10 +1208,7 @@ int tn_rows64(const goctr_mlp* p, int n) {
     if (k > kb) kb = k;
   }
   int cus = engine().compute_units > 0 ? engine().compute_units : 256;
-  int S = cus / kb > 0 ? cus / kb : 1;
-  // a multiple of eight slabs: mlp_tn64_kernel deals whole slabs to XCDs (all k-blocks of a slab on one), and a ninth slab on an
-  // XCD would be a second round of workgroups there (cfg2: 40 slabs of 104 rows x 6 k-blocks = 240 workgroups, 30 per XCD)
-  if (S >= 16 && p->tn_xcd) S &= ~7;
+  const int S = cus / kb > 0 ? cus / kb : 1;
   int rows = (int)cdiv(n, S);
   rows = rows < 32 ? 32 : round_up(rows, 2);
   return rows;
@@ -1330,7 +1315,7 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance, int valid = -1) 
   for (int l = fused_bwd ? 0 : L - 1; l >= 0; --l) {
     const bool img = l == 0 && chain && p->x64();     // the chain launch left row indices, not a copy of the rows
     if (launch_tn64(img ? p->X64.p : p->A[l].p, p->up[l], p->up[l] / 16, p->D[l + 1].p, p->up[l + 1], p->up[l + 1] / 16, n,
-                    tn_rows64(p, n), p->slabs[l].p, img ? p->ridx.p : nullptr, p->tn_xcd)) return -1;
+                    tn_rows64(p, n), p->slabs[l].p, img ? p->ridx.p : nullptr)) return -1;
     if (l >= 1) {
       EpiMlpDAct d{p->D[l].p, p->A[l].p, p->up[l], p->units[l], p->cfg.activation,
                    p->cfg.batch_normalize ? p->bn[l - 1].p : nullptr};

@@ -223,33 +223,6 @@ def test_float64_row_image_and_prefetch_blocks_leave_the_same_bits(knob, B):
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
 
 
-def test_weight_gradient_workgroups_dealt_xcd_affine_agree():
-    """GOCTR_MLP_TN_XCD=0 (mlp_tn64_kernel's workgroups dealt (slab, k-block) = blockIdx, 42 slabs at B 4096) against the default (all
-    k-blocks of a slab on one XCD, a multiple of eight slabs): another slab height, i.e. another association of the same float64 sums"""
-    import os
-    from goctr_amd import capi, mlp as gmlp
-    rng = np.random.default_rng(17)
-    n, F, B = 8192, 281, 4096
-    X = rng.random((n, F), dtype=np.float32)
-    Y = (rng.random(n) < 0.5).astype(np.float32)
-    units = [F, 100, 1]
-    res = []
-    for val in (None, "0"):
-        if val is not None:
-            os.environ["GOCTR_MLP_TN_XCD"] = val
-        try:
-            clf = gmlp.MLPClassifier([100], "relu", "adam", 1e-5)
-            clf.create(units, B, clf.init_params(units, np.random.default_rng(3)))
-            clf.upload(X, Y)
-            clf.train_steps(9)
-            capi.sync()
-            res.append(clf.get_params())
-        finally:
-            os.environ.pop("GOCTR_MLP_TN_XCD", None)
-    assert np.allclose(res[0], res[1], rtol=1e-9, atol=1e-12)
-    assert not np.array_equal(res[0], np.zeros_like(res[0]))
-
-
 def test_reference_nn_forward_kat():
     """the reference-held 3-3-3 forward vector (nn/network_test.go:25-83, tests/golden/ref_kats.json) through the device
     MLP: units [3,3,3], relu hidden, logistic output = the KAT's ReLU and Sigmoid layers; float32 out (mlp.go:33-38)"""
