@@ -324,7 +324,9 @@ int goctr_mlp_fit(goctr_mlp* p, const float* X, const float* Y, int64_t rows, co
 /* the same over the rows goctr_mlp_upload left in HBM (goctr_mlp_fit = goctr_mlp_upload + this): a host that keeps its
  * TrainSample resident across several Fit calls, and the part bench.py times for BASELINE configs[0] */
 int goctr_mlp_fit_resident(goctr_mlp* p, const int32_t* perm, double* loss_curve, int* iters_run);
-/* exactly n_steps updates cycling over resident rows (async) -- bench unit */
+/* exactly n_steps updates cycling over resident rows (async) -- bench unit.
+ * goctr_mlp_upload keeps the rows in HBM twice: float32 as given (rows x F x 4 B) and, for the [F, H, 1] shape, widened once to the
+ * float64 operand image of the weight-gradient GEMM (rows x round_up(F + 1, 16) x 8 B; skipped above 64 GiB or with GOCTR_MLP_X64=0) */
 int goctr_mlp_upload(goctr_mlp* p, const float* X, const float* Y, int64_t rows);
 int goctr_mlp_train_steps(goctr_mlp* p, int64_t first_batch, int n_steps);
 /* SimpleMlpPredWrap.Predict (mlp.go:15-39): f32 in, probabilities f32 out */
