@@ -213,6 +213,7 @@ struct MlpReduceArgs {
   // but the next launches' first latencies depends on it)
   const float* pf_X; const float* pf_Y; const int* pf_perm; long long pf_rows; int pf_F, pf_batch; float* pf_sink;
   const double* pf_X64; int pf_up0; int pf_xcd_shift;
+  unsigned long long* dbg;    // GOCTR_DBG=mlp: cycle stamps [block 0 | loss block | first prefetch block][6]
 };
 constexpr int MLP_PF_BLOCKS = 64;
 
@@ -221,6 +222,7 @@ constexpr int MLP_PF_BLOCKS = 64;
 __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   __shared__ double red[256];
+  const unsigned long long ts0 = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
   if ((int)blockIdx.x > a.nblk) {
     // the rows the next step's chain launch starts with: its prologue is three dependent memory latencies (state -> permutation ->
     // row, 6.5 k cycles at cfg2); this launch leaves 100+ CUs idle, so eight blocks per XCD walk the same chain one step ahead and
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
       }
       if (acc == 1.2345678e-30f) a.pf_sink[t] = acc;    // (keeps the loads; a scratch word nobody reads)
     }
+    if (a.dbg && (int)blockIdx.x == a.nblk + 1 && threadIdx.x == 0) { a.dbg[12] = ts0; a.dbg[13] = __builtin_amdgcn_s_memtime(); }
     return;
   }
   const int par = (int)(a.st->t & 1);
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
         ns.batch_idx = nb >= ns.n_batches ? 0 : nb;
         *a.st_master = ns;
       }
+      if (a.dbg) { a.dbg[6] = ts0; a.dbg[7] = __builtin_amdgcn_s_memtime(); }
     }
     return;
   }
@@ -300,6 +304,8 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
   const double v_pre = pre && a.do_update && a.solver == GOCTR_SOLVER_ADAM ? a.Vo[idx] : 0.0;
   const double vel_pre = pre && a.do_update && a.solver != GOCTR_SOLVER_ADAM ? a.Vel[idx] : 0.0;
   double coop_sum = 0; bool coop_have = false;
+  unsigned long long ts1 = 0, ts2 = 0, ts3 = 0;
+  if (a.dbg) { ts1 = __builtin_amdgcn_s_memtime() + (par & 0); }
   if (a.mode == 0 || a.mode == 3) {
     __shared__ double red2[256];
     double part = 0; bool lead = false; int upo = 1;
@@ -374,6 +380,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
       }
       const double w = w_pre;
       double g;
+      if (a.dbg) ts2 = __builtin_amdgcn_s_memtime() + (s == 1.234e-300 ? 1 : 0);
       if (a.mode == 1) {
         g = a.G[idx];                                         // summed over the ranks by the all-reduce
       } else {
@@ -408,9 +415,13 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
       a.G[idx] = 0;
     }
   }
+  if (a.dbg) ts3 = __builtin_amdgcn_s_memtime();
   red[threadIdx.x] = sq;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) {
+    a.dbg[0] = ts0; a.dbg[1] = ts1; a.dbg[2] = ts2; a.dbg[3] = ts3; a.dbg[4] = __builtin_amdgcn_s_memtime();
+  }
   // mode 2 refreshes this step's parity; an update writes the parity the NEXT step will read; a pure gradient
   // evaluation leaves the weights -- and therefore both buffers -- alone
   if (threadIdx.x == 0) {
@@ -1358,6 +1369,10 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance, int valid = -1) 
     return 0;
   }
   a.mode = 0;
+  static DevBuf<unsigned long long> rdbg;
+  const bool dbg = dbg_on("mlp");
+  if (dbg && !rdbg.p && rdbg.alloc(18)) return -1;
+  a.dbg = dbg ? rdbg.p : nullptr;
   int pf_blocks = 0;
   if (chain && advance && p->rows > 0 && p->pf_sink.p) {
     a.pf_X = p->Xr.p; a.pf_Y = p->Yr.p; a.pf_perm = p->perm.n > 1 ? p->perm.p : nullptr; a.pf_rows = p->rows;
@@ -1371,6 +1386,13 @@ int backward(goctr_mlp* p, int n, bool do_update, bool advance, int valid = -1) 
   }
   hipLaunchKernelGGL(mlp_reduce_update_kernel, dim3(nblk + 1 + pf_blocks), dim3(256), 0, e.stream, a);   // block nblk: loss + state
   GOCTR_HIP(hipGetLastError());
+  if (dbg) {
+    unsigned long long h[18];
+    if (rdbg.download(h, 18)) return -1;
+    // (the shader clock differs between XCDs: durations within a block only)
+    fprintf(stderr, "mlp_reduce block 0: state %llu, slab sums %llu, update %llu, block sum %llu cycles; loss block %llu cycles, "
+            "first prefetch block %llu cycles\n", h[1] - h[0], h[2] - h[1], h[3] - h[2], h[4] - h[3], h[7] - h[6], h[13] - h[12]);
+  }
   return 0;
 }
 
