@@ -250,10 +250,26 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     if (a.dbg && (int)blockIdx.x == a.nblk + 1 && threadIdx.x == 0) { a.dbg[12] = ts0; a.dbg[13] = __builtin_amdgcn_s_memtime(); }
     return;
   }
-  const int par = (int)(a.st->t & 1);
+  // The step state is read through a per-lane copy of its address: the compiler turns a load from a uniform address into load +
+  // wait + readfirstlane WHERE IT STANDS -- a whole memory latency (3.4 k cycles at a launch's start, GOCTR_DBG=mlp) in front of
+  // every other request of the block.  As a vector load it is waited for where its value is used: at the block's end.
+  unsigned long long st_va = reinterpret_cast<unsigned long long>(a.st);
+  asm volatile("" : "+v"(st_va));
+  const MlpState* stv = reinterpret_cast<const MlpState*>(st_va);
+  const long long st_t = stv->t;
   if ((int)blockIdx.x == a.nblk) {
     // loss = sum(terms)/n + 0.5*alpha*sum(W^2)/n (basemlp64.go:359-361) over the weights the forward pass used: their
     // squares were summed per block by the launch that wrote them (parity `par`); closes the step
+    // every request of the block (state, both parities of the per-block sums of squares, the all-reduced term sum, the loss terms) is
+    // issued before the first wait, and the two sums share one tree: the block was five dependent round trips and sixteen barriers
+    // (19.6 k cycles -- as long as a parameter block: the launch's critical path), same additions in the same order
+    __shared__ double redq[256];
+    const unsigned int st_slot = stv->slot;
+    const long long st_bi = stv->batch_idx, st_nb = stv->n_batches;
+    double q0 = 0, q1 = 0;
+    if (a.mode != 3)
+      for (int i = threadIdx.x; i < a.nblk; i += 256) { q0 += a.sumsq_part[i]; q1 += a.sumsq_part[(size_t)a.nblk + i]; }
+    const double g_l = a.mode == 1 ? a.G[a.nflat] : 0.0;
     double s = 0;
     const int real = a.mode == 1 ? 0 : a.n_local * a.no;      // only the `no` real columns of each padded row carry a term
     for (int i0 = threadIdx.x; i0 < real; i0 += 256 * 16) {
@@ -266,29 +282,29 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
 #pragma unroll
       for (int u = 0; u < 16; ++u) s += v[u];
     }
+    const int par = (int)(st_t & 1);
     red[threadIdx.x] = s;
+    redq[threadIdx.x] = par ? q1 : q0;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; redq[threadIdx.x] += redq[threadIdx.x + o]; }
+      __syncthreads();
+    }
     double lsum = red[0];
-    __syncthreads();
     if (a.mode == 3) {                         // data-parallel first half: the local term sum travels with the gradient
       if (threadIdx.x == 0) a.G[a.nflat] = lsum;
       return;
     }
-    if (a.mode == 1) lsum = a.G[a.nflat];
-    s = 0;
-    for (int i = threadIdx.x; i < a.nblk; i += 256) s += a.sumsq_part[(size_t)par * a.nblk + i];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (a.mode == 1) lsum = g_l;
     if (threadIdx.x == 0) {
-      a.ring[a.st->slot % MLP_LOSS_RING] = lsum / (double)(a.n_loss ? a.n_loss : a.n) + (0.5 * a.alpha) * red[0] / (double)a.n;
+      a.ring[st_slot % MLP_LOSS_RING] = lsum / (double)(a.n_loss ? a.n_loss : a.n) + (0.5 * a.alpha) * redq[0] / (double)a.n;
       if (a.advance) {
-        MlpState ns = *a.st;
-        ns.slot += 1;
-        ns.t += 1;
-        const long long nb = ns.batch_idx + 1;
-        ns.batch_idx = nb >= ns.n_batches ? 0 : nb;
+        MlpState ns;
+        ns.slot = st_slot + 1;
+        ns.t = st_t + 1;
+        ns.n_batches = st_nb;
+        const long long nb = st_bi + 1;
+        ns.batch_idx = nb >= st_nb ? 0 : nb;
         *a.st_master = ns;
       }
       if (a.dbg) { a.dbg[6] = ts0; a.dbg[7] = __builtin_amdgcn_s_memtime(); }
@@ -296,6 +312,12 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     return;
   }
   double sq = 0;
+  // all 256 parameters of a block belong to ONE layer (every layer's offset is a multiple of 256: padded sizes are multiples of 16,
+  // goctr_mlp_create checks it), so the layer descriptor is the block's, not the lane's: slab base, stride and count stay scalar and a
+  // slab load is base + lane offset.  Taken per lane they made every load's address a 64-bit vector computation (four registers per
+  // load in flight), and the compiler issued the 42 slab loads of cfg2 four at a time with a full wait between the groups: three
+  // dependent round trips (10.5 k cycles) where one was meant.
+  const long long idx0 = (long long)blockIdx.x * 256;
   // (round 6: the parameter and its moments are requested HERE, in front of the slab sums -- behind them they were two more dependent
   // round trips of a launch that is nothing but round trips: state -> slabs -> W -> moments -> stores)
   const bool pre = idx < a.nflat && a.mode != 2;
@@ -305,14 +327,14 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
   const double vel_pre = pre && a.do_update && a.solver != GOCTR_SOLVER_ADAM ? a.Vel[idx] : 0.0;
   double coop_sum = 0; bool coop_have = false;
   unsigned long long ts1 = 0, ts2 = 0, ts3 = 0;
-  if (a.dbg) { ts1 = __builtin_amdgcn_s_memtime() + (par & 0); }
+  if (a.dbg) { ts1 = __builtin_amdgcn_s_memtime(); }
   if (a.mode == 0 || a.mode == 3) {
     __shared__ double red2[256];
     double part = 0; bool lead = false; int upo = 1;
     if (idx < a.nflat) {
       int l = 0;
 #pragma unroll
-      for (int k = 1; k < 7; ++k) if (k < a.nl && idx >= a.L[k].woff) l = k;
+      for (int k = 1; k < 7; ++k) if (k < a.nl && idx0 >= a.L[k].woff) l = k;
       const MlpLayerDesc& d = a.L[l];
       if (d.coop) {
         const long long e = idx - d.woff;
@@ -346,7 +368,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
     if (idx < a.nflat) {
       int l = 0;
 #pragma unroll
-      for (int k = 1; k < 7; ++k) if (k < a.nl && idx >= a.L[k].woff) l = k;
+      for (int k = 1; k < 7; ++k) if (k < a.nl && idx0 >= a.L[k].woff) l = k;
       const MlpLayerDesc& d = a.L[l];
       const long long e = idx - d.woff;
       const int r = (int)(e / d.upo), c = (int)(e - (long long)r * d.upo);
@@ -356,7 +378,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
   if (idx < a.nflat) {
     int l = 0;
 #pragma unroll
-    for (int k = 1; k < 7; ++k) if (k < a.nl && idx >= a.L[k].woff) l = k;
+    for (int k = 1; k < 7; ++k) if (k < a.nl && idx0 >= a.L[k].woff) l = k;
     const MlpLayerDesc& d = a.L[l];
     const long long e = idx - d.woff;
     const int r = (int)(e / d.upo), c = (int)(e - (long long)r * d.upo);
@@ -367,12 +389,14 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
       else
       if (a.mode != 1) {   // same left-to-right order as a plain loop, but 8 loads in flight at a time
         const size_t sstr = (size_t)d.upi * d.upo;
+        const int ei = (int)e;
         for (int j0 = 0; j0 < d.nslabs; j0 += 48) {           // unconditional loads (clamped), all in flight at once
           double v[48];
 #pragma unroll
           for (int u = 0; u < 48; ++u) {
             const int j = j0 + u;
-            v[u] = d.slabs[(size_t)(j < d.nslabs ? j : d.nslabs - 1) * sstr + e];
+            const double* sp = d.slabs + (size_t)(j < d.nslabs ? j : d.nslabs - 1) * sstr;     // scalar
+            v[u] = sp[ei];
           }
 #pragma unroll
           for (int u = 0; u < 48; ++u) s += (j0 + u < d.nslabs) ? v[u] : 0.0;
@@ -396,7 +420,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
           const double v = a.beta2 * v_pre + (1 - a.beta2) * g * g;
           a.Mo[idx] = m; a.Vo[idx] = v;
           // quirk Q7: beta powers advance once per parameter: exponent (t-1)*n + i + 1
-          const double ex = (double)((a.st->t) * a.nparams + pidx + 1);
+          const double ex = (double)(st_t * a.nparams + pidx + 1);
           // beta^ex < 2^-54 makes (1 - beta^ex) round to exactly 1: the two pow calls (most of this thread's instructions)
           // are only made where they can change a bit -- after t * n passes a few tens of thousands, nowhere
           const double b1t = ex > a.pow_skip1 ? 0.0 : pow(a.beta1, ex), b2t = ex > a.pow_skip2 ? 0.0 : pow(a.beta2, ex);
@@ -424,6 +448,7 @@ __global__ __launch_bounds__(256) void mlp_reduce_update_kernel(MlpReduceArgs a)
   }
   // mode 2 refreshes this step's parity; an update writes the parity the NEXT step will read; a pure gradient
   // evaluation leaves the weights -- and therefore both buffers -- alone
+  const int par = (int)(st_t & 1);
   if (threadIdx.x == 0) {
     if (a.mode == 2) a.sumsq_part[(size_t)par * a.nblk + blockIdx.x] = red[0];
     else if (a.do_update) a.sumsq_part[(size_t)(par ^ 1) * a.nblk + blockIdx.x] = red[0];
