@@ -113,12 +113,14 @@ __device__ __forceinline__ void cx_split8(const float* v, cx_bf8 (&out)[3]) {
 //   * `u < keep` with u = (h >> 8) * 2^-24 is the integer comparison (h >> 8) < ceil(keep * 2^24) (both sides exact).
 struct CxDrop {
   uint32_t hrow, thr, bits, cbase; float kv; bool on;
-  __device__ __forceinline__ void init(const DropCfg& d, const StepState* st, int row, int col_lane) {
+  // (gstep: the step counter as the kernel read it with its first state load -- read here, inside the tile loop, it was one more
+  // load + wait + readfirstlane in front of the h0 split)
+  __device__ __forceinline__ void init(const DropCfg& d, uint32_t gstep, int row, int col_lane) {
     on = d.mode == 2; bits = 0;
     const float keep = on ? 1.0f - d.p : 1.0f;
     kv = 1.0f / keep;
     uint32_t h = mix32(d.seed ^ 0x9E3779B9u);
-    h = mix32(h ^ (st->gstep * 2u + d.layer));
+    h = mix32(h ^ (gstep * 2u + d.layer));
     hrow = mix32(h ^ (d.row_off + (uint32_t)row));
     thr = on ? (uint32_t)ceilf(keep * 16777216.0f) : 0x1000000u;    // off: every 24-bit draw is below the threshold
     cbase = (uint32_t)col_lane * 0x85EBCA6Bu + 0xC2B2AE35u;
@@ -142,16 +144,25 @@ template <class Args>
 __device__ __forceinline__ void cx_ab_ids(const Args& a, int tile, int w, int lane, int (&abid)[4]) {
   const long long b0 = a.st->batch_idx * (long long)a.B;
   const int lc = lane < a.ab_T ? lane : a.ab_T - 1;
+  // unconditional loads from clamped addresses, selects afterwards: a predicated load is a branch, and branches up here
+  // split the scheduling region the first operand loads are issued from.  ALL FOUR loads first, then the tests, and the tests as
+  // bitwise ANDs: written as one short-circuit condition per sample, the compiler sank each load behind the tests in front of it
+  // (b < B && slot < T && row < rows) and waited for it on the spot to evaluate the last two -- four dependent memory round trips,
+  // each draining every operand load in flight, at the head of a launch whose first phase is a third of its duration.
+  int idv[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    // unconditional loads from clamped addresses, selects afterwards: a predicated load is a branch, and branches up here
-    // split the scheduling region the first operand loads are issued from
     const int b = tile * 32 + 4 * w + s;
     const int bc = b < a.B ? b : a.B - 1;
     const long long gr = b0 + bc < a.rows ? b0 + bc : a.rows - 1;
-    const int id = a.ab_ids[gr * a.ab_T + lc];
+    idv[s] = a.ab_ids[gr * a.ab_T + lc];
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int b = tile * 32 + 4 * w + s;
     // missing / out-of-range ids, slots past T and rows past the dataset's end read the all-zero row V (like attn_bwd_kernel)
-    abid[s] = (b < a.B && lane < a.ab_T && b0 + b < a.rows && id >= 0 && id < a.ab_V) ? id : (int)a.ab_V;
+    const int ok = (int)(b < a.B) & (int)(lane < a.ab_T) & (int)(b0 + b < a.rows) & (int)(idv[s] >= 0) & (int)(idv[s] < a.ab_V);
+    abid[s] = ok ? idv[s] : (int)a.ab_V;
   }
 }
 // (gates and similarity weights are only needed at the very end: requested late, 8 registers less through the products)
@@ -268,6 +279,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
 #pragma unroll
   for (int c = 0; c < CX_PF0; ++c) load0(c, c);
 
+  const uint32_t gstep0 = a.st->gstep;          // (with the cursor below: ONE state load, ahead of everything that depends on it)
   float y = 0.f;
   if (!FWD) {
     const long long gr = a.st->batch_idx * (long long)a.B + row;
@@ -302,8 +314,8 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
     for (int c = CX_FWD_NFP; c < CX_PF0; ++c) load0(c, c);
   }
   CxDrop dr0, dr1;
-  dr0.init(a.d0, a.st, row, 32 * tt + 4 * h);
-  dr1.init(a.d1, a.st, row, 0);
+  dr0.init(a.d0, gstep0, row, 32 * tt + 4 * h);
+  dr1.init(a.d1, gstep0, row, 0);
 
   // h0 -> bf16 planes, B-fragment image in LDS
 #pragma unroll

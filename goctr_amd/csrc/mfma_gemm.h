@@ -662,18 +662,29 @@ __device__ __forceinline__ void tn_multi_body_x3(const TnMulti& a, const TnProbl
   const int nA = (CH / 4) * kv, nAll = nA + (CH / 4) * nv;
   // block b = (column group cg, row group r) with r fastest: the 8 lanes of a column group write 64 contiguous bytes of a
   // strip (cg-fastest put 16 lanes on the same LDS banks), and a wavefront's loads still touch 16 cache lines
-  auto slot_of = [&](int b, const float*& src, int& ldv, int& rgv, int& lo) {
-    src = P.A; ldv = P.lda; rgv = 0; lo = -1;
+  // The problem's operand pointers and row strides as SCALARS, pinned: left to the compiler, "stride = block of A ? P.lda : P.ldd"
+  // became ONE vector load from the selected ADDRESS inside the kernel-argument buffer (and the same for the pointer) -- a memory
+  // round trip per lane in front of the first row request of every staging pass; the launch's "wait for chunk 0" (GOCTR_DBG=tn) was
+  // two dependent round trips, descriptor then rows.
+  // (pinned as integers and re-typed as GLOBAL pointers: a pointer that went through the asm statement is a generic one to the
+  // compiler, and its loads would be flat_load -- counted on the LDS counter too)
+  typedef const float __attribute__((address_space(1)))* tn_gptr;
+  unsigned long long pa_u = reinterpret_cast<unsigned long long>(P.A), pd_u = reinterpret_cast<unsigned long long>(P.D);
+  int plda = P.lda, pldd = P.ldd;
+  asm volatile("" : "+s"(pa_u), "+s"(pd_u), "+s"(plda), "+s"(pldd));
+  const tn_gptr PA = (tn_gptr)pa_u, PD = (tn_gptr)pd_u;
+  auto slot_of = [&](int b, tn_gptr& src, int& ldv, int& rgv, int& lo) {
+    src = PA; ldv = plda; rgv = 0; lo = -1;
     if (b < nA) {
       const int cg = b >> 3, r = b & 7;
-      rgv = r; ldv = P.lda;
-      src = P.A + kb0 * 16 + cg * 4;
+      rgv = r; ldv = plda;
+      src = PA + kb0 * 16 + cg * 4;
       lo = (cg * 4) * CHB + 4 * r;
     } else if (b < nAll) {
       const int bb = b - nA;
       const int cg = bb >> 3, r = bb & 7;
-      rgv = r; ldv = P.ldd;
-      src = P.D + n0t * 16 + cg * 4;
+      rgv = r; ldv = pldd;
+      src = PD + n0t * 16 + cg * 4;
       lo = (KTW * 16 + cg * 4) * CHB + 4 * r;
     }
   };
@@ -693,14 +704,14 @@ __device__ __forceinline__ void tn_multi_body_x3(const TnMulti& a, const TnProbl
   // chunk 0 -> buffer 0 by all 512 threads (the multipliers have nothing else to do yet)
   auto stage_first = [&]() {
     for (int b = tid; b < nAll; b += 512) {
-      const float* src; int ldv, rgv, lo;
+      tn_gptr src; int ldv, rgv, lo;
       slot_of(b, src, ldv, rgv, lo);
       vec_t v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int rr = m_begin + 4 * rgv + r;
         rr = rr < m_end ? rr : m_end - 1;
-        v[r] = *reinterpret_cast<const vec_t*>(src + (size_t)rr * ldv);
+        v[r] = *reinterpret_cast<const vec_t __attribute__((address_space(1)))*>(src + (size_t)rr * ldv);
       }
       store_block(base + lo, m_end - (m_begin + 4 * rgv), v);
     }
@@ -709,7 +720,7 @@ __device__ __forceinline__ void tn_multi_body_x3(const TnMulti& a, const TnProbl
   if (wave >= 4) {
     // ------------------------------------------------------------------------------------------------ stagers
     const int stid = tid - 256;
-    const float* gsrc[MAXB]; int ld[MAXB]; int rg[MAXB]; int lofs[MAXB];   // lofs: bf16 offset inside a plane; < 0 unused
+    tn_gptr gsrc[MAXB]; int ld[MAXB]; int rg[MAXB]; int lofs[MAXB];   // lofs: bf16 offset inside a plane; < 0 unused
 #pragma unroll
     for (int s = 0; s < MAXB; ++s) slot_of(stid + s * 256, gsrc[s], ld[s], rg[s], lofs[s]);
     // loads are unconditional (rows past the slab's end re-read its last row and are zeroed at the LDS write)
@@ -721,7 +732,7 @@ __device__ __forceinline__ void tn_multi_body_x3(const TnMulti& a, const TnProbl
           for (int r = 0; r < 4; ++r) {
             int rr = m0 + 4 * rg[s] + r;
             rr = rr < m_end ? rr : m_end - 1;
-            st[s][r] = *reinterpret_cast<const vec_t*>(gsrc[s] + (size_t)rr * ld[s]);
+            st[s][r] = *reinterpret_cast<const vec_t __attribute__((address_space(1)))*>(gsrc[s] + (size_t)rr * ld[s]);
           }
         }
       }
