@@ -169,22 +169,36 @@ __device__ __forceinline__ void cx_ab_ids(const Args& a, int tile, int w, int la
 template <class Args>
 __device__ __forceinline__ void cx_ab_gw(const Args& a, int tile, int w, int lane, float (&abf)[4]) {
   const int lc = lane < a.ab_T ? lane : a.ab_T - 1;
+  // (all loads first, the tests as bitwise ANDs behind them -- see cx_ab_ids: "b < B && slot < T ? f : 0" per sample had become a
+  // branch on the sample's (uniform) row test around load + full wait: four dependent round trips at the launch's tail, to lines the
+  // previous launch wrote)
   if (a.ab_fac) {           // (uniform) the factor as the attention forward left it: one load per sample instead of two
+    float fv[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int b = tile * 32 + 4 * w + s;
       const int bc = b < a.B ? b : a.B - 1;
-      const float f = a.ab_fac[(size_t)bc * a.ab_T + lc];
-      abf[s] = (b < a.B && lane < a.ab_T) ? f : 0.f;
+      fv[s] = a.ab_fac[(size_t)bc * a.ab_T + lc];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int b = tile * 32 + 4 * w + s;
+      abf[s] = ((int)(b < a.B) & (int)(lane < a.ab_T)) ? fv[s] : 0.f;
     }
     return;
   }
+  float gv[4], wv[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int b = tile * 32 + 4 * w + s;
     const int bc = b < a.B ? b : a.B - 1;
-    const float g = a.ab_gate[(size_t)bc * a.ab_T + lc], wv = a.ab_wgt[(size_t)bc * a.ab_T + lc];
-    abf[s] = (b < a.B && lane < a.ab_T) ? (g * (1.0f - g)) * wv : 0.f;      // (the same statement as AttnArgs::fac: the same bits)
+    gv[s] = a.ab_gate[(size_t)bc * a.ab_T + lc]; wv[s] = a.ab_wgt[(size_t)bc * a.ab_T + lc];
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int b = tile * 32 + 4 * w + s;
+    const float f = (gv[s] * (1.0f - gv[s])) * wv[s];       // (the same statement as AttnArgs::fac: the same bits)
+    abf[s] = ((int)(b < a.B) & (int)(lane < a.ab_T)) ? f : 0.f;
   }
 }
 // Samples whose rows are requested inside F0's chunk loop, one or two gathers per chunk (the others: behind B0).  A gather
@@ -192,7 +206,10 @@ __device__ __forceinline__ void cx_ab_gw(const Args& a, int tile, int w, int lan
 // tile needs stall their issuers when they come as one burst; under F0's MFMAs they are free, but each early sample holds
 // 16 registers through the products.  Measured per step (cfg3, same box, three runs each): none early 50.5 us, 2 early 50.4,
 // 3 early 49.8 (255 registers, none spilled); 4 early spills 40 registers and is 1 us slower than none.
-constexpr int CX_AB_EARLY = 3;
+// (Closing sessions of round 6: with the four id loads issued together (cx_ab_ids) three early samples no longer fit -- 256 registers
+// and 8 spilled, the spill of a gathered row sitting behind a full s_waitcnt vmcnt(0) that drains the W0 ring in the middle of F0; two
+// early samples are 244 registers, none spilled, and 41.6 against 42.0 us per step: profiles/r06_dependent_loads.txt.)
+constexpr int CX_AB_EARLY = 2;
 template <class Args>
 __device__ __forceinline__ void cx_ab_gather_one(const Args& a, const int (&abid)[4], int lane, int s, int p, float (&abx)[4][4][4]) {
   const int rl = lane >> 2, dl = lane & 3;

@@ -777,12 +777,21 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(MlpChainArgs a) {
   }
   if constexpr (X64) { if (g == 0 && q == 0 && vrow) a.ridx[row] = (int)src; }
   // the tail chunk of the row: k < F from the row, k == F the ones column, zeros behind (unconditional loads, clamped)
+  // (all four loads, THEN the values pinned, then the selects: written as "load; k < F ? value : constant" per element, the compiler sank
+  // each load into the k < F arm and waited for it there -- four dependent round trips to the row's last line in the prologue)
   double xt[4];
+  float tv[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int k = nfull * 16 + 4 * q + e;
-    const float v = xrow[k < F ? k : F - 1];
-    xt[e] = k < F ? (double)v : (k == F ? 1.0 : 0.0);
+    tv[e] = xrow[k < F ? k : F - 1];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(tv[e]));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = nfull * 16 + 4 * q + e;
+    xt[e] = k < F ? (double)tv[e] : (k == F ? 1.0 : 0.0);
   }
   const double yv = (double)a.Y[src];
   d4 acc[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}}, acd[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
