@@ -582,18 +582,6 @@ __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev
   const unsigned char* keep = a.keep ? a.keep + lo : nullptr;
   const long long cmin = clip_lo[gs] - lo, cmax = clip_hi[gs] - lo;
   const int gbase = (int)(threadIdx.x & 63) & ~(GS - 1);
-  auto ld_word = [&](int id, double (&v)[CPL]) {
-    const int slot = hot.n_words ? hot.word_slot[id] : -1;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k)
-      v[k] = !actk[k] ? 0.0 : (slot >= 0 ? locW[slot * RS + l + k * GS] : hog_load(a.param + (long long)id * dim + l + k * GS));
-  };
-  auto add_word = [&](int id, const double (&v)[CPL]) {
-    const int slot = hot.n_words ? hot.word_slot[id] : -1;
-#pragma unroll
-    for (int k = 0; k < CPL; ++k)
-      if (actk[k] && v[k] != 0.0) { if (slot >= 0) locW[slot * RS + l + k * GS] += v[k]; else hog_add(a.param + (long long)id * dim + l + k * GS, v[k]); }
-  };
   auto ld_node = [&](int nd, bool on, double (&v)[CPL]) {
 #pragma unroll
     for (int k = 0; k < CPL; ++k)
@@ -618,29 +606,68 @@ __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev
         const int wend = win * 2 + 1 - del;
         int w = del;
         while (w < wend) {
+          // A chunk = the next (at most JB) context words in window order, up to the first repeated id (which opens the next chunk).
+          // Opened in ROUNDS -- window offsets (bounds only), then all ids, then all slots, then all vectors: written pair by pair
+          // (find, test, load the vector, next pair) every pair's three dependent loads were waited for before the next pair's
+          // first was issued (vmcnt counts in order: the scan's doc[c] drains the vector loads in front of it) -- twelve serial
+          // round trips per chunk where three do (profiles/r06_w2v_rounds.txt).
           int cid[JB]; double ctx[JB][CPL], tmp[JB][CPL];
+          int cw[JB]; int ncand = 0;
+          {
+            int ws = w;
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+              cw[j] = wend;
+              if (ncand == j) {
+                for (; ws < wend; ++ws) {
+                  if (ws == win) continue;
+                  const long long c = pos - win + ws;
+                  if (c < cmin || c >= cmax) continue;
+                  break;
+                }
+                if (ws < wend) { cw[j] = ws; ++ws; ncand = j + 1; }
+              }
+            }
+          }
+          int fid[JB];
+#pragma unroll
+          for (int j = 0; j < JB; ++j) fid[j] = doc[pos - win + (j < ncand ? cw[j] : win)];     // (past the candidates: the centre word, unused)
           int nj = 0;
 #pragma unroll
           for (int j = 0; j < JB; ++j) {
             cid[j] = -1;
 #pragma unroll
             for (int k = 0; k < CPL; ++k) { ctx[j][k] = 0.0; tmp[j][k] = 0.0; }
-            if (nj == j) {                                       // (the chunk is still open)
-              int found = -1;
-              for (; w < wend; ++w) {
-                if (w == win) continue;
-                const long long c = pos - win + w;
-                if (c < cmin || c >= cmax) continue;
-                found = doc[c];
-                break;
-              }
+            if (nj == j && j < ncand) {                          // (the chunk is still open)
               bool dup = false;
 #pragma unroll
-              for (int k = 0; k < j; ++k) dup = dup || cid[k] == found;
-              if (found >= 0 && !dup) { cid[j] = found; ++w; nj = j + 1; ld_word(found, ctx[j]); }
+              for (int k = 0; k < j; ++k) dup = dup || cid[k] == fid[j];
+              if (!dup) { cid[j] = fid[j]; nj = j + 1; }
             }
           }
+          w = nj < ncand ? cw[nj] : (ncand == JB ? cw[JB - 1] + 1 : wend);     // (a repeated id stays where it is for the next chunk)
           if (nj == 0) break;                                     // (no context left)
+          {
+            int slot[JB];
+#pragma unroll
+            for (int j = 0; j < JB; ++j) slot[j] = hot.n_words ? hot.word_slot[j < nj ? cid[j] : id] : -1;
+            // (the slots pinned in their registers HERE, once: behind the divergent "cached or not" branches below the compiler no longer
+            // knows how many loads are in flight in front of a slot's and waits for everything, i.e. for the previous vector, at every test)
+#pragma unroll
+            for (int j = 0; j < JB; ++j) asm volatile("" : "+v"(slot[j]));
+            // (cached vectors first, then the uncached ones: as "cached ? LDS : memory" per element both arms wrote one register, and
+            // the lanes of the LDS arm waited for the other lanes' load from memory before every read)
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+#pragma unroll
+              for (int k = 0; k < CPL; ++k)
+                if (j < nj && actk[k] && slot[j] >= 0) ctx[j][k] = locW[slot[j] * RS + l + k * GS];
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+#pragma unroll
+              for (int k = 0; k < CPL; ++k)
+                if (j < nj && actk[k] && slot[j] < 0) ctx[j][k] = hog_load(a.param + (long long)cid[j] * dim + l + k * GS);
+          }
           unsigned alive = (1u << nj) - 1u;
           for (int c0 = hp0; c0 < hp1 && alive; c0 += GS) {
             const int n = hp1 - c0 < GS ? hp1 - c0 : GS;
@@ -685,9 +712,23 @@ __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev
               add_node(nd, acc);
             }
           }
+          {                                                        // ctx += tmp (model.go:74-76); the slots again in one round
+            int slot[JB];
 #pragma unroll
-          for (int j = 0; j < JB; ++j)
-            if (j < nj) add_word(cid[j], tmp[j]);                  // ctx += tmp (model.go:74-76)
+            for (int j = 0; j < JB; ++j) slot[j] = hot.n_words ? hot.word_slot[j < nj ? cid[j] : id] : -1;
+#pragma unroll
+            for (int j = 0; j < JB; ++j) asm volatile("" : "+v"(slot[j]));
+#pragma unroll
+            for (int j = 0; j < JB; ++j)
+              if (j < nj) {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k)
+                  if (actk[k] && tmp[j][k] != 0.0) {
+                    if (slot[j] >= 0) locW[slot[j] * RS + l + k * GS] += tmp[j][k];
+                    else hog_add(a.param + (long long)cid[j] * dim + l + k * GS, tmp[j][k]);
+                  }
+              }
+          }
         }
       }
       est += streams * a.est_scale;                                              // (observer estimate: see w2v_hogwild_kernel)
