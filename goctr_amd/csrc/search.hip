@@ -743,6 +743,9 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
           dot += knn_cq[d + 1] * x[1];
         }
       }
+      // (the product pinned before the norm is looked at: the compiler had sunk the row's loads and the 16 multiply-adds behind the
+      // "n2 == 0" return -- norm, wait, row, wait: two dependent round trips to cold lines per survivor where the comment above says one)
+      asm volatile("" : "+v"(dot));
       if (qn == 0 || n2 == 0) return;
       const double sim = dot / qn / n2;                 // searchutil.go:24-25
       if (!(sim > 0 && sim >= bd)) return;
