@@ -141,15 +141,14 @@ struct CxDrop {
 // 4 dl .. 4 dl + 3).  cx_ab_ids / cx_ab_gw: the slot ids / gates and similarity weights of its four samples, slot = lane;
 // cx_ab_gather_one: one pass (16 behaviour rows) of one sample, 16 bytes per lane in flight under the products that follow.
 template <class Args>
-__device__ __forceinline__ void cx_ab_ids(const Args& a, int tile, int w, int lane, int (&abid)[4]) {
+__device__ __forceinline__ void cx_ab_ids_load(const Args& a, int tile, int w, int lane, int (&idv)[4]) {
   const long long b0 = a.st->batch_idx * (long long)a.B;
   const int lc = lane < a.ab_T ? lane : a.ab_T - 1;
   // unconditional loads from clamped addresses, selects afterwards: a predicated load is a branch, and branches up here
-  // split the scheduling region the first operand loads are issued from.  ALL FOUR loads first, then the tests, and the tests as
-  // bitwise ANDs: written as one short-circuit condition per sample, the compiler sank each load behind the tests in front of it
-  // (b < B && slot < T && row < rows) and waited for it on the spot to evaluate the last two -- four dependent memory round trips,
-  // each draining every operand load in flight, at the head of a launch whose first phase is a third of its duration.
-  int idv[4];
+  // split the scheduling region the first operand loads are issued from.  ALL FOUR loads first, then the tests (cx_ab_ids_check), and
+  // the tests as bitwise ANDs: written as one short-circuit condition per sample, the compiler sank each load behind the tests in
+  // front of it (b < B && slot < T && row < rows) and waited for it on the spot to evaluate the last two -- four dependent memory
+  // round trips, each draining every operand load in flight, at the head of a launch whose first phase is a third of its duration.
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int b = tile * 32 + 4 * w + s;
@@ -157,6 +156,11 @@ __device__ __forceinline__ void cx_ab_ids(const Args& a, int tile, int w, int la
     const long long gr = b0 + bc < a.rows ? b0 + bc : a.rows - 1;
     idv[s] = a.ab_ids[gr * a.ab_T + lc];
   }
+}
+// (called behind the h0 split's barrier: the ids have the whole split to arrive in -- tested in the prologue, they were one more
+// round trip in front of it)
+template <class Args>
+__device__ __forceinline__ void cx_ab_ids_check(const Args& a, int tile, int w, int lane, long long b0, const int (&idv)[4], int (&abid)[4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int b = tile * 32 + 4 * w + s;
@@ -305,7 +309,9 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   const bool ab = !FWD && din && a.ab_ids != nullptr;
   int abid[4] = {-1, -1, -1, -1}; float abf[4] = {0.f, 0.f, 0.f, 0.f};
   float abx[4][4][4];
-  if (ab) cx_ab_ids(a, tile, w, lane, abid);
+  int abidv[4] = {0, 0, 0, 0};
+  const long long ab_b0 = ab ? a.st->batch_idx * (long long)a.B : 0;
+  if (ab) cx_ab_ids_load(a, tile, w, lane, abidv);
   // layer-1 columns this wavefront finishes after the exchange: group (u = w / 4, g = w % 4) and, for wavefronts 0..3,
   // (u = 2, g = w):  f = 32 u + 8 g + 4 h + r
   const int fA = 32 * (w >> 2) + 8 * (w & 3) + 4 * h, fB = 64 + 8 * (w & 3) + 4 * h;
@@ -352,6 +358,7 @@ __global__ __launch_bounds__(512, 1) void ctr_chain_x3_kernel(ChainX3Args a) {
   }
   __syncthreads();                                            // (1) h0 image complete
   stamp(1);
+  if (ab) cx_ab_ids_check(a, tile, w, lane, ab_b0, abidv, abid);
 
   // ---------------------------------------------------------------- F0: Z0^T = W0^T . h0^T  (tile tt)
   cx_acc ah0, ac0;
