@@ -669,6 +669,15 @@ __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev
                 if (j < nj && actk[k] && slot[j] < 0) ctx[j][k] = hog_load(a.param + (long long)cid[j] * dim + l + k * GS);
           }
           unsigned alive = (1u << nj) - 1u;
+          // A visit's node update is issued at the head of the NEXT visit, behind that visit's wait for its node vector: vmcnt counts
+          // loads, stores and atomics in one queue and, behind the divergent cached / uncached branches, the compiler waits for all of
+          // them (vmcnt(0)) wherever it waits for a vector -- issued at the visit's end, an uncached node's device-scope atomic adds
+          // were acknowledged (~2 k cycles) in front of the next visit's first multiply; issued here they have that visit's arithmetic
+          // to be acknowledged in.  A path's nodes are distinct and the pending update is flushed before the chunk ends, so nothing
+          // reads a row between its update's old and new place (one-stream Hogwild = the sequential pass: tests/test_gpu_w2v.py).
+          int nd_pend = -1; double acc_pend[CPL];
+#pragma unroll
+          for (int k = 0; k < CPL; ++k) acc_pend[k] = 0.0;
           for (int c0 = hp0; c0 < hp1 && alive; c0 += GS) {
             const int n = hp1 - c0 < GS ? hp1 - c0 : GS;
             const int my_nd = c0 == hp0 ? h_nd0 : (l < n ? a.path_nodes[c0 + l] : 0);
@@ -682,6 +691,9 @@ __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev
               double pvl[CPL], acc[CPL];
 #pragma unroll
               for (int k = 0; k < CPL; ++k) { pvl[k] = pf[0][k]; acc[k] = 0.0; }
+#pragma unroll
+              for (int k = 0; k < CPL; ++k) asm volatile("" : "+v"(pvl[k]));       // (the vector is HERE: the wait stands in front of the update below)
+              if (nd_pend >= 0) add_node(nd_pend, acc_pend);
 #pragma unroll
               for (int q = 0; q + 1 < PF; ++q)
 #pragma unroll
@@ -709,9 +721,12 @@ __global__ __launch_bounds__(HOG_THREADS, WPS) void w2v_hogwild_nm_kernel(W2vDev
                   }
                 }
               }
-              add_node(nd, acc);
+              nd_pend = nd;
+#pragma unroll
+              for (int k = 0; k < CPL; ++k) acc_pend[k] = acc[k];
             }
           }
+          if (nd_pend >= 0) add_node(nd_pend, acc_pend);
           {                                                        // ctx += tmp (model.go:74-76); the slots again in one round
             int slot[JB];
 #pragma unroll
