@@ -596,20 +596,30 @@ __global__ __launch_bounds__(256) void knn_collect_kernel(const double* __restri
   auto stamp = [&](int i) { if (dbg && q == 0 && threadIdx.x == 0) ts[i] = __builtin_amdgcn_s_memtime(); };
   stamp(0);
   const float* tm = tmax + (size_t)q * nt;
-  for (int d = threadIdx.x; d < D; d += 256) { knn_cq[d] = queries[(size_t)q * D + d]; cq32[d] = q32[(size_t)q * D + d]; }
   if (threadIdx.x == 0) { n_blk = 0; n_cand = 0; }
+  // One round of requests at the launch's cold start: the ignore index and the query's elements (into registers), the tile maxima, and only
+  // then the query's copy into LDS and the maximum.  (In the order "copy the query; maxima" the LDS writes waited for the query before the
+  // maxima were even asked for: two dependent round trips where one does, ~1.9 k of the launch's ~29 k ticks.)
+  long long ig_v = ignore[q];
+  const int d0 = (int)threadIdx.x;
+  double q64v = 0.0; float q32v = 0.f;
+  if (d0 < D) { q64v = queries[(size_t)q * D + d0]; q32v = q32[(size_t)q * D + d0]; }
   // (round 6: the first KNN2_TMR x 256 tile maxima stay in registers for the tile list below -- nt <= 1024 at V = 10^6: no re-read)
   constexpr int KNN2_TMR = 4;
   float tmv[KNN2_TMR];
-  float m = 0.f;
 #pragma unroll
   for (int u = 0; u < KNN2_TMR; ++u) {
     const int t = u * 256 + (int)threadIdx.x;
     tmv[u] = t < nt ? tm[t] : 0.f;
-    m = fmaxf(m, tmv[u]);
   }
+  asm volatile("" : "+v"(ig_v));       // (pinned with this round: left alone, the load sinks to its use behind the maxima's wait)
+  const long long ig = ig_v;
+  if (d0 < D) { knn_cq[d0] = q64v; cq32[d0] = q32v; }
+  for (int d = 256 + threadIdx.x; d < D; d += 256) { knn_cq[d] = queries[(size_t)q * D + d]; cq32[d] = q32[(size_t)q * D + d]; }
+  float m = 0.f;
+#pragma unroll
+  for (int u = 0; u < KNN2_TMR; ++u) m = fmaxf(m, tmv[u]);
   for (int t = KNN2_TMR * 256 + threadIdx.x; t < nt; t += 256) m = fmaxf(m, tm[t]);
-  const long long ig = ignore[q];
   {
     // The bound: the `rounds`-th largest of the 256 group maxima, duplicates counted.  Round 5 ranked every maximum against all 256
     // (256 broadcast LDS reads and ~5 instructions each per thread: 12.6 k of the launch's 43 k cycles, GOCTR_DBG=knn).  Now every
